@@ -1,0 +1,285 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself.  Build-container only.
+
+    python -m oracle.make_golden            (from the repo root; needs /root/reference)
+
+Imports the reference's `network` package (read-only, from /root/reference/codes), loads the
+hash weights of oracle/hashweights.py into it, runs the cases of SURVEY.md section 8c and
+stores inputs' seeds + the reference's outputs.  It also checks the oracle restatement against
+the live reference and prints the deviation.  The fixtures are data only: tensors of inputs and
+expected outputs; no reference source travels.
+"""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/codes"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from oracle import hashweights as hw            # noqa: E402
+from oracle import nefnet_oracle as orc         # noqa: E402
+from electrocardio_panorama_amd import synth    # noqa: E402
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def ref_cfg(V, loss_factor=(0.5, 0.5, 1), reg="l1_loss", lr=0.1):
+    return Cfg(MODEL=Cfg(model="model_nefnet", theta_L=1, loss="v1"),
+               DATA=Cfg(lead_num=V, noise=False, super_mode="IIv2v5_v4I_372", dataset="tianchi"),
+               SOLVER=Cfg(optim="sgd", lr=lr, scheduler="MultiStep", lr_step=[50, 100], reg_loss=reg,
+                          loss_using=[1, 2, 3], loss_factor=list(loss_factor), epochs=1),
+               output_dir="/tmp/nef_golden", desc="debug")
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    import network                                          # noqa: F401
+    return network
+
+
+class MaskReplay(torch.nn.Module):
+    def __init__(self, mask, p):
+        super().__init__()
+        self.mask, self.p = mask, p
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        return x * self.mask.to(x.dtype) / (1.0 - self.p)
+
+
+def ref_model(network, V, masks=None, p=0.2):
+    torch.manual_seed(0)
+    m = network.build_model(ref_cfg(V)).float()
+    sd = m.state_dict()
+    P, Bf = hw.hashed_params(V), hw.hashed_buffers()
+    assert set(sd.keys()) == set(P) | set(Bf), sorted(set(sd.keys()) ^ (set(P) | set(Bf)))
+    for k, v in sd.items():
+        src = P[k] if k in P else Bf[k]
+        assert tuple(v.shape) == tuple(src.shape), (k, v.shape, src.shape)
+    m.load_state_dict({**P, **Bf})
+    sites = {"W_encoder.layer1.0": m.W_encoder.layer1[0], "W_encoder.layer1.1": m.W_encoder.layer1[1],
+             "W_encoder.layer1.2": m.W_encoder.layer1[2], "w_conv.0": m.w_conv[0], "z1_conv.0": m.z1_conv[0],
+             "z2_conv1.0": m.z2_conv1[0], "z2_conv2.0": m.z2_conv2[0], "z2_conv2.2": m.z2_conv2[2]}
+    for name, blk in sites.items():
+        blk.dropout = MaskReplay(masks[name] if masks is not None else None, p if masks is not None else 0.0)
+    return m
+
+
+def to_t(batch):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}
+
+
+def sub(t, n=2048):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].numpy().copy()
+
+
+def stats(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
+
+
+def rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def case_eval(network, B, V, L, Q, seed):
+    batch = to_t(synth.make_batch(B, V, L, seed=seed, Q=Q))
+    m = ref_model(network, V).eval()
+    random.seed(seed)
+    st = random.getstate()
+    taps = {}
+    hooks = []
+    with torch.no_grad():
+        outs = m(batch["data"], batch["input_theta"], batch["target_theta"], batch["rois"],
+                 rest_theta=batch["rest_theta"], phase="test")
+        random.setstate(st)
+        c1, c2 = random.randint(0, V - 1), random.randint(0, V - 1)
+        z1, z2 = m(batch["data"], batch["input_theta"], batch["target_theta"], batch["rois"], phase="gen")
+        gen = m.gen_ecg(z1, z2, batch["rest_theta"], batch["rois"])
+        P, Bf = hw.hashed_params(V), hw.hashed_buffers()
+        mine = orc.forward(P, Bf, batch["data"], batch["input_theta"], batch["target_theta"], batch["rois"],
+                           rest_theta=batch["rest_theta"], phase="test", training=False, lead_choice=(c1, c2),
+                           taps=taps)
+        mine_gen = orc.gen_ecg(P, Bf, z1, z2, batch["rest_theta"], batch["rois"])
+    dev = max(rel(a, b) for a, b in zip(mine, outs))
+    dev = max(dev, rel(mine_gen, gen), rel(taps["z1"], z1), rel(taps["z2_seg"], z2))
+    del hooks
+    name = f"eval_B{B}_V{V}_L{L}_Q{Q}"
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), B=B, V=V, L=L, Q=Q, seed=seed, lead_choice=[c1, c2],
+                        out=outs[0].numpy(), shuf_p=outs[1].numpy(), shuf_l=outs[2].numpy(), rest_out=outs[3].numpy(),
+                        gen_ecg=gen.numpy(), z1_sub=sub(z1), z1_stats=stats(z1), z2_sub=sub(z2), z2_stats=stats(z2))
+    print(f"{name}: oracle vs reference rel-L2 {dev:.2e}")
+    return dev
+
+
+def case_train(network, B, V, L, seed, reg="l1_loss", use_masks=True):
+    batch = to_t(synth.make_batch(B, V, L, seed=seed))
+    masks = hw.hashed_masks(V, B, L // 4) if use_masks else None
+    cfg = ref_cfg(V, reg=reg)
+    m = ref_model(network, V, masks=masks).train()
+    loss_fn = network.build_loss(cfg)
+    random.seed(seed)
+    st = random.getstate()
+    outs = m(batch["data"], batch["input_theta"], batch["target_theta"], batch["rois"], phase="train")
+    losses = loss_fn(outs[0], outs[1], outs[2], batch["target_view"].unsqueeze(1), cfg)
+    losses[0].backward()
+    random.setstate(st)
+    c1, c2 = random.randint(0, V - 1), random.randint(0, V - 1)
+    grads = {k: v.grad for k, v in m.named_parameters()}
+    assert all((grads[k] is None) == (k in orc.DEAD_PARAMS) for k in grads), "dead-parameter set changed"
+    # the oracle on the same inputs
+    P, Bf = orc.require_grad(hw.hashed_params(V)), hw.hashed_buffers()
+    mine = orc.forward(P, Bf, batch["data"], batch["input_theta"], batch["target_theta"], batch["rois"],
+                       phase="train", training=True, masks=masks, p=0.2 if use_masks else 0.0,
+                       lead_choice=(c1, c2))
+    mine_l = orc.loss_v1(mine[0], mine[1], mine[2], batch["target_view"].unsqueeze(1), cfg.SOLVER.loss_factor,
+                         cfg.SOLVER.loss_using, reg)
+    mine_l[0].backward()
+    dev = max(rel(a, b) for a, b in zip(mine, outs))
+    flat_ref = torch.cat([g.reshape(-1) for g in grads.values() if g is not None])
+    flat_mine = torch.cat([P[k].grad.reshape(-1) for k in grads if grads[k] is not None])
+    gdev = rel(flat_mine, flat_ref)
+    sd = m.state_dict()
+    bdev = max((Bf[k].double() - sd[k].double()).abs().max().item() for k in Bf)
+    save = dict(B=B, V=V, L=L, seed=seed, lead_choice=[c1, c2], reg=reg, masked=int(use_masks),
+                out=outs[0].detach().numpy(), shuf_p=outs[1].detach().numpy(), shuf_l=outs[2].detach().numpy(),
+                losses=np.array([float(v.detach()) for v in losses]), flat_grad_norm=flat_ref.double().norm().item())
+    for k, g in grads.items():
+        if g is not None:
+            save["gsub:" + k] = sub(g, 256)
+            save["gstat:" + k] = stats(g)
+    for k in Bf:
+        save["buf:" + k] = sd[k].numpy()
+    name = f"train_B{B}_V{V}_L{L}_{reg}" + ("" if use_masks else "_nodrop")
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+    print(f"{name}: oracle vs reference out {dev:.2e} grad {gdev:.2e} bn-buffers {bdev:.2e} "
+          f"losses {[float(v) for v in losses]}")
+    return max(dev, gdev)
+
+
+def case_sgd(network, B, V, L, seed, steps=3):
+    """Three iterations of the reference's own Solver.run_one_epoch(phase='train') (dropout p=0)."""
+    for mod in ("tensorboardX", "skimage", "skimage.metrics", "matplotlib", "matplotlib.pyplot"):
+        if mod not in sys.modules:
+            try:
+                __import__(mod)
+            except Exception:
+                sys.modules[mod] = types.ModuleType(mod)
+    sk = sys.modules["skimage.metrics"]
+    if not hasattr(sk, "structural_similarity"):
+        sk.structural_similarity = lambda *a, **k: 0.0
+        sk.peak_signal_noise_ratio = lambda *a, **k: 0.0
+    if not hasattr(np, "float"):
+        np.float, np.int = float, int
+    from solver.solver import Solver
+    from solver.optim_scheduler import get_optimizer
+    cfg = ref_cfg(V)
+    real_build = network.build_model
+    import solver.solver as ss
+    ss.build_model = lambda c: ref_model(network, V)
+    try:
+        sol = Solver(cfg, use_tensorboardx=False)
+    finally:
+        ss.build_model = real_build
+    ss.tqdm = lambda x: x
+    batches = []
+    for s in range(steps):
+        b = to_t(synth.make_batch(B, V, L, seed=seed + s, Q=2))
+        b["ori_data"] = b["data"]
+        b["unsupervision_lead_name"] = []
+        batches.append(b)
+    opt = get_optimizer(cfg, sol.model.parameters())
+    random.seed(seed)
+    st = random.getstate()
+    losses = sol.run_one_epoch(batches, "train", opt)[0]
+    random.setstate(st)
+    choices = [[random.randint(0, V - 1), random.randint(0, V - 1)] for _ in range(steps)]
+    sd = sol.model.state_dict()
+    # oracle trajectory
+    P, Bf = orc.require_grad(hw.hashed_params(V)), hw.hashed_buffers()
+    o = orc.SGDState(cfg.SOLVER.lr)
+    mine = [orc.train_step(P, Bf, o, batches[s], p=0.0, lead_choice=tuple(choices[s])) for s in range(steps)]
+    ldev = np.abs(np.array(mine) - np.array(losses)).max()
+    pdev = max(rel(P[k], sd[k]) for k in P if k not in orc.DEAD_PARAMS)
+    save = dict(B=B, V=V, L=L, seed=seed, steps=steps, lead_choice=np.array(choices), losses=np.array(losses), lr=cfg.SOLVER.lr)
+    for k in P:
+        save["psub:" + k] = sub(sd[k], 128)
+        save["pstat:" + k] = stats(sd[k])
+    for k in Bf:
+        save["buf:" + k] = sd[k].numpy()
+    name = f"sgd_B{B}_V{V}_L{L}"
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+    print(f"{name}: losses {np.array(losses)[:, 0]}  oracle loss dev {ldev:.2e} param dev {pdev:.2e}")
+    return pdev
+
+
+def case_roi(network):
+    from network.utils.roi_pooling_1d import roi_algin, roi_pooling_reverse
+    real = [[0, 59], [59, 71], [71, 117], [117, 157], [157, 237], [237, 272], [272, 512]]
+    cases = {
+        "real512": (512, [real, [[0, 61], [61, 75], [75, 118], [118, 160], [160, 231], [231, 281], [281, 512]]]),
+        "mod4_512": (512, [[[0, 1], [1, 2], [2, 7], [7, 9], [9, 250], [250, 251], [251, 512]],
+                           [[0, 3], [3, 3], [3, 130], [130, 133], [133, 134], [134, 509], [509, 512]]]),
+        "len5000": (5000, [[[0, 575], [575, 697], [697, 1143], [1143, 1533], [1533, 2317], [2317, 2655], [2655, 5000]],
+                           [[0, 4], [4, 4], [4, 5], [5, 2501], [2501, 2502], [2502, 4999], [4999, 5000]]]),
+        "len1000": (1000, [[[0, 115], [115, 139], [139, 229], [229, 307], [307, 463], [463, 531], [531, 1000]]]),
+    }
+    save = {}
+    worst = 0.0
+    for name, (L, rois) in cases.items():
+        rois = torch.tensor(rois, dtype=torch.int64)
+        Bn, T, C = rois.shape[0], L // 4, 6
+        z = torch.from_numpy(hw.unit_noise("roi-z:" + name, Bn * C * T).reshape(Bn, C, T).astype(np.float32))
+        zs = torch.from_numpy(hw.unit_noise("roi-s:" + name, Bn * C * 7 * 32).reshape(Bn, C, 7, 32).astype(np.float32))
+        keep = rois.clone()
+        a = roi_algin(z, rois, size=16, spatial_scale=0.25)
+        r = roi_pooling_reverse(zs, rois, spatial_scale=0.25)
+        assert torch.equal(keep, rois)
+        start, length = orc.roi_segment_table(rois)
+        worst = max(worst, rel(orc.roi_align_mid(z, rois), a), rel(orc.roi_unpool(zs, rois), r))
+        save.update({f"{name}:L": L, f"{name}:rois": rois.numpy(), f"{name}:align": a.numpy(), f"{name}:unpool": r.numpy(),
+                     f"{name}:seg_start": start.numpy(), f"{name}:seg_len": length.numpy()})
+    np.savez_compressed(os.path.join(OUT, "roi_cases.npz"), **save)
+    print(f"roi_cases: oracle vs reference {worst:.2e}")
+    return worst
+
+
+def case_theta(network):
+    from network.utils.theta_encoder import ThetaEncoder
+    th = torch.from_numpy(synth.LEAD_THETA.astype(np.float32))[None]      # [1, 12, 2]
+    enc = ThetaEncoder(1)(th)
+    np.savez_compressed(os.path.join(OUT, "theta_table.npz"), theta=th.numpy(), enc=enc.numpy())
+    d = rel(orc.angular_encoding(th), enc)
+    print(f"theta_table: oracle vs reference {d:.2e}")
+    return d
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    network = import_reference()
+    worst = [case_theta(network), case_roi(network)]
+    for B, V, L in ((2, 1, 512), (2, 3, 512), (2, 3, 1000), (2, 8, 512)):
+        worst.append(case_eval(network, B, V, L, Q=5, seed=11 + V + L))
+    worst.append(case_train(network, 2, 1, 512, seed=5))
+    worst.append(case_train(network, 2, 3, 512, seed=6))
+    worst.append(case_train(network, 3, 3, 1000, seed=7, reg="l2_loss"))
+    worst.append(case_train(network, 2, 3, 512, seed=8, use_masks=False))
+    worst.append(case_sgd(network, 4, 3, 512, seed=21))
+    print("worst oracle-vs-reference deviation:", max(worst))
+
+
+if __name__ == "__main__":
+    main()
