@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""Nef-Net train-step benchmark (BASELINE.json metric: ECG-samples/sec of one train step).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; each rank trains on its own shard of the synthetic batch (weak scaling: per-GPU batch
+fixed), gradients are summed with ONE RCCL all-reduce of the flat gradient buffer per step.  A step is
+forward + losswrapper + backward + fused momentum-SGD on inputs already resident in HBM.  Rank 0 prints one
+JSON line.  At N=1 the line also carries the CPU baseline (the torch-CPU oracle timed on this box's host cores on
+a bounded sample of the same workload) and the roofline of the dominant kernel (the k=7 grouped-conv MFMA
+kernel), timed live with HIP events on the launch stream.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config 2: 256)")
+    ap.add_argument("--leads", type=int, default=3)
+    ap.add_argument("--len", type=int, default=5000, dest="length")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=32, help="host threads for the CPU baseline (capped at the core count)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true")
+    return ap.parse_args()
+
+
+def make_cfg(V):
+    from electrocardio_panorama_amd.config import get_defaults, resolve_config_path
+    cfg = get_defaults()
+    cfg.merge_from_file(resolve_config_path("config/nef_net.yml"))
+    cfg.DATA.lead_num = V
+    return cfg
+
+
+def cpu_baseline(V, L, B, steps, threads):
+    """The oracle (a torch-CPU port of the reference step) on the host cores: 1 warm-up + `steps` timed steps."""
+    from electrocardio_panorama_amd import synth
+    from oracle import nefnet_oracle as orc
+    # torch-CPU slows down badly when oversubscribed on a many-core host; use a bounded pool and report it
+    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
+    P = orc.require_grad(orc.reference_style_init(V, seed=123))
+    Bf = orc.fresh_buffers()
+    opt = orc.SGDState(0.1)
+    batch = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.make_batch(B, V, L, seed=123).items()}
+    random.seed(123)
+    orc.train_step(P, Bf, opt, batch)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orc.train_step(P, Bf, opt, batch)
+    dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "ECG-samples/sec", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
+            "sample": f"{steps} train steps of the torch-CPU oracle at batch {B}, V={V}, L={L} (1 warm-up step untimed)",
+            "ms_per_step": 1e3 * dt / steps}
+
+
+def main():
+    args = parse()
+    from electrocardio_panorama_amd import ops, parallel, synth
+    from electrocardio_panorama_amd.network import build_loss, build_model
+    from electrocardio_panorama_amd.solver.optim_scheduler import get_optimizer
+    from electrocardio_panorama_amd.utils import seed_torch
+
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    V, L, B = args.leads, args.length, args.batch
+    cfg = make_cfg(V)
+    seed_torch(cfg.seed)                       # identical init and Standin lead choices on every rank
+    model = build_model(cfg).float().to(dev).train()
+    if args.no_dropout:
+        model.dropout_p = 0.0
+    lossf = build_loss(cfg)
+    optim = get_optimizer(cfg, model.parameters())
+    meta = synth.make_batch(B, V, L, seed=123 + rank)
+    data, rois, in_theta, tgt_view, tgt_theta = (torch.from_numpy(np.ascontiguousarray(meta[k])).to(dev) for k in
+                                                 ("data", "rois", "input_theta", "target_view", "target_theta"))
+    tgt_view = tgt_view.unsqueeze(1)
+
+    def step():
+        out, sp, sl = model(data, in_theta, tgt_theta, rois, phase="train")
+        losses = lossf(out, sp, sl, tgt_view, cfg)
+        losses[0].backward()
+        optim.step()
+        optim.zero_grad()
+        return losses[0]
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ops.PROFILE = [] if rank == 0 else None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        # dominant kernel: conv_fwd_kernel<K=7> over the encoder's [B,128V,T] activations (forward AND bwd-data)
+        T = L // 4
+        key = ("conv_fwd", 7, V, 128, 128, B, T)
+        times = [s.elapsed_time(e) for tag, s, e in prof if tag == key]
+        flops = 2.0 * B * (128 * V) * T * 128 * 7
+        roof = None
+        if times:
+            avg_ms = sum(times) / len(times)
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("conv_fwd_k7_bytes_per_launch")
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "kernel": "conv_fwd_kernel<7,2> (k7 grouped conv, fwd + bwd-data)", "launches": len(times),
+                    "avg_ms": round(avg_ms, 4), "flops_per_launch": flops,
+                    "algorithmic_bytes_per_launch": 4.0 * (2 * B * 128 * V * T + 128 * V * 128 * 7),
+                    "hbm_GBps": round(4.0 * (2 * B * 128 * V * T + 128 * V * 128 * 7) / (avg_ms * 1e-3) / 1e9, 1)}
+        by_kernel = {}
+        for tag, s, e in prof:
+            by_kernel.setdefault(tag, []).append(s.elapsed_time(e))
+        breakdown = {"/".join(str(x) for x in k): round(sum(v) / args.steps, 3) for k, v in sorted(
+            by_kernel.items(), key=lambda kv: -sum(kv[1]))[:12]}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(V, L, args.cpu_batch, args.cpu_steps, args.cpu_threads)
+        line = {
+            "metric": "ECG-samples/sec (train step)", "value": round(world * B * args.steps / dt, 2),
+            "unit": "ECG-samples/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: Nef-Net train step, {V}-lead len={L}, batch={B}/GPU, "
+                                   f"3-view-in -> 1-view-out, Standin losses on, dropout "
+                                   f"{'off' if args.no_dropout else 'on'}",
+                       "global_batch": world * B, "seq_len": L, "leads": V, "parallelism": f"dp{world}"},
+            "roofline": roof, "cpu_baseline": cpu, "final_loss": final_loss, "conv_ms_per_step": breakdown,
+        }
+        if cpu:
+            line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

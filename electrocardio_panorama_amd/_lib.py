@@ -1,0 +1,113 @@
+"""ctypes binding of libnefnet_hip.so (declared in include/nefnet_hip.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load, importing any compute
+entry point raises.  Build it with `python -m electrocardio_panorama_amd.csrc.build`.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (first: the library must bind to the HIP runtime PyTorch-ROCm has already loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnefnet_hip.so")
+
+NEF_OK = 0
+_ERR = {-1: "NEF_E_SHAPE", -2: "NEF_E_NULL", -3: "NEF_E_WORKSPACE", -4: "NEF_E_UNSUPPORTED"}
+
+p = C.c_void_p
+i32 = C.c_int
+i64 = C.c_int64
+f32 = C.c_float
+sz = C.c_size_t
+
+
+class ConvArgs(C.Structure):
+    """Mirror of `nef_conv_args` (include/nefnet_hip.h)."""
+    _fields_ = [
+        ("x", p), ("wp", p), ("y", p), ("bias", p), ("in_scale", p), ("res", p), ("gate", p), ("mask", p),
+        ("x_bs", i64), ("x_gs", i64), ("y_bs", i64), ("y_gs", i64), ("sc_bs", i64), ("sc_gs", i64),
+        ("res_bs", i64), ("res_gs", i64), ("gate_bs", i64), ("gate_gs", i64),
+        ("B", i32), ("T", i32), ("G", i32), ("Cin_g", i32), ("Cout_g", i32), ("K", i32),
+        ("relu", i32), ("gate_scale", f32), ("drop_scale", f32), ("drop_p", f32), ("rng_seed", C.c_uint64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/nefnet_hip.h declares
+SIGNATURES = {
+    "nef_abi_version": (i32, []),
+    "nef_stem_fwd": (i32, [p, p, p, i32, i32, i32, p]),
+    "nef_stem_bwd_ws_bytes": (sz, [i32]),
+    "nef_stem_bwd_weight": (i32, [p, p, p, p, p, sz, i32, i32, i32, p]),
+    "nef_pack_weight": (i32, [p, p, i32, i32, i32, i32, i32, p]),
+    "nef_conv_fwd": (i32, [C.POINTER(ConvArgs), p]),
+    "nef_conv_bwd_weight_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "nef_conv_bwd_weight": (i32, [p, i64, i64, p, i64, i64, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32, i32, p]),
+    "nef_chan_sum_ws_bytes": (sz, [i32]),
+    "nef_chan_sum": (i32, [p, p, p, sz, i32, i32, i32, p]),
+    "nef_convt2_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, i32, p]),
+    "nef_convt2_bwd_data": (i32, [p, p, p, i32, i32, i32, i32, i32, p]),
+    "nef_convt2_bwd_weight_ws_bytes": (sz, [i32, i32, i32]),
+    "nef_convt2_bwd_weight": (i32, [p, p, p, p, p, sz, i32, i32, i32, i32, i32, p]),
+    "nef_theta_mlp_fwd": (i32, [p, p, p, p, i32, i32, p]),
+    "nef_theta_mlp_bwd": (i32, [p, p, p, p, i32, i32, p]),
+    "nef_theta_encode": (i32, [p, p, i32, p]),
+    "nef_chscale_fwd": (i32, [p, p, i64, p, i32, i32, i32, p]),
+    "nef_chscale_bwd": (i32, [p, p, p, i64, p, p, i32, i32, i32, p]),
+    "nef_gate": (i32, [p, p, p, f32, i64, p]),
+    "nef_add": (i32, [p, p, p, i64, p]),
+    "nef_roi_align_fwd": (i32, [p, p, p, i32, i32, i32, p]),
+    "nef_roi_align_bwd": (i32, [p, p, p, i32, i32, i32, p]),
+    "nef_roi_unpool_fwd": (i32, [p, p, p, p, i32, i32, i32, p]),
+    "nef_roi_unpool_bwd": (i32, [p, p, p, i32, i32, i32, p]),
+    "nef_roi_segment_table": (i32, [p, p, p, i32, p]),
+    "nef_lead_mean": (i32, [p, p, p, i32, i32, i32, p]),
+    "nef_mix_fwd": (i32, [p, p, p, p, p, i32, i32, i32, i32, i32, p]),
+    "nef_mix_bwd": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p]),
+    "nef_upsample2_fwd": (i32, [p, p, i64, i32, p]),
+    "nef_upsample2_bwd": (i32, [p, p, i64, i32, p]),
+    "nef_bn_ws_bytes": (sz, [i32, i32]),
+    "nef_bn_train_stats": (i32, [p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, f32, f32, p]),
+    "nef_bn_eval_affine": (i32, [p, p, p, p, p, p, i32, f32, p]),
+    "nef_affine_relu_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, p]),
+    "nef_bn_relu_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p]),
+    "nef_outconv_fwd": (i32, [p, p, p, p, i32, i32, i32, p]),
+    "nef_outconv_bwd_data": (i32, [p, p, p, p, i32, i32, i32, p]),
+    "nef_outconv_bwd_weight_ws_bytes": (sz, [i32]),
+    "nef_outconv_bwd_weight": (i32, [p, p, p, p, p, p, sz, i32, i32, i32, p]),
+    "nef_loss_ws_bytes": (sz, []),
+    "nef_loss_fwd": (i32, [p, p, p, p, p, p, sz, i64, f32, f32, f32, i32, i32, p]),
+    "nef_loss_bwd": (i32, [p, p, p, p, p, p, p, p, i64, f32, f32, f32, i32, i32, p]),
+    "nef_sgd_momentum": (i32, [p, p, p, i64, f32, f32, f32, i32, p]),
+}
+
+_lib = None
+
+
+class NefLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle with typed entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NefLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -m electrocardio_panorama_amd.csrc.build`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc == NEF_OK:
+        return
+    if rc < 0:
+        raise NefLibraryError(f"{what}: {_ERR.get(rc, rc)}")
+    raise NefLibraryError(f"{what}: hipError_t {rc}")

@@ -1,0 +1,52 @@
+"""Build libnefnet_hip.so (gfx950) in-tree with hipcc.  `python -m electrocardio_panorama_amd.csrc.build`."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SOURCES = ["conv_mfma.hip", "stem.hip", "elementwise.hip", "roi.hip", "convt_theta.hip"]
+LIB = os.path.join(HERE, "libnefnet_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+         "-I", os.path.join(ROOT, "include"), "-I", HERE]
+
+
+def hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "nef_common.h"),
+                                                       os.path.join(ROOT, "include", "nefnet_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(HERE, s.replace(".hip", ".o"))
+        cmd = [hipcc()] + FLAGS + ["-c", os.path.join(HERE, s), "-o", o]
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(o)
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0 or (verbose and out.strip()):
+            sys.stderr.write(f"--- hipcc {s} ---\n{out}\n")
+        failed |= p.returncode != 0
+    if failed:
+        raise RuntimeError("hipcc failed")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

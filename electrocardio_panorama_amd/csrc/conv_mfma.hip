@@ -1,0 +1,543 @@
+// Grouped Conv1d (stride 1, K in {1,3,7}) forward / backward-data / backward-weight as implicit GEMMs on
+// the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, fmaf-chain numerics).
+//
+// Replaces nn.Conv1d at reference codes/network/model_nefnet.py:18,21,32,44 and
+// codes/network/encoder/resnet_1d.py:23 (forward), and the autograd-derived convolution_backward.
+//
+// GEMM view, per group g (all time-contiguous, so the N / reduction axis is the coalesced one):
+//   forward / bwd-data : Y[co][n] = sum_{ci,k} Wp[k][ci][co] * X[ci][n + k - pad]     M=co  N=(b,t)  K=(ci,k)
+//   bwd-weight         : gW[co][ci][k] = sum_{n} gY[co][n] * X[ci][n + k - pad]       M=co  N=ci     K=(b,t)
+// A column tile never straddles a sample: long sequences are cut into 128(64)-column tiles, short ones
+// (the fixed 16/32-sample ROI latents) pack several whole samples per tile, each with its own zero halo in LDS.
+#include "nef_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int NT = 128;   // forward: columns per workgroup
+constexpr int WT = 64;    // bwd-weight: reduction columns per staged tile
+
+template <int K> struct StageK;
+template <> struct StageK<7> { static constexpr int KC = 16; };
+template <> struct StageK<3> { static constexpr int KC = 32; };
+template <> struct StageK<1> { static constexpr int KC = 64; };
+
+struct ColTiling {
+    int seg_shift;   // log2(columns per sample segment inside a tile)
+    int nseg;        // samples per tile
+    int tps;         // tiles per sample (nseg == 1) else 1
+    int n_tiles;
+};
+
+static ColTiling make_tiling(int B, int T, int tile_cols) {
+    ColTiling c;
+    if (T >= tile_cols) {
+        c.seg_shift = 31 - __builtin_clz(tile_cols);
+        c.nseg = 1;
+        c.tps = (T + tile_cols - 1) / tile_cols;
+        c.n_tiles = B * c.tps;
+    } else {
+        int seg = 16;
+        while (seg < T) seg <<= 1;
+        c.seg_shift = 31 - __builtin_clz(seg);
+        c.nseg = tile_cols / seg;
+        c.tps = 1;
+        c.n_tiles = (B + c.nseg - 1) / c.nseg;
+    }
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / bwd-data
+// ------------------------------------------------------------------------------------------------
+template <int K, int TM>
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int seg_shift, int nseg, int tps,
+                                                         int n_tiles, int m_tiles) {
+    constexpr int KC = StageK<K>::KC;
+    constexpr int MT = 64 * TM;
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int XRS = NT + (NT / 16) * (K - 1);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                  // [K][KC][MT]
+    float* Xl = smem + K * KC * MT;    // [KC][XRS]
+
+    const int tile = blockIdx.x % n_tiles;
+    const int gm = blockIdx.x / n_tiles;
+    const int mt = gm % m_tiles;
+    const int g = gm / m_tiles;
+    const int seg = 1 << seg_shift;
+    int b0, t0;
+    if (nseg == 1) {
+        b0 = tile / tps;
+        t0 = (tile - b0 * tps) * NT;
+    } else {
+        b0 = tile * nseg;
+        t0 = 0;
+    }
+    const int m0 = mt * MT;
+    const int T = a.T, Cig = a.Cin_g, Cog = a.Cout_g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int segw = seg + K - 1;
+    const int xrow = nseg * segw;
+
+    // per-thread staging coordinates along the LDS row (<= 3 positions, xrow <= 176)
+    int64_t xoff[3], soff[3];
+    bool xok[3];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int r = lane + 64 * it;
+        const int s = r / segw;
+        const int u = r - s * segw;
+        const int t = t0 + u - PAD;
+        const int b = b0 + s;
+        xok[it] = (r < xrow) && (b < a.B) && (t >= 0) && (t < T);
+        xoff[it] = (int64_t)b * a.x_bs + (int64_t)g * a.x_gs + t;
+        soff[it] = (int64_t)b * a.sc_bs + (int64_t)g * a.sc_gs;
+    }
+
+    // LDS column offsets of this lane's two 32-column MFMA tiles
+    int coloff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = wn * 64 + j * 32 + lo;
+        coloff[j] = (col >> seg_shift) * segw + (col & (seg - 1));
+    }
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int c0 = 0; c0 < Cig; c0 += KC) {
+        __syncthreads();
+        // weights: K*KC rows of MT floats (row stride Cog in global)
+        {
+            constexpr int M4 = MT / 4;
+            float4* Wl4 = reinterpret_cast<float4*>(Wl);
+            for (int i = threadIdx.x; i < K * KC * M4; i += 256) {
+                const int m4 = i % M4;
+                const int rc = i / M4;
+                const int ci = rc % KC;
+                const int kk = rc / KC;
+                const float4* src =
+                    reinterpret_cast<const float4*>(a.wp + ((int64_t)(g * K + kk) * Cig + c0 + ci) * Cog + m0) + m4;
+                Wl4[i] = *src;
+            }
+        }
+        // activations: KC rows of the halo'd column tile
+        for (int ci = wave; ci < KC; ci += 4) {
+            const int64_t coff = (int64_t)(c0 + ci) * T;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int r = lane + 64 * it;
+                if (r < xrow) {
+                    float v = 0.f;
+                    if (xok[it]) {
+                        v = a.x[xoff[it] + coff];
+                        if (a.in_scale) v *= a.in_scale[soff[it] + c0 + ci];
+                    }
+                    Xl[ci * XRS + r] = v;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+#pragma unroll 4
+            for (int c = 0; c < KC; c += 2) {
+                float av[TM], bv[2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[i] = Wl[(kk * KC + c + hi) * MT + (wm * TM + i) * 32 + lo];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bv[j] = Xl[(c + hi) * XRS + coloff[j] + kk];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: bias, residual, ReLU, dropout, gate; 32 lanes store 128 contiguous bytes per row
+    const int64_t ctot = (int64_t)a.G * Cog;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = wn * 64 + j * 32 + lo;
+        const int s = col >> seg_shift;
+        const int tt = col & (seg - 1);
+        const int b = b0 + s;
+        const int t = t0 + tt;
+        if (b >= a.B || t >= T) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float v = acc[i][j][r];
+                if (a.bias) v += a.bias[g * Cog + co];
+                if (a.res) v += a.res[(int64_t)b * a.res_bs + (int64_t)g * a.res_gs + (int64_t)co * T + t];
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (a.mask || a.drop_p > 0.f) {
+                    const int64_t dense = ((int64_t)b * ctot + (int64_t)g * Cog + co) * T + t;
+                    if (a.mask) {
+                        v *= (float)a.mask[dense] * a.drop_scale;
+                    } else {
+                        v = (nef_rng_uniform(a.rng_seed, (uint64_t)dense) >= a.drop_p) ? v * a.drop_scale : 0.f;
+                    }
+                }
+                if (a.gate) {
+                    const float gt = a.gate[(int64_t)b * a.gate_bs + (int64_t)g * a.gate_gs + (int64_t)co * T + t];
+                    v = gt > 0.f ? v * a.gate_scale : 0.f;
+                }
+                a.y[(int64_t)b * a.y_bs + (int64_t)g * a.y_gs + (int64_t)co * T + t] = v;
+            }
+        }
+    }
+}
+
+template <int K, int TM>
+static int launch_conv_fwd(const nef_conv_args& a, hipStream_t st) {
+    constexpr int KC = StageK<K>::KC;
+    constexpr int MT = 64 * TM;
+    constexpr int XRS = NT + (NT / 16) * (K - 1);
+    constexpr size_t lds = (size_t)(K * KC * MT + KC * XRS) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<K, TM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const ColTiling ct = make_tiling(a.B, a.T, NT);
+    const int m_tiles = a.Cout_g / MT;
+    const int64_t blocks = (int64_t)a.G * m_tiles * ct.n_tiles;
+    if (blocks <= 0 || blocks > 0x7fffffff) return NEF_E_SHAPE;
+    hipLaunchKernelGGL((conv_fwd_kernel<K, TM>), dim3((unsigned)blocks), dim3(256), lds, st, a, ct.seg_shift, ct.nseg,
+                       ct.tps, ct.n_tiles, m_tiles);
+    return nef_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// bwd-weight: split over the (b,t) reduction, partials reduced by a second deterministic kernel
+// ------------------------------------------------------------------------------------------------
+template <int K, int WCO, int TCI>
+__global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
+    const float* __restrict__ x, int64_t x_bs, int64_t x_gs, const float* __restrict__ in_scale, int64_t sc_bs,
+    int64_t sc_gs, const float* __restrict__ gy, int64_t gy_bs, int64_t gy_gs, float* __restrict__ ws, int B, int T,
+    int G, int Cig, int Cog, int seg_shift, int nseg, int tps, int n_tiles, int m_tiles, int ci_chunks, int S) {
+    constexpr int WCI = 4 / WCO;
+    constexpr int MT = 32 * WCO;
+    constexpr int CIT = 32 * TCI * WCI;
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int GYS = WT + 1;
+    constexpr int XS = (WT + (WT / 16) * (K - 1)) | 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* GYl = smem;               // [MT][GYS]
+    float* Xl = smem + MT * GYS;     // [CIT][XS]
+
+    int bid = blockIdx.x;
+    const int cc = bid % ci_chunks;
+    bid /= ci_chunks;
+    const int mt = bid % m_tiles;
+    bid /= m_tiles;
+    const int g = bid % G;
+    const int split = bid / G;
+    const int m0 = mt * MT, c0 = cc * CIT;
+    const int seg = 1 << seg_shift;
+    const int segw = seg + K - 1;
+    const int xrow = nseg * segw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int wco = wave % WCO, wci = wave / WCO;
+
+    f32x16 acc[TCI][K];
+#pragma unroll
+    for (int i = 0; i < TCI; ++i)
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+
+    for (int tile = split; tile < n_tiles; tile += S) {
+        int b0, t0;
+        if (nseg == 1) {
+            b0 = tile / tps;
+            t0 = (tile - b0 * tps) * WT;
+        } else {
+            b0 = tile * nseg;
+            t0 = 0;
+        }
+        __syncthreads();
+        // gY tile: MT rows x 64 columns (zero outside the sample / batch)
+        {
+            const int s = lane >> seg_shift;
+            const int tt = lane & (seg - 1);
+            const int b = b0 + s, t = t0 + tt;
+            const bool ok = (b < B) && (t < T);
+            const int64_t off = (int64_t)b * gy_bs + (int64_t)g * gy_gs + t;
+            for (int row = wave; row < MT; row += 4)
+                GYl[row * GYS + lane] = ok ? gy[off + (int64_t)(m0 + row) * T] : 0.f;
+        }
+        // X tile: CIT rows x halo'd columns
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int r = lane + 64 * it;
+            if (r < xrow) {
+                const int s = r / segw;
+                const int u = r - s * segw;
+                const int b = b0 + s, t = t0 + u - PAD;
+                const bool ok = (b < B) && (t >= 0) && (t < T);
+                const int64_t off = (int64_t)b * x_bs + (int64_t)g * x_gs + t;
+                const int64_t so = (int64_t)b * sc_bs + (int64_t)g * sc_gs;
+                for (int row = wave; row < CIT; row += 4) {
+                    float v = 0.f;
+                    if (ok) {
+                        v = x[off + (int64_t)(c0 + row) * T];
+                        if (in_scale) v *= in_scale[so + c0 + row];
+                    }
+                    Xl[row * XS + r] = v;
+                }
+            }
+        }
+        __syncthreads();
+        for (int s = 0; s < nseg; ++s) {
+            const float* ga = GYl + (wco * 32 + lo) * GYS + s * seg + hi;
+            const float* xb = Xl + ((wci * TCI) * 32 + lo) * XS + s * segw + hi;
+#pragma unroll 4
+            for (int tt = 0; tt < seg; tt += 2) {
+                const float av = ga[tt];
+#pragma unroll
+                for (int i = 0; i < TCI; ++i)
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xb[i * 32 * XS + tt + k], acc[i][k], 0, 0, 0);
+            }
+        }
+    }
+    // partials: ws[split][g][k][co][ci]
+#pragma unroll
+    for (int i = 0; i < TCI; ++i) {
+        const int ci = c0 + (wci * TCI + i) * 32 + lo;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float* dst = ws + ((((int64_t)split * G + g) * K + k) * Cog) * Cig;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                dst[(int64_t)co * Cig + ci] = acc[i][k][r];
+            }
+        }
+    }
+}
+
+// gw[g*Cog+co][ci][k] = sum_split ws[split][g][k][co][ci]
+__global__ void conv_bwd_weight_reduce(const float* __restrict__ ws, float* __restrict__ gw, int G, int Cog, int Cig,
+                                       int K, int S) {
+    const int64_t n = (int64_t)G * K * Cog * Cig;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cig);
+        int64_t r = i / Cig;
+        const int co = (int)(r % Cog);
+        r /= Cog;
+        const int k = (int)(r % K);
+        const int g = (int)(r / K);
+        float s = 0.f;
+        for (int sp = 0; sp < S; ++sp) s += ws[(int64_t)sp * n + i];
+        gw[(((int64_t)g * Cog + co) * Cig + ci) * K + k] = s;
+    }
+}
+
+struct BwdWeightPlan {
+    int wco, tci, m_tiles, ci_chunks, S;
+    ColTiling ct;
+};
+
+static bool plan_bwd_weight(int B, int T, int G, int Cig, int Cog, int K, BwdWeightPlan* p) {
+    if (!(K == 1 || K == 3 || K == 7)) return false;
+    if (Cog % 128 == 0) p->wco = 4;
+    else if (Cog % 64 == 0) p->wco = 2;
+    else return false;
+    const int wci = 4 / p->wco;
+    p->tci = (K <= 3 && Cig % (64 * wci) == 0) ? 2 : 1;
+    const int cit = 32 * p->tci * wci;
+    if (Cig % cit != 0) return false;
+    p->m_tiles = Cog / (32 * p->wco);
+    p->ci_chunks = Cig / cit;
+    p->ct = make_tiling(B, T, WT);
+    const int base = G * p->m_tiles * p->ci_chunks;
+    int S = (768 + base - 1) / base;
+    if (S > p->ct.n_tiles) S = p->ct.n_tiles;
+    if (S < 1) S = 1;
+    p->S = S;
+    return true;
+}
+
+template <int K, int WCO, int TCI>
+static int launch_bwd_weight(const BwdWeightPlan& p, const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale,
+                             int64_t sc_bs, int64_t sc_gs, const float* gy, int64_t gy_bs, int64_t gy_gs, float* ws,
+                             int B, int T, int G, int Cig, int Cog, hipStream_t st) {
+    constexpr int WCI = 4 / WCO;
+    constexpr int MT = 32 * WCO;
+    constexpr int CIT = 32 * TCI * WCI;
+    constexpr int GYS = WT + 1;
+    constexpr int XS = (WT + (WT / 16) * (K - 1)) | 1;
+    constexpr size_t lds = (size_t)(MT * GYS + CIT * XS) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bwd_weight_kernel<K, WCO, TCI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int64_t blocks = (int64_t)p.S * G * p.m_tiles * p.ci_chunks;
+    hipLaunchKernelGGL((conv_bwd_weight_kernel<K, WCO, TCI>), dim3((unsigned)blocks), dim3(256), lds, st, x, x_bs, x_gs,
+                       in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, ws, B, T, G, Cig, Cog, p.ct.seg_shift, p.ct.nseg,
+                       p.ct.tps, p.ct.n_tiles, p.m_tiles, p.ci_chunks, p.S);
+    return nef_launch_status();
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog, int Cig, int K,
+                                   int flip) {
+    const int64_t n = (int64_t)G * Cog * Cig * K;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        // i indexes the PACKED tensor
+        int64_t r = i;
+        int co, ci;
+        if (!flip) {   // [g][k][ci][co]
+            co = (int)(r % Cog); r /= Cog;
+            ci = (int)(r % Cig); r /= Cig;
+        } else {       // [g][k][co][ci]
+            ci = (int)(r % Cig); r /= Cig;
+            co = (int)(r % Cog); r /= Cog;
+        }
+        const int k = (int)(r % K);
+        const int g = (int)(r / K);
+        const int ks = flip ? (K - 1 - k) : k;
+        wp[i] = w[(((int64_t)g * Cog + co) * Cig + ci) * K + ks];
+    }
+}
+
+__global__ void chan_sum_partial(const float* __restrict__ x, double* __restrict__ part, int B, int C, int T,
+                                 int nsplit) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x % C;
+    const int sp = blockIdx.x / C;
+    double s = 0.0;
+    for (int b = sp; b < B; b += nsplit) {
+        const float* row = x + ((int64_t)b * C + c) * T;
+        float ps = 0.f;
+        for (int t = threadIdx.x; t < T; t += blockDim.x) ps += row[t];
+        s += (double)ps;
+    }
+    s = nef_block_sum_d(s, sm);
+    if (threadIdx.x == 0) part[(int64_t)sp * C + c] = s;
+}
+
+__global__ void chan_sum_final(const double* __restrict__ part, float* __restrict__ out, int C, int nsplit) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[(int64_t)sp * C + c];
+    out[c] = (float)s;
+}
+
+constexpr int CHAN_SUM_SPLIT = 16;
+
+}  // namespace
+
+extern "C" {
+
+int nef_abi_version(void) {
+    NEF_ENTER(); return 1; }
+
+int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
+                    nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(w && wp, NEF_E_NULL);
+    NEF_REQUIRE(G > 0 && Cog > 0 && Cig > 0 && K > 0, NEF_E_SHAPE);
+    const int64_t n = (int64_t)G * Cog * Cig * K;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, G,
+                       Cog, Cig, K, transpose_flip);
+    return nef_launch_status();
+}
+
+int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(a && a->x && a->wp && a->y, NEF_E_NULL);
+    NEF_REQUIRE(a->B > 0 && a->T > 0 && a->G > 0, NEF_E_SHAPE);
+    const int K = a->K;
+    NEF_REQUIRE(K == 1 || K == 3 || K == 7, NEF_E_SHAPE);
+    NEF_REQUIRE(a->Cout_g % 64 == 0 && a->Cin_g > 0, NEF_E_SHAPE);
+    const int KC = K == 7 ? 16 : (K == 3 ? 32 : 64);
+    NEF_REQUIRE(a->Cin_g % KC == 0, NEF_E_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const bool big = (a->Cout_g % 128 == 0);
+    switch (K) {
+        case 7: return big ? launch_conv_fwd<7, 2>(*a, st) : launch_conv_fwd<7, 1>(*a, st);
+        case 3: return big ? launch_conv_fwd<3, 2>(*a, st) : launch_conv_fwd<3, 1>(*a, st);
+        default: return big ? launch_conv_fwd<1, 2>(*a, st) : launch_conv_fwd<1, 1>(*a, st);
+    }
+}
+
+size_t nef_conv_bwd_weight_ws_bytes(int B, int T, int G, int Cin_g, int Cout_g, int K) {
+    BwdWeightPlan p;
+    if (!plan_bwd_weight(B, T, G, Cin_g, Cout_g, K, &p)) return 0;
+    return (size_t)p.S * G * K * Cout_g * Cin_g * sizeof(float);
+}
+
+int nef_conv_bwd_weight(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
+                        int64_t sc_gs, const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws,
+                        size_t ws_bytes, int B, int T, int G, int Cin_g, int Cout_g, int K, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && gy && gw && ws, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && T > 0 && G > 0, NEF_E_SHAPE);
+    BwdWeightPlan p;
+    NEF_REQUIRE(plan_bwd_weight(B, T, G, Cin_g, Cout_g, K, &p), NEF_E_SHAPE);
+    const size_t need = (size_t)p.S * G * K * Cout_g * Cin_g * sizeof(float);
+    NEF_REQUIRE(ws_bytes >= need, NEF_E_WORKSPACE);
+    hipStream_t st = (hipStream_t)stream;
+    float* wsf = (float*)ws;
+    int rc;
+#define NEF_BW(KK, WCO, TCI)                                                                                          \
+    rc = launch_bwd_weight<KK, WCO, TCI>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G,    \
+                                         Cin_g, Cout_g, st)
+    if (K == 7) {
+        if (p.wco == 4) NEF_BW(7, 4, 1); else NEF_BW(7, 2, 1);
+    } else if (K == 3) {
+        if (p.wco == 4) { if (p.tci == 2) NEF_BW(3, 4, 2); else NEF_BW(3, 4, 1); }
+        else { if (p.tci == 2) NEF_BW(3, 2, 2); else NEF_BW(3, 2, 1); }
+    } else {
+        if (p.wco == 4) { if (p.tci == 2) NEF_BW(1, 4, 2); else NEF_BW(1, 4, 1); }
+        else { if (p.tci == 2) NEF_BW(1, 2, 2); else NEF_BW(1, 2, 1); }
+    }
+#undef NEF_BW
+    if (rc != NEF_OK) return rc;
+    const int64_t n = (int64_t)G * K * Cout_g * Cin_g;
+    hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3(nef_stream_grid(n, 256)), dim3(256), 0, st, wsf, gw, G, Cout_g,
+                       Cin_g, K, p.S);
+    return nef_launch_status();
+}
+
+size_t nef_chan_sum_ws_bytes(int C) { return (size_t)CHAN_SUM_SPLIT * C * sizeof(double); }
+
+int nef_chan_sum(const float* x, float* out, void* ws, size_t ws_bytes, int B, int C, int T, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && out && ws, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(ws_bytes >= nef_chan_sum_ws_bytes(C), NEF_E_WORKSPACE);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(chan_sum_partial, dim3(C * CHAN_SUM_SPLIT), dim3(256), 0, st, x, (double*)ws, B, C, T,
+                       CHAN_SUM_SPLIT);
+    hipLaunchKernelGGL(chan_sum_final, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, out, C,
+                       CHAN_SUM_SPLIT);
+    return nef_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,763 @@
+// HBM-bound passes of the Nef-Net step: channel scaling, gates, lead mean / Standin mix, linear x2 upsampling,
+// BatchNorm (training statistics, affine+ReLU, backward), the 64->1 output conv with sigmoid(x/3), the
+// L1/L2 + Standin losses and the momentum-SGD update.  Reference call sites are cited per kernel; all are
+// `codes/network/model_nefnet.py` unless stated.  One lane = consecutive time samples, so every global access is
+// a coalesced 256-byte wave transaction along the time axis; reductions use wavefront shuffles.
+#include "nef_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// y[b][c][t] = x[b][c][t] * s[b][c]            (:122-123, :166/:170/:174/:186)
+// ------------------------------------------------------------------------------------------------
+__global__ void chscale_fwd_kernel(const float* __restrict__ x, const float* __restrict__ s, int64_t s_bs,
+                                   float* __restrict__ y, int B, int C, int T) {
+    const int64_t rows = (int64_t)B * C;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int b = (int)(row / C), c = (int)(row % C);
+        const float f = s[(int64_t)b * s_bs + c];
+        const float* xr = x + row * T;
+        float* yr = y + row * T;
+        for (int t = lane; t < T; t += 64) yr[t] = xr[t] * f;
+    }
+}
+
+__global__ void chscale_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                   const float* __restrict__ s, int64_t s_bs, float* __restrict__ gx,
+                                   float* __restrict__ gs, int B, int C, int T) {
+    const int64_t rows = (int64_t)B * C;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int b = (int)(row / C), c = (int)(row % C);
+        const float f = s[(int64_t)b * s_bs + c];
+        const float* gr = gy + row * T;
+        const float* xr = x + row * T;
+        float* gxr = gx + row * T;
+        float acc = 0.f;
+        for (int t = lane; t < T; t += 64) {
+            const float g = gr[t];
+            acc = fmaf(g, xr[t], acc);
+            gxr[t] = g * f;
+        }
+        acc = nef_wave_sum(acc);
+        if (lane == 0) gs[row] = acc;
+    }
+}
+
+__global__ void gate_kernel(const float* __restrict__ g, const float* __restrict__ ref, float* __restrict__ out,
+                            float scale, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = ref[i] > 0.f ? g[i] * scale : 0.f;
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                           int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// latent = cat(mean_v z1, mean_v z2r)          (:146-151)
+// ------------------------------------------------------------------------------------------------
+__global__ void lead_mean_kernel(const float* __restrict__ z1, const float* __restrict__ z2r,
+                                 float* __restrict__ latent, int B, int V, int T) {
+    const int64_t rows = (int64_t)B * 256;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float fv = (float)V;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int b = (int)(row >> 8), c = (int)(row & 255);
+        const float* src = (c < 128 ? z1 : z2r) + ((int64_t)b * V * 128 + (c & 127)) * T;
+        float* dst = latent + row * T;
+        for (int t = lane; t < T; t += 64) {
+            float s = src[t];
+            for (int v = 1; v < V; ++v) s += src[(int64_t)v * 128 * T + t];
+            dst[t] = s / fv;
+        }
+    }
+}
+
+// D[0] = q*latent ; D[1] = q*cat(z1[c1], latent[128:]) ; D[2] = q*cat(latent[:128], z2r[c2])     (:159-176)
+__global__ void mix_fwd_kernel(const float* __restrict__ latent, const float* __restrict__ z1,
+                               const float* __restrict__ z2r, const float* __restrict__ q, float* __restrict__ D,
+                               int B, int V, int T, int c1, int c2) {
+    const int64_t rows = (int64_t)B * 256;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t pass = rows * T;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int b = (int)(row >> 8), c = (int)(row & 255);
+        const float f = q[row];
+        const float* lat = latent + row * T;
+        const float* pick = c < 128 ? z1 + ((int64_t)b * V * 128 + c1 * 128 + c) * T
+                                    : z2r + ((int64_t)b * V * 128 + c2 * 128 + (c - 128)) * T;
+        float* d0 = D + row * T;
+        for (int t = lane; t < T; t += 64) {
+            const float l = lat[t], p = pick[t];
+            d0[t] = f * l;
+            d0[pass + t] = f * (c < 128 ? p : l);
+            d0[2 * pass + t] = f * (c < 128 ? l : p);
+        }
+    }
+}
+
+__global__ void mix_bwd_kernel(const float* __restrict__ gD, const float* __restrict__ latent,
+                               const float* __restrict__ z1, const float* __restrict__ z2r,
+                               const float* __restrict__ q, float* __restrict__ gz1, float* __restrict__ gz2r,
+                               float* __restrict__ gq, int B, int V, int T, int c1, int c2) {
+    const int64_t rows = (int64_t)B * 256;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t pass = rows * T;
+    const float fv = (float)V;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int b = (int)(row >> 8), c = (int)(row & 255);
+        const bool first = c < 128;
+        const int cc = c & 127;
+        const int pick_v = first ? c1 : c2;
+        const float f = q[row];
+        const float* lat = latent + row * T;
+        const float* zsrc = (first ? z1 : z2r) + ((int64_t)b * V * 128 + cc) * T;
+        float* gdst = (first ? gz1 : gz2r) + ((int64_t)b * V * 128 + cc) * T;
+        const float* g0 = gD + row * T;
+        float acc = 0.f;
+        for (int t = lane; t < T; t += 64) {
+            const float ga = g0[t], gb = g0[pass + t], gc = g0[2 * pass + t];
+            // pass that uses the picked lead for this half: D1 for the z1 half, D2 for the z2 half
+            const float g_pick = first ? gb : gc;
+            const float g_mean = first ? (ga + gc) : (ga + gb);
+            const float l = lat[t];
+            const float pk = zsrc[(int64_t)pick_v * 128 * T + t];
+            acc += g_mean * l + g_pick * pk;
+            const float gm = f * g_mean / fv;
+            for (int v = 0; v < V; ++v) gdst[(int64_t)v * 128 * T + t] = gm + (v == pick_v ? f * g_pick : 0.f);
+        }
+        acc = nef_wave_sum(acc);
+        if (lane == 0) gq[row] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// nn.Upsample(scale_factor=2, mode='linear', align_corners=False)        (:102,:104)
+//   y[2m] = .25 x[m-1] + .75 x[m] (m>=1), y[0] = x[0];  y[2m+1] = .75 x[m] + .25 x[min(m+1,Tin-1)]
+// written as torch's CPU kernel evaluates it: lambda0*x[i0] + lambda1*x[i1].
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float up2_at(const float* __restrict__ xr, int Tin, int i) {
+    float src = 0.5f * ((float)i + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    int i0 = (int)src;
+    if (i0 > Tin - 1) i0 = Tin - 1;
+    const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+    const float l1 = src - (float)i0;
+    const float l0 = 1.f - l1;
+    return l0 * xr[i0] + l1 * xr[i1];
+}
+
+__global__ void upsample2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t N, int Tin) {
+    const int To = 2 * Tin;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
+        const float* xr = x + row * Tin;
+        float* yr = y + row * To;
+        for (int i = lane; i < To; i += 64) yr[i] = up2_at(xr, Tin, i);
+    }
+}
+
+// transpose of the above: gx[m] = sum of the (<=4) outputs that read x[m]
+__global__ void upsample2_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int64_t N, int Tin) {
+    const int To = 2 * Tin;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
+        const float* gr = gy + row * To;
+        float* gxr = gx + row * Tin;
+        for (int m = lane; m < Tin; m += 64) {
+            float s = 0.f;
+            // candidates: outputs 2m-2 .. 2m+2 can reference x[m]
+#pragma unroll
+            for (int d = -2; d <= 2; ++d) {
+                const int i = 2 * m + d;
+                if (i < 0 || i >= To) continue;
+                float src = 0.5f * ((float)i + 0.5f) - 0.5f;
+                if (src < 0.f) src = 0.f;
+                int i0 = (int)src;
+                if (i0 > Tin - 1) i0 = Tin - 1;
+                const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+                const float l1 = src - (float)i0;
+                const float l0 = 1.f - l1;
+                const float g = gr[i];
+                if (i0 == m) s += l0 * g;
+                if (i1 == m) s += l1 * g;
+            }
+            gxr[m] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm1d in training mode over P stacked passes                       (:19,:22 )
+// ------------------------------------------------------------------------------------------------
+constexpr int BN_SPLIT = 8;
+
+// partial sums in double: part[(p*C + c)*BN_SPLIT + sp][2]
+__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, double* __restrict__ part, int P,
+                                                        int Bp, int C, int L) {
+    __shared__ double sm[4];
+    int bid = blockIdx.x;
+    const int sp = bid % BN_SPLIT;
+    bid /= BN_SPLIT;
+    const int c = bid % C;
+    const int p = bid / C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = sp; b < Bp; b += BN_SPLIT) {
+        const float* row = x + (((int64_t)p * Bp + b) * C + c) * L;
+        double r1 = 0.0, r2 = 0.0;
+        for (int t = threadIdx.x; t < L; t += 256) {
+            const double v = (double)row[t];
+            r1 += v;
+            r2 += v * v;
+        }
+        s1 += r1;
+        s2 += r2;
+    }
+    s1 = nef_block_sum_d(s1, sm);
+    s2 = nef_block_sum_d(s2, sm);
+    if (threadIdx.x == 0) {
+        part[((int64_t)(p * C + c) * BN_SPLIT + sp) * 2] = s1;
+        part[((int64_t)(p * C + c) * BN_SPLIT + sp) * 2 + 1] = s2;
+    }
+}
+
+__global__ void bn_stats_final(const double* __restrict__ part, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, float* __restrict__ running_mean,
+                               float* __restrict__ running_var, float* __restrict__ mean, float* __restrict__ invstd,
+                               float* __restrict__ a, float* __restrict__ b, int P, int Bp, int C, int L, float eps,
+                               float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double n = (double)Bp * (double)L;
+    float rm = running_mean ? running_mean[c] : 0.f;
+    float rv = running_var ? running_var[c] : 1.f;
+    for (int p = 0; p < P; ++p) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int sp = 0; sp < BN_SPLIT; ++sp) {
+            s1 += part[((int64_t)(p * C + c) * BN_SPLIT + sp) * 2];
+            s2 += part[((int64_t)(p * C + c) * BN_SPLIT + sp) * 2 + 1];
+        }
+        const double m = s1 / n;
+        double var = s2 / n - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)m;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        mean[p * C + c] = mf;
+        invstd[p * C + c] = is;
+        const float af = gamma[c] * is;
+        a[p * C + c] = af;
+        b[p * C + c] = beta[c] - mf * af;
+        const float unbiased = (float)(var * (n / (n - 1.0)));
+        rm = (1.f - momentum) * rm + momentum * mf;
+        rv = (1.f - momentum) * rv + momentum * unbiased;
+    }
+    if (running_mean) running_mean[c] = rm;
+    if (running_var) running_var[c] = rv;
+}
+
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv,
+                                      float* __restrict__ a, float* __restrict__ b, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.0f / sqrtf(rv[c] + eps);
+    const float af = gamma[c] * is;
+    a[c] = af;
+    b[c] = beta[c] - rm[c] * af;
+}
+
+__global__ void affine_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                       const float* __restrict__ b, float* __restrict__ y, int P, int Bp, int C,
+                                       int L) {
+    const int64_t rows = (int64_t)P * Bp * C;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int c = (int)(row % C);
+        const int p = (int)(row / ((int64_t)Bp * C));
+        const float af = a[p * C + c], bf = b[p * C + c];
+        const float* xr = x + row * L;
+        float* yr = y + row * L;
+        for (int t = lane; t < L; t += 64) yr[t] = fmaxf(fmaf(xr[t], af, bf), 0.f);
+    }
+}
+
+// backward reductions per (pass, channel): s1 = sum g, s2 = sum g * xhat, g = gy * [x*a+b > 0]
+__global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ gy, const float* __restrict__ x,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ a, const float* __restrict__ b,
+                                                      double* __restrict__ part, int P, int Bp, int C, int L) {
+    __shared__ double sm[4];
+    int bid = blockIdx.x;
+    const int sp = bid % BN_SPLIT;
+    bid /= BN_SPLIT;
+    const int c = bid % C;
+    const int p = bid / C;
+    const float mf = mean[p * C + c], is = invstd[p * C + c], af = a[p * C + c], bf = b[p * C + c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int bb = sp; bb < Bp; bb += BN_SPLIT) {
+        const int64_t off = (((int64_t)p * Bp + bb) * C + c) * L;
+        float r1 = 0.f, r2 = 0.f;
+        for (int t = threadIdx.x; t < L; t += 256) {
+            const float xv = x[off + t];
+            const float g = fmaf(xv, af, bf) > 0.f ? gy[off + t] : 0.f;
+            r1 += g;
+            r2 = fmaf(g, (xv - mf) * is, r2);
+        }
+        s1 += (double)r1;
+        s2 += (double)r2;
+    }
+    s1 = nef_block_sum_d(s1, sm);
+    s2 = nef_block_sum_d(s2, sm);
+    if (threadIdx.x == 0) {
+        part[((int64_t)(p * C + c) * BN_SPLIT + sp) * 2] = s1;
+        part[((int64_t)(p * C + c) * BN_SPLIT + sp) * 2 + 1] = s2;
+    }
+}
+
+// coef[(p*C+c)*2] = s1/n, s2/n ; ggamma[c] = sum_p s2 ; gbeta[c] = sum_p s1
+__global__ void bn_bwd_final(const double* __restrict__ part, float* __restrict__ coef, float* __restrict__ ggamma,
+                             float* __restrict__ gbeta, int P, int Bp, int C, int L) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double n = (double)Bp * (double)L;
+    double g1 = 0.0, g2 = 0.0;
+    for (int p = 0; p < P; ++p) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int sp = 0; sp < BN_SPLIT; ++sp) {
+            s1 += part[((int64_t)(p * C + c) * BN_SPLIT + sp) * 2];
+            s2 += part[((int64_t)(p * C + c) * BN_SPLIT + sp) * 2 + 1];
+        }
+        coef[(p * C + c) * 2] = (float)(s1 / n);
+        coef[(p * C + c) * 2 + 1] = (float)(s2 / n);
+        g1 += s1;
+        g2 += s2;
+    }
+    gbeta[c] = (float)g1;
+    ggamma[c] = (float)g2;
+}
+
+__global__ void bn_bwd_apply(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
+                             const float* __restrict__ invstd, const float* __restrict__ a, const float* __restrict__ b,
+                             const float* __restrict__ coef, float* __restrict__ gx, int P, int Bp, int C, int L) {
+    const int64_t rows = (int64_t)P * Bp * C;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int c = (int)(row % C);
+        const int p = (int)(row / ((int64_t)Bp * C));
+        const int pc = p * C + c;
+        const float mf = mean[pc], is = invstd[pc], af = a[pc], bf = b[pc];
+        const float k1 = coef[pc * 2], k2 = coef[pc * 2 + 1];
+        const float* xr = x + row * L;
+        const float* gr = gy + row * L;
+        float* gxr = gx + row * L;
+        for (int t = lane; t < L; t += 64) {
+            const float xv = xr[t];
+            const float g = fmaf(xv, af, bf) > 0.f ? gr[t] : 0.f;
+            gxr[t] = af * (g - k1 - (xv - mf) * is * k2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conv1d(C->1, k3, p1, bias) + sigmoid(x/3)                               (:106, :168)
+// ------------------------------------------------------------------------------------------------
+constexpr int OC_MAXC = 64;
+
+__global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          int N, int C, int L, int tiles) {
+    __shared__ float wl[OC_MAXC * 3];
+    for (int i = threadIdx.x; i < C * 3; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int n = blockIdx.x / tiles;
+    const int t = (blockIdx.x % tiles) * 256 + threadIdx.x;
+    if (t >= L) return;
+    const float* xs = x + (int64_t)n * C * L + t;
+    float acc = 0.f;
+    const bool hl = t > 0, hr = t < L - 1;
+    for (int c = 0; c < C; ++c) {
+        const float* r = xs + (int64_t)c * L;
+        const float xm = hl ? r[-1] : 0.f;
+        const float x0 = r[0];
+        const float xp = hr ? r[1] : 0.f;
+        acc = fmaf(wl[c * 3], xm, acc);
+        acc = fmaf(wl[c * 3 + 1], x0, acc);
+        acc = fmaf(wl[c * 3 + 2], xp, acc);
+    }
+    acc += bias[0];
+    const float z = acc / 3.0f;
+    out[(int64_t)n * L + t] = 1.0f / (1.0f + expf(-z));
+}
+
+// go = gout * out * (1 - out) / 3 ; gx[n][c][t] = sum_k w[c][k] * go[n][t - k + 1]
+__global__ __launch_bounds__(256) void outconv_bwd_data_kernel(const float* __restrict__ gout,
+                                                               const float* __restrict__ out,
+                                                               const float* __restrict__ w, float* __restrict__ gx,
+                                                               int N, int C, int L, int tiles) {
+    __shared__ float wl[OC_MAXC * 3];
+    for (int i = threadIdx.x; i < C * 3; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int n = blockIdx.x / tiles;
+    const int t = (blockIdx.x % tiles) * 256 + threadIdx.x;
+    if (t >= L) return;
+    const int64_t base = (int64_t)n * L;
+    auto go_at = [&](int tt) -> float {
+        if (tt < 0 || tt >= L) return 0.f;
+        const float o = out[base + tt];
+        return gout[base + tt] * (o * (1.f - o)) / 3.0f;
+    };
+    const float gm = go_at(t - 1), g0 = go_at(t), gp = go_at(t + 1);
+    float* dst = gx + (int64_t)n * C * L + t;
+    for (int c = 0; c < C; ++c)
+        dst[(int64_t)c * L] = wl[c * 3] * gp + wl[c * 3 + 1] * g0 + wl[c * 3 + 2] * gm;
+}
+
+// gw[c][k] = sum_{n,t} go[n][t] * x[n][c][t+k-1] ; gb = sum go.   grid: (C+1) x OC_SPLIT, partials in double
+constexpr int OC_SPLIT = 16;
+__global__ __launch_bounds__(256) void outconv_bwd_weight_partial(const float* __restrict__ gout,
+                                                                  const float* __restrict__ out,
+                                                                  const float* __restrict__ x, double* __restrict__ part,
+                                                                  int N, int C, int L) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x % (C + 1);     // c == C : bias
+    const int sp = blockIdx.x / (C + 1);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int n = sp; n < N; n += OC_SPLIT) {
+        const int64_t base = (int64_t)n * L;
+        const float* xr = x + ((int64_t)n * C + (c < C ? c : 0)) * L;
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        for (int t = threadIdx.x; t < L; t += 256) {
+            const float o = out[base + t];
+            const float go = gout[base + t] * (o * (1.f - o)) / 3.0f;
+            if (c < C) {
+                if (t > 0) r0 = fmaf(go, xr[t - 1], r0);
+                r1 = fmaf(go, xr[t], r1);
+                if (t < L - 1) r2 = fmaf(go, xr[t + 1], r2);
+            } else {
+                r1 += go;
+            }
+        }
+        a0 += (double)r0;
+        a1 += (double)r1;
+        a2 += (double)r2;
+    }
+    a0 = nef_block_sum_d(a0, sm);
+    a1 = nef_block_sum_d(a1, sm);
+    a2 = nef_block_sum_d(a2, sm);
+    if (threadIdx.x == 0) {
+        double* d = part + ((int64_t)sp * (C + 1) + c) * 3;
+        d[0] = a0; d[1] = a1; d[2] = a2;
+    }
+}
+
+__global__ void outconv_bwd_weight_final(const double* __restrict__ part, float* __restrict__ gw,
+                                         float* __restrict__ gb, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (C + 1) * 3) return;
+    double s = 0.0;
+    for (int sp = 0; sp < OC_SPLIT; ++sp) s += part[(int64_t)sp * (C + 1) * 3 + i];
+    const int c = i / 3, k = i % 3;
+    if (c < C) gw[c * 3 + k] = (float)s;
+    else if (k == 1) gb[0] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// losswrapper                                                    (codes/network/loss/losses.py:21-50)
+// ------------------------------------------------------------------------------------------------
+constexpr int LOSS_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void loss_partial(const float* __restrict__ pred, const float* __restrict__ pp,
+                                                    const float* __restrict__ pl, const float* __restrict__ tgt,
+                                                    double* __restrict__ part, int64_t n, int reg_l2) {
+    __shared__ double sm[4];
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float o = pred[i];
+        s1 += (double)fabsf(o - pp[i]);
+        s2 += (double)fabsf(o - pl[i]);
+        const float d = o - tgt[i];
+        s3 += (double)(reg_l2 ? d * d : fabsf(d));
+    }
+    s1 = nef_block_sum_d(s1, sm);
+    s2 = nef_block_sum_d(s2, sm);
+    s3 = nef_block_sum_d(s3, sm);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 3] = s1;
+        part[blockIdx.x * 3 + 1] = s2;
+        part[blockIdx.x * 3 + 2] = s3;
+    }
+}
+
+__global__ void loss_final(const double* __restrict__ part, float* __restrict__ losses, int nblk, int64_t n, float f0,
+                           float f1, float f2, int use_mask) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int i = 0; i < nblk; ++i) {
+        s1 += part[i * 3];
+        s2 += part[i * 3 + 1];
+        s3 += part[i * 3 + 2];
+    }
+    const float l1 = (use_mask & 1) ? (float)(s1 / (double)n) : 0.f;
+    const float l2 = (use_mask & 2) ? (float)(s2 / (double)n) : 0.f;
+    const float l3 = (use_mask & 4) ? (float)(s3 / (double)n) : 0.f;
+    const float t1 = l1 * f0, t2 = l2 * f1, t3 = l3 * f2;
+    losses[0] = t1 + t2 + t3;
+    losses[1] = t1;
+    losses[2] = t2;
+    losses[3] = t3;
+}
+
+__device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ void loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ pp,
+                                const float* __restrict__ pl, const float* __restrict__ tgt,
+                                const float* __restrict__ gscale, float* __restrict__ g_pred, float* __restrict__ g_p,
+                                float* __restrict__ g_l, int64_t n, float f0, float f1, float f2, int reg_l2,
+                                int use_mask) {
+    const float gs = gscale ? gscale[0] : 1.f;
+    const float inv_n = 1.0f / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float o = pred[i];
+        // d|sg(o) - p| / dp = sign(p - o)
+        g_p[i] = (use_mask & 1) ? gs * f0 * inv_n * sgnf(pp[i] - o) : 0.f;
+        g_l[i] = (use_mask & 2) ? gs * f1 * inv_n * sgnf(pl[i] - o) : 0.f;
+        const float d = o - tgt[i];
+        const float g3 = reg_l2 ? 2.f * d : sgnf(d);
+        g_pred[i] = (use_mask & 4) ? gs * f2 * inv_n * g3 : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// torch.optim.SGD(momentum)                                 (codes/solver/optim_scheduler.py:10)
+// ------------------------------------------------------------------------------------------------
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, int64_t n,
+                           float lr, float mu, float gscale, int first) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gv = g[i] * gscale;
+        const float bv = first ? gv : fmaf(mu, buf[i], gv);
+        buf[i] = bv;
+        p[i] = p[i] - lr * bv;
+    }
+}
+
+}  // namespace
+
+#define NEF_ST ((hipStream_t)stream)
+
+extern "C" {
+
+int nef_chscale_fwd(const float* x, const float* s, int64_t s_bs, float* y, int B, int C, int T, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && s && y, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(chscale_fwd_kernel, dim3(nef_stream_grid((int64_t)B * C, 4)), dim3(256), 0, NEF_ST, x, s, s_bs,
+                       y, B, C, T);
+    return nef_launch_status();
+}
+
+int nef_chscale_bwd(const float* gy, const float* x, const float* s, int64_t s_bs, float* gx, float* gs, int B, int C,
+                    int T, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gy && x && s && gx && gs, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(chscale_bwd_kernel, dim3(nef_stream_grid((int64_t)B * C, 4)), dim3(256), 0, NEF_ST, gy, x, s,
+                       s_bs, gx, gs, B, C, T);
+    return nef_launch_status();
+}
+
+int nef_gate(const float* g, const float* ref, float* out, float scale, int64_t n, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(g && ref && out, NEF_E_NULL);
+    NEF_REQUIRE(n > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(gate_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, g, ref, out, scale, n);
+    return nef_launch_status();
+}
+
+int nef_add(const float* a, const float* b, float* out, int64_t n, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(a && b && out, NEF_E_NULL);
+    NEF_REQUIRE(n > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(add_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, a, b, out, n);
+    return nef_launch_status();
+}
+
+int nef_lead_mean(const float* z1, const float* z2r, float* latent, int B, int V, int T, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(z1 && z2r && latent, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && V > 0 && T > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(lead_mean_kernel, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, z1, z2r,
+                       latent, B, V, T);
+    return nef_launch_status();
+}
+
+int nef_mix_fwd(const float* latent, const float* z1, const float* z2r, const float* q, float* D, int B, int V, int T,
+                int c1, int c2, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(latent && z1 && z2r && q && D, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && V > 0 && T > 0 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
+    hipLaunchKernelGGL(mix_fwd_kernel, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, latent, z1,
+                       z2r, q, D, B, V, T, c1, c2);
+    return nef_launch_status();
+}
+
+int nef_mix_bwd(const float* gD, const float* latent, const float* z1, const float* z2r, const float* q, float* gz1,
+                float* gz2r, float* gq, int B, int V, int T, int c1, int c2, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gD && latent && z1 && z2r && q && gz1 && gz2r && gq, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && V > 0 && T > 0 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
+    hipLaunchKernelGGL(mix_bwd_kernel, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gD, latent, z1,
+                       z2r, q, gz1, gz2r, gq, B, V, T, c1, c2);
+    return nef_launch_status();
+}
+
+int nef_upsample2_fwd(const float* x, float* y, int64_t N, int Tin, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && y, NEF_E_NULL);
+    NEF_REQUIRE(N > 0 && Tin > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(upsample2_fwd_kernel, dim3(nef_stream_grid(N, 4)), dim3(256), 0, NEF_ST, x, y, N, Tin);
+    return nef_launch_status();
+}
+
+int nef_upsample2_bwd(const float* gy, float* gx, int64_t N, int Tin, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gy && gx, NEF_E_NULL);
+    NEF_REQUIRE(N > 0 && Tin > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(nef_stream_grid(N, 4)), dim3(256), 0, NEF_ST, gy, gx, N, Tin);
+    return nef_launch_status();
+}
+
+size_t nef_bn_ws_bytes(int P, int C) {
+    return (size_t)P * C * BN_SPLIT * 2 * sizeof(double) + (size_t)P * C * 2 * sizeof(float);
+}
+
+int nef_bn_train_stats(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       float* mean, float* invstd, float* a, float* b, void* ws, size_t ws_bytes, int P, int Bp, int C,
+                       int L, float eps, float momentum, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && gamma && beta && mean && invstd && a && b && ws, NEF_E_NULL);
+    NEF_REQUIRE(P > 0 && Bp > 0 && C > 0 && L > 0 && (int64_t)Bp * L > 1, NEF_E_SHAPE);
+    NEF_REQUIRE(ws_bytes >= nef_bn_ws_bytes(P, C), NEF_E_WORKSPACE);
+    hipLaunchKernelGGL(bn_stats_partial, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, x, (double*)ws, P, Bp, C, L);
+    hipLaunchKernelGGL(bn_stats_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)ws, gamma, beta,
+                       running_mean, running_var, mean, invstd, a, b, P, Bp, C, L, eps, momentum);
+    return nef_launch_status();
+}
+
+int nef_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float* a, float* b, int C, float eps, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gamma && beta && running_mean && running_var && a && b, NEF_E_NULL);
+    NEF_REQUIRE(C > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, gamma, beta, running_mean,
+                       running_var, a, b, C, eps);
+    return nef_launch_status();
+}
+
+int nef_affine_relu_fwd(const float* x, const float* a, const float* b, float* y, int P, int Bp, int C, int L,
+                        nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && a && b && y, NEF_E_NULL);
+    NEF_REQUIRE(P > 0 && Bp > 0 && C > 0 && L > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(affine_relu_fwd_kernel, dim3(nef_stream_grid((int64_t)P * Bp * C, 4)), dim3(256), 0, NEF_ST, x,
+                       a, b, y, P, Bp, C, L);
+    return nef_launch_status();
+}
+
+int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* invstd,
+                    const float* a, const float* b, float* gx, float* ggamma, float* gbeta, void* ws, size_t ws_bytes,
+                    int P, int Bp, int C, int L, nef_stream_t stream) {
+    NEF_ENTER();
+    (void)gamma;
+    NEF_REQUIRE(gy && x && mean && invstd && a && b && gx && ggamma && gbeta && ws, NEF_E_NULL);
+    NEF_REQUIRE(P > 0 && Bp > 0 && C > 0 && L > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(ws_bytes >= nef_bn_ws_bytes(P, C), NEF_E_WORKSPACE);
+    double* part = (double*)ws;
+    float* coef = (float*)((char*)ws + (size_t)P * C * BN_SPLIT * 2 * sizeof(double));
+    hipLaunchKernelGGL(bn_bwd_partial, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part, P,
+                       Bp, C, L);
+    hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma, gbeta,
+                       P, Bp, C, L);
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(nef_stream_grid((int64_t)P * Bp * C, 4)), dim3(256), 0, NEF_ST, gy, x, mean,
+                       invstd, a, b, (const float*)coef, gx, P, Bp, C, L);
+    return nef_launch_status();
+}
+
+int nef_outconv_fwd(const float* x, const float* w, const float* bias, float* out, int N, int C, int L,
+                    nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && w && bias && out, NEF_E_NULL);
+    NEF_REQUIRE(N > 0 && C > 0 && C <= OC_MAXC && L > 0, NEF_E_SHAPE);
+    const int tiles = (L + 255) / 256;
+    hipLaunchKernelGGL(outconv_fwd_kernel, dim3((unsigned)((int64_t)N * tiles)), dim3(256), 0, NEF_ST, x, w, bias, out,
+                       N, C, L, tiles);
+    return nef_launch_status();
+}
+
+int nef_outconv_bwd_data(const float* gout, const float* out, const float* w, float* gx, int N, int C, int L,
+                         nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gout && out && w && gx, NEF_E_NULL);
+    NEF_REQUIRE(N > 0 && C > 0 && C <= OC_MAXC && L > 0, NEF_E_SHAPE);
+    const int tiles = (L + 255) / 256;
+    hipLaunchKernelGGL(outconv_bwd_data_kernel, dim3((unsigned)((int64_t)N * tiles)), dim3(256), 0, NEF_ST, gout, out,
+                       w, gx, N, C, L, tiles);
+    return nef_launch_status();
+}
+
+size_t nef_outconv_bwd_weight_ws_bytes(int C) { return (size_t)OC_SPLIT * (C + 1) * 3 * sizeof(double); }
+
+int nef_outconv_bwd_weight(const float* gout, const float* out, const float* x, float* gw, float* gb, void* ws,
+                           size_t ws_bytes, int N, int C, int L, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gout && out && x && gw && gb && ws, NEF_E_NULL);
+    NEF_REQUIRE(N > 0 && C > 0 && C <= OC_MAXC && L > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(ws_bytes >= nef_outconv_bwd_weight_ws_bytes(C), NEF_E_WORKSPACE);
+    hipLaunchKernelGGL(outconv_bwd_weight_partial, dim3((C + 1) * OC_SPLIT), dim3(256), 0, NEF_ST, gout, out, x,
+                       (double*)ws, N, C, L);
+    hipLaunchKernelGGL(outconv_bwd_weight_final, dim3(((C + 1) * 3 + 63) / 64), dim3(64), 0, NEF_ST, (const double*)ws,
+                       gw, gb, C);
+    return nef_launch_status();
+}
+
+size_t nef_loss_ws_bytes(void) { return (size_t)LOSS_BLOCKS * 3 * sizeof(double); }
+
+int nef_loss_fwd(const float* pred, const float* pred_p, const float* pred_l, const float* target, float* losses,
+                 void* ws, size_t ws_bytes, int64_t n, float f0, float f1, float f2, int reg_l2, int use_mask,
+                 nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(pred && pred_p && pred_l && target && losses && ws, NEF_E_NULL);
+    NEF_REQUIRE(n > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(ws_bytes >= nef_loss_ws_bytes(), NEF_E_WORKSPACE);
+    hipLaunchKernelGGL(loss_partial, dim3(LOSS_BLOCKS), dim3(256), 0, NEF_ST, pred, pred_p, pred_l, target, (double*)ws,
+                       n, reg_l2);
+    hipLaunchKernelGGL(loss_final, dim3(1), dim3(64), 0, NEF_ST, (const double*)ws, losses, LOSS_BLOCKS, n, f0, f1, f2,
+                       use_mask);
+    return nef_launch_status();
+}
+
+int nef_loss_bwd(const float* pred, const float* pred_p, const float* pred_l, const float* target, const float* gscale,
+                 float* g_pred, float* g_p, float* g_l, int64_t n, float f0, float f1, float f2, int reg_l2,
+                 int use_mask, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(pred && pred_p && pred_l && target && g_pred && g_p && g_l, NEF_E_NULL);
+    NEF_REQUIRE(n > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, pred, pred_p, pred_l,
+                       target, gscale, g_pred, g_p, g_l, n, f0, f1, f2, reg_l2, use_mask);
+    return nef_launch_status();
+}
+
+int nef_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float gscale, int first_step,
+                     nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(p && g && buf, NEF_E_NULL);
+    NEF_REQUIRE(n > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(sgd_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, p, g, buf, n, lr, mu, gscale,
+                       first_step);
+    return nef_launch_status();
+}
+
+}  // extern "C"

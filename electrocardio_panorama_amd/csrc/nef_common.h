@@ -1,0 +1,63 @@
+// Shared helpers for the gfx950 kernels of libnefnet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nefnet_hip.h"
+
+#define NEF_WAVE 64
+
+#define NEF_REQUIRE(cond, code) \
+    do {                        \
+        if (!(cond)) return (code); \
+    } while (0)
+
+// hipGetLastError() is sticky across the process: drop whatever an earlier (foreign) call left behind so that the
+// status returned by an entry point reflects only its own launches.
+#define NEF_ENTER() (void)hipGetLastError()
+
+static inline int nef_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? NEF_OK : (int)e;
+}
+
+static inline int64_t nef_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grid for an HBM-bound elementwise pass: enough blocks to fill 256 CUs, grid-stride beyond.
+static inline int nef_stream_grid(int64_t work_items, int block) {
+    int64_t g = nef_cdiv(work_items, block);
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__device__ __forceinline__ float nef_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double nef_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves).  `sm` must hold >= 4 doubles.  All threads get the result.
+__device__ __forceinline__ double nef_block_sum_d(double v, double* sm) {
+    v = nef_wave_sum_d(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// Counter-based keep decision for in-kernel dropout: uniform in [0,1) from (seed, dense element index).
+__device__ __forceinline__ float nef_rng_uniform(uint64_t seed, uint64_t idx) {
+    uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}

@@ -1,0 +1,271 @@
+// Heartbeat-segment ROI ops on the latent time axis.
+//   roi_align : reference codes/network/utils/roi_pooling_1d.py:38-69 (`roi_algin`).  The reference feeds
+//               F.grid_sample a [B,C,T,1] image and a grid whose x component carries the ROI positions, so x
+//               addresses the size-1 axis and y = 0 addresses the middle of time.  This kernel
+//               evaluates exactly that bilinear sample with zero padding, align_corners=False.
+//   roi_unpool: roi_pooling_1d.py:72-99 (`roi_pooling_reverse`): per (sample, segment) linear resampling
+//               32 -> len_j (align_corners=False) concatenated along time.  Integer bookkeeping (:82-92) is
+//               (long)(float(roi) * 0.25f), bit-exact with the reference.
+// rois stay int64 on the device; no host loop, no per-segment launches.
+#include "nef_common.h"
+
+namespace {
+
+constexpr int NSEG = NEF_N_SEG;
+constexpr int BINS = NEF_ROI_BINS;
+constexpr int SEGW = 2 * NEF_ROI_BINS;   // 32 samples per decoded segment
+
+__device__ __forceinline__ int64_t latent_index(int64_t roi) {
+    return (int64_t)((float)roi * 0.25f);   // rois.float().mul_(0.25).long()  (:82-85)
+}
+
+// grid x for (segment j, bin s): torch.linspace(r0, r1, 16) on fp32, r = roi*0.25*(2/T) - 1   (:50-58)
+__device__ __forceinline__ float grid_x(const int64_t* __restrict__ roi_b, int j, int s, int T) {
+    const float sc = (float)(2.0 / (double)T);
+    const float r0 = ((float)roi_b[2 * j] * 0.25f) * sc + (-1.0f);
+    const float r1 = ((float)roi_b[2 * j + 1] * 0.25f) * sc + (-1.0f);
+    const float step = (r1 - r0) / (float)(BINS - 1);
+    return s < BINS / 2 ? r0 + step * (float)s : r1 - step * (float)(BINS - 1 - s);
+}
+
+// bilinear weight of the single column (W == 1) for normalised x, zero padding
+__device__ __forceinline__ float col_weight(float gx) {
+    const float ix = ((gx + 1.f) * 1.f - 1.f) * 0.5f;
+    const float x0 = floorf(ix);
+    const float we = ix - x0;          // weight of column x0+1
+    const float ww = 1.f - we;         // weight of column x0
+    float w = 0.f;
+    if (x0 == 0.f) w += ww;
+    if (x0 + 1.f == 0.f) w += we;
+    return w;
+}
+
+struct RowTap { int r0, r1; float w0, w1; };
+
+__device__ __forceinline__ RowTap row_taps(int T) {
+    const float iy = ((0.f + 1.f) * (float)T - 1.f) * 0.5f;
+    const float y0 = floorf(iy);
+    RowTap rt;
+    rt.r0 = (int)y0;
+    rt.r1 = rt.r0 + 1;
+    rt.w1 = iy - y0;
+    rt.w0 = 1.f - rt.w1;
+    if (rt.r0 < 0 || rt.r0 >= T) rt.w0 = 0.f;
+    if (rt.r1 < 0 || rt.r1 >= T) { rt.w1 = 0.f; rt.r1 = rt.r0; }
+    if (rt.r0 < 0 || rt.r0 >= T) rt.r0 = rt.r1;
+    return rt;
+}
+
+// one thread per output element; out [B][C][7][16]
+__global__ void roi_align_fwd_kernel(const float* __restrict__ z, const int64_t* __restrict__ rois,
+                                     float* __restrict__ out, int B, int C, int T) {
+    const int64_t n = (int64_t)B * C * NSEG * BINS;
+    const RowTap rt = row_taps(T);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i % BINS);
+        const int j = (int)((i / BINS) % NSEG);
+        const int64_t bc = i / (BINS * NSEG);
+        const int b = (int)(bc / C);
+        const float wx = col_weight(grid_x(rois + (int64_t)b * NSEG * 2, j, s, T));
+        const float* zr = z + bc * T;
+        // grid_sample accumulates nw*(n*w) + ne*.. + sw*(s*w) + se*..; with W == 1 only one column is in range
+        out[i] = zr[rt.r0] * (rt.w0 * wx) + zr[rt.r1] * (rt.w1 * wx);
+    }
+}
+
+// gz [B][C][T]: zero except the two middle rows
+__global__ void roi_align_bwd_kernel(const float* __restrict__ gout, const int64_t* __restrict__ rois,
+                                     float* __restrict__ gz, int B, int C, int T) {
+    const int64_t rows = (int64_t)B * C;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const RowTap rt = row_taps(T);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int b = (int)(row / C);
+        float acc = 0.f;
+        for (int e = lane; e < NSEG * BINS; e += 64) {
+            const int j = e / BINS, s = e % BINS;
+            const float wx = col_weight(grid_x(rois + (int64_t)b * NSEG * 2, j, s, T));
+            acc = fmaf(gout[row * NSEG * BINS + e], wx, acc);
+        }
+        acc = nef_wave_sum(acc);
+        float* gr = gz + row * T;
+        for (int t = lane; t < T; t += 64) {
+            float v = 0.f;
+            if (t == rt.r0) v += acc * rt.w0;
+            if (t == rt.r1 && rt.w1 != 0.f) v += acc * rt.w1;
+            gr[t] = v;
+        }
+    }
+}
+
+struct SegTable { int start[NSEG]; int len[NSEG]; int off[NSEG]; };
+
+__device__ __forceinline__ bool load_segments(const int64_t* __restrict__ roi_b, int T, SegTable& st) {
+    int run = 0;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NSEG; ++j) {
+        const int64_t a = latent_index(roi_b[2 * j]);
+        const int64_t e = latent_index(roi_b[2 * j + 1]);
+        int64_t len = e - a;
+        if (len < 0) { ok = false; len = 0; }
+        if (run + len > T) { ok = false; len = T - run; }
+        st.start[j] = (int)a;
+        st.len[j] = (int)len;
+        st.off[j] = run;
+        run += (int)len;
+    }
+    if (run != T) ok = false;
+    return ok;
+}
+
+// F.interpolate(mode='linear', align_corners=False) source index for output i of a len-long segment
+__device__ __forceinline__ void lerp_src(int i, int len, int& i0, int& i1, float& l0, float& l1) {
+    const float scale = (float)SEGW / (float)len;
+    float src = scale * ((float)i + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > SEGW - 1) i0 = SEGW - 1;
+    i1 = i0 + (i0 < SEGW - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    if (l1 < 0.f) l1 = 0.f;
+    if (l1 > 1.f) l1 = 1.f;
+    l0 = 1.f - l1;
+}
+
+// one wave per (b, c) row of the output; zseg [B][C][7][32] -> out [B][C][T]
+__global__ void roi_unpool_fwd_kernel(const float* __restrict__ zseg, const int64_t* __restrict__ rois,
+                                      float* __restrict__ out, int32_t* __restrict__ status, int B, int C, int T) {
+    const int64_t rows = (int64_t)B * C;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int b = (int)(row / C);
+        SegTable st;
+        const bool ok = load_segments(rois + (int64_t)b * NSEG * 2, T, st);
+        if (!ok && status && lane == 0) status[0] = 1;
+        const float* zr = zseg + row * NSEG * SEGW;
+        float* orow = out + row * T;
+        for (int t = lane; t < T; t += 64) {
+            // the last segment whose offset is <= t (zero-length segments share an offset and are skipped)
+            int j = 0, off_j = st.off[0], len_j = st.len[0];
+#pragma unroll
+            for (int k = 1; k < NSEG; ++k)
+                if (t >= st.off[k]) { j = k; off_j = st.off[k]; len_j = st.len[k]; }
+            float v = 0.f;
+            const int i = t - off_j;
+            if (i < len_j) {
+                int i0, i1;
+                float l0, l1;
+                lerp_src(i, len_j, i0, i1, l0, l1);
+                v = l0 * zr[j * SEGW + i0] + l1 * zr[j * SEGW + i1];
+            }
+            orow[t] = v;
+        }
+    }
+}
+
+// gather form of the transpose: lane s of segment j collects the outputs that read sample s
+__global__ void roi_unpool_bwd_kernel(const float* __restrict__ gout, const int64_t* __restrict__ rois,
+                                      float* __restrict__ gzseg, int B, int C, int T) {
+    const int64_t rows = (int64_t)B * C;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int b = (int)(row / C);
+        SegTable st;
+        load_segments(rois + (int64_t)b * NSEG * 2, T, st);
+        const float* gr = gout + row * T;
+        float* gz = gzseg + row * NSEG * SEGW;
+        for (int e = lane; e < NSEG * SEGW; e += 64) {
+            const int j = e / SEGW, s = e % SEGW;
+            int len = st.len[0], off_j = st.off[0];
+#pragma unroll
+            for (int k = 1; k < NSEG; ++k)
+                if (j == k) { len = st.len[k]; off_j = st.off[k]; }
+            float acc = 0.f;
+            if (len > 0) {
+                // outputs whose source lies in (s-1, s+1): i in ((s-.5)len/32 - .5, (s+1.5)len/32 - .5), widened by 2
+                const float r = (float)len / (float)SEGW;
+                int lo = (int)floorf(((float)s - 0.5f) * r - 0.5f) - 2;
+                int hi = (int)ceilf(((float)s + 1.5f) * r - 0.5f) + 2;
+                if (lo < 0) lo = 0;
+                if (hi > len - 1) hi = len - 1;
+                if (s == 0) lo = 0;
+                for (int i = lo; i <= hi; ++i) {
+                    int i0, i1;
+                    float l0, l1;
+                    lerp_src(i, len, i0, i1, l0, l1);
+                    const float g = gr[off_j + i];
+                    if (i0 == s) acc += l0 * g;
+                    if (i1 == s) acc += l1 * g;
+                }
+            }
+            gz[e] = acc;
+        }
+    }
+}
+
+__global__ void roi_segment_table_kernel(const int64_t* __restrict__ rois, int64_t* __restrict__ seg_start,
+                                         int64_t* __restrict__ seg_len, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t a = latent_index(rois[2 * i]);
+    const int64_t e = latent_index(rois[2 * i + 1]);
+    seg_start[i] = a;
+    seg_len[i] = e - a;
+}
+
+}  // namespace
+
+#define NEF_ST ((hipStream_t)stream)
+
+extern "C" {
+
+int nef_roi_align_fwd(const float* z, const int64_t* rois, float* out, int B, int C, int T, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(z && rois && out, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
+    const int64_t n = (int64_t)B * C * NSEG * BINS;
+    hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, z, rois, out, B, C, T);
+    return nef_launch_status();
+}
+
+int nef_roi_align_bwd(const float* gout, const int64_t* rois, float* gz, int B, int C, int T, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gout && rois && gz, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(nef_stream_grid((int64_t)B * C, 4)), dim3(256), 0, NEF_ST, gout, rois,
+                       gz, B, C, T);
+    return nef_launch_status();
+}
+
+int nef_roi_unpool_fwd(const float* zseg, const int64_t* rois, float* out, int32_t* status, int B, int C, int T,
+                       nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(zseg && rois && out, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(roi_unpool_fwd_kernel, dim3(nef_stream_grid((int64_t)B * C, 4)), dim3(256), 0, NEF_ST, zseg,
+                       rois, out, status, B, C, T);
+    return nef_launch_status();
+}
+
+int nef_roi_unpool_bwd(const float* gout, const int64_t* rois, float* gzseg, int B, int C, int T,
+                       nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gout && rois && gzseg, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(roi_unpool_bwd_kernel, dim3(nef_stream_grid((int64_t)B * C, 4)), dim3(256), 0, NEF_ST, gout,
+                       rois, gzseg, B, C, T);
+    return nef_launch_status();
+}
+
+int nef_roi_segment_table(const int64_t* rois, int64_t* seg_start, int64_t* seg_len, int B, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(rois && seg_start && seg_len, NEF_E_NULL);
+    NEF_REQUIRE(B > 0, NEF_E_SHAPE);
+    const int n = B * NSEG;
+    hipLaunchKernelGGL(roi_segment_table_kernel, dim3((n + 255) / 256), dim3(256), 0, NEF_ST, rois, seg_start, seg_len,
+                       n);
+    return nef_launch_status();
+}
+
+}  // extern "C"

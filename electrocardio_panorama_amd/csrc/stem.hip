@@ -1,0 +1,185 @@
+// Stem of the per-lead encoder, fused: Conv1d(1->128 per lead, k15, s2, p7, no bias) -> ReLU -> MaxPool1d(3,2,1).
+// Replaces reference codes/network/encoder/encoder.py:35-38 (conv1/relu/maxpool built at
+// codes/network/encoder/resnet_1d.py:102-105).  HBM-bound (AI ~7 FLOP/B): the [B,128V,L/2] conv output is never
+// materialised; the backward recomputes it from the 19-sample input window each lane already holds.
+#include "nef_common.h"
+
+namespace {
+
+constexpr int KW = 15;        // taps
+constexpr int TP = 64;        // pooled outputs per workgroup row (one per lane)
+constexpr int CPL = 128;      // channels per lead
+
+// Conv output j (length L/2) reads x[2j-7 .. 2j+7]; pooled output tp covers j in {2tp-1, 2tp, 2tp+1}.
+// So lane tp needs x[4tp-9 .. 4tp+9]  (19 samples), kept in registers.
+__device__ __forceinline__ void load_window(const float* __restrict__ xrow, int L, int tp, float (&xw)[19]) {
+    const int base = 4 * tp - 9;
+#pragma unroll
+    for (int i = 0; i < 19; ++i) {
+        const int p = base + i;
+        xw[i] = (p >= 0 && p < L) ? xrow[p] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       float* __restrict__ y, int B, int V, int L, int T,
+                                                       int tiles_per_row) {
+    __shared__ float wl[CPL * 16];   // [co][16] (15 taps + pad) for 16-byte broadcast reads
+    int bid = blockIdx.x;
+    const int tile = bid % tiles_per_row;
+    bid /= tiles_per_row;
+    const int v = bid % V;
+    const int b = bid / V;
+    for (int i = threadIdx.x; i < CPL * 16; i += 256) {
+        const int co = i >> 4, k = i & 15;
+        wl[i] = k < KW ? w[(v * CPL + co) * KW + k] : 0.f;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tp = tile * TP + lane;
+    float xw[19];
+    load_window(x + ((int64_t)b * V + v) * L, L, tp, xw);
+    __syncthreads();
+    if (tp >= T) return;
+    const int Lc = L / 2;
+    const bool has_l = (2 * tp - 1) >= 0;        // pool padding: window positions outside [0, Lc) are -inf
+    const bool has_r = (2 * tp + 1) < Lc;
+    float* yrow = y + ((int64_t)b * V * CPL + (int64_t)v * CPL) * T + tp;
+    for (int co = wave; co < CPL; co += 4) {
+        const float4* w4 = reinterpret_cast<const float4*>(wl + co * 16);
+        float wk[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t4 = w4[q];
+            wk[4 * q] = t4.x; wk[4 * q + 1] = t4.y; wk[4 * q + 2] = t4.z; wk[4 * q + 3] = t4.w;
+        }
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            c0 = fmaf(wk[k], xw[k], c0);        // j = 2tp-1 : x[4tp-9+k]
+            c1 = fmaf(wk[k], xw[k + 2], c1);    // j = 2tp   : x[4tp-7+k]
+            c2 = fmaf(wk[k], xw[k + 4], c2);    // j = 2tp+1 : x[4tp-5+k]
+        }
+        float m = fmaxf(c1, 0.f);
+        if (has_l) m = fmaxf(m, fmaxf(c0, 0.f));
+        if (has_r) m = fmaxf(m, fmaxf(c2, 0.f));
+        yrow[(int64_t)co * T] = m;
+    }
+}
+
+// Backward wrt the conv weight.  A workgroup owns 16 channels of one lead (4 per wave) and a strided share of the
+// (sample, time-tile) space; each lane keeps 4x15 partial sums, reduced across the wave once at the end.
+constexpr int BW_CPW = 4;                  // channels per wave
+constexpr int BW_CPB = 4 * BW_CPW;         // channels per workgroup
+constexpr int BW_SPLIT = 32;
+
+__global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ gy, float* __restrict__ part,
+                                                              int B, int V, int L, int T, int tiles_per_row) {
+    int bid = blockIdx.x;
+    const int cg = bid % (CPL / BW_CPB);
+    bid /= (CPL / BW_CPB);
+    const int v = bid % V;
+    const int split = bid / V;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ch0 = v * CPL + cg * BW_CPB + wave * BW_CPW;
+    float wk[BW_CPW][KW];
+#pragma unroll
+    for (int c = 0; c < BW_CPW; ++c)
+#pragma unroll
+        for (int k = 0; k < KW; ++k) wk[c][k] = w[(ch0 + c) * KW + k];
+    float acc[BW_CPW][KW];
+#pragma unroll
+    for (int c = 0; c < BW_CPW; ++c)
+#pragma unroll
+        for (int k = 0; k < KW; ++k) acc[c][k] = 0.f;
+    const int Lc = L / 2;
+    const int n_units = B * tiles_per_row;
+    for (int unit = split; unit < n_units; unit += BW_SPLIT) {
+        const int b = unit / tiles_per_row;
+        const int tp = (unit - b * tiles_per_row) * TP + lane;
+        float xw[19];
+        load_window(x + ((int64_t)b * V + v) * L, L, tp, xw);
+        if (tp >= T) continue;
+        const bool has_l = (2 * tp - 1) >= 0;
+        const bool has_r = (2 * tp + 1) < Lc;
+#pragma unroll
+        for (int c = 0; c < BW_CPW; ++c) {
+            const float g = gy[((int64_t)b * V * CPL + ch0 + c) * T + tp];
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                c0 = fmaf(wk[c][k], xw[k], c0);
+                c1 = fmaf(wk[c][k], xw[k + 2], c1);
+                c2 = fmaf(wk[c][k], xw[k + 4], c2);
+            }
+            // arg-max over the pool window in scan order (first maximum wins), then the ReLU gate
+            float best = has_l ? fmaxf(c0, 0.f) : -INFINITY;
+            float pre = c0;
+            int sel = 0;
+            {
+                const float r1 = fmaxf(c1, 0.f);
+                if (r1 > best) { best = r1; sel = 1; pre = c1; }
+            }
+            if (has_r) {
+                const float r2 = fmaxf(c2, 0.f);
+                if (r2 > best) { best = r2; sel = 2; pre = c2; }
+            }
+            const float ge = pre > 0.f ? g : 0.f;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const float xv = sel == 0 ? xw[k] : (sel == 1 ? xw[k + 2] : xw[k + 4]);
+                acc[c][k] = fmaf(ge, xv, acc[c][k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < BW_CPW; ++c)
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const float s = nef_wave_sum(acc[c][k]);
+            if (lane == 0) part[((int64_t)split * V * CPL + ch0 + c) * KW + k] = s;
+        }
+}
+
+__global__ void stem_bwd_weight_reduce(const float* __restrict__ part, float* __restrict__ gw, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int sp = 0; sp < BW_SPLIT; ++sp) s += part[(int64_t)sp * n + i];
+    gw[i] = s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nef_stem_fwd(const float* x, const float* w, float* y, int B, int V, int L, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && w && y, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && V > 0 && L >= 4 && L % 4 == 0, NEF_E_SHAPE);
+    const int T = L / 4;
+    const int tiles = (T + TP - 1) / TP;
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)((int64_t)B * V * tiles)), dim3(256), 0, (hipStream_t)stream, x,
+                       w, y, B, V, L, T, tiles);
+    return nef_launch_status();
+}
+
+size_t nef_stem_bwd_ws_bytes(int V) { return (size_t)BW_SPLIT * V * CPL * KW * sizeof(float); }
+
+int nef_stem_bwd_weight(const float* x, const float* w, const float* gy, float* gw, void* ws, size_t ws_bytes, int B,
+                        int V, int L, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && w && gy && gw && ws, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && V > 0 && L >= 4 && L % 4 == 0, NEF_E_SHAPE);
+    NEF_REQUIRE(ws_bytes >= nef_stem_bwd_ws_bytes(V), NEF_E_WORKSPACE);
+    const int T = L / 4;
+    const int tiles = (T + TP - 1) / TP;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(stem_bwd_weight_kernel, dim3((unsigned)(BW_SPLIT * V * (CPL / BW_CPB))), dim3(256), 0, st, x, w,
+                       gy, (float*)ws, B, V, L, T, tiles);
+    const int n = V * CPL * KW;
+    hipLaunchKernelGGL(stem_bwd_weight_reduce, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)ws, gw, n);
+    return nef_launch_status();
+}
+
+}  // extern "C"

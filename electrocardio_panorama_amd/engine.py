@@ -1,0 +1,245 @@
+"""Forward / backward schedule of the Nef-Net step on top of the HIP ops (ops.py).
+
+This is the hand-written equivalent of what torch autograd derives for the reference's
+`Model_nefnet.forward` (reference codes/network/model_nefnet.py:109-194): one explicit forward that
+records the tensors the backward needs, and one explicit backward that walks the same graph in
+reverse.  Parameters and BatchNorm buffers are addressed by the reference's state_dict names.
+All arithmetic happens in libnefnet_hip.so; this file only sequences launches.
+"""
+import torch
+
+from . import ops
+from .ops import GV
+
+N_SEG, ROI_BINS = 7, 16
+DROP_P = 0.2           # every nn.Dropout on the path (model_nefnet.py:46, encoder/resnet_1d.py:37)
+BN_EPS, BN_MOM = 1e-5, 0.1
+
+DROPOUT_SITES = ("W_encoder.layer1.0", "W_encoder.layer1.1", "W_encoder.layer1.2", "w_conv.0", "z1_conv.0",
+                 "z2_conv1.0", "z2_conv2.0", "z2_conv2.2")
+
+
+class DropCfg:
+    """Dropout behaviour of one forward: off, replayed keep-masks (parity tests), or the in-kernel counter RNG."""
+
+    def __init__(self, training, p=DROP_P, masks=None, seed=0):
+        self.on = bool(training) and p > 0.0
+        self.p = p if self.on else 0.0
+        self.scale = 1.0 / (1.0 - p) if self.on else 1.0
+        self.masks = masks
+        self.seed = seed
+
+    def args(self, site):
+        if not self.on:
+            return dict(mask=None, drop_p=0.0, drop_scale=1.0, seed=0)
+        if self.masks is not None:
+            return dict(mask=self.masks[site], drop_p=0.0, drop_scale=self.scale, seed=0)
+        return dict(mask=None, drop_p=self.p, drop_scale=self.scale,
+                    seed=(self.seed * 0x9E3779B1 + DROPOUT_SITES.index(site) * 0x85EBCA6B + 1) & 0xFFFFFFFFFFFFFFFF)
+
+
+# ----------------------------------------------------------------------------------------------
+# BasicBlock (resnet_1d.py:42-53 with k=7; model_nefnet.py:48-60 with k=3)
+# ----------------------------------------------------------------------------------------------
+def block_fwd(xv, P, prefix, K, Cog, drop):
+    G = xv.G
+    h = ops.conv(xv, ops.pack_weight(P[prefix + ".conv1.weight"], G), Cog, K, relu=True, **drop.args(prefix))
+    res_conv = (K == 3 and Cog != xv.Cg)                     # model_nefnet.py:54
+    if res_conv:
+        r = ops.conv(xv, ops.pack_weight(P[prefix + ".residual_conv.weight"], G), Cog, 1,
+                     bias=P[prefix + ".residual_conv.bias"])
+        resv = GV.dense(r, G)
+    else:
+        resv = xv
+    y = ops.conv(GV.dense(h, G), ops.pack_weight(P[prefix + ".conv2.weight"], G), Cog, K, res=resv, relu=True)
+    return y, (xv, h, y, prefix, K, Cog, res_conv, drop.scale)
+
+
+def block_bwd(saved, gy, P, grads, out=None):
+    """Accumulates the block's parameter gradients into `grads`; returns the gradient wrt the block input
+    (written into the GV `out` when given, e.g. one half of the z1/z2 split)."""
+    xv, h, y, prefix, K, Cog, res_conv, dscale = saved
+    G, Cig = xv.G, xv.Cg
+    g2 = ops.gate(gy, y)                                     # through the final ReLU
+    g2v, hv = GV.dense(g2, G), GV.dense(h, G)
+    grads[prefix + ".conv2.weight"] = ops.conv_bwd_weight(hv, g2v, K)
+    # through conv2, then dropout and the inner ReLU: h > 0 <=> ReLU active and kept
+    gc1 = ops.conv(g2v, ops.pack_weight(P[prefix + ".conv2.weight"], G, flip=True), Cog, K, gate=hv, gate_scale=dscale)
+    gc1v = GV.dense(gc1, G)
+    grads[prefix + ".conv1.weight"] = ops.conv_bwd_weight(xv, gc1v, K)
+    if res_conv:
+        grads[prefix + ".residual_conv.weight"] = ops.conv_bwd_weight(xv, g2v, 1)
+        grads[prefix + ".residual_conv.bias"] = ops.chan_sum(g2)
+        gres = ops.conv(g2v, ops.pack_weight(P[prefix + ".residual_conv.weight"], G, flip=True), Cig, 1)
+        resv = GV.dense(gres, G)
+    else:
+        resv = g2v
+    return ops.conv(gc1v, ops.pack_weight(P[prefix + ".conv1.weight"], G, flip=True), Cig, K, res=resv, out=out)
+
+
+# ----------------------------------------------------------------------------------------------
+# decoder (model_nefnet.py:101-107) + sigmoid(x/3) (:168), P passes stacked along batch
+# ----------------------------------------------------------------------------------------------
+_DEC = (("decoder.1", "0", "1", 128), ("decoder.1", "3", "4", 128), ("decoder.3", "0", "1", 64),
+        ("decoder.3", "3", "4", 64))
+
+
+def decoder_fwd(D, P, Bf, passes, training, save):
+    x = D
+    saved = []
+    for li, (blk, cv, bn, cout) in enumerate(_DEC):
+        if li in (0, 2):
+            x = ops.upsample2_fwd(x)                         # nn.Upsample(scale_factor=2, 'linear')
+        wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
+        c = ops.conv(GV.dense(x, 1), ops.pack_weight(P[wname], 1), cout, 3, bias=P[bname])
+        if training:
+            mean, invstd, a, b = ops.bn_train_stats(c, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
+                                                    Bf[pre + ".running_var"], passes, BN_EPS, BN_MOM)
+            Bf[pre + ".num_batches_tracked"] += passes
+            np_ = passes
+        else:
+            a, b = ops.bn_eval_affine(P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
+                                      Bf[pre + ".running_var"], BN_EPS)
+            mean = invstd = None
+            np_ = 1
+        act = ops.affine_relu_fwd(c, a, b, np_)
+        if save:
+            saved.append((x, c, mean, invstd, a, b))
+        x = act
+    out = ops.outconv_fwd(x, P["decoder.4.weight"], P["decoder.4.bias"])
+    return out, (saved, x, out, passes)
+
+
+def decoder_bwd(dsaved, g_out, P, grads):
+    saved, a4, out, passes = dsaved
+    gw, gb = ops.outconv_bwd_weight(g_out, out, a4)
+    grads["decoder.4.weight"], grads["decoder.4.bias"] = gw, gb
+    g = ops.outconv_bwd_data(g_out, out, P["decoder.4.weight"], a4.shape[1])
+    for li in (3, 2, 1, 0):
+        blk, cv, bn, cout = _DEC[li]
+        x, c, mean, invstd, a, b = saved[li]
+        wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
+        gc, gg, gbeta = ops.bn_relu_bwd(g, c, P[pre + ".weight"], mean, invstd, a, b, passes)
+        grads[pre + ".weight"], grads[pre + ".bias"] = gg, gbeta
+        gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
+        grads[wname] = ops.conv_bwd_weight(xv, gcv, 3)
+        grads[bname] = ops.chan_sum(gc)
+        g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True), x.shape[1], 3)
+        if li in (0, 2):
+            g = ops.upsample2_bwd(g)
+    return g
+
+
+# ----------------------------------------------------------------------------------------------
+# Model_nefnet.forward / backward
+# ----------------------------------------------------------------------------------------------
+def _latents(P, x, in_theta, rois, drop, save):
+    """model_nefnet.py:117-138: everything up to (z1, z2 segments)."""
+    B, V, L = x.shape
+    T = L // 4
+    sv = {}
+    a = ops.stem_fwd(x, P["W_encoder.conv1.weight"])
+    sv["blk_enc"] = []
+    for i in range(3):
+        a, s = block_fwd(GV.dense(a, V), P, f"W_encoder.layer1.{i}", 7, 128, drop)
+        sv["blk_enc"].append(s)
+    e = ops.theta_mlp_fwd(in_theta, P["mlp1.weight"], P["mlp1.bias"])           # [B, V, 128]
+    ew = ops.chscale_fwd(a, e)
+    enc, sv["blk_w_conv"] = block_fwd(GV.dense(ew, V), P, "w_conv.0", 3, 128, drop)
+    z1, sv["blk_z1"] = block_fwd(GV.half(enc, V, 0), P, "z1_conv.0", 3, 128, drop)
+    z2c, sv["blk_z2c"] = block_fwd(GV.half(enc, V, 1), P, "z2_conv1.0", 3, 128, drop)
+    z2a = ops.roi_align_fwd(z2c, rois)                                          # [B, 128V, 7, 16]
+    h0 = z2a.view(B, 128 * V * N_SEG, ROI_BINS)                                 # raw memory order
+    h1, sv["blk_c20"] = block_fwd(GV.dense(h0, N_SEG * V), P, "z2_conv2.0", 3, 128, drop)
+    h2 = ops.convt2_fwd(h1, P["z2_conv2.1.weight"], P["z2_conv2.1.bias"], N_SEG * V)
+    h3, sv["blk_c22"] = block_fwd(GV.dense(h2, N_SEG * V), P, "z2_conv2.2", 3, 128, drop)
+    z2b = h3.view(B, 128 * V, N_SEG, 2 * ROI_BINS)
+    if save:
+        sv.update(x=x, w=a, e=e, in_theta=in_theta, h1=h1, rois=rois, T=T, V=V, B=B)
+    return z1, z2b, (sv if save else None)
+
+
+def forward(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", training=True, drop=None,
+            lead_choice=(0, 0), save=False, rest_chunk=8, status=None):
+    """Returns (outputs tuple, saved-state or None).  `lead_choice` are the two Standin lead indices
+    (model_nefnet.py:154,156), drawn by the caller."""
+    drop = drop or DropCfg(False)
+    B, V, L = x.shape
+    T = L // 4
+    z1, z2b, sv = _latents(P, x, in_theta, rois, drop, save)
+    if phase == "gen":
+        return (z1, z2b), None
+    z2r = ops.roi_unpool_fwd(z2b, rois, T, status)
+    latent = ops.lead_mean(z1, z2r, V)
+    q = ops.theta_mlp_fwd(q_theta, P["mlp2.weight"], P["mlp2.bias"])             # [B, 256]
+    c1, c2 = lead_choice
+    D = ops.mix_fwd(latent, z1, z2r, q, V, c1, c2)                                # [3B, 256, T]
+    out3, dsv = decoder_fwd(D, P, Bf, 3, training, save)
+    outs = (out3[0:B], out3[B:2 * B], out3[2 * B:3 * B])
+    if save:
+        sv.update(z1=z1, z2r=z2r, latent=latent, q=q, q_theta=q_theta, choice=(c1, c2), dec=dsv)
+    if phase == "train":
+        return outs, sv
+    if phase in ("val", "test"):
+        rest = sweep(P, Bf, latent, rest_theta, training, rest_chunk)
+        return outs + (rest,), sv
+    raise KeyError("please type correct phase")
+
+
+def sweep(P, Bf, latent, query_thetas, training=False, chunk=8):
+    """Decode `latent` [B,256,T] at Q query angles [B,Q,2] -> [B,Q,L] (model_nefnet.py:181-190, :207-216).
+    In training mode each angle is its own BatchNorm pass, in the reference's order."""
+    B, Q = query_thetas.shape[0], query_thetas.shape[1]
+    rq = ops.theta_mlp_fwd(query_thetas, P["mlp2.weight"], P["mlp2.bias"])       # [B, Q, 256]
+    L = latent.shape[2] * 4
+    rest = torch.empty(B, Q, L, device=latent.device, dtype=torch.float32)
+    for q0 in range(0, Q, chunk):
+        n = min(chunk, Q - q0)
+        Dq = torch.empty(n * B, 256, latent.shape[2], device=latent.device, dtype=torch.float32)
+        for i in range(n):
+            Dq[i * B:(i + 1) * B] = ops.chscale_fwd(latent, rq[:, q0 + i].contiguous())
+        o, _ = decoder_fwd(Dq, P, Bf, n, training, False)                         # [n*B, 1, L]
+        rest[:, q0:q0 + n] = o.view(n, B, L).transpose(0, 1)
+    return rest
+
+
+def gen_ecg(P, Bf, z1, z2b, query_thetas, rois, chunk=8):
+    """model_nefnet.py:196-218 (always eval-mode BatchNorm)."""
+    V = z1.shape[1] // 128
+    z2r = ops.roi_unpool_fwd(z2b.contiguous(), rois, z1.shape[2])
+    latent = ops.lead_mean(z1, z2r, V)
+    return sweep(P, Bf, latent, query_thetas, False, chunk)
+
+
+def backward(P, sv, g_outs):
+    """g_outs: gradients wrt (out, shuffle_p, shuffle_l), each [B,1,L] or None.  Returns {param name: grad}."""
+    B, V, T = sv["B"], sv["V"], sv["T"]
+    grads = {}
+    like = sv["dec"][2]
+    parts = [g if g is not None else torch.zeros_like(like[0:B]) for g in g_outs]
+    g_out = torch.cat([p_.contiguous() for p_ in parts], dim=0)
+    gD = decoder_bwd(sv["dec"], g_out, P, grads)
+    c1, c2 = sv["choice"]
+    gz1, gz2r, gq = ops.mix_bwd(gD, sv["latent"], sv["z1"], sv["z2r"], sv["q"], V, c1, c2)
+    gW2, gb2 = ops.theta_mlp_bwd(sv["q_theta"], gq, 256)
+    gz2b = ops.roi_unpool_bwd(gz2r, sv["rois"])                                  # [B, 128V, 7, 32]
+    gh3 = gz2b.view(B, 128 * V * N_SEG, 2 * ROI_BINS)
+    gh2 = block_bwd(sv["blk_c22"], gh3, P, grads)
+    gwt, gbt = ops.convt2_bwd_weight(sv["h1"], gh2, N_SEG * V)
+    grads["z2_conv2.1.weight"], grads["z2_conv2.1.bias"] = gwt, gbt
+    gh1 = ops.convt2_bwd_data(gh2, P["z2_conv2.1.weight"], N_SEG * V)
+    gh0 = block_bwd(sv["blk_c20"], gh1, P, grads)
+    gz2c = ops.roi_align_bwd(gh0.view(B, 128 * V, N_SEG, ROI_BINS), sv["rois"], T)
+    genc = torch.empty(B, 128 * V, T, device=gz1.device, dtype=torch.float32)
+    block_bwd(sv["blk_z1"], gz1, P, grads, out=GV.half(genc, V, 0))
+    block_bwd(sv["blk_z2c"], gz2c, P, grads, out=GV.half(genc, V, 1))
+    gew = block_bwd(sv["blk_w_conv"], genc, P, grads)
+    g, ge = ops.chscale_bwd(gew, sv["w"], sv["e"])
+    gW1, gb1 = ops.theta_mlp_bwd(sv["in_theta"], ge, 128)
+    # mlp2 is also used by nothing else in train phase; mlp1/mlp2 grads
+    grads["mlp1.weight"], grads["mlp1.bias"] = gW1, gb1
+    grads["mlp2.weight"], grads["mlp2.bias"] = gW2, gb2
+    for i in (2, 1, 0):
+        g = block_bwd(sv["blk_enc"][i], g, P, grads)
+    grads["W_encoder.conv1.weight"] = ops.stem_bwd_weight(sv["x"], P["W_encoder.conv1.weight"], g)
+    return grads

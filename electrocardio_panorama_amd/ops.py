@@ -1,0 +1,475 @@
+"""Thin tensor-level wrappers over the C ABI (include/nefnet_hip.h).
+
+PyTorch is used only for device memory and streams: every function takes contiguous fp32 (int64 for
+ROIs) tensors on a HIP device, allocates the outputs, and enqueues the library call on the current
+stream.  Nothing here computes on the host and nothing falls back to torch ops.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+N_SEG, ROI_BINS = 7, 16
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype=torch.float32):
+    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return t
+
+
+_WS = {}
+
+# bench.py sets this to a list to collect (tag, start_event, end_event) around selected launches; the events are
+# recorded on the stream the kernel is launched on, so their difference is that kernel's device time.
+PROFILE = None
+
+
+def _timed(tag):
+    if PROFILE is None:
+        return None
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    PROFILE.append((tag, s, e))
+    s.record()
+    return e
+
+
+def workspace(nbytes, device):
+    """Caller-owned scratch, grown on demand, reused by stream-ordered calls."""
+    key = (device.type, device.index)
+    cur = _WS.get(key)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = cur
+    return cur
+
+
+class GV:
+    """Grouped view of an activation: element (b, g, c, t) at base + b*bs + g*gs + c*T + t (in floats)."""
+    __slots__ = ("t", "B", "G", "Cg", "T", "bs", "gs", "off")
+
+    def __init__(self, t, B, G, Cg, T, bs, gs, off=0):
+        self.t, self.B, self.G, self.Cg, self.T, self.bs, self.gs, self.off = t, B, G, Cg, T, bs, gs, off
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + 4 * self.off
+
+    @staticmethod
+    def dense(t, G):
+        _chk(t)
+        B, Ct, T = t.shape
+        return GV(t, B, G, Ct // G, T, Ct * T, (Ct // G) * T, 0)
+
+    @staticmethod
+    def half(t, V, which):
+        """Channels [which*64, which*64+64) of every lead of a [B, 128V, T] tensor (the z1/z2 split,
+        reference codes/network/model_nefnet.py:127-131)."""
+        _chk(t)
+        B, Ct, T = t.shape
+        return GV(t, B, V, 64, T, Ct * T, 128 * T, which * 64 * T)
+
+
+# ------------------------------------------------------------------ stem
+def stem_fwd(x, w):
+    L = _lib.load()
+    _chk(x), _chk(w)
+    B, V, Ln = x.shape
+    y = torch.empty(B, 128 * V, Ln // 4, device=x.device, dtype=torch.float32)
+    _lib.check(L.nef_stem_fwd(_p(x), _p(w), _p(y), B, V, Ln, _stream()), "nef_stem_fwd")
+    return y
+
+
+def stem_bwd_weight(x, w, gy):
+    L = _lib.load()
+    _chk(x), _chk(w), _chk(gy)
+    B, V, Ln = x.shape
+    gw = torch.empty_like(w)
+    n = L.nef_stem_bwd_ws_bytes(V)
+    ws = workspace(n, x.device)
+    _lib.check(L.nef_stem_bwd_weight(_p(x), _p(w), _p(gy), _p(gw), _p(ws), n, B, V, Ln, _stream()), "nef_stem_bwd_weight")
+    return gw
+
+
+# ------------------------------------------------------------------ grouped conv
+def pack_weight(w, G, flip=False):
+    """w [G*Cog, Cig, K] -> packed operand (forward: [G][K][Cig][Cog]; flip: [G][K][Cog][Cig], taps reversed)."""
+    L = _lib.load()
+    _chk(w)
+    Cog, Cig, K = w.shape[0] // G, w.shape[1], w.shape[2]
+    wp = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+    _lib.check(L.nef_pack_weight(_p(w), _p(wp), G, Cog, Cig, K, int(flip), _stream()), "nef_pack_weight")
+    return wp
+
+
+def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None, gate_scale=1.0, relu=False,
+         mask=None, drop_p=0.0, drop_scale=1.0, seed=0):
+    """out = epilogue(conv1d(x * in_scale, w) + bias + res).  `xv`, `res`, `gate`, `out` are GV views;
+    `in_scale` is (tensor, batch_stride, group_stride).  Returns the output tensor."""
+    L = _lib.load()
+    if out is None:
+        y = torch.empty(xv.B, xv.G * Cog, xv.T, device=xv.t.device, dtype=torch.float32)
+        out = GV.dense(y, xv.G)
+    a = _lib.ConvArgs()
+    a.x, a.wp, a.y = xv.ptr, _p(wp), out.ptr
+    a.bias = _p(bias)
+    a.in_scale = None
+    if in_scale is not None:
+        a.in_scale, a.sc_bs, a.sc_gs = _p(in_scale[0]), in_scale[1], in_scale[2]
+    a.res = res.ptr if res is not None else None
+    a.gate = gate.ptr if gate is not None else None
+    a.mask = _p(mask)
+    a.x_bs, a.x_gs, a.y_bs, a.y_gs = xv.bs, xv.gs, out.bs, out.gs
+    if res is not None:
+        a.res_bs, a.res_gs = res.bs, res.gs
+    if gate is not None:
+        a.gate_bs, a.gate_gs = gate.bs, gate.gs
+    a.B, a.T, a.G, a.Cin_g, a.Cout_g, a.K = xv.B, xv.T, xv.G, xv.Cg, Cog, K
+    a.relu = int(relu)
+    a.gate_scale, a.drop_scale, a.drop_p, a.rng_seed = gate_scale, drop_scale, drop_p, seed
+    ev = _timed(("conv_fwd", K, xv.G, xv.Cg, Cog, xv.B, xv.T))
+    _lib.check(L.nef_conv_fwd(C.byref(a), _stream()), "nef_conv_fwd")
+    if ev is not None:
+        ev.record()
+    return out.t
+
+
+def conv_bwd_weight(xv, gyv, K, in_scale=None):
+    """gw [G*Cog, Cig, K] for y = conv(x * in_scale, w)."""
+    L = _lib.load()
+    B, T, G, Cig, Cog = xv.B, xv.T, xv.G, xv.Cg, gyv.Cg
+    gw = torch.empty(G * Cog, Cig, K, device=xv.t.device, dtype=torch.float32)
+    n = L.nef_conv_bwd_weight_ws_bytes(B, T, G, Cig, Cog, K)
+    if n == 0:
+        raise _lib.NefLibraryError(f"conv_bwd_weight: unsupported shape Cig={Cig} Cog={Cog} K={K}")
+    ws = workspace(n, xv.t.device)
+    sc, sc_bs, sc_gs = (None, 0, 0) if in_scale is None else (_p(in_scale[0]), in_scale[1], in_scale[2])
+    ev = _timed(("conv_bwd_weight", K, G, Cig, Cog, B, T))
+    _lib.check(L.nef_conv_bwd_weight(xv.ptr, xv.bs, xv.gs, sc, sc_bs, sc_gs, gyv.ptr, gyv.bs, gyv.gs, _p(gw), _p(ws),
+                                     n, B, T, G, Cig, Cog, K, _stream()), "nef_conv_bwd_weight")
+    if ev is not None:
+        ev.record()
+    return gw
+
+
+def chan_sum(x):
+    L = _lib.load()
+    _chk(x)
+    B, Ct, T = x.shape
+    out = torch.empty(Ct, device=x.device, dtype=torch.float32)
+    n = L.nef_chan_sum_ws_bytes(Ct)
+    ws = workspace(n, x.device)
+    _lib.check(L.nef_chan_sum(_p(x), _p(out), _p(ws), n, B, Ct, T, _stream()), "nef_chan_sum")
+    return out
+
+
+# ------------------------------------------------------------------ transposed conv (k2 s2)
+def convt2_fwd(x, w, bias, G):
+    L = _lib.load()
+    _chk(x), _chk(w), _chk(bias)
+    B, Ct, T = x.shape
+    Cig, Cog = Ct // G, w.shape[1]
+    y = torch.empty(B, G * Cog, 2 * T, device=x.device, dtype=torch.float32)
+    _lib.check(L.nef_convt2_fwd(_p(x), _p(w), _p(bias), _p(y), B, G, Cig, Cog, T, _stream()), "nef_convt2_fwd")
+    return y
+
+
+def convt2_bwd_data(gy, w, G):
+    L = _lib.load()
+    _chk(gy), _chk(w)
+    B, Ct, To = gy.shape
+    Cog, Cig, T = Ct // G, w.shape[0] // G, To // 2
+    gx = torch.empty(B, G * Cig, T, device=gy.device, dtype=torch.float32)
+    _lib.check(L.nef_convt2_bwd_data(_p(gy), _p(w), _p(gx), B, G, Cig, Cog, T, _stream()), "nef_convt2_bwd_data")
+    return gx
+
+
+def convt2_bwd_weight(x, gy, G):
+    L = _lib.load()
+    _chk(x), _chk(gy)
+    B, Ct, T = x.shape
+    Cig, Cog = Ct // G, gy.shape[1] // G
+    gw = torch.empty(G * Cig, Cog, 2, device=x.device, dtype=torch.float32)
+    gb = torch.empty(G * Cog, device=x.device, dtype=torch.float32)
+    n = L.nef_convt2_bwd_weight_ws_bytes(G, Cig, Cog)
+    ws = workspace(n, x.device)
+    _lib.check(L.nef_convt2_bwd_weight(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), n, B, G, Cig, Cog, T, _stream()),
+               "nef_convt2_bwd_weight")
+    return gw, gb
+
+
+# ------------------------------------------------------------------ angular encoding + MLP
+def theta_mlp_fwd(theta, W, bias):
+    L = _lib.load()
+    _chk(theta), _chk(W), _chk(bias)
+    N, O = theta.numel() // 2, W.shape[0]
+    y = torch.empty(*theta.shape[:-1], O, device=theta.device, dtype=torch.float32)
+    _lib.check(L.nef_theta_mlp_fwd(_p(theta), _p(W), _p(bias), _p(y), N, O, _stream()), "nef_theta_mlp_fwd")
+    return y
+
+
+def theta_mlp_bwd(theta, gy, O):
+    L = _lib.load()
+    _chk(theta), _chk(gy)
+    N = theta.numel() // 2
+    gW = torch.empty(O, 12, device=theta.device, dtype=torch.float32)
+    gb = torch.empty(O, device=theta.device, dtype=torch.float32)
+    _lib.check(L.nef_theta_mlp_bwd(_p(theta), _p(gy), _p(gW), _p(gb), N, O, _stream()), "nef_theta_mlp_bwd")
+    return gW, gb
+
+
+def theta_encode(theta):
+    L = _lib.load()
+    _chk(theta)
+    N = theta.numel() // 2
+    enc = torch.empty(*theta.shape[:-1], 12, device=theta.device, dtype=torch.float32)
+    _lib.check(L.nef_theta_encode(_p(theta), _p(enc), N, _stream()), "nef_theta_encode")
+    return enc
+
+
+# ------------------------------------------------------------------ elementwise
+def chscale_fwd(x, s, s_bs=None):
+    L = _lib.load()
+    _chk(x)
+    B, Ct, T = x.shape
+    y = torch.empty_like(x)
+    _lib.check(L.nef_chscale_fwd(_p(x), _p(s), Ct if s_bs is None else s_bs, _p(y), B, Ct, T, _stream()), "nef_chscale_fwd")
+    return y
+
+
+def chscale_bwd(gy, x, s, s_bs=None):
+    L = _lib.load()
+    _chk(gy), _chk(x)
+    B, Ct, T = x.shape
+    gx = torch.empty_like(x)
+    gs = torch.empty(B, Ct, device=x.device, dtype=torch.float32)
+    _lib.check(L.nef_chscale_bwd(_p(gy), _p(x), _p(s), Ct if s_bs is None else s_bs, _p(gx), _p(gs), B, Ct, T, _stream()),
+               "nef_chscale_bwd")
+    return gx, gs
+
+
+def gate(g, ref, scale=1.0):
+    L = _lib.load()
+    _chk(g), _chk(ref)
+    out = torch.empty_like(g)
+    _lib.check(L.nef_gate(_p(g), _p(ref), _p(out), scale, g.numel(), _stream()), "nef_gate")
+    return out
+
+
+def add(a, b):
+    L = _lib.load()
+    _chk(a), _chk(b)
+    out = torch.empty_like(a)
+    _lib.check(L.nef_add(_p(a), _p(b), _p(out), a.numel(), _stream()), "nef_add")
+    return out
+
+
+# ------------------------------------------------------------------ ROI ops
+def roi_align_fwd(z, rois):
+    L = _lib.load()
+    _chk(z), _chk(rois, torch.int64)
+    B, Ct, T = z.shape
+    out = torch.empty(B, Ct, N_SEG, ROI_BINS, device=z.device, dtype=torch.float32)
+    _lib.check(L.nef_roi_align_fwd(_p(z), _p(rois), _p(out), B, Ct, T, _stream()), "nef_roi_align_fwd")
+    return out
+
+
+def roi_align_bwd(gout, rois, T):
+    L = _lib.load()
+    _chk(gout), _chk(rois, torch.int64)
+    B, Ct = gout.shape[0], gout.shape[1]
+    gz = torch.empty(B, Ct, T, device=gout.device, dtype=torch.float32)
+    _lib.check(L.nef_roi_align_bwd(_p(gout), _p(rois), _p(gz), B, Ct, T, _stream()), "nef_roi_align_bwd")
+    return gz
+
+
+def roi_unpool_fwd(zseg, rois, T, status=None):
+    L = _lib.load()
+    _chk(zseg), _chk(rois, torch.int64)
+    B, Ct = zseg.shape[0], zseg.shape[1]
+    out = torch.empty(B, Ct, T, device=zseg.device, dtype=torch.float32)
+    _lib.check(L.nef_roi_unpool_fwd(_p(zseg), _p(rois), _p(out), _p(status), B, Ct, T, _stream()), "nef_roi_unpool_fwd")
+    return out
+
+
+def roi_unpool_bwd(gout, rois):
+    L = _lib.load()
+    _chk(gout), _chk(rois, torch.int64)
+    B, Ct, T = gout.shape
+    gz = torch.empty(B, Ct, N_SEG, 2 * ROI_BINS, device=gout.device, dtype=torch.float32)
+    _lib.check(L.nef_roi_unpool_bwd(_p(gout), _p(rois), _p(gz), B, Ct, T, _stream()), "nef_roi_unpool_bwd")
+    return gz
+
+
+def roi_segment_table(rois):
+    L = _lib.load()
+    _chk(rois, torch.int64)
+    B = rois.shape[0]
+    start = torch.empty(B, N_SEG, device=rois.device, dtype=torch.int64)
+    length = torch.empty(B, N_SEG, device=rois.device, dtype=torch.int64)
+    _lib.check(L.nef_roi_segment_table(_p(rois), _p(start), _p(length), B, _stream()), "nef_roi_segment_table")
+    return start, length
+
+
+# ------------------------------------------------------------------ latent mix
+def lead_mean(z1, z2r, V):
+    L = _lib.load()
+    _chk(z1), _chk(z2r)
+    B, _, T = z1.shape
+    latent = torch.empty(B, 256, T, device=z1.device, dtype=torch.float32)
+    _lib.check(L.nef_lead_mean(_p(z1), _p(z2r), _p(latent), B, V, T, _stream()), "nef_lead_mean")
+    return latent
+
+
+def mix_fwd(latent, z1, z2r, q, V, c1, c2):
+    L = _lib.load()
+    _chk(latent), _chk(q)
+    B, _, T = latent.shape
+    D = torch.empty(3 * B, 256, T, device=latent.device, dtype=torch.float32)
+    _lib.check(L.nef_mix_fwd(_p(latent), _p(z1), _p(z2r), _p(q), _p(D), B, V, T, c1, c2, _stream()), "nef_mix_fwd")
+    return D
+
+
+def mix_bwd(gD, latent, z1, z2r, q, V, c1, c2):
+    L = _lib.load()
+    _chk(gD)
+    B, _, T = latent.shape
+    gz1, gz2r = torch.empty_like(z1), torch.empty_like(z2r)
+    gq = torch.empty(B, 256, device=latent.device, dtype=torch.float32)
+    _lib.check(L.nef_mix_bwd(_p(gD), _p(latent), _p(z1), _p(z2r), _p(q), _p(gz1), _p(gz2r), _p(gq), B, V, T, c1, c2,
+                             _stream()), "nef_mix_bwd")
+    return gz1, gz2r, gq
+
+
+# ------------------------------------------------------------------ decoder pieces
+def upsample2_fwd(x):
+    L = _lib.load()
+    _chk(x)
+    N, Ct, T = x.shape
+    y = torch.empty(N, Ct, 2 * T, device=x.device, dtype=torch.float32)
+    _lib.check(L.nef_upsample2_fwd(_p(x), _p(y), N * Ct, T, _stream()), "nef_upsample2_fwd")
+    return y
+
+
+def upsample2_bwd(gy):
+    L = _lib.load()
+    _chk(gy)
+    N, Ct, To = gy.shape
+    gx = torch.empty(N, Ct, To // 2, device=gy.device, dtype=torch.float32)
+    _lib.check(L.nef_upsample2_bwd(_p(gy), _p(gx), N * Ct, To // 2, _stream()), "nef_upsample2_bwd")
+    return gx
+
+
+def bn_train_stats(x, gamma, beta, running_mean, running_var, P, eps=1e-5, momentum=0.1):
+    """Returns (mean, invstd, a, b), each [P, C]; updates the running statistics in place, pass by pass."""
+    L = _lib.load()
+    _chk(x)
+    N, Ct, Ln = x.shape
+    Bp = N // P
+    mean, invstd, a, b = (torch.empty(P, Ct, device=x.device, dtype=torch.float32) for _ in range(4))
+    n = L.nef_bn_ws_bytes(P, Ct)
+    ws = workspace(n, x.device)
+    _lib.check(L.nef_bn_train_stats(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(mean), _p(invstd),
+                                    _p(a), _p(b), _p(ws), n, P, Bp, Ct, Ln, eps, momentum, _stream()), "nef_bn_train_stats")
+    return mean, invstd, a, b
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps=1e-5):
+    L = _lib.load()
+    Ct = gamma.numel()
+    a = torch.empty(1, Ct, device=gamma.device, dtype=torch.float32)
+    b = torch.empty(1, Ct, device=gamma.device, dtype=torch.float32)
+    _lib.check(L.nef_bn_eval_affine(_p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(a), _p(b), Ct, eps,
+                                    _stream()), "nef_bn_eval_affine")
+    return a, b
+
+
+def affine_relu_fwd(x, a, b, P):
+    L = _lib.load()
+    _chk(x)
+    N, Ct, Ln = x.shape
+    y = torch.empty_like(x)
+    _lib.check(L.nef_affine_relu_fwd(_p(x), _p(a), _p(b), _p(y), P, N // P, Ct, Ln, _stream()), "nef_affine_relu_fwd")
+    return y
+
+
+def bn_relu_bwd(gy, x, gamma, mean, invstd, a, b, P):
+    L = _lib.load()
+    _chk(gy), _chk(x)
+    N, Ct, Ln = x.shape
+    gx = torch.empty_like(x)
+    gg = torch.empty(Ct, device=x.device, dtype=torch.float32)
+    gb = torch.empty(Ct, device=x.device, dtype=torch.float32)
+    n = L.nef_bn_ws_bytes(P, Ct)
+    ws = workspace(n, x.device)
+    _lib.check(L.nef_bn_relu_bwd(_p(gy), _p(x), _p(gamma), _p(mean), _p(invstd), _p(a), _p(b), _p(gx), _p(gg), _p(gb),
+                                 _p(ws), n, P, N // P, Ct, Ln, _stream()), "nef_bn_relu_bwd")
+    return gx, gg, gb
+
+
+def outconv_fwd(x, w, bias):
+    L = _lib.load()
+    _chk(x), _chk(w), _chk(bias)
+    N, Ct, Ln = x.shape
+    out = torch.empty(N, 1, Ln, device=x.device, dtype=torch.float32)
+    _lib.check(L.nef_outconv_fwd(_p(x), _p(w), _p(bias), _p(out), N, Ct, Ln, _stream()), "nef_outconv_fwd")
+    return out
+
+
+def outconv_bwd_data(gout, out, w, Ct):
+    L = _lib.load()
+    _chk(gout), _chk(out)
+    N, Ln = out.shape[0], out.shape[-1]
+    gx = torch.empty(N, Ct, Ln, device=out.device, dtype=torch.float32)
+    _lib.check(L.nef_outconv_bwd_data(_p(gout), _p(out), _p(w), _p(gx), N, Ct, Ln, _stream()), "nef_outconv_bwd_data")
+    return gx
+
+
+def outconv_bwd_weight(gout, out, x):
+    L = _lib.load()
+    _chk(gout), _chk(out), _chk(x)
+    N, Ct, Ln = x.shape
+    gw = torch.empty(1, Ct, 3, device=x.device, dtype=torch.float32)
+    gb = torch.empty(1, device=x.device, dtype=torch.float32)
+    n = L.nef_outconv_bwd_weight_ws_bytes(Ct)
+    ws = workspace(n, x.device)
+    _lib.check(L.nef_outconv_bwd_weight(_p(gout), _p(out), _p(x), _p(gw), _p(gb), _p(ws), n, N, Ct, Ln, _stream()),
+               "nef_outconv_bwd_weight")
+    return gw, gb
+
+
+# ------------------------------------------------------------------ loss / optimiser
+def loss_fwd(pred, pred_p, pred_l, target, factors, reg_l2, use_mask):
+    L = _lib.load()
+    for t in (pred, pred_p, pred_l, target):
+        _chk(t)
+    losses = torch.empty(4, device=pred.device, dtype=torch.float32)
+    n = L.nef_loss_ws_bytes()
+    ws = workspace(n, pred.device)
+    _lib.check(L.nef_loss_fwd(_p(pred), _p(pred_p), _p(pred_l), _p(target), _p(losses), _p(ws), n, pred.numel(),
+                              factors[0], factors[1], factors[2], int(reg_l2), use_mask, _stream()), "nef_loss_fwd")
+    return losses
+
+
+def loss_bwd(pred, pred_p, pred_l, target, gscale, factors, reg_l2, use_mask):
+    L = _lib.load()
+    g_pred, g_p, g_l = torch.empty_like(pred), torch.empty_like(pred_p), torch.empty_like(pred_l)
+    _lib.check(L.nef_loss_bwd(_p(pred), _p(pred_p), _p(pred_l), _p(target), _p(gscale), _p(g_pred), _p(g_p), _p(g_l),
+                              pred.numel(), factors[0], factors[1], factors[2], int(reg_l2), use_mask, _stream()),
+               "nef_loss_bwd")
+    return g_pred, g_p, g_l
+
+
+def sgd_momentum(p, g, buf, lr, mu, gscale, first_step):
+    L = _lib.load()
+    _chk(p), _chk(g), _chk(buf)
+    _lib.check(L.nef_sgd_momentum(_p(p), _p(g), _p(buf), p.numel(), lr, mu, gscale, int(first_step), _stream()),
+               "nef_sgd_momentum")

@@ -1,0 +1,56 @@
+"""Data-parallel plumbing: one process per GPU, the ECG batch sharded by rank, ONE collective per step
+(sum all-reduce of the flat gradient buffer over RCCL/xGMI; backend 'nccl' is RCCL on ROCm).  Replaces the
+single-process nn.DataParallel of reference codes/solver/solver.py:32-34.  BatchNorm
+statistics stay per shard, as under DataParallel; rank 0's running statistics are authoritative."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env():
+    """Initialise torch.distributed from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
+    Returns (rank, world, local_rank).  Single-process runs need no initialisation."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(global_batch, rank, world):
+    """Contiguous equal shards; the global batch must divide evenly so that the mean of per-shard mean
+    losses equals the reference's full-batch mean (solver.py:171-188)."""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} is not divisible by world size {world}")
+    per = global_batch // world
+    return list(range(rank * per, (rank + 1) * per))
+
+
+def shard_batch(meta, rank, world):
+    n = len(next(iter(meta.values())))
+    idx = shard_indices(n, rank, world)
+    return {k: v[idx[0]:idx[-1] + 1] for k, v in meta.items()}
+
+
+def reduce_flat_grads(grads, flat):
+    """Pack `grads` into `flat` (one buffer) and sum it across ranks with a single all-reduce."""
+    torch.cat([g.reshape(-1) for g in grads], out=flat)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat)
+    return flat
+
+
+def broadcast_buffers(model, src=0):
+    """Make rank `src`'s BatchNorm running statistics authoritative (e.g. before a checkpoint)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for b in model.buffers():
+            dist.broadcast(b, src)

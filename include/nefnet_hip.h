@@ -1,0 +1,208 @@
+/* nefnet_hip.h -- C ABI of libnefnet_hip.so: the gfx950 (MI355X) kernels of the Nef-Net train step.
+ *
+ * The reference (WhatAShot/Electrocardio-Panorama) has no FFI of its own: every op below replaces an
+ * implicit PyTorch call site on the hot path, cited per entry as `codes/<file>:<line>`.  The Python
+ * host (`electrocardio_panorama_amd/network`) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates;
+ *   - activations are fp32 `[batch][channel][time]`, time contiguous; ROIs are int64 `[B][7][2]`;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises,
+ *     every entry point is re-entrant and hipGraph-capturable;
+ *   - return 0 on success, a negative NEF_E_* for a rejected call, a positive value = hipError_t.
+ */
+#ifndef NEFNET_HIP_H
+#define NEFNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEF_OK 0
+#define NEF_E_SHAPE (-1)        /* a dimension is out of the supported set */
+#define NEF_E_NULL (-2)         /* a required pointer is NULL */
+#define NEF_E_WORKSPACE (-3)    /* workspace too small */
+#define NEF_E_UNSUPPORTED (-4)  /* configuration not built */
+
+#define NEF_N_SEG 7    /* heartbeat segments per sample (codes/dataset/tianchi.py:103-106) */
+#define NEF_ROI_BINS 16 /* roi_algin size (codes/network/model_nefnet.py:136) */
+
+typedef void* nef_stream_t;
+
+/* ABI version of this header; bumped on any signature change. */
+int nef_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stem: Conv1d(1->128 per lead, k15, s2, p7, no bias) + ReLU + MaxPool1d(3,2,1), fused.
+ * Replaces codes/network/encoder/encoder.py:35-38 (resnet_1d.py:102-105).
+ *   x [B][V][L], w [128V][1][15], y [B][128V][L/4]; L % 4 == 0.
+ * bwd_weight recomputes the conv, routes gy through the pool arg-max and the ReLU.
+ *   ws: nef_stem_bwd_ws_bytes(V) bytes of scratch. */
+int nef_stem_fwd(const float* x, const float* w, float* y, int B, int V, int L, nef_stream_t stream);
+size_t nef_stem_bwd_ws_bytes(int V);
+int nef_stem_bwd_weight(const float* x, const float* w, const float* gy, float* gw, void* ws, size_t ws_bytes,
+                        int B, int V, int L, nef_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Grouped Conv1d (stride 1, odd K in {1,3,7}, pad (K-1)/2) as an implicit GEMM on fp32 MFMA.
+ * Replaces nn.Conv1d at codes/network/model_nefnet.py:18,21,32,44 and encoder/resnet_1d.py:23.
+ *
+ * nef_pack_weight: w [G*Cog][Cig][K] (torch layout) -> wp.
+ *   transpose_flip = 0: forward operand   wp[g][k][ci][co] = w[g*Cog+co][ci][k]
+ *   transpose_flip = 1: bwd-data operand  wp[g][k][co][ci] = w[g*Cog+co][ci][K-1-k]
+ */
+int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
+                    nef_stream_t stream);
+
+typedef struct nef_conv_args {
+    const float* x;        /* input  [B][..][T]; element (b, g, ci, t) at x + b*x_bs + g*x_gs + ci*T + t */
+    const float* wp;       /* packed weights [G][K][Cin_g][Cout_g] (nef_pack_weight) */
+    float* y;              /* output; element (b, g, co, t) at y + b*y_bs + g*y_gs + co*T + t */
+    const float* bias;     /* [G*Cout_g] or NULL */
+    const float* in_scale; /* NULL, or per (sample, input channel) factor at in_scale + b*sc_bs + g*sc_gs + ci */
+    const float* res;      /* NULL, or residual added before the activation, laid out like y with res_bs/res_gs */
+    const float* gate;     /* NULL, or y *= gate_scale * (gate > 0), laid out like y with gate_bs/gate_gs */
+    const uint8_t* mask;   /* NULL, or dropout keep-mask (0/1), dense [B][G*Cout_g][T]; y *= mask * drop_scale */
+    int64_t x_bs, x_gs, y_bs, y_gs, sc_bs, sc_gs, res_bs, res_gs, gate_bs, gate_gs;
+    int32_t B, T, G, Cin_g, Cout_g, K;
+    int32_t relu;          /* apply max(0, .) after bias + residual */
+    float gate_scale;
+    float drop_scale;      /* 1/(1-p); with mask == NULL and drop_p > 0 the keep-mask comes from the counter RNG */
+    float drop_p;
+    uint64_t rng_seed;     /* counter RNG: keep(b, channel, t) = hash(seed, dense index) >= p */
+} nef_conv_args;
+
+/* y = epilogue(conv(x * in_scale, wp) + bias + res).  Also the bwd-data pass (pack with transpose_flip=1,
+ * swap Cin_g/Cout_g). */
+int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream);
+
+/* gw[g*Cog+co][ci][k] = sum_{b,t} gy[b][g][co][t] * (x*in_scale)[b][g][ci][t+k-pad].  gw is overwritten.
+ * ws: nef_conv_bwd_weight_ws_bytes(...) bytes of scratch (split-K partials, reduced deterministically). */
+size_t nef_conv_bwd_weight_ws_bytes(int B, int T, int G, int Cin_g, int Cout_g, int K);
+int nef_conv_bwd_weight(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
+                        int64_t sc_gs, const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws,
+                        size_t ws_bytes, int B, int T, int G, int Cin_g, int Cout_g, int K, nef_stream_t stream);
+
+/* out[c] = sum_{b,t} x[b][c][t] (bias gradients).  ws: nef_chan_sum_ws_bytes(C). */
+size_t nef_chan_sum_ws_bytes(int C);
+int nef_chan_sum(const float* x, float* out, void* ws, size_t ws_bytes, int B, int C, int T, nef_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ConvTranspose1d(k=2, s=2, groups=G, 128 -> 64 per group, bias).  codes/network/model_nefnet.py:96-97.
+ *   x [B][G*Cig][T], w [G*Cig][Cog][2], bias [G*Cog], y [B][G*Cog][2T]. */
+int nef_convt2_fwd(const float* x, const float* w, const float* bias, float* y, int B, int G, int Cig, int Cog,
+                   int T, nef_stream_t stream);
+int nef_convt2_bwd_data(const float* gy, const float* w, float* gx, int B, int G, int Cig, int Cog, int T,
+                        nef_stream_t stream);
+size_t nef_convt2_bwd_weight_ws_bytes(int G, int Cig, int Cog);
+int nef_convt2_bwd_weight(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int B,
+                          int G, int Cig, int Cog, int T, nef_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Angular encoding + Linear(12 -> O).  codes/network/utils/theta_encoder.py:13-29 with
+ * model_nefnet.py:76-77,121,164,183.   theta [N][2], W [O][12], bias [O], y [N][O]. */
+int nef_theta_mlp_fwd(const float* theta, const float* W, const float* bias, float* y, int N, int O,
+                      nef_stream_t stream);
+int nef_theta_mlp_bwd(const float* theta, const float* gy, float* gW, float* gb, int N, int O, nef_stream_t stream);
+/* enc [N][12] only (test hook for the encoding itself). */
+int nef_theta_encode(const float* theta, float* enc, int N, nef_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-(sample, channel) scaling.  model_nefnet.py:122-123 (lead latents x mlp1) and :166,170,174,186.
+ *   y[b][c][t] = x[b][c][t] * s[b*s_bs + c];  bwd: gx = gy * s, gs[b][c] = sum_t gy * x (gs dense [B][C]). */
+int nef_chscale_fwd(const float* x, const float* s, int64_t s_bs, float* y, int B, int C, int T, nef_stream_t stream);
+int nef_chscale_bwd(const float* gy, const float* x, const float* s, int64_t s_bs, float* gx, float* gs, int B,
+                    int C, int T, nef_stream_t stream);
+
+/* out = g * scale * (ref > 0)   (ReLU / dropout back-propagation gate), n elements. */
+int nef_gate(const float* g, const float* ref, float* out, float scale, int64_t n, nef_stream_t stream);
+/* out = a + b, n elements. */
+int nef_add(const float* a, const float* b, float* out, int64_t n, nef_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ROI ops.  rois: int64 [B][7][2] in input-sample units; latent index = roi * 0.25 (model_nefnet.py:136,143).
+ * nef_roi_align_*: codes/network/utils/roi_pooling_1d.py:38-69 with the reference's actual semantics
+ *   (grid x addresses the size-1 axis).  z [B][C][T] -> out [B][C][7][16].
+ * nef_roi_unpool_*: roi_pooling_1d.py:72-99.  zseg [B][C][7][32] -> out [B][C][T].
+ *   status (int32[1], may be NULL): set to 1 if a sample's segment lengths are negative or do not sum to T. */
+int nef_roi_align_fwd(const float* z, const int64_t* rois, float* out, int B, int C, int T, nef_stream_t stream);
+int nef_roi_align_bwd(const float* gout, const int64_t* rois, float* gz, int B, int C, int T, nef_stream_t stream);
+int nef_roi_unpool_fwd(const float* zseg, const int64_t* rois, float* out, int32_t* status, int B, int C, int T,
+                       nef_stream_t stream);
+int nef_roi_unpool_bwd(const float* gout, const int64_t* rois, float* gzseg, int B, int C, int T,
+                       nef_stream_t stream);
+/* seg_start/seg_len int64 [B][7]: the integer bookkeeping of roi_pooling_1d.py:82-92 (bit-exact test hook). */
+int nef_roi_segment_table(const int64_t* rois, int64_t* seg_start, int64_t* seg_len, int B, nef_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Lead mean / Standin shuffle / query scaling.  model_nefnet.py:146-176.
+ *   z1, z2r [B][128V][T]; latent [B][256][T] = cat(mean_v z1, mean_v z2r);
+ *   q [B][256];  D [3][B][256][T]:  D0 = q*latent, D1 = q*cat(z1[c1], z2mean), D2 = q*cat(z1mean, z2r[c2]). */
+int nef_lead_mean(const float* z1, const float* z2r, float* latent, int B, int V, int T, nef_stream_t stream);
+int nef_mix_fwd(const float* latent, const float* z1, const float* z2r, const float* q, float* D, int B, int V,
+                int T, int c1, int c2, nef_stream_t stream);
+int nef_mix_bwd(const float* gD, const float* latent, const float* z1, const float* z2r, const float* q, float* gz1,
+                float* gz2r, float* gq, int B, int V, int T, int c1, int c2, nef_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Decoder pieces.  model_nefnet.py:10-27,101-107.
+ * Upsample(scale 2, linear, align_corners=False): x [N][Tin] rows -> y [N][2Tin]. */
+int nef_upsample2_fwd(const float* x, float* y, int64_t N, int Tin, nef_stream_t stream);
+int nef_upsample2_bwd(const float* gy, float* gx, int64_t N, int Tin, nef_stream_t stream);
+
+/* BatchNorm1d, training mode, P independent passes stacked along batch (x [P*Bp][C][L]).
+ * nef_bn_train_stats: per (pass, channel) batch mean / biased var -> mean, invstd [P][C], the affine
+ *   a = gamma*invstd, b = beta - mean*a [P][C]; then updates running_mean/var sequentially over passes with
+ *   momentum (unbiased var), exactly as P successive module calls would.
+ * nef_bn_eval_affine: a = gamma/sqrt(rv+eps), b = beta - rm*a  [C].
+ * nef_affine_relu_fwd: y = max(0, x*a[p][c] + b[p][c]).
+ * nef_bn_relu_bwd: given gy (grad wrt the ReLU output), x (pre-BN), writes gx, ggamma[C], gbeta[C]. */
+size_t nef_bn_ws_bytes(int P, int C);
+int nef_bn_train_stats(const float* x, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float* mean, float* invstd, float* a, float* b, void* ws, size_t ws_bytes,
+                       int P, int Bp, int C, int L, float eps, float momentum, nef_stream_t stream);
+int nef_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float* a, float* b, int C, float eps, nef_stream_t stream);
+int nef_affine_relu_fwd(const float* x, const float* a, const float* b, float* y, int P, int Bp, int C, int L,
+                        nef_stream_t stream);
+int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* invstd,
+                    const float* a, const float* b, float* gx, float* ggamma, float* gbeta, void* ws, size_t ws_bytes,
+                    int P, int Bp, int C, int L, nef_stream_t stream);
+
+/* Final Conv1d(64->1,k3,p1,bias) + sigmoid(x/3).  model_nefnet.py:106,168.
+ *   x [N][C][L], w [1][C][3], bias [1], out [N][L]. */
+int nef_outconv_fwd(const float* x, const float* w, const float* bias, float* out, int N, int C, int L,
+                    nef_stream_t stream);
+int nef_outconv_bwd_data(const float* gout, const float* out, const float* w, float* gx, int N, int C, int L,
+                         nef_stream_t stream);
+size_t nef_outconv_bwd_weight_ws_bytes(int C);
+int nef_outconv_bwd_weight(const float* gout, const float* out, const float* x, float* gw, float* gb, void* ws,
+                           size_t ws_bytes, int N, int C, int L, nef_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loss.  codes/network/loss/losses.py:21-50 (+ solver.py:185-186 noise):
+ *   l1 = mean|sg(pred)-pred_p|, l2 = mean|sg(pred)-pred_l|, l3 = mean|pred-target| (or squared, reg_l2),
+ *   losses[4] = {f0*l1 + f1*l2 + f2*l3, f0*l1, f1*l2, f2*l3};  use_mask bit i enables term i+1.
+ * bwd: gradients wrt pred (term 3 only), pred_p, pred_l scaled by gscale (d loss). */
+size_t nef_loss_ws_bytes(void);
+int nef_loss_fwd(const float* pred, const float* pred_p, const float* pred_l, const float* target, float* losses,
+                 void* ws, size_t ws_bytes, int64_t n, float f0, float f1, float f2, int reg_l2, int use_mask,
+                 nef_stream_t stream);
+int nef_loss_bwd(const float* pred, const float* pred_p, const float* pred_l, const float* target,
+                 const float* gscale /* device scalar */, float* g_pred, float* g_p, float* g_l, int64_t n, float f0,
+                 float f1, float f2, int reg_l2, int use_mask, nef_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SGD with momentum over a flat buffer.  codes/solver/optim_scheduler.py:10 (torch.optim.SGD semantics:
+ * first step buf = g, afterwards buf = mu*buf + g; p -= lr*buf).  g is multiplied by gscale first
+ * (1/world_size after an all-reduce sum). */
+int nef_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float gscale,
+                     int first_step, nef_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEFNET_HIP_H */

@@ -166,6 +166,7 @@ def roi_align_mid(z, rois, size=ROI_BINS, scale=SCALE):
                                  for j in range(n_roi)], dim=0))
     gx = torch.stack(rows, dim=0)
     grid = torch.stack([gx, torch.zeros_like(gx)], dim=3).to(z.device)
+    grid = grid.to(z.dtype)     # no-op in fp32 (the reference is fp32-only); lets tests run an fp64 yardstick
     return F.grid_sample(z.unsqueeze(-1), grid, align_corners=False)
 
 
@@ -330,7 +331,7 @@ def train_step(P, Bf, opt, batch, loss_factor=(0.5, 0.5, 1.0), loss_using=(1, 2,
         out = out + batch["noise"].unsqueeze(1)
     losses = loss_v1(out, out_p, out_l, batch["target_view"].unsqueeze(1), loss_factor, loss_using, reg_loss)
     losses[0].backward()
-    vals = [float(v) for v in losses]
+    vals = [float(v.detach()) for v in losses]
     opt.step(P)
     return vals
 

@@ -1,0 +1,109 @@
+"""CPU: C-ABI surface, config loader, module surface, synthetic batches, data-parallel plumbing (gloo, world 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    """The shared library loads and exports every function include/nefnet_hip.h declares (no compute calls)."""
+    from electrocardio_panorama_amd import _lib
+    from electrocardio_panorama_amd.csrc import build
+    build.build(verbose=False)
+    hdr = open(os.path.join(ROOT, "include", "nefnet_hip.h")).read()
+    declared = set(re.findall(r"\b(nef_[a-z0-9_]+)\s*\(", hdr)) - {"nef_conv_args", "nef_stream_t"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().nef_abi_version() == 1
+    assert ctypes.sizeof(_lib.ConvArgs) == 192
+
+
+def test_rejects_bad_calls_without_touching_the_gpu():
+    from electrocardio_panorama_amd import _lib
+    L = _lib.load()
+    assert L.nef_stem_fwd(None, None, None, 1, 1, 512, None) == -2            # NEF_E_NULL
+    assert L.nef_conv_bwd_weight_ws_bytes(2, 100, 3, 100, 128, 3) == 0        # unsupported channel count
+    assert L.nef_conv_bwd_weight_ws_bytes(2, 100, 3, 128, 128, 7) > 0
+    a = _lib.ConvArgs()
+    assert L.nef_conv_fwd(ctypes.byref(a), None) == -2
+
+
+def test_config_surface():
+    from electrocardio_panorama_amd.config import get_defaults, resolve_config_path
+    cfg = get_defaults()
+    cfg.merge_from_file(resolve_config_path("config/nef-net.yml"))        # hyphen spelling of README.md:32
+    assert cfg.SOLVER.lr == 0.1 and isinstance(cfg.SOLVER.lr, float)
+    assert cfg.SOLVER.loss_factor == [0.5, 0.5, 1] and cfg.SOLVER.lr_step == [50, 100]
+    assert cfg.DATA.lead_num == 3 and cfg.MODEL.model == "model_nefnet" and cfg.SOLVER.reg_loss == "l1_loss"
+    with pytest.raises(KeyError):
+        cfg.merge_from_list(["SOLVER.not_a_key", 1])
+    with pytest.raises(ValueError):
+        cfg.merge_from_list(["SOLVER.lr", "'text'"])
+    cfg.merge_from_list(["SOLVER.lr", "1e-2", "DATA.lead_num", 8])
+    assert cfg.SOLVER.lr == 0.01 and cfg.DATA.lead_num == 8
+
+
+def test_module_surface_on_cpu():
+    from electrocardio_panorama_amd.config import get_defaults
+    from electrocardio_panorama_amd.network import build_loss, build_model, losswrapper
+    from oracle import nefnet_oracle as orc
+    cfg = get_defaults()
+    cfg.MODEL.model = "model_nefnet"
+    cfg.DATA.lead_num = 2
+    m = build_model(cfg)
+    exp = {**orc.param_shapes(2), **orc.buffer_shapes()}
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(dict(m.named_parameters()).keys() | sd.keys()) or set(sd) == set(exp)
+    assert all(tuple(sd[k].shape) == tuple(exp[k]) for k in exp)
+    assert build_loss(cfg) is losswrapper
+    cfg.MODEL.model = "other"
+    with pytest.raises(ValueError):
+        build_model(cfg)
+    cfg.MODEL.loss = "other"
+    with pytest.raises(ValueError):
+        build_loss(cfg)
+    # no CPU path: the product refuses to compute without a HIP device
+    x = torch.zeros(1, 2, 512)
+    with pytest.raises(RuntimeError):
+        m(x, torch.zeros(1, 2, 2), torch.zeros(1, 2), torch.zeros(1, 7, 2, dtype=torch.int64))
+    # reference-style init statistics (resnet_1d.py:114-120)
+    w = sd["W_encoder.layer1.0.conv1.weight"]
+    assert abs(float(w.std()) - (2.0 / (49 * 256)) ** 0.5) < 5e-4
+
+
+def test_synthetic_batch_schema():
+    from electrocardio_panorama_amd import synth
+    b = synth.make_batch(5, 3, 5000, seed=1, Q=4)
+    assert b["data"].shape == (5, 3, 5000) and b["data"].dtype == np.float32
+    assert b["rois"].shape == (5, 7, 2) and b["rois"].dtype == np.int64
+    r = b["rois"]
+    assert (r[:, 0, 0] == 0).all() and (r[:, 6, 1] == 5000).all() and (r[:, 1:, 0] == r[:, :-1, 1]).all()
+    assert (np.diff(r.reshape(5, -1), axis=1) >= 0).all()
+    assert b["data"].min() >= 0 and b["data"].max() <= 1
+    for i in range(5):
+        assert (b["data"][i, :, r[i, 6, 0]:] == 0).all()
+    assert b["rest_theta"].shape == (5, 4, 2) and b["rest_view"].shape == (5, 4, 5000)
+    b2 = synth.make_batch(5, 3, 5000, seed=1, Q=4)
+    assert all(np.array_equal(b[k], b2[k]) for k in b)
+
+
+def test_data_parallel_plumbing_gloo_world2(tmp_path):
+    """Two CPU ranks over gloo: batch sharding covers the global batch exactly once, and the flat-gradient
+    all-reduce + 1/world averaging that FusedSGD performs matches a single-process run on the full batch."""
+    script = os.path.join(ROOT, "tests", "dp_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(tmp_path)], env=env) for r in range(2)]
+    assert all(p.wait(timeout=300) == 0 for p in procs)
+    a, b = (np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2))
+    assert np.array_equal(a["flat"], b["flat"])
+    assert np.allclose(a["flat"], a["expect"], rtol=1e-6, atol=1e-7)
+    assert sorted(np.concatenate([a["idx"], b["idx"]]).tolist()) == list(range(8))

@@ -1,0 +1,79 @@
+"""CPU: the oracle restatement reproduces the fixtures that oracle/make_golden.py captured from the reference."""
+import glob
+import os
+import random
+
+import numpy as np
+import torch
+
+from util import maxabs, rel, stats, sub
+
+
+def _batch(B, V, L, seed, Q=0):
+    from electrocardio_panorama_amd import synth
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.make_batch(B, V, L, seed=seed, Q=Q).items()}
+
+
+def test_theta_and_roi_fixtures(golden_dir):
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    z = np.load(os.path.join(golden_dir, "theta_table.npz"))
+    assert maxabs(orc.angular_encoding(torch.from_numpy(z["theta"])), z["enc"]) == 0.0
+    z = np.load(os.path.join(golden_dir, "roi_cases.npz"))
+    for name in sorted({k.split(":")[0] for k in z.files}):
+        L = int(z[f"{name}:L"])
+        rois = torch.from_numpy(z[f"{name}:rois"])
+        Bn, T, C = rois.shape[0], L // 4, 6
+        zz = torch.from_numpy(hw.unit_noise("roi-z:" + name, Bn * C * T).reshape(Bn, C, T).astype(np.float32))
+        zs = torch.from_numpy(hw.unit_noise("roi-s:" + name, Bn * C * 7 * 32).reshape(Bn, C, 7, 32).astype(np.float32))
+        start, length = orc.roi_segment_table(rois)
+        assert np.array_equal(start.numpy(), z[f"{name}:seg_start"]) and np.array_equal(length.numpy(), z[f"{name}:seg_len"])
+        assert np.array_equal(start.numpy(), z[f"{name}:rois"][..., 0] // 4)          # == rois // 4
+        assert rel(orc.roi_align_mid(zz, rois), z[f"{name}:align"]) < 1e-7
+        assert rel(orc.roi_unpool(zs, rois), z[f"{name}:unpool"]) < 1e-7
+
+
+def test_eval_fixture_small(golden_dir):
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    f = os.path.join(golden_dir, "eval_B2_V1_L512_Q5.npz")
+    z = np.load(f)
+    B, V, L, Q, seed = (int(z[k]) for k in ("B", "V", "L", "Q", "seed"))
+    b = _batch(B, V, L, seed, Q)
+    P, Bf = hw.hashed_params(V), hw.hashed_buffers()
+    with torch.no_grad():
+        random.seed(seed)
+        out = orc.forward(P, Bf, b["data"], b["input_theta"], b["target_theta"], b["rois"], rest_theta=b["rest_theta"],
+                          phase="test", training=False)
+        z1, z2 = orc.forward(P, Bf, b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="gen", training=False)
+    for got, key in zip(out, ("out", "shuf_p", "shuf_l", "rest_out")):
+        assert rel(got, z[key]) < 1e-6, key
+    assert rel(sub(z1), z["z1_sub"]) < 1e-6 and rel(stats(z2), z["z2_stats"]) < 1e-6
+
+
+def test_train_fixture_small(golden_dir):
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    z = np.load(os.path.join(golden_dir, "train_B2_V1_L512_l1_loss.npz"))
+    B, V, L, seed = (int(z[k]) for k in ("B", "V", "L", "seed"))
+    b = _batch(B, V, L, seed)
+    P, Bf = orc.require_grad(hw.hashed_params(V)), hw.hashed_buffers()
+    random.seed(seed)
+    outs = orc.forward(P, Bf, b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train", training=True,
+                       masks=hw.hashed_masks(V, B, L // 4))
+    losses = orc.loss_v1(outs[0], outs[1], outs[2], b["target_view"].unsqueeze(1))
+    losses[0].backward()
+    assert rel(outs[0], z["out"]) < 1e-6
+    assert maxabs(torch.stack([l_.detach() for l_ in losses]), z["losses"]) < 1e-6
+    for k, p in P.items():
+        if k in orc.DEAD_PARAMS:
+            assert p.grad is None
+        elif not (k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias")):
+            assert rel(sub(p.grad, 256), z["gsub:" + k]) < 1e-4, k
+    assert int(Bf["decoder.1.double_conv.1.num_batches_tracked"]) == 3
+
+
+def test_fixture_inventory(golden_dir):
+    names = {os.path.basename(f) for f in glob.glob(os.path.join(golden_dir, "*.npz"))}
+    assert {"theta_table.npz", "roi_cases.npz", "sgd_B4_V3_L512.npz"} <= names
+    assert sum(n.startswith("eval_") for n in names) >= 4 and sum(n.startswith("train_") for n in names) >= 4
