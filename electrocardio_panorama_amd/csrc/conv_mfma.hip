@@ -12,6 +12,7 @@
 #include "nef_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -83,20 +84,36 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
     const int segw = seg + K - 1;
     const int xrow = nseg * segw;
 
-    // per-thread staging coordinates along the LDS row (<= 3 positions, xrow <= 176)
-    int64_t xoff[3], soff[3];
-    bool xok[3];
+    // Staging through buffer descriptors (nef_common.h): per lane ONE byte offset per row position, rows are
+    // selected by a wave-uniform SGPR offset, out-of-range positions (halo beyond the sample, batch tail) carry
+    // NEF_OOB and read as 0.0 -- so a stage is one burst of independent loads with no branches.
+    constexpr int NIT = (K == 1) ? 2 : 3;          // xrow <= 128 (K=1) or <= 176
+    constexpr int XR = KC / 4;                     // activation rows per wave
+    constexpr int M4 = MT / 4;
+    constexpr int NW = K * KC * M4 / 256;          // float4 weight loads per thread and stage
+    constexpr int RQ = 256 / M4;                   // weight rows covered per pass of the workgroup
+    static_assert(K * KC * M4 % 256 == 0, "weight tile must split evenly over the workgroup");
+    static_assert(KC % RQ == 0, "rows per pass must divide the channel chunk");
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(a.x + (int64_t)b0 * a.x_bs + (int64_t)g * a.x_gs);
+    const __amdgpu_buffer_rsrc_t wrs = nef_rsrc(a.wp + (int64_t)g * K * Cig * Cog + m0);
+    unsigned xvo[NIT];
+    int64_t soff[NIT];
+    bool xok[NIT];
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int r = lane + 64 * it;
         const int s = r / segw;
         const int u = r - s * segw;
         const int t = t0 + u - PAD;
-        const int b = b0 + s;
-        xok[it] = (r < xrow) && (b < a.B) && (t >= 0) && (t < T);
-        xoff[it] = (int64_t)b * a.x_bs + (int64_t)g * a.x_gs + t;
-        soff[it] = (int64_t)b * a.sc_bs + (int64_t)g * a.sc_gs;
+        xok[it] = (r < xrow) && (b0 + s < a.B) && (t >= 0) && (t < T);
+        xvo[it] = xok[it] ? (unsigned)(((int64_t)s * a.x_bs + t) * 4) : NEF_OOB;
+        soff[it] = xok[it] ? (int64_t)(b0 + s) * a.sc_bs + (int64_t)g * a.sc_gs : 0;
     }
+    // weight tile: float4 index i = threadIdx.x + 256*q -> row rc = i / M4 = (kk, ci), column m4 = i % M4;
+    // (kk, ci) of load q is a compile-time offset from this thread's first row.
+    const unsigned wvo = (unsigned)(((int)(threadIdx.x / M4) * Cog + 4 * (int)(threadIdx.x % M4)) * 4);
+    const int w_kstride = Cig * Cog;
 
     // LDS column offsets of this lane's two 32-column MFMA tiles
     int coloff[2];
@@ -114,39 +131,43 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Register-staged pipeline: the loads of stage s+1 are issued before the MFMA loop of stage s and only
+    // written to LDS after it, so HBM/L2 latency hides under the matrix work (one LDS buffer, two barriers).
+    f32x4 wreg[NW];
+    float xreg[XR][NIT];
+#define NEF_ISSUE_LOADS(C0)                                                                                          \
+    {                                                                                                               \
+        _Pragma("unroll") for (int q = 0; q < NW; ++q) wreg[q] = nef_buf_f32x4(                                     \
+            wrs, wvo, (unsigned)((((q * RQ) / KC) * w_kstride + ((q * RQ) % KC + (C0)) * Cog) * 4));                 \
+        _Pragma("unroll") for (int rr = 0; rr < XR; ++rr) {                                                         \
+            const unsigned so = (unsigned)(((C0) + wave_u + 4 * rr) * T * 4);                                       \
+            _Pragma("unroll") for (int it = 0; it < NIT; ++it) xreg[rr][it] = nef_buf_f32(xrs, xvo[it], so);        \
+        }                                                                                                           \
+    }
+    NEF_ISSUE_LOADS(0)
     for (int c0 = 0; c0 < Cig; c0 += KC) {
-        __syncthreads();
-        // weights: K*KC rows of MT floats (row stride Cog in global)
-        {
-            constexpr int M4 = MT / 4;
-            float4* Wl4 = reinterpret_cast<float4*>(Wl);
-            for (int i = threadIdx.x; i < K * KC * M4; i += 256) {
-                const int m4 = i % M4;
-                const int rc = i / M4;
-                const int ci = rc % KC;
-                const int kk = rc / KC;
-                const float4* src =
-                    reinterpret_cast<const float4*>(a.wp + ((int64_t)(g * K + kk) * Cig + c0 + ci) * Cog + m0) + m4;
-                Wl4[i] = *src;
-            }
-        }
-        // activations: KC rows of the halo'd column tile
-        for (int ci = wave; ci < KC; ci += 4) {
-            const int64_t coff = (int64_t)(c0 + ci) * T;
+        if (a.in_scale) {
 #pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                const int r = lane + 64 * it;
-                if (r < xrow) {
-                    float v = 0.f;
-                    if (xok[it]) {
-                        v = a.x[xoff[it] + coff];
-                        if (a.in_scale) v *= a.in_scale[soff[it] + c0 + ci];
-                    }
-                    Xl[ci * XRS + r] = v;
+            for (int rr = 0; rr < XR; ++rr)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    xreg[rr][it] *= a.in_scale[soff[it] + (xok[it] ? c0 + wave + 4 * rr : 0)];
+        }
+        __syncthreads();                 // every wave is done reading the previous stage
+        {
+            f32x4* Wl4 = reinterpret_cast<f32x4*>(Wl);
+#pragma unroll
+            for (int q = 0; q < NW; ++q) Wl4[threadIdx.x + 256 * q] = wreg[q];
+#pragma unroll
+            for (int rr = 0; rr < XR; ++rr)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int r = lane + 64 * it;
+                    if (r < xrow) Xl[(wave + 4 * rr) * XRS + r] = xreg[rr][it];
                 }
-            }
         }
         __syncthreads();
+        if (c0 + KC < Cig) NEF_ISSUE_LOADS(c0 + KC)
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) {
 #pragma unroll 4
@@ -165,7 +186,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
         }
     }
 
-    // epilogue: bias, residual, ReLU, dropout, gate; 32 lanes store 128 contiguous bytes per row
+    // epilogue: bias, residual, ReLU, dropout, gate.  Per 32x32 tile the optional operands are fetched as 16
+    // independent loads per lane before use; 32 lanes store 128 contiguous bytes per output row.
     const int64_t ctot = (int64_t)a.G * Cog;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -174,33 +196,66 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
         const int tt = col & (seg - 1);
         const int b = b0 + s;
         const int t = t0 + tt;
-        if (b >= a.B || t >= T) continue;
+        const bool live = (b < a.B) && (t < T);
+        const int bs = live ? b : 0, ts = live ? t : 0;      // safe coordinates for the loads of dead lanes
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int cobase = m0 + (wm * TM + i) * 32 + 4 * hi;
+            float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float v = acc[i][j][r];
-                if (a.bias) v += a.bias[g * Cog + co];
-                if (a.res) v += a.res[(int64_t)b * a.res_bs + (int64_t)g * a.res_gs + (int64_t)co * T + t];
-                if (a.relu) v = fmaxf(v, 0.f);
-                if (a.mask || a.drop_p > 0.f) {
-                    const int64_t dense = ((int64_t)b * ctot + (int64_t)g * Cog + co) * T + t;
-                    if (a.mask) {
-                        v *= (float)a.mask[dense] * a.drop_scale;
-                    } else {
-                        v = (nef_rng_uniform(a.rng_seed, (uint64_t)dense) >= a.drop_p) ? v * a.drop_scale : 0.f;
-                    }
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+            if (a.bias) {
+                float t16[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t16[r] = a.bias[g * Cog + cobase + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += t16[r];
+            }
+            if (a.res) {
+                const float* rp = a.res + (int64_t)bs * a.res_bs + (int64_t)g * a.res_gs + (int64_t)cobase * T + ts;
+                float t16[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t16[r] = rp[(int64_t)((r & 3) + 8 * (r >> 2)) * T];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += t16[r];
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (a.mask) {
+                const uint8_t* mp = a.mask + ((int64_t)bs * ctot + (int64_t)g * Cog + cobase) * T + ts;
+                float t16[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t16[r] = (float)mp[(int64_t)((r & 3) + 8 * (r >> 2)) * T];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] *= t16[r] * a.drop_scale;
+            } else if (a.drop_p > 0.f) {
+                const int64_t d0 = ((int64_t)bs * ctot + (int64_t)g * Cog + cobase) * T + ts;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint64_t dense = (uint64_t)(d0 + (int64_t)((r & 3) + 8 * (r >> 2)) * T);
+                    v[r] = (nef_rng_uniform(a.rng_seed, dense) >= a.drop_p) ? v[r] * a.drop_scale : 0.f;
                 }
-                if (a.gate) {
-                    const float gt = a.gate[(int64_t)b * a.gate_bs + (int64_t)g * a.gate_gs + (int64_t)co * T + t];
-                    v = gt > 0.f ? v * a.gate_scale : 0.f;
-                }
-                a.y[(int64_t)b * a.y_bs + (int64_t)g * a.y_gs + (int64_t)co * T + t] = v;
+            }
+            if (a.gate) {
+                const float* gp = a.gate + (int64_t)bs * a.gate_bs + (int64_t)g * a.gate_gs + (int64_t)cobase * T + ts;
+                float t16[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t16[r] = gp[(int64_t)((r & 3) + 8 * (r >> 2)) * T];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = t16[r] > 0.f ? v[r] * a.gate_scale : 0.f;
+            }
+            if (live) {
+                float* yp = a.y + (int64_t)b * a.y_bs + (int64_t)g * a.y_gs + (int64_t)cobase * T + t;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yp[(int64_t)((r & 3) + 8 * (r >> 2)) * T] = v[r];
             }
         }
     }
 }
+
+#undef NEF_ISSUE_LOADS
 
 template <int K, int TM>
 static int launch_conv_fwd(const nef_conv_args& a, hipStream_t st) {
@@ -265,52 +320,68 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
 
+    // Register-staged pipeline over this workgroup's tiles: loads of tile i+1 fly during the MFMAs of tile i.
+    constexpr int GR = MT / 4;        // gY rows per wave
+    constexpr int XRW = CIT / 4;      // X rows per wave
+    float greg[GR];
+    float xreg[XRW];
+    constexpr int NH = (CIT * ((WT / 16) * (K - 1)) + 255) / 256;   // halo positions (beyond 64) per thread, upper bound
+    float xh[NH > 0 ? NH : 1];
+    const int nh = xrow - WT;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#define NEF_BW_ISSUE(TILE)                                                                                            \
+    {                                                                                                               \
+        int b0, t0;                                                                                                 \
+        if (nseg == 1) { b0 = (TILE) / tps; t0 = ((TILE) - b0 * tps) * WT; } else { b0 = (TILE) * nseg; t0 = 0; }     \
+        const __amdgpu_buffer_rsrc_t grs = nef_rsrc(gy + (int64_t)b0 * gy_bs + (int64_t)g * gy_gs + (int64_t)m0 * T); \
+        const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(x + (int64_t)b0 * x_bs + (int64_t)g * x_gs + (int64_t)c0 * T);   \
+        {                                                                                                           \
+            const int sg = lane >> seg_shift, t = t0 + (lane & (seg - 1));                                          \
+            const unsigned vo = ((b0 + sg < B) && (t < T)) ? (unsigned)(((int64_t)sg * gy_bs + t) * 4) : NEF_OOB;    \
+            _Pragma("unroll") for (int rr = 0; rr < GR; ++rr)                                                       \
+                greg[rr] = nef_buf_f32(grs, vo, (unsigned)((wave_u + 4 * rr) * T * 4));                             \
+        }                                                                                                           \
+        {   /* main 64 positions of every row: uniform row offsets */                                               \
+            const int sg = lane / segw;                                                                             \
+            const int t = t0 + (lane - sg * segw) - PAD;                                                            \
+            const bool ok = (b0 + sg < B) && (t >= 0) && (t < T);                                                   \
+            const unsigned vo = ok ? (unsigned)(((int64_t)sg * x_bs + t) * 4) : NEF_OOB;                            \
+            _Pragma("unroll") for (int rr = 0; rr < XRW; ++rr)                                                      \
+                xreg[rr] = nef_buf_f32(xrs, vo, (unsigned)((wave_u + 4 * rr) * T * 4));                             \
+            if (in_scale) {                                                                                         \
+                const int64_t so = ok ? (int64_t)(b0 + sg) * sc_bs + (int64_t)g * sc_gs + c0 : 0;                   \
+                _Pragma("unroll") for (int rr = 0; rr < XRW; ++rr) xreg[rr] *= in_scale[so + (ok ? wave + 4 * rr : 0)]; \
+            }                                                                                                       \
+        }                                                                                                           \
+        _Pragma("unroll") for (int h = 0; h < NH; ++h) {   /* the few positions beyond 64: (row, e) per lane */      \
+            const int idx = (int)threadIdx.x + 256 * h;                                                             \
+            const int row = nh > 0 ? idx / nh : 0;                                                                  \
+            const int r = 64 + idx - row * nh;                                                                      \
+            const int sg = r / segw;                                                                                \
+            const int t = t0 + (r - sg * segw) - PAD;                                                               \
+            const bool ok = (nh > 0) && (row < CIT) && (b0 + sg < B) && (t >= 0) && (t < T);                        \
+            xh[h] = nef_buf_f32(xrs, ok ? (unsigned)(((int64_t)sg * x_bs + (int64_t)row * T + t) * 4) : NEF_OOB, 0); \
+            if (in_scale && ok) xh[h] *= in_scale[(int64_t)(b0 + sg) * sc_bs + (int64_t)g * sc_gs + c0 + row];      \
+        }                                                                                                           \
+    }
+    if (split < n_tiles) NEF_BW_ISSUE(split)
     for (int tile = split; tile < n_tiles; tile += S) {
-        int b0, t0;
-        if (nseg == 1) {
-            b0 = tile / tps;
-            t0 = (tile - b0 * tps) * WT;
-        } else {
-            b0 = tile * nseg;
-            t0 = 0;
-        }
         __syncthreads();
-        // gY tile: MT rows x 64 columns (zero outside the sample / batch)
-        {
-            const int s = lane >> seg_shift;
-            const int tt = lane & (seg - 1);
-            const int b = b0 + s, t = t0 + tt;
-            const bool ok = (b < B) && (t < T);
-            const int64_t off = (int64_t)b * gy_bs + (int64_t)g * gy_gs + t;
-            for (int row = wave; row < MT; row += 4)
-                GYl[row * GYS + lane] = ok ? gy[off + (int64_t)(m0 + row) * T] : 0.f;
-        }
-        // X tile: CIT rows x halo'd columns
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int r = lane + 64 * it;
-            if (r < xrow) {
-                const int s = r / segw;
-                const int u = r - s * segw;
-                const int b = b0 + s, t = t0 + u - PAD;
-                const bool ok = (b < B) && (t >= 0) && (t < T);
-                const int64_t off = (int64_t)b * x_bs + (int64_t)g * x_gs + t;
-                const int64_t so = (int64_t)b * sc_bs + (int64_t)g * sc_gs;
-                for (int row = wave; row < CIT; row += 4) {
-                    float v = 0.f;
-                    if (ok) {
-                        v = x[off + (int64_t)(c0 + row) * T];
-                        if (in_scale) v *= in_scale[so + c0 + row];
-                    }
-                    Xl[row * XS + r] = v;
-                }
-            }
+        for (int rr = 0; rr < GR; ++rr) GYl[(wave + 4 * rr) * GYS + lane] = greg[rr];
+#pragma unroll
+        for (int rr = 0; rr < XRW; ++rr) Xl[(wave + 4 * rr) * XS + lane] = xreg[rr];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int idx = (int)threadIdx.x + 256 * h;
+            const int row = nh > 0 ? idx / nh : 0;
+            if (nh > 0 && row < CIT) Xl[row * XS + 64 + idx - row * nh] = xh[h];
         }
         __syncthreads();
+        if (tile + S < n_tiles) NEF_BW_ISSUE(tile + S)
         for (int s = 0; s < nseg; ++s) {
             const float* ga = GYl + (wco * 32 + lo) * GYS + s * seg + hi;
             const float* xb = Xl + ((wci * TCI) * 32 + lo) * XS + s * segw + hi;
-#pragma unroll 4
             for (int tt = 0; tt < seg; tt += 2) {
                 const float av = ga[tt];
 #pragma unroll
@@ -321,6 +392,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
             }
         }
     }
+#undef NEF_BW_ISSUE
     // partials: ws[split][g][k][co][ci]
 #pragma unroll
     for (int i = 0; i < TCI; ++i) {
@@ -432,9 +504,7 @@ __global__ void chan_sum_partial(const float* __restrict__ x, double* __restrict
     double s = 0.0;
     for (int b = sp; b < B; b += nsplit) {
         const float* row = x + ((int64_t)b * C + c) * T;
-        float ps = 0.f;
-        for (int t = threadIdx.x; t < T; t += blockDim.x) ps += row[t];
-        s += (double)ps;
+        for (int t = threadIdx.x; t < T; t += blockDim.x) s += (double)row[t];
     }
     s = nef_block_sum_d(s, sm);
     if (threadIdx.x == 0) part[(int64_t)sp * C + c] = s;

@@ -300,15 +300,13 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
     double s1 = 0.0, s2 = 0.0;
     for (int bb = sp; bb < Bp; bb += BN_SPLIT) {
         const int64_t off = (((int64_t)p * Bp + bb) * C + c) * L;
-        float r1 = 0.f, r2 = 0.f;
+        // accumulate in double from the first element: sum(g) cancels heavily and k1 = sum(g)/n shifts every gx
         for (int t = threadIdx.x; t < L; t += 256) {
             const float xv = x[off + t];
             const float g = fmaf(xv, af, bf) > 0.f ? gy[off + t] : 0.f;
-            r1 += g;
-            r2 = fmaf(g, (xv - mf) * is, r2);
+            s1 += (double)g;
+            s2 += (double)g * (double)((xv - mf) * is);
         }
-        s1 += (double)r1;
-        s2 += (double)r2;
     }
     s1 = nef_block_sum_d(s1, sm);
     s2 = nef_block_sum_d(s2, sm);

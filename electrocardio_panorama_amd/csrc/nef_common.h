@@ -61,3 +61,23 @@ __device__ __forceinline__ float nef_rng_uniform(uint64_t seed, uint64_t idx) {
     z = z ^ (z >> 31);
     return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Buffer-descriptor loads (gfx950 `buffer_load_* ... offen`).  One wave-uniform 128-bit descriptor per tile, a
+// 32-bit per-lane byte offset (VGPR) and a wave-uniform byte offset (SGPR): a whole tile of rows costs ONE address
+// register per lane, and lanes whose offset is NEF_OOB get 0.0 from the hardware range check -- the conv halo /
+// zero padding comes for free, with no branches around the loads.
+// ------------------------------------------------------------------------------------------------------------
+typedef unsigned nef_u32x4 __attribute__((ext_vector_type(4)));
+typedef float nef_f32x4 __attribute__((ext_vector_type(4)));
+#define NEF_OOB 0x80000000u
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t nef_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFC, 0x00020000);
+}
+__device__ __forceinline__ float nef_buf_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ nef_f32x4 nef_buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(nef_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}

@@ -200,13 +200,16 @@ def batch_norm(x, P, Bf, prefix, training):
                         P[prefix + ".weight"], P[prefix + ".bias"], training, BN_MOM, BN_EPS)
 
 
-def decoder(x, P, Bf, training):
-    """model_nefnet.py:101-107 followed by sigmoid(x / 3) (:168)."""
+def decoder(x, P, Bf, training, taps=None):
+    """model_nefnet.py:101-107 followed by sigmoid(x / 3) (:168).  `taps` (a list) collects the four post-ReLU
+    activations for diagnostics."""
     for blk in ("decoder.1", "decoder.3"):
         x = F.interpolate(x, scale_factor=2, mode="linear", align_corners=False)
         for conv, bn in (("0", "1"), ("3", "4")):
             x = F.conv1d(x, P[f"{blk}.double_conv.{conv}.weight"], P[f"{blk}.double_conv.{conv}.bias"], 1, 1)
             x = F.relu(batch_norm(x, P, Bf, f"{blk}.double_conv.{bn}", training))
+            if taps is not None:
+                taps.append(x)
     x = F.conv1d(x, P["decoder.4.weight"], P["decoder.4.bias"], 1, 1)
     return torch.sigmoid(x / 3)
 
