@@ -55,8 +55,10 @@ SIGNATURES = {
     "nef_chscale_bwd": (i32, [p, p, p, i64, p, p, i32, i32, i32, p]),
     "nef_gate": (i32, [p, p, p, f32, i64, p]),
     "nef_add": (i32, [p, p, p, i64, p]),
-    "nef_roi_align_fwd": (i32, [p, p, p, i32, i32, i32, p]),
-    "nef_roi_align_bwd": (i32, [p, p, p, i32, i32, i32, p]),
+    "nef_roi_align_fwd": (i32, [p, p, p, i32, i32, i32, i32, i32, p]),
+    "nef_roi_align_bwd": (i32, [p, p, p, i32, i32, i32, i32, i32, p]),
+    "nef_window_crop": (i32, [p, i64, i64, p, i32, i32, i32, i32, i32, i32, p]),
+    "nef_window_scatter": (i32, [p, p, i64, i64, i32, i32, i32, i32, i32, i32, p]),
     "nef_roi_unpool_fwd": (i32, [p, p, p, p, i32, i32, i32, p]),
     "nef_roi_unpool_bwd": (i32, [p, p, p, i32, i32, i32, p]),
     "nef_roi_segment_table": (i32, [p, p, p, i32, p]),

@@ -57,6 +57,36 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
         out[i] = a[i] + b[i];
 }
 
+// Time-window crop of a grouped view and its zero-filling inverse.  Used to run `z2_conv1` only on the six time samples
+// around the two rows that roi_algin reads: everything else of that block is never consumed.
+__global__ void window_crop_kernel(const float* __restrict__ src, int64_t x_bs, int64_t x_gs, float* __restrict__ dst,
+                                   int B, int G, int Cg, int T, int t0, int W) {
+    const int64_t n = (int64_t)B * G * Cg * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        int64_t r = i / W;
+        const int c = (int)(r % Cg);
+        r /= Cg;
+        const int g = (int)(r % G);
+        const int b = (int)(r / G);
+        dst[i] = src[(int64_t)b * x_bs + (int64_t)g * x_gs + (int64_t)c * T + t0 + w];
+    }
+}
+
+__global__ void window_scatter_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t y_bs, int64_t y_gs,
+                                      int B, int G, int Cg, int T, int t0, int W) {
+    const int64_t rows = (int64_t)B * G * Cg;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int c = (int)(row % Cg);
+        const int g = (int)((row / Cg) % G);
+        const int b = (int)(row / ((int64_t)Cg * G));
+        float* d = dst + (int64_t)b * y_bs + (int64_t)g * y_gs + (int64_t)c * T;
+        const float* s = src + row * W - t0;
+        for (int t = lane; t < T; t += 64) d[t] = (t >= t0 && t < t0 + W) ? s[t] : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // latent = cat(mean_v z1, mean_v z2r)          (:146-151)
 // ------------------------------------------------------------------------------------------------
@@ -580,6 +610,27 @@ int nef_add(const float* a, const float* b, float* out, int64_t n, nef_stream_t 
     NEF_REQUIRE(a && b && out, NEF_E_NULL);
     NEF_REQUIRE(n > 0, NEF_E_SHAPE);
     hipLaunchKernelGGL(add_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, a, b, out, n);
+    return nef_launch_status();
+}
+
+int nef_window_crop(const float* src, int64_t x_bs, int64_t x_gs, float* dst, int B, int G, int Cg, int T, int t0, int W,
+                    nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(src && dst, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && G > 0 && Cg > 0 && W > 0 && t0 >= 0 && t0 + W <= T, NEF_E_SHAPE);
+    const int64_t n = (int64_t)B * G * Cg * W;
+    hipLaunchKernelGGL(window_crop_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, src, x_bs, x_gs, dst, B,
+                       G, Cg, T, t0, W);
+    return nef_launch_status();
+}
+
+int nef_window_scatter(const float* src, float* dst, int64_t y_bs, int64_t y_gs, int B, int G, int Cg, int T, int t0,
+                       int W, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(src && dst, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && G > 0 && Cg > 0 && W > 0 && t0 >= 0 && t0 + W <= T, NEF_E_SHAPE);
+    hipLaunchKernelGGL(window_scatter_kernel, dim3(nef_stream_grid((int64_t)B * G * Cg, 4)), dim3(256), 0, NEF_ST, src,
+                       dst, y_bs, y_gs, B, G, Cg, T, t0, W);
     return nef_launch_status();
 }
 

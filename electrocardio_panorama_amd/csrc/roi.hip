@@ -57,8 +57,10 @@ __device__ __forceinline__ RowTap row_taps(int T) {
 }
 
 // one thread per output element; out [B][C][7][16]
+// z may hold only a window of the time axis: zT stored samples per row starting at time t_off (the two rows read
+// are the only ones roi_algin ever touches, so the producer can skip the rest -- see engine.py).
 __global__ void roi_align_fwd_kernel(const float* __restrict__ z, const int64_t* __restrict__ rois,
-                                     float* __restrict__ out, int B, int C, int T) {
+                                     float* __restrict__ out, int B, int C, int T, int zT, int t_off) {
     const int64_t n = (int64_t)B * C * NSEG * BINS;
     const RowTap rt = row_taps(T);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -67,7 +69,7 @@ __global__ void roi_align_fwd_kernel(const float* __restrict__ z, const int64_t*
         const int64_t bc = i / (BINS * NSEG);
         const int b = (int)(bc / C);
         const float wx = col_weight(grid_x(rois + (int64_t)b * NSEG * 2, j, s, T));
-        const float* zr = z + bc * T;
+        const float* zr = z + bc * zT - t_off;
         // grid_sample accumulates nw*(n*w) + ne*.. + sw*(s*w) + se*..; with W == 1 only one column is in range
         out[i] = zr[rt.r0] * (rt.w0 * wx) + zr[rt.r1] * (rt.w1 * wx);
     }
@@ -75,7 +77,7 @@ __global__ void roi_align_fwd_kernel(const float* __restrict__ z, const int64_t*
 
 // gz [B][C][T]: zero except the two middle rows
 __global__ void roi_align_bwd_kernel(const float* __restrict__ gout, const int64_t* __restrict__ rois,
-                                     float* __restrict__ gz, int B, int C, int T) {
+                                     float* __restrict__ gz, int B, int C, int T, int zT, int t_off) {
     const int64_t rows = (int64_t)B * C;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const RowTap rt = row_taps(T);
@@ -88,8 +90,8 @@ __global__ void roi_align_bwd_kernel(const float* __restrict__ gout, const int64
             acc = fmaf(gout[row * NSEG * BINS + e], wx, acc);
         }
         acc = nef_wave_sum(acc);
-        float* gr = gz + row * T;
-        for (int t = lane; t < T; t += 64) {
+        float* gr = gz + row * zT - t_off;
+        for (int t = t_off + lane; t < t_off + zT; t += 64) {
             float v = 0.f;
             if (t == rt.r0) v += acc * rt.w0;
             if (t == rt.r1 && rt.w1 != 0.f) v += acc * rt.w1;
@@ -220,21 +222,29 @@ __global__ void roi_segment_table_kernel(const int64_t* __restrict__ rois, int64
 
 extern "C" {
 
-int nef_roi_align_fwd(const float* z, const int64_t* rois, float* out, int B, int C, int T, nef_stream_t stream) {
+static bool window_covers_taps(int T, int zT, int t_off) {
+    const int r0 = (T - 1) / 2, r1 = (r0 + 1 < T) ? r0 + 1 : r0;
+    return zT > 0 && t_off >= 0 && t_off <= r0 && r1 < t_off + zT && t_off + zT <= T;
+}
+
+int nef_roi_align_fwd(const float* z, const int64_t* rois, float* out, int B, int C, int T, int zT, int t_off,
+                      nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(z && rois && out, NEF_E_NULL);
-    NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(B > 0 && C > 0 && T > 0 && window_covers_taps(T, zT, t_off), NEF_E_SHAPE);
     const int64_t n = (int64_t)B * C * NSEG * BINS;
-    hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, z, rois, out, B, C, T);
+    hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, z, rois, out, B, C, T,
+                       zT, t_off);
     return nef_launch_status();
 }
 
-int nef_roi_align_bwd(const float* gout, const int64_t* rois, float* gz, int B, int C, int T, nef_stream_t stream) {
+int nef_roi_align_bwd(const float* gout, const int64_t* rois, float* gz, int B, int C, int T, int zT, int t_off,
+                      nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(gout && rois && gz, NEF_E_NULL);
-    NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(B > 0 && C > 0 && T > 0 && window_covers_taps(T, zT, t_off), NEF_E_SHAPE);
     hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(nef_stream_grid((int64_t)B * C, 4)), dim3(256), 0, NEF_ST, gout, rois,
-                       gz, B, C, T);
+                       gz, B, C, T, zT, t_off);
     return nef_launch_status();
 }
 

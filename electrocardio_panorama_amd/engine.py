@@ -29,6 +29,14 @@ class DropCfg:
         self.masks = masks
         self.seed = seed
 
+    def windowed(self, site, t0, W):
+        """Same behaviour on a time window of `site`'s activation (replayed masks are cropped to the window)."""
+        if not self.on or self.masks is None:
+            return self
+        m = dict(self.masks)
+        m[site] = self.masks[site][:, :, t0:t0 + W].contiguous()
+        return DropCfg(True, self.p, m, self.seed)
+
     def args(self, site):
         if not self.on:
             return dict(mask=None, drop_p=0.0, drop_scale=1.0, seed=0)
@@ -147,8 +155,19 @@ def _latents(P, x, in_theta, rois, drop, save):
     ew = ops.chscale_fwd(a, e)
     enc, sv["blk_w_conv"] = block_fwd(GV.dense(ew, V), P, "w_conv.0", 3, 128, drop)
     z1, sv["blk_z1"] = block_fwd(GV.half(enc, V, 0), P, "z1_conv.0", 3, 128, drop)
-    z2c, sv["blk_z2c"] = block_fwd(GV.half(enc, V, 1), P, "z2_conv1.0", 3, 128, drop)
-    z2a = ops.roi_align_fwd(z2c, rois)                                          # [B, 128V, 7, 16]
+    # z2_conv1 feeds only roi_algin, which reads exactly two time rows: run the block on the window of
+    # six samples whose centre two are exact (k=3 twice -> 2 samples of context per side) instead of all T.
+    r0 = (T - 1) // 2
+    win = (r0 - 2, 6) if (T % 2 == 0 and r0 - 2 >= 0 and r0 + 4 <= T) else None
+    if win is not None:
+        xw = ops.window_crop(GV.half(enc, V, 1), win[0], win[1])
+        wdrop = drop.windowed("z2_conv1.0", win[0], win[1])
+        z2c, sv["blk_z2c"] = block_fwd(GV.dense(xw, V), P, "z2_conv1.0", 3, 128, wdrop)
+        z2a = ops.roi_align_fwd(z2c, rois, T, win[0])                           # [B, 128V, 7, 16]
+    else:
+        z2c, sv["blk_z2c"] = block_fwd(GV.half(enc, V, 1), P, "z2_conv1.0", 3, 128, drop)
+        z2a = ops.roi_align_fwd(z2c, rois)
+    sv["z2_win"] = win
     h0 = z2a.view(B, 128 * V * N_SEG, ROI_BINS)                                 # raw memory order
     h1, sv["blk_c20"] = block_fwd(GV.dense(h0, N_SEG * V), P, "z2_conv2.0", 3, 128, drop)
     h2 = ops.convt2_fwd(h1, P["z2_conv2.1.weight"], P["z2_conv2.1.bias"], N_SEG * V)
@@ -229,10 +248,16 @@ def backward(P, sv, g_outs):
     grads["z2_conv2.1.weight"], grads["z2_conv2.1.bias"] = gwt, gbt
     gh1 = ops.convt2_bwd_data(gh2, P["z2_conv2.1.weight"], N_SEG * V)
     gh0 = block_bwd(sv["blk_c20"], gh1, P, grads)
-    gz2c = ops.roi_align_bwd(gh0.view(B, 128 * V, N_SEG, ROI_BINS), sv["rois"], T)
     genc = torch.empty(B, 128 * V, T, device=gz1.device, dtype=torch.float32)
     block_bwd(sv["blk_z1"], gz1, P, grads, out=GV.half(genc, V, 0))
-    block_bwd(sv["blk_z2c"], gz2c, P, grads, out=GV.half(genc, V, 1))
+    win = sv["z2_win"]
+    if win is not None:
+        gz2c = ops.roi_align_bwd(gh0.view(B, 128 * V, N_SEG, ROI_BINS), sv["rois"], T, win[1], win[0])
+        gxw = block_bwd(sv["blk_z2c"], gz2c, P, grads)                           # [B, 64V, 6]
+        ops.window_scatter(gxw, GV.half(genc, V, 1), win[0])
+    else:
+        gz2c = ops.roi_align_bwd(gh0.view(B, 128 * V, N_SEG, ROI_BINS), sv["rois"], T)
+        block_bwd(sv["blk_z2c"], gz2c, P, grads, out=GV.half(genc, V, 1))
     gew = block_bwd(sv["blk_w_conv"], genc, P, grads)
     g, ge = ops.chscale_bwd(gew, sv["w"], sv["e"])
     gW1, gb1 = ops.theta_mlp_bwd(sv["in_theta"], ge, 128)

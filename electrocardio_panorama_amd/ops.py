@@ -273,22 +273,42 @@ def add(a, b):
 
 
 # ------------------------------------------------------------------ ROI ops
-def roi_align_fwd(z, rois):
+def roi_align_fwd(z, rois, T=None, t_off=0):
+    """z [B,C,T], or a time window of it [B,C,zT] that starts at `t_off` of a length-`T` axis."""
     L = _lib.load()
     _chk(z), _chk(rois, torch.int64)
-    B, Ct, T = z.shape
+    B, Ct, zT = z.shape
+    T = zT if T is None else T
     out = torch.empty(B, Ct, N_SEG, ROI_BINS, device=z.device, dtype=torch.float32)
-    _lib.check(L.nef_roi_align_fwd(_p(z), _p(rois), _p(out), B, Ct, T, _stream()), "nef_roi_align_fwd")
+    _lib.check(L.nef_roi_align_fwd(_p(z), _p(rois), _p(out), B, Ct, T, zT, t_off, _stream()), "nef_roi_align_fwd")
     return out
 
 
-def roi_align_bwd(gout, rois, T):
+def roi_align_bwd(gout, rois, T, zT=None, t_off=0):
+    """Gradient wrt z; with (zT, t_off) only that time window is produced (everything outside it is zero)."""
     L = _lib.load()
     _chk(gout), _chk(rois, torch.int64)
     B, Ct = gout.shape[0], gout.shape[1]
-    gz = torch.empty(B, Ct, T, device=gout.device, dtype=torch.float32)
-    _lib.check(L.nef_roi_align_bwd(_p(gout), _p(rois), _p(gz), B, Ct, T, _stream()), "nef_roi_align_bwd")
+    zT = T if zT is None else zT
+    gz = torch.empty(B, Ct, zT, device=gout.device, dtype=torch.float32)
+    _lib.check(L.nef_roi_align_bwd(_p(gout), _p(rois), _p(gz), B, Ct, T, zT, t_off, _stream()), "nef_roi_align_bwd")
     return gz
+
+
+def window_crop(xv, t0, W):
+    """Dense [B, G*Cg, W] copy of the time window [t0, t0+W) of a grouped view."""
+    L = _lib.load()
+    dst = torch.empty(xv.B, xv.G * xv.Cg, W, device=xv.t.device, dtype=torch.float32)
+    _lib.check(L.nef_window_crop(xv.ptr, xv.bs, xv.gs, _p(dst), xv.B, xv.G, xv.Cg, xv.T, t0, W, _stream()), "nef_window_crop")
+    return dst
+
+
+def window_scatter(src, outv, t0):
+    """Write `src` [B, G*Cg, W] into the window [t0, t0+W) of the grouped view `outv`, zero everywhere else."""
+    L = _lib.load()
+    _chk(src)
+    _lib.check(L.nef_window_scatter(_p(src), outv.ptr, outv.bs, outv.gs, outv.B, outv.G, outv.Cg, outv.T, t0,
+                                    src.shape[2], _stream()), "nef_window_scatter")
 
 
 def roi_unpool_fwd(zseg, rois, T, status=None):

@@ -17,12 +17,19 @@ def init_from_env():
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if torch.cuda.is_available():
+        backend = os.environ.get("NEF_DIST_BACKEND")          # test hook: "gloo" lets two ranks share one GPU
+        if os.environ.get("NEF_SHARE_GPU") == "1":
+            local = 0
+        if torch.cuda.is_available() and backend != "gloo":
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local))
         else:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local)
             dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif os.environ.get("NEF_SHARE_GPU") == "1":
+        local = 0
     return rank, world, local
 
 

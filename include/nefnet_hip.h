@@ -33,7 +33,7 @@ extern "C" {
 typedef void* nef_stream_t;
 
 /* ABI version of this header; bumped on any signature change. */
-int nef_abi_version(void);
+int nef_abi_version(void);   /* 2 */
 
 /* ---------------------------------------------------------------------------------------------
  * Stem: Conv1d(1->128 per lead, k15, s2, p7, no bias) + ReLU + MaxPool1d(3,2,1), fused.
@@ -121,15 +121,25 @@ int nef_chscale_bwd(const float* gy, const float* x, const float* s, int64_t s_b
 int nef_gate(const float* g, const float* ref, float* out, float scale, int64_t n, nef_stream_t stream);
 /* out = a + b, n elements. */
 int nef_add(const float* a, const float* b, float* out, int64_t n, nef_stream_t stream);
+/* Time-window copy of a grouped view: dst [B][G*Cg][W] dense <- src(b,g,c, t0 + w)  (src strides x_bs / x_gs, rows T). */
+int nef_window_crop(const float* src, int64_t x_bs, int64_t x_gs, float* dst, int B, int G, int Cg, int T, int t0, int W,
+                    nef_stream_t stream);
+/* Inverse: dst(b,g,c,t) = (t0 <= t < t0+W) ? src[b][g*Cg+c][t-t0] : 0 over the whole grouped view (zero fill). */
+int nef_window_scatter(const float* src, float* dst, int64_t y_bs, int64_t y_gs, int B, int G, int Cg, int T, int t0,
+                       int W, nef_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * ROI ops.  rois: int64 [B][7][2] in input-sample units; latent index = roi * 0.25 (model_nefnet.py:136,143).
  * nef_roi_align_*: codes/network/utils/roi_pooling_1d.py:38-69 with the reference's actual semantics
- *   (grid x addresses the size-1 axis).  z [B][C][T] -> out [B][C][7][16].
+ *   (grid x addresses the size-1 axis).  z [B][C][T] -> out [B][C][7][16].  Only the two middle rows of
+ *   time are ever read, so z / gz may store just a window: zT samples per row starting at time t_off (zT=T, t_off=0
+ *   for a full tensor); the window must contain rows (T-1)/2 and (T-1)/2+1.
  * nef_roi_unpool_*: roi_pooling_1d.py:72-99.  zseg [B][C][7][32] -> out [B][C][T].
  *   status (int32[1], may be NULL): set to 1 if a sample's segment lengths are negative or do not sum to T. */
-int nef_roi_align_fwd(const float* z, const int64_t* rois, float* out, int B, int C, int T, nef_stream_t stream);
-int nef_roi_align_bwd(const float* gout, const int64_t* rois, float* gz, int B, int C, int T, nef_stream_t stream);
+int nef_roi_align_fwd(const float* z, const int64_t* rois, float* out, int B, int C, int T, int zT, int t_off,
+                      nef_stream_t stream);
+int nef_roi_align_bwd(const float* gout, const int64_t* rois, float* gz, int B, int C, int T, int zT, int t_off,
+                      nef_stream_t stream);
 int nef_roi_unpool_fwd(const float* zseg, const int64_t* rois, float* out, int32_t* status, int B, int C, int T,
                        nef_stream_t stream);
 int nef_roi_unpool_bwd(const float* gout, const int64_t* rois, float* gzseg, int B, int C, int T,

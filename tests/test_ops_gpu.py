@@ -229,6 +229,32 @@ def test_roi_backward_and_status():
         ref.backward(gy)
         assert rel(o.roi_unpool_fwd(g(zs.detach()), g(rois), T), ref) < 1e-6
         assert rel(o.roi_unpool_bwd(g(gy), g(rois)), zs.grad) < 1e-5
+    # windowed storage of z / gz and the crop / scatter pair
+    from electrocardio_panorama_amd.ops import GV
+    L, B, C = 1000, 3, 6
+    T = L // 4
+    rois = torch.from_numpy(synth.make_rois(rng, B, L))
+    z = rnd(B, 2 * C, T, seed=70)
+    t0, W = (T - 1) // 2 - 2, 6
+    half = z.view(B, 2, C, T)[:, 1]
+    zw = o.window_crop(GV(g(z), B, 2, C, T, 2 * C * T, C * T, 0), t0, W)
+    assert torch.equal(zw.cpu(), z[:, :, t0:t0 + W])
+    assert rel(o.roi_align_fwd(zw, g(rois), T, t0), orc.roi_align_mid(z, rois)) < 1e-6
+    gy = rnd(B, 2 * C, 7, 16, seed=71)
+    full = o.roi_align_bwd(g(gy), g(rois), T)
+    part = o.roi_align_bwd(g(gy), g(rois), T, W, t0)
+    assert torch.equal(full[:, :, t0:t0 + W], part)
+    outside = full.clone()
+    outside[:, :, t0:t0 + W] = 0
+    assert float(outside.abs().max()) == 0.0
+    dst = torch.full((B, 2 * (2 * C), T), 7.0, device=DEV)                      # two halves per group, like the z split
+    o.window_scatter(part, GV(dst, B, 2, C, T, 4 * C * T, 2 * C * T, C * T), t0)
+    got = dst.cpu().view(B, 2, 2, C, T)
+    assert torch.all(got[:, :, 0] == 7.0)
+    assert torch.equal(got[:, :, 1, :, t0:t0 + W].reshape(B, 2 * C, W), part.cpu())
+    rest = got[:, :, 1].clone()
+    rest[..., t0:t0 + W] = 0
+    assert float(rest.abs().max()) == 0.0
     bad = torch.tensor([[[0, 100], [100, 90], [90, 200], [200, 300], [300, 400], [400, 450], [450, 500]]])
     status = torch.zeros(1, dtype=torch.int32, device=DEV)
     o.roi_unpool_fwd(g(rnd(1, 2, 7, 32)), g(bad), 128, status)
