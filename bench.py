@@ -131,10 +131,14 @@ def main():
     final_loss = float(loss.item())
 
     if rank == 0:
-        # dominant kernel: conv_fwd_kernel<K=7> over the encoder's [B,128V,T] activations (forward AND bwd-data)
+        # dominant kernel: conv_fwd_kernel<K=7> over the encoder's [B,128V,T] activations.  The same kernel runs the
+        # forward (6 launches/step) and the backward-data pass (6 launches/step).  In the backward pass it shares the
+        # matrix pipes with the bwd-weight kernels that run concurrently on the side stream, so its own speed is read
+        # from the forward launches of the timed region; the all-launch average is reported next to it.
         T = L // 4
         key = ("conv_fwd", 7, V, 128, 128, B, T)
         times = [s.elapsed_time(e) for tag, s, e in prof if tag == key]
+        times_bd = [s.elapsed_time(e) for tag, s, e in prof if tag == ("conv_bwd_data",) + key[1:]]
         flops = 2.0 * B * (128 * V) * T * 128 * 7
         roof = None
         if times:
@@ -144,12 +148,14 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("conv_fwd_k7_bytes_per_launch")
+            alg_bytes = 4.0 * (2 * B * 128 * V * T + 128 * V * 128 * 7)
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "kernel": "conv_fwd_kernel<7,2> (k7 grouped conv, fwd + bwd-data)", "launches": len(times),
-                    "avg_ms": round(avg_ms, 4), "flops_per_launch": flops,
-                    "algorithmic_bytes_per_launch": 4.0 * (2 * B * 128 * V * T + 128 * V * 128 * 7),
-                    "hbm_GBps": round(4.0 * (2 * B * 128 * V * T + 128 * V * 128 * 7) / (avg_ms * 1e-3) / 1e9, 1)}
+                    "kernel": "conv_fwd_kernel<7,2> (k7 grouped conv), forward launches", "launches": len(times),
+                    "avg_ms": round(avg_ms, 4), "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+                    "hbm_GBps": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1),
+                    "avg_ms_bwd_data_launches_overlapped": round(sum(times_bd) / max(len(times_bd), 1), 4),
+                    "side_stream": os.environ.get("NEF_SIDE_STREAM", "1") != "0"}
         by_kernel = {}
         for tag, s, e in prof:
             by_kernel.setdefault(tag, []).append(s.elapsed_time(e))

@@ -6,6 +6,8 @@ records the tensors the backward needs, and one explicit backward that walks the
 reverse.  Parameters and BatchNorm buffers are addressed by the reference's state_dict names.
 All arithmetic happens in libnefnet_hip.so; this file only sequences launches.
 """
+import os
+
 import torch
 
 from . import ops
@@ -63,26 +65,35 @@ def block_fwd(xv, P, prefix, K, Cog, drop):
     return y, (xv, h, y, prefix, K, Cog, res_conv, drop.scale)
 
 
-def block_bwd(saved, gy, P, grads, out=None):
+def _side(device):
+    return ops.SideStream.get(device) if os.environ.get("NEF_SIDE_STREAM", "1") != "0" else ops._Inline()
+
+
+def block_bwd(saved, gy, P, grads, out=None, side=None):
     """Accumulates the block's parameter gradients into `grads`; returns the gradient wrt the block input
-    (written into the GV `out` when given, e.g. one half of the z1/z2 split)."""
+    (written into the GV `out` when given, e.g. one half of the z1/z2 split).  Weight / bias gradients are issued on
+    the side stream: they are off the dependency chain and overlap with the chain's HBM-bound kernels."""
     xv, h, y, prefix, K, Cog, res_conv, dscale = saved
+    side = side or ops._Inline()
     G, Cig = xv.G, xv.Cg
     g2 = ops.gate(gy, y)                                     # through the final ReLU
     g2v, hv = GV.dense(g2, G), GV.dense(h, G)
-    grads[prefix + ".conv2.weight"] = ops.conv_bwd_weight(hv, g2v, K)
+    grads[prefix + ".conv2.weight"] = side.run(lambda: ops.conv_bwd_weight(hv, g2v, K), h, g2)
     # through conv2, then dropout and the inner ReLU: h > 0 <=> ReLU active and kept
-    gc1 = ops.conv(g2v, ops.pack_weight(P[prefix + ".conv2.weight"], G, flip=True), Cog, K, gate=hv, gate_scale=dscale)
+    gc1 = ops.conv(g2v, ops.pack_weight(P[prefix + ".conv2.weight"], G, flip=True), Cog, K, gate=hv, gate_scale=dscale,
+                   role="conv_bwd_data")
     gc1v = GV.dense(gc1, G)
-    grads[prefix + ".conv1.weight"] = ops.conv_bwd_weight(xv, gc1v, K)
+    grads[prefix + ".conv1.weight"] = side.run(lambda: ops.conv_bwd_weight(xv, gc1v, K), xv.t, gc1)
     if res_conv:
-        grads[prefix + ".residual_conv.weight"] = ops.conv_bwd_weight(xv, g2v, 1)
-        grads[prefix + ".residual_conv.bias"] = ops.chan_sum(g2)
-        gres = ops.conv(g2v, ops.pack_weight(P[prefix + ".residual_conv.weight"], G, flip=True), Cig, 1)
+        grads[prefix + ".residual_conv.weight"] = side.run(lambda: ops.conv_bwd_weight(xv, g2v, 1), xv.t, g2)
+        grads[prefix + ".residual_conv.bias"] = side.run(lambda: ops.chan_sum(g2), g2)
+        gres = ops.conv(g2v, ops.pack_weight(P[prefix + ".residual_conv.weight"], G, flip=True), Cig, 1,
+                        role="conv_bwd_data")
         resv = GV.dense(gres, G)
     else:
         resv = g2v
-    return ops.conv(gc1v, ops.pack_weight(P[prefix + ".conv1.weight"], G, flip=True), Cig, K, res=resv, out=out)
+    return ops.conv(gc1v, ops.pack_weight(P[prefix + ".conv1.weight"], G, flip=True), Cig, K, res=resv, out=out,
+                    role="conv_bwd_data")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -118,10 +129,11 @@ def decoder_fwd(D, P, Bf, passes, training, save):
     return out, (saved, x, out, passes)
 
 
-def decoder_bwd(dsaved, g_out, P, grads):
+def decoder_bwd(dsaved, g_out, P, grads, side=None):
     saved, a4, out, passes = dsaved
-    gw, gb = ops.outconv_bwd_weight(g_out, out, a4)
-    grads["decoder.4.weight"], grads["decoder.4.bias"] = gw, gb
+    side = side or ops._Inline()
+    grads["decoder.4.weight"], grads["decoder.4.bias"] = side.run(lambda: ops.outconv_bwd_weight(g_out, out, a4),
+                                                                  g_out, out, a4)
     g = ops.outconv_bwd_data(g_out, out, P["decoder.4.weight"], a4.shape[1])
     for li in (3, 2, 1, 0):
         blk, cv, bn, cout = _DEC[li]
@@ -130,9 +142,9 @@ def decoder_bwd(dsaved, g_out, P, grads):
         gc, gg, gbeta = ops.bn_relu_bwd(g, c, P[pre + ".weight"], mean, invstd, a, b, passes)
         grads[pre + ".weight"], grads[pre + ".bias"] = gg, gbeta
         gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
-        grads[wname] = ops.conv_bwd_weight(xv, gcv, 3)
-        grads[bname] = ops.chan_sum(gc)
-        g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True), x.shape[1], 3)
+        grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3), x, gc)
+        grads[bname] = side.run(lambda: ops.chan_sum(gc), gc)
+        g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True), x.shape[1], 3, role="conv_bwd_data")
         if li in (0, 2):
             g = ops.upsample2_bwd(g)
     return g
@@ -237,34 +249,36 @@ def backward(P, sv, g_outs):
     like = sv["dec"][2]
     parts = [g if g is not None else torch.zeros_like(like[0:B]) for g in g_outs]
     g_out = torch.cat([p_.contiguous() for p_ in parts], dim=0)
-    gD = decoder_bwd(sv["dec"], g_out, P, grads)
+    side = _side(g_out.device)
+    gD = decoder_bwd(sv["dec"], g_out, P, grads, side)
     c1, c2 = sv["choice"]
     gz1, gz2r, gq = ops.mix_bwd(gD, sv["latent"], sv["z1"], sv["z2r"], sv["q"], V, c1, c2)
-    gW2, gb2 = ops.theta_mlp_bwd(sv["q_theta"], gq, 256)
+    gW2, gb2 = side.run(lambda: ops.theta_mlp_bwd(sv["q_theta"], gq, 256), gq)
     gz2b = ops.roi_unpool_bwd(gz2r, sv["rois"])                                  # [B, 128V, 7, 32]
     gh3 = gz2b.view(B, 128 * V * N_SEG, 2 * ROI_BINS)
-    gh2 = block_bwd(sv["blk_c22"], gh3, P, grads)
-    gwt, gbt = ops.convt2_bwd_weight(sv["h1"], gh2, N_SEG * V)
+    gh2 = block_bwd(sv["blk_c22"], gh3, P, grads, side=side)
+    gwt, gbt = side.run(lambda: ops.convt2_bwd_weight(sv["h1"], gh2, N_SEG * V), sv["h1"], gh2)
     grads["z2_conv2.1.weight"], grads["z2_conv2.1.bias"] = gwt, gbt
     gh1 = ops.convt2_bwd_data(gh2, P["z2_conv2.1.weight"], N_SEG * V)
-    gh0 = block_bwd(sv["blk_c20"], gh1, P, grads)
+    gh0 = block_bwd(sv["blk_c20"], gh1, P, grads, side=side)
     genc = torch.empty(B, 128 * V, T, device=gz1.device, dtype=torch.float32)
-    block_bwd(sv["blk_z1"], gz1, P, grads, out=GV.half(genc, V, 0))
+    block_bwd(sv["blk_z1"], gz1, P, grads, out=GV.half(genc, V, 0), side=side)
     win = sv["z2_win"]
     if win is not None:
         gz2c = ops.roi_align_bwd(gh0.view(B, 128 * V, N_SEG, ROI_BINS), sv["rois"], T, win[1], win[0])
-        gxw = block_bwd(sv["blk_z2c"], gz2c, P, grads)                           # [B, 64V, 6]
+        gxw = block_bwd(sv["blk_z2c"], gz2c, P, grads, side=side)                # [B, 64V, 6]
         ops.window_scatter(gxw, GV.half(genc, V, 1), win[0])
     else:
         gz2c = ops.roi_align_bwd(gh0.view(B, 128 * V, N_SEG, ROI_BINS), sv["rois"], T)
-        block_bwd(sv["blk_z2c"], gz2c, P, grads, out=GV.half(genc, V, 1))
-    gew = block_bwd(sv["blk_w_conv"], genc, P, grads)
+        block_bwd(sv["blk_z2c"], gz2c, P, grads, out=GV.half(genc, V, 1), side=side)
+    gew = block_bwd(sv["blk_w_conv"], genc, P, grads, side=side)
     g, ge = ops.chscale_bwd(gew, sv["w"], sv["e"])
-    gW1, gb1 = ops.theta_mlp_bwd(sv["in_theta"], ge, 128)
+    gW1, gb1 = side.run(lambda: ops.theta_mlp_bwd(sv["in_theta"], ge, 128), ge)
     # mlp2 is also used by nothing else in train phase; mlp1/mlp2 grads
     grads["mlp1.weight"], grads["mlp1.bias"] = gW1, gb1
     grads["mlp2.weight"], grads["mlp2.bias"] = gW2, gb2
     for i in (2, 1, 0):
-        g = block_bwd(sv["blk_enc"][i], g, P, grads)
+        g = block_bwd(sv["blk_enc"][i], g, P, grads, side=side)
     grads["W_encoder.conv1.weight"] = ops.stem_bwd_weight(sv["x"], P["W_encoder.conv1.weight"], g)
+    side.join()
     return grads

@@ -43,13 +43,64 @@ def _timed(tag):
 
 
 def workspace(nbytes, device):
-    """Caller-owned scratch, grown on demand, reused by stream-ordered calls."""
-    key = (device.type, device.index)
+    """Caller-owned scratch, grown on demand, reused by stream-ordered calls (one buffer per stream)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     cur = _WS.get(key)
     if cur is None or cur.numel() < nbytes:
         cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = cur
     return cur
+
+
+class SideStream:
+    """A second HIP stream for work that is off the critical dependency chain of the backward pass (weight and bias
+    gradients are only needed by the optimiser).  The MFMA-bound bwd-weight kernels then overlap with the HBM-bound
+    elementwise kernels of the main chain instead of queueing behind them.  Tensors crossing streams are registered
+    with the caching allocator (`record_stream`) so their memory is not recycled while the other stream still uses it."""
+
+    _cache = {}
+
+    def __init__(self, device):
+        self.device = device
+        self.stream = torch.cuda.Stream(device)
+        self.outputs = []
+
+    @classmethod
+    def get(cls, device):
+        key = (device.type, device.index)
+        if key not in cls._cache:
+            cls._cache[key] = cls(device)
+        return cls._cache[key]
+
+    def run(self, fn, *inputs):
+        """Run fn() on the side stream once everything enqueued so far on the current stream is done."""
+        main = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(main)
+        for t in inputs:
+            if t is not None:
+                t.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            out = fn()
+        self.outputs.extend(out if isinstance(out, (tuple, list)) else [out])
+        return out
+
+    def join(self):
+        """Make the current stream wait for the side stream and hand its outputs over."""
+        main = torch.cuda.current_stream(self.device)
+        main.wait_stream(self.stream)
+        for t in self.outputs:
+            t.record_stream(main)
+        self.outputs = []
+
+
+class _Inline:
+    """Same interface, everything on the current stream (NEF_SIDE_STREAM=0)."""
+
+    def run(self, fn, *inputs):
+        return fn()
+
+    def join(self):
+        pass
 
 
 class GV:
@@ -111,7 +162,7 @@ def pack_weight(w, G, flip=False):
 
 
 def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None, gate_scale=1.0, relu=False,
-         mask=None, drop_p=0.0, drop_scale=1.0, seed=0):
+         mask=None, drop_p=0.0, drop_scale=1.0, seed=0, role="conv_fwd"):
     """out = epilogue(conv1d(x * in_scale, w) + bias + res).  `xv`, `res`, `gate`, `out` are GV views;
     `in_scale` is (tensor, batch_stride, group_stride).  Returns the output tensor."""
     L = _lib.load()
@@ -135,7 +186,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     a.B, a.T, a.G, a.Cin_g, a.Cout_g, a.K = xv.B, xv.T, xv.G, xv.Cg, Cog, K
     a.relu = int(relu)
     a.gate_scale, a.drop_scale, a.drop_p, a.rng_seed = gate_scale, drop_scale, drop_p, seed
-    ev = _timed(("conv_fwd", K, xv.G, xv.Cg, Cog, xv.B, xv.T))
+    ev = _timed((role, K, xv.G, xv.Cg, Cog, xv.B, xv.T))
     _lib.check(L.nef_conv_fwd(C.byref(a), _stream()), "nef_conv_fwd")
     if ev is not None:
         ev.record()
