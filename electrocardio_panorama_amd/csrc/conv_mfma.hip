@@ -168,21 +168,41 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
         }
         __syncthreads();
         if (c0 + KC < Cig) NEF_ISSUE_LOADS(c0 + KC)
+        // MFMA loop, software-pipelined in registers: the LDS fragments of k-step group gi+1 are read while the
+        // MFMAs of group gi issue (fully unrolled, so every register index is static), one ds_read per MFMA slot.
+        {
+            constexpr int GS = 4;                       // k-steps (of 2 channels) per group
+            constexpr int SPK = KC / 2;                 // k-steps per tap
+            constexpr int NG = K * SPK / GS;
+            static_assert((K * SPK) % GS == 0, "k-steps must split into whole groups");
+            float fa[2][GS][TM], fb[2][GS][2];
+#define NEF_LOAD_GROUP(GI, BUF)                                                                                      \
+    _Pragma("unroll") for (int s_ = 0; s_ < GS; ++s_) {                                                             \
+        const int step_ = (GI) * GS + s_;                                                                           \
+        const int kk_ = step_ / SPK, c_ = (step_ % SPK) * 2;                                                        \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                              \
+            fa[BUF][s_][i] = Wl[(kk_ * KC + c_ + hi) * MT + (wm * TM + i) * 32 + lo];                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) fb[BUF][s_][j] = Xl[(c_ + hi) * XRS + coloff[j] + kk_];       \
+    }
+            NEF_LOAD_GROUP(0, 0)
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) {
-#pragma unroll 4
-            for (int c = 0; c < KC; c += 2) {
-                float av[TM], bv[2];
+            for (int gi = 0; gi < NG; ++gi) {
+                if (gi + 1 < NG) NEF_LOAD_GROUP(gi + 1, (gi + 1) & 1)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) av[i] = Wl[(kk * KC + c + hi) * MT + (wm * TM + i) * 32 + lo];
+                for (int s_ = 0; s_ < GS; ++s_)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bv[j] = Xl[(c + hi) * XRS + coloff[j] + kk];
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gi & 1][s_][i], fb[gi & 1][s_][j],
+                                                                             acc[i][j], 0, 0, 0);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int q = 0; q < GS * (TM + 2); ++q) {      // interleave: one MFMA, one LDS read
+                    __builtin_amdgcn_sched_group_barrier(0x008, (2 * TM * GS) / (GS * (TM + 2)) > 0 ? 1 : 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
+#undef NEF_LOAD_GROUP
         }
     }
 
@@ -379,17 +399,42 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
         }
         __syncthreads();
         if (tile + S < n_tiles) NEF_BW_ISSUE(tile + S)
-        for (int s = 0; s < nseg; ++s) {
-            const float* ga = GYl + (wco * 32 + lo) * GYS + s * seg + hi;
-            const float* xb = Xl + ((wci * TCI) * 32 + lo) * XS + s * segw + hi;
-            for (int tt = 0; tt < seg; tt += 2) {
-                const float av = ga[tt];
+        // 32 reduction steps (2 columns each) per 64-column tile, software-pipelined like the forward kernel: the
+        // fragments of step group gi+1 are read from LDS while the MFMAs of group gi issue.  Column 2*step of the
+        // gY tile is linear; in the X tile every sample segment carries K-1 halo columns.
+        {
+            constexpr int GS = 2;
+            constexpr int NG = (WT / 2) / GS;
+            const float* ga = GYl + (wco * 32 + lo) * GYS + hi;
+            const float* xb = Xl + ((wci * TCI) * 32 + lo) * XS + hi;
+            float fa[2][GS], fb[2][GS][TCI][K];
+#define NEF_BW_LOAD(GI, BUF)                                                                                         \
+    _Pragma("unroll") for (int s_ = 0; s_ < GS; ++s_) {                                                             \
+        const int col_ = 2 * ((GI) * GS + s_);                                                                      \
+        const int xo_ = col_ + (col_ >> seg_shift) * (K - 1);                                                       \
+        fa[BUF][s_] = ga[col_];                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < TCI; ++i)                                                             \
+            _Pragma("unroll") for (int k = 0; k < K; ++k) fb[BUF][s_][i][k] = xb[i * 32 * XS + xo_ + k];            \
+    }
+            NEF_BW_LOAD(0, 0)
 #pragma unroll
-                for (int i = 0; i < TCI; ++i)
+            for (int gi = 0; gi < NG; ++gi) {
+                if (gi + 1 < NG) NEF_BW_LOAD(gi + 1, (gi + 1) & 1)
 #pragma unroll
-                    for (int k = 0; k < K; ++k)
-                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xb[i * 32 * XS + tt + k], acc[i][k], 0, 0, 0);
+                for (int s_ = 0; s_ < GS; ++s_)
+#pragma unroll
+                    for (int i = 0; i < TCI; ++i)
+#pragma unroll
+                        for (int k = 0; k < K; ++k)
+                            acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gi & 1][s_], fb[gi & 1][s_][i][k],
+                                                                             acc[i][k], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < GS * TCI * K; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
+#undef NEF_BW_LOAD
         }
     }
 #undef NEF_BW_ISSUE

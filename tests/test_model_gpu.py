@@ -270,3 +270,50 @@ def test_properties_at_long_sequences():
     fd = float(lp - lm) / (2 * eps)
     an = float((g1[k] * d).sum())
     assert abs(fd - an) < 0.05 * abs(an) + 1e-6, (fd, an)
+
+
+@pytest.mark.parametrize("B,V,L,Q,phase", [
+    (4, 1, 2048, 0, "train"),      # BASELINE configs[0] shape: batch 4, 1 lead, len 2048
+    (2, 8, 5000, 0, "train"),      # configs[2] shape (Tianchi 8-lead, len 5000), small batch
+    (2, 1, 512, 360, "test"),      # configs[3] shape: 1 view in -> 360 queried angles
+    (2, 3, 5000, 12, "test"),      # configs[4]-like: long sequences through the sweep / gen_ecg path
+])
+def test_baseline_config_shapes_vs_oracle(B, V, L, Q, phase):
+    """The BASELINE.json configurations, at batch sizes the CPU oracle finishes in seconds: outputs (and for the train
+    shapes the flat gradient) against the oracle run live on the same seeded inputs."""
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    seed = 100 + V + Q
+    b = batch_t(B, V, L, seed, Q, dev="cpu")
+    if phase == "train":
+        m, outs, losses = _train_once(V, B, L, seed, "l1_loss", False)
+        P, Bf = orc.require_grad(hw.hashed_params(V)), hw.hashed_buffers()
+        random.seed(seed)
+        ref = orc.forward(P, Bf, b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train", training=True,
+                          p=0.0)
+        rl = orc.loss_v1(ref[0], ref[1], ref[2], b["target_view"].unsqueeze(1))
+        rl[0].backward()
+        for a, r in zip(outs, ref):
+            assert rel(a, r) < FWD_TOL
+        assert maxabs(torch.stack([l_.detach() for l_ in losses]), torch.stack([r.detach() for r in rl])) < 1e-6
+        live = [k for k in P if k not in orc.DEAD_PARAMS]
+        named = dict(m.named_parameters())
+        got = torch.cat([named[k].grad.reshape(-1).cpu() for k in live])
+        want = torch.cat([P[k].grad.reshape(-1) for k in live])
+        assert rel(got, want) < LOOSE, rel(got, want)
+    else:
+        m = hashed_model(V).eval()
+        bd = {k: v.to(DEV) for k, v in b.items()}
+        random.seed(seed)
+        outs = m(bd["data"], bd["input_theta"], bd["target_theta"], bd["rois"], rest_theta=bd["rest_theta"], phase="test")
+        P, Bf = hw.hashed_params(V), hw.hashed_buffers()
+        with torch.no_grad():
+            random.seed(seed)
+            ref = orc.forward(P, Bf, b["data"], b["input_theta"], b["target_theta"], b["rois"], rest_theta=b["rest_theta"],
+                              phase="test", training=False)
+        assert outs[3].shape == (B, Q, L)
+        for a, r in zip(outs, ref):
+            assert rel(a, r) < FWD_TOL, rel(a, r)
+        z1, z2 = m(bd["data"], bd["input_theta"], bd["target_theta"], bd["rois"], phase="gen")
+        gen = m.gen_ecg(z1, z2, bd["rest_theta"], bd["rois"])
+        assert rel(gen, ref[3]) < FWD_TOL

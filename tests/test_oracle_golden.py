@@ -77,3 +77,19 @@ def test_fixture_inventory(golden_dir):
     names = {os.path.basename(f) for f in glob.glob(os.path.join(golden_dir, "*.npz"))}
     assert {"theta_table.npz", "roi_cases.npz", "sgd_B4_V3_L512.npz"} <= names
     assert sum(n.startswith("eval_") for n in names) >= 4 and sum(n.startswith("train_") for n in names) >= 4
+
+
+def test_baseline_config0_cpu_plumbing():
+    """BASELINE.json configs[0]: nef_net.yml surface on CPU, synthetic 12-lead-table batch=4 len=2048, 1 input view ->
+    1 target view: the oracle trains for two steps and the loss goes down (plumbing check, no GPU)."""
+    from oracle import nefnet_oracle as orc
+    b = _batch(4, 1, 2048, seed=7)
+    P, Bf = orc.require_grad(orc.reference_style_init(1, seed=123)), orc.fresh_buffers()
+    opt = orc.SGDState(0.1)
+    random.seed(0)
+    l0 = orc.train_step(P, Bf, opt, b, p=0.0)
+    l1 = orc.train_step(P, Bf, opt, b, p=0.0)
+    l2 = orc.train_step(P, Bf, opt, b, p=0.0)
+    assert all(np.isfinite(v) for v in l0 + l1 + l2) and l2[0] < l0[0]
+    assert l0[1] == 0.0 and l0[2] == 0.0          # one lead: the Standin passes equal the prediction
+    assert int(Bf["decoder.3.double_conv.4.num_batches_tracked"]) == 9
