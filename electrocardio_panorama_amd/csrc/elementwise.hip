@@ -300,6 +300,18 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const flo
     b[c] = beta[c] - rm[c] * af;
 }
 
+// eval-mode BatchNorm folded into the preceding conv: w'[co][..] = a[co] * w[co][..], bias' = a * bias + b
+__global__ void fold_bn_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ a,
+                               const float* __restrict__ b, float* __restrict__ w_out, float* __restrict__ bias_out,
+                               int Cout, int inner) {
+    const int64_t n = (int64_t)Cout * inner;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i / inner);
+        w_out[i] = a[co] * w[i];
+        if (i % inner == 0) bias_out[co] = a[co] * bias[co] + b[co];
+    }
+}
+
 __global__ void affine_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
                                        const float* __restrict__ b, float* __restrict__ y, int P, int Bp, int C,
                                        int L) {
@@ -703,6 +715,16 @@ int nef_bn_eval_affine(const float* gamma, const float* beta, const float* runni
     NEF_REQUIRE(C > 0, NEF_E_SHAPE);
     hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, gamma, beta, running_mean,
                        running_var, a, b, C, eps);
+    return nef_launch_status();
+}
+
+int nef_fold_bn(const float* w, const float* bias, const float* a, const float* b, float* w_out, float* bias_out,
+                int Cout, int inner, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(w && bias && a && b && w_out && bias_out, NEF_E_NULL);
+    NEF_REQUIRE(Cout > 0 && inner > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(fold_bn_kernel, dim3(nef_stream_grid((int64_t)Cout * inner, 256)), dim3(256), 0, NEF_ST, w, bias,
+                       a, b, w_out, bias_out, Cout, inner);
     return nef_launch_status();
 }
 

@@ -220,6 +220,8 @@ def forward(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", t
 def sweep(P, Bf, latent, query_thetas, training=False, chunk=8):
     """Decode `latent` [B,256,T] at Q query angles [B,Q,2] -> [B,Q,L] (model_nefnet.py:181-190, :207-216).
     In training mode each angle is its own BatchNorm pass, in the reference's order."""
+    if not training:
+        return sweep_eval(P, Bf, latent, query_thetas, chunk)
     B, Q = query_thetas.shape[0], query_thetas.shape[1]
     rq = ops.theta_mlp_fwd(query_thetas, P["mlp2.weight"], P["mlp2.bias"])       # [B, Q, 256]
     L = latent.shape[2] * 4
@@ -231,6 +233,39 @@ def sweep(P, Bf, latent, query_thetas, training=False, chunk=8):
             Dq[i * B:(i + 1) * B] = ops.chscale_fwd(latent, rq[:, q0 + i].contiguous())
         o, _ = decoder_fwd(Dq, P, Bf, n, training, False)                         # [n*B, 1, L]
         rest[:, q0:q0 + n] = o.view(n, B, L).transpose(0, 1)
+    return rest
+
+
+def sweep_eval(P, Bf, latent, query_thetas, chunk=8):
+    """Eval-mode sweep (the panorama): BatchNorm is a fixed affine, so it is folded into the conv weights once per
+    call; the per-angle scaling commutes with the x2 upsampling, so the latent is upsampled once and the first conv
+    applies q[b, angle, :] while staging its input -- no per-angle elementwise passes at all."""
+    B, Q, T = query_thetas.shape[0], query_thetas.shape[1], latent.shape[2]
+    dev = latent.device
+    rq = ops.theta_mlp_fwd(query_thetas, P["mlp2.weight"], P["mlp2.bias"])       # [B, Q, 256]
+    u = ops.upsample2_fwd(latent)                                                 # [B, 256, 2T], shared by all angles
+    wp, bias = [], []
+    for blk, cv, bn, cout in _DEC:
+        pre = f"{blk}.double_conv.{bn}"
+        a, b = ops.bn_eval_affine(P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
+                                  Bf[pre + ".running_var"], BN_EPS)
+        wf, bf_ = ops.fold_bn(P[f"{blk}.double_conv.{cv}.weight"], P[f"{blk}.double_conv.{cv}.bias"], a, b)
+        wp.append(ops.pack_weight(wf, 1))
+        bias.append(bf_)
+    uv = GV.dense(u, 1)
+    rest = torch.empty(B, Q, 4 * T, device=dev, dtype=torch.float32)
+    for q0 in range(0, Q, chunk):
+        n = min(chunk, Q - q0)
+        c1 = torch.empty(n * B, 128, 2 * T, device=dev, dtype=torch.float32)
+        for i in range(n):
+            ops.conv(uv, wp[0], 128, 3, bias=bias[0], relu=True, in_scale=(rq[:, q0 + i], Q * 256, 0),
+                     out=GV.dense(c1[i * B:(i + 1) * B], 1))
+        c2 = ops.conv(GV.dense(c1, 1), wp[1], 128, 3, bias=bias[1], relu=True)
+        u2 = ops.upsample2_fwd(c2)
+        c3 = ops.conv(GV.dense(u2, 1), wp[2], 64, 3, bias=bias[2], relu=True)
+        c4 = ops.conv(GV.dense(c3, 1), wp[3], 64, 3, bias=bias[3], relu=True)
+        o = ops.outconv_fwd(c4, P["decoder.4.weight"], P["decoder.4.bias"])       # [n*B, 1, L]
+        rest[:, q0:q0 + n] = o.view(n, B, 4 * T).transpose(0, 1)
     return rest
 
 

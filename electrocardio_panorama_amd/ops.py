@@ -463,6 +463,16 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps=1e-5):
     return a, b
 
 
+def fold_bn(w, bias, a, b):
+    """(a[co]*w[co], a*bias+b): eval-mode BatchNorm folded into the conv that feeds it."""
+    L = _lib.load()
+    _chk(w), _chk(bias)
+    wf, bf = torch.empty_like(w), torch.empty_like(bias)
+    _lib.check(L.nef_fold_bn(_p(w), _p(bias), _p(a), _p(b), _p(wf), _p(bf), w.shape[0], w.numel() // w.shape[0], _stream()),
+               "nef_fold_bn")
+    return wf, bf
+
+
 def affine_relu_fwd(x, a, b, P):
     L = _lib.load()
     _chk(x)

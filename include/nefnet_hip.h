@@ -33,7 +33,7 @@ extern "C" {
 typedef void* nef_stream_t;
 
 /* ABI version of this header; bumped on any signature change. */
-int nef_abi_version(void);   /* 2 */
+int nef_abi_version(void);   /* 3 */
 
 /* ---------------------------------------------------------------------------------------------
  * Stem: Conv1d(1->128 per lead, k15, s2, p7, no bias) + ReLU + MaxPool1d(3,2,1), fused.
@@ -176,6 +176,10 @@ int nef_bn_train_stats(const float* x, const float* gamma, const float* beta, fl
                        int P, int Bp, int C, int L, float eps, float momentum, nef_stream_t stream);
 int nef_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float* a, float* b, int C, float eps, nef_stream_t stream);
+/* Eval-mode BN folded into the preceding conv (inference sweep): w_out[co][:] = a[co]*w[co][:], bias_out = a*bias + b;
+ * w [Cout][inner]. */
+int nef_fold_bn(const float* w, const float* bias, const float* a, const float* b, float* w_out, float* bias_out,
+                int Cout, int inner, nef_stream_t stream);
 int nef_affine_relu_fwd(const float* x, const float* a, const float* b, float* y, int P, int Bp, int C, int L,
                         nef_stream_t stream);
 int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* invstd,
