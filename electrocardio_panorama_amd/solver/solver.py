@@ -3,8 +3,9 @@
 Scope: the train-phase body of `run_one_epoch` -- H2D of the meta dict,
 model call, losswrapper, backward, optimiser step -- runs entirely on the device with no per-iteration
 host synchronisation (the reference issues ~10 D2H copies per step, solver.py:179,189,236-240; here the
-four loss scalars stay on the device and are fetched once per epoch).  The epoch driver around it
-(`train`, test-phase metrics) is kept runnable but minimal: PSNR only, no SSIM/TensorBoard."""
+four loss scalars stay on the device and are fetched once per epoch).  The test phase reproduces the reference's
+metric bookkeeping (solver.py:190-230): `loss_unsperv` on the last four rest views, PSNR / SSIM split into generated
+(`gen`, the last `gen_num` rest views) and regressed (`reg`) leads, plus per-lead numbers; TensorBoard is optional."""
 import os
 
 import numpy as np
@@ -13,17 +14,8 @@ import torch.distributed as dist
 
 from ..network import build_model, build_loss
 from ..utils import CheckPointer
+from ..utils.metric import PSNR, SSIM
 from .optim_scheduler import get_optimizer, get_lr_scheduler
-
-
-def _psnr(pred, gt, rois=None):
-    """utils/mertic.py:7-21: mean over samples of 10*log10(1/mse) on the un-padded region."""
-    vals = []
-    for i in range(pred.shape[0]):
-        end = int(rois[i, -1, 0]) if rois is not None else pred.shape[-1]
-        mse = float(np.mean((pred[i, ..., :end] - gt[i, ..., :end]) ** 2))
-        vals.append(10 * np.log10(1.0 / max(mse, 1e-12)))
-    return float(np.mean(vals))
 
 
 class Solver:
@@ -84,6 +76,7 @@ class Solver:
         else:
             raise ValueError('phase param not found.')
         dev_losses, gt_views, predict_views, input_views, rest_views, mertics_all, rois_all = [], [], [], [], [], [], []
+        mertics_gen_singlelead = []
         for meta in dl:
             source_data, rois, input_theta, target_view, target_theta, noise = self._to_device(meta)
             rest_theta = torch.as_tensor(meta['rest_theta']).to(self.device) if 'rest_theta' in meta else None
@@ -107,8 +100,23 @@ class Solver:
                                    rest_view[:, -4:, :].contiguous())
                 dev_losses.append(torch.stack([l_.detach() for l_ in losses]))
                 ro, rv, rn = rest_out.cpu().numpy(), rest_view.cpu().numpy(), rois.cpu().numpy()
-                p_ = _psnr(ro, rv, rn)
-                mertics_all.append([p_, p_, 0.0, 0.0])
+                # which rest views are "generated" (never supervised): solver.py:197-201
+                gen_num = 6 if self.cfg.DATA.lead_num == 336 else 4
+                super_mode = str(self.cfg.DATA.get('super_mode', 'normal'))
+                if super_mode != 'normal' and super_mode[-1].isdigit():
+                    gen_num = int(super_mode[-1])
+                if self.cfg.DATA.get('dataset', 'tianchi') == 'mit' or super_mode[-1] == '0' or super_mode == '_mit':
+                    psnr_gen = psnr_reg = PSNR(ro, rv)
+                    ssim_gen = ssim_reg = SSIM(ro, rv)
+                else:
+                    psnr_gen, psnr_reg = PSNR(ro[:, -gen_num:], rv[:, -gen_num:], rn), PSNR(ro[:, :-gen_num], rv[:, :-gen_num], rn)
+                    ssim_gen, ssim_reg = SSIM(ro[:, -gen_num:], rv[:, -gen_num:], rn), SSIM(ro[:, :-gen_num], rv[:, :-gen_num], rn)
+                    single = []
+                    for i in range(gen_num):
+                        k = ro.shape[1] - gen_num + i
+                        single.append([PSNR(ro[:, k:k + 1], rv[:, k:k + 1], rn), SSIM(ro[:, k:k + 1], rv[:, k:k + 1], rn)])
+                    mertics_gen_singlelead.append(single)
+                mertics_all.append([psnr_gen, psnr_reg, ssim_gen, ssim_reg])
                 predict_views += [x for x in ro]
                 rest_views += [x for x in rv]
             if self.collect_views:
@@ -118,4 +126,4 @@ class Solver:
         losses = torch.stack(dev_losses).cpu().numpy().tolist() if dev_losses else []
         if phase == 'train':
             return losses, gt_views, predict_views, input_views, mertics_all, rois_all
-        return losses, rest_views, predict_views, input_views, mertics_all, rois_all, []
+        return losses, rest_views, predict_views, input_views, mertics_all, rois_all, mertics_gen_singlelead

@@ -317,3 +317,38 @@ def test_baseline_config_shapes_vs_oracle(B, V, L, Q, phase):
         z1, z2 = m(bd["data"], bd["input_theta"], bd["target_theta"], bd["rois"], phase="gen")
         gen = m.gen_ecg(z1, z2, bd["rest_theta"], bd["rois"])
         assert rel(gen, ref[3]) < FWD_TOL
+
+
+def test_solver_test_phase_vs_oracle():
+    """Solver.run_one_epoch(phase='test') (reference solver.py:190-230): five losses incl. loss_unsperv on the last four
+    rest views, PSNR/SSIM bookkeeping; values against the oracle on the same batches."""
+    from electrocardio_panorama_amd import synth
+    from electrocardio_panorama_amd.solver import Solver
+    from electrocardio_panorama_amd.utils.metric import PSNR, SSIM
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    V, B, L, Q = 3, 3, 512, 6
+    cfg = make_cfg(V)
+    cfg.DATA["super_mode"] = "IIv2v5_v4I_372"        # gen_num = 2 (reference solver.py:198-199)
+    cfg.DATA["dataset"] = "tianchi"
+    sol = Solver(cfg, use_tensorboardx=False)
+    sol.model.load_state_dict({**hw.hashed_params(V), **hw.hashed_buffers()})
+    batches = [synth.make_batch(B, V, L, seed=40 + s, Q=Q) for s in range(2)]
+    random.seed(5)
+    losses, rest_views, predict_views, _, mertics_all, _, single = sol.run_one_epoch(batches, "test")
+    assert len(losses) == 2 and len(losses[0]) == 5 and len(mertics_all) == 2 and len(single) == 2 and len(single[0]) == 2
+    P, Bf = hw.hashed_params(V), hw.hashed_buffers()
+    random.seed(5)
+    for i, meta in enumerate(batches):
+        b = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in meta.items()}
+        with torch.no_grad():
+            o = orc.forward(P, Bf, b["data"], b["input_theta"], b["target_theta"], b["rois"], rest_theta=b["rest_theta"],
+                            phase="test", training=False)
+            ref = orc.loss_v1(o[0], o[1], o[2], b["target_view"].unsqueeze(1), rest_out=o[3][:, -4:],
+                              rest_view=b["rest_view"][:, -4:].float())
+        assert np.abs(np.array(losses[i]) - np.array([float(v) for v in ref])).max() < 2e-6
+        ro, rv, rn = o[3].numpy(), meta["rest_view"], meta["rois"]
+        want = [PSNR(ro[:, -2:], rv[:, -2:], rn), PSNR(ro[:, :-2], rv[:, :-2], rn), SSIM(ro[:, -2:], rv[:, -2:], rn),
+                SSIM(ro[:, :-2], rv[:, :-2], rn)]
+        assert np.abs(np.array(mertics_all[i]) - np.array(want)).max() < 1e-3
+    assert len(predict_views) == 2 * B and predict_views[0].shape == (Q, L)
