@@ -72,7 +72,8 @@ SIGNATURES = {
     "nef_bn_eval_affine": (i32, [p, p, p, p, p, p, i32, f32, p]),
     "nef_fold_bn": (i32, [p, p, p, p, p, p, i32, i32, p]),
     "nef_affine_relu_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, p]),
-    "nef_bn_relu_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p]),
+    "nef_bn_bwd_ws_bytes": (sz, [i32, i32, i32]),
+    "nef_bn_relu_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p]),
     "nef_outconv_fwd": (i32, [p, p, p, p, i32, i32, i32, p]),
     "nef_outconv_bwd_data": (i32, [p, p, p, p, i32, i32, i32, p]),
     "nef_outconv_bwd_weight_ws_bytes": (sz, [i32]),

@@ -465,8 +465,17 @@ __global__ void conv_bwd_weight_reduce(const float* __restrict__ ws, float* __re
         r /= Cog;
         const int k = (int)(r % K);
         const int g = (int)(r / K);
+        // fixed summation order (deterministic); loads issued eight at a time so they overlap
         float s = 0.f;
-        for (int sp = 0; sp < S; ++sp) s += ws[(int64_t)sp * n + i];
+        int sp = 0;
+        for (; sp + 8 <= S; sp += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(int64_t)(sp + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; sp < S; ++sp) s += ws[(int64_t)sp * n + i];
         gw[(((int64_t)g * Cog + co) * Cig + ci) * K + k] = s;
     }
 }
@@ -569,7 +578,7 @@ constexpr int CHAN_SUM_SPLIT = 16;
 
 extern "C" {
 
-int nef_abi_version(void) { return 3; }
+int nef_abi_version(void) { return 4; }
 
 int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                     nef_stream_t stream) {

@@ -191,31 +191,49 @@ __global__ void upsample2_fwd_kernel(const float* __restrict__ x, float* __restr
     }
 }
 
-// transpose of the above: gx[m] = sum of the (<=4) outputs that read x[m]
+// transpose of the above.  x[m] is read by outputs 2m-1 (weight .25), 2m (.75), 2m+1 (.75), 2m+2 (.25); the first and
+// the last sample of a row also collect the clamped edge taps.  Lane m loads the pair (g[2m], g[2m+1]) as one 8-byte
+// access (fully coalesced) and takes g[2m-1] / g[2m+2] from its neighbours with wave shuffles.
+__device__ __forceinline__ float up2_bwd_edge(const float* __restrict__ gr, int Tin, int m) {
+    const int To = 2 * Tin;
+    float s = 0.f;
+#pragma unroll
+    for (int d = -1; d <= 2; ++d) {
+        const int i = 2 * m + d;
+        if (i < 0 || i >= To) continue;
+        float src = 0.5f * ((float)i + 0.5f) - 0.5f;
+        if (src < 0.f) src = 0.f;
+        int i0 = (int)src;
+        if (i0 > Tin - 1) i0 = Tin - 1;
+        const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+        const float l1 = src - (float)i0;
+        const float l0 = 1.f - l1;
+        const float g = gr[i];
+        if (i0 == m) s += l0 * g;
+        if (i1 == m) s += l1 * g;
+    }
+    return s;
+}
+
 __global__ void upsample2_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int64_t N, int Tin) {
     const int To = 2 * Tin;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
         const float* gr = gy + row * To;
         float* gxr = gx + row * Tin;
-        for (int m = lane; m < Tin; m += 64) {
-            float s = 0.f;
-            // candidates: outputs 2m-2 .. 2m+2 can reference x[m]
-#pragma unroll
-            for (int d = -2; d <= 2; ++d) {
-                const int i = 2 * m + d;
-                if (i < 0 || i >= To) continue;
-                float src = 0.5f * ((float)i + 0.5f) - 0.5f;
-                if (src < 0.f) src = 0.f;
-                int i0 = (int)src;
-                if (i0 > Tin - 1) i0 = Tin - 1;
-                const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
-                const float l1 = src - (float)i0;
-                const float l0 = 1.f - l1;
-                const float g = gr[i];
-                if (i0 == m) s += l0 * g;
-                if (i1 == m) s += l1 * g;
-            }
+        for (int m0 = 0; m0 < Tin; m0 += 64) {
+            const int m = m0 + lane;
+            const bool in = m < Tin;
+            float2 v = make_float2(0.f, 0.f);
+            if (in) v = *reinterpret_cast<const float2*>(gr + 2 * m);
+            float left = __shfl_up(v.y, 1, 64);       // g[2m-1] from lane-1
+            float right = __shfl_down(v.x, 1, 64);    // g[2m+2] from lane+1
+            if (!in) continue;
+            if (lane == 0 && m > 0) left = gr[2 * m - 1];
+            if (lane == 63 && m + 1 < Tin) right = gr[2 * m + 2];
+            float s;
+            if (m == 0 || m == Tin - 1) s = up2_bwd_edge(gr, Tin, m);
+            else s = 0.25f * left + 0.75f * v.x + 0.75f * v.y + 0.25f * right;
             gxr[m] = s;
         }
     }
@@ -382,7 +400,8 @@ __global__ void bn_bwd_final(const double* __restrict__ part, float* __restrict_
 
 __global__ void bn_bwd_apply(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
                              const float* __restrict__ invstd, const float* __restrict__ a, const float* __restrict__ b,
-                             const float* __restrict__ coef, float* __restrict__ gx, int P, int Bp, int C, int L) {
+                             const float* __restrict__ coef, float* __restrict__ gx, double* __restrict__ rowsum, int P,
+                             int Bp, int C, int L) {
     const int64_t rows = (int64_t)P * Bp * C;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
@@ -394,12 +413,28 @@ __global__ void bn_bwd_apply(const float* __restrict__ gy, const float* __restri
         const float* xr = x + row * L;
         const float* gr = gy + row * L;
         float* gxr = gx + row * L;
+        double rs = 0.0;
         for (int t = lane; t < L; t += 64) {
             const float xv = xr[t];
             const float g = fmaf(xv, af, bf) > 0.f ? gr[t] : 0.f;
-            gxr[t] = af * (g - k1 - (xv - mf) * is * k2);
+            const float o = af * (g - k1 - (xv - mf) * is * k2);
+            gxr[t] = o;
+            rs += (double)o;
+        }
+        if (rowsum) {                      // per-row sum of gx: the bias gradient of the conv feeding this BN
+            rs = nef_wave_sum_d(rs);
+            if (lane == 0) rowsum[row] = rs;
         }
     }
+}
+
+// out[c] = sum over rows (p, b) of rowsum[(p*Bp + b)*C + c]   (fixed order)
+__global__ void rowsum_to_channel(const double* __restrict__ rowsum, float* __restrict__ out, int NB, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int n = 0; n < NB; ++n) s += rowsum[(int64_t)n * C + c];
+    out[c] = (float)s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -738,22 +773,28 @@ int nef_affine_relu_fwd(const float* x, const float* a, const float* b, float* y
     return nef_launch_status();
 }
 
+size_t nef_bn_bwd_ws_bytes(int P, int Bp, int C) { return nef_bn_ws_bytes(P, C) + (size_t)P * Bp * C * sizeof(double); }
+
 int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* invstd,
-                    const float* a, const float* b, float* gx, float* ggamma, float* gbeta, void* ws, size_t ws_bytes,
-                    int P, int Bp, int C, int L, nef_stream_t stream) {
+                    const float* a, const float* b, float* gx, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
+                    size_t ws_bytes, int P, int Bp, int C, int L, nef_stream_t stream) {
     NEF_ENTER();
     (void)gamma;
     NEF_REQUIRE(gy && x && mean && invstd && a && b && gx && ggamma && gbeta && ws, NEF_E_NULL);
     NEF_REQUIRE(P > 0 && Bp > 0 && C > 0 && L > 0, NEF_E_SHAPE);
-    NEF_REQUIRE(ws_bytes >= nef_bn_ws_bytes(P, C), NEF_E_WORKSPACE);
+    NEF_REQUIRE(ws_bytes >= nef_bn_bwd_ws_bytes(P, Bp, C), NEF_E_WORKSPACE);
     double* part = (double*)ws;
     float* coef = (float*)((char*)ws + (size_t)P * C * BN_SPLIT * 2 * sizeof(double));
+    double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(P, C)) : nullptr;
     hipLaunchKernelGGL(bn_bwd_partial, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part, P,
                        Bp, C, L);
     hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma, gbeta,
                        P, Bp, C, L);
     hipLaunchKernelGGL(bn_bwd_apply, dim3(nef_stream_grid((int64_t)P * Bp * C, 4)), dim3(256), 0, NEF_ST, gy, x, mean,
-                       invstd, a, b, (const float*)coef, gx, P, Bp, C, L);
+                       invstd, a, b, (const float*)coef, gx, rowsum, P, Bp, C, L);
+    if (gx_chan_sum)
+        hipLaunchKernelGGL(rowsum_to_channel, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)rowsum,
+                           gx_chan_sum, P * Bp, C);
     return nef_launch_status();
 }
 

@@ -69,14 +69,16 @@ def _side(device):
     return ops.SideStream.get(device) if os.environ.get("NEF_SIDE_STREAM", "1") != "0" else ops._Inline()
 
 
-def block_bwd(saved, gy, P, grads, out=None, side=None):
+def block_bwd(saved, gy, P, grads, out=None, side=None, pre_gated=False, gate_input=False):
     """Accumulates the block's parameter gradients into `grads`; returns the gradient wrt the block input
     (written into the GV `out` when given, e.g. one half of the z1/z2 split).  Weight / bias gradients are issued on
-    the side stream: they are off the dependency chain and overlap with the chain's HBM-bound kernels."""
+    the side stream: they are off the dependency chain and overlap with the chain's HBM-bound kernels.
+    `gate_input`: the block input is itself a ReLU output whose producer would mask this gradient first thing in its own
+    backward -- apply that mask in the epilogue of the last conv here; the producer is then called with `pre_gated`."""
     xv, h, y, prefix, K, Cog, res_conv, dscale = saved
     side = side or ops._Inline()
     G, Cig = xv.G, xv.Cg
-    g2 = ops.gate(gy, y)                                     # through the final ReLU
+    g2 = gy if pre_gated else ops.gate(gy, y)                # through the final ReLU
     g2v, hv = GV.dense(g2, G), GV.dense(h, G)
     grads[prefix + ".conv2.weight"] = side.run(lambda: ops.conv_bwd_weight(hv, g2v, K), h, g2)
     # through conv2, then dropout and the inner ReLU: h > 0 <=> ReLU active and kept
@@ -93,7 +95,7 @@ def block_bwd(saved, gy, P, grads, out=None, side=None):
     else:
         resv = g2v
     return ops.conv(gc1v, ops.pack_weight(P[prefix + ".conv1.weight"], G, flip=True), Cig, K, res=resv, out=out,
-                    role="conv_bwd_data")
+                    gate=xv if gate_input else None, gate_scale=1.0, role="conv_bwd_data")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -139,11 +141,10 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
         blk, cv, bn, cout = _DEC[li]
         x, c, mean, invstd, a, b = saved[li]
         wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
-        gc, gg, gbeta = ops.bn_relu_bwd(g, c, P[pre + ".weight"], mean, invstd, a, b, passes)
-        grads[pre + ".weight"], grads[pre + ".bias"] = gg, gbeta
+        gc, gg, gbeta, gbias = ops.bn_relu_bwd(g, c, P[pre + ".weight"], mean, invstd, a, b, passes, with_chan_sum=True)
+        grads[pre + ".weight"], grads[pre + ".bias"], grads[bname] = gg, gbeta, gbias
         gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
         grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3), x, gc)
-        grads[bname] = side.run(lambda: ops.chan_sum(gc), gc)
         g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True), x.shape[1], 3, role="conv_bwd_data")
         if li in (0, 2):
             g = ops.upsample2_bwd(g)
@@ -297,23 +298,24 @@ def backward(P, sv, g_outs):
     gh1 = ops.convt2_bwd_data(gh2, P["z2_conv2.1.weight"], N_SEG * V)
     gh0 = block_bwd(sv["blk_c20"], gh1, P, grads, side=side)
     genc = torch.empty(B, 128 * V, T, device=gz1.device, dtype=torch.float32)
-    block_bwd(sv["blk_z1"], gz1, P, grads, out=GV.half(genc, V, 0), side=side)
+    # z1_conv / z2_conv1 read the ReLU output of w_conv: they mask their input gradient with it, w_conv skips its gate
+    block_bwd(sv["blk_z1"], gz1, P, grads, out=GV.half(genc, V, 0), side=side, gate_input=True)
     win = sv["z2_win"]
     if win is not None:
         gz2c = ops.roi_align_bwd(gh0.view(B, 128 * V, N_SEG, ROI_BINS), sv["rois"], T, win[1], win[0])
-        gxw = block_bwd(sv["blk_z2c"], gz2c, P, grads, side=side)                # [B, 64V, 6]
+        gxw = block_bwd(sv["blk_z2c"], gz2c, P, grads, side=side, gate_input=True)   # [B, 64V, 6]
         ops.window_scatter(gxw, GV.half(genc, V, 1), win[0])
     else:
         gz2c = ops.roi_align_bwd(gh0.view(B, 128 * V, N_SEG, ROI_BINS), sv["rois"], T)
-        block_bwd(sv["blk_z2c"], gz2c, P, grads, out=GV.half(genc, V, 1), side=side)
-    gew = block_bwd(sv["blk_w_conv"], genc, P, grads, side=side)
+        block_bwd(sv["blk_z2c"], gz2c, P, grads, out=GV.half(genc, V, 1), side=side, gate_input=True)
+    gew = block_bwd(sv["blk_w_conv"], genc, P, grads, side=side, pre_gated=True)
     g, ge = ops.chscale_bwd(gew, sv["w"], sv["e"])
     gW1, gb1 = side.run(lambda: ops.theta_mlp_bwd(sv["in_theta"], ge, 128), ge)
     # mlp2 is also used by nothing else in train phase; mlp1/mlp2 grads
     grads["mlp1.weight"], grads["mlp1.bias"] = gW1, gb1
     grads["mlp2.weight"], grads["mlp2.bias"] = gW2, gb2
     for i in (2, 1, 0):
-        g = block_bwd(sv["blk_enc"][i], g, P, grads, side=side)
+        g = block_bwd(sv["blk_enc"][i], g, P, grads, side=side, pre_gated=(i < 2), gate_input=(i > 0))
     grads["W_encoder.conv1.weight"] = ops.stem_bwd_weight(sv["x"], P["W_encoder.conv1.weight"], g)
     side.join()
     return grads

@@ -482,18 +482,20 @@ def affine_relu_fwd(x, a, b, P):
     return y
 
 
-def bn_relu_bwd(gy, x, gamma, mean, invstd, a, b, P):
+def bn_relu_bwd(gy, x, gamma, mean, invstd, a, b, P, with_chan_sum=False):
+    """Returns (gx, ggamma, gbeta[, sum_{b,t} gx per channel])."""
     L = _lib.load()
     _chk(gy), _chk(x)
     N, Ct, Ln = x.shape
     gx = torch.empty_like(x)
     gg = torch.empty(Ct, device=x.device, dtype=torch.float32)
     gb = torch.empty(Ct, device=x.device, dtype=torch.float32)
-    n = L.nef_bn_ws_bytes(P, Ct)
+    gs = torch.empty(Ct, device=x.device, dtype=torch.float32) if with_chan_sum else None
+    n = L.nef_bn_bwd_ws_bytes(P, N // P, Ct)
     ws = workspace(n, x.device)
     _lib.check(L.nef_bn_relu_bwd(_p(gy), _p(x), _p(gamma), _p(mean), _p(invstd), _p(a), _p(b), _p(gx), _p(gg), _p(gb),
-                                 _p(ws), n, P, N // P, Ct, Ln, _stream()), "nef_bn_relu_bwd")
-    return gx, gg, gb
+                                 _p(gs), _p(ws), n, P, N // P, Ct, Ln, _stream()), "nef_bn_relu_bwd")
+    return (gx, gg, gb, gs) if with_chan_sum else (gx, gg, gb)
 
 
 def outconv_fwd(x, w, bias):

@@ -33,7 +33,7 @@ extern "C" {
 typedef void* nef_stream_t;
 
 /* ABI version of this header; bumped on any signature change. */
-int nef_abi_version(void);   /* 3 */
+int nef_abi_version(void);   /* 4 */
 
 /* ---------------------------------------------------------------------------------------------
  * Stem: Conv1d(1->128 per lead, k15, s2, p7, no bias) + ReLU + MaxPool1d(3,2,1), fused.
@@ -169,7 +169,9 @@ int nef_upsample2_bwd(const float* gy, float* gx, int64_t N, int Tin, nef_stream
  *   momentum (unbiased var), exactly as P successive module calls would.
  * nef_bn_eval_affine: a = gamma/sqrt(rv+eps), b = beta - rm*a  [C].
  * nef_affine_relu_fwd: y = max(0, x*a[p][c] + b[p][c]).
- * nef_bn_relu_bwd: given gy (grad wrt the ReLU output), x (pre-BN), writes gx, ggamma[C], gbeta[C]. */
+ * nef_bn_relu_bwd: given gy (grad wrt the ReLU output), x (pre-BN), writes gx, ggamma[C], gbeta[C] and, when
+ *   gx_chan_sum != NULL, gx_chan_sum[c] = sum_{b,t} gx (the bias gradient of the conv that feeds this BN), fused into
+ *   the same pass.  ws: nef_bn_bwd_ws_bytes(P, Bp, C). */
 size_t nef_bn_ws_bytes(int P, int C);
 int nef_bn_train_stats(const float* x, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, float* mean, float* invstd, float* a, float* b, void* ws, size_t ws_bytes,
@@ -182,9 +184,10 @@ int nef_fold_bn(const float* w, const float* bias, const float* a, const float* 
                 int Cout, int inner, nef_stream_t stream);
 int nef_affine_relu_fwd(const float* x, const float* a, const float* b, float* y, int P, int Bp, int C, int L,
                         nef_stream_t stream);
+size_t nef_bn_bwd_ws_bytes(int P, int Bp, int C);
 int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* invstd,
-                    const float* a, const float* b, float* gx, float* ggamma, float* gbeta, void* ws, size_t ws_bytes,
-                    int P, int Bp, int C, int L, nef_stream_t stream);
+                    const float* a, const float* b, float* gx, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
+                    size_t ws_bytes, int P, int Bp, int C, int L, nef_stream_t stream);
 
 /* Final Conv1d(64->1,k3,p1,bias) + sigmoid(x/3).  model_nefnet.py:106,168.
  *   x [N][C][L], w [1][C][3], bias [1], out [N][L]. */
