@@ -38,8 +38,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config 2: 256)")
     ap.add_argument("--leads", type=int, default=3)
     ap.add_argument("--len", type=int, default=5000, dest="length")
-    ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--cpu-threads", type=int, default=32, help="host threads for the CPU baseline (capped at the core count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")

@@ -428,13 +428,15 @@ __global__ void bn_bwd_apply(const float* __restrict__ gy, const float* __restri
     }
 }
 
-// out[c] = sum over rows (p, b) of rowsum[(p*Bp + b)*C + c]   (fixed order)
-__global__ void rowsum_to_channel(const double* __restrict__ rowsum, float* __restrict__ out, int NB, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] = sum over rows (p, b) of rowsum[(p*Bp + b)*C + c]; one workgroup per channel, fixed reduction tree
+__global__ __launch_bounds__(256) void rowsum_to_channel(const double* __restrict__ rowsum, float* __restrict__ out,
+                                                         int NB, int C) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x;
     double s = 0.0;
-    for (int n = 0; n < NB; ++n) s += rowsum[(int64_t)n * C + c];
-    out[c] = (float)s;
+    for (int n = threadIdx.x; n < NB; n += 256) s += rowsum[(int64_t)n * C + c];
+    s = nef_block_sum_d(s, sm);
+    if (threadIdx.x == 0) out[c] = (float)s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -793,8 +795,8 @@ int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const f
     hipLaunchKernelGGL(bn_bwd_apply, dim3(nef_stream_grid((int64_t)P * Bp * C, 4)), dim3(256), 0, NEF_ST, gy, x, mean,
                        invstd, a, b, (const float*)coef, gx, rowsum, P, Bp, C, L);
     if (gx_chan_sum)
-        hipLaunchKernelGGL(rowsum_to_channel, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)rowsum,
-                           gx_chan_sum, P * Bp, C);
+        hipLaunchKernelGGL(rowsum_to_channel, dim3(C), dim3(256), 0, NEF_ST, (const double*)rowsum, gx_chan_sum,
+                           P * Bp, C);
     return nef_launch_status();
 }
 

@@ -1,23 +1,25 @@
-"""Factory functions of reference codes/network/__init__.py:7-24."""
-from torch.nn import MSELoss, CrossEntropyLoss
+"""`build_model(cfg)` / `build_loss(cfg)`: the factory surface of reference codes/network/__init__.py:7-24
+(same accepted names, same ValueError on anything else)."""
+from torch.nn import CrossEntropyLoss, MSELoss
 
+from .loss import MSELead, losswrapper  # noqa: F401
 from .model_nefnet import Model_nefnet
-from .loss import losswrapper, MSELead  # noqa: F401
+
+_MODELS = {"model_nefnet": lambda cfg: Model_nefnet(theta_encoder_len=cfg.MODEL.theta_L, lead_num=cfg.DATA.lead_num)}
+_LOSSES = {"v1": lambda: losswrapper, "ce": CrossEntropyLoss, "mse": MSELoss}
 
 
 def build_model(cfg):
-    model_name = cfg.MODEL.model
-    if model_name == 'model_nefnet':
-        return Model_nefnet(theta_encoder_len=cfg.MODEL.theta_L, lead_num=cfg.DATA.lead_num)
-    raise ValueError('build model: model name error')
+    try:
+        make = _MODELS[cfg.MODEL.model]
+    except KeyError:
+        raise ValueError('build model: model name error') from None
+    return make(cfg)
 
 
 def build_loss(cfg):
-    loss_name = cfg.MODEL.loss
-    if loss_name == 'v1':
-        return losswrapper
-    if loss_name == 'ce':
-        return CrossEntropyLoss()
-    if loss_name == 'mse':
-        return MSELoss()
-    raise ValueError('build loss: loss name error')
+    try:
+        make = _LOSSES[cfg.MODEL.loss]
+    except KeyError:
+        raise ValueError('build loss: loss name error') from None
+    return make()
