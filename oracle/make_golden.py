@@ -266,11 +266,52 @@ def case_theta(network):
     return d
 
 
+def case_real(network):
+    """G7: one real batch -- the two recordings bundled with the reference (codes/data/tianchi), through the reference's
+    own dataset class and its model in eval mode.  The fixture stores the batch (inputs) and the reference's outputs."""
+    if not hasattr(np, "float"):
+        np.float, np.int = float, int
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        from dataset.tianchi import EcgTianChiInterval
+        cfg = ref_cfg(3)
+        cfg.DATA.update(test_label_path="data/tianchi/tianchi_test_jsons.txt", train_label_path="data/tianchi/tianchi_test_jsons.txt",
+                        train_data_root="data/tianchi/npy_data/tianchi_train_round1", train_label_root="data/tianchi/tianchi_interval",
+                        train_data_mode="input_fix")
+        cfg["MODEL"]["jitter_factor"] = 2.5
+        random.seed(3)
+        np.random.seed(3)
+        ds = EcgTianChiInterval(cfg, "test")
+        items = [ds[i] for i in range(len(ds))]
+    finally:
+        os.chdir(cwd)
+    keys = ("data", "rois", "input_theta", "target_view", "target_theta", "rest_view", "rest_theta")
+    batch = {k: torch.from_numpy(np.stack([np.asarray(it[k]) for it in items])) for k in keys}
+    batch["rois"] = batch["rois"].long()
+    batch["rest_theta"] = batch["rest_theta"].float()
+    m = ref_model(network, 3).eval()
+    random.seed(9)
+    st = random.getstate()
+    with torch.no_grad():
+        outs = m(batch["data"], batch["input_theta"], batch["target_theta"], batch["rois"], rest_theta=batch["rest_theta"],
+                 phase="test")
+        random.setstate(st)
+        P, Bf = hw.hashed_params(3), hw.hashed_buffers()
+        mine = orc.forward(P, Bf, batch["data"], batch["input_theta"], batch["target_theta"], batch["rois"],
+                           rest_theta=batch["rest_theta"], phase="test", training=False)
+    dev = max(rel(a, b) for a, b in zip(mine, outs))
+    np.savez_compressed(os.path.join(OUT, "real_tianchi_B2_V3.npz"), seed=9, **{k: v.numpy() for k, v in batch.items()},
+                        out=outs[0].numpy(), shuf_p=outs[1].numpy(), shuf_l=outs[2].numpy(), rest_out=outs[3].numpy())
+    print(f"real_tianchi_B2_V3: rois {batch['rois'][0].tolist()}  oracle vs reference {dev:.2e}")
+    return dev
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     network = import_reference()
-    worst = [case_theta(network), case_roi(network)]
+    worst = [case_theta(network), case_roi(network), case_real(network)]
     for B, V, L in ((2, 1, 512), (2, 3, 512), (2, 3, 1000), (2, 8, 512)):
         worst.append(case_eval(network, B, V, L, Q=5, seed=11 + V + L))
     worst.append(case_train(network, 2, 1, 512, seed=5))

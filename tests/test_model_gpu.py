@@ -352,3 +352,16 @@ def test_solver_test_phase_vs_oracle():
                 SSIM(ro[:, :-2], rv[:, :-2], rn)]
         assert np.abs(np.array(mertics_all[i]) - np.array(want)).max() < 1e-3
     assert len(predict_views) == 2 * B and predict_views[0].shape == (Q, L)
+
+
+def test_real_recordings_golden(golden_dir):
+    """G7: a real batch (the reference's bundled Tianchi recordings via its own dataset class) against the reference's
+    outputs."""
+    z = np.load(os.path.join(golden_dir, "real_tianchi_B2_V3.npz"))
+    t = {k: torch.from_numpy(z[k]).to(DEV) for k in ("data", "rois", "input_theta", "target_theta", "rest_theta")}
+    m = hashed_model(3).eval()
+    random.seed(int(z["seed"]))
+    outs = m(t["data"], t["input_theta"], t["target_theta"], t["rois"], rest_theta=t["rest_theta"], phase="test")
+    for got, key in zip(outs, ("out", "shuf_p", "shuf_l", "rest_out")):
+        assert rel(got, z[key]) < FWD_TOL, (key, rel(got, z[key]))
+    assert m.segment_status() == 0

@@ -93,3 +93,19 @@ def test_baseline_config0_cpu_plumbing():
     assert all(np.isfinite(v) for v in l0 + l1 + l2) and l2[0] < l0[0]
     assert l0[1] == 0.0 and l0[2] == 0.0          # one lead: the Standin passes equal the prediction
     assert int(Bf["decoder.3.double_conv.4.num_batches_tracked"]) == 9
+
+
+def test_real_recordings_fixture(golden_dir):
+    """G7: the two recordings bundled with the reference, through its own dataset class (inputs stored in the fixture)."""
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    z = np.load(os.path.join(golden_dir, "real_tianchi_B2_V3.npz"))
+    t = {k: torch.from_numpy(z[k]) for k in ("data", "rois", "input_theta", "target_theta", "rest_theta")}
+    assert t["data"].shape == (2, 3, 512) and t["rois"].shape == (2, 7, 2) and int(t["rois"][0, 6, 1]) == 512
+    P, Bf = hw.hashed_params(3), hw.hashed_buffers()
+    random.seed(int(z["seed"]))
+    with torch.no_grad():
+        outs = orc.forward(P, Bf, t["data"], t["input_theta"], t["target_theta"], t["rois"], rest_theta=t["rest_theta"],
+                           phase="test", training=False)
+    for got, key in zip(outs, ("out", "shuf_p", "shuf_l", "rest_out")):
+        assert rel(got, z[key]) < 1e-6, key
