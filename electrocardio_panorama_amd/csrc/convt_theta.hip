@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void convt2_bwd_data_kernel(const float* __res
 }
 
 // gw[g*Cig+ci][co][j] = sum_{b,t} x[b][g*Cig+ci][t] * gy[b][g*Cog+co][2t+j]; partials over sample splits.
-constexpr int CT_SPLIT = 8;
+constexpr int CT_SPLIT = 32;
 __global__ __launch_bounds__(256) void convt2_bwd_weight_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ gy, float* __restrict__ part,
                                                                 int B, int G, int T) {
@@ -173,24 +173,31 @@ __global__ void theta_mlp_fwd_kernel(const float* __restrict__ theta, const floa
     }
 }
 
-// one thread per (o, k) (+ one per o for the bias); N is a few hundred to a few thousand
-__global__ void theta_mlp_bwd_kernel(const float* __restrict__ theta, const float* __restrict__ gy,
-                                     float* __restrict__ gW, float* __restrict__ gb, int N, int O) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= O * 13) return;
-    const int o = i / 13, k = i % 13;
-    double acc = 0.0;
-    for (int n = 0; n < N; ++n) {
+// one workgroup per output unit o: threads stride over the N rows, each evaluating the 12-value encoding once and
+// accumulating the 12 weight-gradient partials + the bias partial; fixed-order block reduction (fp64).
+__global__ __launch_bounds__(256) void theta_mlp_bwd_kernel(const float* __restrict__ theta, const float* __restrict__ gy,
+                                                            float* __restrict__ gW, float* __restrict__ gb, int N, int O) {
+    __shared__ double sm[4];
+    const int o = blockIdx.x;
+    double acc[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) acc[k] = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float e[12];
+        encode12(theta[2 * n], theta[2 * n + 1], e);
         const float g = gy[(int64_t)n * O + o];
-        if (k == 12) {
-            acc += (double)g;
-        } else {
-            const float ek = enc_component(theta[2 * n], theta[2 * n + 1], k);
-            acc += (double)(g * ek);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[k] += (double)(g * e[k]);
+        acc[12] += (double)g;
+    }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const double s = nef_block_sum_d(acc[k], sm);
+        if (threadIdx.x == 0) {
+            if (k < 12) gW[o * 12 + k] = (float)s;
+            else gb[o] = (float)s;
         }
     }
-    if (k == 12) gb[o] = (float)acc;
-    else gW[o * 12 + k] = (float)acc;
 }
 
 }  // namespace
@@ -282,7 +289,7 @@ int nef_theta_mlp_bwd(const float* theta, const float* gy, float* gW, float* gb,
     NEF_ENTER();
     NEF_REQUIRE(theta && gy && gW && gb, NEF_E_NULL);
     NEF_REQUIRE(N > 0 && O > 0, NEF_E_SHAPE);
-    hipLaunchKernelGGL(theta_mlp_bwd_kernel, dim3((O * 13 + 63) / 64), dim3(64), 0, NEF_ST, theta, gy, gW, gb, N, O);
+    hipLaunchKernelGGL(theta_mlp_bwd_kernel, dim3(O), dim3(256), 0, NEF_ST, theta, gy, gW, gb, N, O);
     return nef_launch_status();
 }
 

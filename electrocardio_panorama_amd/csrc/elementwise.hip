@@ -493,50 +493,83 @@ __global__ __launch_bounds__(256) void outconv_bwd_data_kernel(const float* __re
         dst[(int64_t)c * L] = wl[c * 3] * gp + wl[c * 3 + 1] * g0 + wl[c * 3 + 2] * gm;
 }
 
-// gw[c][k] = sum_{n,t} go[n][t] * x[n][c][t+k-1] ; gb = sum go.   grid: (C+1) x OC_SPLIT, partials in double
-constexpr int OC_SPLIT = 16;
+// gw[c][k] = sum_{n,t} go[n][t] * x[n][c][t+k-1] ; gb = sum go, with go = gout * out(1-out)/3.
+// A workgroup walks (sample, 1024-sample tile) units: go of the tile (+1 halo each side) is built once in LDS, every x
+// element is read once (coalesced) and feeds the three taps; per-channel sums stay in registers across units and are
+// wave-reduced once.  OC_BLOCKS partial rows are then summed in a fixed order.
+constexpr int OC_BLOCKS = 1024;
+constexpr int OC_TILE = 1024;
+constexpr int OC_CPW = OC_MAXC / 4;     // channels per wave
+
 __global__ __launch_bounds__(256) void outconv_bwd_weight_partial(const float* __restrict__ gout,
                                                                   const float* __restrict__ out,
                                                                   const float* __restrict__ x, double* __restrict__ part,
-                                                                  int N, int C, int L) {
-    __shared__ double sm[4];
-    const int c = blockIdx.x % (C + 1);     // c == C : bias
-    const int sp = blockIdx.x / (C + 1);
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int n = sp; n < N; n += OC_SPLIT) {
-        const int64_t base = (int64_t)n * L;
-        const float* xr = x + ((int64_t)n * C + (c < C ? c : 0)) * L;
-        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-        for (int t = threadIdx.x; t < L; t += 256) {
-            const float o = out[base + t];
-            const float go = gout[base + t] * (o * (1.f - o)) / 3.0f;
+                                                                  int N, int C, int L, int tiles) {
+    __shared__ float gol[OC_TILE + 2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float acc[OC_CPW][3];
+#pragma unroll
+    for (int j = 0; j < OC_CPW; ++j) acc[j][0] = acc[j][1] = acc[j][2] = 0.f;
+    float bsum = 0.f;
+    const int n_units = N * tiles;
+    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const int n = unit / tiles;
+        const int t0 = (unit - n * tiles) * OC_TILE;
+        __syncthreads();
+        for (int i = threadIdx.x; i < OC_TILE + 2; i += 256) {
+            const int t = t0 - 1 + i;
+            float v = 0.f;
+            if (t >= 0 && t < L) {
+                const float o = out[(int64_t)n * L + t];
+                v = gout[(int64_t)n * L + t] * (o * (1.f - o)) / 3.0f;
+            }
+            gol[i] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < OC_CPW; ++j) {
+            const int c = wave * OC_CPW + j;
             if (c < C) {
-                if (t > 0) r0 = fmaf(go, xr[t - 1], r0);
-                r1 = fmaf(go, xr[t], r1);
-                if (t < L - 1) r2 = fmaf(go, xr[t + 1], r2);
-            } else {
-                r1 += go;
+                const float* xr = x + ((int64_t)n * C + c) * L + t0;
+#pragma unroll 4
+                for (int tl = lane; tl < OC_TILE; tl += 64) {
+                    if (t0 + tl < L) {
+                        const float xv = xr[tl];
+                        acc[j][0] = fmaf(gol[tl + 2], xv, acc[j][0]);
+                        acc[j][1] = fmaf(gol[tl + 1], xv, acc[j][1]);
+                        acc[j][2] = fmaf(gol[tl], xv, acc[j][2]);
+                    }
+                }
             }
         }
-        a0 += (double)r0;
-        a1 += (double)r1;
-        a2 += (double)r2;
+        if (wave == 0)
+            for (int tl = lane; tl < OC_TILE; tl += 64) bsum += gol[tl + 1];
     }
-    a0 = nef_block_sum_d(a0, sm);
-    a1 = nef_block_sum_d(a1, sm);
-    a2 = nef_block_sum_d(a2, sm);
-    if (threadIdx.x == 0) {
-        double* d = part + ((int64_t)sp * (C + 1) + c) * 3;
-        d[0] = a0; d[1] = a1; d[2] = a2;
+    double* row = part + (int64_t)blockIdx.x * (C + 1) * 3;
+#pragma unroll
+    for (int j = 0; j < OC_CPW; ++j) {
+        const int c = wave * OC_CPW + j;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float s = nef_wave_sum(acc[j][k]);
+            if (lane == 0 && c < C) row[c * 3 + k] = (double)s;
+        }
+    }
+    if (wave == 0) {
+        const float s = nef_wave_sum(bsum);
+        if (lane == 0) { row[C * 3] = 0.0; row[C * 3 + 1] = (double)s; row[C * 3 + 2] = 0.0; }
     }
 }
 
-__global__ void outconv_bwd_weight_final(const double* __restrict__ part, float* __restrict__ gw,
-                                         float* __restrict__ gb, int C) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (C + 1) * 3) return;
+// one workgroup per output value: sum the OC_BLOCKS partial rows
+__global__ __launch_bounds__(256) void outconv_bwd_weight_final(const double* __restrict__ part, float* __restrict__ gw,
+                                                                float* __restrict__ gb, int C, int nblk) {
+    __shared__ double sm[4];
+    const int i = blockIdx.x;
     double s = 0.0;
-    for (int sp = 0; sp < OC_SPLIT; ++sp) s += part[(int64_t)sp * (C + 1) * 3 + i];
+    for (int b = threadIdx.x; b < nblk; b += 256) s += part[(int64_t)b * (C + 1) * 3 + i];
+    s = nef_block_sum_d(s, sm);
+    if (threadIdx.x != 0) return;
     const int c = i / 3, k = i % 3;
     if (c < C) gw[c * 3 + k] = (float)s;
     else if (k == 1) gb[0] = (float)s;
@@ -822,7 +855,7 @@ int nef_outconv_bwd_data(const float* gout, const float* out, const float* w, fl
     return nef_launch_status();
 }
 
-size_t nef_outconv_bwd_weight_ws_bytes(int C) { return (size_t)OC_SPLIT * (C + 1) * 3 * sizeof(double); }
+size_t nef_outconv_bwd_weight_ws_bytes(int C) { return (size_t)OC_BLOCKS * (C + 1) * 3 * sizeof(double); }
 
 int nef_outconv_bwd_weight(const float* gout, const float* out, const float* x, float* gw, float* gb, void* ws,
                            size_t ws_bytes, int N, int C, int L, nef_stream_t stream) {
@@ -830,10 +863,13 @@ int nef_outconv_bwd_weight(const float* gout, const float* out, const float* x, 
     NEF_REQUIRE(gout && out && x && gw && gb && ws, NEF_E_NULL);
     NEF_REQUIRE(N > 0 && C > 0 && C <= OC_MAXC && L > 0, NEF_E_SHAPE);
     NEF_REQUIRE(ws_bytes >= nef_outconv_bwd_weight_ws_bytes(C), NEF_E_WORKSPACE);
-    hipLaunchKernelGGL(outconv_bwd_weight_partial, dim3((C + 1) * OC_SPLIT), dim3(256), 0, NEF_ST, gout, out, x,
-                       (double*)ws, N, C, L);
-    hipLaunchKernelGGL(outconv_bwd_weight_final, dim3(((C + 1) * 3 + 63) / 64), dim3(64), 0, NEF_ST, (const double*)ws,
-                       gw, gb, C);
+    const int tiles = (L + OC_TILE - 1) / OC_TILE;
+    const int64_t units = (int64_t)N * tiles;
+    const int nblk = (int)(units < OC_BLOCKS ? units : OC_BLOCKS);
+    hipLaunchKernelGGL(outconv_bwd_weight_partial, dim3(nblk), dim3(256), 0, NEF_ST, gout, out, x, (double*)ws, N, C, L,
+                       tiles);
+    hipLaunchKernelGGL(outconv_bwd_weight_final, dim3((C + 1) * 3), dim3(256), 0, NEF_ST, (const double*)ws, gw, gb, C,
+                       nblk);
     return nef_launch_status();
 }
 

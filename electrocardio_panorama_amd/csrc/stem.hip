@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 // (sample, time-tile) space; each lane keeps 4x15 partial sums, reduced across the wave once at the end.
 constexpr int BW_CPW = 4;                  // channels per wave
 constexpr int BW_CPB = 4 * BW_CPW;         // channels per workgroup
-constexpr int BW_SPLIT = 32;
+constexpr int BW_SPLIT = 64;
 
 __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ gy, float* __restrict__ part,
@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
     bid /= (CPL / BW_CPB);
     const int v = bid % V;
     const int split = bid / V;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // wave index made provably uniform: the 4x15 filter taps then sit in scalar registers, not in 60 VGPRs
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ch0 = v * CPL + cg * BW_CPB + wave * BW_CPW;
     float wk[BW_CPW][KW];
 #pragma unroll
