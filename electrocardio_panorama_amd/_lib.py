@@ -29,6 +29,7 @@ class ConvArgs(C.Structure):
         ("res_bs", i64), ("res_gs", i64), ("gate_bs", i64), ("gate_gs", i64),
         ("B", i32), ("T", i32), ("G", i32), ("Cin_g", i32), ("Cout_g", i32), ("K", i32),
         ("relu", i32), ("gate_scale", f32), ("drop_scale", f32), ("drop_p", f32), ("rng_seed", C.c_uint64),
+        ("pro_a", p), ("pro_b", p), ("pro_mode", i32), ("pro_Bp", i32),
     ]
 
 
@@ -42,6 +43,7 @@ SIGNATURES = {
     "nef_conv_fwd": (i32, [C.POINTER(ConvArgs), p]),
     "nef_conv_bwd_weight_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "nef_conv_bwd_weight": (i32, [p, i64, i64, p, i64, i64, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32, i32, p]),
+    "nef_conv_bwd_weight_pro": (i32, [p, i64, i64, p, p, i32, i32, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32, i32, p]),
     "nef_chan_sum_ws_bytes": (sz, [i32]),
     "nef_chan_sum": (i32, [p, p, p, sz, i32, i32, i32, p]),
     "nef_convt2_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, i32, p]),
@@ -75,6 +77,8 @@ SIGNATURES = {
     "nef_bn_bwd_ws_bytes": (sz, [i32, i32, i32]),
     "nef_bn_relu_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p]),
     "nef_outconv_fwd": (i32, [p, p, p, p, i32, i32, i32, p]),
+    "nef_outconv_fwd_pro": (i32, [p, p, p, i32, p, p, p, i32, i32, i32, p]),
+    "nef_outconv_bwd_weight_pro": (i32, [p, p, p, p, p, i32, p, p, p, sz, i32, i32, i32, p]),
     "nef_outconv_bwd_data": (i32, [p, p, p, p, i32, i32, i32, p]),
     "nef_outconv_bwd_weight_ws_bytes": (sz, [i32]),
     "nef_outconv_bwd_weight": (i32, [p, p, p, p, p, p, sz, i32, i32, i32, p]),

@@ -52,9 +52,13 @@ static ColTiling make_tiling(int B, int T, int tile_cols) {
 // ------------------------------------------------------------------------------------------------
 // forward / bwd-data
 // ------------------------------------------------------------------------------------------------
-template <int K, int TM>
+// PRO: input prologue applied while staging (decoder fusion): bit0 = BatchNorm affine + ReLU of the producing layer,
+// bit1 = the input is stored at half resolution and is x2-upsampled (linear, align_corners=False) on the fly.
+template <int K, int TM, int PRO>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int seg_shift, int nseg, int tps,
                                                          int n_tiles, int m_tiles) {
+    constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
+    constexpr int NS = UP ? 2 : 1;
     constexpr int KC = StageK<K>::KC;
     constexpr int MT = 64 * TM;
     constexpr int PAD = (K - 1) / 2;
@@ -97,7 +101,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(a.x + (int64_t)b0 * a.x_bs + (int64_t)g * a.x_gs);
     const __amdgpu_buffer_rsrc_t wrs = nef_rsrc(a.wp + (int64_t)g * K * Cig * Cog + m0);
-    unsigned xvo[NIT];
+    const int Tin = UP ? (T >> 1) : T;             // stored row length of the input
+    unsigned xvo[NIT][NS];
+    float lam[NIT];                                // weight of the second tap when upsampling
     int64_t soff[NIT];
     bool xok[NIT];
 #pragma unroll
@@ -107,9 +113,23 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
         const int u = r - s * segw;
         const int t = t0 + u - PAD;
         xok[it] = (r < xrow) && (b0 + s < a.B) && (t >= 0) && (t < T);
-        xvo[it] = xok[it] ? (unsigned)(((int64_t)s * a.x_bs + t) * 4) : NEF_OOB;
+        lam[it] = 0.f;
+        if constexpr (UP) {
+            // nn.Upsample(scale_factor=2, 'linear', align_corners=False): src = 0.5*(t+0.5)-0.5, clamped at 0
+            float src = 0.5f * ((float)t + 0.5f) - 0.5f;
+            if (src < 0.f) src = 0.f;
+            int i0 = (int)src;
+            if (i0 > Tin - 1) i0 = Tin - 1;
+            const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+            lam[it] = src - (float)i0;
+            xvo[it][0] = xok[it] ? (unsigned)(((int64_t)s * a.x_bs + i0) * 4) : NEF_OOB;
+            xvo[it][NS - 1] = xok[it] ? (unsigned)(((int64_t)s * a.x_bs + i1) * 4) : NEF_OOB;
+        } else {
+            xvo[it][0] = xok[it] ? (unsigned)(((int64_t)s * a.x_bs + t) * 4) : NEF_OOB;
+        }
         soff[it] = xok[it] ? (int64_t)(b0 + s) * a.sc_bs + (int64_t)g * a.sc_gs : 0;
     }
+    const int pro_row0 = AFF ? (b0 / a.pro_Bp) * a.G * Cig + g * Cig : 0;   // [pass][channel] base of pro_a / pro_b
     // weight tile: float4 index i = threadIdx.x + 256*q -> row rc = i / M4 = (kk, ci), column m4 = i % M4;
     // (kk, ci) of load q is a compile-time offset from this thread's first row.
     const unsigned wvo = (unsigned)(((int)(threadIdx.x / M4) * Cog + 4 * (int)(threadIdx.x % M4)) * 4);
@@ -134,14 +154,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
     // Register-staged pipeline: the loads of stage s+1 are issued before the MFMA loop of stage s and only
     // written to LDS after it, so HBM/L2 latency hides under the matrix work (one LDS buffer, two barriers).
     f32x4 wreg[NW];
-    float xreg[XR][NIT];
+    float xreg[XR][NIT][NS];
 #define NEF_ISSUE_LOADS(C0)                                                                                          \
     {                                                                                                               \
         _Pragma("unroll") for (int q = 0; q < NW; ++q) wreg[q] = nef_buf_f32x4(                                     \
             wrs, wvo, (unsigned)((((q * RQ) / KC) * w_kstride + ((q * RQ) % KC + (C0)) * Cog) * 4));                 \
         _Pragma("unroll") for (int rr = 0; rr < XR; ++rr) {                                                         \
-            const unsigned so = (unsigned)(((C0) + wave_u + 4 * rr) * T * 4);                                       \
-            _Pragma("unroll") for (int it = 0; it < NIT; ++it) xreg[rr][it] = nef_buf_f32(xrs, xvo[it], so);        \
+            const unsigned so = (unsigned)(((C0) + wave_u + 4 * rr) * Tin * 4);                                     \
+            _Pragma("unroll") for (int it = 0; it < NIT; ++it)                                                      \
+                _Pragma("unroll") for (int ns = 0; ns < NS; ++ns) xreg[rr][it][ns] = nef_buf_f32(xrs, xvo[it][ns], so); \
         }                                                                                                           \
     }
     NEF_ISSUE_LOADS(0)
@@ -151,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
             for (int rr = 0; rr < XR; ++rr)
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)
-                    xreg[rr][it] *= a.in_scale[soff[it] + (xok[it] ? c0 + wave + 4 * rr : 0)];
+                    xreg[rr][it][0] *= a.in_scale[soff[it] + (xok[it] ? c0 + wave + 4 * rr : 0)];
         }
         __syncthreads();                 // every wave is done reading the previous stage
         {
@@ -159,12 +180,26 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
 #pragma unroll
             for (int q = 0; q < NW; ++q) Wl4[threadIdx.x + 256 * q] = wreg[q];
 #pragma unroll
-            for (int rr = 0; rr < XR; ++rr)
+            for (int rr = 0; rr < XR; ++rr) {
+                float pa = 1.f, pb = 0.f;
+                if constexpr (AFF) {
+                    pa = a.pro_a[pro_row0 + c0 + wave_u + 4 * rr];
+                    pb = a.pro_b[pro_row0 + c0 + wave_u + 4 * rr];
+                }
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int r = lane + 64 * it;
-                    if (r < xrow) Xl[(wave + 4 * rr) * XRS + r] = xreg[rr][it];
+                    float v = xreg[rr][it][0];
+                    if constexpr (AFF) v = fmaxf(fmaf(v, pa, pb), 0.f);
+                    if constexpr (UP) {
+                        float v1 = xreg[rr][it][NS - 1];
+                        if constexpr (AFF) v1 = fmaxf(fmaf(v1, pa, pb), 0.f);
+                        v = (1.f - lam[it]) * v + lam[it] * v1;
+                    }
+                    if constexpr (PRO != 0) v = xok[it] ? v : 0.f;      // padding is applied AFTER the prologue
+                    if (r < xrow) Xl[(wave + 4 * rr) * XRS + r] = v;
                 }
+            }
         }
         __syncthreads();
         if (c0 + KC < Cig) NEF_ISSUE_LOADS(c0 + KC)
@@ -277,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
 
 #undef NEF_ISSUE_LOADS
 
-template <int K, int TM>
+template <int K, int TM, int PRO = 0>
 static int launch_conv_fwd(const nef_conv_args& a, hipStream_t st) {
     constexpr int KC = StageK<K>::KC;
     constexpr int MT = 64 * TM;
@@ -285,7 +320,7 @@ static int launch_conv_fwd(const nef_conv_args& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(K * KC * MT + KC * XRS) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<K, TM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<K, TM, PRO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -294,7 +329,7 @@ static int launch_conv_fwd(const nef_conv_args& a, hipStream_t st) {
     const int m_tiles = a.Cout_g / MT;
     const int64_t blocks = (int64_t)a.G * m_tiles * ct.n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffff) return NEF_E_SHAPE;
-    hipLaunchKernelGGL((conv_fwd_kernel<K, TM>), dim3((unsigned)blocks), dim3(256), lds, st, a, ct.seg_shift, ct.nseg,
+    hipLaunchKernelGGL((conv_fwd_kernel<K, TM, PRO>), dim3((unsigned)blocks), dim3(256), lds, st, a, ct.seg_shift, ct.nseg,
                        ct.tps, ct.n_tiles, m_tiles);
     return nef_launch_status();
 }
@@ -302,11 +337,15 @@ static int launch_conv_fwd(const nef_conv_args& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // bwd-weight: split over the (b,t) reduction, partials reduced by a second deterministic kernel
 // ------------------------------------------------------------------------------------------------
-template <int K, int WCO, int TCI>
+template <int K, int WCO, int TCI, int PRO>
 __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
     const float* __restrict__ x, int64_t x_bs, int64_t x_gs, const float* __restrict__ in_scale, int64_t sc_bs,
     int64_t sc_gs, const float* __restrict__ gy, int64_t gy_bs, int64_t gy_gs, float* __restrict__ ws, int B, int T,
-    int G, int Cig, int Cog, int seg_shift, int nseg, int tps, int n_tiles, int m_tiles, int ci_chunks, int S) {
+    int G, int Cig, int Cog, int seg_shift, int nseg, int tps, int n_tiles, int m_tiles, int ci_chunks, int S,
+    const float* __restrict__ pro_a, const float* __restrict__ pro_b, int pro_Bp) {
+    constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;   // same input prologue as conv_fwd_kernel
+    constexpr int NS = UP ? 2 : 1;
+    const int Tin = UP ? (T >> 1) : T;
     constexpr int WCI = 4 / WCO;
     constexpr int MT = 32 * WCO;
     constexpr int CIT = 32 * TCI * WCI;
@@ -344,17 +383,34 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
     constexpr int GR = MT / 4;        // gY rows per wave
     constexpr int XRW = CIT / 4;      // X rows per wave
     float greg[GR];
-    float xreg[XRW];
+    float xreg[XRW][NS];
     constexpr int NH = (CIT * ((WT / 16) * (K - 1)) + 255) / 256;   // halo positions (beyond 64) per thread, upper bound
-    float xh[NH > 0 ? NH : 1];
+    float xh[NH > 0 ? NH : 1][NS];
+    // per-position state of the tile held in registers (needed again when the prologue is applied at the LDS store)
+    bool xk_m = false, xk_h[NH > 0 ? NH : 1];
+    float lam_m = 0.f, lam_h[NH > 0 ? NH : 1];
+    int pass_ld = 0;
     const int nh = xrow - WT;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // source taps of output-resolution time t: (i0, i1, weight of i1); identity when not upsampling
+#define NEF_BW_TAPS(TT, I0, I1, LAM)                                                                                 \
+    int I0 = (TT), I1 = (TT);                                                                                       \
+    float LAM = 0.f;                                                                                                \
+    if constexpr (UP) {                                                                                             \
+        float src_ = 0.5f * ((float)(TT) + 0.5f) - 0.5f;                                                            \
+        if (src_ < 0.f) src_ = 0.f;                                                                                 \
+        I0 = (int)src_;                                                                                             \
+        if (I0 > Tin - 1) I0 = Tin - 1;                                                                             \
+        I1 = I0 + (I0 < Tin - 1 ? 1 : 0);                                                                           \
+        LAM = src_ - (float)I0;                                                                                     \
+    }
 #define NEF_BW_ISSUE(TILE)                                                                                            \
     {                                                                                                               \
         int b0, t0;                                                                                                 \
         if (nseg == 1) { b0 = (TILE) / tps; t0 = ((TILE) - b0 * tps) * WT; } else { b0 = (TILE) * nseg; t0 = 0; }     \
+        pass_ld = AFF ? b0 / pro_Bp : 0;                                                                            \
         const __amdgpu_buffer_rsrc_t grs = nef_rsrc(gy + (int64_t)b0 * gy_bs + (int64_t)g * gy_gs + (int64_t)m0 * T); \
-        const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(x + (int64_t)b0 * x_bs + (int64_t)g * x_gs + (int64_t)c0 * T);   \
+        const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(x + (int64_t)b0 * x_bs + (int64_t)g * x_gs + (int64_t)c0 * Tin); \
         {                                                                                                           \
             const int sg = lane >> seg_shift, t = t0 + (lane & (seg - 1));                                          \
             const unsigned vo = ((b0 + sg < B) && (t < T)) ? (unsigned)(((int64_t)sg * gy_bs + t) * 4) : NEF_OOB;    \
@@ -365,12 +421,18 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
             const int sg = lane / segw;                                                                             \
             const int t = t0 + (lane - sg * segw) - PAD;                                                            \
             const bool ok = (b0 + sg < B) && (t >= 0) && (t < T);                                                   \
-            const unsigned vo = ok ? (unsigned)(((int64_t)sg * x_bs + t) * 4) : NEF_OOB;                            \
-            _Pragma("unroll") for (int rr = 0; rr < XRW; ++rr)                                                      \
-                xreg[rr] = nef_buf_f32(xrs, vo, (unsigned)((wave_u + 4 * rr) * T * 4));                             \
+            NEF_BW_TAPS(t, i0_, i1_, l_)                                                                            \
+            xk_m = ok;                                                                                              \
+            lam_m = l_;                                                                                             \
+            const unsigned vo0 = ok ? (unsigned)(((int64_t)sg * x_bs + i0_) * 4) : NEF_OOB;                         \
+            const unsigned vo1 = ok ? (unsigned)(((int64_t)sg * x_bs + i1_) * 4) : NEF_OOB;                         \
+            _Pragma("unroll") for (int rr = 0; rr < XRW; ++rr) {                                                    \
+                xreg[rr][0] = nef_buf_f32(xrs, vo0, (unsigned)((wave_u + 4 * rr) * Tin * 4));                       \
+                if constexpr (UP) xreg[rr][NS - 1] = nef_buf_f32(xrs, vo1, (unsigned)((wave_u + 4 * rr) * Tin * 4)); \
+            }                                                                                                       \
             if (in_scale) {                                                                                         \
                 const int64_t so = ok ? (int64_t)(b0 + sg) * sc_bs + (int64_t)g * sc_gs + c0 : 0;                   \
-                _Pragma("unroll") for (int rr = 0; rr < XRW; ++rr) xreg[rr] *= in_scale[so + (ok ? wave + 4 * rr : 0)]; \
+                _Pragma("unroll") for (int rr = 0; rr < XRW; ++rr) xreg[rr][0] *= in_scale[so + (ok ? wave + 4 * rr : 0)]; \
             }                                                                                                       \
         }                                                                                                           \
         _Pragma("unroll") for (int h = 0; h < NH; ++h) {   /* the few positions beyond 64: (row, e) per lane */      \
@@ -380,8 +442,13 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
             const int sg = r / segw;                                                                                \
             const int t = t0 + (r - sg * segw) - PAD;                                                               \
             const bool ok = (nh > 0) && (row < CIT) && (b0 + sg < B) && (t >= 0) && (t < T);                        \
-            xh[h] = nef_buf_f32(xrs, ok ? (unsigned)(((int64_t)sg * x_bs + (int64_t)row * T + t) * 4) : NEF_OOB, 0); \
-            if (in_scale && ok) xh[h] *= in_scale[(int64_t)(b0 + sg) * sc_bs + (int64_t)g * sc_gs + c0 + row];      \
+            NEF_BW_TAPS(t, i0_, i1_, l_)                                                                            \
+            xk_h[h] = ok;                                                                                           \
+            lam_h[h] = l_;                                                                                          \
+            xh[h][0] = nef_buf_f32(xrs, ok ? (unsigned)(((int64_t)sg * x_bs + (int64_t)row * Tin + i0_) * 4) : NEF_OOB, 0); \
+            if constexpr (UP)                                                                                       \
+                xh[h][NS - 1] = nef_buf_f32(xrs, ok ? (unsigned)(((int64_t)sg * x_bs + (int64_t)row * Tin + i1_) * 4) : NEF_OOB, 0); \
+            if (in_scale && ok) xh[h][0] *= in_scale[(int64_t)(b0 + sg) * sc_bs + (int64_t)g * sc_gs + c0 + row];   \
         }                                                                                                           \
     }
     if (split < n_tiles) NEF_BW_ISSUE(split)
@@ -389,13 +456,50 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
         __syncthreads();
 #pragma unroll
         for (int rr = 0; rr < GR; ++rr) GYl[(wave + 4 * rr) * GYS + lane] = greg[rr];
+        {
+            const int prow0 = AFF ? pass_ld * G * Cig + g * Cig + c0 : 0;
 #pragma unroll
-        for (int rr = 0; rr < XRW; ++rr) Xl[(wave + 4 * rr) * XS + lane] = xreg[rr];
+            for (int rr = 0; rr < XRW; ++rr) {
+                float v = xreg[rr][0];
+                if constexpr (PRO != 0) {
+                    float pa = 1.f, pb = 0.f;
+                    if constexpr (AFF) {
+                        pa = pro_a[prow0 + wave_u + 4 * rr];
+                        pb = pro_b[prow0 + wave_u + 4 * rr];
+                        v = fmaxf(fmaf(v, pa, pb), 0.f);
+                    }
+                    if constexpr (UP) {
+                        float v1 = xreg[rr][NS - 1];
+                        if constexpr (AFF) v1 = fmaxf(fmaf(v1, pa, pb), 0.f);
+                        v = (1.f - lam_m) * v + lam_m * v1;
+                    }
+                    v = xk_m ? v : 0.f;
+                }
+                Xl[(wave + 4 * rr) * XS + lane] = v;
+            }
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            const int idx = (int)threadIdx.x + 256 * h;
-            const int row = nh > 0 ? idx / nh : 0;
-            if (nh > 0 && row < CIT) Xl[row * XS + 64 + idx - row * nh] = xh[h];
+            for (int h = 0; h < NH; ++h) {
+                const int idx = (int)threadIdx.x + 256 * h;
+                const int row = nh > 0 ? idx / nh : 0;
+                float v = xh[h][0];
+                if constexpr (PRO != 0) {
+                    float pa = 1.f, pb = 0.f;
+                    if constexpr (AFF) {
+                        if (xk_h[h]) {
+                            pa = pro_a[prow0 + row];
+                            pb = pro_b[prow0 + row];
+                        }
+                        v = fmaxf(fmaf(v, pa, pb), 0.f);
+                    }
+                    if constexpr (UP) {
+                        float v1 = xh[h][NS - 1];
+                        if constexpr (AFF) v1 = fmaxf(fmaf(v1, pa, pb), 0.f);
+                        v = (1.f - lam_h[h]) * v + lam_h[h] * v1;
+                    }
+                    v = xk_h[h] ? v : 0.f;
+                }
+                if (nh > 0 && row < CIT) Xl[row * XS + 64 + idx - row * nh] = v;
+            }
         }
         __syncthreads();
         if (tile + S < n_tiles) NEF_BW_ISSUE(tile + S)
@@ -438,6 +542,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
         }
     }
 #undef NEF_BW_ISSUE
+#undef NEF_BW_TAPS
     // partials: ws[split][g][k][co][ci]
 #pragma unroll
     for (int i = 0; i < TCI; ++i) {
@@ -485,13 +590,14 @@ struct BwdWeightPlan {
     ColTiling ct;
 };
 
-static bool plan_bwd_weight(int B, int T, int G, int Cig, int Cog, int K, BwdWeightPlan* p) {
+static bool plan_bwd_weight(int B, int T, int G, int Cig, int Cog, int K, BwdWeightPlan* p, int pro_mode = 0) {
     if (!(K == 1 || K == 3 || K == 7)) return false;
     if (Cog % 128 == 0) p->wco = 4;
     else if (Cog % 64 == 0) p->wco = 2;
     else return false;
     const int wci = 4 / p->wco;
     p->tci = (K <= 3 && Cig % (64 * wci) == 0) ? 2 : 1;
+    if (pro_mode != 0 && p->wco == 2) p->tci = 1;      // keep the doubled staging registers within budget
     const int cit = 32 * p->tci * wci;
     if (Cig % cit != 0) return false;
     p->m_tiles = Cog / (32 * p->wco);
@@ -505,10 +611,11 @@ static bool plan_bwd_weight(int B, int T, int G, int Cig, int Cog, int K, BwdWei
     return true;
 }
 
-template <int K, int WCO, int TCI>
+template <int K, int WCO, int TCI, int PRO = 0>
 static int launch_bwd_weight(const BwdWeightPlan& p, const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale,
                              int64_t sc_bs, int64_t sc_gs, const float* gy, int64_t gy_bs, int64_t gy_gs, float* ws,
-                             int B, int T, int G, int Cig, int Cog, hipStream_t st) {
+                             int B, int T, int G, int Cig, int Cog, hipStream_t st, const float* pro_a = nullptr,
+                             const float* pro_b = nullptr, int pro_Bp = 1) {
     constexpr int WCI = 4 / WCO;
     constexpr int MT = 32 * WCO;
     constexpr int CIT = 32 * TCI * WCI;
@@ -517,15 +624,15 @@ static int launch_bwd_weight(const BwdWeightPlan& p, const float* x, int64_t x_b
     constexpr size_t lds = (size_t)(MT * GYS + CIT * XS) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bwd_weight_kernel<K, WCO, TCI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bwd_weight_kernel<K, WCO, TCI, PRO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int64_t blocks = (int64_t)p.S * G * p.m_tiles * p.ci_chunks;
-    hipLaunchKernelGGL((conv_bwd_weight_kernel<K, WCO, TCI>), dim3((unsigned)blocks), dim3(256), lds, st, x, x_bs, x_gs,
-                       in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, ws, B, T, G, Cig, Cog, p.ct.seg_shift, p.ct.nseg,
-                       p.ct.tps, p.ct.n_tiles, p.m_tiles, p.ci_chunks, p.S);
+    hipLaunchKernelGGL((conv_bwd_weight_kernel<K, WCO, TCI, PRO>), dim3((unsigned)blocks), dim3(256), lds, st, x, x_bs,
+                       x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, ws, B, T, G, Cig, Cog, p.ct.seg_shift, p.ct.nseg,
+                       p.ct.tps, p.ct.n_tiles, p.m_tiles, p.ci_chunks, p.S, pro_a, pro_b, pro_Bp);
     return nef_launch_status();
 }
 
@@ -578,7 +685,7 @@ constexpr int CHAN_SUM_SPLIT = 16;
 
 extern "C" {
 
-int nef_abi_version(void) { return 4; }
+int nef_abi_version(void) { return 5; }
 
 int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                     nef_stream_t stream) {
@@ -602,6 +709,20 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
     NEF_REQUIRE(a->Cin_g % KC == 0, NEF_E_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     const bool big = (a->Cout_g % 128 == 0);
+    if (a->pro_mode != 0) {
+        NEF_REQUIRE(K == 3 && a->pro_mode >= 1 && a->pro_mode <= 3 && !a->in_scale, NEF_E_UNSUPPORTED);
+        NEF_REQUIRE(!(a->pro_mode & 1) || (a->pro_a && a->pro_b && a->pro_Bp > 0), NEF_E_NULL);
+        NEF_REQUIRE(!(a->pro_mode & 2) || (a->T % 2 == 0), NEF_E_SHAPE);
+        if (a->pro_mode & 1) {       // a column tile must not straddle two passes
+            const ColTiling ct = make_tiling(a->B, a->T, NT);
+            NEF_REQUIRE(ct.nseg == 1 || a->pro_Bp % ct.nseg == 0, NEF_E_SHAPE);
+        }
+        switch (a->pro_mode) {
+            case 1: return big ? launch_conv_fwd<3, 2, 1>(*a, st) : launch_conv_fwd<3, 1, 1>(*a, st);
+            case 2: return big ? launch_conv_fwd<3, 2, 2>(*a, st) : launch_conv_fwd<3, 1, 2>(*a, st);
+            default: return big ? launch_conv_fwd<3, 2, 3>(*a, st) : launch_conv_fwd<3, 1, 3>(*a, st);
+        }
+    }
     switch (K) {
         case 7: return big ? launch_conv_fwd<7, 2>(*a, st) : launch_conv_fwd<7, 1>(*a, st);
         case 3: return big ? launch_conv_fwd<3, 2>(*a, st) : launch_conv_fwd<3, 1>(*a, st);
@@ -641,6 +762,46 @@ int nef_conv_bwd_weight(const float* x, int64_t x_bs, int64_t x_gs, const float*
         else { if (p.tci == 2) NEF_BW(1, 2, 2); else NEF_BW(1, 2, 1); }
     }
 #undef NEF_BW
+    if (rc != NEF_OK) return rc;
+    const int64_t n = (int64_t)G * K * Cout_g * Cin_g;
+    hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3(nef_stream_grid(n, 256)), dim3(256), 0, st, wsf, gw, G, Cout_g,
+                       Cin_g, K, p.S);
+    return nef_launch_status();
+}
+
+int nef_conv_bwd_weight_pro(const float* x, int64_t x_bs, int64_t x_gs, const float* pro_a, const float* pro_b,
+                            int pro_mode, int pro_Bp, const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws,
+                            size_t ws_bytes, int B, int T, int G, int Cin_g, int Cout_g, int K, nef_stream_t stream) {
+    NEF_ENTER();
+    if (pro_mode == 0)
+        return nef_conv_bwd_weight(x, x_bs, x_gs, nullptr, 0, 0, gy, gy_bs, gy_gs, gw, ws, ws_bytes, B, T, G, Cin_g, Cout_g, K,
+                                   stream);
+    NEF_REQUIRE(x && gy && gw && ws, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && T > 0 && G > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(K == 3 && pro_mode >= 1 && pro_mode <= 3, NEF_E_UNSUPPORTED);
+    NEF_REQUIRE(!(pro_mode & 1) || (pro_a && pro_b && pro_Bp > 0), NEF_E_NULL);
+    NEF_REQUIRE(!(pro_mode & 2) || (T % 2 == 0), NEF_E_SHAPE);
+    BwdWeightPlan p;
+    NEF_REQUIRE(plan_bwd_weight(B, T, G, Cin_g, Cout_g, K, &p, pro_mode), NEF_E_SHAPE);
+    NEF_REQUIRE(!(pro_mode & 1) || p.ct.nseg == 1 || pro_Bp % p.ct.nseg == 0, NEF_E_SHAPE);
+    const size_t need = (size_t)p.S * G * K * Cout_g * Cin_g * sizeof(float);
+    NEF_REQUIRE(ws_bytes >= need, NEF_E_WORKSPACE);
+    hipStream_t st = (hipStream_t)stream;
+    float* wsf = (float*)ws;
+    int rc = NEF_E_UNSUPPORTED;
+#define NEF_BWP(WCO, TCI, PRO)                                                                                          \
+    rc = launch_bwd_weight<3, WCO, TCI, PRO>(p, x, x_bs, x_gs, nullptr, 0, 0, gy, gy_bs, gy_gs, wsf, B, T, G, Cin_g,    \
+                                             Cout_g, st, pro_a, pro_b, pro_Bp)
+#define NEF_BWP_MODE(WCO, TCI)                                                                                          \
+    {                                                                                                                 \
+        if (pro_mode == 1) NEF_BWP(WCO, TCI, 1);                                                                      \
+        else if (pro_mode == 2) NEF_BWP(WCO, TCI, 2);                                                                 \
+        else NEF_BWP(WCO, TCI, 3);                                                                                    \
+    }
+    if (p.wco == 4) { if (p.tci == 2) NEF_BWP_MODE(4, 2) else NEF_BWP_MODE(4, 1) }
+    else NEF_BWP_MODE(2, 1)
+#undef NEF_BWP_MODE
+#undef NEF_BWP
     if (rc != NEF_OK) return rc;
     const int64_t n = (int64_t)G * K * Cout_g * Cin_g;
     hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3(nef_stream_grid(n, 256)), dim3(256), 0, st, wsf, gw, G, Cout_g,

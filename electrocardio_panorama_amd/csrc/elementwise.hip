@@ -446,11 +446,17 @@ constexpr int OC_MAXC = 64;
 
 __global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                          int N, int C, int L, int tiles) {
+                                                          int N, int C, int L, int tiles, const float* __restrict__ pa,
+                                                          const float* __restrict__ pb, int Bp) {
     __shared__ float wl[OC_MAXC * 3];
-    for (int i = threadIdx.x; i < C * 3; i += 256) wl[i] = w[i];
-    __syncthreads();
+    __shared__ float al[OC_MAXC], bl[OC_MAXC];
     const int n = blockIdx.x / tiles;
+    for (int i = threadIdx.x; i < C * 3; i += 256) wl[i] = w[i];
+    for (int i = threadIdx.x; i < C; i += 256) {
+        al[i] = pa ? pa[(n / Bp) * C + i] : 1.f;
+        bl[i] = pa ? pb[(n / Bp) * C + i] : 0.f;
+    }
+    __syncthreads();
     const int t = (blockIdx.x % tiles) * 256 + threadIdx.x;
     if (t >= L) return;
     const float* xs = x + (int64_t)n * C * L + t;
@@ -458,9 +464,14 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restric
     const bool hl = t > 0, hr = t < L - 1;
     for (int c = 0; c < C; ++c) {
         const float* r = xs + (int64_t)c * L;
-        const float xm = hl ? r[-1] : 0.f;
-        const float x0 = r[0];
-        const float xp = hr ? r[1] : 0.f;
+        float xm = hl ? r[-1] : 0.f;
+        float x0 = r[0];
+        float xp = hr ? r[1] : 0.f;
+        if (pa) {       // BatchNorm affine + ReLU of the producing layer; padding stays zero
+            xm = hl ? fmaxf(fmaf(xm, al[c], bl[c]), 0.f) : 0.f;
+            x0 = fmaxf(fmaf(x0, al[c], bl[c]), 0.f);
+            xp = hr ? fmaxf(fmaf(xp, al[c], bl[c]), 0.f) : 0.f;
+        }
         acc = fmaf(wl[c * 3], xm, acc);
         acc = fmaf(wl[c * 3 + 1], x0, acc);
         acc = fmaf(wl[c * 3 + 2], xp, acc);
@@ -504,7 +515,9 @@ constexpr int OC_CPW = OC_MAXC / 4;     // channels per wave
 __global__ __launch_bounds__(256) void outconv_bwd_weight_partial(const float* __restrict__ gout,
                                                                   const float* __restrict__ out,
                                                                   const float* __restrict__ x, double* __restrict__ part,
-                                                                  int N, int C, int L, int tiles) {
+                                                                  int N, int C, int L, int tiles,
+                                                                  const float* __restrict__ pa,
+                                                                  const float* __restrict__ pb, int Bp) {
     __shared__ float gol[OC_TILE + 2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float acc[OC_CPW][3];
@@ -531,10 +544,12 @@ __global__ __launch_bounds__(256) void outconv_bwd_weight_partial(const float* _
             const int c = wave * OC_CPW + j;
             if (c < C) {
                 const float* xr = x + ((int64_t)n * C + c) * L + t0;
+                const float af = pa ? pa[(n / Bp) * C + c] : 1.f, bf = pa ? pb[(n / Bp) * C + c] : 0.f;
 #pragma unroll 4
                 for (int tl = lane; tl < OC_TILE; tl += 64) {
                     if (t0 + tl < L) {
-                        const float xv = xr[tl];
+                        float xv = xr[tl];
+                        if (pa) xv = fmaxf(fmaf(xv, af, bf), 0.f);
                         acc[j][0] = fmaf(gol[tl + 2], xv, acc[j][0]);
                         acc[j][1] = fmaf(gol[tl + 1], xv, acc[j][1]);
                         acc[j][2] = fmaf(gol[tl], xv, acc[j][2]);
@@ -833,15 +848,21 @@ int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const f
     return nef_launch_status();
 }
 
-int nef_outconv_fwd(const float* x, const float* w, const float* bias, float* out, int N, int C, int L,
-                    nef_stream_t stream) {
+int nef_outconv_fwd_pro(const float* x, const float* a, const float* b, int Bp, const float* w, const float* bias,
+                        float* out, int N, int C, int L, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(x && w && bias && out, NEF_E_NULL);
-    NEF_REQUIRE(N > 0 && C > 0 && C <= OC_MAXC && L > 0, NEF_E_SHAPE);
+    NEF_REQUIRE((a == nullptr) == (b == nullptr), NEF_E_NULL);
+    NEF_REQUIRE(N > 0 && C > 0 && C <= OC_MAXC && L > 0 && (!a || Bp > 0), NEF_E_SHAPE);
     const int tiles = (L + 255) / 256;
     hipLaunchKernelGGL(outconv_fwd_kernel, dim3((unsigned)((int64_t)N * tiles)), dim3(256), 0, NEF_ST, x, w, bias, out,
-                       N, C, L, tiles);
+                       N, C, L, tiles, a, b, a ? Bp : 1);
     return nef_launch_status();
+}
+
+int nef_outconv_fwd(const float* x, const float* w, const float* bias, float* out, int N, int C, int L,
+                    nef_stream_t stream) {
+    return nef_outconv_fwd_pro(x, nullptr, nullptr, 1, w, bias, out, N, C, L, stream);
 }
 
 int nef_outconv_bwd_data(const float* gout, const float* out, const float* w, float* gx, int N, int C, int L,
@@ -857,20 +878,26 @@ int nef_outconv_bwd_data(const float* gout, const float* out, const float* w, fl
 
 size_t nef_outconv_bwd_weight_ws_bytes(int C) { return (size_t)OC_BLOCKS * (C + 1) * 3 * sizeof(double); }
 
-int nef_outconv_bwd_weight(const float* gout, const float* out, const float* x, float* gw, float* gb, void* ws,
-                           size_t ws_bytes, int N, int C, int L, nef_stream_t stream) {
+int nef_outconv_bwd_weight_pro(const float* gout, const float* out, const float* x, const float* a, const float* b, int Bp,
+                               float* gw, float* gb, void* ws, size_t ws_bytes, int N, int C, int L, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(gout && out && x && gw && gb && ws, NEF_E_NULL);
-    NEF_REQUIRE(N > 0 && C > 0 && C <= OC_MAXC && L > 0, NEF_E_SHAPE);
+    NEF_REQUIRE((a == nullptr) == (b == nullptr), NEF_E_NULL);
+    NEF_REQUIRE(N > 0 && C > 0 && C <= OC_MAXC && L > 0 && (!a || Bp > 0), NEF_E_SHAPE);
     NEF_REQUIRE(ws_bytes >= nef_outconv_bwd_weight_ws_bytes(C), NEF_E_WORKSPACE);
     const int tiles = (L + OC_TILE - 1) / OC_TILE;
     const int64_t units = (int64_t)N * tiles;
     const int nblk = (int)(units < OC_BLOCKS ? units : OC_BLOCKS);
     hipLaunchKernelGGL(outconv_bwd_weight_partial, dim3(nblk), dim3(256), 0, NEF_ST, gout, out, x, (double*)ws, N, C, L,
-                       tiles);
+                       tiles, a, b, a ? Bp : 1);
     hipLaunchKernelGGL(outconv_bwd_weight_final, dim3((C + 1) * 3), dim3(256), 0, NEF_ST, (const double*)ws, gw, gb, C,
                        nblk);
     return nef_launch_status();
+}
+
+int nef_outconv_bwd_weight(const float* gout, const float* out, const float* x, float* gw, float* gb, void* ws,
+                           size_t ws_bytes, int N, int C, int L, nef_stream_t stream) {
+    return nef_outconv_bwd_weight_pro(gout, out, x, nullptr, nullptr, 1, gw, gb, ws, ws_bytes, N, C, L, stream);
 }
 
 size_t nef_loss_ws_bytes(void) { return (size_t)LOSS_BLOCKS * 3 * sizeof(double); }

@@ -105,12 +105,18 @@ _DEC = (("decoder.1", "0", "1", 128), ("decoder.1", "3", "4", 128), ("decoder.3"
         ("decoder.3", "3", "4", 64))
 
 
-def decoder_fwd(D, P, Bf, passes, training, save):
+def _fusable(D, passes):
+    """The prologue variants index the per-pass BN affine by tile, so a column tile must not span two passes: always
+    true once a sample fills a tile (2T >= 128, i.e. L >= 256); shorter sequences take the unfused path."""
+    return 2 * D.shape[2] >= 128
+
+
+def _decoder_fwd_unfused(D, P, Bf, passes, training, save):
     x = D
     saved = []
     for li, (blk, cv, bn, cout) in enumerate(_DEC):
         if li in (0, 2):
-            x = ops.upsample2_fwd(x)                         # nn.Upsample(scale_factor=2, 'linear')
+            x = ops.upsample2_fwd(x)
         wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
         c = ops.conv(GV.dense(x, 1), ops.pack_weight(P[wname], 1), cout, 3, bias=P[bname])
         if training:
@@ -125,29 +131,61 @@ def decoder_fwd(D, P, Bf, passes, training, save):
             np_ = 1
         act = ops.affine_relu_fwd(c, a, b, np_)
         if save:
-            saved.append((x, c, mean, invstd, a, b))
+            saved.append((x, c, mean, invstd, a, b, (2 if li in (0, 2) else 0, None, None, 1)))
         x = act
     out = ops.outconv_fwd(x, P["decoder.4.weight"], P["decoder.4.bias"])
-    return out, (saved, x, out, passes)
+    return out, (saved, x, out, passes, None)
+
+
+def decoder_fwd(D, P, Bf, passes, training, save):
+    """Upsample -> (conv, BN, ReLU) x2 -> Upsample -> (conv, BN, ReLU) x2 -> conv -> sigmoid(x/3).  Only the conv
+    outputs c1..c4 are materialised: the x2 upsampling and each BatchNorm-affine + ReLU are applied by the CONSUMING
+    kernel while it stages its input (conv prologue modes, outconv prologue)."""
+    if not _fusable(D, passes):
+        return _decoder_fwd_unfused(D, P, Bf, passes, training, save)
+    x, pro_in = D, None                # pro_in: (a, b) of the BN whose output feeds the next conv
+    saved = []
+    N = D.shape[0]
+    for li, (blk, cv, bn, cout) in enumerate(_DEC):
+        wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
+        mode = (2 if li in (0, 2) else 0) | (1 if pro_in is not None else 0)
+        pro = (mode, pro_in[0], pro_in[1], pro_in[2]) if pro_in is not None else (mode, None, None, 1)
+        c = ops.conv(GV.dense(x, 1), ops.pack_weight(P[wname], 1), cout, 3, bias=P[bname], pro=pro)
+        if training:
+            mean, invstd, a, b = ops.bn_train_stats(c, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
+                                                    Bf[pre + ".running_var"], passes, BN_EPS, BN_MOM)
+            Bf[pre + ".num_batches_tracked"] += passes
+            Bp = N // passes
+        else:
+            a, b = ops.bn_eval_affine(P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
+                                      Bf[pre + ".running_var"], BN_EPS)
+            mean = invstd = None
+            Bp = N
+        if save:
+            saved.append((x, c, mean, invstd, a, b, pro))
+        x, pro_in = c, (a, b, Bp)
+    out = ops.outconv_fwd(x, P["decoder.4.weight"], P["decoder.4.bias"], pro=pro_in)
+    return out, (saved, x, out, passes, pro_in)
 
 
 def decoder_bwd(dsaved, g_out, P, grads, side=None):
-    saved, a4, out, passes = dsaved
+    saved, c4, out, passes, pro4 = dsaved
     side = side or ops._Inline()
-    grads["decoder.4.weight"], grads["decoder.4.bias"] = side.run(lambda: ops.outconv_bwd_weight(g_out, out, a4),
-                                                                  g_out, out, a4)
-    g = ops.outconv_bwd_data(g_out, out, P["decoder.4.weight"], a4.shape[1])
+    grads["decoder.4.weight"], grads["decoder.4.bias"] = side.run(
+        lambda: ops.outconv_bwd_weight(g_out, out, c4, pro=pro4), g_out, out, c4)
+    g = ops.outconv_bwd_data(g_out, out, P["decoder.4.weight"], c4.shape[1])     # grad wrt relu(bn(c4))
     for li in (3, 2, 1, 0):
         blk, cv, bn, cout = _DEC[li]
-        x, c, mean, invstd, a, b = saved[li]
+        x, c, mean, invstd, a, b, pro = saved[li]
         wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
         gc, gg, gbeta, gbias = ops.bn_relu_bwd(g, c, P[pre + ".weight"], mean, invstd, a, b, passes, with_chan_sum=True)
         grads[pre + ".weight"], grads[pre + ".bias"], grads[bname] = gg, gbeta, gbias
         gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
-        grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3), x, gc)
+        fused = pro4 is not None
+        grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro if fused else None), x, gc)
         g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True), x.shape[1], 3, role="conv_bwd_data")
-        if li in (0, 2):
-            g = ops.upsample2_bwd(g)
+        if pro[0] & 2:
+            g = ops.upsample2_bwd(g)          # back through the x2 upsampling
     return g
 
 
@@ -282,7 +320,7 @@ def backward(P, sv, g_outs):
     """g_outs: gradients wrt (out, shuffle_p, shuffle_l), each [B,1,L] or None.  Returns {param name: grad}."""
     B, V, T = sv["B"], sv["V"], sv["T"]
     grads = {}
-    like = sv["dec"][2]
+    like = sv["dec"][2]        # stacked decoder output [3B, 1, L]
     parts = [g if g is not None else torch.zeros_like(like[0:B]) for g in g_outs]
     g_out = torch.cat([p_.contiguous() for p_ in parts], dim=0)
     side = _side(g_out.device)

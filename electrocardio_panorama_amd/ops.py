@@ -162,12 +162,15 @@ def pack_weight(w, G, flip=False):
 
 
 def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None, gate_scale=1.0, relu=False,
-         mask=None, drop_p=0.0, drop_scale=1.0, seed=0, role="conv_fwd"):
-    """out = epilogue(conv1d(x * in_scale, w) + bias + res).  `xv`, `res`, `gate`, `out` are GV views;
-    `in_scale` is (tensor, batch_stride, group_stride).  Returns the output tensor."""
+         mask=None, drop_p=0.0, drop_scale=1.0, seed=0, role="conv_fwd", pro=None):
+    """out = epilogue(conv1d(prologue(x) * in_scale, w) + bias + res).  `xv`, `res`, `gate`, `out` are GV views;
+    `in_scale` is (tensor, batch_stride, group_stride).  `pro` = (mode, a, b, Bp): input prologue applied while
+    staging -- bit0 BatchNorm affine + ReLU with a/b [P, C_in], bit1 x2 linear upsampling of a half-resolution input
+    (the output is then 2*xv.T long).  Returns the output tensor."""
     L = _lib.load()
+    T_out = xv.T * 2 if (pro is not None and pro[0] & 2) else xv.T
     if out is None:
-        y = torch.empty(xv.B, xv.G * Cog, xv.T, device=xv.t.device, dtype=torch.float32)
+        y = torch.empty(xv.B, xv.G * Cog, T_out, device=xv.t.device, dtype=torch.float32)
         out = GV.dense(y, xv.G)
     a = _lib.ConvArgs()
     a.x, a.wp, a.y = xv.ptr, _p(wp), out.ptr
@@ -183,20 +186,22 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
         a.res_bs, a.res_gs = res.bs, res.gs
     if gate is not None:
         a.gate_bs, a.gate_gs = gate.bs, gate.gs
-    a.B, a.T, a.G, a.Cin_g, a.Cout_g, a.K = xv.B, xv.T, xv.G, xv.Cg, Cog, K
+    a.B, a.T, a.G, a.Cin_g, a.Cout_g, a.K = xv.B, T_out, xv.G, xv.Cg, Cog, K
+    if pro is not None and pro[0]:
+        a.pro_mode, a.pro_a, a.pro_b, a.pro_Bp = pro[0], _p(pro[1]), _p(pro[2]), pro[3]
     a.relu = int(relu)
     a.gate_scale, a.drop_scale, a.drop_p, a.rng_seed = gate_scale, drop_scale, drop_p, seed
-    ev = _timed((role, K, xv.G, xv.Cg, Cog, xv.B, xv.T))
+    ev = _timed((role, K, xv.G, xv.Cg, Cog, xv.B, T_out))
     _lib.check(L.nef_conv_fwd(C.byref(a), _stream()), "nef_conv_fwd")
     if ev is not None:
         ev.record()
     return out.t
 
 
-def conv_bwd_weight(xv, gyv, K, in_scale=None):
-    """gw [G*Cog, Cig, K] for y = conv(x * in_scale, w)."""
+def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None):
+    """gw [G*Cog, Cig, K] for y = conv(prologue(x) * in_scale, w); `pro` as in conv()."""
     L = _lib.load()
-    B, T, G, Cig, Cog = xv.B, xv.T, xv.G, xv.Cg, gyv.Cg
+    B, T, G, Cig, Cog = xv.B, gyv.T, xv.G, xv.Cg, gyv.Cg
     gw = torch.empty(G * Cog, Cig, K, device=xv.t.device, dtype=torch.float32)
     n = L.nef_conv_bwd_weight_ws_bytes(B, T, G, Cig, Cog, K)
     if n == 0:
@@ -204,8 +209,14 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None):
     ws = workspace(n, xv.t.device)
     sc, sc_bs, sc_gs = (None, 0, 0) if in_scale is None else (_p(in_scale[0]), in_scale[1], in_scale[2])
     ev = _timed(("conv_bwd_weight", K, G, Cig, Cog, B, T))
-    _lib.check(L.nef_conv_bwd_weight(xv.ptr, xv.bs, xv.gs, sc, sc_bs, sc_gs, gyv.ptr, gyv.bs, gyv.gs, _p(gw), _p(ws),
-                                     n, B, T, G, Cig, Cog, K, _stream()), "nef_conv_bwd_weight")
+    if pro is not None and pro[0]:
+        assert in_scale is None
+        _lib.check(L.nef_conv_bwd_weight_pro(xv.ptr, xv.bs, xv.gs, _p(pro[1]), _p(pro[2]), pro[0], pro[3], gyv.ptr, gyv.bs,
+                                             gyv.gs, _p(gw), _p(ws), n, B, T, G, Cig, Cog, K, _stream()),
+                   "nef_conv_bwd_weight_pro")
+    else:
+        _lib.check(L.nef_conv_bwd_weight(xv.ptr, xv.bs, xv.gs, sc, sc_bs, sc_gs, gyv.ptr, gyv.bs, gyv.gs, _p(gw), _p(ws),
+                                         n, B, T, G, Cig, Cog, K, _stream()), "nef_conv_bwd_weight")
     if ev is not None:
         ev.record()
     return gw
@@ -498,12 +509,15 @@ def bn_relu_bwd(gy, x, gamma, mean, invstd, a, b, P, with_chan_sum=False):
     return (gx, gg, gb, gs) if with_chan_sum else (gx, gg, gb)
 
 
-def outconv_fwd(x, w, bias):
+def outconv_fwd(x, w, bias, pro=None):
+    """`pro` = (a, b, Bp): x is the pre-BatchNorm tensor, relu(x*a[p,c]+b[p,c]) is applied on the fly."""
     L = _lib.load()
     _chk(x), _chk(w), _chk(bias)
     N, Ct, Ln = x.shape
     out = torch.empty(N, 1, Ln, device=x.device, dtype=torch.float32)
-    _lib.check(L.nef_outconv_fwd(_p(x), _p(w), _p(bias), _p(out), N, Ct, Ln, _stream()), "nef_outconv_fwd")
+    a, b, Bp = pro if pro is not None else (None, None, 1)
+    _lib.check(L.nef_outconv_fwd_pro(_p(x), _p(a), _p(b), Bp, _p(w), _p(bias), _p(out), N, Ct, Ln, _stream()),
+               "nef_outconv_fwd")
     return out
 
 
@@ -516,7 +530,7 @@ def outconv_bwd_data(gout, out, w, Ct):
     return gx
 
 
-def outconv_bwd_weight(gout, out, x):
+def outconv_bwd_weight(gout, out, x, pro=None):
     L = _lib.load()
     _chk(gout), _chk(out), _chk(x)
     N, Ct, Ln = x.shape
@@ -524,8 +538,9 @@ def outconv_bwd_weight(gout, out, x):
     gb = torch.empty(1, device=x.device, dtype=torch.float32)
     n = L.nef_outconv_bwd_weight_ws_bytes(Ct)
     ws = workspace(n, x.device)
-    _lib.check(L.nef_outconv_bwd_weight(_p(gout), _p(out), _p(x), _p(gw), _p(gb), _p(ws), n, N, Ct, Ln, _stream()),
-               "nef_outconv_bwd_weight")
+    a, b, Bp = pro if pro is not None else (None, None, 1)
+    _lib.check(L.nef_outconv_bwd_weight_pro(_p(gout), _p(out), _p(x), _p(a), _p(b), Bp, _p(gw), _p(gb), _p(ws), n, N, Ct,
+                                            Ln, _stream()), "nef_outconv_bwd_weight")
     return gw, gb
 
 

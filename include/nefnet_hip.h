@@ -33,7 +33,7 @@ extern "C" {
 typedef void* nef_stream_t;
 
 /* ABI version of this header; bumped on any signature change. */
-int nef_abi_version(void);   /* 4 */
+int nef_abi_version(void);   /* 5 */
 
 /* ---------------------------------------------------------------------------------------------
  * Stem: Conv1d(1->128 per lead, k15, s2, p7, no bias) + ReLU + MaxPool1d(3,2,1), fused.
@@ -73,6 +73,17 @@ typedef struct nef_conv_args {
     float drop_scale;      /* 1/(1-p); with mask == NULL and drop_p > 0 the keep-mask comes from the counter RNG */
     float drop_p;
     uint64_t rng_seed;     /* counter RNG: keep(b, channel, t) = hash(seed, dense index) >= p */
+    /* Input prologue, applied while the activation tile is staged (decoder fusion, K == 3 only):
+     *   pro_mode bit0: x' = max(0, x*pro_a[p][ch] + pro_b[p][ch]) with p = sample / pro_Bp -- the BatchNorm affine + ReLU
+     *                  of the producing layer (model_nefnet.py:19-23); pro_a/pro_b are [P][G*Cin_g];
+     *   pro_mode bit1: the input is stored at half resolution [..][T/2] and is x2-upsampled on the fly exactly as
+     *                  nn.Upsample(scale_factor=2, mode='linear', align_corners=False) (model_nefnet.py:102,104);
+     *                  x_bs / x_gs and the channel pitch then refer to the half-resolution tensor.
+     * Zero padding is applied after the prologue.  in_scale must be NULL when pro_mode != 0. */
+    const float* pro_a;
+    const float* pro_b;
+    int32_t pro_mode;
+    int32_t pro_Bp;
 } nef_conv_args;
 
 /* y = epilogue(conv(x * in_scale, wp) + bias + res).  Also the bwd-data pass (pack with transpose_flip=1,
@@ -85,6 +96,10 @@ size_t nef_conv_bwd_weight_ws_bytes(int B, int T, int G, int Cin_g, int Cout_g, 
 int nef_conv_bwd_weight(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
                         int64_t sc_gs, const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws,
                         size_t ws_bytes, int B, int T, int G, int Cin_g, int Cout_g, int K, nef_stream_t stream);
+/* Same with the input prologue of nef_conv_args (pro_mode / pro_a / pro_b / pro_Bp) recomputed while staging x. */
+int nef_conv_bwd_weight_pro(const float* x, int64_t x_bs, int64_t x_gs, const float* pro_a, const float* pro_b,
+                            int pro_mode, int pro_Bp, const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws,
+                            size_t ws_bytes, int B, int T, int G, int Cin_g, int Cout_g, int K, nef_stream_t stream);
 
 /* out[c] = sum_{b,t} x[b][c][t] (bias gradients).  ws: nef_chan_sum_ws_bytes(C). */
 size_t nef_chan_sum_ws_bytes(int C);
@@ -193,6 +208,11 @@ int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const f
  *   x [N][C][L], w [1][C][3], bias [1], out [N][L]. */
 int nef_outconv_fwd(const float* x, const float* w, const float* bias, float* out, int N, int C, int L,
                     nef_stream_t stream);
+/* Variants that take the pre-BatchNorm tensor and apply x' = max(0, x*a[p][c] + b[p][c]), p = n / Bp, on the fly. */
+int nef_outconv_fwd_pro(const float* x, const float* a, const float* b, int Bp, const float* w, const float* bias,
+                        float* out, int N, int C, int L, nef_stream_t stream);
+int nef_outconv_bwd_weight_pro(const float* gout, const float* out, const float* x, const float* a, const float* b, int Bp,
+                               float* gw, float* gb, void* ws, size_t ws_bytes, int N, int C, int L, nef_stream_t stream);
 int nef_outconv_bwd_data(const float* gout, const float* out, const float* w, float* gx, int N, int C, int L,
                          nef_stream_t stream);
 size_t nef_outconv_bwd_weight_ws_bytes(int C);

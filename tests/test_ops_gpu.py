@@ -114,6 +114,52 @@ def test_conv_epilogue_and_views():
         assert torch.all(got[:, :, 1 - which] == 7.0)
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("Cig,Cog,T_out", [(256, 128, 250), (128, 64, 500), (64, 64, 260), (128, 128, 128)])
+def test_conv_prologue_modes(mode, Cig, Cog, T_out):
+    """Decoder fusion: BatchNorm affine + ReLU (bit0) and x2 linear upsampling (bit1) applied while the conv stages
+    its input, forward and backward-weight, three passes with their own affine."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    P, Bp = 3, 2
+    N = P * Bp
+    Tin = T_out // 2 if mode & 2 else T_out
+    x = rnd(N, Cig, Tin, seed=80)
+    a, b = rnd(P, Cig, seed=81) + 1.2, rnd(P, Cig, seed=82) * 0.5
+    w, bias = rnd(Cog, Cig, 3, seed=83, scale=(3 * Cig) ** -0.5), rnd(Cog, seed=84)
+    xin = x
+    if mode & 1:
+        xin = F.relu(x * a.repeat_interleave(Bp, 0)[:, :, None] + b.repeat_interleave(Bp, 0)[:, :, None])
+    if mode & 2:
+        xin = F.interpolate(xin, scale_factor=2, mode="linear", align_corners=False)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv1d(xin, wr, bias, 1, 1)
+    pro = (mode, g(a) if mode & 1 else None, g(b) if mode & 1 else None, Bp)
+    xd = g(x)
+    y = o.conv(GV.dense(xd, 1), o.pack_weight(g(w), 1), Cog, 3, bias=g(bias), pro=pro)
+    assert y.shape == ref.shape and rel(y, ref) < FWD_TOL
+    gy = rnd(*ref.shape, seed=85)
+    ref.backward(gy)
+    gw = o.conv_bwd_weight(GV.dense(xd, 1), GV.dense(g(gy), 1), 3, pro=pro)
+    assert rel(gw, wr.grad) < GRAD_TOL
+
+
+def test_outconv_prologue():
+    o = ops()
+    P, Bp, C, L = 3, 2, 64, 500
+    x, w, b = rnd(P * Bp, C, L, seed=86), rnd(1, C, 3, seed=87, scale=0.2), rnd(1, seed=88)
+    a, bb = rnd(P, C, seed=89) + 1.1, rnd(P, C, seed=90) * 0.4
+    act = F.relu(x * a.repeat_interleave(Bp, 0)[:, :, None] + bb.repeat_interleave(Bp, 0)[:, :, None])
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.sigmoid(F.conv1d(act, wr, br, 1, 1) / 3)
+    out = o.outconv_fwd(g(x), g(w), g(b), pro=(g(a), g(bb), Bp))
+    assert rel(out, ref) < 1e-6
+    gy = rnd(*ref.shape, seed=91)
+    ref.backward(gy)
+    gw, gb = o.outconv_bwd_weight(g(gy), out, g(x), pro=(g(a), g(bb), Bp))
+    assert rel(gw, wr.grad) < 1e-5 and rel(gb, br.grad) < 1e-5
+
+
 def test_conv_dropout_rng():
     o = ops()
     from electrocardio_panorama_amd.ops import GV
@@ -394,14 +440,15 @@ def test_basic_block(prefix, K, G, Cig, T):
         assert rel(v, Pr[k].grad) < GRAD_TOL, k
 
 
-def test_decoder_three_passes():
-    """Three stacked BatchNorm passes.  Four BN layers make this gradient ill-conditioned on random data (torch's own
+@pytest.mark.parametrize("T", [125, 24])
+def test_decoder_three_passes(T):
+    """Three stacked BatchNorm passes (T=125: fused prologue path; T=24: short-sequence unfused path).  Four BN layers make this gradient ill-conditioned on random data (torch's own
     fp32 result sits ~8e-3 from its fp64 result here), so the yardstick is the fp64 oracle and the bar is the fp32
     oracle's own distance from it."""
     from electrocardio_panorama_amd import engine
     from oracle import hashweights as hw
     from oracle import nefnet_oracle as orc
-    B, T = 2, 125
+    B = 2
     P = {k: v for k, v in hw.hashed_params(1).items() if k.startswith("decoder.")}
     Bf = hw.hashed_buffers()
     D = rnd(3 * B, 256, T, seed=67)
