@@ -69,6 +69,7 @@ SIGNATURES = {
     "nef_mix_bwd": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p]),
     "nef_upsample2_fwd": (i32, [p, p, i64, i32, p]),
     "nef_upsample2_bwd": (i32, [p, p, i64, i32, p]),
+    "nef_upsample2_aff_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, p]),
     "nef_bn_ws_bytes": (sz, [i32, i32]),
     "nef_bn_train_stats": (i32, [p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, f32, f32, p]),
     "nef_bn_eval_affine": (i32, [p, p, p, p, p, p, i32, f32, p]),

@@ -181,6 +181,30 @@ __device__ __forceinline__ float up2_at(const float* __restrict__ xr, int Tin, i
     return l0 * xr[i0] + l1 * xr[i1];
 }
 
+// y = upsample2(relu(x*a[p][c] + b[p][c])): the BatchNorm affine + ReLU of the producing layer folded into the resample
+__global__ void upsample2_aff_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                         const float* __restrict__ b, float* __restrict__ y, int64_t rows, int C, int Tin,
+                                         int Bp) {
+    const int To = 2 * Tin;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int c = (int)(row % C);
+        const int p = (int)((row / C) / Bp);
+        const float af = a[p * C + c], bf = b[p * C + c];
+        const float* xr = x + row * Tin;
+        float* yr = y + row * To;
+        for (int i = lane; i < To; i += 64) {
+            float src = 0.5f * ((float)i + 0.5f) - 0.5f;
+            if (src < 0.f) src = 0.f;
+            int i0 = (int)src;
+            if (i0 > Tin - 1) i0 = Tin - 1;
+            const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+            const float l1 = src - (float)i0;
+            yr[i] = (1.f - l1) * fmaxf(fmaf(xr[i0], af, bf), 0.f) + l1 * fmaxf(fmaf(xr[i1], af, bf), 0.f);
+        }
+    }
+}
+
 __global__ void upsample2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t N, int Tin) {
     const int To = 2 * Tin;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -765,6 +789,17 @@ int nef_upsample2_fwd(const float* x, float* y, int64_t N, int Tin, nef_stream_t
     NEF_REQUIRE(x && y, NEF_E_NULL);
     NEF_REQUIRE(N > 0 && Tin > 0, NEF_E_SHAPE);
     hipLaunchKernelGGL(upsample2_fwd_kernel, dim3(nef_stream_grid(N, 4)), dim3(256), 0, NEF_ST, x, y, N, Tin);
+    return nef_launch_status();
+}
+
+int nef_upsample2_aff_fwd(const float* x, const float* a, const float* b, float* y, int N, int C, int Tin, int Bp,
+                          nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && a && b && y, NEF_E_NULL);
+    NEF_REQUIRE(N > 0 && C > 0 && Tin > 0 && Bp > 0, NEF_E_SHAPE);
+    const int64_t rows = (int64_t)N * C;
+    hipLaunchKernelGGL(upsample2_aff_fwd_kernel, dim3(nef_stream_grid(rows, 4)), dim3(256), 0, NEF_ST, x, a, b, y, rows, C,
+                       Tin, Bp);
     return nef_launch_status();
 }
 

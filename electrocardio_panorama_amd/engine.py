@@ -131,7 +131,7 @@ def _decoder_fwd_unfused(D, P, Bf, passes, training, save):
             np_ = 1
         act = ops.affine_relu_fwd(c, a, b, np_)
         if save:
-            saved.append((x, c, mean, invstd, a, b, (2 if li in (0, 2) else 0, None, None, 1)))
+            saved.append((x, c, mean, invstd, a, b, (0, None, None, 1), li in (0, 2)))
         x = act
     out = ops.outconv_fwd(x, P["decoder.4.weight"], P["decoder.4.bias"])
     return out, (saved, x, out, passes, None)
@@ -148,9 +148,18 @@ def decoder_fwd(D, P, Bf, passes, training, save):
     N = D.shape[0]
     for li, (blk, cv, bn, cout) in enumerate(_DEC):
         wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
-        mode = (2 if li in (0, 2) else 0) | (1 if pro_in is not None else 0)
-        pro = (mode, pro_in[0], pro_in[1], pro_in[2]) if pro_in is not None else (mode, None, None, 1)
-        c = ops.conv(GV.dense(x, 1), ops.pack_weight(P[wname], 1), cout, 3, bias=P[bname], pro=pro)
+        if li == 2:
+            # measured: at 128->64 channels the staged (affine+ReLU, x2) prologue costs the two conv kernels more than
+            # one fused elementwise pass, so this layer materialises u2 = up(relu(bn(c2))) and runs the plain conv
+            x_in = ops.upsample2_aff_fwd(x, pro_in[0], pro_in[1], pro_in[2])
+            pro = (0, None, None, 1)
+            up_after = True
+        else:
+            x_in = x
+            mode = (2 if li == 0 else 0) | (1 if pro_in is not None else 0)
+            pro = (mode, pro_in[0], pro_in[1], pro_in[2]) if pro_in is not None else (mode, None, None, 1)
+            up_after = bool(mode & 2)
+        c = ops.conv(GV.dense(x_in, 1), ops.pack_weight(P[wname], 1), cout, 3, bias=P[bname], pro=pro)
         if training:
             mean, invstd, a, b = ops.bn_train_stats(c, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
                                                     Bf[pre + ".running_var"], passes, BN_EPS, BN_MOM)
@@ -162,7 +171,7 @@ def decoder_fwd(D, P, Bf, passes, training, save):
             mean = invstd = None
             Bp = N
         if save:
-            saved.append((x, c, mean, invstd, a, b, pro))
+            saved.append((x_in, c, mean, invstd, a, b, pro, up_after))
         x, pro_in = c, (a, b, Bp)
     out = ops.outconv_fwd(x, P["decoder.4.weight"], P["decoder.4.bias"], pro=pro_in)
     return out, (saved, x, out, passes, pro_in)
@@ -176,15 +185,14 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
     g = ops.outconv_bwd_data(g_out, out, P["decoder.4.weight"], c4.shape[1])     # grad wrt relu(bn(c4))
     for li in (3, 2, 1, 0):
         blk, cv, bn, cout = _DEC[li]
-        x, c, mean, invstd, a, b, pro = saved[li]
+        x, c, mean, invstd, a, b, pro, up_after = saved[li]
         wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
         gc, gg, gbeta, gbias = ops.bn_relu_bwd(g, c, P[pre + ".weight"], mean, invstd, a, b, passes, with_chan_sum=True)
         grads[pre + ".weight"], grads[pre + ".bias"], grads[bname] = gg, gbeta, gbias
         gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
-        fused = pro4 is not None
-        grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro if fused else None), x, gc)
+        grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro), x, gc)
         g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True), x.shape[1], 3, role="conv_bwd_data")
-        if pro[0] & 2:
+        if up_after:
             g = ops.upsample2_bwd(g)          # back through the x2 upsampling
     return g
 

@@ -441,6 +441,16 @@ def upsample2_fwd(x):
     return y
 
 
+def upsample2_aff_fwd(x, a, b, Bp):
+    """upsample2(relu(x*a[p,c] + b[p,c])), p = sample // Bp."""
+    L = _lib.load()
+    _chk(x)
+    N, Ct, T = x.shape
+    y = torch.empty(N, Ct, 2 * T, device=x.device, dtype=torch.float32)
+    _lib.check(L.nef_upsample2_aff_fwd(_p(x), _p(a), _p(b), _p(y), N, Ct, T, Bp, _stream()), "nef_upsample2_aff_fwd")
+    return y
+
+
 def upsample2_bwd(gy):
     L = _lib.load()
     _chk(gy)

@@ -177,6 +177,9 @@ int nef_mix_bwd(const float* gD, const float* latent, const float* z1, const flo
  * Upsample(scale 2, linear, align_corners=False): x [N][Tin] rows -> y [N][2Tin]. */
 int nef_upsample2_fwd(const float* x, float* y, int64_t N, int Tin, nef_stream_t stream);
 int nef_upsample2_bwd(const float* gy, float* gx, int64_t N, int Tin, nef_stream_t stream);
+/* y [N][C][2Tin] = upsample2(max(0, x*a[p][c] + b[p][c])), p = n / Bp: BN affine + ReLU folded into the resample. */
+int nef_upsample2_aff_fwd(const float* x, const float* a, const float* b, float* y, int N, int C, int Tin, int Bp,
+                          nef_stream_t stream);
 
 /* BatchNorm1d, training mode, P independent passes stacked along batch (x [P*Bp][C][L]).
  * nef_bn_train_stats: per (pass, channel) batch mean / biased var -> mean, invstd [P][C], the affine
