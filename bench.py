@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=32, help="host threads for the CPU baseline (capped at the core count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (launch-bound shapes)")
     return ap.parse_args()
 
 
@@ -100,7 +101,14 @@ def main():
                                                  ("data", "rois", "input_theta", "target_view", "target_theta"))
     tgt_view = tgt_view.unsqueeze(1)
 
+    graphed = None
+    if args.graph:
+        from electrocardio_panorama_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, cfg)
+
     def step():
+        if graphed is not None:
+            return graphed(data, in_theta, tgt_theta, rois, tgt_view)[0]
         out, sp, sl = model(data, in_theta, tgt_theta, rois, phase="train")
         losses = lossf(out, sp, sl, tgt_view, cfg)
         losses[0].backward()
@@ -174,6 +182,7 @@ def main():
                                    f"{'off' if args.no_dropout else 'on'}",
                        "global_batch": world * B, "seq_len": L, "leads": V, "parallelism": f"dp{world}"},
             "roofline": roof, "cpu_baseline": cpu, "final_loss": final_loss, "conv_ms_per_step": breakdown,
+            "hip_graph": bool(args.graph),
         }
         if cpu:
             line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)

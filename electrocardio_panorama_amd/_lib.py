@@ -29,7 +29,7 @@ class ConvArgs(C.Structure):
         ("res_bs", i64), ("res_gs", i64), ("gate_bs", i64), ("gate_gs", i64),
         ("B", i32), ("T", i32), ("G", i32), ("Cin_g", i32), ("Cout_g", i32), ("K", i32),
         ("relu", i32), ("gate_scale", f32), ("drop_scale", f32), ("drop_p", f32), ("rng_seed", C.c_uint64),
-        ("pro_a", p), ("pro_b", p), ("pro_mode", i32), ("pro_Bp", i32),
+        ("pro_a", p), ("pro_b", p), ("pro_mode", i32), ("pro_Bp", i32), ("rng_seed_dev", p),
     ]
 
 
@@ -65,8 +65,8 @@ SIGNATURES = {
     "nef_roi_unpool_bwd": (i32, [p, p, p, i32, i32, i32, p]),
     "nef_roi_segment_table": (i32, [p, p, p, i32, p]),
     "nef_lead_mean": (i32, [p, p, p, i32, i32, i32, p]),
-    "nef_mix_fwd": (i32, [p, p, p, p, p, i32, i32, i32, i32, i32, p]),
-    "nef_mix_bwd": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p]),
+    "nef_mix_fwd": (i32, [p, p, p, p, p, i32, i32, i32, i32, i32, p, p]),
+    "nef_mix_bwd": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, p]),
     "nef_upsample2_fwd": (i32, [p, p, i64, i32, p]),
     "nef_upsample2_bwd": (i32, [p, p, i64, i32, p]),
     "nef_upsample2_aff_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, p]),

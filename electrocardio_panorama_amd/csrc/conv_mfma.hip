@@ -287,10 +287,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
                 for (int r = 0; r < 16; ++r) v[r] *= t16[r] * a.drop_scale;
             } else if (a.drop_p > 0.f) {
                 const int64_t d0 = ((int64_t)bs * ctot + (int64_t)g * Cog + cobase) * T + ts;
+                const uint64_t seed = a.rng_seed + (a.rng_seed_dev ? a.rng_seed_dev[0] : 0ull);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint64_t dense = (uint64_t)(d0 + (int64_t)((r & 3) + 8 * (r >> 2)) * T);
-                    v[r] = (nef_rng_uniform(a.rng_seed, dense) >= a.drop_p) ? v[r] * a.drop_scale : 0.f;
+                    v[r] = (nef_rng_uniform(seed, dense) >= a.drop_p) ? v[r] * a.drop_scale : 0.f;
                 }
             }
             if (a.gate) {
@@ -685,7 +686,7 @@ constexpr int CHAN_SUM_SPLIT = 16;
 
 extern "C" {
 
-int nef_abi_version(void) { return 5; }
+int nef_abi_version(void) { return 6; }
 
 int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                     nef_stream_t stream) {

@@ -110,7 +110,8 @@ __global__ void lead_mean_kernel(const float* __restrict__ z1, const float* __re
 // D[0] = q*latent ; D[1] = q*cat(z1[c1], latent[128:]) ; D[2] = q*cat(latent[:128], z2r[c2])     (:159-176)
 __global__ void mix_fwd_kernel(const float* __restrict__ latent, const float* __restrict__ z1,
                                const float* __restrict__ z2r, const float* __restrict__ q, float* __restrict__ D,
-                               int B, int V, int T, int c1, int c2) {
+                               int B, int V, int T, int c1, int c2, const int32_t* __restrict__ choice_dev) {
+    if (choice_dev) { c1 = choice_dev[0]; c2 = choice_dev[1]; }      // graph replay: the Standin draw lives on the device
     const int64_t rows = (int64_t)B * 256;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t pass = rows * T;
@@ -133,7 +134,9 @@ __global__ void mix_fwd_kernel(const float* __restrict__ latent, const float* __
 __global__ void mix_bwd_kernel(const float* __restrict__ gD, const float* __restrict__ latent,
                                const float* __restrict__ z1, const float* __restrict__ z2r,
                                const float* __restrict__ q, float* __restrict__ gz1, float* __restrict__ gz2r,
-                               float* __restrict__ gq, int B, int V, int T, int c1, int c2) {
+                               float* __restrict__ gq, int B, int V, int T, int c1, int c2,
+                               const int32_t* __restrict__ choice_dev) {
+    if (choice_dev) { c1 = choice_dev[0]; c2 = choice_dev[1]; }
     const int64_t rows = (int64_t)B * 256;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t pass = rows * T;
@@ -765,22 +768,23 @@ int nef_lead_mean(const float* z1, const float* z2r, float* latent, int B, int V
 }
 
 int nef_mix_fwd(const float* latent, const float* z1, const float* z2r, const float* q, float* D, int B, int V, int T,
-                int c1, int c2, nef_stream_t stream) {
+                int c1, int c2, const int32_t* choice_dev, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(latent && z1 && z2r && q && D, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && V > 0 && T > 0 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
     hipLaunchKernelGGL(mix_fwd_kernel, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, latent, z1,
-                       z2r, q, D, B, V, T, c1, c2);
+                       z2r, q, D, B, V, T, c1, c2, choice_dev);
     return nef_launch_status();
 }
 
 int nef_mix_bwd(const float* gD, const float* latent, const float* z1, const float* z2r, const float* q, float* gz1,
-                float* gz2r, float* gq, int B, int V, int T, int c1, int c2, nef_stream_t stream) {
+                float* gz2r, float* gq, int B, int V, int T, int c1, int c2, const int32_t* choice_dev,
+                nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(gD && latent && z1 && z2r && q && gz1 && gz2r && gq, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && V > 0 && T > 0 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
     hipLaunchKernelGGL(mix_bwd_kernel, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gD, latent, z1,
-                       z2r, q, gz1, gz2r, gq, B, V, T, c1, c2);
+                       z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev);
     return nef_launch_status();
 }
 

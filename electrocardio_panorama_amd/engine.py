@@ -24,7 +24,8 @@ DROPOUT_SITES = ("W_encoder.layer1.0", "W_encoder.layer1.1", "W_encoder.layer1.2
 class DropCfg:
     """Dropout behaviour of one forward: off, replayed keep-masks (parity tests), or the in-kernel counter RNG."""
 
-    def __init__(self, training, p=DROP_P, masks=None, seed=0):
+    def __init__(self, training, p=DROP_P, masks=None, seed=0, seed_dev=None):
+        self.seed_dev = seed_dev           # device uint64 added to the seed at run time (hipGraph replay)
         self.on = bool(training) and p > 0.0
         self.p = p if self.on else 0.0
         self.scale = 1.0 / (1.0 - p) if self.on else 1.0
@@ -37,14 +38,14 @@ class DropCfg:
             return self
         m = dict(self.masks)
         m[site] = self.masks[site][:, :, t0:t0 + W].contiguous()
-        return DropCfg(True, self.p, m, self.seed)
+        return DropCfg(True, self.p, m, self.seed, self.seed_dev)
 
     def args(self, site):
         if not self.on:
             return dict(mask=None, drop_p=0.0, drop_scale=1.0, seed=0)
         if self.masks is not None:
             return dict(mask=self.masks[site], drop_p=0.0, drop_scale=self.scale, seed=0)
-        return dict(mask=None, drop_p=self.p, drop_scale=self.scale,
+        return dict(mask=None, drop_p=self.p, drop_scale=self.scale, seed_dev=self.seed_dev,
                     seed=(self.seed * 0x9E3779B1 + DROPOUT_SITES.index(site) * 0x85EBCA6B + 1) & 0xFFFFFFFFFFFFFFFF)
 
 
@@ -66,7 +67,9 @@ def block_fwd(xv, P, prefix, K, Cog, drop):
 
 
 def _side(device):
-    return ops.SideStream.get(device) if os.environ.get("NEF_SIDE_STREAM", "1") != "0" else ops._Inline()
+    if os.environ.get("NEF_SIDE_STREAM", "1") == "0" or torch.cuda.is_current_stream_capturing():
+        return ops._Inline()          # inside a hipGraph capture everything stays on the capturing stream
+    return ops.SideStream.get(device)
 
 
 def block_bwd(saved, gy, P, grads, out=None, side=None, pre_gated=False, gate_input=False):
@@ -240,7 +243,7 @@ def _latents(P, x, in_theta, rois, drop, save):
 def forward(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", training=True, drop=None,
             lead_choice=(0, 0), save=False, rest_chunk=8, status=None):
     """Returns (outputs tuple, saved-state or None).  `lead_choice` are the two Standin lead indices
-    (model_nefnet.py:154,156), drawn by the caller."""
+    (model_nefnet.py:154,156), drawn by the caller: a tuple of ints, or a device int32[2] tensor (graph replay)."""
     drop = drop or DropCfg(False)
     B, V, L = x.shape
     T = L // 4
@@ -250,12 +253,11 @@ def forward(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", t
     z2r = ops.roi_unpool_fwd(z2b, rois, T, status)
     latent = ops.lead_mean(z1, z2r, V)
     q = ops.theta_mlp_fwd(q_theta, P["mlp2.weight"], P["mlp2.bias"])             # [B, 256]
-    c1, c2 = lead_choice
-    D = ops.mix_fwd(latent, z1, z2r, q, V, c1, c2)                                # [3B, 256, T]
+    D = ops.mix_fwd(latent, z1, z2r, q, V, lead_choice)                           # [3B, 256, T]
     out3, dsv = decoder_fwd(D, P, Bf, 3, training, save)
     outs = (out3[0:B], out3[B:2 * B], out3[2 * B:3 * B])
     if save:
-        sv.update(z1=z1, z2r=z2r, latent=latent, q=q, q_theta=q_theta, choice=(c1, c2), dec=dsv)
+        sv.update(z1=z1, z2r=z2r, latent=latent, q=q, q_theta=q_theta, choice=lead_choice, dec=dsv)
     if phase == "train":
         return outs, sv
     if phase in ("val", "test"):
@@ -333,8 +335,7 @@ def backward(P, sv, g_outs):
     g_out = torch.cat([p_.contiguous() for p_ in parts], dim=0)
     side = _side(g_out.device)
     gD = decoder_bwd(sv["dec"], g_out, P, grads, side)
-    c1, c2 = sv["choice"]
-    gz1, gz2r, gq = ops.mix_bwd(gD, sv["latent"], sv["z1"], sv["z2r"], sv["q"], V, c1, c2)
+    gz1, gz2r, gq = ops.mix_bwd(gD, sv["latent"], sv["z1"], sv["z2r"], sv["q"], V, sv["choice"])
     gW2, gb2 = side.run(lambda: ops.theta_mlp_bwd(sv["q_theta"], gq, 256), gq)
     gz2b = ops.roi_unpool_bwd(gz2r, sv["rois"])                                  # [B, 128V, 7, 32]
     gh3 = gz2b.view(B, 128 * V * N_SEG, 2 * ROI_BINS)

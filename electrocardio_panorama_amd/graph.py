@@ -1,0 +1,139 @@
+"""hipGraph-captured train step.
+
+At the reference's own training shape (batch 32, 512-sample beats, `train_net.py:27`) a step is ~250 short launches
+and the host cannot issue them as fast as the GPU retires them.  `GraphedTrainStep` captures forward + losswrapper +
+backward + momentum-SGD once per input shape (torch.cuda.CUDAGraph on the stream the C ABI launches into) and replays
+it: inputs are copied into static buffers, and the only per-step host decisions -- the two Standin lead choices
+(reference model_nefnet.py:154,156, drawn from Python's `random` in the reference's order) and the dropout seed --
+travel through device words that the kernels read at run time.  Same arithmetic as the eager path.
+"""
+import random
+
+import torch
+import torch.distributed as dist
+
+from . import engine, ops
+
+
+class GraphedTrainStep:
+    def __init__(self, model, cfg, lr=None, momentum=0.9):
+        if cfg.DATA.noise:
+            raise NotImplementedError("cfg.DATA.noise adds a host-side tensor op between model and loss")
+        self.model, self.cfg = model, cfg
+        self.lr = float(cfg.SOLVER.lr if lr is None else lr)
+        self.mu = float(momentum)
+        self.factors = tuple(float(f) for f in cfg.SOLVER.loss_factor)
+        self.reg_l2 = {"l1_loss": False, "l2_loss": True}[cfg.SOLVER.reg_loss]
+        u = cfg.SOLVER.loss_using
+        self.use_mask = (1 if 1 in u else 0) | (2 if 2 in u else 0) | (4 if 3 in u else 0)
+        self.graph = None
+        self.shape = None
+        self.calls = 0
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    # -------------------------------------------------------------------------------------------------
+    def _flatten(self, live):
+        named = dict(self.model.named_parameters())
+        self.live = live
+        n = sum(named[k].numel() for k in live)
+        dev = self.data.device
+        self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat_g = torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat_buf = torch.zeros(n, device=dev, dtype=torch.float32)
+        off = 0
+        for k in live:
+            p = named[k]
+            m = p.numel()
+            self.flat_p[off:off + m].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + m].view_as(p.data)       # parameters become views of the flat buffer
+            off += m
+
+    def _fwd_bwd(self):
+        m = self.model
+        P = {k: v.detach() for k, v in m.named_parameters()}
+        drop = engine.DropCfg(True, m.dropout_p, m.dropout_masks, seed=0, seed_dev=self.seed_dev)
+        outs, sv = engine.forward(P, dict(m.named_buffers()), self.data, self.in_theta, self.q_theta, self.rois,
+                                  phase="train", training=True, drop=drop, lead_choice=self.choice_dev, save=True,
+                                  status=self.status)
+        o, p_, l_ = (t.contiguous() for t in outs)
+        self.losses.copy_(ops.loss_fwd(o, p_, l_, self.target, self.factors, self.reg_l2, self.use_mask))
+        g3 = ops.loss_bwd(o, p_, l_, self.target, None, self.factors, self.reg_l2, self.use_mask)
+        return engine.backward(P, sv, g3)
+
+    def _sgd(self):
+        ops.sgd_momentum(self.flat_p, self.flat_g, self.flat_buf, self.lr, self.mu, 1.0 / self.world, False)
+
+    def _body(self):
+        grads = self._fwd_bwd()
+        torch.cat([grads[k].reshape(-1) for k in self.live], out=self.flat_g)
+        if self.world == 1:
+            self._sgd()
+
+    def _build(self, data, in_theta, q_theta, rois, target):
+        dev = data.device
+        self.data, self.in_theta, self.q_theta = (torch.empty_like(t, dtype=torch.float32) for t in (data, in_theta, q_theta))
+        self.rois = torch.empty_like(rois, dtype=torch.int64)
+        self.target = torch.empty(data.shape[0], 1, data.shape[2], device=dev, dtype=torch.float32)
+        self.choice_dev = torch.zeros(2, device=dev, dtype=torch.int32)
+        self.seed_dev = torch.zeros(1, device=dev, dtype=torch.int64)
+        self.status = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.losses = torch.zeros(4, device=dev, dtype=torch.float32)
+        self._host = torch.zeros(4, dtype=torch.int64).pin_memory()
+        self._stage(data, in_theta, q_theta, rois, target, draw=False)      # probe: no `random` consumed
+        self.model.train()
+        # eager probe (no update): which parameters are live, and every kernel variant gets its one-time setup
+        saved = {k: v.clone() for k, v in self.model.named_buffers()}
+        grads = self._fwd_bwd()
+        self._flatten([k for k, _ in self.model.named_parameters() if grads.get(k) is not None])
+        for k, v in self.model.named_buffers():
+            v.copy_(saved[k])
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        saved = {k: v.clone() for k, v in self.model.named_buffers()}
+        p0, b0 = self.flat_p.clone(), self.flat_buf.clone()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        # capture does not execute, but keep state exactly as before the capture regardless
+        for k, v in self.model.named_buffers():
+            v.copy_(saved[k])
+        self.flat_p.copy_(p0)
+        self.flat_buf.copy_(b0)
+        self.shape = (tuple(data.shape), tuple(in_theta.shape))
+
+    def _stage(self, data, in_theta, q_theta, rois, target, draw=True):
+        self.data.copy_(data, non_blocking=True)
+        self.in_theta.copy_(in_theta, non_blocking=True)
+        self.q_theta.copy_(q_theta, non_blocking=True)
+        self.rois.copy_(rois, non_blocking=True)
+        self.target.copy_(target.reshape(self.target.shape), non_blocking=True)
+        V = self.model.lead_num
+        if draw:
+            self.calls += 1
+            # Python `random` consumed exactly twice per step, z1 choice first (model_nefnet.py:154,156)
+            self._host[0], self._host[1] = random.randint(0, V - 1), random.randint(0, V - 1)
+        self._host[2] = (torch.initial_seed() + self.calls) & 0x7FFFFFFFFFFF
+        self.choice_dev.copy_(self._host[:2].to(torch.int32), non_blocking=False)
+        self.seed_dev.copy_(self._host[2:3], non_blocking=False)
+
+    # -------------------------------------------------------------------------------------------------
+    def set_lr(self, lr):
+        """A captured launch freezes its scalar arguments: a new learning rate re-captures the graph."""
+        if float(lr) != self.lr:
+            self.lr = float(lr)
+            self.graph = None
+
+    def __call__(self, data, in_theta, q_theta, rois, target):
+        """One train step; returns the device tensor [loss, f0*l1, f1*l2, f2*l3] (valid in stream order)."""
+        shape = (tuple(data.shape), tuple(in_theta.shape))
+        if self.graph is None or self.shape != shape:
+            had_state = self.graph is None and self.shape == shape      # lr change: keep parameters / momentum
+            keep = (self.flat_p, self.flat_buf) if had_state else None
+            self._build(data, in_theta, q_theta, rois, target)
+            if keep is not None:
+                self.flat_buf.copy_(keep[1])
+        self._stage(data, in_theta, q_theta, rois, target)
+        self.graph.replay()
+        if self.world > 1:
+            dist.all_reduce(self.flat_g)
+            self._sgd()
+        return self.losses

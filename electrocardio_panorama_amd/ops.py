@@ -162,7 +162,7 @@ def pack_weight(w, G, flip=False):
 
 
 def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None, gate_scale=1.0, relu=False,
-         mask=None, drop_p=0.0, drop_scale=1.0, seed=0, role="conv_fwd", pro=None):
+         mask=None, drop_p=0.0, drop_scale=1.0, seed=0, role="conv_fwd", pro=None, seed_dev=None):
     """out = epilogue(conv1d(prologue(x) * in_scale, w) + bias + res).  `xv`, `res`, `gate`, `out` are GV views;
     `in_scale` is (tensor, batch_stride, group_stride).  `pro` = (mode, a, b, Bp): input prologue applied while
     staging -- bit0 BatchNorm affine + ReLU with a/b [P, C_in], bit1 x2 linear upsampling of a half-resolution input
@@ -191,6 +191,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
         a.pro_mode, a.pro_a, a.pro_b, a.pro_Bp = pro[0], _p(pro[1]), _p(pro[2]), pro[3]
     a.relu = int(relu)
     a.gate_scale, a.drop_scale, a.drop_p, a.rng_seed = gate_scale, drop_scale, drop_p, seed
+    a.rng_seed_dev = _p(seed_dev)
     ev = _timed((role, K, xv.G, xv.Cg, Cog, xv.B, T_out))
     _lib.check(L.nef_conv_fwd(C.byref(a), _stream()), "nef_conv_fwd")
     if ev is not None:
@@ -411,23 +412,33 @@ def lead_mean(z1, z2r, V):
     return latent
 
 
-def mix_fwd(latent, z1, z2r, q, V, c1, c2):
+def _choice(c):
+    """(c1, c2) as ints, or a device int32[2] tensor (graph replay) -> (c1, c2, device pointer)."""
+    if torch.is_tensor(c):
+        return 0, 0, c.data_ptr()
+    return int(c[0]), int(c[1]), None
+
+
+def mix_fwd(latent, z1, z2r, q, V, c1, c2=None):
     L = _lib.load()
+    c1, c2, cdev = _choice(c1 if c2 is None else (c1, c2))
     _chk(latent), _chk(q)
     B, _, T = latent.shape
     D = torch.empty(3 * B, 256, T, device=latent.device, dtype=torch.float32)
-    _lib.check(L.nef_mix_fwd(_p(latent), _p(z1), _p(z2r), _p(q), _p(D), B, V, T, c1, c2, _stream()), "nef_mix_fwd")
+    _lib.check(L.nef_mix_fwd(_p(latent), _p(z1), _p(z2r), _p(q), _p(D), B, V, T, c1, c2, cdev, _stream()),
+               "nef_mix_fwd")
     return D
 
 
-def mix_bwd(gD, latent, z1, z2r, q, V, c1, c2):
+def mix_bwd(gD, latent, z1, z2r, q, V, c1, c2=None):
     L = _lib.load()
+    c1, c2, cdev = _choice(c1 if c2 is None else (c1, c2))
     _chk(gD)
     B, _, T = latent.shape
     gz1, gz2r = torch.empty_like(z1), torch.empty_like(z2r)
     gq = torch.empty(B, 256, device=latent.device, dtype=torch.float32)
     _lib.check(L.nef_mix_bwd(_p(gD), _p(latent), _p(z1), _p(z2r), _p(q), _p(gz1), _p(gz2r), _p(gq), B, V, T, c1, c2,
-                             _stream()), "nef_mix_bwd")
+                             cdev, _stream()), "nef_mix_bwd")
     return gz1, gz2r, gq
 
 

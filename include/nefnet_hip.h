@@ -33,7 +33,7 @@ extern "C" {
 typedef void* nef_stream_t;
 
 /* ABI version of this header; bumped on any signature change. */
-int nef_abi_version(void);   /* 5 */
+int nef_abi_version(void);   /* 6 */
 
 /* ---------------------------------------------------------------------------------------------
  * Stem: Conv1d(1->128 per lead, k15, s2, p7, no bias) + ReLU + MaxPool1d(3,2,1), fused.
@@ -84,6 +84,8 @@ typedef struct nef_conv_args {
     const float* pro_b;
     int32_t pro_mode;
     int32_t pro_Bp;
+    const uint64_t* rng_seed_dev;  /* NULL, or a device word added to rng_seed at run time (hipGraph replay: a captured
+                                      launch freezes its arguments, the per-step seed must live in device memory) */
 } nef_conv_args;
 
 /* y = epilogue(conv(x * in_scale, wp) + bias + res).  Also the bwd-data pass (pack with transpose_flip=1,
@@ -165,12 +167,14 @@ int nef_roi_segment_table(const int64_t* rois, int64_t* seg_start, int64_t* seg_
 /* ---------------------------------------------------------------------------------------------
  * Lead mean / Standin shuffle / query scaling.  model_nefnet.py:146-176.
  *   z1, z2r [B][128V][T]; latent [B][256][T] = cat(mean_v z1, mean_v z2r);
- *   q [B][256];  D [3][B][256][T]:  D0 = q*latent, D1 = q*cat(z1[c1], z2mean), D2 = q*cat(z1mean, z2r[c2]). */
+ *   q [B][256];  D [3][B][256][T]:  D0 = q*latent, D1 = q*cat(z1[c1], z2mean), D2 = q*cat(z1mean, z2r[c2]).
+ *   choice_dev: NULL, or device int32[2] = {c1, c2} that overrides the arguments (hipGraph replay). */
 int nef_lead_mean(const float* z1, const float* z2r, float* latent, int B, int V, int T, nef_stream_t stream);
 int nef_mix_fwd(const float* latent, const float* z1, const float* z2r, const float* q, float* D, int B, int V,
-                int T, int c1, int c2, nef_stream_t stream);
+                int T, int c1, int c2, const int32_t* choice_dev, nef_stream_t stream);
 int nef_mix_bwd(const float* gD, const float* latent, const float* z1, const float* z2r, const float* q, float* gz1,
-                float* gz2r, float* gq, int B, int V, int T, int c1, int c2, nef_stream_t stream);
+                float* gz2r, float* gq, int B, int V, int T, int c1, int c2, const int32_t* choice_dev,
+                nef_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Decoder pieces.  model_nefnet.py:10-27,101-107.
