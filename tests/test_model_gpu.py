@@ -397,3 +397,47 @@ def test_graphed_step_matches_eager(golden_dir):
     l1 = step2(b["data"], b["input_theta"], b["target_theta"], b["rois"], b["target_view"]).clone()
     l2 = step2(b["data"], b["input_theta"], b["target_theta"], b["rois"], b["target_view"]).clone()
     assert torch.isfinite(l1).all() and torch.isfinite(l2).all() and not torch.equal(l1, l2)
+
+
+def test_adversarial_rois_full_step_vs_oracle():
+    """Zero-length and 1-sample segments, boundaries at every residue mod 4, through a full train step (forward,
+    losses, flat gradient) against the oracle; the integer segment table is bit-exact."""
+    from electrocardio_panorama_amd import ops as o
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    V, B, L, seed = 3, 2, 512, 17
+    b = batch_t(B, V, L, seed, dev="cpu")
+    b["rois"] = torch.tensor([[[0, 1], [1, 2], [2, 7], [7, 9], [9, 250], [250, 251], [251, 512]],
+                              [[0, 3], [3, 3], [3, 130], [130, 133], [133, 134], [134, 509], [509, 512]]])
+    start, length = o.roi_segment_table(b["rois"].to(DEV))
+    rs, rl = orc.roi_segment_table(b["rois"])
+    assert torch.equal(start.cpu(), rs) and torch.equal(length.cpu(), rl) and int(rl.sum()) == 2 * (L // 4)
+    m = hashed_model(V).train()
+    m.dropout_p = 0.0
+    bd = {k: v.to(DEV) for k, v in b.items()}
+    random.seed(seed)
+    outs = m(bd["data"], bd["input_theta"], bd["target_theta"], bd["rois"], phase="train")
+    from electrocardio_panorama_amd.network import build_loss
+    cfg = make_cfg(V)
+    losses = build_loss(cfg)(outs[0], outs[1], outs[2], bd["target_view"].unsqueeze(1), cfg)
+    losses[0].backward()
+    assert m.segment_status() == 0
+    P, Bf = orc.require_grad(hw.hashed_params(V)), hw.hashed_buffers()
+    random.seed(seed)
+    ref = orc.forward(P, Bf, b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train", training=True, p=0.0)
+    rl_ = orc.loss_v1(ref[0], ref[1], ref[2], b["target_view"].unsqueeze(1))
+    rl_[0].backward()
+    for a, r in zip(outs, ref):
+        assert rel(a, r) < FWD_TOL
+    live = [k for k in P if k not in orc.DEAD_PARAMS]
+    named = dict(m.named_parameters())
+    got = torch.cat([named[k].grad.reshape(-1).cpu() for k in live])
+    want = torch.cat([P[k].grad.reshape(-1) for k in live])
+    assert rel(got, want) < LOOSE, rel(got, want)
+    # ROIs that do not tile [0, L] are flagged on the device (the reference would fail in torch.cat)
+    bad = bd["rois"].clone()
+    bad[0, 3, 1] = 5
+    m(bd["data"], bd["input_theta"], bd["target_theta"], bad, phase="train")
+    assert m.segment_status() == 1
+    with pytest.raises(TypeError):
+        m(bd["data"], bd["input_theta"], bd["target_theta"], bd["rois"].float(), phase="train")
