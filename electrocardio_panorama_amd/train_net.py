@@ -1,8 +1,8 @@
 """Packaged equivalent of reference codes/train_net.py:10-32: seed, data loaders, Solver(cfg).train(...).
 
-Datasets are outside this build's scope.  If the reference's `dataset` package is
-importable (put reference `codes/` on PYTHONPATH) it is used unchanged; otherwise seeded synthetic `meta` batches with
-the same schema are generated."""
+Data: when the configured label lists exist (`cfg.DATA.train_label_path` / `test_label_path`, reference on-disk
+format) the packaged Tianchi per-beat dataset (`dataset/tianchi.py`) feeds torch DataLoaders exactly as the reference
+does; otherwise seeded synthetic `meta` batches with the same schema are generated."""
 import os
 
 import numpy as np
@@ -29,15 +29,24 @@ class SyntheticLoader:
 
 
 def build_loaders(cfg, batch_size=32):
-    try:
-        from dataset import build_dataset                      # the reference's package, if present
+    if os.path.exists(cfg.DATA.train_label_path) and os.path.exists(cfg.DATA.test_label_path):
         from torch.utils.data import DataLoader
+        from .dataset import build_dataset
         train = DataLoader(build_dataset(cfg, phase='train'), batch_size=batch_size, shuffle=True, num_workers=16,
-                           drop_last=True)
-        test = DataLoader(build_dataset(cfg, phase='test'), batch_size=batch_size, num_workers=8, drop_last=True)
+                           drop_last=True, collate_fn=_collate)
+        test = DataLoader(build_dataset(cfg, phase='test'), batch_size=batch_size, num_workers=8, drop_last=True,
+                          collate_fn=_collate)
         return train, test
-    except ImportError:
-        return SyntheticLoader(cfg, batch_size, seed=cfg.seed), SyntheticLoader(cfg, batch_size, 2, seed=cfg.seed + 10 ** 6)
+    return SyntheticLoader(cfg, batch_size, seed=cfg.seed), SyntheticLoader(cfg, batch_size, 2, seed=cfg.seed + 10 ** 6)
+
+
+def _collate(items):
+    """Stack the array fields of the `meta` dicts (ids and lead-name lists stay lists)."""
+    out = {}
+    for k in items[0]:
+        v = [it[k] for it in items]
+        out[k] = torch.from_numpy(np.stack(v)) if isinstance(v[0], np.ndarray) else v
+    return out
 
 
 def main(cfg):

@@ -134,3 +134,28 @@ def test_metrics_psnr_ssim():
     vx = 7 / 6 * (uniform_filter(x * x, 7) - ux * ux)
     assert abs(vx[i] - cov[0, 0]) < 1e-12 and abs(ux[i] - wx.mean()) < 1e-12
     assert abs(ssim_1d(x, x) - 1.0) < 1e-12 and s_i < 1
+
+
+def test_dataset_reproduces_reference_batch(tmp_path):
+    """f3: the Tianchi per-beat dataset on the two recordings bundled with the reference (stored as data fixtures)
+    yields, for the same seeds, exactly the batch the reference's own dataset class produced (fixture G7)."""
+    import random
+    from electrocardio_panorama_amd.config import get_defaults, resolve_config_path
+    from electrocardio_panorama_amd.dataset import build_dataset
+    gold = os.path.join(ROOT, "tests", "golden")
+    listing = tmp_path / "test_jsons.txt"
+    listing.write_text("11315.json\n40723.json\n")
+    cfg = get_defaults()
+    cfg.merge_from_file(resolve_config_path("config/nef_net.yml"))
+    cfg.DATA.test_label_path = cfg.DATA.train_label_path = str(listing)
+    cfg.DATA.train_data_root = cfg.DATA.train_label_root = os.path.join(gold, "tianchi")
+    random.seed(3)
+    np.random.seed(3)
+    ds = build_dataset(cfg, "test")
+    items = [ds[i] for i in range(len(ds))]
+    z = np.load(os.path.join(gold, "real_tianchi_B2_V3.npz"))
+    for k in ("data", "rois", "input_theta", "target_view", "target_theta", "rest_view", "rest_theta"):
+        got = np.stack([np.asarray(it[k]) for it in items])
+        assert got.shape == z[k].shape, k
+        assert np.array_equal(got.astype(z[k].dtype), z[k]), k
+    assert items[0]["rois"].dtype == np.int64 and items[0]["rois"][6, 1] == 512 and items[0]["noise"].shape == (512,)
