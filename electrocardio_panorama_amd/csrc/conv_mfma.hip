@@ -709,7 +709,13 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
     const int KC = K == 7 ? 16 : (K == 3 ? 32 : 64);
     NEF_REQUIRE(a->Cin_g % KC == 0, NEF_E_SHAPE);
     hipStream_t st = (hipStream_t)stream;
-    const bool big = (a->Cout_g % 128 == 0);
+    bool big = (a->Cout_g % 128 == 0);
+    if (big) {
+        // small problems (reference-native batch 32, L=512): a 128-row tile gives fewer workgroups than the chip has
+        // CUs; halve the M tile so twice as many workgroups share the same work
+        const ColTiling ct0 = make_tiling(a->B, a->T, NT);
+        if ((int64_t)a->G * (a->Cout_g / 128) * ct0.n_tiles < 384) big = false;
+    }
     if (a->pro_mode != 0) {
         NEF_REQUIRE(K == 3 && a->pro_mode >= 1 && a->pro_mode <= 3 && !a->in_scale, NEF_E_UNSUPPORTED);
         NEF_REQUIRE(!(a->pro_mode & 1) || (a->pro_a && a->pro_b && a->pro_Bp > 0), NEF_E_NULL);

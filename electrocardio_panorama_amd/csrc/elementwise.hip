@@ -644,15 +644,19 @@ __global__ __launch_bounds__(256) void loss_partial(const float* __restrict__ pr
     }
 }
 
-__global__ void loss_final(const double* __restrict__ part, float* __restrict__ losses, int nblk, int64_t n, float f0,
-                           float f1, float f2, int use_mask) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void loss_final(const double* __restrict__ part, float* __restrict__ losses, int nblk,
+                                                  int64_t n, float f0, float f1, float f2, int use_mask) {
+    __shared__ double sm[4];
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int i = 0; i < nblk; ++i) {
+    for (int i = threadIdx.x; i < nblk; i += 256) {
         s1 += part[i * 3];
         s2 += part[i * 3 + 1];
         s3 += part[i * 3 + 2];
     }
+    s1 = nef_block_sum_d(s1, sm);
+    s2 = nef_block_sum_d(s2, sm);
+    s3 = nef_block_sum_d(s3, sm);
+    if (threadIdx.x != 0) return;
     const float l1 = (use_mask & 1) ? (float)(s1 / (double)n) : 0.f;
     const float l2 = (use_mask & 2) ? (float)(s2 / (double)n) : 0.f;
     const float l3 = (use_mask & 4) ? (float)(s3 / (double)n) : 0.f;
@@ -950,7 +954,7 @@ int nef_loss_fwd(const float* pred, const float* pred_p, const float* pred_l, co
     NEF_REQUIRE(ws_bytes >= nef_loss_ws_bytes(), NEF_E_WORKSPACE);
     hipLaunchKernelGGL(loss_partial, dim3(LOSS_BLOCKS), dim3(256), 0, NEF_ST, pred, pred_p, pred_l, target, (double*)ws,
                        n, reg_l2);
-    hipLaunchKernelGGL(loss_final, dim3(1), dim3(64), 0, NEF_ST, (const double*)ws, losses, LOSS_BLOCKS, n, f0, f1, f2,
+    hipLaunchKernelGGL(loss_final, dim3(1), dim3(256), 0, NEF_ST, (const double*)ws, losses, LOSS_BLOCKS, n, f0, f1, f2,
                        use_mask);
     return nef_launch_status();
 }
