@@ -111,7 +111,8 @@ class GraphedTrainStep:
             self.calls += 1
             # Python `random` consumed exactly twice per step, z1 choice first (model_nefnet.py:154,156)
             self._host[0], self._host[1] = random.randint(0, V - 1), random.randint(0, V - 1)
-        self._host[2] = (torch.initial_seed() + self.calls) & 0x7FFFFFFFFFFF
+        rank = dist.get_rank() if self.world > 1 else 0
+        self._host[2] = (torch.initial_seed() + self.calls + rank * 0x9E3779B1) & 0x7FFFFFFFFFFF
         self.choice_dev.copy_(self._host[:2].to(torch.int32), non_blocking=False)
         self.seed_dev.copy_(self._host[2:3], non_blocking=False)
 

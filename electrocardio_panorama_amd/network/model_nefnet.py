@@ -114,9 +114,13 @@ class Model_nefnet(nn.Module):
         return t.detach().to(torch.float32).contiguous()
 
     def _drop_cfg(self):
+        """Counter-RNG seed of this forward: global seed + call counter, offset per data-parallel rank so that shards
+        draw independent masks (parameters and Standin lead choices stay identical across ranks)."""
         self._drop_calls += 1
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and
+                                                torch.distributed.is_initialized()) else 0
         return engine.DropCfg(self.training, self.dropout_p, self.dropout_masks,
-                              seed=(torch.initial_seed() + self._drop_calls) & 0x7FFFFFFFFFFF)
+                              seed=(torch.initial_seed() + self._drop_calls + rank * 0x9E3779B1) & 0x7FFFFFFFFFFF)
 
     def segment_status(self):
         """1 if any forward saw ROIs whose latent segment lengths were negative or did not sum to T (device flag,
