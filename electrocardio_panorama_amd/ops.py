@@ -55,15 +55,21 @@ def workspace(nbytes, device):
 class SideStream:
     """A second HIP stream for work that is off the critical dependency chain of the backward pass (weight and bias
     gradients are only needed by the optimiser).  The MFMA-bound bwd-weight kernels then overlap with the HBM-bound
-    elementwise kernels of the main chain instead of queueing behind them.  Tensors crossing streams are registered
-    with the caching allocator (`record_stream`) so their memory is not recycled while the other stream still uses it."""
+    elementwise kernels of the main chain instead of queueing behind them.
+
+    Memory safety without `record_stream` (which makes the caching allocator hoard memory: blocks with pending
+    cross-stream uses cannot be recycled, so it keeps reserving new ones): the inputs of a side-stream launch are kept
+    referenced here until an event recorded behind that launch has completed, or until `join()` has made the main
+    stream wait for the side stream -- in both cases any later reuse of their memory is ordered after the side
+    kernel.  Outputs are allocated from the side stream's pool and are only reused by side-stream work of a later
+    step, which starts with `wait_stream(main)` and therefore after their last reader."""
 
     _cache = {}
 
     def __init__(self, device):
         self.device = device
         self.stream = torch.cuda.Stream(device)
-        self.outputs = []
+        self.pending = []          # (event, tensors kept alive)
 
     @classmethod
     def get(cls, device):
@@ -76,21 +82,19 @@ class SideStream:
         """Run fn() on the side stream once everything enqueued so far on the current stream is done."""
         main = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(main)
-        for t in inputs:
-            if t is not None:
-                t.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
             out = fn()
-        self.outputs.extend(out if isinstance(out, (tuple, list)) else [out])
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.pending.append((ev, inputs))
+        while self.pending and self.pending[0][0].query():
+            self.pending.pop(0)
         return out
 
     def join(self):
-        """Make the current stream wait for the side stream and hand its outputs over."""
-        main = torch.cuda.current_stream(self.device)
-        main.wait_stream(self.stream)
-        for t in self.outputs:
-            t.record_stream(main)
-        self.outputs = []
+        """Make the current stream wait for everything issued on the side stream."""
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        self.pending.clear()
 
 
 class _Inline:
