@@ -470,3 +470,26 @@ def test_main_entry_trains_and_checkpoints(tmp_path):
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
     # auto-resume from `last_checkpoint`: like the reference (solver.py:53,62) the saved epoch index is re-run
     assert [ln.split(":")[0] for ln in r2.stdout.splitlines() if ln.startswith("Epoch ")] == ["Epoch 1", "Epoch 2"]
+
+
+def test_allocator_footprint_is_stable():
+    """Steady-state training must not grow the allocator's reserved memory step after step (a regression guard for
+    cross-stream lifetime handling in the backward pass)."""
+    from electrocardio_panorama_amd.network import build_loss
+    from electrocardio_panorama_amd.solver.optim_scheduler import get_optimizer
+    V, B, L = 3, 16, 2048
+    cfg = make_cfg(V)
+    m = hashed_model(V).train()
+    lossf, optim = build_loss(cfg), get_optimizer(cfg, m.parameters())
+    b = batch_t(B, V, L, 3)
+    reserved = []
+    for i in range(14):
+        out, sp, sl = m(b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train")
+        ls = lossf(out, sp, sl, b["target_view"].unsqueeze(1), cfg)
+        ls[0].backward()
+        optim.step()
+        optim.zero_grad()
+        torch.cuda.synchronize()
+        reserved.append(torch.cuda.memory_reserved())
+    assert reserved[-1] <= reserved[4] * 1.05, reserved
+    assert torch.isfinite(ls[0])
