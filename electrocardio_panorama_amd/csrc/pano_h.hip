@@ -1,0 +1,344 @@
+// Half-precision panorama decoder (SURVEY §8 f2 / BASELINE configs 4 and 5): the eval-mode view sweep
+// `Model_nefnet.forward(phase='test')` / `gen_ecg` (reference codes/network/model_nefnet.py:181-190, :196-218) decodes
+// one latent at Q query angles; in eval mode BatchNorm is a fixed affine that folds into the conv, so one decoder pass is
+//   up2 -> conv(256->128)+ReLU -> conv(128->128)+ReLU -> up2 -> conv(128->64)+ReLU -> conv(64->64)+ReLU -> conv(64->1)
+//   -> sigmoid(x/3)                                                                  (model_nefnet.py:101-107, :168)
+// Here the four wide convs run on the gfx950 fp16 matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate) with
+// activations stored TIME-MAJOR in half precision, `[pair][time][channel]`: 8 consecutive channels of one time step are
+// one 16-byte vector, which is exactly one lane's MFMA B operand, and a x2 linear upsample along time is a per-row
+// blend.  The reference has no reduced-precision behaviour; this path is gated against the fp32 path at 2e-3 rel-L2
+// (tests/test_pano_gpu.py) and is opt-in (Model_nefnet.panorama_dtype).
+//
+// hconv_kernel<CIN,COUT,NI,PRO>: implicit GEMM  Y[co][t] = sum_{tap,ci} W[co][ci][tap] * X[t+tap-1][ci]
+//   block   = 256 threads (4 waves); tile = all COUT rows x NT = (4/WM)*32*NI time columns of ONE pair
+//   wave    = 64 co x 32*NI t  -> 2 x NI accumulators of v_mfma_f32_32x32x16_f16
+//   K loop  = CIN/64 channel chunks x 3 taps; per (chunk, tap) "stage" 4 MFMA k-steps of 16 channels
+//   LDS     = X chunk [(NT+2) rows][64 ch + 8 pad] halfs (staged once per chunk, all 3 taps read it shifted by a row)
+//             + 2 weight stages of COUT x 64 halfs in MFMA-fragment order (register-prefetched one stage ahead)
+//   PRO bit0: multiply channel ci by scale[pair][ci] while staging (the per-angle query scaling, model_nefnet.py:184-186)
+//   PRO bit1: X is the x2 linear upsample (align_corners=False) of the stored rows, blended while staging
+//   epilogue: + bias, ReLU, -> fp16, transposed through LDS so that every output row is written as full 16-byte vectors
+#include "nef_common.h"
+
+typedef _Float16 nef_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 nef_h4 __attribute__((ext_vector_type(4)));
+typedef float nef_f16acc __attribute__((ext_vector_type(16)));
+typedef float nef_f8 __attribute__((ext_vector_type(8)));
+
+#define PH_XRS 144   // bytes per staged X row: 64 halfs + 16 B pad (conflict-free ds_read_b128 across 16 rows)
+
+// ------------------------------------------------------------------------------------------------------------
+// fp32 [B][C][T] -> fp16 [B][T][C]  (the latent enters the half-precision pipeline once per sweep)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ph_transpose_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int C,
+                                                           int T) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const float* xb = x + (size_t)b * C * T;
+    for (int r = ly; r < 64; r += 4) {
+        const int c = c0 + r, t = t0 + lx;
+        tile[r][lx] = (c < C && t < T) ? xb[(size_t)c * T + t] : 0.f;
+    }
+    __syncthreads();
+    _Float16* yb = y + (size_t)b * T * C;
+    for (int r = ly; r < 64; r += 4) {
+        const int t = t0 + r, c = c0 + lx;
+        if (t < T && c < C) yb[(size_t)t * C + c] = (_Float16)tile[lx][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fp32 weights [Cout][Cin][3] -> fp16 MFMA A fragments, stage-major:
+//   wp[(((cc*3 + tap)*4 + kq)*MT + mt)*64 + lane][e] = w[mt*32 + (lane&31)][cc*64 + kq*16 + 8*(lane>>5) + e][tap]
+// ------------------------------------------------------------------------------------------------------------
+__global__ void ph_pack_weight_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cout, int Cin) {
+    const int MT = Cout / 32;
+    const int64_t total = (int64_t)Cout * Cin * 3;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = i & 7;
+        int64_t f = i >> 3;
+        const int lane = f & 63;
+        f >>= 6;
+        const int mt = f % MT;
+        f /= MT;
+        const int kq = f & 3;
+        f >>= 2;
+        const int tap = f % 3;
+        const int cc = f / 3;
+        const int co = mt * 32 + (lane & 31);
+        const int ci = cc * 64 + kq * 16 + 8 * (lane >> 5) + e;
+        wp[i] = (_Float16)w[((size_t)co * Cin + ci) * 3 + tap];
+    }
+}
+
+template <int CIN, int COUT, int NI, int PRO>
+__global__ __launch_bounds__(256) void hconv_kernel(const _Float16* __restrict__ x, const nef_h8* __restrict__ wp,
+                                                    const float* __restrict__ bias, const float* __restrict__ scale,
+                                                    _Float16* __restrict__ y, int T, int tiles_per_n, int x_div,
+                                                    int nq, long sc_bs, long sc_is) {
+    constexpr int WM = COUT / 64;            // waves along the output-channel axis
+    constexpr int WN = 4 / WM;               // waves along time
+    constexpr int NT = WN * NI * 32;         // time columns per block
+    constexpr int MT = COUT / 32;            // 32-row A fragments per k-step
+    constexpr int XROWS = NT + 2;
+    constexpr int XBYTES = XROWS * PH_XRS;
+    constexpr int WST_V = COUT * 64 / 8;     // h8 vectors per weight stage
+    constexpr int WPT = WST_V / 256;         // ... per thread
+    constexpr int NCC = CIN / 64;
+    constexpr int ORS = COUT * 2 + 16;       // bytes per output-staging row
+    static_assert(XBYTES % 16 == 0, "weight stages must stay 16-byte aligned");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Xl = smem;
+    nef_h8* Wl = (nef_h8*)(smem + XBYTES);   // [2][WST_V]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int n = blockIdx.x / tiles_per_n, t0 = (blockIdx.x % tiles_per_n) * NT;
+    const int Tin = (PRO & 2) ? T / 2 : T;
+    const _Float16* xb = x + (size_t)(n / x_div) * Tin * CIN;
+    const float* sc = (PRO & 1) ? scale + (size_t)(n / nq) * sc_bs + (size_t)(n % nq) * sc_is : nullptr;
+
+    nef_f16acc acc[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    nef_h8 wreg[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) wreg[j] = wp[tid + j * 256];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) Wl[tid + j * 256] = wreg[j];
+
+    const int seg = tid & 7;                 // this thread's 8-channel segment of a staged row (constant: 256 % 8 == 0)
+    const int brow = wn * NI * 32 + (lane & 31);
+    const int bcol = 16 * (lane >> 5);       // byte offset of this lane's 8 k-values inside a 16-channel k-step
+
+#pragma unroll 1
+    for (int cc = 0; cc < NCC; ++cc) {
+        __syncthreads();                     // every wave is done reading the previous X chunk
+        {
+            float q[8];
+            if (PRO & 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[e] = sc[cc * 64 + seg * 8 + e];
+            }
+            for (int idx = tid; idx < XROWS * 8; idx += 256) {
+                const int r = idx >> 3;
+                const int t = t0 - 1 + r;
+                nef_h8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
+                if (t >= 0 && t < T) {
+                    if (PRO == 0) {
+                        v = *(const nef_h8*)(xb + (size_t)t * CIN + cc * 64 + seg * 8);
+                    } else {
+                        float f[8];
+                        if (PRO & 2) {
+                            // Upsample(scale 2, linear, align_corners=False): out[2i] = .25 x[i-1] + .75 x[i],
+                            // out[2i+1] = .75 x[i] + .25 x[i+1], indices clamped to the row range
+                            const int i = t >> 1;
+                            const int j = (t & 1) ? min(i + 1, Tin - 1) : max(i - 1, 0);
+                            const nef_h8 a = *(const nef_h8*)(xb + (size_t)i * CIN + cc * 64 + seg * 8);
+                            const nef_h8 b = *(const nef_h8*)(xb + (size_t)j * CIN + cc * 64 + seg * 8);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] = 0.75f * (float)a[e] + 0.25f * (float)b[e];
+                        } else {
+                            const nef_h8 a = *(const nef_h8*)(xb + (size_t)t * CIN + cc * 64 + seg * 8);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] = (float)a[e];
+                        }
+                        if (PRO & 1) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] *= q[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (_Float16)f[e];
+                    }
+                }
+                *(nef_h8*)(Xl + r * PH_XRS + seg * 16) = v;
+            }
+        }
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int s = cc * 3 + tap;
+            const bool more = s + 1 < NCC * 3;
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < WPT; ++j) wreg[j] = wp[(size_t)(s + 1) * WST_V + tid + j * 256];
+            }
+            __syncthreads();                 // X chunk (tap 0) and weight stage s are visible
+            const nef_h8* Ws = Wl + (s & 1) * WST_V;
+            const char* Xs = Xl + (brow + tap) * PH_XRS + bcol;
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                nef_h8 a[2], b[NI];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[mi] = Ws[(kq * MT + wm * 2 + mi) * 64 + lane];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) b[ni] = *(const nef_h8*)(Xs + ni * 32 * PH_XRS + kq * 32);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (more) {                      // the other stage was last read before this step's barrier
+                nef_h8* Wn = Wl + ((s + 1) & 1) * WST_V;
+#pragma unroll
+                for (int j = 0; j < WPT; ++j) Wn[tid + j * 256] = wreg[j];
+            }
+        }
+    }
+
+    // epilogue: bias + ReLU -> fp16, staged [t][co] in LDS, then whole rows out
+    __syncthreads();
+    char* Ol = smem;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = wm * 64 + mi * 32 + 8 * g + 4 * (lane >> 5);
+            const nef_f32x4 bv = *(const nef_f32x4*)(bias + co);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                nef_h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)fmaxf(acc[mi][ni][g * 4 + e] + bv[e], 0.f);
+                *(nef_h4*)(Ol + (wn * NI * 32 + ni * 32 + (lane & 31)) * ORS + co * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+    _Float16* yb = y + (size_t)n * T * COUT;
+    constexpr int SEGS = COUT / 8;
+    for (int idx = tid; idx < NT * SEGS; idx += 256) {
+        const int r = idx / SEGS, sg = idx % SEGS;
+        if (t0 + r < T) *(nef_h8*)(yb + (size_t)(t0 + r) * COUT + sg * 8) = *(const nef_h8*)(Ol + r * ORS + sg * 16);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Last conv 64 -> 1 (k3, bias) + sigmoid(x/3) (model_nefnet.py:106,:168/:186): HBM-bound.  8 lanes share one time
+// step (8 channels x 3 taps each), a block covers 256 consecutive time steps of one pair.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ph_outconv_kernel(const _Float16* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int T,
+                                                         int tiles_per_n, int nq, long out_bs, long out_is) {
+    __shared__ float res[256];
+    const int tid = threadIdx.x, seg = tid & 7, row = tid >> 3;
+    const int n = blockIdx.x / tiles_per_n, t0 = (blockIdx.x % tiles_per_n) * 256;
+    float wr[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wr[k][e] = w[(seg * 8 + e) * 3 + k];
+    const float b0 = bias[0];
+    const _Float16* xb = x + (size_t)n * T * 64;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int t = t0 + p * 32 + row;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int tt = t + k - 1;
+            if (tt >= 0 && tt < T && t < T) {
+                const nef_h8 v = *(const nef_h8*)(xb + (size_t)tt * 64 + seg * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += wr[k][e] * (float)v[e];
+            }
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (seg == 0) res[p * 32 + row] = s;
+    }
+    __syncthreads();
+    const int t = t0 + tid;
+    if (t < T) {
+        const float v = (res[tid] + b0) / 3.0f;
+        out[(size_t)(n / nq) * out_bs + (size_t)(n % nq) * out_is + t] = 1.0f / (1.0f + expf(-v));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int NI, int PRO>
+static int launch_hconv(const void* x, const void* wp, const float* bias, const float* scale, void* y, int N, int T,
+                        int x_div, int nq, long sc_bs, long sc_is, hipStream_t st) {
+    constexpr int NT = (4 / (COUT / 64)) * NI * 32;
+    constexpr int XB = (NT + 2) * PH_XRS;
+    constexpr int WB = 2 * COUT * 64 * 2;
+    constexpr int OB = NT * (COUT * 2 + 16);
+    constexpr int LDS = (XB + WB) > OB ? (XB + WB) : OB;
+    const int tiles = (T + NT - 1) / NT;
+    auto k = hconv_kernel<CIN, COUT, NI, PRO>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)N * tiles)), dim3(256), LDS, st, (const _Float16*)x,
+                       (const nef_h8*)wp, bias, scale, (_Float16*)y, T, tiles, x_div, nq, sc_bs, sc_is);
+    return nef_launch_status();
+}
+
+extern "C" {
+
+int nef_pano_h_from_f32(const float* x, void* y, int B, int C, int T, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && y, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && C > 0 && T > 0 && B <= 65535, NEF_E_SHAPE);
+    hipLaunchKernelGGL(ph_transpose_kernel, dim3((T + 63) / 64, (C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x,
+                       (_Float16*)y, C, T);
+    return nef_launch_status();
+}
+
+int nef_pano_h_pack_weight(const float* w, void* wp, int Cout, int Cin, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(w && wp, NEF_E_NULL);
+    NEF_REQUIRE(Cout > 0 && Cin > 0 && Cout % 64 == 0 && Cin % 64 == 0, NEF_E_SHAPE);
+    const int64_t total = (int64_t)Cout * Cin * 3;
+    hipLaunchKernelGGL(ph_pack_weight_kernel, dim3(nef_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (_Float16*)wp, Cout, Cin);
+    return nef_launch_status();
+}
+
+int nef_pano_h_conv(const void* x, const void* wp, const float* bias, const float* scale, void* y, int N, int T, int Cin,
+                    int Cout, int pro_mode, int x_div, int nq, int64_t sc_bs, int64_t sc_is, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && wp && bias && y, NEF_E_NULL);
+    NEF_REQUIRE(N > 0 && T > 0 && x_div > 0 && nq > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(!(pro_mode & 1) || scale, NEF_E_NULL);
+    NEF_REQUIRE(!(pro_mode & 2) || T % 2 == 0, NEF_E_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+#define PH_CASE(ci, co, ni, pro) \
+    if (Cin == ci && Cout == co && pro_mode == pro) \
+        return launch_hconv<ci, co, ni, pro>(x, wp, bias, scale, y, N, T, x_div, nq, sc_bs, sc_is, st)
+    PH_CASE(256, 128, 2, 3);
+    PH_CASE(256, 128, 2, 1);
+    PH_CASE(128, 128, 2, 0);
+    PH_CASE(128, 64, 2, 2);
+    PH_CASE(128, 64, 2, 0);
+    PH_CASE(64, 64, 2, 0);
+#undef PH_CASE
+    return NEF_E_UNSUPPORTED;
+}
+
+int nef_pano_h_outconv(const void* x, const float* w, const float* bias, float* out, int N, int T, int nq, int64_t out_bs,
+                       int64_t out_is, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && w && bias && out, NEF_E_NULL);
+    NEF_REQUIRE(N > 0 && T > 0 && nq > 0, NEF_E_SHAPE);
+    const int tiles = (T + 255) / 256;
+    hipLaunchKernelGGL(ph_outconv_kernel, dim3((unsigned)((int64_t)N * tiles)), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)x, w, bias, out, T, tiles, nq, (long)out_bs, (long)out_is);
+    return nef_launch_status();
+}
+
+}  // extern "C"

@@ -241,7 +241,7 @@ def _latents(P, x, in_theta, rois, drop, save):
 
 
 def forward(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", training=True, drop=None,
-            lead_choice=(0, 0), save=False, rest_chunk=8, status=None):
+            lead_choice=(0, 0), save=False, rest_chunk=8, status=None, half_sweep=False):
     """Returns (outputs tuple, saved-state or None).  `lead_choice` are the two Standin lead indices
     (model_nefnet.py:154,156), drawn by the caller: a tuple of ints, or a device int32[2] tensor (graph replay)."""
     drop = drop or DropCfg(False)
@@ -261,15 +261,18 @@ def forward(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", t
     if phase == "train":
         return outs, sv
     if phase in ("val", "test"):
-        rest = sweep(P, Bf, latent, rest_theta, training, rest_chunk)
+        rest = sweep(P, Bf, latent, rest_theta, training, rest_chunk, half_sweep)
         return outs + (rest,), sv
     raise KeyError("please type correct phase")
 
 
-def sweep(P, Bf, latent, query_thetas, training=False, chunk=8):
+def sweep(P, Bf, latent, query_thetas, training=False, chunk=8, half=False):
     """Decode `latent` [B,256,T] at Q query angles [B,Q,2] -> [B,Q,L] (model_nefnet.py:181-190, :207-216).
-    In training mode each angle is its own BatchNorm pass, in the reference's order."""
+    In training mode each angle is its own BatchNorm pass, in the reference's order.  `half` selects the fp16
+    matrix-core decoder for the eval-mode sweep (opt-in; fp32 is the reference behaviour)."""
     if not training:
+        if half:
+            return sweep_eval_h(P, Bf, latent, query_thetas)
         return sweep_eval(P, Bf, latent, query_thetas, chunk)
     B, Q = query_thetas.shape[0], query_thetas.shape[1]
     rq = ops.theta_mlp_fwd(query_thetas, P["mlp2.weight"], P["mlp2.bias"])       # [B, Q, 256]
@@ -318,11 +321,50 @@ def sweep_eval(P, Bf, latent, query_thetas, chunk=8):
     return rest
 
 
-def gen_ecg(P, Bf, z1, z2b, query_thetas, rois, chunk=8):
+def sweep_eval_h(P, Bf, latent, query_thetas, pair_budget=4096):
+    """The eval-mode sweep on the fp16 matrix cores (pano_h.hip; SURVEY 8-f2, BASELINE configs 4/5).  Same folding as
+    sweep_eval; activations are fp16 [pair][time][channel] with pair = (sample, angle) sample-major, so the result
+    lands in rest[b, q] without a transposing copy.  Both x2 upsamplings and the per-angle query scaling happen while
+    the consuming conv stages its input.  Opt-in: there is no reduced-precision behaviour in the reference."""
+    B, Q, T = query_thetas.shape[0], query_thetas.shape[1], latent.shape[2]
+    dev = latent.device
+    rq = ops.theta_mlp_fwd(query_thetas, P["mlp2.weight"], P["mlp2.bias"])       # [B, Q, 256] fp32
+    lat_h = ops.pano_h_from_f32(latent)                                           # [B, T, 256] fp16
+    wp, bias = [], []
+    for blk, cv, bn, cout in _DEC:
+        pre = f"{blk}.double_conv.{bn}"
+        a, b = ops.bn_eval_affine(P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
+                                  Bf[pre + ".running_var"], BN_EPS)
+        wf, bf_ = ops.fold_bn(P[f"{blk}.double_conv.{cv}.weight"], P[f"{blk}.double_conv.{cv}.bias"], a, b)
+        wp.append(ops.pano_h_pack_weight(wf))
+        bias.append(bf_)
+    rest = torch.empty(B, Q, 4 * T, device=dev, dtype=torch.float32)
+    nq = max(1, min(Q, pair_budget // max(B, 1)))      # angles per chunk: bounds the fp16 intermediates
+    bufs = None
+    for q0 in range(0, Q, nq):
+        n = min(nq, Q - q0)
+        N = B * n
+        if bufs is None or bufs[0].shape[0] != N:
+            bufs = (torch.empty(N, 2 * T, 128, device=dev, dtype=torch.float16),
+                    torch.empty(N, 2 * T, 128, device=dev, dtype=torch.float16),
+                    torch.empty(N, 4 * T, 64, device=dev, dtype=torch.float16),
+                    torch.empty(N, 4 * T, 64, device=dev, dtype=torch.float16))
+        c1 = ops.pano_h_conv(lat_h, wp[0], bias[0], 128, N=N, upsample=True, scale=(rq[:, q0:], Q * 256, 256),
+                             x_div=n, nq=n, out=bufs[0])
+        c2 = ops.pano_h_conv(c1, wp[1], bias[1], 128, out=bufs[1])
+        c3 = ops.pano_h_conv(c2, wp[2], bias[2], 64, upsample=True, out=bufs[2])
+        c4 = ops.pano_h_conv(c3, wp[3], bias[3], 64, out=bufs[3])
+        ops.pano_h_outconv(c4, P["decoder.4.weight"], P["decoder.4.bias"], rest[:, q0:], n, Q * 4 * T, 4 * T)
+    return rest
+
+
+def gen_ecg(P, Bf, z1, z2b, query_thetas, rois, chunk=8, half=False):
     """model_nefnet.py:196-218 (always eval-mode BatchNorm)."""
     V = z1.shape[1] // 128
     z2r = ops.roi_unpool_fwd(z2b.contiguous(), rois, z1.shape[2])
     latent = ops.lead_mean(z1, z2r, V)
+    if half:
+        return sweep_eval_h(P, Bf, latent, query_thetas)
     return sweep(P, Bf, latent, query_thetas, False, chunk)
 
 

@@ -91,6 +91,9 @@ class Model_nefnet(nn.Module):
                                      nn.Conv1d(64, 1, 3, padding=1))
         self.dropout_p = engine.DROP_P
         self.dropout_masks = None      # test hook: {site: uint8 keep-mask} replayed instead of the RNG
+        # 'fp32' (reference arithmetic) or 'fp16': eval-mode view sweeps (phase 'val'/'test' rest_out, gen_ecg) on the
+        # fp16 matrix cores with fp32 accumulation -- opt-in, gated at 2e-3 rel-L2 against the fp32 path
+        self.panorama_dtype = 'fp32'
         self._drop_calls = 0
         self._status = None
 
@@ -121,6 +124,11 @@ class Model_nefnet(nn.Module):
                                                 torch.distributed.is_initialized()) else 0
         return engine.DropCfg(self.training, self.dropout_p, self.dropout_masks,
                               seed=(torch.initial_seed() + self._drop_calls + rank * 0x9E3779B1) & 0x7FFFFFFFFFFF)
+
+    def _half_sweep(self):
+        if self.panorama_dtype not in ('fp32', 'fp16'):
+            raise ValueError(f"panorama_dtype must be 'fp32' or 'fp16', got {self.panorama_dtype!r}")
+        return self.panorama_dtype == 'fp16'
 
     def segment_status(self):
         """1 if any forward saw ROIs whose latent segment lengths were negative or did not sum to T (device flag,
@@ -158,7 +166,8 @@ class Model_nefnet(nn.Module):
             with torch.no_grad():
                 outs, _ = engine.forward(self._params_by_name(), self._buffers_by_name(), x, input_thetas, query_theta,
                                          rois, rest_theta=self._f32(rest_theta), phase=phase, training=self.training,
-                                         drop=drop, lead_choice=choice, status=self._status)
+                                         drop=drop, lead_choice=choice, status=self._status,
+                                         half_sweep=self._half_sweep())
             return outs
         raise KeyError("please type correct phase")
 
@@ -166,4 +175,5 @@ class Model_nefnet(nn.Module):
         self.eval()
         with torch.no_grad():
             return engine.gen_ecg(self._params_by_name(), self._buffers_by_name(), self._f32(z1), self._f32(z2),
-                                  self._f32(query_theta), rois.detach().to(torch.int64).contiguous())
+                                  self._f32(query_theta), rois.detach().to(torch.int64).contiguous(),
+                                  half=self._half_sweep())

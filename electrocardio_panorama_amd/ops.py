@@ -596,3 +596,54 @@ def sgd_momentum(p, g, buf, lr, mu, gscale, first_step):
     _chk(p), _chk(g), _chk(buf)
     _lib.check(L.nef_sgd_momentum(_p(p), _p(g), _p(buf), p.numel(), lr, mu, gscale, int(first_step), _stream()),
                "nef_sgd_momentum")
+
+
+# ------------------------------------------------------------------ half-precision panorama decoder (pano_h.hip)
+def pano_h_from_f32(x):
+    """fp32 [B,C,T] -> fp16 [B,T,C] (time-major)."""
+    L = _lib.load()
+    _chk(x)
+    B, Ct, T = x.shape
+    y = torch.empty(B, T, Ct, device=x.device, dtype=torch.float16)
+    _lib.check(L.nef_pano_h_from_f32(_p(x), _p(y), B, Ct, T, _stream()), "nef_pano_h_from_f32")
+    return y
+
+
+def pano_h_pack_weight(w):
+    """fp32 [Cout,Cin,3] -> fp16 MFMA A-fragment order (flat)."""
+    L = _lib.load()
+    _chk(w)
+    Co, Ci, K = w.shape
+    assert K == 3
+    wp = torch.empty(Co * Ci * 3, device=w.device, dtype=torch.float16)
+    _lib.check(L.nef_pano_h_pack_weight(_p(w), _p(wp), Co, Ci, _stream()), "nef_pano_h_pack_weight")
+    return wp
+
+
+def pano_h_conv(x, wp, bias, Cout, N=None, upsample=False, scale=None, x_div=1, nq=1, out=None):
+    """ReLU(conv_k3(pro(x)) + bias) on fp16 [.,Tin,Cin] -> fp16 [N,T,Cout].  `scale` = (tensor, sc_bs, sc_is)."""
+    L = _lib.load()
+    _chk(x, torch.float16), _chk(bias)
+    Tin, Ci = x.shape[1], x.shape[2]
+    N = x.shape[0] * x_div if N is None else N
+    T = 2 * Tin if upsample else Tin
+    y = torch.empty(N, T, Cout, device=x.device, dtype=torch.float16) if out is None else out
+    mode = (1 if scale is not None else 0) | (2 if upsample else 0)
+    sc, sc_bs, sc_is = scale if scale is not None else (None, 0, 0)
+    e = _timed(("pano_h_conv", Ci, Cout, N, T))
+    _lib.check(L.nef_pano_h_conv(_p(x), _p(wp), _p(bias), _p(sc), _p(y), N, T, Ci, Cout, mode, x_div, nq, sc_bs, sc_is,
+                                 _stream()), "nef_pano_h_conv")
+    if e is not None:
+        e.record()
+    return y
+
+
+def pano_h_outconv(x, w, bias, out, nq, out_bs, out_is):
+    """out[(n/nq)*out_bs + (n%nq)*out_is + t] = sigmoid((conv_k3(x[n]) + bias)/3); x fp16 [N,T,64], out fp32 view base."""
+    L = _lib.load()
+    _chk(x, torch.float16), _chk(w)
+    N, T, Ci = x.shape
+    assert Ci == 64
+    _lib.check(L.nef_pano_h_outconv(_p(x), _p(w), _p(bias), _p(out), N, T, nq, out_bs, out_is, _stream()),
+               "nef_pano_h_outconv")
+    return out

@@ -33,7 +33,7 @@ extern "C" {
 typedef void* nef_stream_t;
 
 /* ABI version of this header; bumped on any signature change. */
-int nef_abi_version(void);   /* 6 */
+int nef_abi_version(void);   /* 7 */
 
 /* ---------------------------------------------------------------------------------------------
  * Stem: Conv1d(1->128 per lead, k15, s2, p7, no bias) + ReLU + MaxPool1d(3,2,1), fused.
@@ -245,6 +245,27 @@ int nef_loss_bwd(const float* pred, const float* pred_p, const float* pred_l, co
  * (1/world_size after an all-reduce sum). */
 int nef_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float gscale,
                      int first_step, nef_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Half-precision panorama decoder (BASELINE configs 4/5): the eval-mode view sweep of
+ * model_nefnet.py:181-190 / gen_ecg :196-218 with BatchNorm folded into the convs (nef_fold_bn), activations kept
+ * as fp16 [pair][time][channel] and the four wide decoder convs (model_nefnet.py:18,21 inside :103,:105) on the
+ * fp16 matrix cores with fp32 accumulation.  No reference counterpart in reduced precision: gated against the fp32
+ * path (2e-3 rel-L2).  Pairs are (sample, angle), sample-major: pair n = b*nq + i.
+ * nef_pano_h_from_f32 : x fp32 [B][C][T] -> y fp16 [B][T][C].
+ * nef_pano_h_pack_weight: w fp32 [Cout][Cin][3] (BN already folded) -> fp16 MFMA A-fragment order, Cout*Cin*3 halfs.
+ * nef_pano_h_conv     : y[n] = ReLU(conv_k3_pad1(pro(x[n / x_div])) + bias), x fp16 [.][Tin][Cin], y fp16 [N][T][Cout];
+ *                       pro_mode bit0: channel ci times scale[(n/nq)*sc_bs + (n%nq)*sc_is + ci] (fp32; the query
+ *                       encoding q of model_nefnet.py:184-186), bit1: x2 linear upsample along time (Tin = T/2,
+ *                       nn.Upsample align_corners=False, :102,:104).  (Cin,Cout) in {(256,128),(128,128),(128,64),(64,64)}.
+ * nef_pano_h_outconv  : out[(n/nq)*out_bs + (n%nq)*out_is + t] = sigmoid((conv_k3(x[n]; w [1][64][3]) + bias)/3),
+ *                       x fp16 [N][T][64], out fp32 (model_nefnet.py:106 + :186). */
+int nef_pano_h_from_f32(const float* x, void* y, int B, int C, int T, nef_stream_t stream);
+int nef_pano_h_pack_weight(const float* w, void* wp, int Cout, int Cin, nef_stream_t stream);
+int nef_pano_h_conv(const void* x, const void* wp, const float* bias, const float* scale, void* y, int N, int T, int Cin,
+                    int Cout, int pro_mode, int x_div, int nq, int64_t sc_bs, int64_t sc_is, nef_stream_t stream);
+int nef_pano_h_outconv(const void* x, const float* w, const float* bias, float* out, int N, int T, int nq,
+                       int64_t out_bs, int64_t out_is, nef_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,159 @@
+"""GPU: the half-precision panorama decoder (csrc/pano_h.hip; SURVEY 8-f2, BASELINE configs 4/5).
+
+The reference computes the view sweep in fp32 only, so there is no reduced-precision behaviour to match: the kernels
+are checked (a) exactly-ish against fp64 torch-CPU math on the SAME fp16-rounded operands (what remains is fp32
+accumulation order and the final rounding of each output to fp16: <= 2^-11 relative per element), and (b) end to end
+against the fp32 product path, the CPU oracle and the reference's golden outputs at the 2e-3 rel-L2 gate SURVEY 8c names.
+"""
+import glob
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import rel, rnd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+HALF_TOL = 2e-3      # rel-L2 gate for the fp16 decoder vs fp32 results (SURVEY 8c "fp16 (C5) ... <= 2e-3 rel-L2")
+
+
+def ops():
+    from electrocardio_panorama_amd import ops as o
+    return o
+
+
+from test_model_gpu import batch_t, hashed_model  # noqa: E402  (same hashed weights / synthetic batches)
+
+
+def up2(x):   # [N, C, T] fp64, nn.Upsample(scale_factor=2, mode='linear', align_corners=False)
+    return F.interpolate(x, scale_factor=2, mode="linear", align_corners=False)
+
+
+def test_from_f32_is_a_rounding_transpose():
+    x = rnd(3, 70, 45, seed=1, scale=4.0)
+    y = ops().pano_h_from_f32(x.to(DEV))
+    assert y.dtype == torch.float16 and y.shape == (3, 45, 70)
+    assert torch.equal(y.cpu(), x.transpose(1, 2).to(torch.float16))
+
+
+@pytest.mark.parametrize("Cin,Cout,T,N,upsample,scaled", [
+    (128, 128, 256, 2, False, False),      # whole tiles
+    (128, 128, 300, 3, False, False),      # ragged last tile
+    (64, 64, 520, 2, False, False),        # 256-column tiles, ragged
+    (128, 64, 512, 2, True, False),        # x2 upsample while staging
+    (128, 64, 200, 1, True, False),
+    (256, 128, 256, 6, True, True),        # layer 1: shared latent, per-(sample, angle) channel scale
+    (256, 128, 40, 3, True, True),         # shorter than one tile
+])
+def test_h_conv_matches_fp64_on_the_same_operands(Cin, Cout, T, N, upsample, scaled):
+    o = ops()
+    Tin = T // 2 if upsample else T
+    nq = 3 if scaled else 1                 # angles per sample
+    NB = N // nq if scaled else N           # stored x rows
+    xh = rnd(NB, Tin, Cin, seed=2).to(torch.float16)
+    w = (rnd(Cout, Cin, 3, seed=3) * (2.0 / (3 * Cin)) ** 0.5).to(torch.float16).float()
+    bias = rnd(Cout, seed=4, scale=0.1)
+    sc = rnd(NB, 5, Cin, seed=5, scale=1.5) if scaled else None          # [sample][angle slot][ci], uses slots 1..3
+    wp = o.pano_h_pack_weight(w.to(DEV))
+    scale = (sc.to(DEV)[:, 1:], 5 * Cin, Cin) if scaled else None
+    y = o.pano_h_conv(xh.to(DEV), wp, bias.to(DEV), Cout, N=N, upsample=upsample, scale=scale,
+                      x_div=nq if scaled else 1, nq=nq)
+    assert y.shape == (N, T, Cout) and y.dtype == torch.float16
+    # the same pipeline in fp64: blend (fp32 in the kernel) -> scale -> round to fp16 -> conv -> +bias -> ReLU
+    x = xh.double().transpose(1, 2)                                       # [NB, Cin, Tin]
+    if upsample:
+        x = up2(x)
+    if scaled:
+        x = torch.stack([x[n // nq] * sc[n // nq, 1 + n % nq].double()[:, None] for n in range(N)])
+    x = x.float().to(torch.float16).double()                              # staging rounds once, from fp32
+    ref = F.relu(F.conv1d(x, w.double(), bias.double(), padding=1)).transpose(1, 2)
+    err = (y.cpu().double() - ref).abs()
+    # fp16 output rounding (2^-11 relative) + fp32 accumulation noise; staging double-rounding can flip one input ulp
+    bound = 2.0 ** -10 * ref.abs() + 2e-3
+    assert bool((err <= bound).all()), float((err - bound).max())
+    assert rel(y, ref) < 5e-4
+
+
+def test_h_outconv():
+    o = ops()
+    N, T, nq = 6, 700, 3
+    xh = rnd(N, T, 64, seed=6, scale=2.0).to(torch.float16)
+    w, b = rnd(1, 64, 3, seed=7, scale=0.2), rnd(1, seed=8)
+    out = torch.full((2, 5, T), -1.0, device=DEV)
+    o.pano_h_outconv(xh.to(DEV), w.to(DEV), b.to(DEV), out[:, 1:], nq, 5 * T, T)
+    ref = torch.sigmoid(F.conv1d(xh.double().transpose(1, 2), w.double(), b.double(), padding=1) / 3.0)[:, 0]
+    got = out.cpu()
+    assert torch.all(got[:, 0] == -1.0) and torch.all(got[:, 4] == -1.0)      # untouched angle slots
+    assert rel(got[:, 1:4].reshape(N, T), ref) < 1e-6
+
+
+def _logit3(o):
+    o = torch.as_tensor(o).double().cpu().clamp(1e-12, 1 - 1e-12)
+    return 3.0 * torch.log(o / (1 - o))
+
+
+@pytest.mark.parametrize("B,V,L,Q", [(2, 3, 512, 5), (3, 1, 1000, 7), (2, 8, 512, 4)])
+def test_sweep_fp16_vs_fp32_path(B, V, L, Q):
+    """Both product paths on the same inputs: outputs and pre-sigmoid logits within the half-precision gate."""
+    m = hashed_model(V).eval()
+    b = batch_t(B, V, L, 11, Q)
+    random.seed(0)
+    ref = m(b["data"], b["input_theta"], b["target_theta"], b["rois"], rest_theta=b["rest_theta"], phase="test")
+    m.panorama_dtype = "fp16"
+    random.seed(0)
+    got = m(b["data"], b["input_theta"], b["target_theta"], b["rois"], rest_theta=b["rest_theta"], phase="test")
+    for a, r in zip(got[:3], ref[:3]):
+        assert torch.equal(a, r)                      # the three training-style outputs stay on the fp32 path
+    assert got[3].shape == (B, Q, L) and got[3].dtype == torch.float32
+    assert rel(got[3], ref[3]) < HALF_TOL, rel(got[3], ref[3])
+    assert rel(_logit3(got[3]), _logit3(ref[3])) < 2 * HALF_TOL, rel(_logit3(got[3]), _logit3(ref[3]))
+    z1, z2 = m(b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="gen")
+    g16 = m.gen_ecg(z1, z2, b["rest_theta"], b["rois"])
+    m.panorama_dtype = "fp32"
+    g32 = m.gen_ecg(z1, z2, b["rest_theta"], b["rois"])
+    assert rel(g16, g32) < HALF_TOL
+    assert torch.equal(g32, ref[3])
+
+
+def test_sweep_fp16_vs_reference_golden(golden_dir):
+    """Against the reference's own outputs (tests/golden/eval_*.npz, written by oracle/make_golden.py)."""
+    files = sorted(glob.glob(os.path.join(golden_dir, "eval_*.npz")))
+    assert files
+    for f in files:
+        z = np.load(f)
+        B, V, L, Q, seed = (int(z[k]) for k in ("B", "V", "L", "Q", "seed"))
+        b = batch_t(B, V, L, seed, Q)
+        m = hashed_model(V).eval()
+        m.panorama_dtype = "fp16"
+        random.seed(seed)
+        rest = m(b["data"], b["input_theta"], b["target_theta"], b["rois"], rest_theta=b["rest_theta"], phase="test")[3]
+        assert rel(rest, z["rest_out"]) < HALF_TOL, (os.path.basename(f), rel(rest, z["rest_out"]))
+        z1, z2 = m(b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="gen")
+        assert rel(m.gen_ecg(z1, z2, b["rest_theta"], b["rois"]), z["gen_ecg"]) < HALF_TOL
+
+
+def test_sweep_fp16_chunking_is_invisible():
+    """Angle chunks (bounded intermediates) must not change a single bit of the result."""
+    from electrocardio_panorama_amd import engine
+    m = hashed_model(1).eval()
+    b = batch_t(4, 1, 512, 5, 9)
+    z1, z2 = m(b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="gen")
+    P, Bf = dict(m.named_parameters()), dict(m.named_buffers())
+    with torch.no_grad():
+        z2r = ops().roi_unpool_fwd(z2.contiguous(), b["rois"], z1.shape[2])
+        latent = ops().lead_mean(z1, z2r, 1)
+        whole = engine.sweep_eval_h(P, Bf, latent, b["rest_theta"], pair_budget=1 << 20)
+        parts = engine.sweep_eval_h(P, Bf, latent, b["rest_theta"], pair_budget=8)       # 2 angles per chunk, ragged end
+    assert torch.equal(whole, parts)
+
+
+def test_panorama_dtype_is_validated():
+    m = hashed_model(1).eval()
+    m.panorama_dtype = "bf16"
+    b = batch_t(2, 1, 512, 5, 3)
+    with pytest.raises(ValueError):
+        m(b["data"], b["input_theta"], b["target_theta"], b["rois"], rest_theta=b["rest_theta"], phase="test")
