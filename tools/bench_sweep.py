@@ -11,6 +11,11 @@ B = int(os.environ.get("B", 1024)); V = int(os.environ.get("V", 1)); L = int(os.
 cfg = bench.make_cfg(V)
 torch.manual_seed(123)
 m = build_model(cfg).float().cuda().eval()
+m.panorama_dtype = os.environ.get("PANO", "fp32")
+BUDGET = os.environ.get("PAIR_BUDGET")
+if BUDGET:
+    from electrocardio_panorama_amd import engine
+    engine.sweep_eval_h.__defaults__ = (int(BUDGET),)
 meta = synth.make_batch(B, V, L, seed=123, Q=Q)
 t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in meta.items()}
 def run():
@@ -23,5 +28,5 @@ for _ in range(n):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 flops = B * Q * 113.5e6 * (L / 512)
-print(f"sweep B={B} V={V} L={L} Q={Q}: {dt*1e3:.1f} ms  {B/dt:.1f} samples/s  {B*Q/dt:.0f} views/s  "
+print(f"sweep[{m.panorama_dtype}] B={B} V={V} L={L} Q={Q}: {dt*1e3:.1f} ms  {B/dt:.1f} samples/s  {B*Q/dt:.0f} views/s  "
       f"{flops/dt/1e12:.1f} TFLOP/s (decoder convs)  out {4*B*Q*L/dt/1e9:.1f} GB/s  peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
