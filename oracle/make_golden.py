@@ -307,11 +307,97 @@ def case_real(network):
     return dev
 
 
+PTB_CONFIGS = ((3, "IIv2v5_v4I_372", "input_fix", "train"), (3, "IIv2v5_v4I_372", "random", "test"),
+               (8, "_8120", "input_fix", "train"), (1, "_192", "input_fix", "test"), (5, "_561", "input_fix", "train"))
+
+
+def synth_ptb_records(seed=31):
+    """Three small PTB-format records (12 leads in PTB order, integer ADC counts) with P/R/T annotations."""
+    rng = np.random.default_rng(seed)
+    recs = {}
+    for patient, name, nbeat in (("pA", "s0001_re", 4), ("pA", "s0002_re", 3), ("pB", "s0101lre", 5)):
+        lens = rng.integers(380, 513, size=nbeat)    # <= 512: the reference cannot pad the noise of a longer beat (ptbv2.py:142)
+        on = np.concatenate([[int(rng.integers(5, 40))], lens]).cumsum()
+        n = int(on[-1]) + 40
+        t = np.arange(n)
+        sig = np.zeros((12, n))
+        lab = {k: [] for k in ("P on", "P off", "R on", "R off", "T on", "T off")}
+        for b in range(nbeat + 1):
+            p0 = int(on[b])
+            ln = int(lens[b]) if b < nbeat else 420
+            f = np.array([0.115, 0.139, 0.229, 0.307, 0.463]) * (1 + rng.uniform(-0.1, 0.1, 5))
+            marks = [p0] + [p0 + int(round(ln * x)) for x in f]
+            for k, v in zip(lab, marks):
+                lab[k].append(int(v))
+            for c, w, a in ((0.06, 0.02, 0.15), (0.18, 0.008, 1.0), (0.38, 0.04, 0.3)):
+                amp = a * rng.normal(1.0, 0.3, size=(12, 1))
+                sig += amp * np.exp(-0.5 * ((t[None] - (p0 + c * ln)) / (w * ln)) ** 2)
+        sig = np.round(1000 * (sig + rng.normal(0, 0.01, sig.shape))).astype(np.int16)
+        recs[(patient, name)] = (sig, lab)
+    return recs
+
+
+def write_ptb_tree(root, recs):
+    import json
+    for (patient, name), (sig, lab) in recs.items():
+        os.makedirs(os.path.join(root, patient), exist_ok=True)
+        np.save(os.path.join(root, patient, name + ".npy"), sig)
+        with open(os.path.join(root, patient, name + ".json"), "w") as f:
+            json.dump(lab, f)
+    with open(os.path.join(root, "patients.txt"), "w") as f:
+        f.write("pA\npB\n")
+
+
+def case_ptb():
+    """f3: the reference's PTBV2 / HeartBeatList on a synthetic PTB-format tree (no PTB recording ships with the
+    reference).  The fixture stores the records (data) and every `meta` the reference's dataset class returned."""
+    import json
+    import tempfile
+    if not hasattr(np, "float"):
+        np.float, np.int = float, int
+    sys.path.insert(0, REF)
+    recs = synth_ptb_records()
+    out = {}
+    for (patient, name), (sig, lab) in recs.items():
+        out[f"rec/{patient}/{name}/signal"] = sig
+        out[f"rec/{patient}/{name}/label"] = np.frombuffer(json.dumps(lab).encode(), dtype=np.uint8)
+    real_listdir = os.listdir
+    with tempfile.TemporaryDirectory() as tmp:
+        write_ptb_tree(tmp, recs)
+        os.listdir = lambda p: sorted(real_listdir(p))          # harness: a defined record order inside a patient
+        try:
+            from dataset.ptbv2 import PTBV2
+            for ci, (V, mode, dmode, phase) in enumerate(PTB_CONFIGS):
+                cfg = ref_cfg(V)
+                cfg.DATA.update(super_mode=mode, train_data_mode=dmode, dataset="ptbv2",
+                                train_pkl_path=os.path.join(tmp, f"none{ci}.pkl"), test_pkl_path=os.path.join(tmp, f"none{ci}.pkl"),
+                                train_label_path=os.path.join(tmp, "patients.txt"), test_label_path=os.path.join(tmp, "patients.txt"),
+                                train_data_root=tmp)
+                cfg["MODEL"]["jitter_factor"] = 2.5
+                random.seed(40 + ci)
+                np.random.seed(40 + ci)
+                ds = PTBV2(cfg, phase)
+                items = [ds[i] for i in range(len(ds))]
+                out[f"cfg{ci}/n"] = np.int64(len(items))
+                for k in ("data", "rois", "input_theta", "target_view", "target_theta", "ori_data", "rest_view",
+                          "rest_theta", "noise"):
+                    out[f"cfg{ci}/{k}"] = np.stack([np.asarray(it[k]) for it in items])
+                out[f"cfg{ci}/unsup"] = np.array(items[0]["unsupervision_lead_name"], dtype=np.int64)
+        finally:
+            os.listdir = real_listdir
+    np.savez_compressed(os.path.join(OUT, "ptb_synth.npz"), **out)
+    print(f"ptb_synth: {len(recs)} records, {int(out['cfg0/n'])} beats, {len(PTB_CONFIGS)} lead plans")
+    return 0.0
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["ptb"]:
+        case_ptb()
+        return
     network = import_reference()
-    worst = [case_theta(network), case_roi(network), case_real(network)]
+    worst = [case_theta(network), case_roi(network), case_real(network), case_ptb()]
     for B, V, L in ((2, 1, 512), (2, 3, 512), (2, 3, 1000), (2, 8, 512)):
         worst.append(case_eval(network, B, V, L, Q=5, seed=11 + V + L))
     worst.append(case_train(network, 2, 1, 512, seed=5))

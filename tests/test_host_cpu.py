@@ -159,3 +159,65 @@ def test_dataset_reproduces_reference_batch(tmp_path):
         assert got.shape == z[k].shape, k
         assert np.array_equal(got.astype(z[k].dtype), z[k]), k
     assert items[0]["rois"].dtype == np.int64 and items[0]["rois"][6, 1] == 512 and items[0]["noise"].shape == (512,)
+
+
+def test_ptb_dataset_reproduces_reference_items(tmp_path):
+    """f3: PTBV2 / HeartBeatList on a PTB-format tree.  No PTB recording ships with the reference, so the tree is
+    synthetic (oracle/make_golden.py::case_ptb wrote it into the fixture together with every `meta` the REFERENCE's
+    PTBV2 returned for five lead plans); same seeds -> identical items, bit for bit, and the cache round-trips."""
+    import json
+    import random
+    from electrocardio_panorama_amd.config import get_defaults, resolve_config_path
+    from electrocardio_panorama_amd.dataset import HeartBeat, build_dataset
+    from electrocardio_panorama_amd.dataset.ptbv2 import HeartBeatList
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ptb_synth.npz"))
+    for k in z.files:
+        if k.startswith("rec/") and k.endswith("/signal"):
+            _, patient, name, _ = k.split("/")
+            os.makedirs(tmp_path / patient, exist_ok=True)
+            np.save(tmp_path / patient / (name + ".npy"), z[k])
+            (tmp_path / patient / (name + ".json")).write_text(bytes(z[k.replace("/signal", "/label")]).decode())
+    (tmp_path / "patients.txt").write_text("pA\npB\n")
+    plans = ((3, "IIv2v5_v4I_372", "input_fix", "train"), (3, "IIv2v5_v4I_372", "random", "test"),
+             (8, "_8120", "input_fix", "train"), (1, "_192", "input_fix", "test"), (5, "_561", "input_fix", "train"))
+    for ci, (V, mode, dmode, phase) in enumerate(plans):
+        cfg = get_defaults()
+        cfg.merge_from_file(resolve_config_path("config/nef_net.yml"))
+        cfg.DATA.dataset, cfg.DATA.lead_num, cfg.DATA.super_mode, cfg.DATA.train_data_mode = "ptbv2", V, mode, dmode
+        cfg.MODEL.jitter_factor = 2.5
+        paths = dict(train_pkl_path=str(tmp_path / f"cache{ci}.pkl"), test_pkl_path=str(tmp_path / f"cache{ci}.pkl"),
+                     train_label_path=str(tmp_path / "patients.txt"), test_label_path=str(tmp_path / "patients.txt"),
+                     train_data_root=str(tmp_path))
+        for attempt in range(2):                      # second pass reads the .npz beat cache written by the first
+            random.seed(40 + ci)
+            np.random.seed(40 + ci)
+            ds = build_dataset(cfg, phase, ptb_paths=paths)
+            assert len(ds) == int(z[f"cfg{ci}/n"])
+            items = [ds[i] for i in range(len(ds))]
+            for k in ("data", "rois", "input_theta", "target_view", "target_theta", "ori_data", "rest_view", "rest_theta",
+                      "noise"):
+                got, exp = np.stack([np.asarray(it[k]) for it in items]), z[f"cfg{ci}/{k}"]
+                assert got.shape == exp.shape and got.dtype == exp.dtype, (ci, k, got.dtype, exp.dtype)
+                assert np.array_equal(got, exp), (ci, k, attempt)
+            assert items[0]["unsupervision_lead_name"] == z[f"cfg{ci}/unsup"].tolist()
+        assert os.path.exists(tmp_path / f"cache{ci}.npz")
+    # a pickle written by the reference (objects of ITS HeartBeat class) is readable
+    import pickle
+    import sys
+    import types
+    mod = types.ModuleType("dataset.ptbv2")
+
+    class _RefHeartBeat:
+        def __init__(self, data, rois_list):
+            self.data, self.rois_list = data, rois_list
+    _RefHeartBeat.__name__ = _RefHeartBeat.__qualname__ = "HeartBeat"
+    _RefHeartBeat.__module__ = "dataset.ptbv2"
+    mod.HeartBeat = _RefHeartBeat
+    sys.modules["dataset"], sys.modules["dataset.ptbv2"] = types.ModuleType("dataset"), mod
+    try:
+        blob = pickle.dumps([_RefHeartBeat(np.ones((12, 5)), np.arange(14).reshape(7, 2))], pickle.HIGHEST_PROTOCOL)
+    finally:
+        del sys.modules["dataset"], sys.modules["dataset.ptbv2"]
+    (tmp_path / "ref.pkl").write_bytes(blob)
+    hbs = HeartBeatList("unused", "unused", str(tmp_path / "ref.pkl")).heart_beats
+    assert isinstance(hbs[0], HeartBeat) and hbs[0].data.shape == (12, 5) and hbs[0].rois_list[6, 1] == 13
