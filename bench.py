@@ -76,6 +76,12 @@ def cpu_baseline(V, L, B, steps, threads):
             "ms_per_step": 1e3 * dt / steps}
 
 
+def _config_name(V, B, L):
+    """Which BASELINE.json config the per-GPU shape is."""
+    return {(3, 256, 5000): "configs[1]", (8, 256, 5000): "configs[2] (per-GPU shard)", (1, 4, 2048): "configs[0]"}.get(
+        (V, B, L), "custom shape")
+
+
 def main():
     args = parse()
     from electrocardio_panorama_amd import ops, parallel, synth
@@ -154,7 +160,7 @@ def main():
             ach = flops / (avg_ms * 1e-3) / 1e12
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and (V, B, L) == (3, 256, 5000):     # PMC pass was taken at configs[1] only
                 traffic = json.load(open(tpath)).get("conv_fwd_k7_bytes_per_launch")
             alg_bytes = 4.0 * (2 * B * 128 * V * T + 128 * V * 128 * 7)
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -177,7 +183,7 @@ def main():
             "unit": "ECG-samples/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: Nef-Net train step, {V}-lead len={L}, batch={B}/GPU, "
+            "config": {"workload": f"{_config_name(V, B, L)}: Nef-Net train step, {V}-lead len={L}, batch={B}/GPU, "
                                    f"3-view-in -> 1-view-out, Standin losses on, dropout "
                                    f"{'off' if args.no_dropout else 'on'}",
                        "global_batch": world * B, "seq_len": L, "leads": V, "parallelism": f"dp{world}"},

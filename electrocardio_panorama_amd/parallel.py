@@ -14,7 +14,8 @@ def init_from_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("NEF_DIST_FORCE") == "1"      # test hook: a 1-rank group still goes through RCCL
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("NEF_DIST_BACKEND")          # test hook: "gloo" lets two ranks share one GPU

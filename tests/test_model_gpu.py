@@ -493,3 +493,16 @@ def test_allocator_footprint_is_stable():
         reserved.append(torch.cuda.memory_reserved())
     assert reserved[-1] <= reserved[4] * 1.05, reserved
     assert torch.isfinite(ls[0])
+
+
+def test_rccl_single_rank():
+    """The data-parallel collectives on the real backend: torchrun, one rank, backend 'nccl' (RCCL).  Multi-GPU boxes
+    are not available to the test suite; rank-count logic is covered by the gloo world-2 test in test_host_cpu.py."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "tests", "rccl_worker.py")]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -1,8 +1,4 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_pano_gpu.py -q 2>&1 | tail -5
-timeout 300 python tools/pano_err.py 2>&1 | tail -6
-PANO=fp16 PAIR_BUDGET=16384 timeout 300 python tools/bench_sweep.py 2>&1 | tail -1
-mkdir -p gpurun_out/prof_pano
-PANO=fp16 PAIR_BUDGET=16384 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_pano -o pano -- python tools/bench_sweep.py > gpurun_out/prof_pano.log 2>&1
-python tools/rocprof_summary.py gpurun_out/prof_pano/pano_results.db /tmp/p.md > /dev/null 2>&1; head -10 /tmp/p.md
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8
+timeout 600 python bench.py --leads 8 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-900
