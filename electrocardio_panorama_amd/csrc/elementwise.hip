@@ -281,16 +281,36 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     const int c = bid % C;
     const int p = bid / C;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = sp; b < Bp; b += BN_SPLIT) {
-        const float* row = x + (((int64_t)p * Bp + b) * C + c) * L;
-        double r1 = 0.0, r2 = 0.0;
-        for (int t = threadIdx.x; t < L; t += 256) {
-            const double v = (double)row[t];
-            r1 += v;
-            r2 += v * v;
+    if ((L & 3) == 0) {
+        // 16-byte loads, two rows in flight per trip: this pass is pure HBM streaming, latency hidden by loads in flight
+        const int L4 = L >> 2;
+        for (int b = sp; b < Bp; b += 2 * BN_SPLIT) {
+            const nef_f32x4* r0 = (const nef_f32x4*)(x + (((int64_t)p * Bp + b) * C + c) * L);
+            const bool two = b + BN_SPLIT < Bp;
+            const nef_f32x4* r1 = two ? (const nef_f32x4*)(x + (((int64_t)p * Bp + b + BN_SPLIT) * C + c) * L) : r0;
+            for (int t = threadIdx.x; t < L4; t += 256) {
+                const nef_f32x4 u = r0[t];
+                nef_f32x4 w = r1[t];
+                if (!two) w = nef_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double a = (double)u[e], bq = (double)w[e];
+                    s1 += a;
+                    s2 += a * a;
+                    s1 += bq;
+                    s2 += bq * bq;
+                }
+            }
         }
-        s1 += r1;
-        s2 += r2;
+    } else {
+        for (int b = sp; b < Bp; b += BN_SPLIT) {
+            const float* row = x + (((int64_t)p * Bp + b) * C + c) * L;
+            for (int t = threadIdx.x; t < L; t += 256) {
+                const double v = (double)row[t];
+                s1 += v;
+                s2 += v * v;
+            }
+        }
     }
     s1 = nef_block_sum_d(s1, sm);
     s2 = nef_block_sum_d(s2, sm);
@@ -385,14 +405,33 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
     const int p = bid / C;
     const float mf = mean[p * C + c], is = invstd[p * C + c], af = a[p * C + c], bf = b[p * C + c];
     double s1 = 0.0, s2 = 0.0;
-    for (int bb = sp; bb < Bp; bb += BN_SPLIT) {
-        const int64_t off = (((int64_t)p * Bp + bb) * C + c) * L;
-        // accumulate in double from the first element: sum(g) cancels heavily and k1 = sum(g)/n shifts every gx
-        for (int t = threadIdx.x; t < L; t += 256) {
-            const float xv = x[off + t];
-            const float g = fmaf(xv, af, bf) > 0.f ? gy[off + t] : 0.f;
-            s1 += (double)g;
-            s2 += (double)g * (double)((xv - mf) * is);
+    // accumulate in double from the first element: sum(g) cancels heavily and k1 = sum(g)/n shifts every gx
+    if ((L & 3) == 0) {
+        const int L4 = L >> 2;
+        for (int bb = sp; bb < Bp; bb += BN_SPLIT) {
+            const int64_t off = (((int64_t)p * Bp + bb) * C + c) * L;
+            const nef_f32x4* xr = (const nef_f32x4*)(x + off);
+            const nef_f32x4* gr = (const nef_f32x4*)(gy + off);
+#pragma unroll 2
+            for (int t = threadIdx.x; t < L4; t += 256) {
+                const nef_f32x4 xv = xr[t], gv = gr[t];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = fmaf(xv[e], af, bf) > 0.f ? gv[e] : 0.f;
+                    s1 += (double)g;
+                    s2 += (double)g * (double)((xv[e] - mf) * is);
+                }
+            }
+        }
+    } else {
+        for (int bb = sp; bb < Bp; bb += BN_SPLIT) {
+            const int64_t off = (((int64_t)p * Bp + bb) * C + c) * L;
+            for (int t = threadIdx.x; t < L; t += 256) {
+                const float xv = x[off + t];
+                const float g = fmaf(xv, af, bf) > 0.f ? gy[off + t] : 0.f;
+                s1 += (double)g;
+                s2 += (double)g * (double)((xv - mf) * is);
+            }
         }
     }
     s1 = nef_block_sum_d(s1, sm);
@@ -441,12 +480,28 @@ __global__ void bn_bwd_apply(const float* __restrict__ gy, const float* __restri
         const float* gr = gy + row * L;
         float* gxr = gx + row * L;
         double rs = 0.0;
-        for (int t = lane; t < L; t += 64) {
-            const float xv = xr[t];
-            const float g = fmaf(xv, af, bf) > 0.f ? gr[t] : 0.f;
-            const float o = af * (g - k1 - (xv - mf) * is * k2);
-            gxr[t] = o;
-            rs += (double)o;
+        if ((L & 3) == 0) {
+            const int L4 = L >> 2;
+#pragma unroll 2
+            for (int t = lane; t < L4; t += 64) {
+                const nef_f32x4 xv = ((const nef_f32x4*)xr)[t], gv = ((const nef_f32x4*)gr)[t];
+                nef_f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = fmaf(xv[e], af, bf) > 0.f ? gv[e] : 0.f;
+                    o[e] = af * (g - k1 - (xv[e] - mf) * is * k2);
+                    rs += (double)o[e];
+                }
+                ((nef_f32x4*)gxr)[t] = o;
+            }
+        } else {
+            for (int t = lane; t < L; t += 64) {
+                const float xv = xr[t];
+                const float g = fmaf(xv, af, bf) > 0.f ? gr[t] : 0.f;
+                const float o = af * (g - k1 - (xv - mf) * is * k2);
+                gxr[t] = o;
+                rs += (double)o;
+            }
         }
         if (rowsum) {                      // per-row sum of gx: the bias gradient of the conv feeding this BN
             rs = nef_wave_sum_d(rs);
