@@ -16,17 +16,21 @@
 //   K loop  = CIN/64 channel chunks x 3 taps; per (chunk, tap) "stage" 4 MFMA k-steps of 16 channels
 //   LDS     = X chunk [(NT+2) rows][64 ch + 8 pad] halfs (staged once per chunk, all 3 taps read it shifted by a row;
 //             the 16-byte pad makes the 16-row ds_read_b128 groups conflict-free)
-//             + 2 weight stages of COUT x 64 halfs in MFMA-fragment order (1 KB per fragment, lane-linear)
-//   pipeline: the X rows of the NEXT (tile, chunk) travel global -> registers while the current chunk's three stages
-//             run (buffer loads whose descriptor spans exactly one pair: the conv zero padding is the hardware's
-//             out-of-range zero), the weights of the next stage likewise (L2-resident, shared by every block)
+//             + the chunk's 3 x COUT x 64 weight halfs in MFMA-fragment order (1 KB per fragment, lane-linear)
+//   pipeline: the X rows and the weights of the NEXT (tile, chunk) travel global -> registers while the current
+//             chunk's 48 MFMAs per wave run, two barriers per chunk (buffer loads whose descriptor spans exactly one
+//             pair: the conv zero padding is the hardware's out-of-range zero; weights are L2-resident, shared by
+//             every block, and stay in LDS for the whole kernel when the layer has a single chunk)
 //   PRO bit0: multiply channel ci by scale[pair][ci] while staging (the per-angle query scaling, model_nefnet.py:184-186)
 //   PRO bit1: X is the x2 linear upsample (align_corners=False) of the stored rows: raw rows go to an LDS scratch and
 //             are blended from there with packed-half fma
 //   epilogue: + bias, ReLU, -> fp16, transposed through LDS (over the X chunk, 64 channels per pass) so that every
 //             output row leaves as 16-byte vectors
-// Measured (MI355X, BASELINE config 4: 1024 samples x 360 angles, len 512): 70 ms per sweep against 400 ms on the fp32
-// path; per 4096 pairs L1 237 us (0.87 PFLOP/s), L2 133 us (4.0 TB/s), L3 144 us, L4 95 us (5.6 TB/s), last conv 75 us.
+//   OUT=1   : the 64->64 layer also evaluates the last conv (64 -> 1) on its staged tile (see below)
+// Measured (MI355X, BASELINE config 4: 1024 samples x 360 angles, len 512): 62 ms per sweep against 400 ms on the fp32
+// path; per 4096 pairs L1 250 us (0.82 PFLOP/s), L2 126 us (4.2 TB/s), L3 150 us, L4 + last conv 80 us.  PMC on L2:
+// matrix pipes busy 36 % of SIMD cycles at an effective 1.5 GHz, 31 % of wave time waiting on memory -- the layer-wise
+// pipeline is within 25 % of its HBM floor; the next step is keeping c1 / c3 on chip (layer pairs fused).
 #include "nef_common.h"
 
 typedef _Float16 nef_h8 __attribute__((ext_vector_type(8)));
@@ -84,12 +88,18 @@ __global__ void ph_pack_weight_kernel(const float* __restrict__ w, _Float16* __r
 // Persistent version: a block walks tiles blockIdx.x, +gridDim.x, ...; the X rows of the NEXT (tile, channel chunk) are
 // in flight (global -> registers) while the matrix cores work on the current one, and the weight stage after the
 // current one likewise, so that neither HBM nor L2 latency sits on a block's critical path.
-template <int CIN, int COUT, int PRO>
-__global__ __launch_bounds__(256, 2) void hconv_kernel(const _Float16* __restrict__ x, const nef_h8* __restrict__ wp,
+// OUT = 1 (64 -> 64 layer only): the tile never leaves the chip -- the last conv (64 -> 1, k3) is evaluated on the staged
+// fp16 tile and its pre-activation goes to `logit` (fp32, addressed like the final output): interior columns by plain
+// stores, the two edge columns of a tile by atomic adds, because their neighbour tap lives in the adjacent tile, which
+// adds its share the same way (exactly two addends on a zeroed word: order-independent, hence deterministic).
+template <int CIN, int COUT, int PRO, int OUT, int NI, int MINB>
+__global__ __launch_bounds__(256, MINB) void hconv_kernel(const _Float16* __restrict__ x, const nef_h8* __restrict__ wp,
                                                        const float* __restrict__ bias, const float* __restrict__ scale,
                                                        _Float16* __restrict__ y, int T, int tiles_per_n, int total_tiles,
-                                                       int x_div, int nq, long sc_bs, long sc_is) {
-    constexpr int NI = 2;
+                                                       int x_div, int nq, long sc_bs, long sc_is,
+                                                       const float* __restrict__ wout, float* __restrict__ logit,
+                                                       long out_bs, long out_is) {
+    static_assert(!OUT || (COUT == 64 && PRO == 0), "the fused last conv rides on the 64-channel layer");
     constexpr int WM = COUT / 64;            // waves along the output-channel axis
     constexpr int WN = 4 / WM;               // waves along time
     constexpr int NT = WN * NI * 32;         // time columns per tile (128 for COUT=128, 256 for COUT=64)
@@ -102,13 +112,13 @@ __global__ __launch_bounds__(256, 2) void hconv_kernel(const _Float16* __restric
     constexpr int WST_V = COUT * 64 / 8;     // h8 vectors per weight stage
     constexpr int WPT = WST_V / 256;         // ... per thread
     constexpr int NCC = CIN / 64;
-    constexpr int NST = NCC * 3;
     constexpr int NPASS = COUT / 64;         // epilogue passes: 64 output channels per staged row
     static_assert(XBYTES % 16 == 0 && SBYTES % 16 == 0, "LDS regions must stay 16-byte aligned");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Xl = smem;                         // [XROWS][PH_XRS]; the epilogue's output staging aliases it
     char* Sl = smem + XBYTES;                // [SROWS][PH_XRS] (upsampling prologue only)
-    nef_h8* Wl = (nef_h8*)(smem + XBYTES + SBYTES);   // [2][WST_V]
+    nef_h8* Wl = (nef_h8*)(smem + XBYTES + SBYTES);   // [3 taps][WST_V]: the weights of one channel chunk
+    float* Ol = (float*)(smem + XBYTES + SBYTES + 3 * WST_V * 16);   // OUT: wout[192], d0[NT], d2[NT]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
@@ -154,24 +164,31 @@ __global__ __launch_bounds__(256, 2) void hconv_kernel(const _Float16* __restric
         }                                                                                                     \
     }
     const __amdgpu_buffer_rsrc_t wd = nef_rsrc(wp);
-#define PH_WFETCH(stage_)                                                                                     \
-    _Pragma("unroll") for (int j = 0; j < WPT; ++j) wreg[j] = __builtin_bit_cast(                             \
-        nef_h8, __builtin_amdgcn_raw_buffer_load_b128(wd, tid * 16, (stage_) * (WST_V * 16) + j * 4096, 0));
+#define PH_WFETCH(cc_)                                                                                        \
+    _Pragma("unroll") for (int tp = 0; tp < 3; ++tp) _Pragma("unroll") for (int j = 0; j < WPT; ++j)          \
+        wreg[tp][j] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(                       \
+            wd, tid * 16, ((cc_) * 3 + tp) * (WST_V * 16) + j * 4096, 0));
 
-    nef_h8 wreg[WPT];
+    nef_h8 wreg[3][WPT];
     PH_WFETCH(0);
+    if (OUT && tid < 192) Ol[tid] = wout[tid];   // [ci][tap]; visible after the first barrier
     int tile = blockIdx.x;
     if (tile < total_tiles) PH_FETCH(tile, 0);
-#pragma unroll
-    for (int j = 0; j < WPT; ++j) Wl[tid + j * 256] = wreg[j];
-    int wbuf = 0;                            // LDS weight buffer holding the stage about to be used
+    bool wfresh = true;                      // wreg holds weights that are not in LDS yet
 
 #pragma unroll 1
     for (; tile < total_tiles; tile += gridDim.x) {
         const int n = tile / tiles_per_n, t0 = (tile % tiles_per_n) * NT;
 #pragma unroll 1
         for (int cc = 0; cc < NCC; ++cc) {
-            __syncthreads();                 // every wave is done reading Xl (previous chunk, or the epilogue staging)
+            __syncthreads();                 // every wave is done reading Xl / Wl (previous chunk, or the epilogue staging)
+            if (wfresh) {
+#pragma unroll
+                for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+                    for (int j = 0; j < WPT; ++j) Wl[tp * WST_V + tid + j * 256] = wreg[tp][j];
+                wfresh = NCC > 1;            // a single chunk's weights stay resident for the whole kernel
+            }
             if (PRO & 2) {
 #pragma unroll
                 for (int j = 0; j < XIT; ++j) {
@@ -221,23 +238,18 @@ __global__ __launch_bounds__(256, 2) void hconv_kernel(const _Float16* __restric
                     if (j < XIT - 1 || idx < SROWS * 8) *(nef_h8*)(Xl + (idx >> 3) * PH_XRS + seg * 16) = v;
                 }
             }
+            // Next chunk's operands, in flight during this chunk's 48 MFMAs (and the epilogue).  Weights FIRST: loads
+            // retire in order, and the L2-resident weights must not queue behind rows that come from HBM.
+            if (NCC > 1) PH_WFETCH(cc + 1 < NCC ? cc + 1 : 0);
+            if (cc + 1 < NCC) {
+                PH_FETCH(tile, cc + 1);
+            } else if (tile + (int)gridDim.x < total_tiles) {
+                PH_FETCH(tile + (int)gridDim.x, 0);
+            }
+            __syncthreads();                 // X chunk and the chunk's weights are visible
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
-                const int s = cc * 3 + tap;
-                const int snext = (s + 1 == NST) ? 0 : s + 1;
-                PH_WFETCH(snext);
-                if (tap == 0) {
-                    // rows of the next (tile, chunk): in flight during this chunk's stages (and the epilogue).  Issued
-                    // AFTER this stage's weight fetch: loads retire in order, so the wait for those weights at the end
-                    // of the stage must not have these (HBM-latency) loads queued in front of it.
-                    if (cc + 1 < NCC) {
-                        PH_FETCH(tile, cc + 1);
-                    } else if (tile + (int)gridDim.x < total_tiles) {
-                        PH_FETCH(tile + (int)gridDim.x, 0);
-                    }
-                }
-                __syncthreads();             // X chunk (tap 0) and this stage's weights are visible
-                const nef_h8* Ws = Wl + wbuf * WST_V;
+                const nef_h8* Ws = Wl + tap * WST_V;
                 const char* Xs = Xl + (brow + tap) * PH_XRS + bcol;
 #pragma unroll
                 for (int kq = 0; kq < 4; ++kq) {
@@ -252,10 +264,6 @@ __global__ __launch_bounds__(256, 2) void hconv_kernel(const _Float16* __restric
                         for (int ni = 0; ni < NI; ++ni)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
                 }
-                wbuf ^= 1;                   // the other buffer was last read before this stage's barrier
-                nef_h8* Wn = Wl + wbuf * WST_V;
-#pragma unroll
-                for (int j = 0; j < WPT; ++j) Wn[tid + j * 256] = wreg[j];
             }
         }
 
@@ -285,12 +293,45 @@ __global__ __launch_bounds__(256, 2) void hconv_kernel(const _Float16* __restric
                 }
             }
             __syncthreads();
-            for (int idx = tid; idx < NT * 8; idx += 256) {
-                const int r = idx >> 3;
-                const int slot = seg * 8;
-                const int co = (NPASS == 2) ? (slot >> 5) * 64 + p * 32 + (slot & 31) : slot;
-                if (t0 + r < T)
-                    *(nef_h8*)(yb + (size_t)(t0 + r) * COUT + co) = *(const nef_h8*)(Xl + r * PH_XRS + seg * 16);
+            if (OUT) {
+                // last conv on the staged tile: row r = this thread; d_k = sum_c wout[c][k] * tile[r][c]
+                const int r = tid, t = t0 + r;
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+                if (r < NT && t < T) {
+#pragma unroll
+                    for (int sg = 0; sg < 8; ++sg) {
+                        const nef_h8 v = *(const nef_h8*)(Xl + r * PH_XRS + sg * 16);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = (float)v[e];
+                            const float* wc = Ol + (sg * 8 + e) * 3;
+                            d0 = fmaf(wc[0], f, d0);
+                            d1 = fmaf(wc[1], f, d1);
+                            d2 = fmaf(wc[2], f, d2);
+                        }
+                    }
+                }
+                if (r < NT) {
+                    Ol[192 + r] = d0;        // tap 0 weights this row into column t+1
+                    Ol[192 + NT + r] = d2;   // tap 2 into column t-1
+                }
+                __syncthreads();
+                float* lg = logit + (size_t)(n / nq) * out_bs + (size_t)(n % nq) * out_is;
+                if (r < NT && t < T) {
+                    const float s_ = d1 + (r > 0 ? Ol[192 + r - 1] : 0.f) + (r < NT - 1 ? Ol[192 + NT + r + 1] : 0.f);
+                    if (r == 0 || r == NT - 1) atomicAdd(lg + t, s_);
+                    else lg[t] = s_;
+                    if (r == NT - 1 && t + 1 < T) atomicAdd(lg + t + 1, d0);
+                    if (r == 0 && t > 0) atomicAdd(lg + t - 1, d2);
+                }
+            } else {
+                for (int idx = tid; idx < NT * 8; idx += 256) {
+                    const int r = idx >> 3;
+                    const int slot = seg * 8;
+                    const int co = (NPASS == 2) ? (slot >> 5) * 64 + p * 32 + (slot & 31) : slot;
+                    if (t0 + r < T)
+                        *(nef_h8*)(yb + (size_t)(t0 + r) * COUT + co) = *(const nef_h8*)(Xl + r * PH_XRS + seg * 16);
+                }
             }
         }
     }
@@ -344,17 +385,43 @@ __global__ __launch_bounds__(256) void ph_outconv_kernel(const _Float16* __restr
 // ------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int PRO>
+// zero the tile-edge columns the fused kernel accumulates into (t = k*NT and k*NT + NT-1)
+__global__ void ph_zero_edges_kernel(float* __restrict__ logit, int N, int T, int NT, int tiles_per_n, int nq,
+                                     long out_bs, long out_is) {
+    const int64_t total = (int64_t)N * tiles_per_n * 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int side = (int)(i & 1);
+        const int tile = (int)((i >> 1) % tiles_per_n);
+        const int n = (int)((i >> 1) / tiles_per_n);
+        const int t = tile * NT + (side ? NT - 1 : 0);
+        if (t < T) logit[(size_t)(n / nq) * out_bs + (size_t)(n % nq) * out_is + t] = 0.f;
+    }
+}
+
+// out = sigmoid((logit + bias) / 3) in place (model_nefnet.py:168/:186)
+__global__ void ph_sigmoid3_kernel(float* __restrict__ io, const float* __restrict__ bias, int N, int T, int nq,
+                                   long out_bs, long out_is) {
+    const float b0 = bias[0];
+    const int64_t total = (int64_t)N * T;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / T), t = (int)(i % T);
+        float* p = io + (size_t)(n / nq) * out_bs + (size_t)(n % nq) * out_is + t;
+        *p = 1.0f / (1.0f + expf(-(*p + b0) / 3.0f));
+    }
+}
+
+template <int CIN, int COUT, int PRO, int OUT = 0, int NI = 2, int MINB = 2>
 static int launch_hconv(const void* x, const void* wp, const float* bias, const float* scale, void* y, int N, int T,
-                        int x_div, int nq, long sc_bs, long sc_is, hipStream_t st) {
-    constexpr int NT = (4 / (COUT / 64)) * 64;
+                        int x_div, int nq, long sc_bs, long sc_is, hipStream_t st, const float* wout = nullptr,
+                        float* logit = nullptr, long out_bs = 0, long out_is = 0) {
+    constexpr int NT = (4 / (COUT / 64)) * NI * 32;
     constexpr int XB = (NT + 2) * PH_XRS;
     constexpr int SB = (PRO & 2) ? (NT / 2 + 4) * PH_XRS : 0;
-    constexpr int LDS = XB + SB + 2 * COUT * 64 * 2;
+    constexpr int LDS = XB + SB + 3 * COUT * 64 * 2 + (OUT ? (192 + 2 * NT) * 4 : 0);
     const int tiles = (T + NT - 1) / NT;
     const int64_t total = (int64_t)N * tiles;
     if (total > 0x7FFFFFFF) return NEF_E_SHAPE;
-    auto k = hconv_kernel<CIN, COUT, PRO>;
+    auto k = hconv_kernel<CIN, COUT, PRO, OUT, NI, MINB>;
     static int resident = 0;                 // blocks that fit the device at once (persistent grid)
     if (resident == 0) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -368,7 +435,7 @@ static int launch_hconv(const void* x, const void* wp, const float* bias, const 
     }
     const int grid = (int)(total < resident ? total : resident);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), LDS, st, (const _Float16*)x, (const nef_h8*)wp, bias, scale,
-                       (_Float16*)y, T, tiles, (int)total, x_div, nq, sc_bs, sc_is);
+                       (_Float16*)y, T, tiles, (int)total, x_div, nq, sc_bs, sc_is, wout, logit, out_bs, out_is);
     return nef_launch_status();
 }
 
@@ -412,6 +479,26 @@ int nef_pano_h_conv(const void* x, const void* wp, const float* bias, const floa
     PH_CASE(64, 64, 0);
 #undef PH_CASE
     return NEF_E_UNSUPPORTED;
+}
+
+int nef_pano_h_conv_outconv(const void* x, const void* wp, const float* bias, const float* wout, const float* bout,
+                            float* out, int N, int T, int nq, int64_t out_bs, int64_t out_is, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && wp && bias && wout && bout && out, NEF_E_NULL);
+    NEF_REQUIRE(N > 0 && T > 0 && nq > 0, NEF_E_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const int NT = 256;                      // tile width of the 64-channel layer
+    const int tiles = (T + NT - 1) / NT;
+    hipLaunchKernelGGL(ph_zero_edges_kernel, dim3(nef_stream_grid((int64_t)N * tiles * 2, 256)), dim3(256), 0, st, out, N,
+                       T, NT, tiles, nq, (long)out_bs, (long)out_is);
+    int rc = nef_launch_status();
+    if (rc != NEF_OK) return rc;
+    rc = launch_hconv<64, 64, 0, 1>(x, wp, bias, nullptr, nullptr, N, T, 1, nq, 0, 0, st, wout, out, (long)out_bs,
+                                    (long)out_is);
+    if (rc != NEF_OK) return rc;
+    hipLaunchKernelGGL(ph_sigmoid3_kernel, dim3(nef_stream_grid((int64_t)N * T, 256)), dim3(256), 0, st, out, bout, N, T,
+                       nq, (long)out_bs, (long)out_is);
+    return nef_launch_status();
 }
 
 int nef_pano_h_outconv(const void* x, const float* w, const float* bias, float* out, int N, int T, int nq, int64_t out_bs,

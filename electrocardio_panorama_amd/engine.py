@@ -321,7 +321,7 @@ def sweep_eval(P, Bf, latent, query_thetas, chunk=8):
     return rest
 
 
-def sweep_eval_h(P, Bf, latent, query_thetas, pair_budget=4096):
+def sweep_eval_h(P, Bf, latent, query_thetas, pair_budget=16384):
     """The eval-mode sweep on the fp16 matrix cores (pano_h.hip; SURVEY 8-f2, BASELINE configs 4/5).  Same folding as
     sweep_eval; activations are fp16 [pair][time][channel] with pair = (sample, angle) sample-major, so the result
     lands in rest[b, q] without a transposing copy.  Both x2 upsamplings and the per-angle query scaling happen while
@@ -347,14 +347,13 @@ def sweep_eval_h(P, Bf, latent, query_thetas, pair_budget=4096):
         if bufs is None or bufs[0].shape[0] != N:
             bufs = (torch.empty(N, 2 * T, 128, device=dev, dtype=torch.float16),
                     torch.empty(N, 2 * T, 128, device=dev, dtype=torch.float16),
-                    torch.empty(N, 4 * T, 64, device=dev, dtype=torch.float16),
                     torch.empty(N, 4 * T, 64, device=dev, dtype=torch.float16))
         c1 = ops.pano_h_conv(lat_h, wp[0], bias[0], 128, N=N, upsample=True, scale=(rq[:, q0:], Q * 256, 256),
                              x_div=n, nq=n, out=bufs[0])
         c2 = ops.pano_h_conv(c1, wp[1], bias[1], 128, out=bufs[1])
         c3 = ops.pano_h_conv(c2, wp[2], bias[2], 64, upsample=True, out=bufs[2])
-        c4 = ops.pano_h_conv(c3, wp[3], bias[3], 64, out=bufs[3])
-        ops.pano_h_outconv(c4, P["decoder.4.weight"], P["decoder.4.bias"], rest[:, q0:], n, Q * 4 * T, 4 * T)
+        ops.pano_h_conv_outconv(c3, wp[3], bias[3], P["decoder.4.weight"], P["decoder.4.bias"], rest[:, q0:], n,
+                                Q * 4 * T, 4 * T)
     return rest
 
 

@@ -647,3 +647,17 @@ def pano_h_outconv(x, w, bias, out, nq, out_bs, out_is):
     _lib.check(L.nef_pano_h_outconv(_p(x), _p(w), _p(bias), _p(out), N, T, nq, out_bs, out_is, _stream()),
                "nef_pano_h_outconv")
     return out
+
+
+def pano_h_conv_outconv(x, wp, bias, wout, bout, out, nq, out_bs, out_is):
+    """Layer 4 (64->64) + last conv + sigmoid(x/3) in one pass; x fp16 [N,T,64], out fp32 view base."""
+    L = _lib.load()
+    _chk(x, torch.float16), _chk(bias), _chk(wout)
+    N, T, Ci = x.shape
+    assert Ci == 64
+    e = _timed(("pano_h_conv_outconv", N, T))
+    _lib.check(L.nef_pano_h_conv_outconv(_p(x), _p(wp), _p(bias), _p(wout), _p(bout), _p(out), N, T, nq, out_bs, out_is,
+                                         _stream()), "nef_pano_h_conv_outconv")
+    if e is not None:
+        e.record()
+    return out

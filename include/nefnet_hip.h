@@ -264,6 +264,11 @@ int nef_pano_h_from_f32(const float* x, void* y, int B, int C, int T, nef_stream
 int nef_pano_h_pack_weight(const float* w, void* wp, int Cout, int Cin, nef_stream_t stream);
 int nef_pano_h_conv(const void* x, const void* wp, const float* bias, const float* scale, void* y, int N, int T, int Cin,
                     int Cout, int pro_mode, int x_div, int nq, int64_t sc_bs, int64_t sc_is, nef_stream_t stream);
+ /* nef_pano_h_conv_outconv: the 64->64 layer and the last conv in one pass: out = sigmoid((conv_k3(ReLU(conv_k3(x) +
+ * bias); wout) + bout)/3); the 64-channel intermediate never reaches memory (it is rounded to fp16 exactly as the
+ * two-call sequence nef_pano_h_conv + nef_pano_h_outconv rounds it). */
+int nef_pano_h_conv_outconv(const void* x, const void* wp, const float* bias, const float* wout, const float* bout,
+                            float* out, int N, int T, int nq, int64_t out_bs, int64_t out_is, nef_stream_t stream);
 int nef_pano_h_outconv(const void* x, const float* w, const float* bias, float* out, int N, int T, int nq,
                        int64_t out_bs, int64_t out_is, nef_stream_t stream);
 

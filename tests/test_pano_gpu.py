@@ -14,7 +14,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from util import rel, rnd
+from util import maxabs, rel, rnd
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -89,6 +89,30 @@ def test_h_outconv():
     got = out.cpu()
     assert torch.all(got[:, 0] == -1.0) and torch.all(got[:, 4] == -1.0)      # untouched angle slots
     assert rel(got[:, 1:4].reshape(N, T), ref) < 1e-6
+
+
+@pytest.mark.parametrize("T", [256, 700, 5000, 40])
+def test_h_conv_outconv_fused_equals_two_calls(T):
+    """Layer 4 + last conv in one pass (the 64-channel tile never reaches memory) against the two-call sequence: the
+    intermediate is rounded to fp16 identically, only the summation order of the 192-term last conv differs."""
+    o = ops()
+    N, nq = 6, 3
+    xh = rnd(N, T, 64, seed=21).to(torch.float16).to(DEV)
+    w4 = (rnd(64, 64, 3, seed=22) * 0.1).to(DEV)
+    b4 = rnd(64, seed=23, scale=0.1).to(DEV)
+    wo, bo = rnd(1, 64, 3, seed=24, scale=0.2).to(DEV), rnd(1, seed=25).to(DEV)
+    wp = o.pano_h_pack_weight(w4)
+    two = torch.full((2, 5, T), -1.0, device=DEV)
+    c4 = o.pano_h_conv(xh, wp, b4, 64)
+    o.pano_h_outconv(c4, wo, bo, two[:, 1:], nq, 5 * T, T)
+    one = torch.full((2, 5, T), -1.0, device=DEV)
+    o.pano_h_conv_outconv(xh, wp, b4, wo, bo, one[:, 1:], nq, 5 * T, T)
+    assert torch.all(one[:, 0] == -1.0) and torch.all(one[:, 4] == -1.0)
+    assert rel(one[:, 1:4], two[:, 1:4]) < 1e-6
+    assert maxabs(one[:, 1:4], two[:, 1:4]) < 1e-6
+    again = torch.full((2, 5, T), 7.0, device=DEV)                # stale contents at the tile edges must not leak in
+    o.pano_h_conv_outconv(xh, wp, b4, wo, bo, again[:, 1:], nq, 5 * T, T)
+    assert torch.equal(again[:, 1:4], one[:, 1:4])                # and the result is run-to-run identical
 
 
 def _logit3(o):
