@@ -240,6 +240,25 @@ def _latents(P, x, in_theta, rois, drop, save):
     return z1, z2b, (sv if save else None)
 
 
+def _head_fwd(P, Bf, z1, z2r, q_theta, V, rest_theta, phase, training, lead_choice, sv, rest_chunk, half_sweep):
+    """model_nefnet.py:146-190: lead means, Standin mixes, query scaling, the three decoder passes (+ the sweep)."""
+    B = z1.shape[0]
+    save = sv is not None
+    latent = ops.lead_mean(z1, z2r, V)
+    q = ops.theta_mlp_fwd(q_theta, P["mlp2.weight"], P["mlp2.bias"])             # [B, 256]
+    D = ops.mix_fwd(latent, z1, z2r, q, V, lead_choice)                           # [3B, 256, T]
+    out3, dsv = decoder_fwd(D, P, Bf, 3, training, save)
+    outs = (out3[0:B], out3[B:2 * B], out3[2 * B:3 * B])
+    if save:
+        sv.update(z1=z1, z2r=z2r, latent=latent, q=q, q_theta=q_theta, choice=lead_choice, dec=dsv, hB=B, hV=V)
+    if phase == "train":
+        return outs, sv
+    if phase in ("val", "test"):
+        rest = sweep(P, Bf, latent, rest_theta, training, rest_chunk, half_sweep)
+        return outs + (rest,), sv
+    raise KeyError("please type correct phase")
+
+
 def forward(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", training=True, drop=None,
             lead_choice=(0, 0), save=False, rest_chunk=8, status=None, half_sweep=False):
     """Returns (outputs tuple, saved-state or None).  `lead_choice` are the two Standin lead indices
@@ -251,19 +270,45 @@ def forward(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", t
     if phase == "gen":
         return (z1, z2b), None
     z2r = ops.roi_unpool_fwd(z2b, rois, T, status)
-    latent = ops.lead_mean(z1, z2r, V)
-    q = ops.theta_mlp_fwd(q_theta, P["mlp2.weight"], P["mlp2.bias"])             # [B, 256]
-    D = ops.mix_fwd(latent, z1, z2r, q, V, lead_choice)                           # [3B, 256, T]
-    out3, dsv = decoder_fwd(D, P, Bf, 3, training, save)
-    outs = (out3[0:B], out3[B:2 * B], out3[2 * B:3 * B])
+    return _head_fwd(P, Bf, z1, z2r, q_theta, V, rest_theta, phase, training, lead_choice, sv, rest_chunk, half_sweep)
+
+
+def _lead_view(t, i, V):
+    """Lead i of a lead-blocked [B, 128V, T] tensor as a one-group view."""
+    B, Ct, T = t.shape
+    return GV(t, B, 1, 128, T, Ct * T, 128 * T, i * 128 * T)
+
+
+def forward2(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", training=True, drop=None,
+             lead_choice=(0, 0), save=False, rest_chunk=8, status=None, half_sweep=False):
+    """Model_nefnet2.forward (reference codes/network/model_nefnet2.py:118-194): ONE single-lead encoder shared by all
+    leads.  The reference loops over the leads; here the leads are folded into the batch (lead-major, n = v*B + b), so
+    the shared-weight encoder runs once on V*B single-lead samples, and the two extra convs (`single_conv_z1/_z2`,
+    :140,:149) write their outputs lead by lead into lead-blocked [B, 128V, T] tensors, from where the lead mean, the
+    Standin mixes and the decoder are exactly Model_nefnet's."""
+    drop = drop or DropCfg(False)
+    B, V, L = x.shape
+    T, N = L // 4, V * B
+    xf = x.transpose(0, 1).reshape(N, 1, L).contiguous()
+    thf = in_theta.transpose(0, 1).reshape(N, 1, 2).contiguous()
+    roisf = rois.repeat(V, 1, 1)
+    z1f, z2bf, sv = _latents(P, xf, thf, roisf, drop, save)
+    z2rf = ops.roi_unpool_fwd(z2bf, roisf, T, status)                              # [N, 128, T]
+    Z1 = torch.empty(B, 128 * V, T, device=x.device, dtype=torch.float32)
+    Z2 = torch.empty_like(Z1)
+    wp1 = ops.pack_weight(P["single_conv_z1.0.weight"], 1)
+    wp2 = ops.pack_weight(P["single_conv_z2.0.weight"], 1)
+    for i in range(V):
+        ops.conv(GV.dense(z1f[i * B:(i + 1) * B], 1), wp1, 128, 3, bias=P["single_conv_z1.0.bias"],
+                 out=_lead_view(Z1, i, V))
+        ops.conv(GV.dense(z2rf[i * B:(i + 1) * B], 1), wp2, 128, 3, bias=P["single_conv_z2.0.bias"],
+                 out=_lead_view(Z2, i, V))
+    if phase == "gen":                                                             # :158-159: the two lead means
+        latent = ops.lead_mean(Z1, Z2, V)
+        return (latent[:, :128].contiguous(), latent[:, 128:].contiguous()), None
     if save:
-        sv.update(z1=z1, z2r=z2r, latent=latent, q=q, q_theta=q_theta, choice=lead_choice, dec=dsv)
-    if phase == "train":
-        return outs, sv
-    if phase in ("val", "test"):
-        rest = sweep(P, Bf, latent, rest_theta, training, rest_chunk, half_sweep)
-        return outs + (rest,), sv
-    raise KeyError("please type correct phase")
+        sv.update(z1f=z1f, z2rf=z2rf, fold=(B, V))
+    return _head_fwd(P, Bf, Z1, Z2, q_theta, V, rest_theta, phase, training, lead_choice, sv, rest_chunk, half_sweep)
 
 
 def sweep(P, Bf, latent, query_thetas, training=False, chunk=8, half=False):
@@ -367,17 +412,22 @@ def gen_ecg(P, Bf, z1, z2b, query_thetas, rois, chunk=8, half=False):
     return sweep(P, Bf, latent, query_thetas, False, chunk)
 
 
-def backward(P, sv, g_outs):
-    """g_outs: gradients wrt (out, shuffle_p, shuffle_l), each [B,1,L] or None.  Returns {param name: grad}."""
-    B, V, T = sv["B"], sv["V"], sv["T"]
-    grads = {}
+def _head_bwd(P, sv, g_outs, grads, side):
+    """Back through decoder passes, Standin mixes and mlp2: returns the gradients wrt the lead-blocked z1 and z2r."""
+    B, V = sv["hB"], sv["hV"]
     like = sv["dec"][2]        # stacked decoder output [3B, 1, L]
     parts = [g if g is not None else torch.zeros_like(like[0:B]) for g in g_outs]
     g_out = torch.cat([p_.contiguous() for p_ in parts], dim=0)
-    side = _side(g_out.device)
     gD = decoder_bwd(sv["dec"], g_out, P, grads, side)
     gz1, gz2r, gq = ops.mix_bwd(gD, sv["latent"], sv["z1"], sv["z2r"], sv["q"], V, sv["choice"])
     gW2, gb2 = side.run(lambda: ops.theta_mlp_bwd(sv["q_theta"], gq, 256), gq)
+    grads["mlp2.weight"], grads["mlp2.bias"] = gW2, gb2
+    return gz1, gz2r
+
+
+def _latents_bwd(P, sv, gz1, gz2r, grads, side):
+    """Back through `_latents` (+ the segment un-pooling that follows it): encoder-side parameter gradients."""
+    B, V, T = sv["B"], sv["V"], sv["T"]
     gz2b = ops.roi_unpool_bwd(gz2r, sv["rois"])                                  # [B, 128V, 7, 32]
     gh3 = gz2b.view(B, 128 * V * N_SEG, 2 * ROI_BINS)
     gh2 = block_bwd(sv["blk_c22"], gh3, P, grads, side=side)
@@ -399,11 +449,45 @@ def backward(P, sv, g_outs):
     gew = block_bwd(sv["blk_w_conv"], genc, P, grads, side=side, pre_gated=True)
     g, ge = ops.chscale_bwd(gew, sv["w"], sv["e"])
     gW1, gb1 = side.run(lambda: ops.theta_mlp_bwd(sv["in_theta"], ge, 128), ge)
-    # mlp2 is also used by nothing else in train phase; mlp1/mlp2 grads
     grads["mlp1.weight"], grads["mlp1.bias"] = gW1, gb1
-    grads["mlp2.weight"], grads["mlp2.bias"] = gW2, gb2
     for i in (2, 1, 0):
         g = block_bwd(sv["blk_enc"][i], g, P, grads, side=side, pre_gated=(i < 2), gate_input=(i > 0))
     grads["W_encoder.conv1.weight"] = ops.stem_bwd_weight(sv["x"], P["W_encoder.conv1.weight"], g)
+
+
+def backward(P, sv, g_outs):
+    """g_outs: gradients wrt (out, shuffle_p, shuffle_l), each [B,1,L] or None.  Returns {param name: grad}."""
+    grads = {}
+    side = _side(sv["z1"].device)
+    gz1, gz2r = _head_bwd(P, sv, g_outs, grads, side)
+    _latents_bwd(P, sv, gz1, gz2r, grads, side)
+    side.join()
+    return grads
+
+
+def backward2(P, sv, g_outs):
+    """Backward of forward2: the head as in Model_nefnet, then the two shared single convs lead by lead (their weight
+    gradients summed over the leads in lead order), then the folded-batch encoder."""
+    grads = {}
+    side = _side(sv["z1"].device)
+    gZ1, gZ2 = _head_bwd(P, sv, g_outs, grads, side)                              # [B, 128V, T]
+    B, V = sv["fold"]
+    T = gZ1.shape[2]
+    gz1f = torch.empty(V * B, 128, T, device=gZ1.device, dtype=torch.float32)
+    gz2rf = torch.empty_like(gz1f)
+    for name, gZ, xin, gout in (("single_conv_z1.0", gZ1, sv["z1f"], gz1f), ("single_conv_z2.0", gZ2, sv["z2rf"], gz2rf)):
+        wf = ops.pack_weight(P[name + ".weight"], 1, flip=True)
+        gw = None
+        for i in range(V):
+            gv = _lead_view(gZ, i, V)
+            ops.conv(gv, wf, 128, 3, out=GV.dense(gout[i * B:(i + 1) * B], 1), role="conv_bwd_data")
+            w = ops.conv_bwd_weight(GV.dense(xin[i * B:(i + 1) * B], 1), gv, 3)
+            gw = w if gw is None else ops.add(gw, w)
+        cs = ops.chan_sum(gZ)                                                      # [128V]
+        gb = cs[0:128].contiguous()
+        for i in range(1, V):
+            gb = ops.add(gb, cs[i * 128:(i + 1) * 128].contiguous())
+        grads[name + ".weight"], grads[name + ".bias"] = gw, gb
+    _latents_bwd(P, sv, gz1f, gz2rf, grads, side)
     side.join()
     return grads

@@ -3,9 +3,11 @@
 from torch.nn import CrossEntropyLoss, MSELoss
 
 from .loss import MSELead, losswrapper  # noqa: F401
-from .model_nefnet import Model_nefnet
+from .model_nefnet import Model_nefnet, Model_nefnet2
 
-_MODELS = {"model_nefnet": lambda cfg: Model_nefnet(theta_encoder_len=cfg.MODEL.theta_L, lead_num=cfg.DATA.lead_num)}
+_MODELS = {"model_nefnet": lambda cfg: Model_nefnet(theta_encoder_len=cfg.MODEL.theta_L, lead_num=cfg.DATA.lead_num),
+           # not in the reference's factory (its model_nefnet2.py is unreachable from config); an extension name
+           "model_nefnet2": lambda cfg: Model_nefnet2(theta_encoder_len=cfg.MODEL.theta_L, lead_num=cfg.DATA.lead_num)}
 _LOSSES = {"v1": lambda: losswrapper, "ce": CrossEntropyLoss, "mse": MSELoss}
 
 

@@ -54,28 +54,31 @@ class _NefNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, in_theta, q_theta, rois, choice, drop, names, *params):
         P = dict(zip(names, params))
-        outs, sv = engine.forward(P, model._buffers_by_name(), x, in_theta, q_theta, rois, phase="train",
-                                  training=model.training, drop=drop, lead_choice=choice, save=True,
-                                  status=model._status)
-        ctx.sv, ctx.names, ctx.P = sv, names, P
+        outs, sv = model._engine_fwd(P, model._buffers_by_name(), x, in_theta, q_theta, rois, phase="train",
+                                     training=model.training, drop=drop, lead_choice=choice, save=True,
+                                     status=model._status)
+        ctx.sv, ctx.names, ctx.P, ctx.bwd = sv, names, P, model._engine_bwd
         return outs
 
     @staticmethod
     def backward(ctx, g_out, g_p, g_l):
-        grads = engine.backward(ctx.P, ctx.sv, (g_out, g_p, g_l))
+        grads = ctx.bwd(ctx.P, ctx.sv, (g_out, g_p, g_l))
         ctx.sv = None
         return (None,) * 8 + tuple(grads.get(n) for n in ctx.names)
 
 
 class Model_nefnet(nn.Module):
     """Nef-Net (reference codes/network/model_nefnet.py:63)."""
+    _engine_fwd = staticmethod(engine.forward)
+    _engine_bwd = staticmethod(engine.backward)
 
     def __init__(self, theta_encoder_len=1, lead_num=1):
         super().__init__()
         if theta_encoder_len != 1:
             # ThetaEncoder.forward ignores encoder_len (theta_encoder.py:13-29), so mlp1/mlp2 only fit theta_L == 1
             raise ValueError("theta_encoder_len must be 1 (the reference's angular encoding emits 12 values)")
-        V = self.lead_num = lead_num
+        self.lead_num = lead_num
+        V = self._group_leads(lead_num)          # leads the grouped encoder layers are built for
         self.W_encoder = _Encoder(V, 128)
         self.mlp1 = nn.Linear(12, 128)
         self.mlp2 = nn.Linear(12, 256)
@@ -89,6 +92,7 @@ class Model_nefnet(nn.Module):
             _Block(448 * V, 896 * V, 7 * V, 3, True))
         self.decoder = nn.Sequential(nn.Identity(), _DoubleConv(256, 128), nn.Identity(), _DoubleConv(128, 64),
                                      nn.Conv1d(64, 1, 3, padding=1))
+        self._extra_layers()
         self.dropout_p = engine.DROP_P
         self.dropout_masks = None      # test hook: {site: uint8 keep-mask} replayed instead of the RNG
         # 'fp32' (reference arithmetic) or 'fp16': eval-mode view sweeps (phase 'val'/'test' rest_out, gen_ecg) on the
@@ -98,6 +102,13 @@ class Model_nefnet(nn.Module):
         self._status = None
 
     # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _group_leads(lead_num):
+        return lead_num
+
+    def _extra_layers(self):
+        pass
+
     def _params_by_name(self):
         return dict(self.named_parameters())
 
@@ -146,7 +157,7 @@ class Model_nefnet(nn.Module):
         drop = self._drop_cfg()
         if phase == 'gen':
             with torch.no_grad():
-                (z1, z2), _ = engine.forward(self._params_by_name(), self._buffers_by_name(), x, input_thetas,
+                (z1, z2), _ = self._engine_fwd(self._params_by_name(), self._buffers_by_name(), x, input_thetas,
                                              query_theta, rois, phase='gen', training=self.training, drop=drop)
             return z1, z2
         # Python `random` is consumed exactly twice, z1 choice first (model_nefnet.py:154,156)
@@ -158,13 +169,13 @@ class Model_nefnet(nn.Module):
                 return _NefNetFn.apply(self, x, input_thetas, query_theta, rois, choice, drop, names,
                                        *[p for _, p in named])
             with torch.no_grad():
-                outs, _ = engine.forward(dict(named), self._buffers_by_name(), x, input_thetas, query_theta, rois,
+                outs, _ = self._engine_fwd(dict(named), self._buffers_by_name(), x, input_thetas, query_theta, rois,
                                          phase='train', training=self.training, drop=drop, lead_choice=choice,
                                          status=self._status)
             return outs
         if phase in ('val', 'test'):
             with torch.no_grad():
-                outs, _ = engine.forward(self._params_by_name(), self._buffers_by_name(), x, input_thetas, query_theta,
+                outs, _ = self._engine_fwd(self._params_by_name(), self._buffers_by_name(), x, input_thetas, query_theta,
                                          rois, rest_theta=self._f32(rest_theta), phase=phase, training=self.training,
                                          drop=drop, lead_choice=choice, status=self._status,
                                          half_sweep=self._half_sweep())
@@ -177,3 +188,21 @@ class Model_nefnet(nn.Module):
             return engine.gen_ecg(self._params_by_name(), self._buffers_by_name(), self._f32(z1), self._f32(z2),
                                   self._f32(query_theta), rois.detach().to(torch.int64).contiguous(),
                                   half=self._half_sweep())
+
+
+class Model_nefnet2(Model_nefnet):
+    """Nef-Net2 (reference codes/network/model_nefnet2.py:63-228): one single-lead encoder shared by every input lead,
+    plus `single_conv_z1` / `single_conv_z2`.  Same forward / gen_ecg signatures and return tuples as Model_nefnet,
+    except that phase 'gen' returns the two lead MEANS `(z1_mean, z2_mean)`, each [B, 128, T] (model_nefnet2.py:158-159).
+    Not reachable from the reference's config (`build_model` only knows 'model_nefnet'); offered under the name
+    'model_nefnet2'.  `dropout_masks`, when set, are per folded sample (lead-major, V*B rows)."""
+    _engine_fwd = staticmethod(engine.forward2)
+    _engine_bwd = staticmethod(engine.backward2)
+
+    @staticmethod
+    def _group_leads(lead_num):
+        return 1
+
+    def _extra_layers(self):
+        self.single_conv_z1 = nn.Sequential(nn.Conv1d(128, 128, 3, 1, 1))
+        self.single_conv_z2 = nn.Sequential(nn.Conv1d(128, 128, 3, 1, 1))

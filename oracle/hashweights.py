@@ -15,7 +15,7 @@ import zlib
 import numpy as np
 import torch
 
-from .nefnet_oracle import buffer_shapes, param_shapes
+from .nefnet_oracle import buffer_shapes, param_shapes, param_shapes2
 
 
 def _mix32(x):
@@ -44,9 +44,14 @@ def _half_width(name, shp):
     return 0.05
 
 
-def hashed_params(V):
+def hashed_params2():
+    """Model_nefnet2's tensors (single-lead inventory + the two single convs)."""
+    return hashed_params(1, param_shapes2())
+
+
+def hashed_params(V, shapes=None):
     P = {}
-    for name, shp in param_shapes(V).items():
+    for name, shp in (shapes or param_shapes(V)).items():
         n = int(np.prod(shp))
         u = unit_noise(name, n)
         if ".double_conv.1." in name or ".double_conv.4." in name:

@@ -307,6 +307,77 @@ def case_real(network):
     return dev
 
 
+def case_nefnet2(network, B, V, L, Q, seed, reg="l1_loss"):
+    """f4: the reference's Model_nefnet2 (shared single-lead encoder), eval test-phase + one train-phase fwd/bwd with
+    dropout off.  Hash weights of oracle/hashweights.py::hashed_params2."""
+    from network.model_nefnet2 import Model_nefnet2
+    batch = to_t(synth.make_batch(B, V, L, seed=seed, Q=Q))
+    cfg = ref_cfg(V, reg=reg)
+    loss_fn = network.build_loss(cfg)
+
+    def make():
+        torch.manual_seed(0)
+        m = Model_nefnet2(1, V).float()
+        P, Bf = hw.hashed_params2(), hw.hashed_buffers()
+        sd = m.state_dict()
+        assert set(sd.keys()) == set(P) | set(Bf), sorted(set(sd.keys()) ^ (set(P) | set(Bf)))
+        m.load_state_dict({**P, **Bf})
+        for blk in (m.W_encoder.layer1[0], m.W_encoder.layer1[1], m.W_encoder.layer1[2], m.w_conv[0], m.z1_conv[0],
+                    m.z2_conv1[0], m.z2_conv2[0], m.z2_conv2[2]):
+            blk.dropout = MaskReplay(None, 0.0)
+        return m
+
+    m = make().eval()
+    random.seed(seed)
+    st = random.getstate()
+    with torch.no_grad():
+        outs = m(batch["data"], batch["input_theta"], batch["target_theta"], batch["rois"],
+                 rest_theta=batch["rest_theta"], phase="test")
+        random.setstate(st)
+        c1, c2 = random.randint(0, V - 1), random.randint(0, V - 1)
+        z1m, z2m = m(batch["data"], batch["input_theta"], batch["target_theta"], batch["rois"], phase="gen")
+        mine = orc.forward2(hw.hashed_params2(), hw.hashed_buffers(), batch["data"], batch["input_theta"],
+                            batch["target_theta"], batch["rois"], rest_theta=batch["rest_theta"], phase="test",
+                            training=False, lead_choice=(c1, c2))
+        mine_gen = orc.forward2(hw.hashed_params2(), hw.hashed_buffers(), batch["data"], batch["input_theta"],
+                                batch["target_theta"], batch["rois"], phase="gen", training=False)
+    dev = max(max(rel(a, b) for a, b in zip(mine, outs)), rel(mine_gen[0], z1m), rel(mine_gen[1], z2m))
+    save = dict(B=B, V=V, L=L, Q=Q, seed=seed, lead_choice=[c1, c2], reg=reg,
+                out=outs[0].numpy(), shuf_p=outs[1].numpy(), shuf_l=outs[2].numpy(), rest_out=outs[3].numpy(),
+                z1m_sub=sub(z1m), z1m_stats=stats(z1m), z2m_sub=sub(z2m), z2m_stats=stats(z2m))
+    # train phase, dropout off
+    m = make().train()
+    random.setstate(st)
+    touts = m(batch["data"], batch["input_theta"], batch["target_theta"], batch["rois"], phase="train")
+    losses = loss_fn(touts[0], touts[1], touts[2], batch["target_view"].unsqueeze(1), cfg)
+    losses[0].backward()
+    grads = {k: v.grad for k, v in m.named_parameters()}
+    assert all((grads[k] is None) == (k in orc.DEAD_PARAMS) for k in grads), "dead-parameter set changed"
+    P, Bf = orc.require_grad(hw.hashed_params2()), hw.hashed_buffers()
+    tmine = orc.forward2(P, Bf, batch["data"], batch["input_theta"], batch["target_theta"], batch["rois"],
+                         phase="train", training=True, p=0.0, lead_choice=(c1, c2))
+    ml = orc.loss_v1(tmine[0], tmine[1], tmine[2], batch["target_view"].unsqueeze(1), cfg.SOLVER.loss_factor,
+                     cfg.SOLVER.loss_using, reg)
+    ml[0].backward()
+    dev = max(dev, max(rel(a, b) for a, b in zip(tmine, touts)))
+    flat_ref = torch.cat([g.reshape(-1) for g in grads.values() if g is not None])
+    flat_mine = torch.cat([P[k].grad.reshape(-1) for k in grads if grads[k] is not None])
+    gdev = rel(flat_mine, flat_ref)
+    sd = m.state_dict()
+    save.update(t_out=touts[0].detach().numpy(), t_shuf_p=touts[1].detach().numpy(), t_shuf_l=touts[2].detach().numpy(),
+                losses=np.array([float(v.detach()) for v in losses]), flat_grad_norm=flat_ref.double().norm().item())
+    for k, g in grads.items():
+        if g is not None:
+            save["gsub:" + k] = sub(g, 256)
+            save["gstat:" + k] = stats(g)
+    for k in Bf:
+        save["buf:" + k] = sd[k].numpy()
+    name = f"nefnet2_B{B}_V{V}_L{L}_Q{Q}"
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+    print(f"{name}: oracle vs reference out {dev:.2e} grad {gdev:.2e}")
+    return max(dev, gdev)
+
+
 PTB_CONFIGS = ((3, "IIv2v5_v4I_372", "input_fix", "train"), (3, "IIv2v5_v4I_372", "random", "test"),
                (8, "_8120", "input_fix", "train"), (1, "_192", "input_fix", "test"), (5, "_561", "input_fix", "train"))
 
@@ -396,6 +467,10 @@ def main():
     if sys.argv[1:] == ["ptb"]:
         case_ptb()
         return
+    if sys.argv[1:] == ["nefnet2"]:
+        network = import_reference()
+        print(max(case_nefnet2(network, 2, 3, 512, 4, seed=31), case_nefnet2(network, 3, 1, 1000, 3, seed=32)))
+        return
     network = import_reference()
     worst = [case_theta(network), case_roi(network), case_real(network), case_ptb()]
     for B, V, L in ((2, 1, 512), (2, 3, 512), (2, 3, 1000), (2, 8, 512)):
@@ -405,6 +480,8 @@ def main():
     worst.append(case_train(network, 3, 3, 1000, seed=7, reg="l2_loss"))
     worst.append(case_train(network, 2, 3, 512, seed=8, use_masks=False))
     worst.append(case_sgd(network, 4, 3, 512, seed=21))
+    worst.append(case_nefnet2(network, 2, 3, 512, 4, seed=31))
+    worst.append(case_nefnet2(network, 3, 1, 1000, 3, seed=32))
     print("worst oracle-vs-reference deviation:", max(worst))
 
 

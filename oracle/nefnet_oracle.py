@@ -85,6 +85,15 @@ def param_shapes(V):
     return s
 
 
+def param_shapes2():
+    """Model_nefnet2 (network/model_nefnet2.py:68-116): the single-lead inventory plus the two single convs."""
+    s = param_shapes(1)
+    for name in ("single_conv_z1.0", "single_conv_z2.0"):
+        s[name + ".weight"] = (128, 128, 3)
+        s[name + ".bias"] = (128,)
+    return s
+
+
 def buffer_shapes():
     s = {}
     for blk, c in (("decoder.1", 128), ("decoder.3", 64)):
@@ -267,6 +276,57 @@ def forward(P, Bf, x, input_thetas, query_theta, rois, rest_theta=None, phase="t
     out_l = decoder(q[:, :, None] * shuf_l, P, Bf, training)                # :174-176
     if taps is not None:
         taps.update(z2_rev=z2r, latent_all=latent, q=q)
+    if phase == "train":
+        return out, out_p, out_l
+    if phase in ("val", "test"):
+        rq = F.linear(angular_encoding(rest_theta), P["mlp2.weight"], P["mlp2.bias"])
+        rest = [decoder(rq[:, i, :, None] * latent, P, Bf, training) for i in range(rq.shape[1])]
+        return out, out_p, out_l, torch.cat(rest, dim=1)
+    raise KeyError("please type correct phase")
+
+
+def forward2(P, Bf, x, input_thetas, query_theta, rois, rest_theta=None, phase="train", training=True, masks=None,
+             p=DROP_P, lead_choice=None):
+    """network/model_nefnet2.py:118-194: the lead loop with ONE shared single-lead encoder, restated as written."""
+    B, V, _ = x.shape
+    z1_list, z2_list = [], []
+    for i in range(V):                                                       # :126
+        xs, ths = x[:, i:i + 1], input_thetas[:, i:i + 1]
+        w = stem(xs, P, 1)                                                   # :130
+        for k in range(3):
+            w = res_block(w, P, f"W_encoder.layer1.{k}", 1, 7, training, masks, p)
+        e = F.linear(angular_encoding(ths), P["mlp1.weight"], P["mlp1.bias"])   # :131-133
+        w = e[:, 0][:, :, None] * w                                          # :134
+        w = res_block(w, P, "w_conv.0", 1, 3, training, masks, p)            # :135
+        z1, z2 = torch.chunk(w, 2, dim=1)                                    # :137
+        z1 = res_block(z1, P, "z1_conv.0", 1, 3, training, masks, p)         # :139
+        z1 = F.conv1d(z1, P["single_conv_z1.0.weight"], P["single_conv_z1.0.bias"], padding=1)   # :140
+        z2 = res_block(z2, P, "z2_conv1.0", 1, 3, training, masks, p)        # :141
+        z2 = roi_align_mid(z2, rois)                                         # :143
+        h = z2.contiguous().view(B, 128 * N_SEG, ROI_BINS)                   # :144
+        h = res_block(h, P, "z2_conv2.0", N_SEG, 3, training, masks, p)      # :145
+        h = F.conv_transpose1d(h, P["z2_conv2.1.weight"], P["z2_conv2.1.bias"], 2, 0, 0, N_SEG)
+        h = res_block(h, P, "z2_conv2.2", N_SEG, 3, training, masks, p)
+        z2 = roi_unpool(h.view(B, 128, N_SEG, 2 * ROI_BINS), rois)           # :147
+        z2 = F.conv1d(z2, P["single_conv_z2.0.weight"], P["single_conv_z2.0.bias"], padding=1)   # :148
+        z1_list.append(z1)
+        z2_list.append(z2)
+    z1m = torch.mean(torch.stack(z1_list, dim=0), dim=0)                     # :154-155
+    z2m = torch.mean(torch.stack(z2_list, dim=0), dim=0)
+    latent = torch.cat([z1m, z2m], dim=1)
+    if phase == "gen":                                                       # :158-159
+        return z1m, z2m
+    if lead_choice is None:
+        c1 = random.randint(0, V - 1)                                        # :162
+        c2 = random.randint(0, V - 1)                                        # :164
+    else:
+        c1, c2 = lead_choice
+    shuf_p = torch.cat([z1_list[c1], z2m], dim=1)                            # :167
+    shuf_l = torch.cat([z1m, z2_list[c2]], dim=1)                            # :168
+    q = F.linear(angular_encoding(query_theta).reshape(B, -1), P["mlp2.weight"], P["mlp2.bias"])
+    out = decoder(q[:, :, None] * latent, P, Bf, training)                   # :174-176
+    out_p = decoder(q[:, :, None] * shuf_p, P, Bf, training)
+    out_l = decoder(q[:, :, None] * shuf_l, P, Bf, training)
     if phase == "train":
         return out, out_p, out_l
     if phase in ("val", "test"):

@@ -506,3 +506,89 @@ def test_rccl_single_rank():
            "127.0.0.1", "--master-port", "29533", os.path.join(root, "tests", "rccl_worker.py")]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def hashed_model2(V):
+    from electrocardio_panorama_amd.network import build_model
+    from oracle import hashweights as hw
+    c = make_cfg(V)
+    c.MODEL.model = "model_nefnet2"
+    m = build_model(c).float()
+    m.load_state_dict({**hw.hashed_params2(), **hw.hashed_buffers()})
+    return m.to(DEV)
+
+
+def test_nefnet2_golden(golden_dir):
+    """f4: Model_nefnet2 (one single-lead encoder shared by all leads + the two single convs) against the reference's
+    own outputs, lead means, losses and gradients (tests/golden/nefnet2_*.npz, dropout off)."""
+    from electrocardio_panorama_amd.network import build_loss
+    from oracle import nefnet_oracle as orc
+    flat_rels = []
+    for f in golden(golden_dir, "nefnet2_*.npz"):
+        z = np.load(f)
+        B, V, L, Q, seed = (int(z[k]) for k in ("B", "V", "L", "Q", "seed"))
+        name = os.path.basename(f)
+        b = batch_t(B, V, L, seed, Q)
+        m = hashed_model2(V).eval()
+        random.seed(seed)
+        outs = m(b["data"], b["input_theta"], b["target_theta"], b["rois"], rest_theta=b["rest_theta"], phase="test")
+        for got, key in zip(outs, ("out", "shuf_p", "shuf_l", "rest_out")):
+            assert rel(got, z[key]) < FWD_TOL, (name, key, rel(got, z[key]))
+        z1m, z2m = m(b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="gen")
+        assert z1m.shape == (B, 128, L // 4) and z2m.shape == (B, 128, L // 4)
+        assert rel(sub(z1m), z["z1m_sub"]) < FWD_TOL and rel(stats(z2m), z["z2m_stats"]) < 1e-5
+        # train phase
+        cfg = make_cfg(V, str(z["reg"]))
+        m = hashed_model2(V).train()
+        m.dropout_p = 0.0
+        random.seed(seed)
+        touts = m(b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train")
+        losses = build_loss(cfg)(touts[0], touts[1], touts[2], b["target_view"].unsqueeze(1), cfg)
+        losses[0].backward()
+        for got, key in zip(touts, ("t_out", "t_shuf_p", "t_shuf_l")):
+            assert rel(got, z[key]) < FWD_TOL, (name, key, rel(got, z[key]))
+        assert maxabs(torch.stack([l_.detach() for l_ in losses]), z["losses"]) < 1e-6, name
+        sq, got_all, ref_all = 0.0, [], []
+        for k, p in m.named_parameters():
+            if k in orc.DEAD_PARAMS:
+                assert p.grad is None, k
+                continue
+            assert p.grad is not None, k
+            ref_sub = z["gsub:" + k]
+            if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
+                assert maxabs(sub(p.grad, 256), ref_sub) < 1e-6, (name, k)
+                continue
+            assert rel(sub(p.grad, 256), ref_sub) < 5 * LOOSE, (name, k, rel(sub(p.grad, 256), ref_sub))
+            got_all.append(sub(p.grad, 256))
+            ref_all.append(ref_sub)
+            sq += float((p.grad.double() ** 2).sum())
+        assert abs(sq ** 0.5 - float(z["flat_grad_norm"])) < LOOSE * float(z["flat_grad_norm"]), name
+        flat_rels.append(rel(np.concatenate(got_all), np.concatenate(ref_all)))
+        sd = m.state_dict()
+        for k in sd:
+            if "running" in k:
+                assert rel(sd[k], z["buf:" + k]) < 1e-5, (name, k)
+    assert max(flat_rels) < LOOSE, flat_rels
+    assert min(flat_rels) < TIGHT, flat_rels
+
+
+def test_nefnet2_sgd_step_runs_through_solver_api():
+    """Model_nefnet2 with FusedSGD: shared-weight gradients reach the optimiser, parameters move, dead ones do not."""
+    from electrocardio_panorama_amd.network import build_loss
+    from electrocardio_panorama_amd.solver.optim_scheduler import get_optimizer
+    from oracle import nefnet_oracle as orc
+    cfg = make_cfg(3)
+    m = hashed_model2(3).train()
+    optim = get_optimizer(cfg, m.parameters())
+    b = batch_t(4, 3, 512, 3)
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    random.seed(1)
+    outs = m(b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train")
+    build_loss(cfg)(outs[0], outs[1], outs[2], b["target_view"].unsqueeze(1), cfg)[0].backward()
+    optim.step()
+    optim.zero_grad()
+    for k, v in m.named_parameters():
+        if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
+            continue                                   # gradient analytically zero (SURVEY Q6): may or may not move
+        moved = not torch.equal(v.detach(), before[k])
+        assert moved == (k not in orc.DEAD_PARAMS), k

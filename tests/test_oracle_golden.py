@@ -109,3 +109,31 @@ def test_real_recordings_fixture(golden_dir):
                            phase="test", training=False)
     for got, key in zip(outs, ("out", "shuf_p", "shuf_l", "rest_out")):
         assert rel(got, z[key]) < 1e-6, key
+
+
+def test_nefnet2_fixture(golden_dir):
+    """f4: the oracle's Model_nefnet2 restatement (shared single-lead encoder, lead loop) against the reference's own
+    outputs and gradients (dropout off)."""
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    z = np.load(os.path.join(golden_dir, "nefnet2_B2_V3_L512_Q4.npz"))
+    B, V, L, Q, seed = (int(z[k]) for k in ("B", "V", "L", "Q", "seed"))
+    b = _batch(B, V, L, seed, Q)
+    choice = tuple(int(c) for c in z["lead_choice"])
+    with torch.no_grad():
+        out = orc.forward2(hw.hashed_params2(), hw.hashed_buffers(), b["data"], b["input_theta"], b["target_theta"],
+                           b["rois"], rest_theta=b["rest_theta"], phase="test", training=False, lead_choice=choice)
+        z1m, z2m = orc.forward2(hw.hashed_params2(), hw.hashed_buffers(), b["data"], b["input_theta"], b["target_theta"],
+                                b["rois"], phase="gen", training=False)
+    for got, key in zip(out, ("out", "shuf_p", "shuf_l", "rest_out")):
+        assert rel(got, z[key]) < 1e-6, key
+    assert z1m.shape == (B, 128, L // 4) and rel(sub(z1m), z["z1m_sub"]) < 1e-6 and rel(stats(z2m), z["z2m_stats"]) < 1e-6
+    P, Bf = orc.require_grad(hw.hashed_params2()), hw.hashed_buffers()
+    outs = orc.forward2(P, Bf, b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train", training=True,
+                        p=0.0, lead_choice=choice)
+    losses = orc.loss_v1(outs[0], outs[1], outs[2], b["target_view"].unsqueeze(1), reg_loss=str(z["reg"]))
+    losses[0].backward()
+    assert maxabs(torch.stack([l_.detach() for l_ in losses]), z["losses"]) < 1e-6
+    for k in ("single_conv_z1.0.weight", "single_conv_z2.0.bias", "W_encoder.conv1.weight", "mlp1.weight"):
+        assert rel(sub(P[k].grad, 256), z["gsub:" + k]) < 1e-5, k
+    assert all(P[k].grad is None for k in orc.DEAD_PARAMS)
