@@ -319,6 +319,14 @@ def test_baseline_config_shapes_vs_oracle(B, V, L, Q, phase):
         assert rel(gen, ref[3]) < FWD_TOL
 
 
+@pytest.mark.parametrize("V", [2, 4, 5, 9, 12])
+def test_every_supported_lead_count_vs_oracle(V):
+    """The input-lead schemes the reference's datasets can emit (lead_num 1/2/3/4/5/8/9/12: tianchi.py:127-190); 1, 3 and
+    8 are covered by the fixtures above, the rest here: train-phase outputs, losses and the flat gradient (dropout
+    off), ragged length 520 (T=130: one full column tile + 2)."""
+    test_baseline_config_shapes_vs_oracle(2, V, 520, 0, "train")
+
+
 def test_solver_test_phase_vs_oracle():
     """Solver.run_one_epoch(phase='test') (reference solver.py:190-230): five losses incl. loss_unsperv on the last four
     rest views, PSNR/SSIM bookkeeping; values against the oracle on the same batches."""
