@@ -48,6 +48,9 @@ SIGNATURES = {
     "nef_chan_sum": (i32, [p, p, p, sz, i32, i32, i32, p]),
     "nef_convt2_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, i32, p]),
     "nef_convt2_bwd_data": (i32, [p, p, p, i32, i32, i32, i32, i32, p]),
+    "nef_group_transpose": (i32, [p, p, i32, i32, i32, p]),
+    "nef_convt2_interleave": (i32, [p, p, p, i32, i32, i32, p]),
+    "nef_convt2_deinterleave": (i32, [p, p, i32, i32, i32, p]),
     "nef_convt2_bwd_weight_ws_bytes": (sz, [i32, i32, i32]),
     "nef_convt2_bwd_weight": (i32, [p, p, p, p, p, sz, i32, i32, i32, i32, i32, p]),
     "nef_theta_mlp_fwd": (i32, [p, p, p, p, i32, i32, p]),

@@ -133,6 +133,48 @@ __global__ void convt2_bwd_weight_reduce(const float* __restrict__ part, float* 
     }
 }
 
+
+// ---------------- ConvTranspose1d(k=2,s=2) as a grouped 1x1 conv on the matrix cores ----------------
+// y[b][g][co][2t+j] = bias + sum_ci x[b][g][ci][t] * w[g][ci][co][j] is a 1x1 conv onto 2*Cog "channels" m = co*2+j
+// followed by an interleave of (m, t) -> (co, 2t+j).  The three helpers below are the layout passes around
+// nef_conv_fwd / nef_conv_bwd_weight with K = 1 (a few tens of MB per step).
+// per-group transpose: out[g][c][r] = in[g][r][c]
+__global__ void group_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int G, int R, int Cn) {
+    __shared__ float tile[32][33];
+    const int g = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const float* ig = in + (size_t)g * R * Cn;
+    float* og = out + (size_t)g * R * Cn;
+    for (int i = ly; i < 32; i += 8)
+        if (r0 + i < R && c0 + lx < Cn) tile[i][lx] = ig[(size_t)(r0 + i) * Cn + c0 + lx];
+    __syncthreads();
+    for (int i = ly; i < 32; i += 8)
+        if (c0 + i < Cn && r0 + lx < R) og[(size_t)(c0 + i) * R + r0 + lx] = tile[lx][i];
+}
+
+// y[n][c][2t+j] = yq[n][2c+j][t] + bias[c]     (rows n = b*G*Cog-flattened: C = total output channels)
+__global__ void convt_interleave_kernel(const float* __restrict__ yq, const float* __restrict__ bias,
+                                        float* __restrict__ y, int64_t rows, int C, int T) {
+    const int64_t total = rows * 2 * T;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int u = (int)(i % (2 * T));
+        const int64_t row = i / (2 * T);                   // (b, c)
+        const int t = u >> 1, j = u & 1;
+        const float bv = bias ? bias[row % C] : 0.f;
+        y[i] = yq[(row * 2 + j) * T + t] + bv;
+    }
+}
+
+// gyq[n][2c+j][t] = gy[n][c][2t+j]
+__global__ void convt_deinterleave_kernel(const float* __restrict__ gy, float* __restrict__ gyq, int64_t rows, int T) {
+    const int64_t total = rows * 2 * T;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T);
+        const int64_t rj = i / T;                          // row*2 + j
+        gyq[i] = gy[(rj >> 1) * 2 * T + 2 * t + (rj & 1)];
+    }
+}
+
 // ---------------- angular encoding ----------------
 __device__ __forceinline__ void encode12(float th, float ph, float (&e)[12]) {
     const float a[4] = {th, ph, th + ph, th - ph};
@@ -265,6 +307,35 @@ int nef_convt2_bwd_weight(const float* x, const float* gy, float* gw, float* gb,
     if (rc != NEF_OK) return rc;
     void* cs_ws = (char*)ws + (size_t)CT_SPLIT * n * sizeof(float);
     return nef_chan_sum(gy, gb, cs_ws, nef_chan_sum_ws_bytes(G * Cog), B, G * Cog, 2 * T, stream);
+}
+
+int nef_group_transpose(const float* in, float* out, int G, int R, int Cn, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(in && out, NEF_E_NULL);
+    NEF_REQUIRE(G > 0 && G <= 65535 && R > 0 && Cn > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(group_transpose_kernel, dim3((Cn + 31) / 32, (R + 31) / 32, G), dim3(256), 0, NEF_ST, in, out, G, R,
+                       Cn);
+    return nef_launch_status();
+}
+
+int nef_convt2_interleave(const float* yq, const float* bias, float* y, int B, int C, int T, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(yq && y, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
+    const int64_t rows = (int64_t)B * C;
+    hipLaunchKernelGGL(convt_interleave_kernel, dim3(nef_stream_grid(rows * 2 * T, 256)), dim3(256), 0, NEF_ST, yq, bias,
+                       y, rows, C, T);
+    return nef_launch_status();
+}
+
+int nef_convt2_deinterleave(const float* gy, float* gyq, int B, int C, int T, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gy && gyq, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
+    const int64_t rows = (int64_t)B * C;
+    hipLaunchKernelGGL(convt_deinterleave_kernel, dim3(nef_stream_grid(rows * 2 * T, 256)), dim3(256), 0, NEF_ST, gy, gyq,
+                       rows, T);
+    return nef_launch_status();
 }
 
 int nef_theta_encode(const float* theta, float* enc, int N, nef_stream_t stream) {

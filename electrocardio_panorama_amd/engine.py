@@ -431,9 +431,10 @@ def _latents_bwd(P, sv, gz1, gz2r, grads, side):
     gz2b = ops.roi_unpool_bwd(gz2r, sv["rois"])                                  # [B, 128V, 7, 32]
     gh3 = gz2b.view(B, 128 * V * N_SEG, 2 * ROI_BINS)
     gh2 = block_bwd(sv["blk_c22"], gh3, P, grads, side=side)
-    gwt, gbt = side.run(lambda: ops.convt2_bwd_weight(sv["h1"], gh2, N_SEG * V), sv["h1"], gh2)
+    gh2q = ops.convt2_deinterleave(gh2)                  # shared by the data and the weight gradient
+    gwt, gbt = side.run(lambda: ops.convt2_bwd_weight(sv["h1"], gh2, N_SEG * V, gyq=gh2q), sv["h1"], gh2, gh2q)
     grads["z2_conv2.1.weight"], grads["z2_conv2.1.bias"] = gwt, gbt
-    gh1 = ops.convt2_bwd_data(gh2, P["z2_conv2.1.weight"], N_SEG * V)
+    gh1 = ops.convt2_bwd_data(gh2, P["z2_conv2.1.weight"], N_SEG * V, gyq=gh2q)
     gh0 = block_bwd(sv["blk_c20"], gh1, P, grads, side=side)
     genc = torch.empty(B, 128 * V, T, device=gz1.device, dtype=torch.float32)
     # z1_conv / z2_conv1 read the ReLU output of w_conv: they mask their input gradient with it, w_conv skips its gate

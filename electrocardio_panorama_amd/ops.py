@@ -239,7 +239,7 @@ def chan_sum(x):
 
 
 # ------------------------------------------------------------------ transposed conv (k2 s2)
-def convt2_fwd(x, w, bias, G):
+def _convt2_fma_fwd(x, w, bias, G):
     L = _lib.load()
     _chk(x), _chk(w), _chk(bias)
     B, Ct, T = x.shape
@@ -249,7 +249,7 @@ def convt2_fwd(x, w, bias, G):
     return y
 
 
-def convt2_bwd_data(gy, w, G):
+def _convt2_fma_bwd_data(gy, w, G):
     L = _lib.load()
     _chk(gy), _chk(w)
     B, Ct, To = gy.shape
@@ -259,7 +259,7 @@ def convt2_bwd_data(gy, w, G):
     return gx
 
 
-def convt2_bwd_weight(x, gy, G):
+def _convt2_fma_bwd_weight(x, gy, G):
     L = _lib.load()
     _chk(x), _chk(gy)
     B, Ct, T = x.shape
@@ -271,6 +271,64 @@ def convt2_bwd_weight(x, gy, G):
     _lib.check(L.nef_convt2_bwd_weight(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), n, B, G, Cig, Cog, T, _stream()),
                "nef_convt2_bwd_weight")
     return gw, gb
+
+
+def group_transpose(t, G, R, Cn):
+    """out[g][c][r] = in[g][r][c] over a flat [G*R*Cn] fp32 buffer."""
+    L = _lib.load()
+    _chk(t)
+    out = torch.empty_like(t)
+    _lib.check(L.nef_group_transpose(_p(t), _p(out), G, R, Cn, _stream()), "nef_group_transpose")
+    return out
+
+
+def convt2_as_conv_weight(w, G):
+    """ConvTranspose1d weight [G*Cig, Cog, 2] -> the 1x1 conv weight [G*2Cog, Cig, 1] onto channels m = co*2+j."""
+    Cig, Cog = w.shape[0] // G, w.shape[1]
+    return group_transpose(w, G, Cig, 2 * Cog).view(G * 2 * Cog, Cig, 1)
+
+
+def convt2_deinterleave(gy):
+    L = _lib.load()
+    _chk(gy)
+    B, Ct, To = gy.shape
+    gyq = torch.empty(B, 2 * Ct, To // 2, device=gy.device, dtype=torch.float32)
+    _lib.check(L.nef_convt2_deinterleave(_p(gy), _p(gyq), B, Ct, To // 2, _stream()), "nef_convt2_deinterleave")
+    return gyq
+
+
+def convt2_fwd(x, w, bias, G, fma=False):
+    """ConvTranspose1d(k=2, s=2, groups=G, bias).  Default: grouped 1x1 conv on the matrix cores + interleave;
+    `fma=True` selects the plain-FMA kernel (kept as a cross-check)."""
+    if fma:
+        return _convt2_fma_fwd(x, w, bias, G)
+    L = _lib.load()
+    _chk(x), _chk(w), _chk(bias)
+    B, Ct, T = x.shape
+    Cog = w.shape[1]
+    yq = conv(GV.dense(x, G), pack_weight(convt2_as_conv_weight(w, G), G), 2 * Cog, 1)     # [B, G*2Cog, T]
+    y = torch.empty(B, G * Cog, 2 * T, device=x.device, dtype=torch.float32)
+    _lib.check(L.nef_convt2_interleave(_p(yq), _p(bias), _p(y), B, G * Cog, T, _stream()), "nef_convt2_interleave")
+    return y
+
+
+def convt2_bwd_data(gy, w, G, fma=False, gyq=None):
+    if fma:
+        return _convt2_fma_bwd_data(gy, w, G)
+    Cig = w.shape[0] // G
+    gyq = convt2_deinterleave(gy) if gyq is None else gyq
+    return conv(GV.dense(gyq, G), pack_weight(convt2_as_conv_weight(w, G), G, flip=True), Cig, 1, role="conv_bwd_data")
+
+
+def convt2_bwd_weight(x, gy, G, fma=False, gyq=None):
+    if fma:
+        return _convt2_fma_bwd_weight(x, gy, G)
+    B, Ct, T = x.shape
+    Cig, Cog = Ct // G, gy.shape[1] // G
+    gyq = convt2_deinterleave(gy) if gyq is None else gyq
+    gwc = conv_bwd_weight(GV.dense(x, G), GV.dense(gyq, G), 1)                              # [G*2Cog, Cig, 1]
+    gw = group_transpose(gwc.contiguous(), G, 2 * Cog, Cig).view(G * Cig, Cog, 2)
+    return gw, chan_sum(gy)
 
 
 # ------------------------------------------------------------------ angular encoding + MLP

@@ -114,6 +114,14 @@ int nef_convt2_fwd(const float* x, const float* w, const float* bias, float* y, 
                    int T, nef_stream_t stream);
 int nef_convt2_bwd_data(const float* gy, const float* w, float* gx, int B, int G, int Cig, int Cog, int T,
                         nef_stream_t stream);
+/* The same op through the matrix cores: a grouped 1x1 conv onto m = co*2+j (nef_conv_fwd, K=1, weights
+ * nef_group_transpose'd to [G][2Cog][Cig]) + these layout passes:
+ *   nef_group_transpose    : out[g][c][r] = in[g][r][c]                     (weights both ways: the op is an involution)
+ *   nef_convt2_interleave  : y[b][c][2t+j] = yq[b][2c+j][t] + bias[c]       (bias may be NULL), C = G*Cog
+ *   nef_convt2_deinterleave: gyq[b][2c+j][t] = gy[b][c][2t+j] */
+int nef_group_transpose(const float* in, float* out, int G, int R, int Cn, nef_stream_t stream);
+int nef_convt2_interleave(const float* yq, const float* bias, float* y, int B, int C, int T, nef_stream_t stream);
+int nef_convt2_deinterleave(const float* gy, float* gyq, int B, int C, int T, nef_stream_t stream);
 size_t nef_convt2_bwd_weight_ws_bytes(int G, int Cig, int Cog);
 int nef_convt2_bwd_weight(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int B,
                           int G, int Cig, int Cog, int T, nef_stream_t stream);

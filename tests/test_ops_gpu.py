@@ -183,19 +183,20 @@ def test_chan_sum():
     assert rel(o.chan_sum(g(x)), x.sum(dim=(0, 2))) < 1e-6
 
 
+@pytest.mark.parametrize("fma", [False, True])      # matrix-core path (1x1 conv + interleave) and the plain-FMA kernel
 @pytest.mark.parametrize("B,G,T", [(3, 7, 16), (5, 21, 16), (2, 56, 16)])
-def test_convt2(B, G, T):
+def test_convt2(B, G, T, fma):
     o = ops()
     x, w, b = rnd(B, G * 128, T, seed=17), rnd(G * 128, 64, 2, seed=18, scale=0.1), rnd(G * 64, seed=19)
     xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
     ref = F.conv_transpose1d(xr, wr, br, 2, 0, 0, G)
-    y = o.convt2_fwd(g(x), g(w), g(b), G)
+    y = o.convt2_fwd(g(x), g(w), g(b), G, fma=fma)
     assert rel(y, ref) < FWD_TOL
     gy = rnd(*ref.shape, seed=20)
     ref.backward(gy)
-    assert rel(o.convt2_bwd_data(g(gy), g(w), G), xr.grad) < GRAD_TOL
-    gw, gb = o.convt2_bwd_weight(g(x), g(gy), G)
-    assert rel(gw, wr.grad) < GRAD_TOL and rel(gb, br.grad) < GRAD_TOL
+    assert rel(o.convt2_bwd_data(g(gy), g(w), G, fma=fma), xr.grad) < GRAD_TOL
+    gw, gb = o.convt2_bwd_weight(g(x), g(gy), G, fma=fma)
+    assert gw.shape == wr.shape and rel(gw, wr.grad) < GRAD_TOL and rel(gb, br.grad) < GRAD_TOL
 
 
 def test_theta(golden_dir):
