@@ -221,6 +221,32 @@ __global__ void upsample2_fwd_kernel(const float* __restrict__ x, float* __restr
 // transpose of the above.  x[m] is read by outputs 2m-1 (weight .25), 2m (.75), 2m+1 (.75), 2m+2 (.25); the first and
 // the last sample of a row also collect the clamped edge taps.  Lane m loads the pair (g[2m], g[2m+1]) as one 8-byte
 // access (fully coalesced) and takes g[2m-1] / g[2m+2] from its neighbours with wave shuffles.
+// One workgroup per row, four outputs per thread (Tin even): y[4q..4q+3] from x[2q-1..2q+2], same operation order as above.
+__global__ __launch_bounds__(256) void upsample2_aff_fwd_rows(const float* __restrict__ x, const float* __restrict__ a,
+                                                              const float* __restrict__ b, float* __restrict__ y, int C,
+                                                              int Tin, int Bp) {
+    const int64_t row = blockIdx.x;
+    const int c = (int)(row % C);
+    const int p = (int)((row / C) / Bp);
+    const float af = a[p * C + c], bf = b[p * C + c];
+    const float* xr = x + row * Tin;
+    nef_f32x4* yr = (nef_f32x4*)(y + row * 2 * Tin);
+    const int Q = Tin >> 1;
+    for (int q = threadIdx.x; q < Q; q += 256) {
+        const float2 m = *reinterpret_cast<const float2*>(xr + 2 * q);
+        const float xl = xr[q > 0 ? 2 * q - 1 : 0], xh = xr[2 * q + 2 < Tin ? 2 * q + 2 : Tin - 1];
+        const float r0 = fmaxf(fmaf(xl, af, bf), 0.f), r1 = fmaxf(fmaf(m.x, af, bf), 0.f);
+        const float r2 = fmaxf(fmaf(m.y, af, bf), 0.f), r3 = fmaxf(fmaf(xh, af, bf), 0.f);
+        nef_f32x4 o;
+        // i = 4q: src = 2q - .25 (clamped to 0 at q = 0: l1 = 0, both taps are x[0])
+        o[0] = q > 0 ? 0.25f * r0 + 0.75f * r1 : 1.f * r1 + 0.f * r2;
+        o[1] = 0.75f * r1 + 0.25f * r2;
+        o[2] = 0.25f * r1 + 0.75f * r2;
+        o[3] = 0.75f * r2 + 0.25f * r3;
+        yr[q] = o;
+    }
+}
+
 __device__ __forceinline__ float up2_bwd_edge(const float* __restrict__ gr, int Tin, int m) {
     const int To = 2 * Tin;
     float s = 0.f;
@@ -263,6 +289,29 @@ __global__ void upsample2_bwd_kernel(const float* __restrict__ gy, float* __rest
             else s = 0.25f * left + 0.75f * v.x + 0.75f * v.y + 0.25f * right;
             gxr[m] = s;
         }
+    }
+}
+
+// One workgroup per row, two outputs per thread from one 16-byte load (Tin even)
+__global__ __launch_bounds__(256) void upsample2_bwd_rows(const float* __restrict__ gy, float* __restrict__ gx, int Tin) {
+    const int64_t row = blockIdx.x;
+    const float* gr = gy + row * 2 * Tin;
+    float2* gxr = reinterpret_cast<float2*>(gx + row * Tin);
+    const int Q = Tin >> 1;
+    for (int q = threadIdx.x; q < Q; q += 256) {
+        const nef_f32x4 v = *(const nef_f32x4*)(gr + 4 * q);
+        float2 o;
+        if (q == 0) {
+            o.x = up2_bwd_edge(gr, Tin, 0);
+        } else {
+            o.x = 0.25f * gr[4 * q - 1] + 0.75f * v[0] + 0.75f * v[1] + 0.25f * v[2];
+        }
+        if (q == Q - 1) {
+            o.y = up2_bwd_edge(gr, Tin, Tin - 1);
+        } else {
+            o.y = 0.25f * v[1] + 0.75f * v[2] + 0.75f * v[3] + 0.25f * gr[4 * q + 4];
+        }
+        gxr[q] = o;
     }
 }
 
@@ -507,6 +556,53 @@ __global__ void bn_bwd_apply(const float* __restrict__ gy, const float* __restri
             rs = nef_wave_sum_d(rs);
             if (lane == 0) rowsum[row] = rs;
         }
+    }
+}
+
+// Same pass, one workgroup per (pass, sample, channel) row with 16-byte accesses (L % 4 == 0): the row's six constants
+// are wave-uniform scalar loads, every thread has all its loads in flight at once, and the optional row sum costs one
+// block reduction per row instead of a double-precision shuffle tree per wave.
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict__ gy, const float* __restrict__ x,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ coef, float* __restrict__ gx,
+                                                         double* __restrict__ rowsum, int Bp, int C, int L4) {
+    __shared__ double sm[4];
+    const int64_t row = blockIdx.x;
+    const int c = (int)(row % C);
+    const int p = (int)(row / ((int64_t)Bp * C));
+    const int pc = p * C + c;
+    const float mf = mean[pc], is = invstd[pc], af = a[pc], bf = b[pc];
+    const float k1 = coef[pc * 2], k2 = coef[pc * 2 + 1];
+    const nef_f32x4* xr = (const nef_f32x4*)(x + row * 4 * L4);
+    const nef_f32x4* gr = (const nef_f32x4*)(gy + row * 4 * L4);
+    nef_f32x4* gxr = (nef_f32x4*)(gx + row * 4 * L4);
+    double rs = 0.0;
+    for (int t0 = 0; t0 < L4; t0 += 1024) {
+        nef_f32x4 xv[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * 256 + threadIdx.x;
+            if (t < L4) { xv[u] = xr[t]; gv[u] = gr[t]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * 256 + threadIdx.x;
+            if (t < L4) {
+                nef_f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = fmaf(xv[u][e], af, bf) > 0.f ? gv[u][e] : 0.f;
+                    o[e] = af * (g - k1 - (xv[u][e] - mf) * is * k2);
+                    rs += (double)o[e];
+                }
+                gxr[t] = o;
+            }
+        }
+    }
+    if (rowsum) {
+        rs = nef_block_sum_d(rs, sm);
+        if (threadIdx.x == 0) rowsum[row] = rs;
     }
 }
 
@@ -861,6 +957,10 @@ int nef_upsample2_aff_fwd(const float* x, const float* a, const float* b, float*
     NEF_REQUIRE(x && a && b && y, NEF_E_NULL);
     NEF_REQUIRE(N > 0 && C > 0 && Tin > 0 && Bp > 0, NEF_E_SHAPE);
     const int64_t rows = (int64_t)N * C;
+    if ((Tin & 1) == 0 && Tin >= 4 && rows <= 0x7FFFFFFF) {
+        hipLaunchKernelGGL(upsample2_aff_fwd_rows, dim3((unsigned)rows), dim3(256), 0, NEF_ST, x, a, b, y, C, Tin, Bp);
+        return nef_launch_status();
+    }
     hipLaunchKernelGGL(upsample2_aff_fwd_kernel, dim3(nef_stream_grid(rows, 4)), dim3(256), 0, NEF_ST, x, a, b, y, rows, C,
                        Tin, Bp);
     return nef_launch_status();
@@ -870,6 +970,10 @@ int nef_upsample2_bwd(const float* gy, float* gx, int64_t N, int Tin, nef_stream
     NEF_ENTER();
     NEF_REQUIRE(gy && gx, NEF_E_NULL);
     NEF_REQUIRE(N > 0 && Tin > 0, NEF_E_SHAPE);
+    if ((Tin & 1) == 0 && Tin >= 4 && N <= 0x7FFFFFFF) {
+        hipLaunchKernelGGL(upsample2_bwd_rows, dim3((unsigned)N), dim3(256), 0, NEF_ST, gy, gx, Tin);
+        return nef_launch_status();
+    }
     hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(nef_stream_grid(N, 4)), dim3(256), 0, NEF_ST, gy, gx, N, Tin);
     return nef_launch_status();
 }
@@ -938,8 +1042,13 @@ int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const f
                        Bp, C, L);
     hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma, gbeta,
                        P, Bp, C, L);
-    hipLaunchKernelGGL(bn_bwd_apply, dim3(nef_stream_grid((int64_t)P * Bp * C, 4)), dim3(256), 0, NEF_ST, gy, x, mean,
-                       invstd, a, b, (const float*)coef, gx, rowsum, P, Bp, C, L);
+    const int64_t rows = (int64_t)P * Bp * C;
+    if ((L & 3) == 0 && rows <= 0x7FFFFFFF)
+        hipLaunchKernelGGL(bn_bwd_apply_rows, dim3((unsigned)rows), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b,
+                           (const float*)coef, gx, rowsum, Bp, C, L >> 2);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply, dim3(nef_stream_grid(rows, 4)), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b,
+                           (const float*)coef, gx, rowsum, P, Bp, C, L);
     if (gx_chan_sum)
         hipLaunchKernelGGL(rowsum_to_channel, dim3(C), dim3(256), 0, NEF_ST, (const double*)rowsum, gx_chan_sum,
                            P * Bp, C);
