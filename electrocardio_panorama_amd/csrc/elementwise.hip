@@ -622,6 +622,7 @@ __global__ __launch_bounds__(256) void rowsum_to_channel(const double* __restric
 // ------------------------------------------------------------------------------------------------
 constexpr int OC_MAXC = 64;
 
+template <bool VEC4>
 __global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           int N, int C, int L, int tiles, const float* __restrict__ pa,
@@ -635,6 +636,37 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restric
         bl[i] = pa ? pb[(n / Bp) * C + i] : 0.f;
     }
     __syncthreads();
+    if (VEC4) {
+        // four consecutive outputs per thread: one 16-byte load + the two neighbours per channel
+        const int t = ((blockIdx.x % tiles) * 256 + threadIdx.x) * 4;
+        if (t >= L) return;
+        const float* xs = x + (int64_t)n * C * L + t;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool hl = t > 0, hr = t + 4 < L;
+        for (int c = 0; c < C; ++c) {
+            const float* r = xs + (int64_t)c * L;
+            const nef_f32x4 m = *(const nef_f32x4*)r;
+            float v[6] = {hl ? r[-1] : 0.f, m[0], m[1], m[2], m[3], hr ? r[4] : 0.f};
+            if (pa) {   // BatchNorm affine + ReLU of the producing layer; padding stays zero
+#pragma unroll
+                for (int e = 0; e < 6; ++e) v[e] = fmaxf(fmaf(v[e], al[c], bl[c]), 0.f);
+                if (!hl) v[0] = 0.f;
+                if (!hr) v[5] = 0.f;
+            }
+            const float w0 = wl[c * 3], w1 = wl[c * 3 + 1], w2 = wl[c * 3 + 2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[e] = fmaf(w0, v[e], acc[e]);
+                acc[e] = fmaf(w1, v[e + 1], acc[e]);
+                acc[e] = fmaf(w2, v[e + 2], acc[e]);
+            }
+        }
+        nef_f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = 1.0f / (1.0f + expf(-((acc[e] + bias[0]) / 3.0f)));
+        *(nef_f32x4*)(out + (int64_t)n * L + t) = o;
+        return;
+    }
     const int t = (blockIdx.x % tiles) * 256 + threadIdx.x;
     if (t >= L) return;
     const float* xs = x + (int64_t)n * C * L + t;
@@ -717,6 +749,41 @@ __global__ __launch_bounds__(256) void outconv_bwd_weight_partial(const float* _
             gol[i] = v;
         }
         __syncthreads();
+        if ((L & 3) == 0) {
+            // this lane's go values (4 runs of 4 positions + 1 halo each side) live in registers for all channels
+            float gr[4][6];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 6; ++e) gr[i][e] = gol[(lane + 64 * i) * 4 + e];
+#pragma unroll
+            for (int j = 0; j < OC_CPW; ++j) {
+                const int c = wave * OC_CPW + j;
+                if (c < C) {
+                    const float* xr = x + ((int64_t)n * C + c) * L + t0;
+                    const float af = pa ? pa[(n / Bp) * C + c] : 1.f, bf = pa ? pb[(n / Bp) * C + c] : 0.f;
+                    nef_f32x4 xv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int tl = (lane + 64 * i) * 4;
+                        xv[i] = t0 + tl < L ? *(const nef_f32x4*)(xr + tl) : nef_f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (t0 + (lane + 64 * i) * 4 < L) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float v = xv[i][e];
+                                if (pa) v = fmaxf(fmaf(v, af, bf), 0.f);
+                                acc[j][0] = fmaf(gr[i][e + 2], v, acc[j][0]);
+                                acc[j][1] = fmaf(gr[i][e + 1], v, acc[j][1]);
+                                acc[j][2] = fmaf(gr[i][e], v, acc[j][2]);
+                            }
+                        }
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < OC_CPW; ++j) {
             const int c = wave * OC_CPW + j;
@@ -1061,9 +1128,15 @@ int nef_outconv_fwd_pro(const float* x, const float* a, const float* b, int Bp, 
     NEF_REQUIRE(x && w && bias && out, NEF_E_NULL);
     NEF_REQUIRE((a == nullptr) == (b == nullptr), NEF_E_NULL);
     NEF_REQUIRE(N > 0 && C > 0 && C <= OC_MAXC && L > 0 && (!a || Bp > 0), NEF_E_SHAPE);
+    if ((L & 3) == 0) {
+        const int tiles = (L + 1023) / 1024;
+        hipLaunchKernelGGL(outconv_fwd_kernel<true>, dim3((unsigned)((int64_t)N * tiles)), dim3(256), 0, NEF_ST, x, w, bias,
+                           out, N, C, L, tiles, a, b, a ? Bp : 1);
+        return nef_launch_status();
+    }
     const int tiles = (L + 255) / 256;
-    hipLaunchKernelGGL(outconv_fwd_kernel, dim3((unsigned)((int64_t)N * tiles)), dim3(256), 0, NEF_ST, x, w, bias, out,
-                       N, C, L, tiles, a, b, a ? Bp : 1);
+    hipLaunchKernelGGL(outconv_fwd_kernel<false>, dim3((unsigned)((int64_t)N * tiles)), dim3(256), 0, NEF_ST, x, w, bias,
+                       out, N, C, L, tiles, a, b, a ? Bp : 1);
     return nef_launch_status();
 }
 
