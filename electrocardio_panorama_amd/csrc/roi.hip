@@ -100,7 +100,7 @@ __global__ void roi_align_bwd_kernel(const float* __restrict__ gout, const int64
     }
 }
 
-struct SegTable { int start[NSEG]; int len[NSEG]; int off[NSEG]; };
+struct SegTable { int start[NSEG]; int len[NSEG]; int off[NSEG]; float scale[NSEG]; };
 
 __device__ __forceinline__ bool load_segments(const int64_t* __restrict__ roi_b, int T, SegTable& st) {
     int run = 0;
@@ -115,6 +115,7 @@ __device__ __forceinline__ bool load_segments(const int64_t* __restrict__ roi_b,
         st.start[j] = (int)a;
         st.len[j] = (int)len;
         st.off[j] = run;
+        st.scale[j] = len > 0 ? (float)SEGW / (float)(int)len : 0.f;      // F.interpolate's input/output ratio
         run += (int)len;
     }
     if (run != T) ok = false;
@@ -122,8 +123,7 @@ __device__ __forceinline__ bool load_segments(const int64_t* __restrict__ roi_b,
 }
 
 // F.interpolate(mode='linear', align_corners=False) source index for output i of a len-long segment
-__device__ __forceinline__ void lerp_src(int i, int len, int& i0, int& i1, float& l0, float& l1) {
-    const float scale = (float)SEGW / (float)len;
+__device__ __forceinline__ void lerp_src(int i, float scale, int& i0, int& i1, float& l0, float& l1) {
     float src = scale * ((float)i + 0.5f) - 0.5f;
     if (src < 0.f) src = 0.f;
     i0 = (int)src;
@@ -150,15 +150,16 @@ __global__ void roi_unpool_fwd_kernel(const float* __restrict__ zseg, const int6
         for (int t = lane; t < T; t += 64) {
             // the last segment whose offset is <= t (zero-length segments share an offset and are skipped)
             int j = 0, off_j = st.off[0], len_j = st.len[0];
+            float sc_j = st.scale[0];
 #pragma unroll
             for (int k = 1; k < NSEG; ++k)
-                if (t >= st.off[k]) { j = k; off_j = st.off[k]; len_j = st.len[k]; }
+                if (t >= st.off[k]) { j = k; off_j = st.off[k]; len_j = st.len[k]; sc_j = st.scale[k]; }
             float v = 0.f;
             const int i = t - off_j;
             if (i < len_j) {
                 int i0, i1;
                 float l0, l1;
-                lerp_src(i, len_j, i0, i1, l0, l1);
+                lerp_src(i, sc_j, i0, i1, l0, l1);
                 v = l0 * zr[j * SEGW + i0] + l1 * zr[j * SEGW + i1];
             }
             orow[t] = v;
@@ -180,9 +181,10 @@ __global__ void roi_unpool_bwd_kernel(const float* __restrict__ gout, const int6
         for (int e = lane; e < NSEG * SEGW; e += 64) {
             const int j = e / SEGW, s = e % SEGW;
             int len = st.len[0], off_j = st.off[0];
+            float sc = st.scale[0];
 #pragma unroll
             for (int k = 1; k < NSEG; ++k)
-                if (j == k) { len = st.len[k]; off_j = st.off[k]; }
+                if (j == k) { len = st.len[k]; off_j = st.off[k]; sc = st.scale[k]; }
             float acc = 0.f;
             if (len > 0) {
                 // outputs whose source lies in (s-1, s+1): i in ((s-.5)len/32 - .5, (s+1.5)len/32 - .5), widened by 2
@@ -195,7 +197,7 @@ __global__ void roi_unpool_bwd_kernel(const float* __restrict__ gout, const int6
                 for (int i = lo; i <= hi; ++i) {
                     int i0, i1;
                     float l0, l1;
-                    lerp_src(i, len, i0, i1, l0, l1);
+                    lerp_src(i, sc, i0, i1, l0, l1);
                     const float g = gr[off_j + i];
                     if (i0 == s) acc += l0 * g;
                     if (i1 == s) acc += l1 * g;
