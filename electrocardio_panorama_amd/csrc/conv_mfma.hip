@@ -357,9 +357,24 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
     float* GYl = smem;               // [MT][GYS]
     float* Xl = smem + MT * GYS;     // [CIT][XS]
 
+    // Workgroup -> (unit, ci chunk).  The ci chunks of one unit read the SAME gY tiles; workgroup ids go round-robin over
+    // the 8 XCDs (each with its own L2), so the chunks of a unit are placed 8 ids apart: same XCD, dispatched together,
+    // and all but the first find the gY tiles in that L2.
     int bid = blockIdx.x;
-    const int cc = bid % ci_chunks;
-    bid /= ci_chunks;
+    int cc;
+    {
+        const int units = (int)gridDim.x / ci_chunks;
+        const int full = (units / 8) * 8 * ci_chunks;          // ids covered by whole groups of 8 units
+        if (bid < full) {
+            const int grp = bid / (8 * ci_chunks), r = bid % (8 * ci_chunks);
+            cc = r / 8;
+            bid = grp * 8 + (r % 8);
+        } else {
+            const int r = bid - full;
+            cc = r % ci_chunks;
+            bid = (units / 8) * 8 + r / ci_chunks;
+        }
+    }
     const int mt = bid % m_tiles;
     bid /= m_tiles;
     const int g = bid % G;
