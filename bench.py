@@ -162,7 +162,9 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath) and (V, B, L) == (3, 256, 5000):     # PMC pass was taken at configs[1] only
                 traffic = json.load(open(tpath)).get("conv_fwd_k7_bytes_per_launch")
-            alg_bytes = 4.0 * (2 * B * 128 * V * T + 128 * V * 128 * 7)
+            # forward launches: conv1 of a block reads x and writes h; conv2 reads h AND the residual x, writes y
+            act = 4.0 * B * 128 * V * T
+            alg_bytes = ((2 * act) + (3 * act)) / 2 + 4.0 * 128 * V * 128 * 7
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "kernel": "conv_fwd_kernel<7,2> (k7 grouped conv), forward launches", "launches": len(times),

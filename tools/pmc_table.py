@@ -1,0 +1,64 @@
+"""profiles/r01_pmc_traffic.md + profiles/traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of
+`python bench.py --steps 1 --warmup 1 --no-cpu-baseline` (2 steps).
+
+    python tools/pmc_table.py <fetch.db> <write.db> <out.md> <traffic.json>
+
+HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: on gfx950 FETCH_SIZE counts half of the bytes read (MI355X guide);
+re-checked in every run on `bn_stats_partial`, a pure streaming read whose traffic is known (numel x 4 bytes).
+"""
+import json
+import sqlite3
+import sys
+
+fetch_db, write_db, out_md, out_json = sys.argv[1:5]
+
+
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+def per_dispatch(path, counter):
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select dispatch_id, kernel_name, grid_size, sum(value) from counters_collection where counter_name=? "
+                       "group by dispatch_id order by dispatch_id", (counter,)).fetchall()
+    return [(short(n), g, v) for _, n, g, v in rows]
+
+
+F, W = per_dispatch(fetch_db, "FETCH_SIZE"), per_dispatch(write_db, "WRITE_SIZE")
+assert [x[:2] for x in F] == [x[:2] for x in W], "the two passes must launch the same kernel sequence"
+stats = {}
+for (n, g, f), (_, _, w) in zip(F, W):
+    stats.setdefault(n, []).append((f, w))
+# calibration: bn_stats_partial over the [768,128,2500] and [768,64,5000] conv outputs reads exactly 983,040,000 bytes
+cal = [f for (n, g, f) in F if n == "bn_stats_partial"]
+cal_ratio = (sum(cal) / len(cal)) * 1024 / 983040000.0 if cal else float("nan")
+# dominant kernel, forward launches only: the first 6 launches of each step are the encoder's forward convs
+k7 = [(f, w) for (n, g, f), (_, _, w) in zip(F, W) if n.startswith("conv_fwd_kernel<7")]
+per_step = len(k7) // 2
+fwd = k7[0:6] + k7[per_step:per_step + 6]
+fwd_bytes = sum((2 * f + w) * 1024 for f, w in fwd) / len(fwd)
+all_bytes = sum((2 * f + w) * 1024 for f, w in k7) / len(k7)
+with open(out_md, "w") as fh:
+    fh.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1, config 2 "
+             "(B=256,V=3,L=5000)\n\n")
+    fh.write("Counter unit: KB per dispatch.  HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- gfx950's FETCH_SIZE counts\n"
+             "half of the bytes read (MI355X guide).  Calibration in this run: `bn_stats_partial` streams 983,040,000 bytes\n"
+             f"per launch and FETCH_SIZE x 1024 reads {cal_ratio:.3f} of that.  Fabric-side counters: hits in the memory-side\n"
+             "cache (MALL) are counted like HBM reads, so these are upper bounds on DRAM traffic.\n\n")
+    fh.write(f"Dominant kernel `conv_fwd_kernel<7,2,0>`: forward launches (6 per step: 3 read x, 3 read x + residual; "
+             f"algorithmic 0.984 / 1.476 GB) move {fwd_bytes/1e9:.3f} GB per launch on average; all 12 launches per step "
+             f"(forward + backward-data, which also read a gate or residual operand) {all_bytes/1e9:.3f} GB.\n\n")
+    fh.write("| kernel | launches | FETCH_SIZE avg (min..max) KB | WRITE_SIZE avg (min..max) KB | corrected bytes/launch (GB) |\n"
+             "|---|---:|---:|---:|---:|\n")
+    order = sorted(stats.items(), key=lambda kv: -sum((2 * f + w) for f, w in kv[1]))
+    for n, v in order:
+        fs, ws = [f for f, _ in v], [w for _, w in v]
+        gb = sum((2 * f + w) * 1024 for f, w in v) / len(v) / 1e9
+        fh.write(f"| `{n}` | {len(v)} | {sum(fs)/len(fs):.0f} ({min(fs):.0f}..{max(fs):.0f}) | "
+                 f"{sum(ws)/len(ws):.0f} ({min(ws):.0f}..{max(ws):.0f}) | {gb:.3f} |\n")
+json.dump({"conv_fwd_k7_bytes_per_launch": int(fwd_bytes), "conv_fwd_k7_bytes_per_launch_all": int(all_bytes),
+           "algorithmic_bytes_per_forward_launch": int((3 * 984416256 + 3 * 1475936256) / 6),
+           "note": "round 1: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, mean over the forward launches of conv_fwd_kernel<7,2,0> "
+                   "(the launches bench.py times for roofline.achieved); see profiles/r01_pmc_traffic.md"},
+          open(out_json, "w"), indent=1)
+print(open(out_md).read()[:1800])
