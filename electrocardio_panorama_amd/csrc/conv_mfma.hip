@@ -21,6 +21,19 @@ constexpr int WT = 64;    // bwd-weight: reduction columns per staged tile
 
 template <int K> struct StageK;
 template <> struct StageK<7> { static constexpr int KC = 16; };
+// Forward stage size per (K, TM).  The 128-row K=7 kernel stages 8 channels at a time: 34 KB of LDS and 162 VGPRs put 3
+// workgroups on a CU instead of 2, so one more workgroup's MFMA stream covers the others' barriers and epilogues:
+// 126.7 -> 133.1 TFLOP/s on the encoder convs (80.5 -> 84.6 % of the fp32 matrix peak).  The 64-row variants cannot
+// split an 8-channel weight tile evenly over 256 threads and keep 16.  The 128-row K=3 kernels take 8 as well (-0.4 ms).
+#ifndef NEF_K7_KC
+#define NEF_K7_KC 8
+#endif
+#ifndef NEF_K3_KC2
+#define NEF_K3_KC2 8
+#endif
+template <int K, int TM> struct FwdStage {
+    static constexpr int KC = (K == 7 && TM == 2) ? NEF_K7_KC : (K == 3 && TM == 2) ? NEF_K3_KC2 : StageK<K>::KC;
+};
 // K=3: 16-channel stages keep the kernel at <= 168 VGPRs and 34 KB of LDS -> 3 workgroups per CU (the per-tile fixed
 // costs of these short-K convs then overlap across workgroups): -2.3 % step time against 32-channel stages.
 template <> struct StageK<3> { static constexpr int KC = 16; };
@@ -61,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
                                                          int n_tiles, int m_tiles) {
     constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
     constexpr int NS = UP ? 2 : 1;
-    constexpr int KC = StageK<K>::KC;
+    constexpr int KC = FwdStage<K, TM>::KC;
     constexpr int MT = 64 * TM;
     constexpr int PAD = (K - 1) / 2;
     constexpr int XRS = NT + (NT / 16) * (K - 1);
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
 
 template <int K, int TM, int PRO = 0>
 static int launch_conv_fwd(const nef_conv_args& a, hipStream_t st) {
-    constexpr int KC = StageK<K>::KC;
+    constexpr int KC = FwdStage<K, TM>::KC;
     constexpr int MT = 64 * TM;
     constexpr int XRS = NT + (NT / 16) * (K - 1);
     constexpr size_t lds = (size_t)(K * KC * MT + KC * XRS) * sizeof(float);
