@@ -221,7 +221,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
         // MFMA loop, software-pipelined in registers: the LDS fragments of k-step group gi+1 are read while the
         // MFMAs of group gi issue (fully unrolled, so every register index is static), one ds_read per MFMA slot.
         {
-            constexpr int GS = 4;                       // k-steps (of 2 channels) per group
+#ifndef NEF_GS
+#define NEF_GS 2
+#endif
+            constexpr int GS = NEF_GS;                  // k-steps (of 2 channels) per group
             constexpr int SPK = KC / 2;                 // k-steps per tap
             constexpr int NG = K * SPK / GS;
             static_assert((K * SPK) % GS == 0, "k-steps must split into whole groups");
