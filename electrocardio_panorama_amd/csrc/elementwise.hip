@@ -51,6 +51,18 @@ __global__ void gate_kernel(const float* __restrict__ g, const float* __restrict
         out[i] = ref[i] > 0.f ? g[i] * scale : 0.f;
 }
 
+// 16-byte version (n % 4 == 0, pointers 16-byte aligned)
+__global__ void gate4_kernel(const nef_f32x4* __restrict__ g, const nef_f32x4* __restrict__ ref,
+                             nef_f32x4* __restrict__ out, float scale, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const nef_f32x4 gv = g[i], rv = ref[i];
+        nef_f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rv[e] > 0.f ? gv[e] * scale : 0.f;
+        out[i] = o;
+    }
+}
+
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                            int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -947,6 +959,11 @@ int nef_gate(const float* g, const float* ref, float* out, float scale, int64_t 
     NEF_ENTER();
     NEF_REQUIRE(g && ref && out, NEF_E_NULL);
     NEF_REQUIRE(n > 0, NEF_E_SHAPE);
+    if ((n & 3) == 0 && (((uintptr_t)g | (uintptr_t)ref | (uintptr_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(gate4_kernel, dim3(nef_stream_grid(n >> 2, 256)), dim3(256), 0, NEF_ST, (const nef_f32x4*)g,
+                           (const nef_f32x4*)ref, (nef_f32x4*)out, scale, n >> 2);
+        return nef_launch_status();
+    }
     hipLaunchKernelGGL(gate_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, g, ref, out, scale, n);
     return nef_launch_status();
 }
