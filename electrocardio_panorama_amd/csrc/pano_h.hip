@@ -27,7 +27,7 @@
 //   epilogue: + bias, ReLU, -> fp16, transposed through LDS (over the X chunk, 64 channels per pass) so that every
 //             output row leaves as 16-byte vectors
 //   OUT=1   : the 64->64 layer also evaluates the last conv (64 -> 1) on its staged tile (see below)
-// Measured (MI355X, BASELINE config 4: 1024 samples x 360 angles, len 512): 62 ms per sweep against 400 ms on the fp32
+// Measured (MI355X, BASELINE config 4: 1024 samples x 360 angles, len 512): 62 ms per sweep against 377 ms on the fp32
 // path; per 4096 pairs L1 250 us (0.82 PFLOP/s), L2 126 us (4.2 TB/s), L3 150 us, L4 + last conv 80 us.  PMC on L2:
 // matrix pipes busy 36 % of SIMD cycles at an effective 1.5 GHz, 31 % of wave time waiting on memory -- the layer-wise
 // pipeline is within 25 % of its HBM floor; the next step is keeping c1 / c3 on chip (layer pairs fused).
