@@ -106,8 +106,8 @@ def _train_once(V, B, L, seed, reg, masked):
 
 # Gradient bars.  A backward pass through ReLU is discontinuous: when a pre-activation lands within fp32 round-off of
 # zero, the HIP path and the CPU reference can legitimately pick different sides, and at these tiny test shapes ONE such
-# tie among ~2e5 activations moves the whole flat gradient by 2e-4 .. 1.3e-3 (measured with tools/debug_tie.py: 2e-4 on
-# the 3-lead fixture, 1.3e-3 on the 5-lead case of test_every_supported_lead_count_vs_oracle, where the single
+# tie among ~2e5 activations moves the whole flat gradient by 2e-4 .. 1.3e-3 (2e-4 was measured on the 3-lead
+# fixture before the decoder fusion; tools/debug_tie.py shows 1.3e-3 on the 5-lead case of test_every_supported_lead_count_vs_oracle, where the single
 # differing sign sits on a BatchNorm output of 1.9e-6 against a mean magnitude of 0.79).  So every case must stay under
 # LOOSE, and most cases -- the tie-free ones -- must sit at fp32 round-off (TIGHT).
 TIGHT, LOOSE = 2e-5, 3e-3
