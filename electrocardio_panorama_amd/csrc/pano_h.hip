@@ -31,8 +31,6 @@
 // path; per 4096 pairs L1 250 us (0.82 PFLOP/s), L2 126 us (4.2 TB/s), L3 150 us, L4 + last conv 80 us.  PMC on L2:
 // matrix pipes busy 36 % of SIMD cycles at an effective 1.5 GHz, 31 % of wave time waiting on memory -- the layer-wise
 // pipeline is within 25 % of its HBM floor; the next step is keeping c1 / c3 on chip (layer pairs fused).
-#include <stdlib.h>
-
 #include "nef_common.h"
 
 typedef _Float16 nef_h8 __attribute__((ext_vector_type(8)));
@@ -387,309 +385,6 @@ __global__ __launch_bounds__(256) void ph_outconv_kernel(const _Float16* __restr
 // ------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------
-
-// ============================================================================================================
-// hconv2_kernel: the same implicit GEMM with PRODUCER / CONSUMER waves.  Ablations of hconv_kernel showed the matrix
-// pipes idle two thirds of the time: fetch -> LDS -> barrier -> 48 MFMAs is one dependent chain per workgroup.  Here a
-// workgroup has 8 waves: waves 0-3 only read fragments and issue MFMAs (and write results), waves 4-7 only move data --
-// the next (tile, chunk)'s activation rows and weights from memory through registers (upsample blend / query scaling
-// applied on the way) into the other half of a double-buffered LDS stage.  One barrier per chunk hands a stage over.
-//   LDS: 2 x (X chunk + 3 weight stages) + per-producer-wave blend scratch + per-consumer-wave 16-row output staging
-//        (<= 154 KB -> one workgroup per CU: one MFMA wave and one mover wave per SIMD)
-//   producers split the X rows of a chunk into four contiguous ranges, one per wave, so the blend scratch and its
-//   synchronisation are wave-local; consumers stage their own 64 x 64 output tile 16 rows at a time, wave-local too.
-// ============================================================================================================
-template <int CIN, int COUT, int PRO, int OUT>
-__global__ __launch_bounds__(512, 1) void hconv2_kernel(const _Float16* __restrict__ x, const nef_h8* __restrict__ wp,
-                                                        const float* __restrict__ bias, const float* __restrict__ scale,
-                                                        _Float16* __restrict__ y, int T, int tiles_per_n, int total_tiles,
-                                                        int x_div, int nq, long sc_bs, long sc_is,
-                                                        const float* __restrict__ wout, float* __restrict__ logit,
-                                                        long out_bs, long out_is) {
-    static_assert(!OUT || (COUT == 64 && PRO == 0), "the fused last conv rides on the 64-channel layer");
-    constexpr int WM = COUT / 64, WN = 4 / WM, NT = WN * 64, MT = COUT / 32;
-    constexpr int XROWS = NT + 2;
-    constexpr int XBYTES = XROWS * PH_XRS;
-    constexpr int WST_V = COUT * 64 / 8;          // h8 vectors per weight stage (one tap of a 64-channel chunk)
-    constexpr int WCH_V = 3 * WST_V;              // ... per chunk
-    constexpr int BUF = XBYTES + WCH_V * 16;
-    constexpr int NCC = CIN / 64;
-    constexpr int PR = (XROWS + 3) / 4;           // up-rows per producer wave
-    constexpr int SRW = (PRO & 2) ? PR / 2 + 3 : 0;   // source rows a producer wave needs for them
-    constexpr int SCR = SRW * PH_XRS;
-    constexpr int STG = 16 * PH_XRS;
-    constexpr int XLD = (PRO & 2) ? (SRW * 8 + 63) / 64 : (PR * 8 + 63) / 64;   // X loads per producer lane and chunk
-    constexpr int XBL = (PR * 8 + 63) / 64;       // blend / copy items per producer lane and chunk
-    constexpr int WLD = WCH_V / 256;              // weight loads per producer lane and chunk
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* scr_base = smem + 2 * BUF;
-    char* stg_base = scr_base + 4 * SCR;
-    float* Ol = (float*)(stg_base + 4 * STG);     // OUT: wout[192], then per consumer wave lg[66]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Tin = (PRO & 2) ? T / 2 : T;
-    const int my_tiles = (int)blockIdx.x < total_tiles ? (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    const int G = my_tiles * NCC;                 // (tile, chunk) items of this workgroup
-    if (OUT && tid < 192) Ol[tid] = wout[tid];
-
-    if (wave >= 4) {
-        // ------------------------------------------------------------------ producers
-        const int pw = wave - 4, ptid = tid - 256;
-        const int seg = lane & 7;
-        char* Scr = scr_base + pw * SCR;
-        const __amdgpu_buffer_rsrc_t wd = nef_rsrc(wp);
-        // two register sets: the chunks at distance 1 and 2 are both in flight (set = chunk parity)
-        nef_h8 wreg0[WLD], xr0[XLD], wreg1[WLD], xr1[XLD];
-        float qr0[8], qr1[8];
-        nef_h8 hzero;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) hzero[e] = (_Float16)0.f;
-        const int r0 = pw * PR;                   // first up-row of this wave
-        int t0_ld0 = 0, smin_ld0 = 0, t0_ld1 = 0, smin_ld1 = 0;   // tile origin / first fetched row, per set
-        bool wload0 = true, wload1 = true;
-
-#define PH2_ISSUE(h_, S)                                                                                       \
-        {                                                                                                     \
-            const int tile_ = (int)blockIdx.x + ((h_) / NCC) * (int)gridDim.x, cc_ = (h_) % NCC;              \
-            const int n_ = tile_ / tiles_per_n;                                                               \
-            t0_ld##S = (tile_ % tiles_per_n) * NT;                                                            \
-            wload##S = (NCC > 1) || (h_) < 2;     /* a single chunk's weights only fill the two buffers once */ \
-            if (wload##S) {                                                                                   \
-                _Pragma("unroll") for (int j = 0; j < WLD; ++j) wreg##S[j] = __builtin_bit_cast(              \
-                    nef_h8, __builtin_amdgcn_raw_buffer_load_b128(wd, ptid * 16, cc_ * (WCH_V * 16) + j * 4096, 0)); \
-            }                                                                                                 \
-            const __amdgpu_buffer_rsrc_t xd_ = __builtin_amdgcn_make_buffer_rsrc(                             \
-                const_cast<_Float16*>(x + (size_t)(n_ / x_div) * Tin * CIN), 0, Tin * CIN * 2, 0x00020000);   \
-            /* first row fetched: source resolution when upsampling */                                        \
-            smin_ld##S = (PRO & 2) ? ((t0_ld##S - 1 + r0) >> 1) - 1 : t0_ld##S - 1 + r0;                      \
-            _Pragma("unroll") for (int j = 0; j < XLD; ++j) {                                                 \
-                const int it = lane + 64 * j, k = it >> 3;                                                    \
-                const bool live = (PRO & 2) ? (k < SRW) : (k < PR && r0 + k < XROWS);                         \
-                const unsigned o_ = live ? (unsigned)(((smin_ld##S + k) * CIN + cc_ * 64 + seg * 8) * 2) : NEF_OOB; \
-                xr##S[j] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(xd_, (int)o_, 0, 0)); \
-            }                                                                                                 \
-            if (PRO & 1) {                                                                                    \
-                const float* sc_ = scale + (size_t)(n_ / nq) * sc_bs + (size_t)(n_ % nq) * sc_is + cc_ * 64;  \
-                const __amdgpu_buffer_rsrc_t sd_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sc_), 0, 256, 0x00020000); \
-                const nef_f32x4 q0_ = nef_buf_f32x4(sd_, seg * 32, 0), q1_ = nef_buf_f32x4(sd_, seg * 32 + 16, 0); \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) { qr##S[e] = q0_[e]; qr##S[4 + e] = q1_[e]; }   \
-            }                                                                                                 \
-        }
-        // registers of set S -> LDS stage `b_`
-#define PH2_STORE(b_, S)                                                                                       \
-        {                                                                                                     \
-            char* Xb = smem + (b_) * BUF;                                                                     \
-            nef_h8* Wb = (nef_h8*)(Xb + XBYTES);                                                              \
-            if (wload##S) {                                                                                   \
-                _Pragma("unroll") for (int j = 0; j < WLD; ++j) Wb[ptid + j * 256] = wreg##S[j];              \
-            }                                                                                                 \
-            if (PRO & 2) {                                                                                    \
-                _Pragma("unroll") for (int j = 0; j < XLD; ++j) {                                             \
-                    const int it = lane + 64 * j;                                                             \
-                    if ((it >> 3) < SRW) *(nef_h8*)(Scr + (it >> 3) * PH_XRS + seg * 16) = xr##S[j];          \
-                }                                                                                             \
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                        \
-                __builtin_amdgcn_wave_barrier();                                                              \
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                        \
-                nef_h8 qh, c75;                                                                               \
-                _Pragma("unroll") for (int e = 0; e < 8; ++e) { qh[e] = (PRO & 1) ? (_Float16)qr##S[e] : (_Float16)1.f; c75[e] = (_Float16)0.75f; } \
-                _Pragma("unroll") for (int j = 0; j < XBL; ++j) {                                             \
-                    const int it = lane + 64 * j, k = it >> 3, r = r0 + k, t = t0_ld##S - 1 + r;              \
-                    if (k < PR && r < XROWS) {                                                                \
-                        nef_h8 v = hzero;                                                                     \
-                        if (t >= 0 && t < T) {                                                                \
-                            const int i = t >> 1;                                                             \
-                            const int jn = (t == 0 || t == T - 1) ? i : ((t & 1) ? i + 1 : i - 1);            \
-                            const nef_h8 a = *(const nef_h8*)(Scr + (i - smin_ld##S) * PH_XRS + seg * 16);    \
-                            const nef_h8 bq = *(const nef_h8*)(Scr + (jn - smin_ld##S) * PH_XRS + seg * 16);  \
-                            v = __builtin_elementwise_fma(a, c75, bq * (_Float16)0.25f);                      \
-                            if (PRO & 1) v = v * qh;                                                          \
-                        }                                                                                     \
-                        *(nef_h8*)(Xb + r * PH_XRS + seg * 16) = v;                                           \
-                    }                                                                                         \
-                }                                                                                             \
-                __builtin_amdgcn_wave_barrier();      /* scratch is rewritten by this wave's next chunk */     \
-            } else {                                                                                          \
-                _Pragma("unroll") for (int j = 0; j < XLD; ++j) {                                             \
-                    const int it = lane + 64 * j, k = it >> 3, r = r0 + k;                                    \
-                    nef_h8 v = xr##S[j];                                                                      \
-                    if (PRO & 1) {                                                                            \
-                        _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] * qr##S[e]); \
-                    }                                                                                         \
-                    if (k < PR && r < XROWS) *(nef_h8*)(Xb + r * PH_XRS + seg * 16) = v;                      \
-                }                                                                                             \
-            }                                                                                                 \
-        }
-        if (G > 0) PH2_ISSUE(0, 0)
-        if (G > 1) PH2_ISSUE(1, 1)
-        if (G > 0) PH2_STORE(0, 0)
-        if (G > 2) PH2_ISSUE(2, 0)
-        __syncthreads();                          // stage 0 ready
-        // iteration g: stage chunk g+1 (set (g+1)&1) into buffer (g+1)&1, then refill that set with chunk g+3
-#pragma unroll 1
-        for (int g = 0; g < G; g += 2) {
-            if (g + 1 < G) {
-                PH2_STORE(1, 1)
-                if (g + 3 < G) PH2_ISSUE(g + 3, 1)
-            }
-            __syncthreads();                      // consumers are done with stage 0, stage 1 is complete
-            if (g + 1 < G) {
-                if (g + 2 < G) {
-                    PH2_STORE(0, 0)
-                    if (g + 4 < G) PH2_ISSUE(g + 4, 0)
-                }
-                __syncthreads();
-            }
-        }
-#undef PH2_ISSUE
-#undef PH2_STORE
-        return;
-    }
-
-    // ---------------------------------------------------------------------- consumers
-    const int wm = wave % WM, wn = wave / WM;
-    const int brow = wn * 64 + (lane & 31);
-    const int bcol = 16 * (lane >> 5);
-    char* Stg = stg_base + wave * STG;
-    float* lg = Ol + 192 + wave * 66;
-    nef_f16acc acc[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    nef_f32x4 bvr[2][4];                          // this lane's bias values, fetched once
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) bvr[mi][gq] = *(const nef_f32x4*)(bias + wm * 64 + mi * 32 + 8 * gq + 4 * (lane >> 5));
-    __syncthreads();                              // stage 0 ready
-#pragma unroll 1
-    for (int g = 0; g < G; ++g) {
-        const char* Xb = smem + (g & 1) * BUF;
-        const nef_h8* Wb = (const nef_h8*)(Xb + XBYTES);
-        // 12 k-steps (3 taps x 4) software-pipelined in registers: the fragments of step s+1 are read from LDS while the
-        // MFMAs of step s issue -- this wave is alone on its SIMD's matrix pipe, nobody else hides its LDS latency
-        {
-            nef_h8 fa[2][2], fb[2][2];
-#define PH2_FRAGS(S_, BUF_)                                                                                    \
-    {                                                                                                         \
-        const int tap_ = (S_) >> 2, kq_ = (S_) & 3;                                                           \
-        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                      \
-            fa[BUF_][mi] = Wb[tap_ * WST_V + (kq_ * MT + wm * 2 + mi) * 64 + lane];                           \
-        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                      \
-            fb[BUF_][ni] = *(const nef_h8*)(Xb + (brow + tap_ + ni * 32) * PH_XRS + bcol + kq_ * 32);         \
-    }
-            PH2_FRAGS(0, 0)
-#pragma unroll
-            for (int st = 0; st < 12; ++st) {
-                if (st + 1 < 12) PH2_FRAGS(st + 1, (st + 1) & 1)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st & 1][mi], fb[st & 1][ni], acc[mi][ni],
-                                                                             0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {         // interleave: one MFMA, one LDS read
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            }
-#undef PH2_FRAGS
-        }
-        if (g % NCC == NCC - 1) {
-            // epilogue of this wave's 64 co x 64 t tile, 16 time rows at a time through its own staging rows
-            const int tile = (int)blockIdx.x + (g / NCC) * (int)gridDim.x;
-            const int n = tile / tiles_per_n, t0 = (tile % tiles_per_n) * NT + wn * 64;
-            _Float16* yb = y + (size_t)n * T * COUT + wm * 64;
-            if (OUT) {
-                lg[lane] = 0.f;
-                if (lane < 2) lg[64 + lane] = 0.f;
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int ni = p >> 1, half = p & 1;
-                if (((lane >> 4) & 1) == half) {
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            const int cw = mi * 32 + 8 * gq + 4 * (lane >> 5);
-                            const nef_f32x4 bv = bvr[mi][gq];
-                            nef_h4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (_Float16)fmaxf(acc[mi][ni][gq * 4 + e] + bv[e], 0.f);
-                            *(nef_h4*)(Stg + (lane & 15) * PH_XRS + cw * 2) = o;
-                        }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (!OUT) {
-#pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        const int idx = lane + 64 * it, row = idx >> 3, sg = idx & 7;
-                        const int t = t0 + p * 16 + row;
-                        if (t < T) *(nef_h8*)(yb + (size_t)t * COUT + sg * 8) = *(const nef_h8*)(Stg + row * PH_XRS + sg * 16);
-                    }
-                } else {
-                    // last conv (64 -> 1, k3) on the staged rows: 4 lanes per row, 16 channels each
-                    const int row = lane >> 2, qd = lane & 3;
-                    const int t = t0 + p * 16 + row;
-                    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const nef_h8 v = *(const nef_h8*)(Stg + row * PH_XRS + (qd * 2 + hh) * 16);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float f = (float)v[e];
-                            const float* wc = Ol + ((qd * 2 + hh) * 8 + e) * 3;
-                            d0 = fmaf(wc[0], f, d0);
-                            d1 = fmaf(wc[1], f, d1);
-                            d2 = fmaf(wc[2], f, d2);
-                        }
-                    }
-                    d0 += __shfl_xor(d0, 1, 64); d0 += __shfl_xor(d0, 2, 64);
-                    d1 += __shfl_xor(d1, 1, 64); d1 += __shfl_xor(d1, 2, 64);
-                    d2 += __shfl_xor(d2, 1, 64); d2 += __shfl_xor(d2, 2, 64);
-                    if (t >= T) d0 = d1 = d2 = 0.f;
-                    const int R = p * 16 + row;       // row inside the wave tile; lg[1 + R]
-                    // three ordered sub-steps (distinct addresses within each): a fixed summation order per column
-                    if (qd == 0) lg[1 + R] += d1;
-                    __builtin_amdgcn_wave_barrier();
-                    if (qd == 0) lg[2 + R] += d0;     // tap 0 of row R feeds column R+1
-                    __builtin_amdgcn_wave_barrier();
-                    if (qd == 0) lg[R] += d2;         // tap 2 of row R feeds column R-1
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            if (OUT) {
-                float* lgl = logit + (size_t)(n / nq) * out_bs + (size_t)(n % nq) * out_is;
-                const int t = t0 + lane;
-                if (t < T) {
-                    const float v = lg[1 + lane];
-                    if (lane == 0 || lane == 63) atomicAdd(lgl + t, v);
-                    else lgl[t] = v;
-                }
-                if (lane == 0 && t0 > 0) atomicAdd(lgl + t0 - 1, lg[0]);
-                if (lane == 63 && t0 + 64 < T) atomicAdd(lgl + t0 + 64, lg[65]);
-                __builtin_amdgcn_wave_barrier();
-            }
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        }
-        __syncthreads();                          // hand stage g&1 back to the producers
-    }
-}
-
 // zero the tile-edge columns the fused kernel accumulates into (t = k*NT and k*NT + NT-1)
 __global__ void ph_zero_edges_kernel(float* __restrict__ logit, int N, int T, int NT, int tiles_per_n, int nq,
                                      long out_bs, long out_is) {
@@ -744,40 +439,6 @@ static int launch_hconv(const void* x, const void* wp, const float* bias, const 
     return nef_launch_status();
 }
 
-
-template <int CIN, int COUT, int PRO, int OUT = 0>
-static int launch_hconv2(const void* x, const void* wp, const float* bias, const float* scale, void* y, int N, int T,
-                         int x_div, int nq, long sc_bs, long sc_is, hipStream_t st, const float* wout = nullptr,
-                         float* logit = nullptr, long out_bs = 0, long out_is = 0) {
-    constexpr int NT = (4 / (COUT / 64)) * 64;
-    constexpr int XROWS = NT + 2, PR = (XROWS + 3) / 4, SRW = (PRO & 2) ? PR / 2 + 3 : 0;
-    constexpr int BUF = XROWS * PH_XRS + 3 * (COUT * 64 / 8) * 16;
-    constexpr int LDS = 2 * BUF + 4 * SRW * PH_XRS + 4 * 16 * PH_XRS + (OUT ? (192 + 4 * 66) * 4 : 0);
-    static_assert(LDS <= 160 * 1024, "one workgroup must fit a CU's LDS");
-    const int tiles = (T + NT - 1) / NT;
-    const int64_t total = (int64_t)N * tiles;
-    if (total > 0x7FFFFFFF) return NEF_E_SHAPE;
-    auto k = hconv2_kernel<CIN, COUT, PRO, OUT>;
-    static int resident = 0;
-    if (resident == 0) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        int dev = 0, cus = 0;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
-        resident = cus;
-    }
-    const int grid = (int)(total < resident ? total : resident);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS, st, (const _Float16*)x, (const nef_h8*)wp, bias, scale,
-                       (_Float16*)y, T, tiles, (int)total, x_div, nq, sc_bs, sc_is, wout, logit, out_bs, out_is);
-    return nef_launch_status();
-}
-
-static bool pano_v2() {
-    static const int v = getenv("NEF_PANO_V2") ? atoi(getenv("NEF_PANO_V2")) : 0;
-    return v != 0;
-}
-
 extern "C" {
 
 int nef_pano_h_from_f32(const float* x, void* y, int B, int C, int T, nef_stream_t stream) {
@@ -809,8 +470,7 @@ int nef_pano_h_conv(const void* x, const void* wp, const float* bias, const floa
     hipStream_t st = (hipStream_t)stream;
 #define PH_CASE(ci, co, pro) \
     if (Cin == ci && Cout == co && pro_mode == pro) \
-        return pano_v2() ? launch_hconv2<ci, co, pro>(x, wp, bias, scale, y, N, T, x_div, nq, sc_bs, sc_is, st) \
-                         : launch_hconv<ci, co, pro>(x, wp, bias, scale, y, N, T, x_div, nq, sc_bs, sc_is, st)
+        return launch_hconv<ci, co, pro>(x, wp, bias, scale, y, N, T, x_div, nq, sc_bs, sc_is, st)
     PH_CASE(256, 128, 3);
     PH_CASE(256, 128, 1);
     PH_CASE(128, 128, 0);
@@ -827,16 +487,14 @@ int nef_pano_h_conv_outconv(const void* x, const void* wp, const float* bias, co
     NEF_REQUIRE(x && wp && bias && wout && bout && out, NEF_E_NULL);
     NEF_REQUIRE(N > 0 && T > 0 && nq > 0, NEF_E_SHAPE);
     hipStream_t st = (hipStream_t)stream;
-    const int NT = pano_v2() ? 64 : 256;     // span whose edge columns are completed by a neighbour
+    const int NT = 256;                      // tile width of the 64-channel layer
     const int tiles = (T + NT - 1) / NT;
     hipLaunchKernelGGL(ph_zero_edges_kernel, dim3(nef_stream_grid((int64_t)N * tiles * 2, 256)), dim3(256), 0, st, out, N,
                        T, NT, tiles, nq, (long)out_bs, (long)out_is);
     int rc = nef_launch_status();
     if (rc != NEF_OK) return rc;
-    rc = pano_v2() ? launch_hconv2<64, 64, 0, 1>(x, wp, bias, nullptr, nullptr, N, T, 1, nq, 0, 0, st, wout, out,
-                                                 (long)out_bs, (long)out_is)
-                   : launch_hconv<64, 64, 0, 1>(x, wp, bias, nullptr, nullptr, N, T, 1, nq, 0, 0, st, wout, out,
-                                                (long)out_bs, (long)out_is);
+    rc = launch_hconv<64, 64, 0, 1>(x, wp, bias, nullptr, nullptr, N, T, 1, nq, 0, 0, st, wout, out, (long)out_bs,
+                                    (long)out_is);
     if (rc != NEF_OK) return rc;
     hipLaunchKernelGGL(ph_sigmoid3_kernel, dim3(nef_stream_grid((int64_t)N * T, 256)), dim3(256), 0, st, out, bout, N, T,
                        nq, (long)out_bs, (long)out_is);
