@@ -454,10 +454,37 @@ __global__ void affine_relu_fwd_kernel(const float* __restrict__ x, const float*
 }
 
 // backward reductions per (pass, channel): s1 = sum g, s2 = sum g * xhat, g = gy * [x*a+b > 0]
+// go = gout * out * (1 - out) / 3: the gradient at the last conv's pre-activation (sigmoid(x/3), model_nefnet.py:168)
+__global__ void outconv_go_kernel(const float* __restrict__ gout, const float* __restrict__ out, float* __restrict__ go,
+                                  int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float o = out[i];
+        go[i] = gout[i] * (o * (1.f - o)) / 3.0f;
+    }
+}
+
+// Four consecutive values of g[c][t] = w[c][0]*go[t+1] + w[c][1]*go[t] + w[c][2]*go[t-1] (the input gradient of the last
+// conv, same expression as outconv_bwd_data_kernel) from one go row, so that BatchNorm-backward can read the small go
+// instead of a materialised [N][64][L] gradient.
+__device__ __forceinline__ nef_f32x4 oc_grad4(const float* __restrict__ gor, int t4, int L, float w0, float w1, float w2) {
+    const nef_f32x4 m = *(const nef_f32x4*)(gor + 4 * t4);
+    const float lo = t4 > 0 ? gor[4 * t4 - 1] : 0.f;
+    const float hi = 4 * t4 + 4 < L ? gor[4 * t4 + 4] : 0.f;
+    nef_f32x4 g;
+    g[0] = w0 * m[1] + w1 * m[0] + w2 * lo;
+    g[1] = w0 * m[2] + w1 * m[1] + w2 * m[0];
+    g[2] = w0 * m[3] + w1 * m[2] + w2 * m[1];
+    g[3] = w0 * hi + w1 * m[3] + w2 * m[2];
+    return g;
+}
+
+// OC: `gy` is the go tensor [P*Bp][L] of the last conv and `ocw` its weight [C][3]; g is rebuilt on the fly (L % 4 == 0)
+template <bool OC>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ gy, const float* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ a, const float* __restrict__ b,
-                                                      double* __restrict__ part, int P, int Bp, int C, int L) {
+                                                      double* __restrict__ part, int P, int Bp, int C, int L,
+                                                      const float* __restrict__ ocw) {
     __shared__ double sm[4];
     int bid = blockIdx.x;
     const int sp = bid % BN_SPLIT;
@@ -465,6 +492,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
     const int c = bid % C;
     const int p = bid / C;
     const float mf = mean[p * C + c], is = invstd[p * C + c], af = a[p * C + c], bf = b[p * C + c];
+    const float w0 = OC ? ocw[c * 3] : 0.f, w1 = OC ? ocw[c * 3 + 1] : 0.f, w2 = OC ? ocw[c * 3 + 2] : 0.f;
     double s1 = 0.0, s2 = 0.0;
     // accumulate in double from the first element: sum(g) cancels heavily and k1 = sum(g)/n shifts every gx
     if ((L & 3) == 0) {
@@ -473,9 +501,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
             const int64_t off = (((int64_t)p * Bp + bb) * C + c) * L;
             const nef_f32x4* xr = (const nef_f32x4*)(x + off);
             const nef_f32x4* gr = (const nef_f32x4*)(gy + off);
+            const float* gor = gy + ((int64_t)p * Bp + bb) * L;
 #pragma unroll 2
             for (int t = threadIdx.x; t < L4; t += 256) {
-                const nef_f32x4 xv = xr[t], gv = gr[t];
+                const nef_f32x4 xv = xr[t], gv = OC ? oc_grad4(gor, t, L, w0, w1, w2) : gr[t];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float g = fmaf(xv[e], af, bf) > 0.f ? gv[e] : 0.f;
@@ -574,11 +603,13 @@ __global__ void bn_bwd_apply(const float* __restrict__ gy, const float* __restri
 // Same pass, one workgroup per (pass, sample, channel) row with 16-byte accesses (L % 4 == 0): the row's six constants
 // are wave-uniform scalar loads, every thread has all its loads in flight at once, and the optional row sum costs one
 // block reduction per row instead of a double-precision shuffle tree per wave.
+template <bool OC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict__ gy, const float* __restrict__ x,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ a, const float* __restrict__ b,
                                                          const float* __restrict__ coef, float* __restrict__ gx,
-                                                         double* __restrict__ rowsum, int Bp, int C, int L4) {
+                                                         double* __restrict__ rowsum, int Bp, int C, int L4,
+                                                         const float* __restrict__ ocw) {
     __shared__ double sm[4];
     const int64_t row = blockIdx.x;
     const int c = (int)(row % C);
@@ -586,8 +617,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict
     const int pc = p * C + c;
     const float mf = mean[pc], is = invstd[pc], af = a[pc], bf = b[pc];
     const float k1 = coef[pc * 2], k2 = coef[pc * 2 + 1];
+    const float w0 = OC ? ocw[c * 3] : 0.f, w1 = OC ? ocw[c * 3 + 1] : 0.f, w2 = OC ? ocw[c * 3 + 2] : 0.f;
     const nef_f32x4* xr = (const nef_f32x4*)(x + row * 4 * L4);
     const nef_f32x4* gr = (const nef_f32x4*)(gy + row * 4 * L4);
+    const float* gor = gy + (row / C) * 4 * L4;          // OC: the sample's go row
     nef_f32x4* gxr = (nef_f32x4*)(gx + row * 4 * L4);
     double rs = 0.0;
     for (int t0 = 0; t0 < L4; t0 += 1024) {
@@ -595,7 +628,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int t = t0 + u * 256 + threadIdx.x;
-            if (t < L4) { xv[u] = xr[t]; gv[u] = gr[t]; }
+            if (t < L4) { xv[u] = xr[t]; gv[u] = OC ? oc_grad4(gor, t, 4 * L4, w0, w1, w2) : gr[t]; }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1122,17 +1155,49 @@ int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const f
     double* part = (double*)ws;
     float* coef = (float*)((char*)ws + (size_t)P * C * BN_SPLIT * 2 * sizeof(double));
     double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(P, C)) : nullptr;
-    hipLaunchKernelGGL(bn_bwd_partial, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part, P,
-                       Bp, C, L);
+    hipLaunchKernelGGL(bn_bwd_partial<false>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part,
+                       P, Bp, C, L, (const float*)nullptr);
     hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma, gbeta,
                        P, Bp, C, L);
     const int64_t rows = (int64_t)P * Bp * C;
     if ((L & 3) == 0 && rows <= 0x7FFFFFFF)
-        hipLaunchKernelGGL(bn_bwd_apply_rows, dim3((unsigned)rows), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b,
-                           (const float*)coef, gx, rowsum, Bp, C, L >> 2);
+        hipLaunchKernelGGL(bn_bwd_apply_rows<false>, dim3((unsigned)rows), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b,
+                           (const float*)coef, gx, rowsum, Bp, C, L >> 2, (const float*)nullptr);
     else
         hipLaunchKernelGGL(bn_bwd_apply, dim3(nef_stream_grid(rows, 4)), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b,
                            (const float*)coef, gx, rowsum, P, Bp, C, L);
+    if (gx_chan_sum)
+        hipLaunchKernelGGL(rowsum_to_channel, dim3(C), dim3(256), 0, NEF_ST, (const double*)rowsum, gx_chan_sum,
+                           P * Bp, C);
+    return nef_launch_status();
+}
+
+size_t nef_bn_bwd_outconv_ws_bytes(int P, int Bp, int C, int L) {
+    return nef_bn_bwd_ws_bytes(P, Bp, C) + (size_t)P * Bp * L * sizeof(float);
+}
+
+int nef_bn_relu_bwd_outconv(const float* gout, const float* out, const float* wout, const float* x, const float* mean,
+                            const float* invstd, const float* a, const float* b, float* gx, float* ggamma, float* gbeta,
+                            float* gx_chan_sum, void* ws, size_t ws_bytes, int P, int Bp, int C, int L,
+                            nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gout && out && wout && x && mean && invstd && a && b && gx && ggamma && gbeta && ws, NEF_E_NULL);
+    NEF_REQUIRE(P > 0 && Bp > 0 && C > 0 && L > 0 && (L & 3) == 0, NEF_E_SHAPE);
+    const int64_t rows = (int64_t)P * Bp * C;
+    NEF_REQUIRE(rows <= 0x7FFFFFFF, NEF_E_SHAPE);
+    NEF_REQUIRE(ws_bytes >= nef_bn_bwd_outconv_ws_bytes(P, Bp, C, L), NEF_E_WORKSPACE);
+    double* part = (double*)ws;
+    float* coef = (float*)((char*)ws + (size_t)P * C * BN_SPLIT * 2 * sizeof(double));
+    double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(P, C)) : nullptr;
+    float* go = (float*)((char*)ws + nef_bn_bwd_ws_bytes(P, Bp, C));
+    const int64_t n = (int64_t)P * Bp * L;
+    hipLaunchKernelGGL(outconv_go_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, gout, out, go, n);
+    hipLaunchKernelGGL(bn_bwd_partial<true>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, (const float*)go, x, mean, invstd,
+                       a, b, part, P, Bp, C, L, wout);
+    hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma, gbeta,
+                       P, Bp, C, L);
+    hipLaunchKernelGGL(bn_bwd_apply_rows<true>, dim3((unsigned)rows), dim3(256), 0, NEF_ST, (const float*)go, x, mean,
+                       invstd, a, b, (const float*)coef, gx, rowsum, Bp, C, L >> 2, wout);
     if (gx_chan_sum)
         hipLaunchKernelGGL(rowsum_to_channel, dim3(C), dim3(256), 0, NEF_ST, (const double*)rowsum, gx_chan_sum,
                            P * Bp, C);

@@ -185,12 +185,18 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
     side = side or ops._Inline()
     grads["decoder.4.weight"], grads["decoder.4.bias"] = side.run(
         lambda: ops.outconv_bwd_weight(g_out, out, c4, pro=pro4), g_out, out, c4)
-    g = ops.outconv_bwd_data(g_out, out, P["decoder.4.weight"], c4.shape[1])     # grad wrt relu(bn(c4))
+    # the last BatchNorm's backward rebuilds the last conv's input gradient from go on the fly (never materialised)
+    fuse_last = c4.shape[2] % 4 == 0
+    g = None if fuse_last else ops.outconv_bwd_data(g_out, out, P["decoder.4.weight"], c4.shape[1])
     for li in (3, 2, 1, 0):
         blk, cv, bn, cout = _DEC[li]
         x, c, mean, invstd, a, b, pro, up_after = saved[li]
         wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
-        gc, gg, gbeta, gbias = ops.bn_relu_bwd(g, c, P[pre + ".weight"], mean, invstd, a, b, passes, with_chan_sum=True)
+        if li == 3 and fuse_last:
+            gc, gg, gbeta, gbias = ops.bn_relu_bwd_outconv(g_out, out, P["decoder.4.weight"], c, mean, invstd, a, b, passes)
+        else:
+            gc, gg, gbeta, gbias = ops.bn_relu_bwd(g, c, P[pre + ".weight"], mean, invstd, a, b, passes,
+                                                   with_chan_sum=True)
         grads[pre + ".weight"], grads[pre + ".bias"], grads[bname] = gg, gbeta, gbias
         gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
         grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro), x, gc)

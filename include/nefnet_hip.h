@@ -221,6 +221,15 @@ int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const f
 
 /* Final Conv1d(64->1,k3,p1,bias) + sigmoid(x/3).  model_nefnet.py:106,168.
  *   x [N][C][L], w [1][C][3], bias [1], out [N][L]. */
+/* BatchNorm+ReLU backward of the LAST decoder BatchNorm fed straight from the last conv's output gradient: the
+ * [N][C][L] input gradient of Conv1d(C->1) (what nef_outconv_bwd_data would write) is rebuilt on the fly from
+ * go = gout*out*(1-out)/3, so it is never materialised.  Same results as nef_outconv_bwd_data + nef_bn_relu_bwd.
+ * L % 4 == 0.  wout [1][C][3].  ws: nef_bn_bwd_outconv_ws_bytes(P, Bp, C, L). */
+size_t nef_bn_bwd_outconv_ws_bytes(int P, int Bp, int C, int L);
+int nef_bn_relu_bwd_outconv(const float* gout, const float* out, const float* wout, const float* x, const float* mean,
+                            const float* invstd, const float* a, const float* b, float* gx, float* ggamma, float* gbeta,
+                            float* gx_chan_sum, void* ws, size_t ws_bytes, int P, int Bp, int C, int L,
+                            nef_stream_t stream);
 int nef_outconv_fwd(const float* x, const float* w, const float* bias, float* out, int N, int C, int L,
                     nef_stream_t stream);
 /* Variants that take the pre-BatchNorm tensor and apply x' = max(0, x*a[p][c] + b[p][c]), p = n / Bp, on the fly. */

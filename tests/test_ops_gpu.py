@@ -383,6 +383,27 @@ def test_outconv():
     assert rel(gw, wr.grad) < GRAD_TOL and rel(gb, br.grad) < GRAD_TOL
 
 
+@pytest.mark.parametrize("L", [500, 2048, 12])
+def test_bn_relu_bwd_through_last_conv_equals_two_calls(L):
+    """nef_bn_relu_bwd_outconv rebuilds the last conv's input gradient from go on the fly: it must give exactly what
+    nef_outconv_bwd_data followed by nef_bn_relu_bwd gives (same expressions, same summation order)."""
+    o = ops()
+    P, Bp, C = 3, 2, 64
+    N = P * Bp
+    x = rnd(N, C, L, seed=120).to(DEV)
+    gamma, beta = (rnd(C, seed=121) + 1.2).to(DEV), rnd(C, seed=122, scale=0.3).to(DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, invstd, a, b = o.bn_train_stats(x, gamma, beta, rm, rv, P)
+    w, bias = rnd(1, C, 3, seed=123, scale=0.2).to(DEV), rnd(1, seed=124).to(DEV)
+    out = o.outconv_fwd(x, w, bias, pro=(a, b, Bp))
+    gout = rnd(N, 1, L, seed=125).to(DEV)
+    g = o.outconv_bwd_data(gout, out, w, C)
+    ref = o.bn_relu_bwd(g, x, gamma, mean, invstd, a, b, P, with_chan_sum=True)
+    got = o.bn_relu_bwd_outconv(gout, out, w, x, mean, invstd, a, b, P)
+    for r, q in zip(ref, got):
+        assert torch.equal(r, q)
+
+
 @pytest.mark.parametrize("reg", ["l1_loss", "l2_loss"])
 def test_loss(reg):
     o = ops()
