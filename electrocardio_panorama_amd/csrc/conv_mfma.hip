@@ -89,8 +89,18 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(nef_conv_args a, int s
     const int seg = 1 << seg_shift;
     int b0, t0;
     if (nseg == 1) {
-        b0 = tile / tps;
-        t0 = (tile - b0 * tps) * NT;
+        // Column tiles of one sample share their boundary cache lines (rows are not 128-byte multiples) and their halo
+        // columns.  Workgroup ids go round-robin over the 8 XCDs, so the tiles of a sample are issued 8 ids apart: same
+        // XCD, back to back -- the shared lines are then L2 hits instead of second fetches.
+        const int full = (n_tiles / (8 * tps)) * (8 * tps);
+        if (tile < full) {
+            const int grp = tile / (8 * tps), r = tile % (8 * tps);
+            b0 = grp * 8 + (r & 7);
+            t0 = (r >> 3) * NT;
+        } else {
+            b0 = tile / tps;
+            t0 = (tile - b0 * tps) * NT;
+        }
     } else {
         b0 = tile * nseg;
         t0 = 0;
