@@ -143,6 +143,36 @@ __global__ void mix_fwd_kernel(const float* __restrict__ latent, const float* __
     }
 }
 
+__device__ __forceinline__ float up2_bwd_edge(const float* __restrict__ gr, int Tin, int m) {
+    const int To = 2 * Tin;
+    float s = 0.f;
+#pragma unroll
+    for (int d = -1; d <= 2; ++d) {
+        const int i = 2 * m + d;
+        if (i < 0 || i >= To) continue;
+        float src = 0.5f * ((float)i + 0.5f) - 0.5f;
+        if (src < 0.f) src = 0.f;
+        int i0 = (int)src;
+        if (i0 > Tin - 1) i0 = Tin - 1;
+        const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+        const float l1 = src - (float)i0;
+        const float l0 = 1.f - l1;
+        const float g = gr[i];
+        if (i0 == m) s += l0 * g;
+        if (i1 == m) s += l1 * g;
+    }
+    return s;
+}
+
+// adjoint of Upsample(x2, linear, align_corners=False) at input position m, read from the 2*Tin-long gradient row `gr`
+// (the expression of upsample2_bwd_rows, so a consumer that rebuilds it on the fly is bit-identical to the two-pass form)
+__device__ __forceinline__ float up2_adjoint(const float* __restrict__ gr, int Tin, int m) {
+    if (m == 0 || m == Tin - 1) return up2_bwd_edge(gr, Tin, m);
+    return 0.25f * gr[2 * m - 1] + 0.75f * gr[2 * m] + 0.75f * gr[2 * m + 1] + 0.25f * gr[2 * m + 2];
+}
+
+// UP: gD is the gradient wrt the x2-UPSAMPLED decoder input [3B][256][2T]; its adjoint is taken while reading
+template <bool UP>
 __global__ void mix_bwd_kernel(const float* __restrict__ gD, const float* __restrict__ latent,
                                const float* __restrict__ z1, const float* __restrict__ z2r,
                                const float* __restrict__ q, float* __restrict__ gz1, float* __restrict__ gz2r,
@@ -162,10 +192,18 @@ __global__ void mix_bwd_kernel(const float* __restrict__ gD, const float* __rest
         const float* lat = latent + row * T;
         const float* zsrc = (first ? z1 : z2r) + ((int64_t)b * V * 128 + cc) * T;
         float* gdst = (first ? gz1 : gz2r) + ((int64_t)b * V * 128 + cc) * T;
-        const float* g0 = gD + row * T;
+        const float* g0 = gD + row * (UP ? 2 * T : T);
+        const int64_t gpass = UP ? 2 * pass : pass;
         float acc = 0.f;
         for (int t = lane; t < T; t += 64) {
-            const float ga = g0[t], gb = g0[pass + t], gc = g0[2 * pass + t];
+            float ga, gb, gc;
+            if (UP) {
+                ga = up2_adjoint(g0, T, t);
+                gb = up2_adjoint(g0 + gpass, T, t);
+                gc = up2_adjoint(g0 + 2 * gpass, T, t);
+            } else {
+                ga = g0[t]; gb = g0[gpass + t]; gc = g0[2 * gpass + t];
+            }
             // pass that uses the picked lead for this half: D1 for the z1 half, D2 for the z2 half
             const float g_pick = first ? gb : gc;
             const float g_mean = first ? (ga + gc) : (ga + gb);
@@ -259,26 +297,6 @@ __global__ __launch_bounds__(256) void upsample2_aff_fwd_rows(const float* __res
     }
 }
 
-__device__ __forceinline__ float up2_bwd_edge(const float* __restrict__ gr, int Tin, int m) {
-    const int To = 2 * Tin;
-    float s = 0.f;
-#pragma unroll
-    for (int d = -1; d <= 2; ++d) {
-        const int i = 2 * m + d;
-        if (i < 0 || i >= To) continue;
-        float src = 0.5f * ((float)i + 0.5f) - 0.5f;
-        if (src < 0.f) src = 0.f;
-        int i0 = (int)src;
-        if (i0 > Tin - 1) i0 = Tin - 1;
-        const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
-        const float l1 = src - (float)i0;
-        const float l0 = 1.f - l1;
-        const float g = gr[i];
-        if (i0 == m) s += l0 * g;
-        if (i1 == m) s += l1 * g;
-    }
-    return s;
-}
 
 __global__ void upsample2_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int64_t N, int Tin) {
     const int To = 2 * Tin;
@@ -1055,8 +1073,19 @@ int nef_mix_bwd(const float* gD, const float* latent, const float* z1, const flo
     NEF_ENTER();
     NEF_REQUIRE(gD && latent && z1 && z2r && q && gz1 && gz2r && gq, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && V > 0 && T > 0 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
-    hipLaunchKernelGGL(mix_bwd_kernel, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gD, latent, z1,
-                       z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev);
+    hipLaunchKernelGGL(mix_bwd_kernel<false>, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gD, latent,
+                       z1, z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev);
+    return nef_launch_status();
+}
+
+int nef_mix_bwd_up(const float* gU, const float* latent, const float* z1, const float* z2r, const float* q, float* gz1,
+                   float* gz2r, float* gq, int B, int V, int T, int c1, int c2, const int32_t* choice_dev,
+                   nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gU && latent && z1 && z2r && q && gz1 && gz2r && gq, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && V > 0 && T > 1 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
+    hipLaunchKernelGGL(mix_bwd_kernel<true>, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gU, latent,
+                       z1, z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev);
     return nef_launch_status();
 }
 

@@ -201,9 +201,10 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
         gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
         grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro), x, gc)
         g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True), x.shape[1], 3, role="conv_bwd_data")
-        if up_after:
+        if up_after and li > 0:
             g = ops.upsample2_bwd(g)          # back through the x2 upsampling
-    return g
+    # the adjoint of the FIRST upsampling is left to the consumer (mix_bwd takes it while reading)
+    return g, bool(saved[0][7])
 
 
 # ----------------------------------------------------------------------------------------------
@@ -424,8 +425,8 @@ def _head_bwd(P, sv, g_outs, grads, side):
     like = sv["dec"][2]        # stacked decoder output [3B, 1, L]
     parts = [g if g is not None else torch.zeros_like(like[0:B]) for g in g_outs]
     g_out = torch.cat([p_.contiguous() for p_ in parts], dim=0)
-    gD = decoder_bwd(sv["dec"], g_out, P, grads, side)
-    gz1, gz2r, gq = ops.mix_bwd(gD, sv["latent"], sv["z1"], sv["z2r"], sv["q"], V, sv["choice"])
+    gD, up = decoder_bwd(sv["dec"], g_out, P, grads, side)
+    gz1, gz2r, gq = ops.mix_bwd(gD, sv["latent"], sv["z1"], sv["z2r"], sv["q"], V, sv["choice"], upsampled=up)
     gW2, gb2 = side.run(lambda: ops.theta_mlp_bwd(sv["q_theta"], gq, 256), gq)
     grads["mlp2.weight"], grads["mlp2.bias"] = gW2, gb2
     return gz1, gz2r

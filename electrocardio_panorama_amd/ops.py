@@ -492,15 +492,18 @@ def mix_fwd(latent, z1, z2r, q, V, c1, c2=None):
     return D
 
 
-def mix_bwd(gD, latent, z1, z2r, q, V, c1, c2=None):
+def mix_bwd(gD, latent, z1, z2r, q, V, c1, c2=None, upsampled=False):
+    """`upsampled`: gD is the gradient wrt the x2-upsampled decoder input [3B,256,2T]; its adjoint is taken on the fly."""
     L = _lib.load()
     c1, c2, cdev = _choice(c1 if c2 is None else (c1, c2))
     _chk(gD)
     B, _, T = latent.shape
+    assert gD.shape[2] == (2 * T if upsampled else T)
     gz1, gz2r = torch.empty_like(z1), torch.empty_like(z2r)
     gq = torch.empty(B, 256, device=latent.device, dtype=torch.float32)
-    _lib.check(L.nef_mix_bwd(_p(gD), _p(latent), _p(z1), _p(z2r), _p(q), _p(gz1), _p(gz2r), _p(gq), B, V, T, c1, c2,
-                             cdev, _stream()), "nef_mix_bwd")
+    fn = L.nef_mix_bwd_up if upsampled else L.nef_mix_bwd
+    _lib.check(fn(_p(gD), _p(latent), _p(z1), _p(z2r), _p(q), _p(gz1), _p(gz2r), _p(gq), B, V, T, c1, c2, cdev, _stream()),
+               "nef_mix_bwd")
     return gz1, gz2r, gq
 
 

@@ -183,6 +183,11 @@ int nef_mix_fwd(const float* latent, const float* z1, const float* z2r, const fl
 int nef_mix_bwd(const float* gD, const float* latent, const float* z1, const float* z2r, const float* q, float* gz1,
                 float* gz2r, float* gq, int B, int V, int T, int c1, int c2, const int32_t* choice_dev,
                 nef_stream_t stream);
+/* nef_mix_bwd_up: same, but gU is the gradient wrt the x2-UPSAMPLED decoder input [3B][256][2T] (what the first decoder
+ * conv's backward-data writes); the upsampling adjoint (nef_upsample2_bwd) is taken while reading it. */
+int nef_mix_bwd_up(const float* gU, const float* latent, const float* z1, const float* z2r, const float* q, float* gz1,
+                float* gz2r, float* gq, int B, int V, int T, int c1, int c2, const int32_t* choice_dev,
+                nef_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Decoder pieces.  model_nefnet.py:10-27,101-107.

@@ -404,6 +404,20 @@ def test_bn_relu_bwd_through_last_conv_equals_two_calls(L):
         assert torch.equal(r, q)
 
 
+def test_mix_bwd_takes_the_upsampling_adjoint_on_the_fly():
+    """mix_bwd(upsampled=True) on the gradient wrt the x2-upsampled decoder input == upsample2_bwd followed by mix_bwd,
+    bit for bit (same expressions)."""
+    o = ops()
+    B, V, T = 3, 3, 130
+    latent, z1, z2r = g(rnd(B, 256, T, seed=130)), g(rnd(B, 128 * V, T, seed=131)), g(rnd(B, 128 * V, T, seed=132))
+    q = g(rnd(B, 256, seed=133))
+    gU = g(rnd(3 * B, 256, 2 * T, seed=134))
+    ref = o.mix_bwd(o.upsample2_bwd(gU), latent, z1, z2r, q, V, (2, 0))
+    got = o.mix_bwd(gU, latent, z1, z2r, q, V, (2, 0), upsampled=True)
+    for r, c in zip(ref, got):
+        assert torch.equal(r, c)
+
+
 @pytest.mark.parametrize("reg", ["l1_loss", "l2_loss"])
 def test_loss(reg):
     o = ops()
@@ -492,7 +506,9 @@ def test_decoder_three_passes(T):
     for k in Bf:
         assert rel(Bfd[k].float(), Bfr[k].float()) < 1e-5, k
     grads = {}
-    gD = engine.decoder_bwd(dsv, g(gy), Pd, grads)
+    gD, up = engine.decoder_bwd(dsv, g(gy), Pd, grads)
+    if up:                                   # the first upsampling's adjoint is left to the consumer (mix_bwd)
+        gD = ops().upsample2_bwd(gD)
     assert rel(gD, gD64) < GRAD_TOL + 2 * rel(gD32, gD64), (rel(gD, gD64), rel(gD32, gD64))
     for k, v in grads.items():
         if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
