@@ -496,8 +496,25 @@ __device__ __forceinline__ nef_f32x4 oc_grad4(const float* __restrict__ gor, int
     return g;
 }
 
-// OC: `gy` is the go tensor [P*Bp][L] of the last conv and `ocw` its weight [C][3]; g is rebuilt on the fly (L % 4 == 0)
-template <bool OC>
+// four consecutive values of the x2-upsampling adjoint (positions 4*t4 .. 4*t4+3 of an L-long row) from the 2L-long
+// gradient row `gr`: the expressions of up2_adjoint / upsample2_bwd_rows
+__device__ __forceinline__ nef_f32x4 up2_adjoint4(const float* __restrict__ gr, int t4, int L) {
+    const nef_f32x4 v0 = *(const nef_f32x4*)(gr + 8 * t4), v1 = *(const nef_f32x4*)(gr + 8 * t4 + 4);
+    const float lo = t4 > 0 ? gr[8 * t4 - 1] : 0.f;
+    const float hi = 8 * t4 + 8 < 2 * L ? gr[8 * t4 + 8] : 0.f;
+    nef_f32x4 g;
+    g[0] = 0.25f * lo + 0.75f * v0[0] + 0.75f * v0[1] + 0.25f * v0[2];
+    g[1] = 0.25f * v0[1] + 0.75f * v0[2] + 0.75f * v0[3] + 0.25f * v1[0];
+    g[2] = 0.25f * v0[3] + 0.75f * v1[0] + 0.75f * v1[1] + 0.25f * v1[2];
+    g[3] = 0.25f * v1[1] + 0.75f * v1[2] + 0.75f * v1[3] + 0.25f * hi;
+    if (t4 == 0) g[0] = up2_bwd_edge(gr, L, 0);
+    if (4 * t4 + 3 == L - 1) g[3] = up2_bwd_edge(gr, L, L - 1);
+    return g;
+}
+
+// MODE 1: `gy` is the go tensor [P*Bp][L] of the last conv and `ocw` its weight [C][3]; MODE 2: `gy` is the gradient wrt
+// the x2-UPSAMPLED activation [rows][2L]; in both cases g is rebuilt on the fly (L % 4 == 0)
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ gy, const float* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ a, const float* __restrict__ b,
@@ -510,6 +527,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
     const int c = bid % C;
     const int p = bid / C;
     const float mf = mean[p * C + c], is = invstd[p * C + c], af = a[p * C + c], bf = b[p * C + c];
+    constexpr bool OC = MODE == 1, UPG = MODE == 2;
     const float w0 = OC ? ocw[c * 3] : 0.f, w1 = OC ? ocw[c * 3 + 1] : 0.f, w2 = OC ? ocw[c * 3 + 2] : 0.f;
     double s1 = 0.0, s2 = 0.0;
     // accumulate in double from the first element: sum(g) cancels heavily and k1 = sum(g)/n shifts every gx
@@ -520,9 +538,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
             const nef_f32x4* xr = (const nef_f32x4*)(x + off);
             const nef_f32x4* gr = (const nef_f32x4*)(gy + off);
             const float* gor = gy + ((int64_t)p * Bp + bb) * L;
+            const float* gur = gy + 2 * off;
 #pragma unroll 2
             for (int t = threadIdx.x; t < L4; t += 256) {
-                const nef_f32x4 xv = xr[t], gv = OC ? oc_grad4(gor, t, L, w0, w1, w2) : gr[t];
+                const nef_f32x4 xv = xr[t],
+                                gv = OC ? oc_grad4(gor, t, L, w0, w1, w2) : (UPG ? up2_adjoint4(gur, t, L) : gr[t]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float g = fmaf(xv[e], af, bf) > 0.f ? gv[e] : 0.f;
@@ -621,7 +641,7 @@ __global__ void bn_bwd_apply(const float* __restrict__ gy, const float* __restri
 // Same pass, one workgroup per (pass, sample, channel) row with 16-byte accesses (L % 4 == 0): the row's six constants
 // are wave-uniform scalar loads, every thread has all its loads in flight at once, and the optional row sum costs one
 // block reduction per row instead of a double-precision shuffle tree per wave.
-template <bool OC>
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict__ gy, const float* __restrict__ x,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ a, const float* __restrict__ b,
@@ -635,10 +655,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict
     const int pc = p * C + c;
     const float mf = mean[pc], is = invstd[pc], af = a[pc], bf = b[pc];
     const float k1 = coef[pc * 2], k2 = coef[pc * 2 + 1];
+    constexpr bool OC = MODE == 1, UPG = MODE == 2;
     const float w0 = OC ? ocw[c * 3] : 0.f, w1 = OC ? ocw[c * 3 + 1] : 0.f, w2 = OC ? ocw[c * 3 + 2] : 0.f;
     const nef_f32x4* xr = (const nef_f32x4*)(x + row * 4 * L4);
     const nef_f32x4* gr = (const nef_f32x4*)(gy + row * 4 * L4);
     const float* gor = gy + (row / C) * 4 * L4;          // OC: the sample's go row
+    const float* gur = gy + row * 8 * L4;                // UPG: this row at twice the length
     nef_f32x4* gxr = (nef_f32x4*)(gx + row * 4 * L4);
     double rs = 0.0;
     for (int t0 = 0; t0 < L4; t0 += 1024) {
@@ -646,7 +668,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int t = t0 + u * 256 + threadIdx.x;
-            if (t < L4) { xv[u] = xr[t]; gv[u] = OC ? oc_grad4(gor, t, 4 * L4, w0, w1, w2) : gr[t]; }
+            if (t < L4) {
+                xv[u] = xr[t];
+                gv[u] = OC ? oc_grad4(gor, t, 4 * L4, w0, w1, w2) : (UPG ? up2_adjoint4(gur, t, 4 * L4) : gr[t]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1184,17 +1209,41 @@ int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const f
     double* part = (double*)ws;
     float* coef = (float*)((char*)ws + (size_t)P * C * BN_SPLIT * 2 * sizeof(double));
     double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(P, C)) : nullptr;
-    hipLaunchKernelGGL(bn_bwd_partial<false>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part,
+    hipLaunchKernelGGL(bn_bwd_partial<0>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part,
                        P, Bp, C, L, (const float*)nullptr);
     hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma, gbeta,
                        P, Bp, C, L);
     const int64_t rows = (int64_t)P * Bp * C;
     if ((L & 3) == 0 && rows <= 0x7FFFFFFF)
-        hipLaunchKernelGGL(bn_bwd_apply_rows<false>, dim3((unsigned)rows), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b,
+        hipLaunchKernelGGL(bn_bwd_apply_rows<0>, dim3((unsigned)rows), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b,
                            (const float*)coef, gx, rowsum, Bp, C, L >> 2, (const float*)nullptr);
     else
         hipLaunchKernelGGL(bn_bwd_apply, dim3(nef_stream_grid(rows, 4)), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b,
                            (const float*)coef, gx, rowsum, P, Bp, C, L);
+    if (gx_chan_sum)
+        hipLaunchKernelGGL(rowsum_to_channel, dim3(C), dim3(256), 0, NEF_ST, (const double*)rowsum, gx_chan_sum,
+                           P * Bp, C);
+    return nef_launch_status();
+}
+
+int nef_bn_relu_bwd_up(const float* gu, const float* x, const float* mean, const float* invstd, const float* a,
+                       const float* b, float* gx, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
+                       size_t ws_bytes, int P, int Bp, int C, int L, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gu && x && mean && invstd && a && b && gx && ggamma && gbeta && ws, NEF_E_NULL);
+    NEF_REQUIRE(P > 0 && Bp > 0 && C > 0 && L >= 8 && (L & 3) == 0, NEF_E_SHAPE);
+    const int64_t rows = (int64_t)P * Bp * C;
+    NEF_REQUIRE(rows <= 0x7FFFFFFF, NEF_E_SHAPE);
+    NEF_REQUIRE(ws_bytes >= nef_bn_bwd_ws_bytes(P, Bp, C), NEF_E_WORKSPACE);
+    double* part = (double*)ws;
+    float* coef = (float*)((char*)ws + (size_t)P * C * BN_SPLIT * 2 * sizeof(double));
+    double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(P, C)) : nullptr;
+    hipLaunchKernelGGL(bn_bwd_partial<2>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gu, x, mean, invstd, a, b, part, P,
+                       Bp, C, L, (const float*)nullptr);
+    hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma, gbeta,
+                       P, Bp, C, L);
+    hipLaunchKernelGGL(bn_bwd_apply_rows<2>, dim3((unsigned)rows), dim3(256), 0, NEF_ST, gu, x, mean, invstd, a, b,
+                       (const float*)coef, gx, rowsum, Bp, C, L >> 2, (const float*)nullptr);
     if (gx_chan_sum)
         hipLaunchKernelGGL(rowsum_to_channel, dim3(C), dim3(256), 0, NEF_ST, (const double*)rowsum, gx_chan_sum,
                            P * Bp, C);
@@ -1221,11 +1270,11 @@ int nef_bn_relu_bwd_outconv(const float* gout, const float* out, const float* wo
     float* go = (float*)((char*)ws + nef_bn_bwd_ws_bytes(P, Bp, C));
     const int64_t n = (int64_t)P * Bp * L;
     hipLaunchKernelGGL(outconv_go_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, gout, out, go, n);
-    hipLaunchKernelGGL(bn_bwd_partial<true>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, (const float*)go, x, mean, invstd,
+    hipLaunchKernelGGL(bn_bwd_partial<1>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, (const float*)go, x, mean, invstd,
                        a, b, part, P, Bp, C, L, wout);
     hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma, gbeta,
                        P, Bp, C, L);
-    hipLaunchKernelGGL(bn_bwd_apply_rows<true>, dim3((unsigned)rows), dim3(256), 0, NEF_ST, (const float*)go, x, mean,
+    hipLaunchKernelGGL(bn_bwd_apply_rows<1>, dim3((unsigned)rows), dim3(256), 0, NEF_ST, (const float*)go, x, mean,
                        invstd, a, b, (const float*)coef, gx, rowsum, Bp, C, L >> 2, wout);
     if (gx_chan_sum)
         hipLaunchKernelGGL(rowsum_to_channel, dim3(C), dim3(256), 0, NEF_ST, (const double*)rowsum, gx_chan_sum,

@@ -187,6 +187,7 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
         lambda: ops.outconv_bwd_weight(g_out, out, c4, pro=pro4), g_out, out, c4)
     # the last BatchNorm's backward rebuilds the last conv's input gradient from go on the fly (never materialised)
     fuse_last = c4.shape[2] % 4 == 0
+    g_is_up = False
     g = None if fuse_last else ops.outconv_bwd_data(g_out, out, P["decoder.4.weight"], c4.shape[1])
     for li in (3, 2, 1, 0):
         blk, cv, bn, cout = _DEC[li]
@@ -194,6 +195,8 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
         wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
         if li == 3 and fuse_last:
             gc, gg, gbeta, gbias = ops.bn_relu_bwd_outconv(g_out, out, P["decoder.4.weight"], c, mean, invstd, a, b, passes)
+        elif g_is_up:
+            gc, gg, gbeta, gbias = ops.bn_relu_bwd_up(g, c, mean, invstd, a, b, passes)
         else:
             gc, gg, gbeta, gbias = ops.bn_relu_bwd(g, c, P[pre + ".weight"], mean, invstd, a, b, passes,
                                                    with_chan_sum=True)
@@ -201,8 +204,11 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
         gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
         grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro), x, gc)
         g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True), x.shape[1], 3, role="conv_bwd_data")
-        if up_after and li > 0:
-            g = ops.upsample2_bwd(g)          # back through the x2 upsampling
+        # back through the x2 upsampling in front of this layer: the next BatchNorm backward takes the adjoint while it
+        # reads (rows of 4k >= 8 samples), otherwise it is a pass of its own
+        g_is_up = bool(up_after and li > 0 and c.shape[2] % 8 == 0 and c.shape[2] >= 16)
+        if up_after and li > 0 and not g_is_up:
+            g = ops.upsample2_bwd(g)
     # the adjoint of the FIRST upsampling is left to the consumer (mix_bwd takes it while reading)
     return g, bool(saved[0][7])
 

@@ -595,6 +595,24 @@ def bn_relu_bwd(gy, x, gamma, mean, invstd, a, b, P, with_chan_sum=False):
     return (gx, gg, gb, gs) if with_chan_sum else (gx, gg, gb)
 
 
+def bn_relu_bwd_up(gu, x, mean, invstd, a, b, P):
+    """bn_relu_bwd(upsample2_bwd(gu), x, ...) with the upsampling adjoint taken on the fly; gu [N,C,2L].
+    Returns (gx, ggamma, gbeta, sum_{b,t} gx per channel)."""
+    L = _lib.load()
+    _chk(gu), _chk(x)
+    N, Ct, Ln = x.shape
+    assert gu.shape == (N, Ct, 2 * Ln)
+    gx = torch.empty_like(x)
+    gg = torch.empty(Ct, device=x.device, dtype=torch.float32)
+    gb = torch.empty(Ct, device=x.device, dtype=torch.float32)
+    gs = torch.empty(Ct, device=x.device, dtype=torch.float32)
+    n = L.nef_bn_bwd_ws_bytes(P, N // P, Ct)
+    ws = workspace(n, x.device)
+    _lib.check(L.nef_bn_relu_bwd_up(_p(gu), _p(x), _p(mean), _p(invstd), _p(a), _p(b), _p(gx), _p(gg), _p(gb), _p(gs),
+                                    _p(ws), n, P, N // P, Ct, Ln, _stream()), "nef_bn_relu_bwd_up")
+    return gx, gg, gb, gs
+
+
 def bn_relu_bwd_outconv(gout, out, wout, x, mean, invstd, a, b, P):
     """bn_relu_bwd(outconv_bwd_data(gout, out, wout), x, ...) without materialising the [N,C,L] gradient in between.
     Returns (gx, ggamma, gbeta, sum_{b,t} gx per channel)."""

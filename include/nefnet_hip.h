@@ -230,6 +230,12 @@ int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const f
  * [N][C][L] input gradient of Conv1d(C->1) (what nef_outconv_bwd_data would write) is rebuilt on the fly from
  * go = gout*out*(1-out)/3, so it is never materialised.  Same results as nef_outconv_bwd_data + nef_bn_relu_bwd.
  * L % 4 == 0.  wout [1][C][3].  ws: nef_bn_bwd_outconv_ws_bytes(P, Bp, C, L). */
+/* nef_bn_relu_bwd_up: nef_bn_relu_bwd whose incoming gradient is given at TWICE the length, gu [N][C][2L] = the
+ * gradient wrt nn.Upsample(x2)(ReLU(BN(x))) (model_nefnet.py:104); the upsampling adjoint (nef_upsample2_bwd) is taken
+ * while reading.  L % 4 == 0, L >= 8.  ws: nef_bn_bwd_ws_bytes. */
+int nef_bn_relu_bwd_up(const float* gu, const float* x, const float* mean, const float* invstd, const float* a,
+                       const float* b, float* gx, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
+                       size_t ws_bytes, int P, int Bp, int C, int L, nef_stream_t stream);
 size_t nef_bn_bwd_outconv_ws_bytes(int P, int Bp, int C, int L);
 int nef_bn_relu_bwd_outconv(const float* gout, const float* out, const float* wout, const float* x, const float* mean,
                             const float* invstd, const float* a, const float* b, float* gx, float* ggamma, float* gbeta,

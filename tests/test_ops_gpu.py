@@ -418,6 +418,22 @@ def test_mix_bwd_takes_the_upsampling_adjoint_on_the_fly():
         assert torch.equal(r, c)
 
 
+@pytest.mark.parametrize("L", [500, 16, 2048])
+def test_bn_relu_bwd_takes_the_upsampling_adjoint_on_the_fly(L):
+    """nef_bn_relu_bwd_up on the gradient wrt the x2-upsampled activation == upsample2_bwd + bn_relu_bwd, bit for bit."""
+    o = ops()
+    P, Bp, C = 3, 2, 128
+    N = P * Bp
+    x = rnd(N, C, L, seed=140).to(DEV)
+    gamma, beta = (rnd(C, seed=141) + 1.2).to(DEV), rnd(C, seed=142, scale=0.3).to(DEV)
+    mean, invstd, a, b = o.bn_train_stats(x, gamma, beta, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), P)
+    gu = rnd(N, C, 2 * L, seed=143).to(DEV)
+    ref = o.bn_relu_bwd(o.upsample2_bwd(gu), x, gamma, mean, invstd, a, b, P, with_chan_sum=True)
+    got = o.bn_relu_bwd_up(gu, x, mean, invstd, a, b, P)
+    for r, q in zip(ref, got):
+        assert torch.equal(r, q)
+
+
 @pytest.mark.parametrize("reg", ["l1_loss", "l2_loss"])
 def test_loss(reg):
     o = ops()
