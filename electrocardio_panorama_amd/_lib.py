@@ -57,7 +57,7 @@ SIGNATURES = {
     "nef_theta_mlp_bwd": (i32, [p, p, p, p, i32, i32, p]),
     "nef_theta_encode": (i32, [p, p, i32, p]),
     "nef_chscale_fwd": (i32, [p, p, i64, p, i32, i32, i32, p]),
-    "nef_chscale_bwd": (i32, [p, p, p, i64, p, p, i32, i32, i32, p]),
+    "nef_chscale_bwd": (i32, [p, p, p, i64, p, p, i32, i32, i32, i32, p]),
     "nef_gate": (i32, [p, p, p, f32, i64, p]),
     "nef_add": (i32, [p, p, p, i64, p]),
     "nef_roi_align_fwd": (i32, [p, p, p, i32, i32, i32, i32, i32, p]),
@@ -69,8 +69,8 @@ SIGNATURES = {
     "nef_roi_segment_table": (i32, [p, p, p, i32, p]),
     "nef_lead_mean": (i32, [p, p, p, i32, i32, i32, p]),
     "nef_mix_fwd": (i32, [p, p, p, p, p, i32, i32, i32, i32, i32, p, p]),
-    "nef_mix_bwd": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, p]),
-    "nef_mix_bwd_up": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, p]),
+    "nef_mix_bwd": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, i32, p]),
+    "nef_mix_bwd_up": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, i32, p]),
     "nef_upsample2_fwd": (i32, [p, p, i64, i32, p]),
     "nef_upsample2_bwd": (i32, [p, p, i64, i32, p]),
     "nef_upsample2_aff_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, p]),

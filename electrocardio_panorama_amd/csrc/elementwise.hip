@@ -25,7 +25,7 @@ __global__ void chscale_fwd_kernel(const float* __restrict__ x, const float* __r
 
 __global__ void chscale_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                    const float* __restrict__ s, int64_t s_bs, float* __restrict__ gx,
-                                   float* __restrict__ gs, int B, int C, int T) {
+                                   float* __restrict__ gs, int B, int C, int T, int relu_x) {
     const int64_t rows = (int64_t)B * C;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
@@ -36,9 +36,10 @@ __global__ void chscale_bwd_kernel(const float* __restrict__ gy, const float* __
         float* gxr = gx + row * T;
         float acc = 0.f;
         for (int t = lane; t < T; t += 64) {
-            const float g = gr[t];
-            acc = fmaf(g, xr[t], acc);
-            gxr[t] = g * f;
+            const float g = gr[t], xv = xr[t];
+            acc = fmaf(g, xv, acc);
+            // relu_x: x is a ReLU output whose producer would mask this gradient first thing in its own backward
+            gxr[t] = (relu_x && !(xv > 0.f)) ? 0.f : g * f;
         }
         acc = nef_wave_sum(acc);
         if (lane == 0) gs[row] = acc;
@@ -177,7 +178,7 @@ __global__ void mix_bwd_kernel(const float* __restrict__ gD, const float* __rest
                                const float* __restrict__ z1, const float* __restrict__ z2r,
                                const float* __restrict__ q, float* __restrict__ gz1, float* __restrict__ gz2r,
                                float* __restrict__ gq, int B, int V, int T, int c1, int c2,
-                               const int32_t* __restrict__ choice_dev) {
+                               const int32_t* __restrict__ choice_dev, int relu_z1) {
     if (choice_dev) { c1 = choice_dev[0]; c2 = choice_dev[1]; }
     const int64_t rows = (int64_t)B * 256;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -211,7 +212,12 @@ __global__ void mix_bwd_kernel(const float* __restrict__ gD, const float* __rest
             const float pk = zsrc[(int64_t)pick_v * 128 * T + t];
             acc += g_mean * l + g_pick * pk;
             const float gm = f * g_mean / fv;
-            for (int v = 0; v < V; ++v) gdst[(int64_t)v * 128 * T + t] = gm + (v == pick_v ? f * g_pick : 0.f);
+            for (int v = 0; v < V; ++v) {
+                float o = gm + (v == pick_v ? f * g_pick : 0.f);
+                // relu_z1: z1 is a ReLU output (z1_conv's block): mask its gradient here instead of in a pass of its own
+                if (relu_z1 && first && !(zsrc[(int64_t)v * 128 * T + t] > 0.f)) o = 0.f;
+                gdst[(int64_t)v * 128 * T + t] = o;
+            }
         }
         acc = nef_wave_sum(acc);
         if (lane == 0) gq[row] = acc;
@@ -1022,12 +1028,12 @@ int nef_chscale_fwd(const float* x, const float* s, int64_t s_bs, float* y, int 
 }
 
 int nef_chscale_bwd(const float* gy, const float* x, const float* s, int64_t s_bs, float* gx, float* gs, int B, int C,
-                    int T, nef_stream_t stream) {
+                    int T, int relu_x, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(gy && x && s && gx && gs, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
     hipLaunchKernelGGL(chscale_bwd_kernel, dim3(nef_stream_grid((int64_t)B * C, 4)), dim3(256), 0, NEF_ST, gy, x, s,
-                       s_bs, gx, gs, B, C, T);
+                       s_bs, gx, gs, B, C, T, relu_x);
     return nef_launch_status();
 }
 
@@ -1093,24 +1099,24 @@ int nef_mix_fwd(const float* latent, const float* z1, const float* z2r, const fl
 }
 
 int nef_mix_bwd(const float* gD, const float* latent, const float* z1, const float* z2r, const float* q, float* gz1,
-                float* gz2r, float* gq, int B, int V, int T, int c1, int c2, const int32_t* choice_dev,
+                float* gz2r, float* gq, int B, int V, int T, int c1, int c2, const int32_t* choice_dev, int relu_z1,
                 nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(gD && latent && z1 && z2r && q && gz1 && gz2r && gq, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && V > 0 && T > 0 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
     hipLaunchKernelGGL(mix_bwd_kernel<false>, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gD, latent,
-                       z1, z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev);
+                       z1, z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev, relu_z1);
     return nef_launch_status();
 }
 
 int nef_mix_bwd_up(const float* gU, const float* latent, const float* z1, const float* z2r, const float* q, float* gz1,
-                   float* gz2r, float* gq, int B, int V, int T, int c1, int c2, const int32_t* choice_dev,
+                   float* gz2r, float* gq, int B, int V, int T, int c1, int c2, const int32_t* choice_dev, int relu_z1,
                    nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(gU && latent && z1 && z2r && q && gz1 && gz2r && gq, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && V > 0 && T > 1 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
     hipLaunchKernelGGL(mix_bwd_kernel<true>, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gU, latent,
-                       z1, z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev);
+                       z1, z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev, relu_z1);
     return nef_launch_status();
 }
 

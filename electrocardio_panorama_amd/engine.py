@@ -425,20 +425,22 @@ def gen_ecg(P, Bf, z1, z2b, query_thetas, rois, chunk=8, half=False):
     return sweep(P, Bf, latent, query_thetas, False, chunk)
 
 
-def _head_bwd(P, sv, g_outs, grads, side):
+def _head_bwd(P, sv, g_outs, grads, side, relu_z1=False):
     """Back through decoder passes, Standin mixes and mlp2: returns the gradients wrt the lead-blocked z1 and z2r."""
     B, V = sv["hB"], sv["hV"]
     like = sv["dec"][2]        # stacked decoder output [3B, 1, L]
     parts = [g if g is not None else torch.zeros_like(like[0:B]) for g in g_outs]
     g_out = torch.cat([p_.contiguous() for p_ in parts], dim=0)
     gD, up = decoder_bwd(sv["dec"], g_out, P, grads, side)
-    gz1, gz2r, gq = ops.mix_bwd(gD, sv["latent"], sv["z1"], sv["z2r"], sv["q"], V, sv["choice"], upsampled=up)
+    # relu_z1: z1 is the ReLU output of z1_conv's block, whose backward would start by masking gz1 -- done here
+    gz1, gz2r, gq = ops.mix_bwd(gD, sv["latent"], sv["z1"], sv["z2r"], sv["q"], V, sv["choice"], upsampled=up,
+                                relu_z1=relu_z1)
     gW2, gb2 = side.run(lambda: ops.theta_mlp_bwd(sv["q_theta"], gq, 256), gq)
     grads["mlp2.weight"], grads["mlp2.bias"] = gW2, gb2
     return gz1, gz2r
 
 
-def _latents_bwd(P, sv, gz1, gz2r, grads, side):
+def _latents_bwd(P, sv, gz1, gz2r, grads, side, z1_pre_gated=False):
     """Back through `_latents` (+ the segment un-pooling that follows it): encoder-side parameter gradients."""
     B, V, T = sv["B"], sv["V"], sv["T"]
     gz2b = ops.roi_unpool_bwd(gz2r, sv["rois"])                                  # [B, 128V, 7, 32]
@@ -451,7 +453,7 @@ def _latents_bwd(P, sv, gz1, gz2r, grads, side):
     gh0 = block_bwd(sv["blk_c20"], gh1, P, grads, side=side)
     genc = torch.empty(B, 128 * V, T, device=gz1.device, dtype=torch.float32)
     # z1_conv / z2_conv1 read the ReLU output of w_conv: they mask their input gradient with it, w_conv skips its gate
-    block_bwd(sv["blk_z1"], gz1, P, grads, out=GV.half(genc, V, 0), side=side, gate_input=True)
+    block_bwd(sv["blk_z1"], gz1, P, grads, out=GV.half(genc, V, 0), side=side, pre_gated=z1_pre_gated, gate_input=True)
     win = sv["z2_win"]
     if win is not None:
         gz2c = ops.roi_align_bwd(gh0.view(B, 128 * V, N_SEG, ROI_BINS), sv["rois"], T, win[1], win[0])
@@ -461,11 +463,11 @@ def _latents_bwd(P, sv, gz1, gz2r, grads, side):
         gz2c = ops.roi_align_bwd(gh0.view(B, 128 * V, N_SEG, ROI_BINS), sv["rois"], T)
         block_bwd(sv["blk_z2c"], gz2c, P, grads, out=GV.half(genc, V, 1), side=side, gate_input=True)
     gew = block_bwd(sv["blk_w_conv"], genc, P, grads, side=side, pre_gated=True)
-    g, ge = ops.chscale_bwd(gew, sv["w"], sv["e"])
+    g, ge = ops.chscale_bwd(gew, sv["w"], sv["e"], relu_x=True)      # sv["w"]: ReLU output of the last encoder block
     gW1, gb1 = side.run(lambda: ops.theta_mlp_bwd(sv["in_theta"], ge, 128), ge)
     grads["mlp1.weight"], grads["mlp1.bias"] = gW1, gb1
     for i in (2, 1, 0):
-        g = block_bwd(sv["blk_enc"][i], g, P, grads, side=side, pre_gated=(i < 2), gate_input=(i > 0))
+        g = block_bwd(sv["blk_enc"][i], g, P, grads, side=side, pre_gated=True, gate_input=(i > 0))
     grads["W_encoder.conv1.weight"] = ops.stem_bwd_weight(sv["x"], P["W_encoder.conv1.weight"], g)
 
 
@@ -473,8 +475,8 @@ def backward(P, sv, g_outs):
     """g_outs: gradients wrt (out, shuffle_p, shuffle_l), each [B,1,L] or None.  Returns {param name: grad}."""
     grads = {}
     side = _side(sv["z1"].device)
-    gz1, gz2r = _head_bwd(P, sv, g_outs, grads, side)
-    _latents_bwd(P, sv, gz1, gz2r, grads, side)
+    gz1, gz2r = _head_bwd(P, sv, g_outs, grads, side, relu_z1=True)
+    _latents_bwd(P, sv, gz1, gz2r, grads, side, z1_pre_gated=True)
     side.join()
     return grads
 

@@ -370,13 +370,15 @@ def chscale_fwd(x, s, s_bs=None):
     return y
 
 
-def chscale_bwd(gy, x, s, s_bs=None):
+def chscale_bwd(gy, x, s, s_bs=None, relu_x=False):
+    """`relu_x`: x is a ReLU output -- gx also carries that ReLU's backward mask (x > 0)."""
     L = _lib.load()
     _chk(gy), _chk(x)
     B, Ct, T = x.shape
     gx = torch.empty_like(x)
     gs = torch.empty(B, Ct, device=x.device, dtype=torch.float32)
-    _lib.check(L.nef_chscale_bwd(_p(gy), _p(x), _p(s), Ct if s_bs is None else s_bs, _p(gx), _p(gs), B, Ct, T, _stream()),
+    _lib.check(L.nef_chscale_bwd(_p(gy), _p(x), _p(s), Ct if s_bs is None else s_bs, _p(gx), _p(gs), B, Ct, T,
+                                 int(relu_x), _stream()),
                "nef_chscale_bwd")
     return gx, gs
 
@@ -492,7 +494,7 @@ def mix_fwd(latent, z1, z2r, q, V, c1, c2=None):
     return D
 
 
-def mix_bwd(gD, latent, z1, z2r, q, V, c1, c2=None, upsampled=False):
+def mix_bwd(gD, latent, z1, z2r, q, V, c1, c2=None, upsampled=False, relu_z1=False):
     """`upsampled`: gD is the gradient wrt the x2-upsampled decoder input [3B,256,2T]; its adjoint is taken on the fly."""
     L = _lib.load()
     c1, c2, cdev = _choice(c1 if c2 is None else (c1, c2))
@@ -502,7 +504,9 @@ def mix_bwd(gD, latent, z1, z2r, q, V, c1, c2=None, upsampled=False):
     gz1, gz2r = torch.empty_like(z1), torch.empty_like(z2r)
     gq = torch.empty(B, 256, device=latent.device, dtype=torch.float32)
     fn = L.nef_mix_bwd_up if upsampled else L.nef_mix_bwd
-    _lib.check(fn(_p(gD), _p(latent), _p(z1), _p(z2r), _p(q), _p(gz1), _p(gz2r), _p(gq), B, V, T, c1, c2, cdev, _stream()),
+    # relu_z1: z1 is a ReLU output; gz1 also carries that ReLU's backward mask
+    _lib.check(fn(_p(gD), _p(latent), _p(z1), _p(z2r), _p(q), _p(gz1), _p(gz2r), _p(gq), B, V, T, c1, c2, cdev,
+                  int(relu_z1), _stream()),
                "nef_mix_bwd")
     return gz1, gz2r, gq
 

@@ -139,8 +139,9 @@ int nef_theta_encode(const float* theta, float* enc, int N, nef_stream_t stream)
  * Per-(sample, channel) scaling.  model_nefnet.py:122-123 (lead latents x mlp1) and :166,170,174,186.
  *   y[b][c][t] = x[b][c][t] * s[b*s_bs + c];  bwd: gx = gy * s, gs[b][c] = sum_t gy * x (gs dense [B][C]). */
 int nef_chscale_fwd(const float* x, const float* s, int64_t s_bs, float* y, int B, int C, int T, nef_stream_t stream);
+/* relu_x != 0: x is a ReLU output; gx is additionally masked with x > 0 (the gate its producer's backward starts with). */
 int nef_chscale_bwd(const float* gy, const float* x, const float* s, int64_t s_bs, float* gx, float* gs, int B,
-                    int C, int T, nef_stream_t stream);
+                    int C, int T, int relu_x, nef_stream_t stream);
 
 /* out = g * scale * (ref > 0)   (ReLU / dropout back-propagation gate), n elements. */
 int nef_gate(const float* g, const float* ref, float* out, float scale, int64_t n, nef_stream_t stream);
@@ -181,12 +182,13 @@ int nef_lead_mean(const float* z1, const float* z2r, float* latent, int B, int V
 int nef_mix_fwd(const float* latent, const float* z1, const float* z2r, const float* q, float* D, int B, int V,
                 int T, int c1, int c2, const int32_t* choice_dev, nef_stream_t stream);
 int nef_mix_bwd(const float* gD, const float* latent, const float* z1, const float* z2r, const float* q, float* gz1,
-                float* gz2r, float* gq, int B, int V, int T, int c1, int c2, const int32_t* choice_dev,
+                float* gz2r, float* gq, int B, int V, int T, int c1, int c2, const int32_t* choice_dev, int relu_z1,
                 nef_stream_t stream);
-/* nef_mix_bwd_up: same, but gU is the gradient wrt the x2-UPSAMPLED decoder input [3B][256][2T] (what the first decoder
+/* relu_z1 != 0 (both): z1 is a ReLU output; gz1 is additionally masked with z1 > 0.
+ * nef_mix_bwd_up: same, but gU is the gradient wrt the x2-UPSAMPLED decoder input [3B][256][2T] (what the first decoder
  * conv's backward-data writes); the upsampling adjoint (nef_upsample2_bwd) is taken while reading it. */
 int nef_mix_bwd_up(const float* gU, const float* latent, const float* z1, const float* z2r, const float* q, float* gz1,
-                float* gz2r, float* gq, int B, int V, int T, int c1, int c2, const int32_t* choice_dev,
+                float* gz2r, float* gq, int B, int V, int T, int c1, int c2, const int32_t* choice_dev, int relu_z1,
                 nef_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -434,6 +434,21 @@ def test_bn_relu_bwd_takes_the_upsampling_adjoint_on_the_fly(L):
         assert torch.equal(r, q)
 
 
+def test_relu_masks_folded_into_producers():
+    """chscale_bwd(relu_x) and mix_bwd(relu_z1) == the unmasked call followed by the gate pass, bit for bit."""
+    o = ops()
+    B, V, T = 3, 3, 130
+    x, gy, sc = g(rnd(B, 128 * V, T, seed=150)), g(rnd(B, 128 * V, T, seed=151)), g(rnd(B, 128 * V, seed=152))
+    gx, gs = o.chscale_bwd(gy, x, sc)
+    gxm, gsm = o.chscale_bwd(gy, x, sc, relu_x=True)
+    assert torch.equal(gxm, o.gate(gx, x)) and torch.equal(gsm, gs)
+    latent, z1, z2r = g(rnd(B, 256, T, seed=153)), g(rnd(B, 128 * V, T, seed=154)), g(rnd(B, 128 * V, T, seed=155))
+    q, gD = g(rnd(B, 256, seed=156)), g(rnd(3 * B, 256, T, seed=157))
+    ref = o.mix_bwd(gD, latent, z1, z2r, q, V, (1, 2))
+    got = o.mix_bwd(gD, latent, z1, z2r, q, V, (1, 2), relu_z1=True)
+    assert torch.equal(got[0], o.gate(ref[0], z1)) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+
+
 @pytest.mark.parametrize("reg", ["l1_loss", "l2_loss"])
 def test_loss(reg):
     o = ops()
