@@ -70,6 +70,10 @@ SIGNATURES = {
     "nef_lead_mean": (i32, [p, p, p, i32, i32, i32, p]),
     "nef_mix_fwd": (i32, [p, p, p, p, p, i32, i32, i32, i32, i32, p, p]),
     "nef_mix_bwd": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, i32, p]),
+    "nef_mix_fwd_shared": (i32, [p, p, p, p, p, i32, i32, i32, i32, i32, p, p]),
+    "nef_mix_bwd_shared_up": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, i32, p]),
+    "nef_pass_combine_fwd": (i32, [p, p, p, i32, i32, i32, p]),
+    "nef_pass_combine_bwd": (i32, [p, p, i32, i32, i32, p]),
     "nef_mix_bwd_up": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, i32, p]),
     "nef_upsample2_fwd": (i32, [p, p, i64, i32, p]),
     "nef_upsample2_bwd": (i32, [p, p, i64, i32, p]),

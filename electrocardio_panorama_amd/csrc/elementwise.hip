@@ -121,6 +121,10 @@ __global__ void lead_mean_kernel(const float* __restrict__ z1, const float* __re
 }
 
 // D[0] = q*latent ; D[1] = q*cat(z1[c1], latent[128:]) ; D[2] = q*cat(latent[:128], z2r[c2])     (:159-176)
+// SHARED: only the two DISTINCT inputs are written, D [2B][256][T] = (q*cat(z1m, z2m) | q*cat(z1[c1], z2r[c2])): the three
+// decoder inputs of model_nefnet.py:159-176 are q*cat(mean|mean), q*cat(pick|mean), q*cat(mean|pick), and the first
+// decoder conv is linear in the two channel halves, so it only has to see each half once (engine.decoder_fwd)
+template <bool SHARED>
 __global__ void mix_fwd_kernel(const float* __restrict__ latent, const float* __restrict__ z1,
                                const float* __restrict__ z2r, const float* __restrict__ q, float* __restrict__ D,
                                int B, int V, int T, int c1, int c2, const int32_t* __restrict__ choice_dev) {
@@ -138,8 +142,12 @@ __global__ void mix_fwd_kernel(const float* __restrict__ latent, const float* __
         for (int t = lane; t < T; t += 64) {
             const float l = lat[t], p = pick[t];
             d0[t] = f * l;
-            d0[pass + t] = f * (c < 128 ? p : l);
-            d0[2 * pass + t] = f * (c < 128 ? l : p);
+            if (SHARED) {
+                d0[pass + t] = f * p;
+            } else {
+                d0[pass + t] = f * (c < 128 ? p : l);
+                d0[2 * pass + t] = f * (c < 128 ? l : p);
+            }
         }
     }
 }
@@ -173,7 +181,8 @@ __device__ __forceinline__ float up2_adjoint(const float* __restrict__ gr, int T
 }
 
 // UP: gD is the gradient wrt the x2-UPSAMPLED decoder input [3B][256][2T]; its adjoint is taken while reading
-template <bool UP>
+// SHARED: gD has two passes (wrt q*cat(mean|mean) and q*cat(pick|pick), see mix_fwd_kernel<true>)
+template <bool UP, bool SHARED>
 __global__ void mix_bwd_kernel(const float* __restrict__ gD, const float* __restrict__ latent,
                                const float* __restrict__ z1, const float* __restrict__ z2r,
                                const float* __restrict__ q, float* __restrict__ gz1, float* __restrict__ gz2r,
@@ -201,13 +210,13 @@ __global__ void mix_bwd_kernel(const float* __restrict__ gD, const float* __rest
             if (UP) {
                 ga = up2_adjoint(g0, T, t);
                 gb = up2_adjoint(g0 + gpass, T, t);
-                gc = up2_adjoint(g0 + 2 * gpass, T, t);
+                gc = SHARED ? 0.f : up2_adjoint(g0 + 2 * gpass, T, t);
             } else {
-                ga = g0[t]; gb = g0[gpass + t]; gc = g0[2 * gpass + t];
+                ga = g0[t]; gb = g0[gpass + t]; gc = SHARED ? 0.f : g0[2 * gpass + t];
             }
             // pass that uses the picked lead for this half: D1 for the z1 half, D2 for the z2 half
-            const float g_pick = first ? gb : gc;
-            const float g_mean = first ? (ga + gc) : (ga + gb);
+            const float g_pick = SHARED ? gb : (first ? gb : gc);
+            const float g_mean = SHARED ? ga : (first ? (ga + gc) : (ga + gb));
             const float l = lat[t];
             const float pk = zsrc[(int64_t)pick_v * 128 * T + t];
             acc += g_mean * l + g_pick * pk;
@@ -1018,6 +1027,79 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
 
 extern "C" {
 
+int nef_mix_bwd_shared_up(const float* gU2, const float* latent, const float* z1, const float* z2r, const float* q,
+                          float* gz1, float* gz2r, float* gq, int B, int V, int T, int c1, int c2,
+                          const int32_t* choice_dev, int relu_z1, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gU2 && latent && z1 && z2r && q && gz1 && gz2r && gq, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && V > 0 && T > 1 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
+    hipLaunchKernelGGL((mix_bwd_kernel<true, true>), dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gU2,
+                       latent, z1, z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev, relu_z1);
+    return nef_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// First decoder conv shared between the three Standin passes: P2 [2B][2C][L] holds, per sample n, the half-conv of
+// the z1-type half (channels 0..C) and of the z2-type half (C..2C) of input n (n < B: the lead means, n >= B: the picked
+// leads).  c1[p] = A-half[ia(p)] + B-half[ib(p)] + bias with (ia, ib) = (mean, mean), (pick, mean), (mean, pick).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pass_combine_fwd_kernel(const float* __restrict__ P2, const float* __restrict__ bias,
+                                                               float* __restrict__ c1, int B, int C, int L) {
+    const int64_t row = blockIdx.x;                 // (b, c)
+    const int b = (int)(row / C), c = (int)(row % C);
+    const float bv = bias[c];
+    const float* am = P2 + ((int64_t)b * 2 * C + c) * L;
+    const float* bm = P2 + ((int64_t)b * 2 * C + C + c) * L;
+    const float* ap = P2 + ((int64_t)(B + b) * 2 * C + c) * L;
+    const float* bp = P2 + ((int64_t)(B + b) * 2 * C + C + c) * L;
+    float* o0 = c1 + ((int64_t)b * C + c) * L;
+    float* o1 = c1 + ((int64_t)(B + b) * C + c) * L;
+    float* o2 = c1 + ((int64_t)(2 * B + b) * C + c) * L;
+    for (int t = threadIdx.x; t < L; t += 256) {
+        const float a0 = am[t], b0 = bm[t], a1 = ap[t], b1 = bp[t];
+        o0[t] = a0 + b0 + bv;
+        o1[t] = a1 + b0 + bv;
+        o2[t] = a0 + b1 + bv;
+    }
+}
+
+// adjoint: gP2 A-half[mean] = g0 + g2, A-half[pick] = g1, B-half[mean] = g0 + g1, B-half[pick] = g2
+__global__ __launch_bounds__(256) void pass_combine_bwd_kernel(const float* __restrict__ gc1, float* __restrict__ gP2,
+                                                               int B, int C, int L) {
+    const int64_t row = blockIdx.x;
+    const int b = (int)(row / C), c = (int)(row % C);
+    const float* g0 = gc1 + ((int64_t)b * C + c) * L;
+    const float* g1 = gc1 + ((int64_t)(B + b) * C + c) * L;
+    const float* g2 = gc1 + ((int64_t)(2 * B + b) * C + c) * L;
+    float* am = gP2 + ((int64_t)b * 2 * C + c) * L;
+    float* bm = gP2 + ((int64_t)b * 2 * C + C + c) * L;
+    float* ap = gP2 + ((int64_t)(B + b) * 2 * C + c) * L;
+    float* bp = gP2 + ((int64_t)(B + b) * 2 * C + C + c) * L;
+    for (int t = threadIdx.x; t < L; t += 256) {
+        const float x0 = g0[t], x1 = g1[t], x2 = g2[t];
+        am[t] = x0 + x2;
+        ap[t] = x1;
+        bm[t] = x0 + x1;
+        bp[t] = x2;
+    }
+}
+
+int nef_pass_combine_fwd(const float* P2, const float* bias, float* c1, int B, int C, int L, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(P2 && bias && c1, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && C > 0 && L > 0 && (int64_t)B * C <= 0x7FFFFFFF, NEF_E_SHAPE);
+    hipLaunchKernelGGL(pass_combine_fwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, NEF_ST, P2, bias, c1, B, C, L);
+    return nef_launch_status();
+}
+
+int nef_pass_combine_bwd(const float* gc1, float* gP2, int B, int C, int L, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gc1 && gP2, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && C > 0 && L > 0 && (int64_t)B * C <= 0x7FFFFFFF, NEF_E_SHAPE);
+    hipLaunchKernelGGL(pass_combine_bwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, NEF_ST, gc1, gP2, B, C, L);
+    return nef_launch_status();
+}
+
 int nef_chscale_fwd(const float* x, const float* s, int64_t s_bs, float* y, int B, int C, int T, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(x && s && y, NEF_E_NULL);
@@ -1093,8 +1175,18 @@ int nef_mix_fwd(const float* latent, const float* z1, const float* z2r, const fl
     NEF_ENTER();
     NEF_REQUIRE(latent && z1 && z2r && q && D, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && V > 0 && T > 0 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
-    hipLaunchKernelGGL(mix_fwd_kernel, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, latent, z1,
+    hipLaunchKernelGGL(mix_fwd_kernel<false>, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, latent, z1,
                        z2r, q, D, B, V, T, c1, c2, choice_dev);
+    return nef_launch_status();
+}
+
+int nef_mix_fwd_shared(const float* latent, const float* z1, const float* z2r, const float* q, float* D2, int B, int V,
+                       int T, int c1, int c2, const int32_t* choice_dev, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(latent && z1 && z2r && q && D2, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && V > 0 && T > 0 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
+    hipLaunchKernelGGL(mix_fwd_kernel<true>, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, latent, z1,
+                       z2r, q, D2, B, V, T, c1, c2, choice_dev);
     return nef_launch_status();
 }
 
@@ -1104,7 +1196,7 @@ int nef_mix_bwd(const float* gD, const float* latent, const float* z1, const flo
     NEF_ENTER();
     NEF_REQUIRE(gD && latent && z1 && z2r && q && gz1 && gz2r && gq, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && V > 0 && T > 0 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
-    hipLaunchKernelGGL(mix_bwd_kernel<false>, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gD, latent,
+    hipLaunchKernelGGL((mix_bwd_kernel<false, false>), dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gD, latent,
                        z1, z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev, relu_z1);
     return nef_launch_status();
 }
@@ -1115,7 +1207,7 @@ int nef_mix_bwd_up(const float* gU, const float* latent, const float* z1, const 
     NEF_ENTER();
     NEF_REQUIRE(gU && latent && z1 && z2r && q && gz1 && gz2r && gq, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && V > 0 && T > 1 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
-    hipLaunchKernelGGL(mix_bwd_kernel<true>, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gU, latent,
+    hipLaunchKernelGGL((mix_bwd_kernel<true, false>), dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gU, latent,
                        z1, z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev, relu_z1);
     return nef_launch_status();
 }

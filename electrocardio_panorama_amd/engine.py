@@ -108,6 +108,17 @@ _DEC = (("decoder.1", "0", "1", 128), ("decoder.1", "3", "4", 128), ("decoder.3"
         ("decoder.3", "3", "4", 64))
 
 
+def _regroup_halves(w):
+    """decoder.1.double_conv.0.weight [128, 256, 3] -> grouped-conv weight [2*128, 128, 3] (group = input-channel half)."""
+    co, ci, k = w.shape
+    return w.view(co, 2, ci // 2, k).permute(1, 0, 2, 3).contiguous().view(2 * co, ci // 2, k)
+
+
+def _ungroup_halves(w2):
+    co2, cih, k = w2.shape
+    return w2.view(2, co2 // 2, cih, k).permute(1, 0, 2, 3).contiguous().view(co2 // 2, 2 * cih, k)
+
+
 def _fusable(D, passes):
     """The prologue variants index the per-pass BN affine by tile, so a column tile must not span two passes: always
     true once a sample fills a tile (2T >= 128, i.e. L >= 256); shorter sequences take the unfused path."""
@@ -140,15 +151,18 @@ def _decoder_fwd_unfused(D, P, Bf, passes, training, save):
     return out, (saved, x, out, passes, None)
 
 
-def decoder_fwd(D, P, Bf, passes, training, save):
+def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
     """Upsample -> (conv, BN, ReLU) x2 -> Upsample -> (conv, BN, ReLU) x2 -> conv -> sigmoid(x/3).  Only the conv
     outputs c1..c4 are materialised: the x2 upsampling and each BatchNorm-affine + ReLU are applied by the CONSUMING
     kernel while it stages its input (conv prologue modes, outconv prologue)."""
     if not _fusable(D, passes):
+        assert shared_B is None
         return _decoder_fwd_unfused(D, P, Bf, passes, training, save)
     x, pro_in = D, None                # pro_in: (a, b) of the BN whose output feeds the next conv
     saved = []
-    N = D.shape[0]
+    # shared_B: D holds only the two distinct inputs of the three Standin passes (ops.mix_fwd_shared); the first conv
+    # runs once per distinct channel half (a 2-group conv) and pass_combine_fwd assembles the three pass outputs
+    N = D.shape[0] if shared_B is None else 3 * shared_B
     for li, (blk, cv, bn, cout) in enumerate(_DEC):
         wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
         if li == 2:
@@ -162,7 +176,11 @@ def decoder_fwd(D, P, Bf, passes, training, save):
             mode = (2 if li == 0 else 0) | (1 if pro_in is not None else 0)
             pro = (mode, pro_in[0], pro_in[1], pro_in[2]) if pro_in is not None else (mode, None, None, 1)
             up_after = bool(mode & 2)
-        c = ops.conv(GV.dense(x_in, 1), ops.pack_weight(P[wname], 1), cout, 3, bias=P[bname], pro=pro)
+        if li == 0 and shared_B is not None:
+            p2 = ops.conv(GV.dense(x_in, 2), ops.pack_weight(_regroup_halves(P[wname]), 2), cout, 3, pro=pro)
+            c = ops.pass_combine_fwd(p2, P[bname], shared_B)
+        else:
+            c = ops.conv(GV.dense(x_in, 1), ops.pack_weight(P[wname], 1), cout, 3, bias=P[bname], pro=pro)
         if training:
             mean, invstd, a, b = ops.bn_train_stats(c, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
                                                     Bf[pre + ".running_var"], passes, BN_EPS, BN_MOM)
@@ -177,11 +195,12 @@ def decoder_fwd(D, P, Bf, passes, training, save):
             saved.append((x_in, c, mean, invstd, a, b, pro, up_after))
         x, pro_in = c, (a, b, Bp)
     out = ops.outconv_fwd(x, P["decoder.4.weight"], P["decoder.4.bias"], pro=pro_in)
-    return out, (saved, x, out, passes, pro_in)
+    return out, (saved, x, out, passes, pro_in, shared_B)
 
 
 def decoder_bwd(dsaved, g_out, P, grads, side=None):
-    saved, c4, out, passes, pro4 = dsaved
+    saved, c4, out, passes, pro4 = dsaved[:5]
+    shared_B = dsaved[5] if len(dsaved) > 5 else None
     side = side or ops._Inline()
     grads["decoder.4.weight"], grads["decoder.4.bias"] = side.run(
         lambda: ops.outconv_bwd_weight(g_out, out, c4, pro=pro4), g_out, out, c4)
@@ -201,16 +220,23 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
             gc, gg, gbeta, gbias = ops.bn_relu_bwd(g, c, P[pre + ".weight"], mean, invstd, a, b, passes,
                                                    with_chan_sum=True)
         grads[pre + ".weight"], grads[pre + ".bias"], grads[bname] = gg, gbeta, gbias
-        gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
-        grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro), x, gc)
-        g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True), x.shape[1], 3, role="conv_bwd_data")
+        if li == 0 and shared_B is not None:
+            gp2 = ops.pass_combine_bwd(gc)                               # [2B, 2*128, 2T]: per distinct half-conv output
+            gpv, xv = GV.dense(gp2, 2), GV.dense(x, 2)
+            grads[wname] = side.run(lambda: _ungroup_halves(ops.conv_bwd_weight(xv, gpv, 3, pro=pro)), x, gp2)
+            g = ops.conv(gpv, ops.pack_weight(_regroup_halves(P[wname]), 2, flip=True), x.shape[1] // 2, 3,
+                         role="conv_bwd_data")
+        else:
+            gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
+            grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro), x, gc)
+            g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True), x.shape[1], 3, role="conv_bwd_data")
         # back through the x2 upsampling in front of this layer: the next BatchNorm backward takes the adjoint while it
         # reads (rows of 4k >= 8 samples), otherwise it is a pass of its own
         g_is_up = bool(up_after and li > 0 and c.shape[2] % 8 == 0 and c.shape[2] >= 16)
         if up_after and li > 0 and not g_is_up:
             g = ops.upsample2_bwd(g)
     # the adjoint of the FIRST upsampling is left to the consumer (mix_bwd takes it while reading)
-    return g, bool(saved[0][7])
+    return g, bool(saved[0][7]), shared_B is not None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -259,8 +285,12 @@ def _head_fwd(P, Bf, z1, z2r, q_theta, V, rest_theta, phase, training, lead_choi
     save = sv is not None
     latent = ops.lead_mean(z1, z2r, V)
     q = ops.theta_mlp_fwd(q_theta, P["mlp2.weight"], P["mlp2.bias"])             # [B, 256]
-    D = ops.mix_fwd(latent, z1, z2r, q, V, lead_choice)                           # [3B, 256, T]
-    out3, dsv = decoder_fwd(D, P, Bf, 3, training, save)
+    if 2 * latent.shape[2] >= 128:     # (_fusable) the first decoder conv sees each distinct channel half once
+        D2 = ops.mix_fwd_shared(latent, z1, z2r, q, V, lead_choice)               # [2B, 256, T]
+        out3, dsv = decoder_fwd(D2, P, Bf, 3, training, save, shared_B=B)
+    else:
+        D = ops.mix_fwd(latent, z1, z2r, q, V, lead_choice)                       # [3B, 256, T]
+        out3, dsv = decoder_fwd(D, P, Bf, 3, training, save)
     outs = (out3[0:B], out3[B:2 * B], out3[2 * B:3 * B])
     if save:
         sv.update(z1=z1, z2r=z2r, latent=latent, q=q, q_theta=q_theta, choice=lead_choice, dec=dsv, hB=B, hV=V)
@@ -431,10 +461,14 @@ def _head_bwd(P, sv, g_outs, grads, side, relu_z1=False):
     like = sv["dec"][2]        # stacked decoder output [3B, 1, L]
     parts = [g if g is not None else torch.zeros_like(like[0:B]) for g in g_outs]
     g_out = torch.cat([p_.contiguous() for p_ in parts], dim=0)
-    gD, up = decoder_bwd(sv["dec"], g_out, P, grads, side)
+    gD, up, shared = decoder_bwd(sv["dec"], g_out, P, grads, side)
     # relu_z1: z1 is the ReLU output of z1_conv's block, whose backward would start by masking gz1 -- done here
-    gz1, gz2r, gq = ops.mix_bwd(gD, sv["latent"], sv["z1"], sv["z2r"], sv["q"], V, sv["choice"], upsampled=up,
-                                relu_z1=relu_z1)
+    if shared:
+        gz1, gz2r, gq = ops.mix_bwd_shared_up(gD, sv["latent"], sv["z1"], sv["z2r"], sv["q"], V, sv["choice"],
+                                              relu_z1=relu_z1)
+    else:
+        gz1, gz2r, gq = ops.mix_bwd(gD, sv["latent"], sv["z1"], sv["z2r"], sv["q"], V, sv["choice"], upsampled=up,
+                                    relu_z1=relu_z1)
     gW2, gb2 = side.run(lambda: ops.theta_mlp_bwd(sv["q_theta"], gq, 256), gq)
     grads["mlp2.weight"], grads["mlp2.bias"] = gW2, gb2
     return gz1, gz2r

@@ -494,6 +494,51 @@ def mix_fwd(latent, z1, z2r, q, V, c1, c2=None):
     return D
 
 
+def mix_fwd_shared(latent, z1, z2r, q, V, c1, c2=None):
+    """The two DISTINCT decoder inputs, [2B,256,T] = (q*cat(z1m|z2m) | q*cat(z1[c1]|z2r[c2]))."""
+    L = _lib.load()
+    c1, c2, cdev = _choice(c1 if c2 is None else (c1, c2))
+    _chk(latent), _chk(q)
+    B, _, T = latent.shape
+    D2 = torch.empty(2 * B, 256, T, device=latent.device, dtype=torch.float32)
+    _lib.check(L.nef_mix_fwd_shared(_p(latent), _p(z1), _p(z2r), _p(q), _p(D2), B, V, T, c1, c2, cdev, _stream()),
+               "nef_mix_fwd_shared")
+    return D2
+
+
+def mix_bwd_shared_up(gU2, latent, z1, z2r, q, V, c1, c2=None, relu_z1=False):
+    """mix_bwd for the two-pass gradient wrt the x2-upsampled shared input, gU2 [2B,256,2T]."""
+    L = _lib.load()
+    c1, c2, cdev = _choice(c1 if c2 is None else (c1, c2))
+    _chk(gU2)
+    B, _, T = latent.shape
+    assert gU2.shape == (2 * B, 256, 2 * T)
+    gz1, gz2r = torch.empty_like(z1), torch.empty_like(z2r)
+    gq = torch.empty(B, 256, device=latent.device, dtype=torch.float32)
+    _lib.check(L.nef_mix_bwd_shared_up(_p(gU2), _p(latent), _p(z1), _p(z2r), _p(q), _p(gz1), _p(gz2r), _p(gq), B, V, T, c1,
+                                       c2, cdev, int(relu_z1), _stream()), "nef_mix_bwd_shared_up")
+    return gz1, gz2r, gq
+
+
+def pass_combine_fwd(P2, bias, B):
+    """P2 [2B,2C,L] (A | B half-conv outputs of the mean / picked inputs) -> c1 [3B,C,L] of the three Standin passes."""
+    L = _lib.load()
+    _chk(P2), _chk(bias)
+    C2, Ln = P2.shape[1], P2.shape[2]
+    c1 = torch.empty(3 * B, C2 // 2, Ln, device=P2.device, dtype=torch.float32)
+    _lib.check(L.nef_pass_combine_fwd(_p(P2), _p(bias), _p(c1), B, C2 // 2, Ln, _stream()), "nef_pass_combine_fwd")
+    return c1
+
+
+def pass_combine_bwd(gc1):
+    L = _lib.load()
+    _chk(gc1)
+    B3, Ct, Ln = gc1.shape
+    gP2 = torch.empty(2 * (B3 // 3), 2 * Ct, Ln, device=gc1.device, dtype=torch.float32)
+    _lib.check(L.nef_pass_combine_bwd(_p(gc1), _p(gP2), B3 // 3, Ct, Ln, _stream()), "nef_pass_combine_bwd")
+    return gP2
+
+
 def mix_bwd(gD, latent, z1, z2r, q, V, c1, c2=None, upsampled=False, relu_z1=False):
     """`upsampled`: gD is the gradient wrt the x2-upsampled decoder input [3B,256,2T]; its adjoint is taken on the fly."""
     L = _lib.load()

@@ -191,6 +191,22 @@ int nef_mix_bwd_up(const float* gU, const float* latent, const float* z1, const 
                 float* gz2r, float* gq, int B, int V, int T, int c1, int c2, const int32_t* choice_dev, int relu_z1,
                 nef_stream_t stream);
 
+/* Shared first decoder conv (train step): the three decoder inputs of model_nefnet.py:159-176 are
+ * q*cat(z1m|z2m), q*cat(z1[c1]|z2m), q*cat(z1m|z2r[c2]) and decoder.1.double_conv.0 is linear in the two channel halves,
+ * so each distinct half goes through its half of the conv once (4 half-convs instead of 6):
+ *   nef_mix_fwd_shared   : D2 [2B][256][T] = (q*cat(z1m|z2m) | q*cat(z1[c1]|z2r[c2]))
+ *   (grouped conv, G = 2, on D2 with the weight regrouped to [2*Cout][Cin/2][3] -> P2 [2B][2C][L])
+ *   nef_pass_combine_fwd : c1[p][b][c] = P2 A-half[ia(p)] + P2 B-half[ib(p)] + bias[c],  (ia,ib) = (m,m),(pick,m),(m,pick)
+ *   nef_pass_combine_bwd : its adjoint, gc1 [3B][C][L] -> gP2 [2B][2C][L]
+ *   nef_mix_bwd_shared_up: nef_mix_bwd_up for the two-pass gradient gU2 [2B][256][2T] (wrt the upsampled D2). */
+int nef_mix_fwd_shared(const float* latent, const float* z1, const float* z2r, const float* q, float* D2, int B, int V,
+                       int T, int c1, int c2, const int32_t* choice_dev, nef_stream_t stream);
+int nef_mix_bwd_shared_up(const float* gU2, const float* latent, const float* z1, const float* z2r, const float* q,
+                          float* gz1, float* gz2r, float* gq, int B, int V, int T, int c1, int c2,
+                          const int32_t* choice_dev, int relu_z1, nef_stream_t stream);
+int nef_pass_combine_fwd(const float* P2, const float* bias, float* c1, int B, int C, int L, nef_stream_t stream);
+int nef_pass_combine_bwd(const float* gc1, float* gP2, int B, int C, int L, nef_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Decoder pieces.  model_nefnet.py:10-27,101-107.
  * Upsample(scale 2, linear, align_corners=False): x [N][Tin] rows -> y [N][2Tin]. */

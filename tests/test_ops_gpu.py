@@ -449,6 +449,39 @@ def test_relu_masks_folded_into_producers():
     assert torch.equal(got[0], o.gate(ref[0], z1)) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
 
 
+def test_shared_first_conv_pieces():
+    """mix_fwd_shared / pass_combine_fwd / pass_combine_bwd / mix_bwd_shared_up against their definitions (torch CPU)."""
+    o = ops()
+    B, V, T, c1, c2 = 3, 3, 66, 2, 0
+    lat, z1, z2r, q = rnd(B, 256, T, seed=160), rnd(B, 128 * V, T, seed=161), rnd(B, 128 * V, T, seed=162), rnd(B, 256, seed=163)
+    z1r, z2rr, qr, latr = (t.clone().double().requires_grad_(True) for t in (z1, z2r, q, lat))
+    pick = torch.cat([z1r[:, 128 * c1:128 * (c1 + 1)], z2rr[:, 128 * c2:128 * (c2 + 1)]], 1)
+    D2ref = torch.cat([qr[:, :, None] * latr, qr[:, :, None] * pick], 0)
+    D2 = o.mix_fwd_shared(g(lat), g(z1), g(z2r), g(q), V, (c1, c2))
+    assert D2.shape == (2 * B, 256, T) and rel(D2, D2ref) < 1e-6
+    # backward through the x2 upsampling: latent is (z1 mean | z2r mean) in the real graph; here an independent tensor,
+    # so compare the three gradients the kernel produces (gz1, gz2r with the 1/V mean spread, gq)
+    gU2 = rnd(2 * B, 256, 2 * T, seed=164)
+    up = F.interpolate(D2ref, scale_factor=2, mode="linear", align_corners=False)
+    (up * gU2.double()).sum().backward()
+    gz1, gz2r, gq = o.mix_bwd_shared_up(g(gU2), g(lat), g(z1), g(z2r), g(q), V, (c1, c2))
+    glat = latr.grad                                         # d/d(mean input): spread over the V leads by 1/V
+    exp_z1 = z1r.grad + glat[:, :128].repeat(1, V, 1) / V
+    exp_z2 = z2rr.grad + glat[:, 128:].repeat(1, V, 1) / V
+    assert rel(gz1, exp_z1) < 1e-5 and rel(gz2r, exp_z2) < 1e-5 and rel(gq, qr.grad) < 1e-5
+    # combine: c1[p] = A[ia] + B[ib] + bias and its adjoint
+    C, L = 8, 37
+    P2, bias, gc1 = rnd(2 * B, 2 * C, L, seed=165), rnd(C, seed=166), rnd(3 * B, C, L, seed=167)
+    A, Bh = P2[:, :C], P2[:, C:]
+    ref = torch.cat([A[:B] + Bh[:B], A[B:] + Bh[:B], A[:B] + Bh[B:]], 0) + bias[None, :, None]
+    c1t = o.pass_combine_fwd(g(P2), g(bias), B)
+    assert torch.equal(c1t.cpu(), ref)
+    gP2 = o.pass_combine_bwd(g(gc1)).cpu()
+    g0, g1, g2 = gc1[:B], gc1[B:2 * B], gc1[2 * B:]
+    assert torch.equal(gP2[:B, :C], g0 + g2) and torch.equal(gP2[B:, :C], g1)
+    assert torch.equal(gP2[:B, C:], g0 + g1) and torch.equal(gP2[B:, C:], g2)
+
+
 @pytest.mark.parametrize("reg", ["l1_loss", "l2_loss"])
 def test_loss(reg):
     o = ops()
@@ -537,7 +570,7 @@ def test_decoder_three_passes(T):
     for k in Bf:
         assert rel(Bfd[k].float(), Bfr[k].float()) < 1e-5, k
     grads = {}
-    gD, up = engine.decoder_bwd(dsv, g(gy), Pd, grads)
+    gD, up, _ = engine.decoder_bwd(dsv, g(gy), Pd, grads)
     if up:                                   # the first upsampling's adjoint is left to the consumer (mix_bwd)
         gD = ops().upsample2_bwd(gD)
     assert rel(gD, gD64) < GRAD_TOL + 2 * rel(gD32, gD64), (rel(gD, gD64), rel(gD32, gD64))
