@@ -86,6 +86,7 @@ SIGNATURES = {
     "nef_bn_bwd_ws_bytes": (sz, [i32, i32, i32]),
     "nef_bn_relu_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p]),
     "nef_bn_relu_bwd_up": (i32, [p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p]),
+    "nef_bn_relu_bwd_combine3": (i32, [p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, p]),
     "nef_bn_bwd_outconv_ws_bytes": (sz, [i32, i32, i32, i32]),
     "nef_bn_relu_bwd_outconv": (i32, [p, p, p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p]),
     "nef_outconv_fwd": (i32, [p, p, p, p, i32, i32, i32, p]),

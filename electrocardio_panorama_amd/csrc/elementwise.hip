@@ -709,6 +709,57 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict
     }
 }
 
+// BatchNorm-backward apply of the FIRST decoder BatchNorm with the pass adjoint of pass_combine_bwd fused in: one
+// workgroup per (sample, channel) computes the three passes' gx and writes the four half-conv output gradients
+// (A[mean] = g0 + g2, A[pick] = g1, B[mean] = g0 + g1, B[pick] = g2) -- gx itself is only needed for its row sums.
+__global__ __launch_bounds__(256) void bn_bwd_apply_combine3(const float* __restrict__ gy, const float* __restrict__ x,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ a,
+                                                             const float* __restrict__ b, const float* __restrict__ coef,
+                                                             float* __restrict__ gP2, double* __restrict__ rowsum, int Bp,
+                                                             int C, int L) {
+    __shared__ double sm[4];
+    const int bb = blockIdx.x / C, c = blockIdx.x % C;
+    float mf[3], is[3], af[3], bf[3], k1[3], k2[3];
+    const float* xr[3];
+    const float* gr[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int pc = p * C + c;
+        mf[p] = mean[pc]; is[p] = invstd[pc]; af[p] = a[pc]; bf[p] = b[pc];
+        k1[p] = coef[pc * 2]; k2[p] = coef[pc * 2 + 1];
+        const int64_t off = (((int64_t)p * Bp + bb) * C + c) * L;
+        xr[p] = x + off;
+        gr[p] = gy + off;
+    }
+    float* am = gP2 + ((int64_t)bb * 2 * C + c) * L;
+    float* bm = gP2 + ((int64_t)bb * 2 * C + C + c) * L;
+    float* ap = gP2 + ((int64_t)(Bp + bb) * 2 * C + c) * L;
+    float* bp = gP2 + ((int64_t)(Bp + bb) * 2 * C + C + c) * L;
+    double rs[3] = {0.0, 0.0, 0.0};
+    for (int t = threadIdx.x; t < L; t += 256) {
+        float o[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const float xv = xr[p][t];
+            const float g = fmaf(xv, af[p], bf[p]) > 0.f ? gr[p][t] : 0.f;
+            o[p] = af[p] * (g - k1[p] - (xv - mf[p]) * is[p] * k2[p]);
+            rs[p] += (double)o[p];
+        }
+        am[t] = o[0] + o[2];
+        ap[t] = o[1];
+        bm[t] = o[0] + o[1];
+        bp[t] = o[2];
+    }
+    if (rowsum) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const double v = nef_block_sum_d(rs[p], sm);
+            if (threadIdx.x == 0) rowsum[((int64_t)p * Bp + bb) * C + c] = v;
+        }
+    }
+}
+
 // out[c] = sum over rows (p, b) of rowsum[(p*Bp + b)*C + c]; one workgroup per channel, fixed reduction tree
 __global__ __launch_bounds__(256) void rowsum_to_channel(const double* __restrict__ rowsum, float* __restrict__ out,
                                                          int NB, int C) {
@@ -1345,6 +1396,28 @@ int nef_bn_relu_bwd_up(const float* gu, const float* x, const float* mean, const
     if (gx_chan_sum)
         hipLaunchKernelGGL(rowsum_to_channel, dim3(C), dim3(256), 0, NEF_ST, (const double*)rowsum, gx_chan_sum,
                            P * Bp, C);
+    return nef_launch_status();
+}
+
+int nef_bn_relu_bwd_combine3(const float* gy, const float* x, const float* mean, const float* invstd, const float* a,
+                             const float* b, float* gP2, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
+                             size_t ws_bytes, int Bp, int C, int L, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gy && x && mean && invstd && a && b && gP2 && ggamma && gbeta && ws, NEF_E_NULL);
+    NEF_REQUIRE(Bp > 0 && C > 0 && L > 0 && (int64_t)Bp * C <= 0x7FFFFFFF, NEF_E_SHAPE);
+    NEF_REQUIRE(ws_bytes >= nef_bn_bwd_ws_bytes(3, Bp, C), NEF_E_WORKSPACE);
+    double* part = (double*)ws;
+    float* coef = (float*)((char*)ws + (size_t)3 * C * BN_SPLIT * 2 * sizeof(double));
+    double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(3, C)) : nullptr;
+    hipLaunchKernelGGL(bn_bwd_partial<0>, dim3(3 * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part, 3,
+                       Bp, C, L, (const float*)nullptr);
+    hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma, gbeta,
+                       3, Bp, C, L);
+    hipLaunchKernelGGL(bn_bwd_apply_combine3, dim3((unsigned)(Bp * C)), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b,
+                       (const float*)coef, gP2, rowsum, Bp, C, L);
+    if (gx_chan_sum)
+        hipLaunchKernelGGL(rowsum_to_channel, dim3(C), dim3(256), 0, NEF_ST, (const double*)rowsum, gx_chan_sum, 3 * Bp,
+                           C);
     return nef_launch_status();
 }
 

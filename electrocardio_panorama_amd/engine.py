@@ -214,6 +214,9 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
         wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
         if li == 3 and fuse_last:
             gc, gg, gbeta, gbias = ops.bn_relu_bwd_outconv(g_out, out, P["decoder.4.weight"], c, mean, invstd, a, b, passes)
+        elif li == 0 and shared_B is not None and not g_is_up:
+            # gc is the per-half gradient [2B, 2*128, 2T] straight away (pass_combine_bwd fused into the apply pass)
+            gc, gg, gbeta, gbias = ops.bn_relu_bwd_combine3(g, c, mean, invstd, a, b)
         elif g_is_up:
             gc, gg, gbeta, gbias = ops.bn_relu_bwd_up(g, c, mean, invstd, a, b, passes)
         else:
@@ -221,7 +224,7 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
                                                    with_chan_sum=True)
         grads[pre + ".weight"], grads[pre + ".bias"], grads[bname] = gg, gbeta, gbias
         if li == 0 and shared_B is not None:
-            gp2 = ops.pass_combine_bwd(gc)                               # [2B, 2*128, 2T]: per distinct half-conv output
+            gp2 = gc if gc.shape[0] == 2 * shared_B else ops.pass_combine_bwd(gc)   # [2B, 2*128, 2T]
             gpv, xv = GV.dense(gp2, 2), GV.dense(x, 2)
             grads[wname] = side.run(lambda: _ungroup_halves(ops.conv_bwd_weight(xv, gpv, 3, pro=pro)), x, gp2)
             g = ops.conv(gpv, ops.pack_weight(_regroup_halves(P[wname]), 2, flip=True), x.shape[1] // 2, 3,

@@ -644,6 +644,23 @@ def bn_relu_bwd(gy, x, gamma, mean, invstd, a, b, P, with_chan_sum=False):
     return (gx, gg, gb, gs) if with_chan_sum else (gx, gg, gb)
 
 
+def bn_relu_bwd_combine3(gy, x, mean, invstd, a, b):
+    """pass_combine_bwd(bn_relu_bwd(gy, x, ..., P=3)) in one pass: returns (gP2 [2B,2C,L], ggamma, gbeta, chan sum of gx)."""
+    L = _lib.load()
+    _chk(gy), _chk(x)
+    N, Ct, Ln = x.shape
+    Bp = N // 3
+    gP2 = torch.empty(2 * Bp, 2 * Ct, Ln, device=x.device, dtype=torch.float32)
+    gg = torch.empty(Ct, device=x.device, dtype=torch.float32)
+    gb = torch.empty(Ct, device=x.device, dtype=torch.float32)
+    gs = torch.empty(Ct, device=x.device, dtype=torch.float32)
+    n = L.nef_bn_bwd_ws_bytes(3, Bp, Ct)
+    ws = workspace(n, x.device)
+    _lib.check(L.nef_bn_relu_bwd_combine3(_p(gy), _p(x), _p(mean), _p(invstd), _p(a), _p(b), _p(gP2), _p(gg), _p(gb),
+                                          _p(gs), _p(ws), n, Bp, Ct, Ln, _stream()), "nef_bn_relu_bwd_combine3")
+    return gP2, gg, gb, gs
+
+
 def bn_relu_bwd_up(gu, x, mean, invstd, a, b, P):
     """bn_relu_bwd(upsample2_bwd(gu), x, ...) with the upsampling adjoint taken on the fly; gu [N,C,2L].
     Returns (gx, ggamma, gbeta, sum_{b,t} gx per channel)."""

@@ -254,6 +254,11 @@ int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const f
 int nef_bn_relu_bwd_up(const float* gu, const float* x, const float* mean, const float* invstd, const float* a,
                        const float* b, float* gx, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
                        size_t ws_bytes, int P, int Bp, int C, int L, nef_stream_t stream);
+/* nef_bn_relu_bwd_combine3: nef_bn_relu_bwd (P = 3) followed by nef_pass_combine_bwd in one pass: writes gP2 [2Bp][2C][L]
+ * instead of gx (only gx's per-channel sum is kept).  ws: nef_bn_bwd_ws_bytes(3, Bp, C). */
+int nef_bn_relu_bwd_combine3(const float* gy, const float* x, const float* mean, const float* invstd, const float* a,
+                             const float* b, float* gP2, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
+                             size_t ws_bytes, int Bp, int C, int L, nef_stream_t stream);
 size_t nef_bn_bwd_outconv_ws_bytes(int P, int Bp, int C, int L);
 int nef_bn_relu_bwd_outconv(const float* gout, const float* out, const float* wout, const float* x, const float* mean,
                             const float* invstd, const float* a, const float* b, float* gx, float* ggamma, float* gbeta,

@@ -482,6 +482,19 @@ def test_shared_first_conv_pieces():
     assert torch.equal(gP2[:B, C:], g0 + g1) and torch.equal(gP2[B:, C:], g2)
 
 
+def test_bn_relu_bwd_combine3_equals_two_calls():
+    o = ops()
+    Bp, C, L = 2, 16, 301
+    N = 3 * Bp
+    x, gy = rnd(N, C, L, seed=170).to(DEV), rnd(N, C, L, seed=171).to(DEV)
+    gamma, beta = (rnd(C, seed=172) + 1.2).to(DEV), rnd(C, seed=173, scale=0.3).to(DEV)
+    mean, invstd, a, b = o.bn_train_stats(x, gamma, beta, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), 3)
+    gx, gg, gb, gs = o.bn_relu_bwd(gy, x, gamma, mean, invstd, a, b, 3, with_chan_sum=True)
+    got = o.bn_relu_bwd_combine3(gy, x, mean, invstd, a, b)
+    assert torch.equal(got[0], o.pass_combine_bwd(gx))
+    assert torch.equal(got[1], gg) and torch.equal(got[2], gb) and rel(got[3], gs) < 1e-6
+
+
 @pytest.mark.parametrize("reg", ["l1_loss", "l2_loss"])
 def test_loss(reg):
     o = ops()
