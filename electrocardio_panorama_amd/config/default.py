@@ -22,6 +22,7 @@ _DEFAULTS = {
         "train_data_mode": "normal",
         "super_mode": "normal",
         "weighted_sample": False,
+        "synthetic": False,            # (not in the reference) train / validate on seeded synthetic `meta` batches
     },
     "MODEL": {
         "model": "modelv2",            # 'model_nefnet' selects Nef-Net

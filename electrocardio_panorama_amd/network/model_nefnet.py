@@ -58,6 +58,8 @@ class _NefNetFn(torch.autograd.Function):
                                      training=model.training, drop=drop, lead_choice=choice, save=True,
                                      status=model._status)
         ctx.sv, ctx.names, ctx.P, ctx.bwd = sv, names, P, model._engine_bwd
+        if model.keep_saved:
+            model.last_saved = sv
         return outs
 
     @staticmethod
@@ -95,10 +97,13 @@ class Model_nefnet(nn.Module):
         self._extra_layers()
         self.dropout_p = engine.DROP_P
         self.dropout_masks = None      # test hook: {site: uint8 keep-mask} replayed instead of the RNG
+        self.keep_saved = False        # test hook: expose the saved forward state of the last train-phase call
+        self.last_saved = None
         # 'fp32' (reference arithmetic) or 'fp16': eval-mode view sweeps (phase 'val'/'test' rest_out, gen_ecg) on the
         # fp16 matrix cores with fp32 accumulation -- opt-in, gated at 2e-3 rel-L2 against the fp32 path
         self.panorama_dtype = 'fp32'
         self._drop_calls = 0
+        self.dropout_epoch = 0         # set by Solver.train: a resumed run must not replay the masks of epoch 0
         self._status = None
 
     # ------------------------------------------------------------------ helpers
@@ -128,13 +133,14 @@ class Model_nefnet(nn.Module):
         return t.detach().to(torch.float32).contiguous()
 
     def _drop_cfg(self):
-        """Counter-RNG seed of this forward: global seed + call counter, offset per data-parallel rank so that shards
-        draw independent masks (parameters and Standin lead choices stay identical across ranks)."""
+        """Counter-RNG seed of this forward: global seed + epoch + call counter, offset per data-parallel rank so that
+        shards draw independent masks (parameters and Standin lead choices stay identical across ranks)."""
         self._drop_calls += 1
         rank = torch.distributed.get_rank() if (torch.distributed.is_available() and
                                                 torch.distributed.is_initialized()) else 0
         return engine.DropCfg(self.training, self.dropout_p, self.dropout_masks,
-                              seed=(torch.initial_seed() + self._drop_calls + rank * 0x9E3779B1) & 0x7FFFFFFFFFFF)
+                              seed=(torch.initial_seed() + self._drop_calls + int(self.dropout_epoch) * 0x1000003
+                                    + rank * 0x9E3779B1) & 0x7FFFFFFFFFFF)
 
     def _half_sweep(self):
         if self.panorama_dtype not in ('fp32', 'fp16'):

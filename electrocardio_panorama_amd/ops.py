@@ -42,6 +42,19 @@ def _timed(tag):
     return e
 
 
+def _hbm(name, *tensors):
+    """bench.py hook for the HBM-bound passes: the tag carries the launch's ALGORITHMIC bytes (its external inputs and
+    outputs, each counted once), so bytes / event time is the pass's achieved bandwidth."""
+    if PROFILE is None:
+        return None
+    return _timed(("hbm", name, sum(t.numel() * t.element_size() for t in tensors if t is not None)))
+
+
+def _done(ev):
+    if ev is not None:
+        ev.record()
+
+
 def workspace(nbytes, device):
     """Caller-owned scratch, grown on demand, reused by stream-ordered calls (one buffer per stream)."""
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
@@ -139,7 +152,9 @@ def stem_fwd(x, w):
     _chk(x), _chk(w)
     B, V, Ln = x.shape
     y = torch.empty(B, 128 * V, Ln // 4, device=x.device, dtype=torch.float32)
+    ev = _hbm("stem_fwd", x, y)
     _lib.check(L.nef_stem_fwd(_p(x), _p(w), _p(y), B, V, Ln, _stream()), "nef_stem_fwd")
+    _done(ev)
     return y
 
 
@@ -150,7 +165,9 @@ def stem_bwd_weight(x, w, gy):
     gw = torch.empty_like(w)
     n = L.nef_stem_bwd_ws_bytes(V)
     ws = workspace(n, x.device)
+    ev = _hbm("stem_bwd_weight", x, gy)
     _lib.check(L.nef_stem_bwd_weight(_p(x), _p(w), _p(gy), _p(gw), _p(ws), n, B, V, Ln, _stream()), "nef_stem_bwd_weight")
+    _done(ev)
     return gw
 
 
@@ -366,7 +383,9 @@ def chscale_fwd(x, s, s_bs=None):
     _chk(x)
     B, Ct, T = x.shape
     y = torch.empty_like(x)
+    ev = _hbm("chscale_fwd", x, y)
     _lib.check(L.nef_chscale_fwd(_p(x), _p(s), Ct if s_bs is None else s_bs, _p(y), B, Ct, T, _stream()), "nef_chscale_fwd")
+    _done(ev)
     return y
 
 
@@ -377,9 +396,11 @@ def chscale_bwd(gy, x, s, s_bs=None, relu_x=False):
     B, Ct, T = x.shape
     gx = torch.empty_like(x)
     gs = torch.empty(B, Ct, device=x.device, dtype=torch.float32)
+    ev = _hbm("chscale_bwd", gy, x, gx)
     _lib.check(L.nef_chscale_bwd(_p(gy), _p(x), _p(s), Ct if s_bs is None else s_bs, _p(gx), _p(gs), B, Ct, T,
                                  int(relu_x), _stream()),
                "nef_chscale_bwd")
+    _done(ev)
     return gx, gs
 
 
@@ -443,7 +464,9 @@ def roi_unpool_fwd(zseg, rois, T, status=None):
     _chk(zseg), _chk(rois, torch.int64)
     B, Ct = zseg.shape[0], zseg.shape[1]
     out = torch.empty(B, Ct, T, device=zseg.device, dtype=torch.float32)
+    ev = _hbm("roi_unpool_fwd", zseg, out)
     _lib.check(L.nef_roi_unpool_fwd(_p(zseg), _p(rois), _p(out), _p(status), B, Ct, T, _stream()), "nef_roi_unpool_fwd")
+    _done(ev)
     return out
 
 
@@ -452,7 +475,9 @@ def roi_unpool_bwd(gout, rois):
     _chk(gout), _chk(rois, torch.int64)
     B, Ct, T = gout.shape
     gz = torch.empty(B, Ct, N_SEG, 2 * ROI_BINS, device=gout.device, dtype=torch.float32)
+    ev = _hbm("roi_unpool_bwd", gout, gz)
     _lib.check(L.nef_roi_unpool_bwd(_p(gout), _p(rois), _p(gz), B, Ct, T, _stream()), "nef_roi_unpool_bwd")
+    _done(ev)
     return gz
 
 
@@ -472,7 +497,9 @@ def lead_mean(z1, z2r, V):
     _chk(z1), _chk(z2r)
     B, _, T = z1.shape
     latent = torch.empty(B, 256, T, device=z1.device, dtype=torch.float32)
+    ev = _hbm("lead_mean", z1, z2r, latent)
     _lib.check(L.nef_lead_mean(_p(z1), _p(z2r), _p(latent), B, V, T, _stream()), "nef_lead_mean")
+    _done(ev)
     return latent
 
 
@@ -501,8 +528,10 @@ def mix_fwd_shared(latent, z1, z2r, q, V, c1, c2=None):
     _chk(latent), _chk(q)
     B, _, T = latent.shape
     D2 = torch.empty(2 * B, 256, T, device=latent.device, dtype=torch.float32)
+    ev = _hbm("mix_fwd_shared", latent, z1, z2r, D2)
     _lib.check(L.nef_mix_fwd_shared(_p(latent), _p(z1), _p(z2r), _p(q), _p(D2), B, V, T, c1, c2, cdev, _stream()),
                "nef_mix_fwd_shared")
+    _done(ev)
     return D2
 
 
@@ -515,8 +544,10 @@ def mix_bwd_shared_up(gU2, latent, z1, z2r, q, V, c1, c2=None, relu_z1=False):
     assert gU2.shape == (2 * B, 256, 2 * T)
     gz1, gz2r = torch.empty_like(z1), torch.empty_like(z2r)
     gq = torch.empty(B, 256, device=latent.device, dtype=torch.float32)
+    ev = _hbm("mix_bwd_shared_up", gU2, z1, z2r, gz1, gz2r)
     _lib.check(L.nef_mix_bwd_shared_up(_p(gU2), _p(latent), _p(z1), _p(z2r), _p(q), _p(gz1), _p(gz2r), _p(gq), B, V, T, c1,
                                        c2, cdev, int(relu_z1), _stream()), "nef_mix_bwd_shared_up")
+    _done(ev)
     return gz1, gz2r, gq
 
 
@@ -526,7 +557,9 @@ def pass_combine_fwd(P2, bias, B):
     _chk(P2), _chk(bias)
     C2, Ln = P2.shape[1], P2.shape[2]
     c1 = torch.empty(3 * B, C2 // 2, Ln, device=P2.device, dtype=torch.float32)
+    ev = _hbm("pass_combine_fwd", P2, c1)
     _lib.check(L.nef_pass_combine_fwd(_p(P2), _p(bias), _p(c1), B, C2 // 2, Ln, _stream()), "nef_pass_combine_fwd")
+    _done(ev)
     return c1
 
 
@@ -572,7 +605,9 @@ def upsample2_aff_fwd(x, a, b, Bp):
     _chk(x)
     N, Ct, T = x.shape
     y = torch.empty(N, Ct, 2 * T, device=x.device, dtype=torch.float32)
+    ev = _hbm("upsample2_aff_fwd", x, y)
     _lib.check(L.nef_upsample2_aff_fwd(_p(x), _p(a), _p(b), _p(y), N, Ct, T, Bp, _stream()), "nef_upsample2_aff_fwd")
+    _done(ev)
     return y
 
 
@@ -594,8 +629,10 @@ def bn_train_stats(x, gamma, beta, running_mean, running_var, P, eps=1e-5, momen
     mean, invstd, a, b = (torch.empty(P, Ct, device=x.device, dtype=torch.float32) for _ in range(4))
     n = L.nef_bn_ws_bytes(P, Ct)
     ws = workspace(n, x.device)
+    ev = _hbm("bn_train_stats", x)
     _lib.check(L.nef_bn_train_stats(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(mean), _p(invstd),
                                     _p(a), _p(b), _p(ws), n, P, Bp, Ct, Ln, eps, momentum, _stream()), "nef_bn_train_stats")
+    _done(ev)
     return mean, invstd, a, b
 
 
@@ -639,8 +676,10 @@ def bn_relu_bwd(gy, x, gamma, mean, invstd, a, b, P, with_chan_sum=False):
     gs = torch.empty(Ct, device=x.device, dtype=torch.float32) if with_chan_sum else None
     n = L.nef_bn_bwd_ws_bytes(P, N // P, Ct)
     ws = workspace(n, x.device)
+    ev = _hbm("bn_relu_bwd", gy, x, gx)
     _lib.check(L.nef_bn_relu_bwd(_p(gy), _p(x), _p(gamma), _p(mean), _p(invstd), _p(a), _p(b), _p(gx), _p(gg), _p(gb),
                                  _p(gs), _p(ws), n, P, N // P, Ct, Ln, _stream()), "nef_bn_relu_bwd")
+    _done(ev)
     return (gx, gg, gb, gs) if with_chan_sum else (gx, gg, gb)
 
 
@@ -656,8 +695,10 @@ def bn_relu_bwd_combine3(gy, x, mean, invstd, a, b):
     gs = torch.empty(Ct, device=x.device, dtype=torch.float32)
     n = L.nef_bn_bwd_ws_bytes(3, Bp, Ct)
     ws = workspace(n, x.device)
+    ev = _hbm("bn_relu_bwd_combine3", gy, x, gP2)
     _lib.check(L.nef_bn_relu_bwd_combine3(_p(gy), _p(x), _p(mean), _p(invstd), _p(a), _p(b), _p(gP2), _p(gg), _p(gb),
                                           _p(gs), _p(ws), n, Bp, Ct, Ln, _stream()), "nef_bn_relu_bwd_combine3")
+    _done(ev)
     return gP2, gg, gb, gs
 
 
@@ -674,8 +715,10 @@ def bn_relu_bwd_up(gu, x, mean, invstd, a, b, P):
     gs = torch.empty(Ct, device=x.device, dtype=torch.float32)
     n = L.nef_bn_bwd_ws_bytes(P, N // P, Ct)
     ws = workspace(n, x.device)
+    ev = _hbm("bn_relu_bwd_up", gu, x, gx)
     _lib.check(L.nef_bn_relu_bwd_up(_p(gu), _p(x), _p(mean), _p(invstd), _p(a), _p(b), _p(gx), _p(gg), _p(gb), _p(gs),
                                     _p(ws), n, P, N // P, Ct, Ln, _stream()), "nef_bn_relu_bwd_up")
+    _done(ev)
     return gx, gg, gb, gs
 
 
@@ -691,9 +734,11 @@ def bn_relu_bwd_outconv(gout, out, wout, x, mean, invstd, a, b, P):
     gs = torch.empty(Ct, device=x.device, dtype=torch.float32)
     n = L.nef_bn_bwd_outconv_ws_bytes(P, N // P, Ct, Ln)
     ws = workspace(n, x.device)
+    ev = _hbm("bn_relu_bwd_outconv", gout, out, x, gx)
     _lib.check(L.nef_bn_relu_bwd_outconv(_p(gout), _p(out), _p(wout), _p(x), _p(mean), _p(invstd), _p(a), _p(b), _p(gx),
                                          _p(gg), _p(gb), _p(gs), _p(ws), n, P, N // P, Ct, Ln, _stream()),
                "nef_bn_relu_bwd_outconv")
+    _done(ev)
     return gx, gg, gb, gs
 
 
@@ -704,8 +749,10 @@ def outconv_fwd(x, w, bias, pro=None):
     N, Ct, Ln = x.shape
     out = torch.empty(N, 1, Ln, device=x.device, dtype=torch.float32)
     a, b, Bp = pro if pro is not None else (None, None, 1)
+    ev = _hbm("outconv_fwd", x, out)
     _lib.check(L.nef_outconv_fwd_pro(_p(x), _p(a), _p(b), Bp, _p(w), _p(bias), _p(out), N, Ct, Ln, _stream()),
                "nef_outconv_fwd")
+    _done(ev)
     return out
 
 
@@ -727,8 +774,10 @@ def outconv_bwd_weight(gout, out, x, pro=None):
     n = L.nef_outconv_bwd_weight_ws_bytes(Ct)
     ws = workspace(n, x.device)
     a, b, Bp = pro if pro is not None else (None, None, 1)
+    ev = _hbm("outconv_bwd_weight", gout, out, x)
     _lib.check(L.nef_outconv_bwd_weight_pro(_p(gout), _p(out), _p(x), _p(a), _p(b), Bp, _p(gw), _p(gb), _p(ws), n, N, Ct,
                                             Ln, _stream()), "nef_outconv_bwd_weight")
+    _done(ev)
     return gw, gb
 
 
@@ -754,11 +803,26 @@ def loss_bwd(pred, pred_p, pred_l, target, gscale, factors, reg_l2, use_mask):
     return g_pred, g_p, g_l
 
 
+def view_metrics(pred, gt, rois=None):
+    """Per-row PSNR and SSIM tables (fp64 [B, Q]) of pred vs gt [B, Q, L] on [0, rois[i, -1, 0])."""
+    L = _lib.load()
+    _chk(pred), _chk(gt)
+    if rois is not None:
+        _chk(rois, torch.int64)
+    B, Q, Ln = pred.shape
+    psnr = torch.empty(B, Q, device=pred.device, dtype=torch.float64)
+    ssim = torch.empty(B, Q, device=pred.device, dtype=torch.float64)
+    _lib.check(L.nef_view_metrics(_p(pred), _p(gt), _p(rois), _p(psnr), _p(ssim), B, Q, Ln, _stream()), "nef_view_metrics")
+    return psnr, ssim
+
+
 def sgd_momentum(p, g, buf, lr, mu, gscale, first_step):
     L = _lib.load()
     _chk(p), _chk(g), _chk(buf)
+    ev = _hbm("sgd_momentum", p, p, g, buf, buf)
     _lib.check(L.nef_sgd_momentum(_p(p), _p(g), _p(buf), p.numel(), lr, mu, gscale, int(first_step), _stream()),
                "nef_sgd_momentum")
+    _done(ev)
 
 
 # ------------------------------------------------------------------ half-precision panorama decoder (pano_h.hip)

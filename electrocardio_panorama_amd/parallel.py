@@ -8,6 +8,20 @@ import torch
 import torch.distributed as dist
 
 
+def local_rank():
+    """Index of the HIP device this process drives: torchrun's LOCAL_RANK (0 when ranks share one GPU under the
+    NEF_SHARE_GPU test hook, or when not launched by torchrun)."""
+    if os.environ.get("NEF_SHARE_GPU") == "1":
+        return 0
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def rank_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def init_from_env():
     """Initialise torch.distributed from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
     Returns (rank, world, local_rank).  Single-process runs need no initialisation."""
@@ -47,6 +61,23 @@ def shard_batch(meta, rank, world):
     n = len(next(iter(meta.values())))
     idx = shard_indices(n, rank, world)
     return {k: v[idx[0]:idx[-1] + 1] for k, v in meta.items()}
+
+
+class ShardedLoader:
+    """Wraps an iterable of GLOBAL `meta` batches (identical on every rank: same seed, same order) and yields this
+    rank's contiguous shard of each -- what nn.DataParallel's scatter does to the reference's batch
+    (solver.py:32-34).  With world == 1 it is the identity."""
+
+    def __init__(self, loader, rank=None, world=None):
+        r, w = rank_world()
+        self.loader, self.rank, self.world = loader, (r if rank is None else rank), (w if world is None else world)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for meta in self.loader:
+            yield meta if self.world == 1 else shard_batch(meta, self.rank, self.world)
 
 
 def reduce_flat_grads(grads, flat):

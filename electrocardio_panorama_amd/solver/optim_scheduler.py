@@ -35,6 +35,11 @@ class FusedSGD(torch.optim.Optimizer):
         self._flat[gi] = dict(ids=[id(p) for p in live], params=live, p=flat_p, buf=flat_b,
                               g=torch.empty(n, device=dev, dtype=torch.float32))
 
+    def load_state_dict(self, state_dict):
+        """The loaded momentum buffers replace the flat one: drop the flat views so the next step() re-imports them."""
+        super().load_state_dict(state_dict)
+        self._flat = {}
+
     @torch.no_grad()
     def step(self, closure=None):
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -55,10 +60,31 @@ class FusedSGD(torch.optim.Optimizer):
         return None
 
 
+class DataParallelAdam(Adam):
+    """torch Adam (the reference's other optimiser choice, optim_scheduler.py:8) whose step first averages the
+    gradients over the data-parallel ranks with the same single flat all-reduce FusedSGD uses -- without it the
+    ranks' parameters would silently diverge."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if world > 1:
+            live = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
+            if live:
+                flat = torch.empty(sum(p.numel() for p in live), device=live[0].device, dtype=torch.float32)
+                reduce_flat_grads([p.grad for p in live], flat)
+                flat.mul_(1.0 / world)
+                off = 0
+                for p in live:
+                    p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+                    off += p.numel()
+        return super().step(closure)
+
+
 def get_optimizer(cfg, model_params):
     optim_name = cfg.SOLVER.optim
     if optim_name == 'adam':
-        return Adam(model_params, lr=cfg.SOLVER.lr)
+        return DataParallelAdam(model_params, lr=cfg.SOLVER.lr)
     elif optim_name == 'sgd':
         return FusedSGD(model_params, lr=cfg.SOLVER.lr, momentum=0.9)
 

@@ -1,72 +1,199 @@
-"""Training driver with the surface of reference codes/solver/solver.py:16-245.
+"""Training driver with the surface of reference codes/solver/solver.py:16-245 (`Solver.train`, `Solver.val`,
+`Solver.run_one_epoch`, `write_tensorboardx`).
 
-Scope: the train-phase body of `run_one_epoch` -- H2D of the meta dict,
-model call, losswrapper, backward, optimiser step -- runs entirely on the device with no per-iteration
-host synchronisation (the reference issues ~10 D2H copies per step, solver.py:179,189,236-240; here the
-four loss scalars stay on the device and are fetched once per epoch).  The test phase reproduces the reference's
-metric bookkeeping (solver.py:190-230): `loss_unsperv` on the last four rest views, PSNR / SSIM split into generated
-(`gen`, the last `gen_num` rest views) and regressed (`reg`) leads, plus per-lead numbers; TensorBoard is optional."""
+Scope.  The train-phase body of `run_one_epoch` -- H2D of the meta dict, model
+call, losswrapper, backward, optimiser step -- runs on the device with NO per-iteration host synchronisation: the
+reference issues ~10 blocking D2H copies per step (solver.py:179,189,236-240); here the loss scalars, the predicted
+views and the metric tables are copied to pinned host memory asynchronously and read once at the end of the epoch,
+so the returned lists are the reference's while the launch queue never drains.  The test phase reproduces the
+reference's bookkeeping (solver.py:190-230): `loss_unsperv` on the last four rest views, PSNR / SSIM split into
+generated (`gen`, the last `gen_num` rest views) and regressed (`reg`) leads plus per-lead numbers -- computed on the
+device by `nef_view_metrics`, one launch per batch.
+
+Data parallelism replaces `nn.DataParallel` (solver.py:32-34) with one process per GPU (`parallel.py`): the loaders
+hand every rank its shard, FusedSGD all-reduces the flat gradient, rank 0 owns the BatchNorm running statistics,
+the scalar log and the checkpoints."""
+import json
 import os
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
+from .. import ops, parallel
 from ..network import build_model, build_loss
 from ..utils import CheckPointer
-from ..utils.metric import PSNR, SSIM
 from .optim_scheduler import get_optimizer, get_lr_scheduler
 
 
+class JsonlScalarWriter:
+    """`add_scalar(tag, value, global_step)` sink used when neither tensorboardX nor torch.utils.tensorboard is
+    installed (solver.py:8,24): one JSON object per scalar in `<logdir>/scalars.jsonl`."""
+
+    def __init__(self, logdir):
+        os.makedirs(logdir, exist_ok=True)
+        self.path = os.path.join(logdir, 'scalars.jsonl')
+
+    def add_scalar(self, tag, scalar_value, global_step=None):
+        with open(self.path, 'a') as f:
+            f.write(json.dumps({'tag': tag, 'value': float(scalar_value), 'step': global_step}) + '\n')
+
+    def close(self):
+        pass
+
+
+def make_summary_writer(logdir):
+    try:
+        import tensorboardX
+        return tensorboardX.SummaryWriter(logdir=logdir)
+    except ImportError:
+        pass
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(log_dir=logdir)
+    except ImportError:
+        return JsonlScalarWriter(logdir)
+
+
+class _HostSink:
+    """Device tensors queued for the host: each is copied into pinned memory on the current stream (no sync); `rows()`
+    waits once and returns them."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, t):
+        t = t.detach()
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        self.items.append(h)
+
+    def arrays(self):
+        if self.items:
+            torch.cuda.synchronize()
+        return [h.numpy() for h in self.items]
+
+    def rows(self):
+        return [x for a in self.arrays() for x in a]
+
+
+def _is_main():
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
 class Solver:
-    def __init__(self, cfg, use_tensorboardx=True, collect_views=False):
+    def __init__(self, cfg, use_tensorboardx=True, collect_views=True):
         self.cfg = cfg
         self.output_dir = os.path.join(cfg.output_dir, cfg.desc)
         self.desc = cfg.desc
-        self.collect_views = collect_views
+        self.collect_views = collect_views       # False: skip the per-view host lists (benchmarks)
         self.model = build_model(cfg).float()
         self.loss = build_loss(cfg)
         self._init_model_device()
-        self.summary_writer = None
+        if self.desc != 'debug' and use_tensorboardx and _is_main():       # solver.py:23-26
+            self.summary_writer = make_summary_writer(os.path.join(cfg.output_dir, 'tf_logs'))
+        else:
+            self.summary_writer = None
 
     def _init_model_device(self):
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device: this build has no CPU path (use the oracle for CPU runs)")
-        local = int(os.environ.get("LOCAL_RANK", 0))
-        self.device = torch.device('cuda', local if dist.is_available() and dist.is_initialized() else 0)
+        self.device = torch.device('cuda', parallel.local_rank() if dist.is_available() and dist.is_initialized() else 0)
         self.model.to(self.device)
+
+    def write_tensorboardx(self, scalars, names, epoch):
+        for i in range(len(scalars)):
+            self.summary_writer.add_scalar(names[i], scalars[i], global_step=epoch)
 
     def train(self, dl_train, dl_test=None):
         optimizer = get_optimizer(self.cfg, self.model.parameters())
         scheduler = get_lr_scheduler(self.cfg, optimizer)
         checkpointer = CheckPointer(self.model, optimizer, scheduler, self.output_dir)
         extra = checkpointer.load(self.cfg.MODEL.resume)
+        max_epochs = self.cfg.SOLVER.epochs
         start_epoch = extra.get('epoch', 0)
-        best = extra.get('best_test_psnr_gen', 0.)
+        best_test_psnr_gen = extra.get('best_test_psnr_gen', 0.)
+        self.model.dropout_epoch = start_epoch          # a resumed run must not replay epoch 0's dropout masks
+        print('the latest best_test_psnr_gen is {:06f}'.format(best_test_psnr_gen))
         save_arguments = {}
-        for epoch in range(start_epoch, self.cfg.SOLVER.epochs):
+        for epoch in range(start_epoch, max_epochs):
+            print('---------------------------------{}---{}-------------------------------------'.format(self.cfg.desc, epoch))
+            if hasattr(getattr(dl_train, 'sampler', None), 'set_epoch'):
+                dl_train.sampler.set_epoch(epoch)         # DistributedSampler: a new shuffle per epoch
+            self.model.dropout_epoch = epoch
             train_losses = self.run_one_epoch(dl_train, phase='train', optim=optimizer)[0]
             scheduler.step()
-            msg = 'Epoch {}: train_loss: {}'.format(epoch, float(np.mean(train_losses, axis=0)[0]))
-            psnr_gen = 0.
+            parallel.broadcast_buffers(self.model)        # rank 0's BatchNorm running statistics are the model's
+            tl = np.mean(train_losses, axis=0)
+            train_loss_all = float(tl[0])
+            scalars, names = [train_loss_all, float(tl[1]), float(tl[2]), float(tl[3])], \
+                ['train_loss_all', 'train_loss_1', 'train_loss_2', 'train_3']
+            psnr_gen = psnr_reg = 0.
+            msg = 'Epoch {}: train_loss: {}'.format(epoch, train_loss_all)
             if dl_test is not None:
-                test_losses, _, _, _, mertics_all, _, _ = self.run_one_epoch(dl_test, phase='test')
-                psnr_gen = float(np.mean(mertics_all, axis=0)[0])
-                msg += ', test_loss: {}, psnr_gen: {}'.format(float(np.mean(test_losses, axis=0)[0]), psnr_gen)
+                test_losses, _, _, _, mertics_all, _, single = self.run_one_epoch(dl_test, phase='test')
+                te = np.mean(test_losses, axis=0)
+                psnr_gen, psnr_reg, ssim_gen, ssim_reg = (float(v) for v in np.mean(mertics_all, axis=0))
+                # the reference's scalar set and names (solver.py:82-100)
+                scalars = [train_loss_all, float(te[0]), float(tl[1]), float(te[1]), float(tl[2]), float(te[2]),
+                           float(tl[3]), float(te[3]), float(te[4]), psnr_gen, psnr_reg, ssim_gen, ssim_reg]
+                names = ['train_loss_all', 'test_loss_all', 'train_loss_1', 'test_loss_1', 'train_loss_2', 'test_loss_2',
+                         'train_3', 'test_3', 'test_unsuperv', 'psnr_gen', 'psnr_reg', 'ssim_gen', 'ssim_reg']
+                if len(single) != 0:
+                    single = np.array(single)
+                    for i in range(single.shape[1]):
+                        names += ['psnr_reg_lead_{}'.format(i), 'ssim_reg_lead_{}'.format(i)]
+                        scalars += [float(np.mean(single[:, i, 0])), float(np.mean(single[:, i, 1]))]
+                msg += ', test_loss: {}'.format(float(te[0]))
+                msg += '\npsnr_gen: {}, psnr_reg: {}, ssim_gen:{}, ssim_reg:{}'.format(psnr_gen, psnr_reg, ssim_gen, ssim_reg)
+            if self.summary_writer is not None:
+                self.write_tensorboardx(scalars, names, epoch)
             print(msg)
-            save_arguments.update(psnr_gen=psnr_gen, epoch=epoch)
-            if not dist.is_initialized() or dist.get_rank() == 0:
+            save_arguments['psnr_gen'] = psnr_gen
+            save_arguments['psnr_reg'] = psnr_reg
+            save_arguments['epoch'] = epoch
+            if _is_main():
                 checkpointer.save('epoch_{}'.format(epoch), **save_arguments)
-                if psnr_gen > best:
-                    best = psnr_gen
-                    save_arguments['best_test_psnr_gen'] = best
+                if psnr_gen > best_test_psnr_gen:
+                    best_test_psnr_gen = psnr_gen
+                    save_arguments['best_test_psnr_gen'] = best_test_psnr_gen
+                    save_arguments['epoch'] = epoch
                     checkpointer.save('best_valid', **save_arguments)
+
+    def val(self, dl_test, epoch=-1):
+        """solver.py:118-137: load `best_valid.pkl` (epoch == -1) or `epoch_<n>.pkl`, run the test phase, print and
+        return (psnr_gen, psnr_reg, ssim_gen, ssim_reg)."""
+        self.model.eval()
+        optimizer = get_optimizer(self.cfg, self.model.parameters())
+        scheduler = get_lr_scheduler(self.cfg, optimizer)
+        checkpointer = CheckPointer(self.model, optimizer, scheduler, self.output_dir)
+        if epoch == -1:
+            extra = checkpointer.load(best_valid=True)
+        else:
+            extra = checkpointer.load(os.path.join(self.output_dir, 'epoch_{}.pkl'.format(epoch)))
+        print('the latest best_test_psnr_gen is {:06f} of epoch {}'.format(extra.get('best_test_psnr_gen', 0.),
+                                                                           extra.get('epoch', 0)))
+        with torch.no_grad():
+            mertics_all = self.run_one_epoch(dl_test, phase='test')[4]
+        psnr_gen, psnr_reg, ssim_gen, ssim_reg = (float(v) for v in np.mean(mertics_all, axis=0))
+        print('psnr_gen:{}, psnr_reg:{}, ssim_gen:{}, ssim_reg:{}'.format(psnr_gen, psnr_reg, ssim_gen, ssim_reg))
+        return psnr_gen, psnr_reg, ssim_gen, ssim_reg
 
     def _to_device(self, meta):
         dev = self.device
         t = lambda v: torch.as_tensor(v).to(dev, non_blocking=True)   # noqa: E731
         return (t(meta['data']), t(meta['rois']), t(meta['input_theta']), t(meta['target_view']).unsqueeze(1),
                 t(meta['target_theta']), t(meta['noise']).unsqueeze(1))
+
+    def _gen_num(self):
+        """How many trailing rest views are 'generated' (never supervised), and whether the split applies at all
+        (solver.py:197-203)."""
+        gen_num = 6 if self.cfg.DATA.lead_num == 336 else 4
+        super_mode = str(self.cfg.DATA.get('super_mode', 'normal'))
+        if super_mode != 'normal':
+            gen_num = int(super_mode[-1])
+        whole = self.cfg.DATA.get('dataset', 'tianchi') == 'mit' or super_mode[-1] == '0' or super_mode == '_mit'
+        return gen_num, whole
 
     def run_one_epoch(self, dl, phase, optim=None):
         if phase == 'train':
@@ -75,55 +202,56 @@ class Solver:
             self.model.eval()
         else:
             raise ValueError('phase param not found.')
-        dev_losses, gt_views, predict_views, input_views, rest_views, mertics_all, rois_all = [], [], [], [], [], [], []
-        mertics_gen_singlelead = []
+        keep = self.collect_views
+        losses_s, pred_s, gt_s, in_s, rest_s, rois_s, psnr_s, ssim_s = (_HostSink() for _ in range(8))
         for meta in dl:
             source_data, rois, input_theta, target_view, target_theta, noise = self._to_device(meta)
             rest_theta = torch.as_tensor(meta['rest_theta']).to(self.device) if 'rest_theta' in meta else None
             if phase == 'train':
                 out, shuf_p, shuf_l = self.model(source_data, input_theta, target_theta, rois, rest_theta=rest_theta,
                                                  phase='train')
+                if keep:
+                    pred_s.add(out.squeeze(1))                     # solver.py:179 (before the optional noise)
                 if self.cfg.DATA.noise:
                     out = out + noise
                 losses = self.loss(out, shuf_p, shuf_l, target_view, self.cfg)
-                dev_losses.append(torch.stack([l_.detach() for l_ in losses]))
+                losses_s.add(torch.stack([l_.detach() for l_ in losses]))
                 losses[0].backward()
                 optim.step()
                 optim.zero_grad()
-                if self.collect_views:
-                    predict_views += [x for x in out.squeeze(1).detach().cpu().numpy()]
             else:
-                rest_view = torch.as_tensor(meta['rest_view']).to(self.device, torch.float32)
+                rest_view = torch.as_tensor(meta['rest_view']).to(self.device, torch.float32).contiguous()
                 out, shuf_p, shuf_l, rest_out = self.model(source_data, input_theta, target_theta, rois,
                                                            rest_theta=rest_theta, phase='test')
                 losses = self.loss(out, shuf_p, shuf_l, target_view, self.cfg, rest_out[:, -4:, :].contiguous(),
                                    rest_view[:, -4:, :].contiguous())
-                dev_losses.append(torch.stack([l_.detach() for l_ in losses]))
-                ro, rv, rn = rest_out.cpu().numpy(), rest_view.cpu().numpy(), rois.cpu().numpy()
-                # which rest views are "generated" (never supervised): solver.py:197-201
-                gen_num = 6 if self.cfg.DATA.lead_num == 336 else 4
-                super_mode = str(self.cfg.DATA.get('super_mode', 'normal'))
-                if super_mode != 'normal' and super_mode[-1].isdigit():
-                    gen_num = int(super_mode[-1])
-                if self.cfg.DATA.get('dataset', 'tianchi') == 'mit' or super_mode[-1] == '0' or super_mode == '_mit':
-                    psnr_gen = psnr_reg = PSNR(ro, rv)
-                    ssim_gen = ssim_reg = SSIM(ro, rv)
-                else:
-                    psnr_gen, psnr_reg = PSNR(ro[:, -gen_num:], rv[:, -gen_num:], rn), PSNR(ro[:, :-gen_num], rv[:, :-gen_num], rn)
-                    ssim_gen, ssim_reg = SSIM(ro[:, -gen_num:], rv[:, -gen_num:], rn), SSIM(ro[:, :-gen_num], rv[:, :-gen_num], rn)
-                    single = []
-                    for i in range(gen_num):
-                        k = ro.shape[1] - gen_num + i
-                        single.append([PSNR(ro[:, k:k + 1], rv[:, k:k + 1], rn), SSIM(ro[:, k:k + 1], rv[:, k:k + 1], rn)])
-                    mertics_gen_singlelead.append(single)
-                mertics_all.append([psnr_gen, psnr_reg, ssim_gen, ssim_reg])
-                predict_views += [x for x in ro]
-                rest_views += [x for x in rv]
-            if self.collect_views:
-                gt_views += [x for x in target_view.squeeze(1).cpu().numpy()]
-                input_views += [x for x in source_data.cpu().numpy()]
-                rois_all += [x for x in rois.cpu().numpy()]
-        losses = torch.stack(dev_losses).cpu().numpy().tolist() if dev_losses else []
+                losses_s.add(torch.stack([l_.detach() for l_ in losses]))
+                whole = self._gen_num()[1]
+                ps, ss = ops.view_metrics(rest_out.contiguous(), rest_view, None if whole else rois.contiguous())
+                psnr_s.add(ps)
+                ssim_s.add(ss)
+                pred_s.add(rest_out)                               # solver.py:182
+                rest_s.add(rest_view)
+            if keep:
+                gt_s.add(target_view.squeeze(1))
+                in_s.add(source_data)
+                rois_s.add(rois)
+        losses = [a.tolist() for a in losses_s.arrays()]
         if phase == 'train':
-            return losses, gt_views, predict_views, input_views, mertics_all, rois_all
-        return losses, rest_views, predict_views, input_views, mertics_all, rois_all, mertics_gen_singlelead
+            return losses, gt_s.rows(), pred_s.rows(), in_s.rows(), [], rois_s.rows()
+        gen_num, whole = self._gen_num()
+        mertics_all, mertics_gen_singlelead = [], []
+        for ps, ss in zip(psnr_s.arrays(), ssim_s.arrays()):
+            if np.isnan(ss).any():
+                raise ValueError("win_size exceeds signal extent (a test row is shorter than the 7-tap SSIM window)")
+            if whole:
+                pg = pr = float(ps.mean())
+                sg = sr = float(ss.mean())
+            else:
+                pg, pr = float(ps[:, -gen_num:].mean()), float(ps[:, :-gen_num].mean())
+                sg, sr = float(ss[:, -gen_num:].mean()), float(ss[:, :-gen_num].mean())
+                Q = ps.shape[1]
+                mertics_gen_singlelead.append([[float(ps[:, Q - gen_num + i].mean()), float(ss[:, Q - gen_num + i].mean())]
+                                               for i in range(gen_num)])
+            mertics_all.append([pg, pr, sg, sr])
+        return losses, rest_s.rows(), pred_s.rows(), in_s.rows(), mertics_all, rois_s.rows(), mertics_gen_singlelead

@@ -28,12 +28,19 @@ class CheckPointer:
         with open(os.path.join(self.save_dir, self._last_checkpoint_name), 'w') as f:
             f.write(save_file)
 
-    def load(self, f=None, best_valid=False, use_latest=True):
-        if best_valid and self.save_dir:
-            f = os.path.join(self.save_dir, 'best_valid.pkl')
-        elif use_latest and self.has_checkpoint():
-            f = self.get_checkpoint_file()
+    def load(self, f=None, best_valid=False):
+        """Which file is loaded follows the reference (checkpointer.py:40-60): an explicit path `f` (cfg.MODEL.resume,
+        `Solver.val(epoch=n)`) wins; otherwise `best_valid.pkl` when `best_valid`, else the `last_checkpoint` pointer.
+        Returns the extra entries of the checkpoint ({} when there is nothing to load).  One deliberate difference: an
+        explicit path is honoured even before any `last_checkpoint` pointer exists in `save_dir` (the reference
+        silently starts from scratch then)."""
+        if not f:
+            if not self.has_checkpoint():
+                return {}
+            f = os.path.join(self.save_dir, 'best_valid.pkl') if best_valid else self.get_checkpoint_file()
         if not f or not os.path.exists(f):
+            if f:
+                raise FileNotFoundError(f)
             return {}
         checkpoint = torch.load(f, map_location='cpu')
         model_sd = {(k[7:] if k.startswith('module.') else k): v for k, v in checkpoint.pop('model').items()}

@@ -298,6 +298,15 @@ int nef_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, 
                      int first_step, nef_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Test-phase metrics on the device.  Replaces PSNR / SSIM of codes/utils/mertic.py:7-32 as called from
+ * codes/solver/solver.py:202-228: per (sample, view) row over the un-padded region [0, rois[i][6][0]) (whole row
+ * when rois is NULL).  pred, gt fp32 [B][Q][L]; psnr, ssim fp64 [B][Q].  PSNR = 100 for an exact match, else
+ * 20*log10(1/rmse).  SSIM = skimage structural_similarity(data_range=1.0) for 1-D input (7-tap uniform window,
+ * sample covariance, borders of 3 cropped); NaN for rows shorter than 7 (skimage raises there). */
+int nef_view_metrics(const float* pred, const float* gt, const int64_t* rois, double* psnr, double* ssim, int B, int Q,
+                     int L, nef_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Half-precision panorama decoder (BASELINE configs 4/5): the eval-mode view sweep of
  * model_nefnet.py:181-190 / gen_ecg :196-218 with BatchNorm folded into the convs (nef_fold_bn), activations kept
  * as fp16 [pair][time][channel] and the four wide decoder convs (model_nefnet.py:18,21 inside :103,:105) on the

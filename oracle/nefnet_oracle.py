@@ -124,6 +124,60 @@ def fresh_buffers():
 
 
 # --------------------------------------------------------------------------
+# decision replay (test instrument for gradient parity)
+# --------------------------------------------------------------------------
+class Decisions:
+    """The backward pass is discontinuous wherever the forward takes a DISCRETE decision: ReLU on/off
+    (model_nefnet.py:39,59; resnet_1d.py:34,52; DoubleConv :20,23) and the sign of an L1 residual (losses.py:8,27).
+    When a pre-activation lies within fp32 round-off of the switching point, two correct fp32 implementations may
+    decide differently, and one such tie can move the whole flat gradient by 1e-3 at small shapes.  This object lets
+    the oracle REPLAY the decisions another implementation took (`masks[site]`: bool tensor, True = ReLU passes; for
+    sign sites a float tensor of -1/0/+1; or a callable(own_decision) -> decision for partial overrides) and records,
+    per site, how many decisions the oracle itself would have taken differently and how far from the switching point
+    those pre-activations were.  A parity test then asserts (a) every differing decision is a tie -- |pre-activation|
+    at round-off level -- and (b) the gradients agree at the tie-free tolerance.  With `masks` empty it only records
+    nothing and the oracle is the plain reference restatement."""
+
+    def __init__(self, masks=None):
+        self.masks = masks or {}
+        self.report = {}          # site -> dict(flips, worst, rms, numel)
+
+    def _note(self, site, own, taken, pre):
+        flips = own != taken
+        n = int(flips.sum())
+        self.report[site] = dict(flips=n, worst=float(pre[flips].abs().max()) if n else 0.0,
+                                 rms=float(pre.detach().double().pow(2).mean().sqrt()), numel=pre.numel())
+
+    def relu(self, site, pre):
+        m = self.masks.get(site)
+        if m is None:
+            return F.relu(pre)
+        own = pre.detach() > 0
+        if callable(m):
+            m = m(own)
+        m = m.to(pre.device)
+        self._note(site, own, m, pre.detach())
+        return pre * m.to(pre.dtype)
+
+    def l1(self, site, a, b):
+        """nn.L1Loss()(a, b) = mean(|a - b|); with a replayed sign tensor its derivative uses that sign."""
+        sg = self.masks.get(site)
+        if sg is None:
+            return F.l1_loss(a, b)
+        d = a - b
+        own = torch.sign(d.detach())
+        sg = sg.to(d.dtype)
+        self._note(site, own, sg, d.detach())
+        return (d * sg).mean()
+
+    def total_flips(self):
+        return sum(r["flips"] for r in self.report.values())
+
+
+_PLAIN = Decisions()
+
+
+# --------------------------------------------------------------------------
 # building blocks
 # --------------------------------------------------------------------------
 def angular_encoding(theta):
@@ -143,17 +197,17 @@ def _drop(x, site, training, masks, p):
     return F.dropout(x, p, True)
 
 
-def res_block(x, P, prefix, groups, k, training, masks, p):
+def res_block(x, P, prefix, groups, k, training, masks, p, dec=_PLAIN):
     """BasicBlock: encoder/resnet_1d.py:42-53 (k=7) and model_nefnet.py:48-60 (k=3)."""
     h = F.conv1d(x, P[prefix + ".conv1.weight"], None, 1, k // 2, 1, groups)
-    h = F.relu(h)
+    h = dec.relu(prefix + ".relu1", h)
     h = _drop(h, prefix, training, masks, p)
     h = F.conv1d(h, P[prefix + ".conv2.weight"], None, 1, k // 2, 1, groups)
     res = x
     if k == 3 and h.shape[1] != x.shape[1]:       # model_nefnet.py:54
         res = F.conv1d(x, P[prefix + ".residual_conv.weight"],
                        P[prefix + ".residual_conv.bias"], 1, 0, 1, groups)
-    return F.relu(h + res)
+    return dec.relu(prefix + ".relu2", h + res)
 
 
 def stem(x, P, V):
@@ -209,14 +263,14 @@ def batch_norm(x, P, Bf, prefix, training):
                         P[prefix + ".weight"], P[prefix + ".bias"], training, BN_MOM, BN_EPS)
 
 
-def decoder(x, P, Bf, training, taps=None):
+def decoder(x, P, Bf, training, taps=None, dec=_PLAIN, pass_id=0):
     """model_nefnet.py:101-107 followed by sigmoid(x / 3) (:168).  `taps` (a list) collects the four post-ReLU
-    activations for diagnostics."""
+    activations for diagnostics.  Decision sites: "pass<pass_id>.<blk>.double_conv.<bn>"."""
     for blk in ("decoder.1", "decoder.3"):
         x = F.interpolate(x, scale_factor=2, mode="linear", align_corners=False)
         for conv, bn in (("0", "1"), ("3", "4")):
             x = F.conv1d(x, P[f"{blk}.double_conv.{conv}.weight"], P[f"{blk}.double_conv.{conv}.bias"], 1, 1)
-            x = F.relu(batch_norm(x, P, Bf, f"{blk}.double_conv.{bn}", training))
+            x = dec.relu(f"pass{pass_id}.{blk}.double_conv.{bn}", batch_norm(x, P, Bf, f"{blk}.double_conv.{bn}", training))
             if taps is not None:
                 taps.append(x)
     x = F.conv1d(x, P["decoder.4.weight"], P["decoder.4.bias"], 1, 1)
@@ -231,7 +285,7 @@ def lead_mean(z, V):
 # Model_nefnet.forward / gen_ecg
 # --------------------------------------------------------------------------
 def forward(P, Bf, x, input_thetas, query_theta, rois, rest_theta=None, phase="train",
-            training=True, masks=None, p=DROP_P, lead_choice=None, taps=None):
+            training=True, masks=None, p=DROP_P, lead_choice=None, taps=None, dec=_PLAIN):
     """network/model_nefnet.py:109-194.
 
     `lead_choice=(c1, c2)` overrides the two `random.randint` draws (:154,:156); when None
@@ -240,21 +294,21 @@ def forward(P, Bf, x, input_thetas, query_theta, rois, rest_theta=None, phase="t
     V = x.shape[1]
     w = stem(x, P, V)                                                       # :117
     for i in range(3):
-        w = res_block(w, P, f"W_encoder.layer1.{i}", V, 7, training, masks, p)
+        w = res_block(w, P, f"W_encoder.layer1.{i}", V, 7, training, masks, p, dec)
     enc_in = F.linear(angular_encoding(input_thetas), P["mlp1.weight"], P["mlp1.bias"])   # :118,:121
     B, C, T = w.shape
     ew = w * enc_in.reshape(B, C, 1)                                        # :122-123
-    ew = res_block(ew, P, "w_conv.0", V, 3, training, masks, p)             # :124
+    ew = res_block(ew, P, "w_conv.0", V, 3, training, masks, p, dec)             # :124
     ew = ew.reshape(B, V, 2, 64, T)                                         # :127-131
     z1 = ew[:, :, 0].reshape(B, 64 * V, T)
     z2 = ew[:, :, 1].reshape(B, 64 * V, T)
-    z1 = res_block(z1, P, "z1_conv.0", V, 3, training, masks, p)            # :133
-    z2 = res_block(z2, P, "z2_conv1.0", V, 3, training, masks, p)           # :134
+    z1 = res_block(z1, P, "z1_conv.0", V, 3, training, masks, p, dec)            # :133
+    z2 = res_block(z2, P, "z2_conv1.0", V, 3, training, masks, p, dec)           # :134
     z2a = roi_align_mid(z2, rois)                                           # :136
     h = z2a.contiguous().view(B, C * N_SEG, ROI_BINS)                       # :137
-    h = res_block(h, P, "z2_conv2.0", N_SEG * V, 3, training, masks, p)
+    h = res_block(h, P, "z2_conv2.0", N_SEG * V, 3, training, masks, p, dec)
     h = F.conv_transpose1d(h, P["z2_conv2.1.weight"], P["z2_conv2.1.bias"], 2, 0, 0, N_SEG * V)
-    h = res_block(h, P, "z2_conv2.2", N_SEG * V, 3, training, masks, p)
+    h = res_block(h, P, "z2_conv2.2", N_SEG * V, 3, training, masks, p, dec)
     z2b = h.view(B, C, N_SEG, 2 * ROI_BINS)                                 # :138
     if taps is not None:
         taps.update(w=w, z1=z1, z2_conv1=z2, z2_roi=z2a, z2_seg=z2b)
@@ -271,9 +325,9 @@ def forward(P, Bf, x, input_thetas, query_theta, rois, rest_theta=None, phase="t
     shuf_p = torch.cat([z1[:, 128 * c1:128 * (c1 + 1)], z2m], dim=1)        # :159
     shuf_l = torch.cat([z1m, z2r[:, 128 * c2:128 * (c2 + 1)]], dim=1)       # :160
     q = F.linear(angular_encoding(query_theta).reshape(B, -1), P["mlp2.weight"], P["mlp2.bias"])
-    out = decoder(q[:, :, None] * latent, P, Bf, training)                  # :166-168
-    out_p = decoder(q[:, :, None] * shuf_p, P, Bf, training)                # :170-172
-    out_l = decoder(q[:, :, None] * shuf_l, P, Bf, training)                # :174-176
+    out = decoder(q[:, :, None] * latent, P, Bf, training, dec=dec, pass_id=0)                  # :166-168
+    out_p = decoder(q[:, :, None] * shuf_p, P, Bf, training, dec=dec, pass_id=1)                # :170-172
+    out_l = decoder(q[:, :, None] * shuf_l, P, Bf, training, dec=dec, pass_id=2)                # :174-176
     if taps is not None:
         taps.update(z2_rev=z2r, latent_all=latent, q=q)
     if phase == "train":
@@ -285,28 +339,39 @@ def forward(P, Bf, x, input_thetas, query_theta, rois, rest_theta=None, phase="t
     raise KeyError("please type correct phase")
 
 
+class _LeadSites:
+    """Decision sites of the shared single-lead encoder, one set per lead: "<site>@<lead>"."""
+
+    def __init__(self, dec, lead):
+        self.dec, self.lead = dec, lead
+
+    def relu(self, site, pre):
+        return self.dec.relu(f"{site}@{self.lead}", pre)
+
+
 def forward2(P, Bf, x, input_thetas, query_theta, rois, rest_theta=None, phase="train", training=True, masks=None,
-             p=DROP_P, lead_choice=None):
+             p=DROP_P, lead_choice=None, dec=_PLAIN):
     """network/model_nefnet2.py:118-194: the lead loop with ONE shared single-lead encoder, restated as written."""
     B, V, _ = x.shape
     z1_list, z2_list = [], []
     for i in range(V):                                                       # :126
+        ld = _LeadSites(dec, i)
         xs, ths = x[:, i:i + 1], input_thetas[:, i:i + 1]
         w = stem(xs, P, 1)                                                   # :130
         for k in range(3):
-            w = res_block(w, P, f"W_encoder.layer1.{k}", 1, 7, training, masks, p)
+            w = res_block(w, P, f"W_encoder.layer1.{k}", 1, 7, training, masks, p, ld)
         e = F.linear(angular_encoding(ths), P["mlp1.weight"], P["mlp1.bias"])   # :131-133
         w = e[:, 0][:, :, None] * w                                          # :134
-        w = res_block(w, P, "w_conv.0", 1, 3, training, masks, p)            # :135
+        w = res_block(w, P, "w_conv.0", 1, 3, training, masks, p, ld)            # :135
         z1, z2 = torch.chunk(w, 2, dim=1)                                    # :137
-        z1 = res_block(z1, P, "z1_conv.0", 1, 3, training, masks, p)         # :139
+        z1 = res_block(z1, P, "z1_conv.0", 1, 3, training, masks, p, ld)         # :139
         z1 = F.conv1d(z1, P["single_conv_z1.0.weight"], P["single_conv_z1.0.bias"], padding=1)   # :140
-        z2 = res_block(z2, P, "z2_conv1.0", 1, 3, training, masks, p)        # :141
+        z2 = res_block(z2, P, "z2_conv1.0", 1, 3, training, masks, p, ld)        # :141
         z2 = roi_align_mid(z2, rois)                                         # :143
         h = z2.contiguous().view(B, 128 * N_SEG, ROI_BINS)                   # :144
-        h = res_block(h, P, "z2_conv2.0", N_SEG, 3, training, masks, p)      # :145
+        h = res_block(h, P, "z2_conv2.0", N_SEG, 3, training, masks, p, ld)      # :145
         h = F.conv_transpose1d(h, P["z2_conv2.1.weight"], P["z2_conv2.1.bias"], 2, 0, 0, N_SEG)
-        h = res_block(h, P, "z2_conv2.2", N_SEG, 3, training, masks, p)
+        h = res_block(h, P, "z2_conv2.2", N_SEG, 3, training, masks, p, ld)
         z2 = roi_unpool(h.view(B, 128, N_SEG, 2 * ROI_BINS), rois)           # :147
         z2 = F.conv1d(z2, P["single_conv_z2.0.weight"], P["single_conv_z2.0.bias"], padding=1)   # :148
         z1_list.append(z1)
@@ -324,9 +389,9 @@ def forward2(P, Bf, x, input_thetas, query_theta, rois, rest_theta=None, phase="
     shuf_p = torch.cat([z1_list[c1], z2m], dim=1)                            # :167
     shuf_l = torch.cat([z1m, z2_list[c2]], dim=1)                            # :168
     q = F.linear(angular_encoding(query_theta).reshape(B, -1), P["mlp2.weight"], P["mlp2.bias"])
-    out = decoder(q[:, :, None] * latent, P, Bf, training)                   # :174-176
-    out_p = decoder(q[:, :, None] * shuf_p, P, Bf, training)
-    out_l = decoder(q[:, :, None] * shuf_l, P, Bf, training)
+    out = decoder(q[:, :, None] * latent, P, Bf, training, dec=dec, pass_id=0)                   # :174-176
+    out_p = decoder(q[:, :, None] * shuf_p, P, Bf, training, dec=dec, pass_id=1)
+    out_l = decoder(q[:, :, None] * shuf_l, P, Bf, training, dec=dec, pass_id=2)
     if phase == "train":
         return out, out_p, out_l
     if phase in ("val", "test"):
@@ -350,13 +415,17 @@ def gen_ecg(P, Bf, z1, z2, query_theta, rois):
 # loss (network/loss/losses.py:5-50) and the solver step (solver/solver.py:171-189,232-235)
 # --------------------------------------------------------------------------
 def loss_v1(pred, pred_p, pred_l, target, loss_factor=(0.5, 0.5, 1.0), loss_using=(1, 2, 3),
-            reg_loss="l1_loss", rest_out=None, rest_view=None):
+            reg_loss="l1_loss", rest_out=None, rest_view=None, dec=_PLAIN):
     reg = F.mse_loss if reg_loss == "l2_loss" else F.l1_loss
     if reg_loss not in ("l1_loss", "l2_loss"):
         raise NotImplementedError
-    l1 = F.l1_loss(pred.detach(), pred_p) if 1 in loss_using else 0.0
-    l2 = F.l1_loss(pred.detach(), pred_l) if 2 in loss_using else 0.0
-    l3 = reg(pred, target) if 3 in loss_using else 0.0
+    # nn.L1Loss == mean(|a - b|); `dec` may replay the residual signs (see Decisions)
+    l1 = dec.l1("loss1", pred.detach(), pred_p) if 1 in loss_using else 0.0
+    l2 = dec.l1("loss2", pred.detach(), pred_l) if 2 in loss_using else 0.0
+    if 3 in loss_using:
+        l3 = dec.l1("loss3", pred, target) if reg_loss == "l1_loss" else reg(pred, target)
+    else:
+        l3 = 0.0
     f = loss_factor
     total = l1 * f[0] + l2 * f[1] + l3 * f[2]
     if rest_out is not None and rest_view is not None:
@@ -397,6 +466,37 @@ def train_step(P, Bf, opt, batch, loss_factor=(0.5, 0.5, 1.0), loss_using=(1, 2,
     vals = [float(v.detach()) for v in losses]
     opt.step(P)
     return vals
+
+
+def dp_train_step(P, Bf_ranks, opt, shards, masks_ranks=None, p=DROP_P, lead_choice=None, **loss_kw):
+    """One data-parallel iteration with the semantics of the reference's `nn.DataParallel` wrapper
+    (solver/solver.py:32-34): every replica runs the forward on its equal-sized shard with
+    BatchNorm statistics of THAT shard (replica r updates `Bf_ranks[r]`; replica 0's buffers are the module's own),
+    the loss is the mean over the gathered batch, i.e. the parameter gradient is the average of the per-shard
+    mean-loss gradients; one SGD step on the shared parameters.  Both Standin lead draws are shared by the replicas
+    (the build's defined behaviour: identical seeds on every rank).  Returns (per-shard loss 4-tuples, averaged grads)."""
+    if lead_choice is None:
+        V = shards[0]["data"].shape[1]
+        lead_choice = (random.randint(0, V - 1), random.randint(0, V - 1))
+    world = len(shards)
+    acc, vals = {}, []
+    for r, batch in enumerate(shards):
+        for v in P.values():
+            v.grad = None
+        out, out_p, out_l = forward(P, Bf_ranks[r], batch["data"], batch["input_theta"], batch["target_theta"],
+                                    batch["rois"], phase="train", training=True,
+                                    masks=None if masks_ranks is None else masks_ranks[r], p=p, lead_choice=lead_choice)
+        losses = loss_v1(out, out_p, out_l, batch["target_view"].unsqueeze(1), **loss_kw)
+        losses[0].backward()
+        vals.append([float(v.detach()) for v in losses])
+        for k, v in P.items():
+            if v.grad is not None:
+                acc[k] = v.grad.clone() if k not in acc else acc[k] + v.grad
+    for k, v in P.items():
+        v.grad = acc[k] / world if k in acc else None
+    avg = {k: v.grad.clone() for k, v in P.items() if v.grad is not None}
+    opt.step(P)
+    return vals, avg
 
 
 def require_grad(P):

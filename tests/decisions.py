@@ -1,0 +1,119 @@
+"""Tie-aware gradient parity (test helper).
+
+A backward pass is discontinuous at every ReLU and L1 residual whose argument sits at the switching point.  Instead of
+loosening the gradient bar for such ties, the oracle REPLAYS the discrete decisions the HIP path took
+(`oracle.Decisions`), the test asserts that every decision the oracle itself would have taken differently is a genuine
+tie (pre-activation at round-off level relative to that site's scale), and the gradients are then held to the
+tie-free bars: flat <= 1e-4, per tensor <= 1e-3 rel-L2."""
+import torch
+
+from util import rel
+
+FLAT_TOL, TENSOR_TOL = 1e-4, 1e-3
+TIE_REL = 1e-4            # a flipped decision must have |pre-activation| <= TIE_REL * rms(pre-activation of its site)
+TIE_FRAC = 1e-5           # and flips must be rare: <= TIE_FRAC * numel + 2 per site
+
+
+def _pos(t):
+    return (t > 0).cpu()
+
+
+def gpu_decisions(model, outs, target, keep_masks=None, reg_l1=True, fold=None):
+    """Decision masks of the last train-phase forward of `model` (needs model.keep_saved = True before the call).
+    `fold=(B, V)`: Model_nefnet2 -- the encoder ran on the lead-folded batch (row n = v*B + b); its sites are emitted
+    per lead as "<site>@<v>"."""
+    sv = model.last_saved
+    assert sv is not None, "set model.keep_saved = True before the forward"
+    dm = {}
+
+    def emit(site, full):
+        """`full`: bool tensor over the (folded) batch, or callable(own rows, row slice) -> decision."""
+        if fold is None:
+            dm[site] = full if not callable(full) else (lambda own, f=full: f(own, slice(None)))
+            return
+        B, V = fold
+        for v in range(V):
+            rows = slice(v * B, (v + 1) * B)
+            dm[f"{site}@{v}"] = full[rows] if not callable(full) else (lambda own, f=full, rows=rows: f(own, rows))
+
+    def block(saved, window=None):
+        h, y, prefix = saved[1], saved[2], saved[3]
+        h1, y1 = _pos(h), _pos(y)
+        keep = None if keep_masks is None else keep_masks[prefix].bool()
+        if window is None:
+            if keep is None:
+                emit(prefix + ".relu1", h1)
+            else:       # dropped positions (keep == 0) carry no decision: leave the oracle's own there
+                emit(prefix + ".relu1", lambda own, rows: torch.where(keep[rows], h1[rows], own))
+            emit(prefix + ".relu2", y1)
+            return
+        # the block ran on a 6-sample window: h is exact on window columns 1..4, y on columns 2..3 (the two rows
+        # roi_algin reads); everything else keeps the oracle's own decision and carries no gradient
+        t0 = window[0]
+
+        def r1(own, rows):
+            m = own.clone()
+            sl = slice(t0 + 1, t0 + 5)
+            hw_ = h1[rows][:, :, 1:5]
+            m[:, :, sl] = hw_ if keep is None else torch.where(keep[rows][:, :, sl], hw_, own[:, :, sl])
+            return m
+
+        def r2(own, rows):
+            m = own.clone()
+            m[:, :, t0 + 2:t0 + 4] = y1[rows][:, :, 2:4]
+            return m
+        emit(prefix + ".relu1", r1)
+        emit(prefix + ".relu2", r2)
+
+    for s in sv["blk_enc"]:
+        block(s)
+    for key in ("blk_w_conv", "blk_z1", "blk_c20", "blk_c22"):
+        block(sv[key])
+    block(sv["blk_z2c"], sv["z2_win"])
+    saved, passes = sv["dec"][0], sv["dec"][3]
+    names = ("decoder.1.double_conv.1", "decoder.1.double_conv.4", "decoder.3.double_conv.1", "decoder.3.double_conv.4")
+    for li, ent in enumerate(saved):
+        c, a, b = ent[1], ent[4], ent[5]
+        Bp = c.shape[0] // passes
+        for p in range(passes):
+            pre = torch.addcmul(b[p].double().view(1, -1, 1), c[p * Bp:(p + 1) * Bp].double(), a[p].double().view(1, -1, 1))
+            dm[f"pass{p}.{names[li]}"] = _pos(pre)
+    o, op, ol = (t.detach() for t in outs)
+    dm["loss1"] = torch.sign(o - op).cpu()
+    dm["loss2"] = torch.sign(o - ol).cpu()
+    if reg_l1:
+        dm["loss3"] = torch.sign(o - target.to(o.device)).cpu()
+    return dm
+
+
+def assert_flips_are_ties(dec):
+    for site, r in dec.report.items():
+        if r["flips"] == 0:
+            continue
+        assert r["flips"] <= TIE_FRAC * r["numel"] + 2, (site, r)
+        assert r["worst"] <= TIE_REL * max(r["rms"], 1e-30), (site, r)
+
+
+def assert_grad_parity(named_grads, P_ref, dead=(), zero_abs=None, flat_tol=FLAT_TOL, tensor_tol=TENSOR_TOL):
+    """named_grads: {name: HIP gradient}; P_ref: oracle params with .grad.  `zero_abs`: names whose gradient is
+    analytically zero (BatchNorm-shadowed biases), held to an absolute bar instead."""
+    zero_abs = zero_abs or (lambda k: k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"))
+    got, want, worst = [], [], (0.0, None)
+    for k, v in P_ref.items():
+        if k in dead:
+            assert named_grads.get(k) is None, k
+            continue
+        g = named_grads[k].detach().double().cpu()
+        r = v.grad.detach().double()
+        if zero_abs(k):
+            assert float((g - r).abs().max()) < 1e-6, k
+            continue
+        e = rel(g, r)
+        if e > worst[0]:
+            worst = (e, k)
+        got.append(g.reshape(-1))
+        want.append(r.reshape(-1))
+    flat = rel(torch.cat(got), torch.cat(want))
+    assert flat < flat_tol, (flat, worst)
+    assert worst[0] < tensor_tol, worst
+    return flat, worst

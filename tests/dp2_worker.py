@@ -1,0 +1,84 @@
+"""One data-parallel rank of tests/test_dp_gpu.py.  Two of these share cuda:0 (NEF_SHARE_GPU=1) and talk over gloo
+(NEF_DIST_BACKEND=gloo), so the REAL train step -- Model_nefnet forward, losswrapper, backward, FusedSGD with its
+flat-gradient all-reduce -- runs with world_size 2 on a one-GPU box.  Launched with RANK / WORLD_SIZE / MASTER_* set.
+
+part 1 (BASELINE configs[2] shape: 8 leads): one step on this rank's shard of a (4, 8, L) batch, dropout masks replayed.
+part 2: two iterations of Solver.run_one_epoch over parallel.ShardedLoader (the packaged driver's sharding)."""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from electrocardio_panorama_amd import parallel, synth                       # noqa: E402
+from electrocardio_panorama_amd.network import build_loss, build_model       # noqa: E402
+from electrocardio_panorama_amd.solver import Solver                         # noqa: E402
+from electrocardio_panorama_amd.solver.optim_scheduler import get_optimizer  # noqa: E402
+from oracle import hashweights as hw                                         # noqa: E402
+from test_model_gpu import make_cfg                                          # noqa: E402
+
+out_dir = sys.argv[1]
+rank, world, local = parallel.init_from_env()
+assert world == 2 and dist.is_initialized() and local == 0
+dev = torch.device("cuda", local)
+
+
+def flat_params(model):
+    return torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()
+
+
+def buffers(model):
+    return {k: v.detach().cpu().numpy().copy() for k, v in model.named_buffers() if "running" in k}
+
+
+# ---------------------------------------------------------------- part 1: one 8-lead step
+V, B, L, seed = 8, 4, 1000, 21
+cfg = make_cfg(V)
+model = build_model(cfg).float()
+model.load_state_dict({**hw.hashed_params(V), **hw.hashed_buffers()})
+model.to(dev).train()
+full = synth.make_batch(B, V, L, seed=seed)
+shard = parallel.shard_batch(full, rank, world)
+idx = parallel.shard_indices(B, rank, world)
+masks = hw.hashed_masks(V, B, L // 4)
+model.dropout_masks = {k: v[idx[0]:idx[-1] + 1].contiguous().to(dev) for k, v in masks.items()}
+b = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in shard.items()}
+optim = get_optimizer(cfg, model.parameters())
+random.seed(seed)
+outs = model(b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train")
+losses = build_loss(cfg)(outs[0], outs[1], outs[2], b["target_view"].unsqueeze(1), cfg)
+losses[0].backward()
+names = [n for n, p in model.named_parameters() if p.grad is not None]
+optim.step()
+avg_grad = (optim._flat[0]["g"] / world).cpu().numpy()          # the all-reduced sum / world, in `names` order
+optim.zero_grad()
+buf_before = buffers(model)
+parallel.broadcast_buffers(model)
+buf_after = buffers(model)
+np.savez(os.path.join(out_dir, f"step_rank{rank}.npz"), params=flat_params(model), avg_grad=avg_grad,
+         names=np.array(names), losses=np.array([float(v) for v in losses]), idx=np.array(idx),
+         **{"before:" + k: v for k, v in buf_before.items()}, **{"after:" + k: v for k, v in buf_after.items()})
+del model, optim, outs, losses
+dist.barrier()
+
+# ---------------------------------------------------------------- part 2: Solver.run_one_epoch over sharded loaders
+V, B, L, seed, steps = 3, 4, 512, 5, 2
+cfg = make_cfg(V)
+sol = Solver(cfg, use_tensorboardx=False)
+assert sol.device == dev
+sol.model.load_state_dict({**hw.hashed_params(V), **hw.hashed_buffers()})
+sol.model.dropout_p = 0.0
+batches = [synth.make_batch(B, V, L, seed=seed + s, Q=2) for s in range(steps)]
+optim = get_optimizer(cfg, sol.model.parameters())
+random.seed(seed)
+res = sol.run_one_epoch(parallel.ShardedLoader(batches), "train", optim)
+assert len(res[2]) == steps * B // world and res[2][0].shape == (L,)        # predicted views of this rank's shards
+np.savez(os.path.join(out_dir, f"solver_rank{rank}.npz"), params=flat_params(sol.model), losses=np.array(res[0]))
+dist.barrier()
+dist.destroy_process_group()
+print("DP2_OK", rank)

@@ -1,0 +1,126 @@
+"""Data parallelism with world_size 2 on the REAL train step (BASELINE configs[2] semantics).
+
+The test box has one GPU, so two ranks share cuda:0 and exchange gradients over gloo (test hooks NEF_SHARE_GPU /
+NEF_DIST_BACKEND of parallel.init_from_env); everything else -- sharding, per-shard BatchNorm, the flat-gradient
+all-reduce folded into the fused SGD kernel, rank-0 buffers, bench.py's multi-rank branch -- is the production path.
+The oracle side restates the reference's nn.DataParallel semantics (oracle.dp_train_step)."""
+import json
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import rel
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(port):
+    return dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", NEF_DIST_BACKEND="gloo",
+                NEF_SHARE_GPU="1", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+
+@pytest.fixture(scope="module")
+def dp_run(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("dp2"))
+    script = os.path.join(ROOT, "tests", "dp2_worker.py")
+    procs = [subprocess.Popen([sys.executable, script, out], env=dict(_env(29681), RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(lg[-3000:] for lg in logs)
+    return out
+
+
+def test_world2_step_8_leads_vs_per_shard_bn_oracle(dp_run):
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    from electrocardio_panorama_amd import parallel, synth
+    a, b = (np.load(os.path.join(dp_run, f"step_rank{r}.npz")) for r in range(2))
+    # (i) both ranks hold bit-identical parameters after the step; the shards cover the batch exactly once
+    assert np.array_equal(a["params"], b["params"]) and np.array_equal(a["avg_grad"], b["avg_grad"])
+    assert sorted(np.concatenate([a["idx"], b["idx"]]).tolist()) == [0, 1, 2, 3]
+    # (ii) against the oracle: two shard gradients with PER-SHARD BatchNorm statistics, averaged, one SGD step
+    V, B, L, seed = 8, 4, 1000, 21
+    full = synth.make_batch(B, V, L, seed=seed)
+    masks = hw.hashed_masks(V, B, L // 4)
+    shards, mranks = [], []
+    for r in range(2):
+        sh = parallel.shard_batch(full, r, 2)
+        idx = parallel.shard_indices(B, r, 2)
+        shards.append({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sh.items()})
+        mranks.append({k: v[idx[0]:idx[-1] + 1] for k, v in masks.items()})
+    P = orc.require_grad(hw.hashed_params(V))
+    P0 = {k: v.detach().clone() for k, v in P.items()}
+    Bfs = [hw.hashed_buffers(), hw.hashed_buffers()]
+    random.seed(seed)
+    vals, avg = orc.dp_train_step(P, Bfs, orc.SGDState(0.1), shards, masks_ranks=mranks, loss_factor=(0.5, 0.5, 1.0))
+    for r, z in enumerate((a, b)):
+        assert np.abs(z["losses"] - np.array(vals[r])).max() < 2e-6, (r, z["losses"], vals[r])
+    names = [str(n) for n in a["names"]]
+    assert set(names) == {k for k in P if k not in orc.DEAD_PARAMS}
+    want = torch.cat([avg[n].reshape(-1) for n in names]).numpy()
+    assert rel(a["avg_grad"], want) < 2e-4, rel(a["avg_grad"], want)
+    # post-step parameters: compare the UPDATE (p_new - p_old), which is what the step produced
+    from test_model_gpu import make_cfg
+    from electrocardio_panorama_amd.network import build_model
+    order = [n for n, _ in build_model(make_cfg(V)).named_parameters()]
+    new = torch.cat([P[n].detach().reshape(-1) for n in order]).numpy()
+    old = torch.cat([P0[n].reshape(-1) for n in order]).numpy()
+    assert rel(a["params"] - old, new - old) < 2e-4, rel(a["params"] - old, new - old)
+    # (iii) running statistics are per shard until rank 0's are broadcast
+    keys = [k[7:] for k in a.files if k.startswith("before:")]
+    assert keys and any(not np.array_equal(a["before:" + k], b["before:" + k]) for k in keys)
+    for k in keys:
+        assert np.array_equal(a["after:" + k], a["before:" + k])            # rank 0 is authoritative
+        assert np.array_equal(b["after:" + k], a["before:" + k])
+        assert rel(a["before:" + k], Bfs[0][k].numpy()) < 1e-5 and rel(b["before:" + k], Bfs[1][k].numpy()) < 1e-5
+
+
+def test_world2_solver_epoch_sharded_loader_vs_oracle(dp_run):
+    """Solver.run_one_epoch over parallel.ShardedLoader on two ranks == the oracle's DataParallel iteration, twice
+    (momentum carried): per-rank losses are the shard means, parameters agree across ranks and with the oracle."""
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    from electrocardio_panorama_amd import parallel, synth
+    from electrocardio_panorama_amd.network import build_model
+    from test_model_gpu import make_cfg
+    a, b = (np.load(os.path.join(dp_run, f"solver_rank{r}.npz")) for r in range(2))
+    assert np.array_equal(a["params"], b["params"])
+    V, B, L, seed, steps = 3, 4, 512, 5, 2
+    P = orc.require_grad(hw.hashed_params(V))
+    P0 = {k: v.detach().clone() for k, v in P.items()}
+    Bfs, opt = [hw.hashed_buffers(), hw.hashed_buffers()], orc.SGDState(0.1)
+    random.seed(seed)
+    for s in range(steps):
+        full = synth.make_batch(B, V, L, seed=seed + s, Q=2)
+        shards = [{k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in parallel.shard_batch(full, r, 2).items()}
+                  for r in range(2)]
+        vals, _ = orc.dp_train_step(P, Bfs, opt, shards, p=0.0, loss_factor=(0.5, 0.5, 1.0))
+        for r, z in enumerate((a, b)):
+            assert np.abs(z["losses"][s] - np.array(vals[r])).max() < 2e-5, (s, r)
+    order = [n for n, _ in build_model(make_cfg(V)).named_parameters()]
+    new = torch.cat([P[n].detach().reshape(-1) for n in order]).numpy()
+    old = torch.cat([P0[n].reshape(-1) for n in order]).numpy()
+    assert rel(a["params"] - old, new - old) < 5e-4, rel(a["params"] - old, new - old)
+
+
+def test_bench_two_ranks_prints_one_json_line():
+    """bench.py's torchrun branch (barrier, max-over-ranks timing, whole-job value) with world_size 2."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29683", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--batch", "8", "--len", "1000", "--leads", "8"]
+    env = _env(29683)
+    env.pop("WORLD_SIZE")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 16
+    assert line["value"] > 0 and abs(line["value"] - 16 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-3 * line["value"]
+    assert line["cpu_baseline"] is None and np.isfinite(line["final_loss"])

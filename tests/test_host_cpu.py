@@ -221,3 +221,137 @@ def test_ptb_dataset_reproduces_reference_items(tmp_path):
     (tmp_path / "ref.pkl").write_bytes(blob)
     hbs = HeartBeatList("unused", "unused", str(tmp_path / "ref.pkl")).heart_beats
     assert isinstance(hbs[0], HeartBeat) and hbs[0].data.shape == (12, 5) and hbs[0].rois_list[6, 1] == 13
+
+
+def test_checkpointer_load_order(tmp_path):
+    """Reference checkpointer.py:40-60: an explicit path wins over `last_checkpoint`; best_valid only without a path."""
+    import torch
+    from electrocardio_panorama_amd.utils import CheckPointer
+    m = torch.nn.Linear(2, 2)
+    ck = CheckPointer(m, save_dir=str(tmp_path))
+    assert ck.load() == {} and ck.load(best_valid=True) == {}
+    for e in (0, 1):
+        with torch.no_grad():
+            m.weight.fill_(float(e))
+        ck.save(f"epoch_{e}", epoch=e)
+    with torch.no_grad():
+        m.weight.fill_(7.0)
+    ck.save("best_valid", epoch=0, best_test_psnr_gen=3.0)
+    ck.save("epoch_2", epoch=2)
+    assert ck.load(os.path.join(tmp_path, "epoch_0.pkl"))["epoch"] == 0 and float(m.weight[0, 0]) == 0.0
+    assert ck.load("")["epoch"] == 2 and ck.load(None)["epoch"] == 2                     # the pointer
+    assert ck.load(best_valid=True)["best_test_psnr_gen"] == 3.0 and float(m.weight[0, 0]) == 7.0
+    assert ck.load(os.path.join(tmp_path, "epoch_1.pkl"), best_valid=True)["epoch"] == 1  # explicit path still wins
+    with pytest.raises(FileNotFoundError):
+        ck.load(os.path.join(tmp_path, "epoch_9.pkl"))
+    sd = torch.load(os.path.join(tmp_path, "epoch_1.pkl"))
+    torch.save({"model": {"module." + k: v for k, v in sd["model"].items()}, "epoch": 5}, os.path.join(tmp_path, "dp.pkl"))
+    assert ck.load(os.path.join(tmp_path, "dp.pkl"))["epoch"] == 5 and float(m.weight[0, 0]) == 1.0
+
+
+def test_sharded_loader_and_missing_label_lists(tmp_path):
+    from electrocardio_panorama_amd import parallel, synth
+    from electrocardio_panorama_amd.config import get_defaults
+    batches = [synth.make_batch(8, 2, 64, seed=s) for s in range(3)]
+    seen = [list(parallel.ShardedLoader(batches, r, 4)) for r in range(4)]
+    assert all(len(s_) == 3 for s_ in seen) and len(parallel.ShardedLoader(batches, 0, 4)) == 3
+    for i, full in enumerate(batches):
+        for k in full:
+            assert np.array_equal(np.concatenate([seen[r][i][k] for r in range(4)]), full[k])
+    assert list(parallel.ShardedLoader(batches, 0, 1))[1] is batches[1]
+    with pytest.raises(ValueError):
+        parallel.shard_batch(batches[0], 0, 3)
+    # a mistyped label list is an error (as in the reference), not a silent switch to synthetic data
+    from electrocardio_panorama_amd import train_net
+    cfg = get_defaults()
+    cfg.DATA.train_label_path = str(tmp_path / "nope.txt")
+    with pytest.raises(FileNotFoundError):
+        train_net.build_loaders(cfg)
+    cfg.DATA.synthetic = True
+    cfg.DATA.lead_num = 3
+    tr, te = train_net.build_loaders(cfg, batch_size=4)
+    b = next(iter(tr))
+    assert b["data"].shape == (4, 3, 512) and b["rest_view"].shape[1] == 9 and next(iter(te))["data"].shape[0] == 4
+
+
+def test_oracle_decision_replay_and_dp_step():
+    """The test instruments of the oracle: replaying the oracle's OWN decisions changes nothing and reports no flips; a
+    forced difference is reported with its distance from the switching point; dp_train_step with one replica equals
+    train_step, with two replicas it averages per-shard gradients (per-shard BatchNorm)."""
+    import random
+    import torch
+    from electrocardio_panorama_amd import parallel, synth
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    V, B, L = 2, 2, 256
+    b = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.make_batch(B, V, L, seed=9).items()}
+
+    def run(dec):
+        P = orc.require_grad(hw.hashed_params(V))
+        o = orc.forward(P, hw.hashed_buffers(), b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train",
+                        training=True, p=0.0, lead_choice=(0, 1), dec=dec)
+        orc.loss_v1(o[0], o[1], o[2], b["target_view"].unsqueeze(1), dec=dec)[0].backward()
+        return o, torch.cat([v.grad.reshape(-1) for k, v in P.items() if v.grad is not None])
+
+    class Spy(orc.Decisions):                       # records the oracle's own decisions
+        def relu(self, site, pre):
+            self.masks_seen = getattr(self, "masks_seen", {})
+            self.masks_seen[site] = pre.detach() > 0
+            return super().relu(site, pre)
+
+    spy = Spy()
+    o0, g0 = run(spy)
+    own = dict(spy.masks_seen)
+    own.update(loss1=torch.sign(o0[0].detach() - o0[1].detach()), loss2=torch.sign(o0[0].detach() - o0[2].detach()),
+               loss3=torch.sign(o0[0].detach() - b["target_view"].unsqueeze(1)))
+    d1 = orc.Decisions(own)
+    _, g1 = run(d1)
+    assert d1.total_flips() == 0 and len(d1.report) == len(own) and float((g1 - g0).abs().max()) < 1e-7 * float(g0.abs().max())
+    site = "pass0.decoder.3.double_conv.4"
+    forced = dict(own)
+    forced[site] = own[site].clone()
+    forced[site][0, 0, 0] = ~forced[site][0, 0, 0]
+    d2 = orc.Decisions(forced)
+    run(d2)
+    assert d2.total_flips() == 1 and d2.report[site]["flips"] == 1 and d2.report[site]["worst"] > 0
+
+    def fresh():
+        return orc.require_grad(hw.hashed_params(V)), orc.SGDState(0.1)
+
+    P1, o1 = fresh()
+    random.seed(1)
+    v1 = orc.train_step(P1, hw.hashed_buffers(), o1, b, p=0.0, lead_choice=(1, 0))
+    P2, o2 = fresh()
+    vals, _ = orc.dp_train_step(P2, [hw.hashed_buffers()], o2, [b], p=0.0, lead_choice=(1, 0))
+    assert vals[0] == v1 and all(torch.equal(P1[k], P2[k]) for k in P1)
+    P3, o3 = fresh()
+    shards = [{k: v[r:r + 1] for k, v in b.items()} for r in range(2)]
+    Bfs = [hw.hashed_buffers(), hw.hashed_buffers()]
+    vals3, avg = orc.dp_train_step(P3, Bfs, o3, shards, p=0.0, lead_choice=(1, 0))
+    assert len(vals3) == 2 and not torch.equal(Bfs[0]["decoder.1.double_conv.1.running_mean"],
+                                               Bfs[1]["decoder.1.double_conv.1.running_mean"])
+    assert not all(torch.equal(P1[k], P3[k]) for k in P1)        # per-shard BatchNorm != full-batch BatchNorm
+
+
+def test_dropin_shim_resolves_reference_import_lines():
+    """With electrocardio_panorama_amd/dropin first on sys.path, the import statements of the reference's entry scripts
+    (codes/main.py:1-9, train_net.py:1-8, val_net.py:1-6, solver/solver.py:10-13) resolve to this build's objects."""
+    code = (
+        "from train_net import main\n"
+        "from config import cfg\n"
+        "from dataset import build_dataset\n"
+        "from dataset import *\n"
+        "from solver import Solver\n"
+        "from utils import seed_torch\n"
+        "from network import build_model, build_loss\n"
+        "from solver.optim_scheduler import get_optimizer, get_lr_scheduler\n"
+        "from utils.mertic import SSIM, PSNR\n"
+        "from utils import CheckPointer\n"
+        "import val_net, electrocardio_panorama_amd.train_net as tn, electrocardio_panorama_amd.solver.solver as ss\n"
+        "import electrocardio_panorama_amd.utils.metric as mm, electrocardio_panorama_amd.config as cc\n"
+        "assert main is tn.main and Solver is ss.Solver and PSNR is mm.PSNR and cfg is cc.cfg\n"
+        "assert callable(val_net.main) and callable(build_dataset) and cfg.SOLVER.optim == 'sgd'\n"
+        "print('DROPIN_OK')\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "electrocardio_panorama_amd", "dropin"), ROOT]))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0 and "DROPIN_OK" in r.stdout, r.stderr[-2000:]

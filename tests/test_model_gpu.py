@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 import torch
 
-from util import FWD_TOL, GRAD_TOL, maxabs, rel, stats, sub
+from decisions import FLAT_TOL, TENSOR_TOL, assert_flips_are_ties, assert_grad_parity, gpu_decisions
+from util import FWD_TOL, maxabs, rel, stats, sub
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -92,6 +93,7 @@ def _train_once(V, B, L, seed, reg, masked):
     from oracle import hashweights as hw
     cfg = make_cfg(V, reg)
     m = hashed_model(V).train()
+    m.keep_saved = True
     if masked:
         m.dropout_masks = {k: v.to(DEV) for k, v in hw.hashed_masks(V, B, L // 4).items()}
     else:
@@ -104,84 +106,92 @@ def _train_once(V, B, L, seed, reg, masked):
     return m, outs, losses
 
 
-# Gradient bars.  A backward pass through ReLU is discontinuous: when a pre-activation lands within fp32 round-off of
-# zero, the HIP path and the CPU reference can legitimately pick different sides, and at these tiny test shapes ONE such
-# tie among ~2e5 activations moves the whole flat gradient by 2e-4 .. 1.3e-3 (2e-4 was measured on the 3-lead
-# fixture before the decoder fusion; tools/debug_tie.py shows 1.3e-3 on the 5-lead case of test_every_supported_lead_count_vs_oracle, where the single
-# differing sign sits on a BatchNorm output of 1.9e-6 against a mean magnitude of 0.79).  So every case must stay under
-# LOOSE, and most cases -- the tie-free ones -- must sit at fp32 round-off (TIGHT).
-TIGHT, LOOSE = 2e-5, 3e-3
+def oracle_replaying(m, outs, b, V, seed, masks=None, dt=torch.float32, reg="l1_loss", model2=False, fold=None,
+                     lead_choice=None):
+    """Run the CPU oracle on the same inputs while it REPLAYS the discrete decisions (ReLU on/off, L1 signs) the HIP
+    path took in `m`'s last forward (tests/decisions.py); assert every decision the oracle would have taken differently
+    is a tie; assert the gradients agree at the tie-free bars (flat <= 1e-4, per tensor <= 1e-3).  Returns
+    (oracle outputs, oracle losses, Decisions, flat gradient rel-L2)."""
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    tgt = b["target_view"].unsqueeze(1)
+    dec = orc.Decisions(gpu_decisions(m, outs, tgt, keep_masks=masks, reg_l1=(reg == "l1_loss"), fold=fold))
+    src = hw.hashed_params2() if model2 else hw.hashed_params(V)
+    P = orc.require_grad({k: v.to(dt) for k, v in src.items()})
+    Bf = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in hw.hashed_buffers().items()}
+    random.seed(seed)
+    fwd = orc.forward2 if model2 else orc.forward
+    ref = fwd(P, Bf, b["data"].to(dt), b["input_theta"].to(dt), b["target_theta"].to(dt), b["rois"], phase="train",
+              training=True, masks=masks, p=0.2 if masks is not None else 0.0, dec=dec, lead_choice=lead_choice)
+    rl = orc.loss_v1(ref[0], ref[1], ref[2], tgt.to(dt), reg_loss=reg, dec=dec)
+    rl[0].backward()
+    assert_flips_are_ties(dec)
+    named = {k: p.grad for k, p in m.named_parameters()}
+    flat, worst = assert_grad_parity(named, P, dead=orc.DEAD_PARAMS)
+    dec.oracle_buffers = Bf
+    return ref, rl, dec, flat
+
+
+# Gradient bars (tests/decisions.py): flat gradient <= 1e-4, every tensor <= 1e-3 rel-L2 -- unconditionally.  The one
+# legitimate source of larger deviations, a ReLU / L1 argument within fp32 round-off of its switching point (one such tie
+# moved the flat gradient by 1.3e-3 at these tiny shapes in round 1, tools/debug_tie.py), is handled by making the
+# oracle replay the HIP path's decisions and asserting that each replayed difference IS a tie.
 
 
 def test_train_golden(golden_dir):
+    """Outputs, losses, BN buffers against the reference's own fixtures; gradients against the fixtures when the step
+    had no tie, and against the decision-replaying oracle always."""
+    from oracle import hashweights as hw
     from oracle import nefnet_oracle as orc
-    flat_rels = []
+    n_fixture_grad = 0
     for f in golden(golden_dir, "train_*.npz"):
         z = np.load(f)
         B, V, L, seed = (int(z[k]) for k in ("B", "V", "L", "seed"))
         name = os.path.basename(f)
-        m, outs, losses = _train_once(V, B, L, seed, str(z["reg"]), bool(int(z["masked"])))
+        masked = bool(int(z["masked"]))
+        m, outs, losses = _train_once(V, B, L, seed, str(z["reg"]), masked)
         for got, key in zip(outs, ("out", "shuf_p", "shuf_l")):
             assert rel(got, z[key]) < FWD_TOL, (name, key, rel(got, z[key]))
         assert maxabs(torch.stack([l_.detach() for l_ in losses]), z["losses"]) < 1e-6, name
-        sq, got_all, ref_all = 0.0, [], []
-        for k, p in m.named_parameters():
-            if k in orc.DEAD_PARAMS:
-                assert p.grad is None, k
-                continue
-            assert p.grad is not None, k
-            ref_sub = z["gsub:" + k]
-            if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
-                assert maxabs(sub(p.grad, 256), ref_sub) < 1e-6, (name, k)      # analytically zero
-                continue
-            assert rel(sub(p.grad, 256), ref_sub) < 5 * LOOSE, (name, k, rel(sub(p.grad, 256), ref_sub))
-            got_all.append(sub(p.grad, 256))
-            ref_all.append(ref_sub)
-            sq += float((p.grad.double() ** 2).sum())
-        assert abs(sq ** 0.5 - float(z["flat_grad_norm"])) < LOOSE * float(z["flat_grad_norm"]), name
-        flat_rels.append(rel(np.concatenate(got_all), np.concatenate(ref_all)))
+        masks = hw.hashed_masks(V, B, L // 4) if masked else None
+        _, _, dec, _ = oracle_replaying(m, outs, batch_t(B, V, L, seed, dev="cpu"), V, seed, masks=masks, reg=str(z["reg"]))
+        if dec.total_flips() == 0:      # tie-free: the reference's own gradients, at the same bars
+            n_fixture_grad += 1
+            sq, got_all, ref_all = 0.0, [], []
+            for k, p in m.named_parameters():
+                if k in orc.DEAD_PARAMS:
+                    assert p.grad is None, k
+                    continue
+                ref_sub = z["gsub:" + k]
+                if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
+                    assert maxabs(sub(p.grad, 256), ref_sub) < 1e-6, (name, k)      # analytically zero (SURVEY Q6)
+                    continue
+                assert rel(sub(p.grad, 256), ref_sub) < TENSOR_TOL, (name, k, rel(sub(p.grad, 256), ref_sub))
+                got_all.append(sub(p.grad, 256))
+                ref_all.append(ref_sub)
+                sq += float((p.grad.double() ** 2).sum())
+            assert abs(sq ** 0.5 - float(z["flat_grad_norm"])) < FLAT_TOL * float(z["flat_grad_norm"]), name
+            assert rel(np.concatenate(got_all), np.concatenate(ref_all)) < FLAT_TOL, name
         sd = m.state_dict()
         for k in sd:
             if "running" in k:
                 assert rel(sd[k], z["buf:" + k]) < 1e-5, (name, k)
             if k.endswith("num_batches_tracked"):
                 assert int(sd[k]) == 3, k
-    assert max(flat_rels) < LOOSE, flat_rels
-    assert sum(r < TIGHT for r in flat_rels) * 2 >= len(flat_rels), flat_rels
+    assert n_fixture_grad >= 1
 
 
 def test_train_vs_oracle_live():
     """Full flat gradient against the fp64 oracle run on the host (dropout masks replayed), several seeds."""
     from oracle import hashweights as hw
-    from oracle import nefnet_oracle as orc
     B, V, L = 2, 3, 520
-    rels, noise = [], []
     for seed in (31, 32, 33, 34):
         m, outs, losses = _train_once(V, B, L, seed, "l1_loss", True)
         b = batch_t(B, V, L, seed, dev="cpu")
-        masks = hw.hashed_masks(V, B, L // 4)
-
-        def oracle(dt):
-            P = orc.require_grad({k: v.to(dt) for k, v in hw.hashed_params(V).items()})
-            Bf = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in hw.hashed_buffers().items()}
-            random.seed(seed)
-            ref = orc.forward(P, Bf, b["data"].to(dt), b["input_theta"].to(dt), b["target_theta"].to(dt), b["rois"],
-                              phase="train", training=True, masks=masks)
-            orc.loss_v1(ref[0], ref[1], ref[2], b["target_view"].unsqueeze(1).to(dt))[0].backward()
-            return ref, P
-
-        r32, P32 = oracle(torch.float32)
-        r64, P64 = oracle(torch.float64)
-        for a, r in zip(outs, r32):
+        ref, rl, dec, flat = oracle_replaying(m, outs, b, V, seed, masks=hw.hashed_masks(V, B, L // 4), dt=torch.float64)
+        for a, r in zip(outs, ref):
             assert rel(a, r) < FWD_TOL
-        live = [k for k in P64 if k not in orc.DEAD_PARAMS]
-        named = dict(m.named_parameters())
-        flat = lambda Pd: torch.cat([Pd[k].grad.reshape(-1).double() for k in live])       # noqa: E731
-        got = torch.cat([named[k].grad.reshape(-1).double().cpu() for k in live])
-        rels.append(rel(got, flat(P64)))
-        noise.append(rel(flat(P32), flat(P64)))
-    assert max(rels) < LOOSE, (rels, noise)
-    assert sorted(rels)[len(rels) // 2 - 1] < max(TIGHT, 10 * max(noise)), (rels, noise)
+        assert flat < 2e-5, flat         # fp32 round-off against fp64 once ties are out of the picture
 
 
 def test_sgd_steps_golden(golden_dir):
@@ -322,6 +332,45 @@ def test_full_baseline_batch_vs_oracle_rows():
     assert bool(torch.isfinite(g1).all()) and float(g1.norm()) > 0
 
 
+def test_full_size_train_gradients_vs_oracle():
+    """BASELINE configs[1] at FULL size in TRAIN mode (256 x 3 x 5000, dropout masks replayed, batch-statistics
+    BatchNorm over 3.84 M elements per channel, split-K weight gradients over 320 k columns): outputs, losses, BN running
+    statistics and EVERY gradient tensor against the CPU oracle on the same batch, at the tie-free bars.  The oracle
+    needs ~40 GB of host memory for this batch; on a smaller host the same test runs at batch 64."""
+    import psutil
+    from electrocardio_panorama_amd.network import build_loss
+    from oracle import hashweights as hw
+    V, L, seed = 3, 5000, 271
+    B = 256 if psutil.virtual_memory().available > 90e9 else 64
+    T, C = L // 4, 128 * V
+    g = torch.Generator().manual_seed(seed)
+    shapes = {"W_encoder.layer1.0": (B, C, T), "W_encoder.layer1.1": (B, C, T), "W_encoder.layer1.2": (B, C, T),
+              "w_conv.0": (B, C, T), "z1_conv.0": (B, C, T), "z2_conv1.0": (B, C, T), "z2_conv2.0": (B, 7 * C, 16),
+              "z2_conv2.2": (B, 7 * C, 32)}
+    masks = {k: (torch.rand(sh, generator=g) >= 0.2).to(torch.uint8) for k, sh in shapes.items()}
+    cfg = make_cfg(V)
+    m = hashed_model(V).train()
+    m.keep_saved = True
+    m.dropout_masks = {k: v.to(DEV) for k, v in masks.items()}
+    b = batch_t(B, V, L, seed, dev="cpu")
+    bd = {k: v.to(DEV) for k, v in b.items()}
+    random.seed(seed)
+    outs = m(bd["data"], bd["input_theta"], bd["target_theta"], bd["rois"], phase="train")
+    losses = build_loss(cfg)(outs[0], outs[1], outs[2], bd["target_view"].unsqueeze(1), cfg)
+    losses[0].backward()
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    ref, rl, dec, flat = oracle_replaying(m, outs, b, V, seed, masks=masks)
+    for a, r in zip(outs, ref):
+        assert rel(a, r) < FWD_TOL, rel(a, r)
+    assert maxabs(torch.stack([l_.detach() for l_ in losses]), torch.stack([r.detach() for r in rl])) < 1e-6
+    sd = m.state_dict()
+    for k, v in dec.oracle_buffers.items():
+        if "running" in k:
+            assert rel(sd[k], v) < 1e-5, k
+    print(f"full-size train parity: B={B}, flat gradient rel-L2 {flat:.2e}, replayed ties {dec.total_flips()}")
+    m.last_saved = None
+
+
 @pytest.mark.parametrize("B,V,L,Q,phase", [
     (4, 1, 2048, 0, "train"),      # BASELINE configs[0] shape: batch 4, 1 lead, len 2048
     (2, 8, 5000, 0, "train"),      # configs[2] shape (Tianchi 8-lead, len 5000), small batch
@@ -337,20 +386,10 @@ def test_baseline_config_shapes_vs_oracle(B, V, L, Q, phase):
     b = batch_t(B, V, L, seed, Q, dev="cpu")
     if phase == "train":
         m, outs, losses = _train_once(V, B, L, seed, "l1_loss", False)
-        P, Bf = orc.require_grad(hw.hashed_params(V)), hw.hashed_buffers()
-        random.seed(seed)
-        ref = orc.forward(P, Bf, b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train", training=True,
-                          p=0.0)
-        rl = orc.loss_v1(ref[0], ref[1], ref[2], b["target_view"].unsqueeze(1))
-        rl[0].backward()
+        ref, rl, dec, flat = oracle_replaying(m, outs, b, V, seed)
         for a, r in zip(outs, ref):
             assert rel(a, r) < FWD_TOL
         assert maxabs(torch.stack([l_.detach() for l_ in losses]), torch.stack([r.detach() for r in rl])) < 1e-6
-        live = [k for k in P if k not in orc.DEAD_PARAMS]
-        named = dict(m.named_parameters())
-        got = torch.cat([named[k].grad.reshape(-1).cpu() for k in live])
-        want = torch.cat([P[k].grad.reshape(-1) for k in live])
-        assert rel(got, want) < LOOSE, rel(got, want)
     else:
         m = hashed_model(V).eval()
         bd = {k: v.to(DEV) for k, v in b.items()}
@@ -410,6 +449,77 @@ def test_solver_test_phase_vs_oracle():
                 SSIM(ro[:, :-2], rv[:, :-2], rn)]
         assert np.abs(np.array(mertics_all[i]) - np.array(want)).max() < 1e-3
     assert len(predict_views) == 2 * B and predict_views[0].shape == (Q, L)
+
+
+def test_view_metrics_kernel_vs_host():
+    """nef_view_metrics (per-row PSNR / SSIM on the un-padded region) against the host restatement of mertic.py."""
+    from electrocardio_panorama_amd import ops as o
+    from electrocardio_panorama_amd.utils.metric import PSNR, SSIM
+    rng = np.random.default_rng(3)
+    B, Q, L = 5, 6, 512
+    gt = rng.random((B, Q, L)).astype(np.float32)
+    pred = (gt + 0.05 * rng.standard_normal((B, Q, L))).astype(np.float32)
+    pred[1, 2] = gt[1, 2]                                        # exact match -> PSNR 100, SSIM 1
+    rois = np.zeros((B, 7, 2), np.int64)
+    rois[:, -1, 0] = [512, 300, 7, 333, 64]
+    ps, ss = o.view_metrics(torch.from_numpy(pred).to(DEV), torch.from_numpy(gt).to(DEV), torch.from_numpy(rois).to(DEV))
+    ps, ss = ps.cpu().numpy(), ss.cpu().numpy()
+    assert ps[1, 2] == 100.0 and abs(ss[1, 2] - 1.0) < 1e-12
+    for i in range(B):
+        for j in range(Q):
+            assert abs(ps[i, j] - PSNR(pred[i:i + 1, j:j + 1], gt[i:i + 1, j:j + 1], rois[i:i + 1])) < 1e-9
+            assert abs(ss[i, j] - SSIM(pred[i:i + 1, j:j + 1], gt[i:i + 1, j:j + 1], rois[i:i + 1])) < 1e-9
+    assert abs(ps.mean() - PSNR(pred, gt, rois)) < 1e-9 and abs(ss[:, -2:].mean() - SSIM(pred[:, -2:], gt[:, -2:], rois)) < 1e-9
+    ps2, ss2 = o.view_metrics(torch.from_numpy(pred).to(DEV), torch.from_numpy(gt).to(DEV))
+    assert abs(ps2.cpu().numpy().mean() - PSNR(pred, gt)) < 1e-9
+    rois[0, -1, 0] = 5                                            # shorter than the SSIM window
+    _, ss3 = o.view_metrics(torch.from_numpy(pred).to(DEV), torch.from_numpy(gt).to(DEV), torch.from_numpy(rois).to(DEV))
+    assert bool(torch.isnan(ss3[0]).all()) and not bool(torch.isnan(ss3[1:]).any())
+
+
+def test_solver_val_loads_checkpoints_and_reproduces_oracle_metrics(tmp_path):
+    """Solver.val (reference solver.py:118-137): epoch=-1 loads best_valid.pkl, epoch=n loads epoch_n.pkl even when
+    `last_checkpoint` points elsewhere (checkpointer.py:49-60); PSNR / SSIM equal the oracle's on the same batches."""
+    from electrocardio_panorama_amd import synth
+    from electrocardio_panorama_amd.solver import Solver
+    from electrocardio_panorama_amd.utils import CheckPointer
+    from electrocardio_panorama_amd.utils.metric import PSNR, SSIM
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    V, B, L, Q = 3, 3, 512, 6
+    cfg = make_cfg(V)
+    cfg["output_dir"], cfg["desc"] = str(tmp_path), "debug"
+    good = Solver(cfg, use_tensorboardx=False)
+    good.model.load_state_dict({**hw.hashed_params(V), **hw.hashed_buffers()})
+    ck = CheckPointer(good.model, save_dir=good.output_dir)
+    ck.save("epoch_7", epoch=7, psnr_gen=1.0, psnr_reg=2.0)
+    ck.save("best_valid", epoch=7, best_test_psnr_gen=1.0)
+    other = Solver(cfg, use_tensorboardx=False)                   # a different (randomly initialised) model saved LAST
+    CheckPointer(other.model, save_dir=other.output_dir).save("epoch_8", epoch=8)
+    assert open(os.path.join(good.output_dir, "last_checkpoint")).read().strip().endswith("epoch_8.pkl")
+    batches = [synth.make_batch(B, V, L, seed=60 + s, Q=Q) for s in range(2)]
+    P, Bf = hw.hashed_params(V), hw.hashed_buffers()
+    want = []
+    random.seed(5)
+    for meta in batches:
+        b = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in meta.items()}
+        with torch.no_grad():
+            o = orc.forward(P, Bf, b["data"], b["input_theta"], b["target_theta"], b["rois"], rest_theta=b["rest_theta"],
+                            phase="test", training=False)
+        ro, rv, rn = o[3].numpy(), meta["rest_view"], meta["rois"]
+        want.append([PSNR(ro[:, -4:], rv[:, -4:], rn), PSNR(ro[:, :-4], rv[:, :-4], rn), SSIM(ro[:, -4:], rv[:, -4:], rn),
+                     SSIM(ro[:, :-4], rv[:, :-4], rn)])
+    want = np.mean(want, axis=0)
+    for epoch in (-1, 7):
+        fresh = Solver(cfg, use_tensorboardx=False)
+        random.seed(5)
+        got = fresh.val(batches, epoch=epoch)
+        assert np.abs(np.array(got) - want).max() < 1e-3, (epoch, got, want)
+    random.seed(5)
+    last = Solver(cfg, use_tensorboardx=False).val(batches, epoch=8)
+    assert abs(last[0] - want[0]) > 1e-2                          # epoch_8 really is the other model
+    with pytest.raises(FileNotFoundError):
+        Solver(cfg, use_tensorboardx=False).val(batches, epoch=99)
 
 
 def test_real_recordings_golden(golden_dir):
@@ -472,6 +582,7 @@ def test_adversarial_rois_full_step_vs_oracle():
     assert torch.equal(start.cpu(), rs) and torch.equal(length.cpu(), rl) and int(rl.sum()) == 2 * (L // 4)
     m = hashed_model(V).train()
     m.dropout_p = 0.0
+    m.keep_saved = True
     bd = {k: v.to(DEV) for k, v in b.items()}
     random.seed(seed)
     outs = m(bd["data"], bd["input_theta"], bd["target_theta"], bd["rois"], phase="train")
@@ -480,18 +591,9 @@ def test_adversarial_rois_full_step_vs_oracle():
     losses = build_loss(cfg)(outs[0], outs[1], outs[2], bd["target_view"].unsqueeze(1), cfg)
     losses[0].backward()
     assert m.segment_status() == 0
-    P, Bf = orc.require_grad(hw.hashed_params(V)), hw.hashed_buffers()
-    random.seed(seed)
-    ref = orc.forward(P, Bf, b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train", training=True, p=0.0)
-    rl_ = orc.loss_v1(ref[0], ref[1], ref[2], b["target_view"].unsqueeze(1))
-    rl_[0].backward()
+    ref, rl_, dec, flat = oracle_replaying(m, outs, b, V, seed)
     for a, r in zip(outs, ref):
         assert rel(a, r) < FWD_TOL
-    live = [k for k in P if k not in orc.DEAD_PARAMS]
-    named = dict(m.named_parameters())
-    got = torch.cat([named[k].grad.reshape(-1).cpu() for k in live])
-    want = torch.cat([P[k].grad.reshape(-1) for k in live])
-    assert rel(got, want) < LOOSE, rel(got, want)
     # ROIs that do not tile [0, L] are flagged on the device (the reference would fail in torch.cat)
     bad = bd["rois"].clone()
     bad[0, 3, 1] = 5
@@ -509,7 +611,7 @@ def test_main_entry_trains_and_checkpoints(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "electrocardio_panorama_amd.main", "--config-file", "config/nef-net.yml",
-           "SOLVER.epochs", "2", "output_dir", str(tmp_path), "DATA.train_label_path", "/nonexistent",
+           "SOLVER.epochs", "2", "output_dir", str(tmp_path), "DATA.synthetic", "True",
            "DATA.lead_num", "3"]
     env = dict(os.environ, PYTHONPATH=root)
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
@@ -520,7 +622,19 @@ def test_main_entry_trains_and_checkpoints(tmp_path):
     assert l1 < l0
     outdir = os.path.join(str(tmp_path), "nef-net", "nef-net")
     ck = torch.load(os.path.join(outdir, "epoch_1.pkl"), map_location="cpu")
-    assert {"model", "optimizer", "scheduler", "epoch", "psnr_gen"} <= set(ck)
+    assert {"model", "optimizer", "scheduler", "epoch", "psnr_gen", "psnr_reg"} <= set(ck)      # solver.py:103-107
+    # the reference's scalar set (solver.py:82-100) through the fallback writer (no tensorboard in this image)
+    import json
+    rows = [json.loads(ln) for ln in open(os.path.join(str(tmp_path), "nef-net", "tf_logs", "scalars.jsonl"))]
+    tags = {r_["tag"] for r_ in rows}
+    assert {'train_loss_all', 'test_loss_all', 'train_loss_1', 'test_loss_1', 'train_loss_2', 'test_loss_2', 'train_3',
+            'test_3', 'test_unsuperv', 'psnr_gen', 'psnr_reg', 'ssim_gen', 'ssim_reg', 'psnr_reg_lead_0',
+            'ssim_reg_lead_3'} <= tags and {r_["step"] for r_ in rows} == {0, 1}
+    # val_net entry (reference val_net.py:9-48): loads best_valid.pkl and prints the four metrics
+    rv = subprocess.run([sys.executable, "-m", "electrocardio_panorama_amd.val_net"] + cmd[3:5] + cmd[7:], cwd=root, env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert rv.returncode == 0 and "psnr_gen:" in rv.stdout and "the latest best_test_psnr_gen" in rv.stdout, \
+        rv.stdout[-2000:] + rv.stderr[-2000:]
     from oracle import nefnet_oracle as orc
     assert set(ck["model"]) == set(orc.param_shapes(3)) | set(orc.buffer_shapes())
     assert open(os.path.join(outdir, "last_checkpoint")).read().strip().endswith(".pkl")
@@ -581,7 +695,7 @@ def test_nefnet2_golden(golden_dir):
     own outputs, lead means, losses and gradients (tests/golden/nefnet2_*.npz, dropout off)."""
     from electrocardio_panorama_amd.network import build_loss
     from oracle import nefnet_oracle as orc
-    flat_rels = []
+    n_fixture_grad = 0
     for f in golden(golden_dir, "nefnet2_*.npz"):
         z = np.load(f)
         B, V, L, Q, seed = (int(z[k]) for k in ("B", "V", "L", "Q", "seed"))
@@ -599,6 +713,7 @@ def test_nefnet2_golden(golden_dir):
         cfg = make_cfg(V, str(z["reg"]))
         m = hashed_model2(V).train()
         m.dropout_p = 0.0
+        m.keep_saved = True
         random.seed(seed)
         touts = m(b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train")
         losses = build_loss(cfg)(touts[0], touts[1], touts[2], b["target_view"].unsqueeze(1), cfg)
@@ -606,28 +721,30 @@ def test_nefnet2_golden(golden_dir):
         for got, key in zip(touts, ("t_out", "t_shuf_p", "t_shuf_l")):
             assert rel(got, z[key]) < FWD_TOL, (name, key, rel(got, z[key]))
         assert maxabs(torch.stack([l_.detach() for l_ in losses]), z["losses"]) < 1e-6, name
-        sq, got_all, ref_all = 0.0, [], []
-        for k, p in m.named_parameters():
-            if k in orc.DEAD_PARAMS:
-                assert p.grad is None, k
-                continue
-            assert p.grad is not None, k
-            ref_sub = z["gsub:" + k]
-            if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
-                assert maxabs(sub(p.grad, 256), ref_sub) < 1e-6, (name, k)
-                continue
-            assert rel(sub(p.grad, 256), ref_sub) < 5 * LOOSE, (name, k, rel(sub(p.grad, 256), ref_sub))
-            got_all.append(sub(p.grad, 256))
-            ref_all.append(ref_sub)
-            sq += float((p.grad.double() ** 2).sum())
-        assert abs(sq ** 0.5 - float(z["flat_grad_norm"])) < LOOSE * float(z["flat_grad_norm"]), name
-        flat_rels.append(rel(np.concatenate(got_all), np.concatenate(ref_all)))
+        bc = {k: v.cpu() for k, v in b.items()}
+        _, _, dec, _ = oracle_replaying(m, touts, bc, V, seed, reg=str(z["reg"]), model2=True, fold=(B, V))
+        if dec.total_flips() == 0:      # tie-free: the reference's own gradients, at the same bars
+            n_fixture_grad += 1
+            sq, got_all, ref_all = 0.0, [], []
+            for k, p in m.named_parameters():
+                if k in orc.DEAD_PARAMS:
+                    assert p.grad is None, k
+                    continue
+                ref_sub = z["gsub:" + k]
+                if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
+                    assert maxabs(sub(p.grad, 256), ref_sub) < 1e-6, (name, k)
+                    continue
+                assert rel(sub(p.grad, 256), ref_sub) < TENSOR_TOL, (name, k, rel(sub(p.grad, 256), ref_sub))
+                got_all.append(sub(p.grad, 256))
+                ref_all.append(ref_sub)
+                sq += float((p.grad.double() ** 2).sum())
+            assert abs(sq ** 0.5 - float(z["flat_grad_norm"])) < FLAT_TOL * float(z["flat_grad_norm"]), name
+            assert rel(np.concatenate(got_all), np.concatenate(ref_all)) < FLAT_TOL, name
         sd = m.state_dict()
         for k in sd:
             if "running" in k:
                 assert rel(sd[k], z["buf:" + k]) < 1e-5, (name, k)
-    assert max(flat_rels) < LOOSE, flat_rels
-    assert min(flat_rels) < TIGHT, flat_rels
+    assert n_fixture_grad >= 1
 
 
 def test_nefnet2_sgd_step_runs_through_solver_api():
