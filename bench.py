@@ -40,8 +40,9 @@ def parse():
     ap.add_argument("--len", type=int, default=5000, dest="length")
     ap.add_argument("--cpu-batch", type=int, default=32, help="CPU-baseline batch (SURVEY 8d: config-2 shape at B=32)")
     ap.add_argument("--cpu-steps", type=int, default=4)
-    ap.add_argument("--cpu-threads", type=str, default="all,32,1",
-                    help="thread pools to time the CPU baseline with ('all' = os.cpu_count()); the best one is headlined")
+    ap.add_argument("--cpu-threads", type=str, default="16,1",
+                    help="thread pools to time the CPU baseline with ('all' = os.cpu_count(): 5 MINUTES PER STEP on the "
+                         "256-core GPU box, profiles/r02_cpu_thread_sweep.md); the best one is headlined")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (launch-bound shapes)")
@@ -58,9 +59,11 @@ def make_cfg(V):
 
 def cpu_baseline(V, L, B, steps, pools):
     """The oracle (a torch-CPU port of the reference step) on this box's host cores, SURVEY 8d: config-2 shape at batch
-    32, 1 warm-up + `steps` timed steps with torch.set_num_threads(os.cpu_count()); also a bounded pool (torch-CPU
-    oversubscribes badly on many-core hosts: profiles/r02_cpu_thread_sweep.md) and a 1-thread figure (batch 4, fewer
-    steps -- a bounded sample).  `value` is the BEST pool's throughput, i.e. the strongest CPU baseline measured."""
+    32, 1 warm-up + `steps` timed steps per thread pool, plus a 1-thread figure (batch 4, fewer steps -- a bounded
+    sample).  SURVEY 8d asks for torch.set_num_threads(os.cpu_count()); on the 256-core GPU box that pool takes 307 s
+    per step (0.10 samples/s, measured: profiles/r02_cpu_thread_sweep.md) -- torch-CPU oversubscribes -- so the default
+    pools are the measured optimum (16 threads) and 1 thread; `--cpu-threads all,16,1` reproduces the full-pool
+    figure.  `value` is the BEST pool's throughput, i.e. the strongest CPU baseline measured."""
     from electrocardio_panorama_amd import synth
     from oracle import nefnet_oracle as orc
     ncpu = os.cpu_count() or 1

@@ -20,7 +20,7 @@ from electrocardio_panorama_amd.network import build_loss, build_model       # n
 from electrocardio_panorama_amd.solver import Solver                         # noqa: E402
 from electrocardio_panorama_amd.solver.optim_scheduler import get_optimizer  # noqa: E402
 from oracle import hashweights as hw                                         # noqa: E402
-from test_model_gpu import make_cfg                                          # noqa: E402
+from test_model_gpu import make_cfg, oracle_replaying                        # noqa: E402
 
 out_dir = sys.argv[1]
 rank, world, local = parallel.init_from_env()
@@ -42,11 +42,13 @@ cfg = make_cfg(V)
 model = build_model(cfg).float()
 model.load_state_dict({**hw.hashed_params(V), **hw.hashed_buffers()})
 model.to(dev).train()
+model.keep_saved = True
 full = synth.make_batch(B, V, L, seed=seed)
 shard = parallel.shard_batch(full, rank, world)
 idx = parallel.shard_indices(B, rank, world)
 masks = hw.hashed_masks(V, B, L // 4)
-model.dropout_masks = {k: v[idx[0]:idx[-1] + 1].contiguous().to(dev) for k, v in masks.items()}
+shard_masks = {k: v[idx[0]:idx[-1] + 1].contiguous() for k, v in masks.items()}
+model.dropout_masks = {k: v.to(dev) for k, v in shard_masks.items()}
 b = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in shard.items()}
 optim = get_optimizer(cfg, model.parameters())
 random.seed(seed)
@@ -54,6 +56,12 @@ outs = model(b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="t
 losses = build_loss(cfg)(outs[0], outs[1], outs[2], b["target_view"].unsqueeze(1), cfg)
 losses[0].backward()
 names = [n for n, p in model.named_parameters() if p.grad is not None]
+# this rank's shard gradient against the oracle on the same shard (tie-free bars, decisions replayed); the oracle's
+# shard gradient is handed to the parent, which checks the all-reduced average against the average of the two
+bc = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in shard.items()}
+_, _, dec, shard_flat = oracle_replaying(model, outs, bc, V, seed, masks=shard_masks)
+oracle_grad = torch.cat([dec.oracle_params[n].grad.reshape(-1) for n in names]).numpy()
+model.last_saved = None
 optim.step()
 avg_grad = (optim._flat[0]["g"] / world).cpu().numpy()          # the all-reduced sum / world, in `names` order
 optim.zero_grad()
@@ -61,7 +69,8 @@ buf_before = buffers(model)
 parallel.broadcast_buffers(model)
 buf_after = buffers(model)
 np.savez(os.path.join(out_dir, f"step_rank{rank}.npz"), params=flat_params(model), avg_grad=avg_grad,
-         names=np.array(names), losses=np.array([float(v) for v in losses]), idx=np.array(idx),
+         names=np.array(names), losses=np.array([float(v) for v in losses]), idx=np.array(idx), oracle_grad=oracle_grad,
+         flips=np.array(dec.total_flips()), shard_flat=np.array(shard_flat),
          **{"before:" + k: v for k, v in buf_before.items()}, **{"after:" + k: v for k, v in buf_after.items()})
 del model, optim, outs, losses
 dist.barrier()

@@ -63,15 +63,26 @@ def test_world2_step_8_leads_vs_per_shard_bn_oracle(dp_run):
         assert np.abs(z["losses"] - np.array(vals[r])).max() < 2e-6, (r, z["losses"], vals[r])
     names = [str(n) for n in a["names"]]
     assert set(names) == {k for k in P if k not in orc.DEAD_PARAMS}
-    want = torch.cat([avg[n].reshape(-1) for n in names]).numpy()
-    assert rel(a["avg_grad"], want) < 2e-4, rel(a["avg_grad"], want)
-    # post-step parameters: compare the UPDATE (p_new - p_old), which is what the step produced
+    # each rank checked its own shard gradient against the oracle (decision replay, flat <= 1e-4 / tensor <= 1e-3, inside
+    # the worker); the all-reduced, 1/world-scaled buffer must be the average of the two oracle shard gradients
+    assert float(a["shard_flat"]) < 1e-4 and float(b["shard_flat"]) < 1e-4
+    want = 0.5 * (a["oracle_grad"].astype(np.float64) + b["oracle_grad"].astype(np.float64))
+    assert rel(a["avg_grad"], want) < 1e-4, rel(a["avg_grad"], want)
+    if int(a["flips"]) == 0 and int(b["flips"]) == 0:       # no ReLU / L1 tie on either shard: the plain oracle, too
+        plain = torch.cat([avg[n].reshape(-1) for n in names]).numpy()
+        assert rel(a["avg_grad"], plain) < 2e-4, rel(a["avg_grad"], plain)
+    # post-step parameters: compare the UPDATE (p_new - p_old) = -lr * averaged gradient (first step: buf = g)
     from test_model_gpu import make_cfg
     from electrocardio_panorama_amd.network import build_model
     order = [n for n, _ in build_model(make_cfg(V)).named_parameters()]
-    new = torch.cat([P[n].detach().reshape(-1) for n in order]).numpy()
     old = torch.cat([P0[n].reshape(-1) for n in order]).numpy()
-    assert rel(a["params"] - old, new - old) < 2e-4, rel(a["params"] - old, new - old)
+    upd = {n: np.zeros(P0[n].numel(), np.float64) for n in order}
+    off = 0
+    for n in names:
+        k = P0[n].numel()
+        upd[n] = -0.1 * want[off:off + k]
+        off += k
+    assert rel(a["params"].astype(np.float64) - old, np.concatenate([upd[n] for n in order])) < 2e-4
     # (iii) running statistics are per shard until rank 0's are broadcast
     keys = [k[7:] for k in a.files if k.startswith("before:")]
     assert keys and any(not np.array_equal(a["before:" + k], b["before:" + k]) for k in keys)

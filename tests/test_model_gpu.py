@@ -128,7 +128,7 @@ def oracle_replaying(m, outs, b, V, seed, masks=None, dt=torch.float32, reg="l1_
     assert_flips_are_ties(dec)
     named = {k: p.grad for k, p in m.named_parameters()}
     flat, worst = assert_grad_parity(named, P, dead=orc.DEAD_PARAMS)
-    dec.oracle_buffers = Bf
+    dec.oracle_buffers, dec.oracle_params = Bf, P
     return ref, rl, dec, flat
 
 
