@@ -94,9 +94,12 @@ def assert_flips_are_ties(dec):
         assert r["worst"] <= TIE_REL * max(r["rms"], 1e-30), (site, r)
 
 
-def assert_grad_parity(named_grads, P_ref, dead=(), zero_abs=None, flat_tol=FLAT_TOL, tensor_tol=TENSOR_TOL):
+def assert_grad_parity(named_grads, P_ref, dead=(), zero_abs=None, flat_tol=FLAT_TOL, tensor_tol=TENSOR_TOL, n_terms=1e4):
     """named_grads: {name: HIP gradient}; P_ref: oracle params with .grad.  `zero_abs`: names whose gradient is
-    analytically zero (BatchNorm-shadowed biases), held to an absolute bar instead."""
+    analytically zero -- the conv biases in front of a train-mode BatchNorm: both sides only hold the
+    rounding residue of a sum of ~N cancelling terms, so the HIP value is held to an ABSOLUTE bar that scales like that
+    residue: 1e-6 * max(1, sqrt(n_terms / 1e4)) times the scale of the summed terms (the matching BatchNorm-bias gradient,
+    a sum over the same N positions)."""
     zero_abs = zero_abs or (lambda k: k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"))
     got, want, worst = [], [], (0.0, None)
     for k, v in P_ref.items():
@@ -106,7 +109,10 @@ def assert_grad_parity(named_grads, P_ref, dead=(), zero_abs=None, flat_tol=FLAT
         g = named_grads[k].detach().double().cpu()
         r = v.grad.detach().double()
         if zero_abs(k):
-            assert float((g - r).abs().max()) < 1e-6, k
+            bn_bias = k[:-len("0.bias")] + ("1.bias" if k.endswith("double_conv.0.bias") else "4.bias")
+            scale = max(1.0, float(P_ref[bn_bias].grad.detach().abs().max()))
+            bar = 1e-6 * max(1.0, (n_terms / 1e4) ** 0.5) * scale
+            assert float(g.abs().max()) < bar and float(r.abs().max()) < 10 * bar, (k, float(g.abs().max()), float(r.abs().max()), bar)
             continue
         e = rel(g, r)
         if e > worst[0]:
