@@ -29,7 +29,7 @@ class ConvArgs(C.Structure):
         ("res_bs", i64), ("res_gs", i64), ("gate_bs", i64), ("gate_gs", i64),
         ("B", i32), ("T", i32), ("G", i32), ("Cin_g", i32), ("Cout_g", i32), ("K", i32),
         ("relu", i32), ("gate_scale", f32), ("drop_scale", f32), ("drop_p", f32), ("rng_seed", C.c_uint64),
-        ("pro_a", p), ("pro_b", p), ("pro_mode", i32), ("pro_Bp", i32), ("rng_seed_dev", p),
+        ("pro_a", p), ("pro_b", p), ("pro_mode", i32), ("pro_Bp", i32), ("rng_seed_dev", p), ("wino", i32),
     ]
 
 
@@ -40,6 +40,7 @@ SIGNATURES = {
     "nef_stem_bwd_ws_bytes": (sz, [i32]),
     "nef_stem_bwd_weight": (i32, [p, p, p, p, p, sz, i32, i32, i32, p]),
     "nef_pack_weight": (i32, [p, p, i32, i32, i32, i32, i32, p]),
+    "nef_pack_weight_wino": (i32, [p, p, i32, i32, i32, i32, p]),
     "nef_conv_fwd": (i32, [C.POINTER(ConvArgs), p]),
     "nef_conv_bwd_weight_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "nef_conv_bwd_weight": (i32, [p, i64, i64, p, i64, i64, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32, i32, p]),

@@ -13,6 +13,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -361,6 +362,337 @@ static int launch_conv_fwd(const nef_conv_args& a, hipStream_t st) {
     hipLaunchKernelGGL((conv_fwd_kernel<K, TM, PRO>), dim3((unsigned)blocks), dim3(256), lds, st, a, ct.seg_shift, ct.nseg,
                        ct.tps, ct.n_tiles, m_tiles);
     return nef_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K = 3 through Winograd F(2,3): 4 multiplies per 2 outputs instead of 6 -- 2/3 of the matrix-core work
+// ------------------------------------------------------------------------------------------------
+// For output pair j of a row (outputs 2j, 2j+1; inputs d_m = x[2j-1+m], m = 0..3, zero padded) and taps g0..g2:
+//     v0 = d0-d2   v1 = d1+d2   v2 = d2-d1   v3 = d1-d3              (input transform)
+//     u0 = g0   u1 = (g0+g1+g2)/2   u2 = (g0-g1+g2)/2   u3 = g2      (weight transform, nef_pack_weight_wino)
+//     M_i[co][j] = sum_ci u_i[ci][co] * v_i[ci][j]                   (4 GEMMs over ci on the matrix cores)
+//     y[2j] = M0+M1+M2   y[2j+1] = M1-M2-M3                          (output transform, in the epilogue)
+// The activation tile is staged RAW exactly as in conv_fwd_kernel (so in_scale and both input prologues work
+// unchanged); the input transform happens on the way from LDS to the MFMA B operand: one lane owns pair j, reads
+// x[2j..2j+3] of a channel row as two conflict-free ds_read_b64 and forms v0..v3 with four VALU ops.  A wave owns
+// 64 output channels x 32 pairs (64 outputs) = 4 x 2 accumulator tiles; a workgroup is WM x (4/WM) waves:
+// WM = 2 -> 128 channels x 128 outputs, WM = 1 -> 64 channels x 256 outputs.  Still exact fp32 multiplies and adds;
+// the result differs from the direct form by the rounding of the three transforms (transform entries are 0, +-1,
+// 1/2: a few ulp, measured in tests/test_ops_gpu.py::test_conv_winograd).  Sequences shorter than a tile keep the
+// direct kernel.  NEF_WINOGRAD=0 in the environment disables this path (ops.py).
+constexpr int WKC = 16;   // channels per stage: 64 MFMAs per wave between barriers
+
+template <int WM, int PRO>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int tps, int n_tiles, int m_tiles) {
+    constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
+    constexpr int NS = UP ? 2 : 1;
+    constexpr int KC = WKC;
+    constexpr int WN = 4 / WM;
+    constexpr int MT = 64 * WM;          // output channels per workgroup
+    constexpr int NTO = 64 * WN;         // outputs (columns) per workgroup
+    constexpr int XROW = NTO + 2;        // staged positions per channel row: t0-1 .. t0+NTO
+    constexpr int XRS = NTO + 16;        // LDS row pitch (even: rows stay 8-byte aligned for ds_read_b64)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                    // [4][KC][MT]
+    float* Xl = smem + 4 * KC * MT;      // [KC][XRS]
+
+    const int tile = blockIdx.x % n_tiles;
+    const int gm = blockIdx.x / n_tiles;
+    const int mt = gm % m_tiles;
+    const int g = gm / m_tiles;
+    int b0, t0;
+    {   // tiles of one sample 8 workgroup ids apart: same XCD, shared boundary lines hit in that L2 (see conv_fwd_kernel)
+        const int full = (n_tiles / (8 * tps)) * (8 * tps);
+        if (tile < full) {
+            const int grp = tile / (8 * tps), r = tile % (8 * tps);
+            b0 = grp * 8 + (r & 7);
+            t0 = (r >> 3) * NTO;
+        } else {
+            b0 = tile / tps;
+            t0 = (tile - b0 * tps) * NTO;
+        }
+    }
+    const int m0 = mt * MT;
+    const int T = a.T, Cig = a.Cin_g, Cog = a.Cout_g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    constexpr int NIT = (XROW + 63) / 64;
+    constexpr int XR = KC / 4;
+    constexpr int M4 = MT / 4;
+    constexpr int NW = 4 * KC * M4 / 256;
+    constexpr int RQ = 256 / M4;
+    static_assert(4 * KC * M4 % 256 == 0 && KC % RQ == 0, "weight tile must split evenly over the workgroup");
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(a.x + (int64_t)b0 * a.x_bs + (int64_t)g * a.x_gs);
+    const __amdgpu_buffer_rsrc_t wrs = nef_rsrc(a.wp + (int64_t)g * 4 * Cig * Cog + m0);
+    const int Tin = UP ? (T >> 1) : T;
+    unsigned xvo[NIT][NS];
+    float lam[NIT];
+    bool xok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int r = lane + 64 * it;
+        const int t = t0 + r - 1;
+        xok[it] = (r < XROW) && (t >= 0) && (t < T);
+        lam[it] = 0.f;
+        if constexpr (UP) {
+            float src = 0.5f * ((float)t + 0.5f) - 0.5f;
+            if (src < 0.f) src = 0.f;
+            int i0 = (int)src;
+            if (i0 > Tin - 1) i0 = Tin - 1;
+            const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+            lam[it] = src - (float)i0;
+            xvo[it][0] = xok[it] ? (unsigned)(i0 * 4) : NEF_OOB;
+            xvo[it][NS - 1] = xok[it] ? (unsigned)(i1 * 4) : NEF_OOB;
+        } else {
+            xvo[it][0] = xok[it] ? (unsigned)(t * 4) : NEF_OOB;
+        }
+    }
+    const int64_t soff = (int64_t)b0 * a.sc_bs + (int64_t)g * a.sc_gs;
+    const int pro_row0 = AFF ? (b0 / a.pro_Bp) * a.G * Cig + g * Cig : 0;
+    const unsigned wvo = (unsigned)(((int)(threadIdx.x / M4) * Cog + 4 * (int)(threadIdx.x % M4)) * 4);
+    const int w_istride = Cig * Cog;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][tm][r] = 0.f;
+
+    f32x4 wreg[NW];
+    float xreg[XR][NIT][NS];
+#define NEF_WISSUE(C0)                                                                                              \
+    {                                                                                                               \
+        _Pragma("unroll") for (int q = 0; q < NW; ++q) wreg[q] = nef_buf_f32x4(                                     \
+            wrs, wvo, (unsigned)((((q * RQ) / KC) * w_istride + ((q * RQ) % KC + (C0)) * Cog) * 4));                 \
+        _Pragma("unroll") for (int rr = 0; rr < XR; ++rr) {                                                         \
+            const unsigned so = (unsigned)(((C0) + wave_u + 4 * rr) * Tin * 4);                                     \
+            _Pragma("unroll") for (int it = 0; it < NIT; ++it)                                                      \
+                _Pragma("unroll") for (int ns = 0; ns < NS; ++ns) xreg[rr][it][ns] = nef_buf_f32(xrs, xvo[it][ns], so); \
+        }                                                                                                           \
+    }
+    NEF_WISSUE(0)
+    for (int c0 = 0; c0 < Cig; c0 += KC) {
+        if (a.in_scale) {
+#pragma unroll
+            for (int rr = 0; rr < XR; ++rr) {
+                const float sc = a.in_scale[soff + c0 + wave + 4 * rr];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) xreg[rr][it][0] *= sc;
+            }
+        }
+        __syncthreads();
+        {
+            f32x4* Wl4 = reinterpret_cast<f32x4*>(Wl);
+#pragma unroll
+            for (int q = 0; q < NW; ++q) Wl4[threadIdx.x + 256 * q] = wreg[q];
+#pragma unroll
+            for (int rr = 0; rr < XR; ++rr) {
+                float pa = 1.f, pb = 0.f;
+                if constexpr (AFF) {
+                    pa = a.pro_a[pro_row0 + c0 + wave_u + 4 * rr];
+                    pb = a.pro_b[pro_row0 + c0 + wave_u + 4 * rr];
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int r = lane + 64 * it;
+                    float v = xreg[rr][it][0];
+                    if constexpr (AFF) v = fmaxf(fmaf(v, pa, pb), 0.f);
+                    if constexpr (UP) {
+                        float v1 = xreg[rr][it][NS - 1];
+                        if constexpr (AFF) v1 = fmaxf(fmaf(v1, pa, pb), 0.f);
+                        v = (1.f - lam[it]) * v + lam[it] * v1;
+                    }
+                    if constexpr (PRO != 0) v = xok[it] ? v : 0.f;
+                    if (r < XROW) Xl[(wave + 4 * rr) * XRS + r] = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (c0 + KC < Cig) NEF_WISSUE(c0 + KC)
+        {
+            constexpr int SPK = KC / 2;
+            float fa[2][4][2];
+            f32x2 fx[2][2];
+#define NEF_WLOAD(S, BUF)                                                                                            \
+    {                                                                                                               \
+        const int c_ = 2 * (S) + hi;                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
+            _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                        \
+                fa[BUF][i][tm] = Wl[(i * KC + c_) * MT + (wm * 2 + tm) * 32 + lo];                                  \
+        const f32x2* xp_ = reinterpret_cast<const f32x2*>(Xl + c_ * XRS + 2 * (wn * 32 + lo));                      \
+        fx[BUF][0] = xp_[0];                                                                                        \
+        fx[BUF][1] = xp_[1];                                                                                        \
+    }
+            NEF_WLOAD(0, 0)
+#pragma unroll
+            for (int s_ = 0; s_ < SPK; ++s_) {
+                if (s_ + 1 < SPK) NEF_WLOAD(s_ + 1, (s_ + 1) & 1)
+                const float d0 = fx[s_ & 1][0][0], d1 = fx[s_ & 1][0][1], d2 = fx[s_ & 1][1][0], d3 = fx[s_ & 1][1][1];
+                float v[4];
+                v[0] = d0 - d2;
+                v[1] = d1 + d2;
+                v[2] = d2 - d1;
+                v[3] = d1 - d3;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+                        acc[i][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_ & 1][i][tm], v[i], acc[i][tm], 0, 0, 0);
+                // interleave: one MFMA, then part of the next step's 10 LDS reads
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+#undef NEF_WLOAD
+        }
+    }
+#undef NEF_WISSUE
+
+    // epilogue: output transform, then bias / residual / ReLU / dropout / gate exactly as conv_fwd_kernel, on the two
+    // adjacent outputs (2j, 2j+1) a lane owns per channel row: 8-byte loads and stores, 256 contiguous bytes per row.
+    const int64_t ctot = (int64_t)a.G * Cog;
+    const int t = t0 + 2 * (wn * 32 + lo);
+    const bool live = (b0 < a.B) && (t < T);
+    const int ts = live ? t : 0;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        const int cobase = m0 + (wm * 2 + tm) * 32 + 4 * hi;
+        float y0[16], y1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            y0[r] = (acc[0][tm][r] + acc[1][tm][r]) + acc[2][tm][r];
+            y1[r] = (acc[1][tm][r] - acc[2][tm][r]) - acc[3][tm][r];
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bv = a.bias[g * Cog + cobase + (r & 3) + 8 * (r >> 2)];
+                y0[r] += bv;
+                y1[r] += bv;
+            }
+        }
+        if (a.res) {
+            const float* rp = a.res + (int64_t)b0 * a.res_bs + (int64_t)g * a.res_gs + (int64_t)cobase * T + ts;
+            f32x2 t16[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                t16[r] = *reinterpret_cast<const f32x2*>(rp + (int64_t)((r & 3) + 8 * (r >> 2)) * T);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                y0[r] += t16[r][0];
+                y1[r] += t16[r][1];
+            }
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                y0[r] = fmaxf(y0[r], 0.f);
+                y1[r] = fmaxf(y1[r], 0.f);
+            }
+        }
+        if (a.mask) {
+            const uint8_t* mp = a.mask + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T + ts;
+            unsigned short t16[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                t16[r] = *reinterpret_cast<const unsigned short*>(mp + (int64_t)((r & 3) + 8 * (r >> 2)) * T);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                y0[r] *= (float)(t16[r] & 0xff) * a.drop_scale;
+                y1[r] *= (float)(t16[r] >> 8) * a.drop_scale;
+            }
+        } else if (a.drop_p > 0.f) {
+            const int64_t d0 = ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T + ts;
+            const uint64_t seed = a.rng_seed + (a.rng_seed_dev ? a.rng_seed_dev[0] : 0ull);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint64_t dense = (uint64_t)(d0 + (int64_t)((r & 3) + 8 * (r >> 2)) * T);
+                y0[r] = (nef_rng_uniform(seed, dense) >= a.drop_p) ? y0[r] * a.drop_scale : 0.f;
+                y1[r] = (nef_rng_uniform(seed, dense + 1) >= a.drop_p) ? y1[r] * a.drop_scale : 0.f;
+            }
+        }
+        if (a.gate) {
+            const float* gp = a.gate + (int64_t)b0 * a.gate_bs + (int64_t)g * a.gate_gs + (int64_t)cobase * T + ts;
+            f32x2 t16[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                t16[r] = *reinterpret_cast<const f32x2*>(gp + (int64_t)((r & 3) + 8 * (r >> 2)) * T);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                y0[r] = t16[r][0] > 0.f ? y0[r] * a.gate_scale : 0.f;
+                y1[r] = t16[r][1] > 0.f ? y1[r] * a.gate_scale : 0.f;
+            }
+        }
+        if (live) {
+            float* yp = a.y + (int64_t)b0 * a.y_bs + (int64_t)g * a.y_gs + (int64_t)cobase * T + t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                f32x2 o;
+                o[0] = y0[r];
+                o[1] = y1[r];
+                *reinterpret_cast<f32x2*>(yp + (int64_t)((r & 3) + 8 * (r >> 2)) * T) = o;
+            }
+        }
+    }
+}
+
+template <int WM, int PRO = 0>
+static int launch_conv_wino(const nef_conv_args& a, hipStream_t st) {
+    constexpr int MT = 64 * WM;
+    constexpr int NTO = 64 * (4 / WM);
+    constexpr size_t lds = (size_t)(4 * WKC * MT + WKC * (NTO + 16)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<WM, PRO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tps = (a.T + NTO - 1) / NTO;
+    const int n_tiles = a.B * tps;
+    const int m_tiles = a.Cout_g / MT;
+    const int64_t blocks = (int64_t)a.G * m_tiles * n_tiles;
+    if (blocks <= 0 || blocks > 0x7fffffff) return NEF_E_SHAPE;
+    hipLaunchKernelGGL((conv_wino_kernel<WM, PRO>), dim3((unsigned)blocks), dim3(256), lds, st, a, tps, n_tiles, m_tiles);
+    return nef_launch_status();
+}
+
+// wp[g][i][r][c], i = 0..3 the F(2,3) weight transform of the three taps; (r, c) = (ci, co) forward,
+// (co, ci) with the taps reversed for the backward-data operand
+__global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog, int Cig,
+                                        int flip) {
+    const int64_t n = (int64_t)G * Cog * Cig;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        int co, ci;
+        if (!flip) {   // [g][.][ci][co]
+            co = (int)(r % Cog); r /= Cog;
+            ci = (int)(r % Cig); r /= Cig;
+        } else {       // [g][.][co][ci]
+            ci = (int)(r % Cig); r /= Cig;
+            co = (int)(r % Cog); r /= Cog;
+        }
+        const int g = (int)r;
+        const float* src = w + (((int64_t)g * Cog + co) * Cig + ci) * 3;
+        const float g0 = flip ? src[2] : src[0], g1 = src[1], g2 = flip ? src[0] : src[2];
+        float* dst = wp + (int64_t)g * 4 * n / G + (i - (int64_t)g * (n / G));
+        const int64_t plane = n / G;
+        dst[0] = g0;
+        dst[plane] = ((g0 + g1) + g2) * 0.5f;
+        dst[2 * plane] = ((g0 - g1) + g2) * 0.5f;
+        dst[3 * plane] = g2;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -729,7 +1061,7 @@ constexpr int CHAN_SUM_SPLIT = 16;
 
 extern "C" {
 
-int nef_abi_version(void) { return 7; }
+int nef_abi_version(void) { return 8; }
 
 int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                     nef_stream_t stream) {
@@ -739,6 +1071,16 @@ int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, i
     const int64_t n = (int64_t)G * Cog * Cig * K;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, G,
                        Cog, Cig, K, transpose_flip);
+    return nef_launch_status();
+}
+
+int nef_pack_weight_wino(const float* w, float* wp, int G, int Cog, int Cig, int transpose_flip, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(w && wp, NEF_E_NULL);
+    NEF_REQUIRE(G > 0 && Cog > 0 && Cig > 0, NEF_E_SHAPE);
+    const int64_t n = (int64_t)G * Cog * Cig;
+    hipLaunchKernelGGL(pack_weight_wino_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, w, wp,
+                       G, Cog, Cig, transpose_flip);
     return nef_launch_status();
 }
 
@@ -758,6 +1100,19 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
         // CUs; halve the M tile so twice as many workgroups share the same work
         const ColTiling ct0 = make_tiling(a->B, a->T, NT);
         if ((int64_t)a->G * (a->Cout_g / 128) * ct0.n_tiles < 384) big = false;
+    }
+    if (a->wino) {       // weights packed by nef_pack_weight_wino: F(2,3) path, whole tiles of one sample only
+        NEF_REQUIRE(K == 3 && a->T % 2 == 0 && a->Cin_g % WKC == 0, NEF_E_SHAPE);
+        NEF_REQUIRE(a->pro_mode >= 0 && a->pro_mode <= 3 && !(a->pro_mode && a->in_scale), NEF_E_UNSUPPORTED);
+        NEF_REQUIRE(!(a->pro_mode & 1) || (a->pro_a && a->pro_b && a->pro_Bp > 0), NEF_E_NULL);
+        const bool wide = (a->Cout_g % 128 == 0);
+        NEF_REQUIRE(a->T >= (wide ? 128 : 256), NEF_E_SHAPE);
+        switch (a->pro_mode) {
+            case 0: return wide ? launch_conv_wino<2, 0>(*a, st) : launch_conv_wino<1, 0>(*a, st);
+            case 1: return wide ? launch_conv_wino<2, 1>(*a, st) : launch_conv_wino<1, 1>(*a, st);
+            case 2: return wide ? launch_conv_wino<2, 2>(*a, st) : launch_conv_wino<1, 2>(*a, st);
+            default: return wide ? launch_conv_wino<2, 3>(*a, st) : launch_conv_wino<1, 3>(*a, st);
+        }
     }
     if (a->pro_mode != 0) {
         NEF_REQUIRE(K == 3 && a->pro_mode >= 1 && a->pro_mode <= 3 && !a->in_scale, NEF_E_UNSUPPORTED);

@@ -54,7 +54,7 @@ class DropCfg:
 # ----------------------------------------------------------------------------------------------
 def block_fwd(xv, P, prefix, K, Cog, drop):
     G = xv.G
-    h = ops.conv(xv, ops.pack_weight(P[prefix + ".conv1.weight"], G), Cog, K, relu=True, **drop.args(prefix))
+    h = ops.conv(xv, ops.pack_weight(P[prefix + ".conv1.weight"], G, T=xv.T), Cog, K, relu=True, **drop.args(prefix))
     res_conv = (K == 3 and Cog != xv.Cg)                     # model_nefnet.py:54
     if res_conv:
         r = ops.conv(xv, ops.pack_weight(P[prefix + ".residual_conv.weight"], G), Cog, 1,
@@ -62,7 +62,7 @@ def block_fwd(xv, P, prefix, K, Cog, drop):
         resv = GV.dense(r, G)
     else:
         resv = xv
-    y = ops.conv(GV.dense(h, G), ops.pack_weight(P[prefix + ".conv2.weight"], G), Cog, K, res=resv, relu=True)
+    y = ops.conv(GV.dense(h, G), ops.pack_weight(P[prefix + ".conv2.weight"], G, T=xv.T), Cog, K, res=resv, relu=True)
     return y, (xv, h, y, prefix, K, Cog, res_conv, drop.scale)
 
 
@@ -85,7 +85,7 @@ def block_bwd(saved, gy, P, grads, out=None, side=None, pre_gated=False, gate_in
     g2v, hv = GV.dense(g2, G), GV.dense(h, G)
     grads[prefix + ".conv2.weight"] = side.run(lambda: ops.conv_bwd_weight(hv, g2v, K), h, g2)
     # through conv2, then dropout and the inner ReLU: h > 0 <=> ReLU active and kept
-    gc1 = ops.conv(g2v, ops.pack_weight(P[prefix + ".conv2.weight"], G, flip=True), Cog, K, gate=hv, gate_scale=dscale,
+    gc1 = ops.conv(g2v, ops.pack_weight(P[prefix + ".conv2.weight"], G, flip=True, T=xv.T), Cog, K, gate=hv, gate_scale=dscale,
                    role="conv_bwd_data")
     gc1v = GV.dense(gc1, G)
     grads[prefix + ".conv1.weight"] = side.run(lambda: ops.conv_bwd_weight(xv, gc1v, K), xv.t, gc1)
@@ -97,7 +97,7 @@ def block_bwd(saved, gy, P, grads, out=None, side=None, pre_gated=False, gate_in
         resv = GV.dense(gres, G)
     else:
         resv = g2v
-    return ops.conv(gc1v, ops.pack_weight(P[prefix + ".conv1.weight"], G, flip=True), Cig, K, res=resv, out=out,
+    return ops.conv(gc1v, ops.pack_weight(P[prefix + ".conv1.weight"], G, flip=True, T=xv.T), Cig, K, res=resv, out=out,
                     gate=xv if gate_input else None, gate_scale=1.0, role="conv_bwd_data")
 
 
@@ -132,7 +132,7 @@ def _decoder_fwd_unfused(D, P, Bf, passes, training, save):
         if li in (0, 2):
             x = ops.upsample2_fwd(x)
         wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
-        c = ops.conv(GV.dense(x, 1), ops.pack_weight(P[wname], 1), cout, 3, bias=P[bname])
+        c = ops.conv(GV.dense(x, 1), ops.pack_weight(P[wname], 1, T=x.shape[2]), cout, 3, bias=P[bname])
         if training:
             mean, invstd, a, b = ops.bn_train_stats(c, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
                                                     Bf[pre + ".running_var"], passes, BN_EPS, BN_MOM)
@@ -176,11 +176,12 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
             mode = (2 if li == 0 else 0) | (1 if pro_in is not None else 0)
             pro = (mode, pro_in[0], pro_in[1], pro_in[2]) if pro_in is not None else (mode, None, None, 1)
             up_after = bool(mode & 2)
+        T_out = x_in.shape[2] * (2 if up_after and pro[0] & 2 else 1)
         if li == 0 and shared_B is not None:
-            p2 = ops.conv(GV.dense(x_in, 2), ops.pack_weight(_regroup_halves(P[wname]), 2), cout, 3, pro=pro)
+            p2 = ops.conv(GV.dense(x_in, 2), ops.pack_weight(_regroup_halves(P[wname]), 2, T=T_out), cout, 3, pro=pro)
             c = ops.pass_combine_fwd(p2, P[bname], shared_B)
         else:
-            c = ops.conv(GV.dense(x_in, 1), ops.pack_weight(P[wname], 1), cout, 3, bias=P[bname], pro=pro)
+            c = ops.conv(GV.dense(x_in, 1), ops.pack_weight(P[wname], 1, T=T_out), cout, 3, bias=P[bname], pro=pro)
         if training:
             mean, invstd, a, b = ops.bn_train_stats(c, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
                                                     Bf[pre + ".running_var"], passes, BN_EPS, BN_MOM)
@@ -227,12 +228,12 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
             gp2 = gc if gc.shape[0] == 2 * shared_B else ops.pass_combine_bwd(gc)   # [2B, 2*128, 2T]
             gpv, xv = GV.dense(gp2, 2), GV.dense(x, 2)
             grads[wname] = side.run(lambda: _ungroup_halves(ops.conv_bwd_weight(xv, gpv, 3, pro=pro)), x, gp2)
-            g = ops.conv(gpv, ops.pack_weight(_regroup_halves(P[wname]), 2, flip=True), x.shape[1] // 2, 3,
+            g = ops.conv(gpv, ops.pack_weight(_regroup_halves(P[wname]), 2, flip=True, T=gp2.shape[2]), x.shape[1] // 2, 3,
                          role="conv_bwd_data")
         else:
             gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
             grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro), x, gc)
-            g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True), x.shape[1], 3, role="conv_bwd_data")
+            g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True, T=gc.shape[2]), x.shape[1], 3, role="conv_bwd_data")
         # back through the x2 upsampling in front of this layer: the next BatchNorm backward takes the adjoint while it
         # reads (rows of 4k >= 8 samples), otherwise it is a pass of its own
         g_is_up = bool(up_after and li > 0 and c.shape[2] % 8 == 0 and c.shape[2] >= 16)
@@ -342,8 +343,8 @@ def forward2(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", 
     z2rf = ops.roi_unpool_fwd(z2bf, roisf, T, status)                              # [N, 128, T]
     Z1 = torch.empty(B, 128 * V, T, device=x.device, dtype=torch.float32)
     Z2 = torch.empty_like(Z1)
-    wp1 = ops.pack_weight(P["single_conv_z1.0.weight"], 1)
-    wp2 = ops.pack_weight(P["single_conv_z2.0.weight"], 1)
+    wp1 = ops.pack_weight(P["single_conv_z1.0.weight"], 1, T=T)
+    wp2 = ops.pack_weight(P["single_conv_z2.0.weight"], 1, T=T)
     for i in range(V):
         ops.conv(GV.dense(z1f[i * B:(i + 1) * B], 1), wp1, 128, 3, bias=P["single_conv_z1.0.bias"],
                  out=_lead_view(Z1, i, V))
@@ -388,12 +389,12 @@ def sweep_eval(P, Bf, latent, query_thetas, chunk=8):
     rq = ops.theta_mlp_fwd(query_thetas, P["mlp2.weight"], P["mlp2.bias"])       # [B, Q, 256]
     u = ops.upsample2_fwd(latent)                                                 # [B, 256, 2T], shared by all angles
     wp, bias = [], []
-    for blk, cv, bn, cout in _DEC:
+    for li, (blk, cv, bn, cout) in enumerate(_DEC):
         pre = f"{blk}.double_conv.{bn}"
         a, b = ops.bn_eval_affine(P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
                                   Bf[pre + ".running_var"], BN_EPS)
         wf, bf_ = ops.fold_bn(P[f"{blk}.double_conv.{cv}.weight"], P[f"{blk}.double_conv.{cv}.bias"], a, b)
-        wp.append(ops.pack_weight(wf, 1))
+        wp.append(ops.pack_weight(wf, 1, T=(2 * T if li < 2 else 4 * T)))
         bias.append(bf_)
     uv = GV.dense(u, 1)
     rest = torch.empty(B, Q, 4 * T, device=dev, dtype=torch.float32)
@@ -529,7 +530,7 @@ def backward2(P, sv, g_outs):
     gz1f = torch.empty(V * B, 128, T, device=gZ1.device, dtype=torch.float32)
     gz2rf = torch.empty_like(gz1f)
     for name, gZ, xin, gout in (("single_conv_z1.0", gZ1, sv["z1f"], gz1f), ("single_conv_z2.0", gZ2, sv["z2rf"], gz2rf)):
-        wf = ops.pack_weight(P[name + ".weight"], 1, flip=True)
+        wf = ops.pack_weight(P[name + ".weight"], 1, flip=True, T=T)
         gw = None
         for i in range(V):
             gv = _lead_view(gZ, i, V)

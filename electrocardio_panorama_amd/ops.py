@@ -5,6 +5,7 @@ ROIs) tensors on a HIP device, allocates the outputs, and enqueues the library c
 stream.  Nothing here computes on the host and nothing falls back to torch ops.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -172,11 +173,29 @@ def stem_bwd_weight(x, w, gy):
 
 
 # ------------------------------------------------------------------ grouped conv
-def pack_weight(w, G, flip=False):
-    """w [G*Cog, Cig, K] -> packed operand (forward: [G][K][Cig][Cog]; flip: [G][K][Cog][Cig], taps reversed)."""
+# K = 3 convs through Winograd F(2,3) (conv_mfma.hip: conv_wino_kernel) wherever a whole output tile of one sample
+# exists; NEF_WINOGRAD=0 keeps every conv on the direct kernel.
+WINOGRAD = os.environ.get("NEF_WINOGRAD", "1") != "0"
+
+
+def wino_ok(K, Cin_g, Cout_g, T_out):
+    return (WINOGRAD and K == 3 and T_out % 2 == 0 and Cin_g % 16 == 0 and
+            ((Cout_g % 128 == 0 and T_out >= 128) or (Cout_g % 128 != 0 and Cout_g % 64 == 0 and T_out >= 256)))
+
+
+def pack_weight(w, G, flip=False, T=None):
+    """w [G*Cog, Cig, K] -> packed operand (forward: [G][K][Cig][Cog]; flip: [G][K][Cog][Cig], taps reversed).
+    `T`: output length of the conv launch this operand is for; when the Winograd F(2,3) path applies to that launch
+    the operand is packed for it ([G][4][.][.], marked with `.nef_wino`) and `conv()` takes that path."""
     L = _lib.load()
     _chk(w)
     Cog, Cig, K = w.shape[0] // G, w.shape[1], w.shape[2]
+    cin_g, cout_g = (Cog, Cig) if flip else (Cig, Cog)          # roles in the launch that consumes the operand
+    if T is not None and wino_ok(K, cin_g, cout_g, T):
+        wp = torch.empty(G * 4 * Cog * Cig, device=w.device, dtype=torch.float32)
+        _lib.check(L.nef_pack_weight_wino(_p(w), _p(wp), G, Cog, Cig, int(flip), _stream()), "nef_pack_weight_wino")
+        wp.nef_wino = True
+        return wp
     wp = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
     _lib.check(L.nef_pack_weight(_p(w), _p(wp), G, Cog, Cig, K, int(flip), _stream()), "nef_pack_weight")
     return wp
@@ -213,6 +232,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     a.relu = int(relu)
     a.gate_scale, a.drop_scale, a.drop_p, a.rng_seed = gate_scale, drop_scale, drop_p, seed
     a.rng_seed_dev = _p(seed_dev)
+    a.wino = 1 if getattr(wp, "nef_wino", False) else 0
     ev = _timed((role, K, xv.G, xv.Cg, Cog, xv.B, T_out))
     _lib.check(L.nef_conv_fwd(C.byref(a), _stream()), "nef_conv_fwd")
     if ev is not None:

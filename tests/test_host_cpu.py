@@ -23,7 +23,7 @@ def test_header_symbols_exported():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().nef_abi_version() == 7
+    assert _lib.load().nef_abi_version() == 8
     assert ctypes.sizeof(_lib.ConvArgs) == 224
 
 

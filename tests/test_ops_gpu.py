@@ -592,3 +592,106 @@ def test_decoder_three_passes(T):
             assert maxabs(v, g64[k]) < 1e-5, k          # analytically zero
         else:
             assert rel(v, g64[k]) < GRAD_TOL + 2 * rel(g32[k], g64[k]), (k, rel(v, g64[k]), rel(g32[k], g64[k]))
+
+
+WINO_CASES = [  # G, Cig, Cog, T, B   (K = 3)
+    (3, 128, 128, 128, 2), (3, 128, 128, 250, 3), (3, 64, 128, 130, 2), (1, 256, 128, 250, 3), (2, 128, 128, 1250, 2),
+    (1, 128, 64, 500, 2), (1, 64, 64, 260, 3), (1, 128, 64, 256, 2), (1, 64, 128, 5000, 2), (1, 128, 256, 250, 2),
+]
+
+
+@pytest.mark.parametrize("G,Cig,Cog,T,B", WINO_CASES)
+def test_conv_winograd(G, Cig, Cog, T, B):
+    """K = 3 through Winograd F(2,3) (conv_wino_kernel): forward and backward-data against F.conv1d at the forward /
+    gradient bars, and its distance from exact (fp64) arithmetic next to the direct kernel's."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    assert o.wino_ok(3, Cig, Cog, T) and o.wino_ok(3, Cog, Cig, T) == (Cig % 128 == 0 or T >= 256)
+    x = rnd(B, G * Cig, T, seed=5)
+    w = rnd(G * Cog, Cig, 3, seed=6, scale=(Cig * 3) ** -0.5)
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv1d(xr, w, None, 1, 1, 1, G)
+    ref64 = F.conv1d(x.double(), w.double(), None, 1, 1, 1, G)
+    xd, wd = g(x), g(w)
+    wpw = o.pack_weight(wd, G, T=T)
+    assert getattr(wpw, "nef_wino", False) and wpw.numel() == 4 * G * Cog * Cig
+    y = o.conv(GV.dense(xd, G), wpw, Cog, 3)
+    yd = o.conv(GV.dense(xd, G), o.pack_weight(wd, G), Cog, 3)
+    assert rel(y, ref) < FWD_TOL, "forward"
+    e_w, e_d, e_t = rel(y, ref64), rel(yd, ref64), rel(ref, ref64)
+    assert e_w < 4 * max(e_d, e_t) + 1e-7, (e_w, e_d, e_t)       # the transforms cost a small constant factor, not more
+    gy = rnd(*ref.shape, seed=7)
+    ref.backward(gy)
+    wf = o.pack_weight(wd, G, flip=True, T=T)
+    gx = o.conv(GV.dense(g(gy), G), wf, Cig, 3)
+    assert rel(gx, xr.grad) < GRAD_TOL, "bwd-data"
+
+
+def test_conv_winograd_epilogue_views_and_rng():
+    """Every epilogue / operand option of the conv entry point on the Winograd path: bias, residual, ReLU, replayed and
+    counter-RNG dropout, gate, in_scale, strided input and output views."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    B, V, T, K = 2, 3, 250, 3
+    enc = rnd(B, 128 * V, T, seed=8)
+    w = rnd(128 * V, 64, K, seed=9, scale=0.1)
+    bias, res = rnd(128 * V, seed=10), rnd(B, 128 * V, T, seed=11)
+    gate = rnd(B, 128 * V, T, seed=12)
+    mask = (rnd(B, 128 * V, T, seed=13) > -0.6).to(torch.uint8)
+    scale = rnd(B, 128 * V, seed=14)
+    for which in (0, 1):
+        xin = enc.view(B, V, 2, 64, T)[:, :, which].reshape(B, 64 * V, T)
+        sc = scale.view(B, V, 2, 64)[:, :, which].reshape(B, 64 * V)
+        ref = F.conv1d(xin * sc[:, :, None], w, bias, 1, 1, 1, V) + res
+        ref = F.relu(ref) * mask / 0.8
+        ref = torch.where(gate > 0, ref * 1.25, torch.zeros_like(ref))
+        encd, scd = g(enc), g(scale)
+        wp = o.pack_weight(g(w), V, T=T)
+        assert wp.nef_wino
+        y = o.conv(GV.half(encd, V, which), wp, 128, K, bias=g(bias),
+                   in_scale=(scd.view(-1)[which * 64:], 128 * V, 128), res=GV.dense(g(res), V), gate=GV.dense(g(gate), V),
+                   gate_scale=1.25, relu=True, mask=g(mask), drop_scale=1.25)
+        assert rel(y, ref) < FWD_TOL
+    # bwd-data (128 -> 64 channels per group needs T >= 256) written into one half of a full gradient tensor
+    T2 = 300
+    gy = rnd(B, 128 * V, T2, seed=15)
+    for which in (0, 1):
+        full = torch.full((B, 128 * V, T2), 7.0, device=DEV)
+        xr = rnd(B, 64 * V, T2, seed=16).requires_grad_(True)
+        F.conv1d(xr, w, None, 1, 1, 1, V).backward(gy)
+        wf = o.pack_weight(g(w), V, flip=True, T=T2)
+        assert wf.nef_wino
+        o.conv(GV.dense(g(gy), V), wf, 64, K, out=GV.half(full, V, which))
+        got = full.cpu().view(B, V, 2, 64, T2)
+        assert rel(got[:, :, which].reshape(B, 64 * V, T2), xr.grad) < GRAD_TOL
+        assert torch.all(got[:, :, 1 - which] == 7.0)
+    # counter-RNG dropout: the keep decision is keyed by the dense element index, so both kernels drop the same elements
+    xd, wd = g(rnd(B, 128, T, seed=17)), g(rnd(128, 128, 3, seed=18, scale=0.05))
+    kw = dict(relu=False, drop_p=0.2, drop_scale=1.25, seed=1234)
+    a = o.conv(GV.dense(xd, 1), o.pack_weight(wd, 1, T=T), 128, 3, **kw)
+    d = o.conv(GV.dense(xd, 1), o.pack_weight(wd, 1), 128, 3, **kw)
+    assert torch.equal(a == 0, d == 0) and 0.15 < float((a == 0).float().mean()) < 0.25 and rel(a, d) < 1e-6
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("Cig,Cog,T_out", [(256, 128, 250), (128, 64, 500), (64, 64, 260), (128, 128, 128)])
+def test_conv_winograd_prologue_modes(mode, Cig, Cog, T_out):
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    P, Bp = 3, 2
+    N = P * Bp
+    Tin = T_out // 2 if mode & 2 else T_out
+    x = rnd(N, Cig, Tin, seed=80)
+    a, b = rnd(P, Cig, seed=81) + 1.2, rnd(P, Cig, seed=82) * 0.5
+    w, bias = rnd(Cog, Cig, 3, seed=83, scale=(3 * Cig) ** -0.5), rnd(Cog, seed=84)
+    xin = x
+    if mode & 1:
+        xin = F.relu(x * a.repeat_interleave(Bp, 0)[:, :, None] + b.repeat_interleave(Bp, 0)[:, :, None])
+    if mode & 2:
+        xin = F.interpolate(xin, scale_factor=2, mode="linear", align_corners=False)
+    ref = F.conv1d(xin, w, bias, 1, 1)
+    pro = (mode, g(a) if mode & 1 else None, g(b) if mode & 1 else None, Bp)
+    wp = o.pack_weight(g(w), 1, T=T_out)
+    assert wp.nef_wino
+    y = o.conv(GV.dense(g(x), 1), wp, Cog, 3, bias=g(bias), pro=pro)
+    assert y.shape == ref.shape and rel(y, ref) < FWD_TOL

@@ -26,9 +26,13 @@ for name, K, G, Cig, Cog, B, T in SHAPES:
     w = torch.randn(G * Cog, Cig, K, device="cuda") * 0.05
     gy = torch.randn(B, G * Cog, T, device="cuda")
     wp = ops.pack_weight(w, G)
+    wpw = ops.pack_weight(w, G, T=T)
     flops = 2.0 * B * G * Cog * T * Cig * K
-    for what in ("fwd", "bwd_w"):
+    for what in ("fwd", "wino", "bwd_w"):
+        if what == "wino" and not getattr(wpw, "nef_wino", False):
+            continue
         fn = (lambda: ops.conv(GV.dense(x, G), wp, Cog, K, relu=True)) if what == "fwd" else \
+             (lambda: ops.conv(GV.dense(x, G), wpw, Cog, K, relu=True)) if what == "wino" else \
              (lambda: ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K))
         for _ in range(2):
             fn()
