@@ -380,8 +380,15 @@ static int launch_conv_fwd(const nef_conv_args& a, hipStream_t st) {
 // the result differs from the direct form by the rounding of the three transforms (transform entries are 0, +-1,
 // 1/2: a few ulp, measured in tests/test_ops_gpu.py::test_conv_winograd).  Sequences shorter than a tile keep the
 // direct kernel.  NEF_WINOGRAD=0 in the environment disables this path (ops.py).
-constexpr int WKC = 16;   // channels per stage: 64 MFMAs per wave between barriers
+constexpr int WKC = 16;   // channels per activation stage: 64 MFMAs per wave between barriers
 
+// Operand paths.  B (activations): raw tile through LDS, DOUBLE-buffered -- the registers holding stage s+1 (fetched
+// during the MFMA loop of stage s) are written to the other buffer right after that loop, so there is ONE barrier per
+// stage and nothing between it and the next MFMA.  A (transformed weights, [g][i][ci][co]): never touches LDS -- a lane's
+// A fragment for (i, channel pair, co tile) is 32 consecutive floats of one packed row, i.e. a perfectly coalesced
+// 128-byte line per half-wave, so every wave fetches its own fragments straight from L2/L1 (the whole operand is
+// <= 0.5 MB per group and stays resident) three k-steps ahead of use into four rotating register sets.  That takes
+// the weight tile (32 KB per stage), its LDS writes and 8 of the 10 LDS reads per k-step out of the kernel.
 template <int WM, int PRO>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int tps, int n_tiles, int m_tiles) {
     constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
@@ -393,8 +400,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
     constexpr int XROW = NTO + 2;        // staged positions per channel row: t0-1 .. t0+NTO
     constexpr int XRS = NTO + 16;        // LDS row pitch (even: rows stay 8-byte aligned for ds_read_b64)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Wl = smem;                    // [4][KC][MT]
-    float* Xl = smem + 4 * KC * MT;      // [KC][XRS]
+    float* Xl = smem;                    // [2][KC][XRS]
 
     const int tile = blockIdx.x % n_tiles;
     const int gm = blockIdx.x / n_tiles;
@@ -420,13 +426,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
 
     constexpr int NIT = (XROW + 63) / 64;
     constexpr int XR = KC / 4;
-    constexpr int M4 = MT / 4;
-    constexpr int NW = 4 * KC * M4 / 256;
-    constexpr int RQ = 256 / M4;
-    static_assert(4 * KC * M4 % 256 == 0 && KC % RQ == 0, "weight tile must split evenly over the workgroup");
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm_u = wave_u / WN;
     const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(a.x + (int64_t)b0 * a.x_bs + (int64_t)g * a.x_gs);
-    const __amdgpu_buffer_rsrc_t wrs = nef_rsrc(a.wp + (int64_t)g * 4 * Cig * Cog + m0);
+    const __amdgpu_buffer_rsrc_t wrs = nef_rsrc(a.wp + (int64_t)g * 4 * Cig * Cog + m0 + wm_u * 64);
     const int Tin = UP ? (T >> 1) : T;
     unsigned xvo[NIT][NS];
     float lam[NIT];
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
     }
     const int64_t soff = (int64_t)b0 * a.sc_bs + (int64_t)g * a.sc_gs;
     const int pro_row0 = AFF ? (b0 / a.pro_Bp) * a.G * Cig + g * Cig : 0;
-    const unsigned wvo = (unsigned)(((int)(threadIdx.x / M4) * Cog + 4 * (int)(threadIdx.x % M4)) * 4);
+    const unsigned avo = (unsigned)((hi * Cog + lo) * 4);     // A fragment: row (channel + hi), column lo of a 32-wide co tile
     const int w_istride = Cig * Cog;
 
     f32x16 acc[4][2];
@@ -463,101 +466,99 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][tm][r] = 0.f;
 
-    f32x4 wreg[NW];
+    constexpr int SPK = KC / 2;          // k-steps (channel pairs) per stage
+    constexpr int AHEAD = 3;             // A fragments are fetched this many k-steps ahead (4 rotating sets)
+    static_assert(SPK % 4 == 0, "the four A sets must line up across stages");
+    const int nsteps = Cig / 2;
+    float fa[4][4][2];
     float xreg[XR][NIT][NS];
-#define NEF_WISSUE(C0)                                                                                              \
+#define NEF_WA_ISSUE(GS, SET)                                                                                        \
     {                                                                                                               \
-        _Pragma("unroll") for (int q = 0; q < NW; ++q) wreg[q] = nef_buf_f32x4(                                     \
-            wrs, wvo, (unsigned)((((q * RQ) / KC) * w_istride + ((q * RQ) % KC + (C0)) * Cog) * 4));                 \
+        const int gs_ = (GS) < nsteps ? (GS) : nsteps - 1;      /* past the end: a harmless repeat of the last step */ \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
+            _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                        \
+                fa[SET][i][tm] = nef_buf_f32(wrs, avo, (unsigned)((i * w_istride + 2 * gs_ * Cog + tm * 32) * 4));   \
+    }
+#define NEF_WX_ISSUE(C0)                                                                                             \
+    {                                                                                                               \
         _Pragma("unroll") for (int rr = 0; rr < XR; ++rr) {                                                         \
             const unsigned so = (unsigned)(((C0) + wave_u + 4 * rr) * Tin * 4);                                     \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it)                                                      \
                 _Pragma("unroll") for (int ns = 0; ns < NS; ++ns) xreg[rr][it][ns] = nef_buf_f32(xrs, xvo[it][ns], so); \
         }                                                                                                           \
     }
-    NEF_WISSUE(0)
-    for (int c0 = 0; c0 < Cig; c0 += KC) {
-        if (a.in_scale) {
-#pragma unroll
-            for (int rr = 0; rr < XR; ++rr) {
-                const float sc = a.in_scale[soff + c0 + wave + 4 * rr];
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) xreg[rr][it][0] *= sc;
-            }
-        }
-        __syncthreads();
-        {
-            f32x4* Wl4 = reinterpret_cast<f32x4*>(Wl);
-#pragma unroll
-            for (int q = 0; q < NW; ++q) Wl4[threadIdx.x + 256 * q] = wreg[q];
-#pragma unroll
-            for (int rr = 0; rr < XR; ++rr) {
-                float pa = 1.f, pb = 0.f;
-                if constexpr (AFF) {
-                    pa = a.pro_a[pro_row0 + c0 + wave_u + 4 * rr];
-                    pb = a.pro_b[pro_row0 + c0 + wave_u + 4 * rr];
-                }
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int r = lane + 64 * it;
-                    float v = xreg[rr][it][0];
-                    if constexpr (AFF) v = fmaxf(fmaf(v, pa, pb), 0.f);
-                    if constexpr (UP) {
-                        float v1 = xreg[rr][it][NS - 1];
-                        if constexpr (AFF) v1 = fmaxf(fmaf(v1, pa, pb), 0.f);
-                        v = (1.f - lam[it]) * v + lam[it] * v1;
-                    }
-                    if constexpr (PRO != 0) v = xok[it] ? v : 0.f;
-                    if (r < XROW) Xl[(wave + 4 * rr) * XRS + r] = v;
-                }
-            }
-        }
-        __syncthreads();
-        if (c0 + KC < Cig) NEF_WISSUE(c0 + KC)
-        {
-            constexpr int SPK = KC / 2;
-            float fa[2][4][2];
-            f32x2 fx[2][2];
-#define NEF_WLOAD(S, BUF)                                                                                            \
+#define NEF_WX_STORE(C0, BUFP)                                                                                       \
     {                                                                                                               \
-        const int c_ = 2 * (S) + hi;                                                                                \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
-            _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                        \
-                fa[BUF][i][tm] = Wl[(i * KC + c_) * MT + (wm * 2 + tm) * 32 + lo];                                  \
-        const f32x2* xp_ = reinterpret_cast<const f32x2*>(Xl + c_ * XRS + 2 * (wn * 32 + lo));                      \
+        if (a.in_scale) {                                                                                           \
+            _Pragma("unroll") for (int rr = 0; rr < XR; ++rr) {                                                     \
+                const float sc = a.in_scale[soff + (C0) + wave + 4 * rr];                                           \
+                _Pragma("unroll") for (int it = 0; it < NIT; ++it) xreg[rr][it][0] *= sc;                           \
+            }                                                                                                       \
+        }                                                                                                           \
+        _Pragma("unroll") for (int rr = 0; rr < XR; ++rr) {                                                         \
+            float pa = 1.f, pb = 0.f;                                                                               \
+            if constexpr (AFF) {                                                                                    \
+                pa = a.pro_a[pro_row0 + (C0) + wave_u + 4 * rr];                                                    \
+                pb = a.pro_b[pro_row0 + (C0) + wave_u + 4 * rr];                                                    \
+            }                                                                                                       \
+            _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                    \
+                const int r = lane + 64 * it;                                                                       \
+                float v = xreg[rr][it][0];                                                                          \
+                if constexpr (AFF) v = fmaxf(fmaf(v, pa, pb), 0.f);                                                 \
+                if constexpr (UP) {                                                                                 \
+                    float v1 = xreg[rr][it][NS - 1];                                                                \
+                    if constexpr (AFF) v1 = fmaxf(fmaf(v1, pa, pb), 0.f);                                           \
+                    v = (1.f - lam[it]) * v + lam[it] * v1;                                                         \
+                }                                                                                                   \
+                if constexpr (PRO != 0) v = xok[it] ? v : 0.f;                                                      \
+                if (r < XROW) (BUFP)[(wave + 4 * rr) * XRS + r] = v;                                                \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
+    NEF_WX_ISSUE(0)
+#pragma unroll
+    for (int s_ = 0; s_ < AHEAD; ++s_) NEF_WA_ISSUE(s_, s_)
+    NEF_WX_STORE(0, Xl)
+    __syncthreads();
+    int st = 0;
+    for (int c0 = 0; c0 < Cig; c0 += KC, ++st) {
+        const float* xb = Xl + (st & 1) * (KC * XRS) + hi * XRS + 2 * (wn * 32 + lo);
+        const bool more = c0 + KC < Cig;
+        f32x2 fx[2][2];
+#define NEF_WX_LOAD(S, BUF)                                                                                          \
+    {                                                                                                               \
+        const f32x2* xp_ = reinterpret_cast<const f32x2*>(xb + 2 * (S) * XRS);                                      \
         fx[BUF][0] = xp_[0];                                                                                        \
         fx[BUF][1] = xp_[1];                                                                                        \
     }
-            NEF_WLOAD(0, 0)
+        NEF_WX_LOAD(0, 0)
 #pragma unroll
-            for (int s_ = 0; s_ < SPK; ++s_) {
-                if (s_ + 1 < SPK) NEF_WLOAD(s_ + 1, (s_ + 1) & 1)
-                const float d0 = fx[s_ & 1][0][0], d1 = fx[s_ & 1][0][1], d2 = fx[s_ & 1][1][0], d3 = fx[s_ & 1][1][1];
-                float v[4];
-                v[0] = d0 - d2;
-                v[1] = d1 + d2;
-                v[2] = d2 - d1;
-                v[3] = d1 - d3;
+        for (int s_ = 0; s_ < SPK; ++s_) {
+            NEF_WA_ISSUE(st * SPK + s_ + AHEAD, (s_ + AHEAD) & 3)
+            // the activation rows of the next stage are requested once per stage, right behind an A request: the first
+            // A fragment that is YOUNGER than them is consumed four k-steps later, by when they have long arrived
+            // (vector-memory results return in order)
+            if (s_ == 0 && more) NEF_WX_ISSUE(c0 + KC)
+            if (s_ + 1 < SPK) NEF_WX_LOAD(s_ + 1, (s_ + 1) & 1)
+            const float d0 = fx[s_ & 1][0][0], d1 = fx[s_ & 1][0][1], d2 = fx[s_ & 1][1][0], d3 = fx[s_ & 1][1][1];
+            float v[4];
+            v[0] = d0 - d2;
+            v[1] = d1 + d2;
+            v[2] = d2 - d1;
+            v[3] = d1 - d3;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int tm = 0; tm < 2; ++tm)
-                        acc[i][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_ & 1][i][tm], v[i], acc[i][tm], 0, 0, 0);
-                // interleave: one MFMA, then part of the next step's 10 LDS reads
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            }
-#undef NEF_WLOAD
+                for (int tm = 0; tm < 2; ++tm)
+                    acc[i][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_ & 3][i][tm], v[i], acc[i][tm], 0, 0, 0);
         }
+#undef NEF_WX_LOAD
+        if (more) NEF_WX_STORE(c0 + KC, Xl + ((st + 1) & 1) * (KC * XRS))
+        __syncthreads();
     }
-#undef NEF_WISSUE
+#undef NEF_WA_ISSUE
+#undef NEF_WX_ISSUE
+#undef NEF_WX_STORE
 
     // epilogue: output transform, then bias / residual / ReLU / dropout / gate exactly as conv_fwd_kernel, on the two
     // adjacent outputs (2j, 2j+1) a lane owns per channel row: 8-byte loads and stores, 256 contiguous bytes per row.
@@ -651,7 +652,7 @@ template <int WM, int PRO = 0>
 static int launch_conv_wino(const nef_conv_args& a, hipStream_t st) {
     constexpr int MT = 64 * WM;
     constexpr int NTO = 64 * (4 / WM);
-    constexpr size_t lds = (size_t)(4 * WKC * MT + WKC * (NTO + 16)) * sizeof(float);
+    constexpr size_t lds = (size_t)(2 * WKC * (NTO + 16)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<WM, PRO>),
