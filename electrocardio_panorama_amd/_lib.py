@@ -40,7 +40,7 @@ SIGNATURES = {
     "nef_stem_bwd_ws_bytes": (sz, [i32]),
     "nef_stem_bwd_weight": (i32, [p, p, p, p, p, sz, i32, i32, i32, p]),
     "nef_pack_weight": (i32, [p, p, i32, i32, i32, i32, i32, p]),
-    "nef_pack_weight_wino": (i32, [p, p, i32, i32, i32, i32, p]),
+    "nef_pack_weight_wino": (i32, [p, p, i32, i32, i32, i32, i32, p]),
     "nef_conv_fwd": (i32, [C.POINTER(ConvArgs), p]),
     "nef_conv_bwd_weight_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "nef_conv_bwd_weight": (i32, [p, i64, i64, p, i64, i64, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32, i32, p]),

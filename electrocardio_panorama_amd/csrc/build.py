@@ -25,6 +25,24 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name, defines, sources=("conv_mfma.hip",)):
+    """A/B builds for kernel experiments: csrc/variants/lib<name>.so with extra -D flags on `sources` (the other objects
+    are taken from the regular build).  Select one at run time with NEF_LIB=<path>."""
+    build(force=False, verbose=False)
+    vdir = os.path.join(HERE, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    objs = []
+    for s in SOURCES:
+        o = os.path.join(HERE, s.replace(".hip", ".o"))
+        if s in sources:
+            o = os.path.join(vdir, f"{name}_{s.replace('.hip', '.o')}")
+            subprocess.check_call([hipcc()] + FLAGS + [f"-D{d}" for d in defines] + ["-c", os.path.join(HERE, s), "-o", o])
+        objs.append(o)
+    lib = os.path.join(vdir, f"lib{name}.so")
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB

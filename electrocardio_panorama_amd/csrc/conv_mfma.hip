@@ -389,15 +389,24 @@ constexpr int WKC = 16;   // channels per activation stage: 64 MFMAs per wave be
 // 128-byte line per half-wave, so every wave fetches its own fragments straight from L2/L1 (the whole operand is
 // <= 0.5 MB per group and stays resident) three k-steps ahead of use into four rotating register sets.  That takes
 // the weight tile (32 KB per stage), its LDS writes and 8 of the 10 LDS reads per k-step out of the kernel.
-template <int WM, int PRO>
+//
+// K = 7 uses the same machinery on the taps split 3 + 3 + 1: y[2j], y[2j+1] = F(2,3)(w0..w2; x[2j-3..2j]) +
+// F(2,3)(w3..w5; x[2j..2j+3]) + w6 * (x[2j+3], x[2j+4]).  Both F(2,3) groups accumulate into the SAME four M tiles (the
+// output transform is linear), and the single tap goes straight to M0 (which only feeds y[2j]) with weight w6 and to M3
+// (which only feeds y[2j+1], negated) with weight -w6: 4 + 4 + 2 = 10 multiplies per channel pair instead of 14.  A lane
+// reads x[2j-3 .. 2j+4] of a channel row as four aligned ds_read_b64; the packed operand has 10 planes per group
+// (nef_pack_weight_wino with K = 7).
+template <int K, int WM, int PRO>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int tps, int n_tiles, int m_tiles) {
     constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
     constexpr int NS = UP ? 2 : 1;
     constexpr int KC = WKC;
     constexpr int WN = 4 / WM;
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int NPL = K == 3 ? 4 : 10; // weight planes per (ci, co)
     constexpr int MT = 64 * WM;          // output channels per workgroup
     constexpr int NTO = 64 * WN;         // outputs (columns) per workgroup
-    constexpr int XROW = NTO + 2;        // staged positions per channel row: t0-1 .. t0+NTO
+    constexpr int XROW = NTO + K - 1;    // staged positions per channel row: t0-PAD .. t0+NTO+PAD-1
     constexpr int XRS = NTO + 16;        // LDS row pitch (even: rows stay 8-byte aligned for ds_read_b64)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xl = smem;                    // [2][KC][XRS]
@@ -429,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm_u = wave_u / WN;
     const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(a.x + (int64_t)b0 * a.x_bs + (int64_t)g * a.x_gs);
-    const __amdgpu_buffer_rsrc_t wrs = nef_rsrc(a.wp + (int64_t)g * 4 * Cig * Cog + m0 + wm_u * 64);
+    const __amdgpu_buffer_rsrc_t wrs = nef_rsrc(a.wp + (int64_t)g * NPL * Cig * Cog + m0 + wm_u * 64);
     const int Tin = UP ? (T >> 1) : T;
     unsigned xvo[NIT][NS];
     float lam[NIT];
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int r = lane + 64 * it;
-        const int t = t0 + r - 1;
+        const int t = t0 + r - PAD;
         xok[it] = (r < XROW) && (t >= 0) && (t < T);
         lam[it] = 0.f;
         if constexpr (UP) {
@@ -467,15 +476,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
             for (int r = 0; r < 16; ++r) acc[i][tm][r] = 0.f;
 
     constexpr int SPK = KC / 2;          // k-steps (channel pairs) per stage
-    constexpr int AHEAD = 3;             // A fragments are fetched this many k-steps ahead (4 rotating sets)
-    static_assert(SPK % 4 == 0, "the four A sets must line up across stages");
+    // A fragments are fetched AHEAD k-steps ahead into NSET rotating register sets (a K = 7 step is 20 MFMAs long, one
+    // step of lead covers the L2 latency; the 8-MFMA steps of K = 3 need three)
+    constexpr int AHEAD = K == 3 ? 3 : 1;
+    constexpr int NSET = AHEAD + 1;
+    static_assert(SPK % NSET == 0, "the A sets must line up across stages");
     const int nsteps = Cig / 2;
-    float fa[4][4][2];
+    float fa[NSET][NPL][2];
     float xreg[XR][NIT][NS];
 #define NEF_WA_ISSUE(GS, SET)                                                                                        \
     {                                                                                                               \
         const int gs_ = (GS) < nsteps ? (GS) : nsteps - 1;      /* past the end: a harmless repeat of the last step */ \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
+        _Pragma("unroll") for (int i = 0; i < NPL; ++i)                                                             \
             _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                        \
                 fa[SET][i][tm] = nef_buf_f32(wrs, avo, (unsigned)((i * w_istride + 2 * gs_ * Cog + tm * 32) * 4));   \
     }
@@ -524,33 +536,52 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
     for (int c0 = 0; c0 < Cig; c0 += KC, ++st) {
         const float* xb = Xl + (st & 1) * (KC * XRS) + hi * XRS + 2 * (wn * 32 + lo);
         const bool more = c0 + KC < Cig;
-        f32x2 fx[2][2];
+        constexpr int NXV = K == 3 ? 2 : 4;        // ds_read_b64 per lane and k-step: x[2j-PAD .. 2j-PAD+2*NXV)
+        f32x2 fx[2][NXV];
 #define NEF_WX_LOAD(S, BUF)                                                                                          \
     {                                                                                                               \
         const f32x2* xp_ = reinterpret_cast<const f32x2*>(xb + 2 * (S) * XRS);                                      \
-        fx[BUF][0] = xp_[0];                                                                                        \
-        fx[BUF][1] = xp_[1];                                                                                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < NXV; ++q_) fx[BUF][q_] = xp_[q_];                                   \
     }
         NEF_WX_LOAD(0, 0)
 #pragma unroll
         for (int s_ = 0; s_ < SPK; ++s_) {
-            NEF_WA_ISSUE(st * SPK + s_ + AHEAD, (s_ + AHEAD) & 3)
+            NEF_WA_ISSUE(st * SPK + s_ + AHEAD, (s_ + AHEAD) % NSET)
             // the activation rows of the next stage are requested once per stage, right behind an A request: the first
-            // A fragment that is YOUNGER than them is consumed four k-steps later, by when they have long arrived
+            // A fragment that is YOUNGER than them is consumed later in the stage, by when they have long arrived
             // (vector-memory results return in order)
             if (s_ == 0 && more) NEF_WX_ISSUE(c0 + KC)
             if (s_ + 1 < SPK) NEF_WX_LOAD(s_ + 1, (s_ + 1) & 1)
-            const float d0 = fx[s_ & 1][0][0], d1 = fx[s_ & 1][0][1], d2 = fx[s_ & 1][1][0], d3 = fx[s_ & 1][1][1];
+            const f32x2* d = fx[s_ & 1];
+            const float (*w)[2] = fa[s_ % NSET];
             float v[4];
-            v[0] = d0 - d2;
-            v[1] = d1 + d2;
-            v[2] = d2 - d1;
-            v[3] = d1 - d3;
+            v[0] = d[0][0] - d[1][0];
+            v[1] = d[0][1] + d[1][0];
+            v[2] = d[1][0] - d[0][1];
+            v[3] = d[0][1] - d[1][1];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm)
-                    acc[i][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_ & 3][i][tm], v[i], acc[i][tm], 0, 0, 0);
+                    acc[i][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i][tm], v[i], acc[i][tm], 0, 0, 0);
+            if constexpr (K == 7) {
+                // second group on x[2j .. 2j+3] = d3..d6, single tap on (d6, d7)
+                float u[4];
+                u[0] = d[1][1] - d[2][1];
+                u[1] = d[2][0] + d[2][1];
+                u[2] = d[2][1] - d[2][0];
+                u[3] = d[2][0] - d[3][0];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+                        acc[i][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[4 + i][tm], u[i], acc[i][tm], 0, 0, 0);
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    acc[0][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[8][tm], d[3][0], acc[0][tm], 0, 0, 0);
+                    acc[3][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[9][tm], d[3][1], acc[3][tm], 0, 0, 0);
+                }
+            }
         }
 #undef NEF_WX_LOAD
         if (more) NEF_WX_STORE(c0 + KC, Xl + ((st + 1) & 1) * (KC * XRS))
@@ -648,14 +679,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
     }
 }
 
-template <int WM, int PRO = 0>
+template <int K, int WM, int PRO = 0>
 static int launch_conv_wino(const nef_conv_args& a, hipStream_t st) {
     constexpr int MT = 64 * WM;
     constexpr int NTO = 64 * (4 / WM);
     constexpr size_t lds = (size_t)(2 * WKC * (NTO + 16)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<WM, PRO>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<K, WM, PRO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -665,15 +696,18 @@ static int launch_conv_wino(const nef_conv_args& a, hipStream_t st) {
     const int m_tiles = a.Cout_g / MT;
     const int64_t blocks = (int64_t)a.G * m_tiles * n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffff) return NEF_E_SHAPE;
-    hipLaunchKernelGGL((conv_wino_kernel<WM, PRO>), dim3((unsigned)blocks), dim3(256), lds, st, a, tps, n_tiles, m_tiles);
+    hipLaunchKernelGGL((conv_wino_kernel<K, WM, PRO>), dim3((unsigned)blocks), dim3(256), lds, st, a, tps, n_tiles, m_tiles);
     return nef_launch_status();
 }
 
-// wp[g][i][r][c], i = 0..3 the F(2,3) weight transform of the three taps; (r, c) = (ci, co) forward,
-// (co, ci) with the taps reversed for the backward-data operand
+// wp[g][plane][r][c]; (r, c) = (ci, co) forward, (co, ci) with the taps reversed for the backward-data operand.
+// K = 3: planes 0..3 = the F(2,3) weight transform (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) of the three taps.
+// K = 7: planes 0..3 / 4..7 = that transform of taps 0..2 / 3..5, plane 8 = tap 6, plane 9 = -tap 6.
 __global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog, int Cig,
-                                        int flip) {
+                                        int K, int flip) {
     const int64_t n = (int64_t)G * Cog * Cig;
+    const int64_t plane = n / G;
+    const int npl = K == 3 ? 4 : 10;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t r = i;
         int co, ci;
@@ -685,14 +719,21 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __re
             co = (int)(r % Cog); r /= Cog;
         }
         const int g = (int)r;
-        const float* src = w + (((int64_t)g * Cog + co) * Cig + ci) * 3;
-        const float g0 = flip ? src[2] : src[0], g1 = src[1], g2 = flip ? src[0] : src[2];
-        float* dst = wp + (int64_t)g * 4 * n / G + (i - (int64_t)g * (n / G));
-        const int64_t plane = n / G;
-        dst[0] = g0;
-        dst[plane] = ((g0 + g1) + g2) * 0.5f;
-        dst[2 * plane] = ((g0 - g1) + g2) * 0.5f;
-        dst[3 * plane] = g2;
+        const float* src = w + (((int64_t)g * Cog + co) * Cig + ci) * K;
+        float* dst = wp + (int64_t)g * npl * plane + (i - (int64_t)g * plane);
+        for (int grp = 0; grp < K / 3; ++grp) {
+            const float g0 = src[flip ? K - 1 - 3 * grp : 3 * grp], g1 = src[flip ? K - 2 - 3 * grp : 3 * grp + 1],
+                        g2 = src[flip ? K - 3 - 3 * grp : 3 * grp + 2];
+            dst[(4 * grp) * plane] = g0;
+            dst[(4 * grp + 1) * plane] = ((g0 + g1) + g2) * 0.5f;
+            dst[(4 * grp + 2) * plane] = ((g0 - g1) + g2) * 0.5f;
+            dst[(4 * grp + 3) * plane] = g2;
+        }
+        if (K == 7) {
+            const float g6 = src[flip ? 0 : 6];
+            dst[8 * plane] = g6;
+            dst[9 * plane] = -g6;
+        }
     }
 }
 
@@ -1075,13 +1116,14 @@ int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, i
     return nef_launch_status();
 }
 
-int nef_pack_weight_wino(const float* w, float* wp, int G, int Cog, int Cig, int transpose_flip, nef_stream_t stream) {
+int nef_pack_weight_wino(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
+                         nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(w && wp, NEF_E_NULL);
-    NEF_REQUIRE(G > 0 && Cog > 0 && Cig > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(G > 0 && Cog > 0 && Cig > 0 && (K == 3 || K == 7), NEF_E_SHAPE);
     const int64_t n = (int64_t)G * Cog * Cig;
     hipLaunchKernelGGL(pack_weight_wino_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, w, wp,
-                       G, Cog, Cig, transpose_flip);
+                       G, Cog, Cig, K, transpose_flip);
     return nef_launch_status();
 }
 
@@ -1102,17 +1144,19 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
         const ColTiling ct0 = make_tiling(a->B, a->T, NT);
         if ((int64_t)a->G * (a->Cout_g / 128) * ct0.n_tiles < 384) big = false;
     }
-    if (a->wino) {       // weights packed by nef_pack_weight_wino: F(2,3) path, whole tiles of one sample only
-        NEF_REQUIRE(K == 3 && a->T % 2 == 0 && a->Cin_g % WKC == 0, NEF_E_SHAPE);
+    if (a->wino) {       // weights packed by nef_pack_weight_wino: Winograd F(2,3) path, whole tiles of one sample only
+        NEF_REQUIRE((K == 3 || K == 7) && a->T % 2 == 0 && a->Cin_g % WKC == 0, NEF_E_SHAPE);
         NEF_REQUIRE(a->pro_mode >= 0 && a->pro_mode <= 3 && !(a->pro_mode && a->in_scale), NEF_E_UNSUPPORTED);
+        NEF_REQUIRE(K == 3 || a->pro_mode == 0, NEF_E_UNSUPPORTED);
         NEF_REQUIRE(!(a->pro_mode & 1) || (a->pro_a && a->pro_b && a->pro_Bp > 0), NEF_E_NULL);
         const bool wide = (a->Cout_g % 128 == 0);
         NEF_REQUIRE(a->T >= (wide ? 128 : 256), NEF_E_SHAPE);
+        if (K == 7) return wide ? launch_conv_wino<7, 2, 0>(*a, st) : launch_conv_wino<7, 1, 0>(*a, st);
         switch (a->pro_mode) {
-            case 0: return wide ? launch_conv_wino<2, 0>(*a, st) : launch_conv_wino<1, 0>(*a, st);
-            case 1: return wide ? launch_conv_wino<2, 1>(*a, st) : launch_conv_wino<1, 1>(*a, st);
-            case 2: return wide ? launch_conv_wino<2, 2>(*a, st) : launch_conv_wino<1, 2>(*a, st);
-            default: return wide ? launch_conv_wino<2, 3>(*a, st) : launch_conv_wino<1, 3>(*a, st);
+            case 0: return wide ? launch_conv_wino<3, 2, 0>(*a, st) : launch_conv_wino<3, 1, 0>(*a, st);
+            case 1: return wide ? launch_conv_wino<3, 2, 1>(*a, st) : launch_conv_wino<3, 1, 1>(*a, st);
+            case 2: return wide ? launch_conv_wino<3, 2, 2>(*a, st) : launch_conv_wino<3, 1, 2>(*a, st);
+            default: return wide ? launch_conv_wino<3, 2, 3>(*a, st) : launch_conv_wino<3, 1, 3>(*a, st);
         }
     }
     if (a->pro_mode != 0) {

@@ -173,13 +173,13 @@ def stem_bwd_weight(x, w, gy):
 
 
 # ------------------------------------------------------------------ grouped conv
-# K = 3 convs through Winograd F(2,3) (conv_mfma.hip: conv_wino_kernel) wherever a whole output tile of one sample
-# exists; NEF_WINOGRAD=0 keeps every conv on the direct kernel.
+# K = 3 and K = 7 convs through Winograd F(2,3) (conv_mfma.hip: conv_wino_kernel) wherever a whole output tile of one
+# sample exists; NEF_WINOGRAD=0 keeps every conv on the direct kernel.
 WINOGRAD = os.environ.get("NEF_WINOGRAD", "1") != "0"
 
 
-def wino_ok(K, Cin_g, Cout_g, T_out):
-    return (WINOGRAD and K == 3 and T_out % 2 == 0 and Cin_g % 16 == 0 and
+def wino_ok(K, Cin_g, Cout_g, T_out, pro=0):
+    return (WINOGRAD and (K == 3 or (K == 7 and not pro)) and T_out % 2 == 0 and Cin_g % 16 == 0 and
             ((Cout_g % 128 == 0 and T_out >= 128) or (Cout_g % 128 != 0 and Cout_g % 64 == 0 and T_out >= 256)))
 
 
@@ -192,8 +192,8 @@ def pack_weight(w, G, flip=False, T=None):
     Cog, Cig, K = w.shape[0] // G, w.shape[1], w.shape[2]
     cin_g, cout_g = (Cog, Cig) if flip else (Cig, Cog)          # roles in the launch that consumes the operand
     if T is not None and wino_ok(K, cin_g, cout_g, T):
-        wp = torch.empty(G * 4 * Cog * Cig, device=w.device, dtype=torch.float32)
-        _lib.check(L.nef_pack_weight_wino(_p(w), _p(wp), G, Cog, Cig, int(flip), _stream()), "nef_pack_weight_wino")
+        wp = torch.empty(G * (4 if K == 3 else 10) * Cog * Cig, device=w.device, dtype=torch.float32)
+        _lib.check(L.nef_pack_weight_wino(_p(w), _p(wp), G, Cog, Cig, K, int(flip), _stream()), "nef_pack_weight_wino")
         wp.nef_wino = True
         return wp
     wp = torch.empty(w.numel(), device=w.device, dtype=torch.float32)

@@ -57,9 +57,11 @@ int nef_stem_bwd_weight(const float* x, const float* w, const float* gy, float* 
 int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                     nef_stream_t stream);
 
-/* Winograd F(2,3) operand for K == 3: wp[g][i][ci][co], i = 0..3 = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) of the taps
- * w[g*Cog+co][ci][0..2]; transpose_flip = 1: the backward-data operand wp[g][i][co][ci] of the reversed taps. */
-int nef_pack_weight_wino(const float* w, float* wp, int G, int Cog, int Cig, int transpose_flip, nef_stream_t stream);
+/* Winograd F(2,3) operand, wp[g][plane][ci][co] (transpose_flip = 1: the backward-data operand wp[g][plane][co][ci] of
+ * the reversed taps).  K == 3: 4 planes (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) of the taps w[g*Cog+co][ci][0..2].
+ * K == 7 (taps split 3 + 3 + 1): 10 planes = that transform of taps 0..2, of taps 3..5, then tap 6 and -tap 6. */
+int nef_pack_weight_wino(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
+                         nef_stream_t stream);
 
 typedef struct nef_conv_args {
     const float* x;        /* input  [B][..][T]; element (b, g, ci, t) at x + b*x_bs + g*x_gs + ci*T + t */
@@ -90,10 +92,10 @@ typedef struct nef_conv_args {
     int32_t pro_Bp;
     const uint64_t* rng_seed_dev;  /* NULL, or a device word added to rng_seed at run time (hipGraph replay: a captured
                                       launch freezes its arguments, the per-step seed must live in device memory) */
-    int32_t wino;          /* 1: wp was packed by nef_pack_weight_wino ([G][4][Cin_g][Cout_g]) -- K == 3 through Winograd
-                              F(2,3) (2/3 of the multiplies; still exact-fp32 arithmetic, results differ from the direct
-                              form by the rounding of the transforms).  Needs T even, T >= 128 (Cout_g % 128 == 0) or
-                              T >= 256 (Cout_g % 64 == 0), Cin_g % 16 == 0. */
+    int32_t wino;          /* 1: wp was packed by nef_pack_weight_wino -- K == 3 / K == 7 through Winograd F(2,3) (2/3 resp.
+                              5/7 of the multiplies; still fp32 multiplies and adds on the matrix cores, results differ
+                              from the direct form by the rounding of the transforms).  Needs T even, T >= 128
+                              (Cout_g % 128 == 0) or T >= 256 (Cout_g % 64 == 0), Cin_g % 16 == 0; K == 7: pro_mode 0. */
 } nef_conv_args;
 
 /* y = epilogue(conv(x * in_scale, wp) + bias + res).  Also the bwd-data pass (pack with transpose_flip=1,

@@ -594,37 +594,67 @@ def test_decoder_three_passes(T):
             assert rel(v, g64[k]) < GRAD_TOL + 2 * rel(g32[k], g64[k]), (k, rel(v, g64[k]), rel(g32[k], g64[k]))
 
 
-WINO_CASES = [  # G, Cig, Cog, T, B   (K = 3)
-    (3, 128, 128, 128, 2), (3, 128, 128, 250, 3), (3, 64, 128, 130, 2), (1, 256, 128, 250, 3), (2, 128, 128, 1250, 2),
-    (1, 128, 64, 500, 2), (1, 64, 64, 260, 3), (1, 128, 64, 256, 2), (1, 64, 128, 5000, 2), (1, 128, 256, 250, 2),
+WINO_CASES = [  # K, G, Cig, Cog, T, B
+    (3, 3, 128, 128, 128, 2), (3, 3, 128, 128, 250, 3), (3, 3, 64, 128, 130, 2), (3, 1, 256, 128, 250, 3),
+    (3, 2, 128, 128, 1250, 2), (3, 1, 128, 64, 500, 2), (3, 1, 64, 64, 260, 3), (3, 1, 128, 64, 256, 2),
+    (3, 1, 64, 128, 5000, 2), (3, 1, 128, 256, 250, 2),
+    (7, 3, 128, 128, 128, 2), (7, 1, 128, 128, 300, 2), (7, 2, 128, 128, 1250, 2), (7, 1, 128, 64, 500, 2),
+    (7, 3, 128, 128, 130, 3), (7, 1, 64, 128, 256, 2),
 ]
 
 
-@pytest.mark.parametrize("G,Cig,Cog,T,B", WINO_CASES)
-def test_conv_winograd(G, Cig, Cog, T, B):
-    """K = 3 through Winograd F(2,3) (conv_wino_kernel): forward and backward-data against F.conv1d at the forward /
-    gradient bars, and its distance from exact (fp64) arithmetic next to the direct kernel's."""
+@pytest.mark.parametrize("K,G,Cig,Cog,T,B", WINO_CASES)
+def test_conv_winograd(K, G, Cig, Cog, T, B):
+    """K = 3 and K = 7 (taps split 3 + 3 + 1) through Winograd F(2,3) (conv_wino_kernel): forward and backward-data
+    against F.conv1d at the forward / gradient bars, and the distance from exact (fp64) arithmetic next to the direct
+    kernel's."""
     o = ops()
     from electrocardio_panorama_amd.ops import GV
-    assert o.wino_ok(3, Cig, Cog, T) and o.wino_ok(3, Cog, Cig, T) == (Cig % 128 == 0 or T >= 256)
+    assert o.wino_ok(K, Cig, Cog, T) and o.wino_ok(K, Cog, Cig, T) == (Cig % 128 == 0 or T >= 256)
     x = rnd(B, G * Cig, T, seed=5)
-    w = rnd(G * Cog, Cig, 3, seed=6, scale=(Cig * 3) ** -0.5)
+    w = rnd(G * Cog, Cig, K, seed=6, scale=(Cig * K) ** -0.5)
     xr = x.clone().requires_grad_(True)
-    ref = F.conv1d(xr, w, None, 1, 1, 1, G)
-    ref64 = F.conv1d(x.double(), w.double(), None, 1, 1, 1, G)
+    ref = F.conv1d(xr, w, None, 1, K // 2, 1, G)
+    ref64 = F.conv1d(x.double(), w.double(), None, 1, K // 2, 1, G)
     xd, wd = g(x), g(w)
     wpw = o.pack_weight(wd, G, T=T)
-    assert getattr(wpw, "nef_wino", False) and wpw.numel() == 4 * G * Cog * Cig
-    y = o.conv(GV.dense(xd, G), wpw, Cog, 3)
-    yd = o.conv(GV.dense(xd, G), o.pack_weight(wd, G), Cog, 3)
+    assert getattr(wpw, "nef_wino", False) and wpw.numel() == (4 if K == 3 else 10) * G * Cog * Cig
+    y = o.conv(GV.dense(xd, G), wpw, Cog, K)
+    yd = o.conv(GV.dense(xd, G), o.pack_weight(wd, G), Cog, K)
     assert rel(y, ref) < FWD_TOL, "forward"
     e_w, e_d, e_t = rel(y, ref64), rel(yd, ref64), rel(ref, ref64)
     assert e_w < 4 * max(e_d, e_t) + 1e-7, (e_w, e_d, e_t)       # the transforms cost a small constant factor, not more
     gy = rnd(*ref.shape, seed=7)
     ref.backward(gy)
-    wf = o.pack_weight(wd, G, flip=True, T=T)
-    gx = o.conv(GV.dense(g(gy), G), wf, Cig, 3)
-    assert rel(gx, xr.grad) < GRAD_TOL, "bwd-data"
+    if o.wino_ok(K, Cog, Cig, T):
+        wf = o.pack_weight(wd, G, flip=True, T=T)
+        assert wf.nef_wino
+        gx = o.conv(GV.dense(g(gy), G), wf, Cig, K)
+        assert rel(gx, xr.grad) < GRAD_TOL, "bwd-data"
+
+
+def test_conv_winograd_k7_block_epilogues():
+    """The two conv launches of an encoder BasicBlock (resnet_1d.py:42-53) and their backward-data counterparts on the
+    K = 7 Winograd path: ReLU + replayed dropout; residual + ReLU; gated backward-data with a residual gradient."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    B, V, T, K = 2, 3, 250, 7
+    x = rnd(B, 128 * V, T, seed=21)
+    w1, w2 = rnd(128 * V, 128, K, seed=22, scale=0.03), rnd(128 * V, 128, K, seed=23, scale=0.03)
+    keep = (rnd(B, 128 * V, T, seed=24) > -0.6).to(torch.uint8)
+    xr, w1r, w2r = (t.clone().requires_grad_(True) for t in (x, w1, w2))
+    h = F.relu(F.conv1d(xr, w1r, None, 1, 3, 1, V)) * keep / 0.8
+    y = F.relu(F.conv1d(h, w2r, None, 1, 3, 1, V) + xr)
+    gy = rnd(B, 128 * V, T, seed=25)
+    y.backward(gy)
+    xd, w1d, w2d, kd = g(x), g(w1), g(w2), g(keep)
+    hd = o.conv(GV.dense(xd, V), o.pack_weight(w1d, V, T=T), 128, K, relu=True, mask=kd, drop_scale=1.25)
+    yd = o.conv(GV.dense(hd, V), o.pack_weight(w2d, V, T=T), 128, K, res=GV.dense(xd, V), relu=True)
+    assert rel(hd, h) < FWD_TOL and rel(yd, y) < FWD_TOL
+    g2 = o.gate(g(gy), yd)
+    gc1 = o.conv(GV.dense(g2, V), o.pack_weight(w2d, V, flip=True, T=T), 128, K, gate=GV.dense(hd, V), gate_scale=1.25)
+    gx = o.conv(GV.dense(gc1, V), o.pack_weight(w1d, V, flip=True, T=T), 128, K, res=GV.dense(g2, V))
+    assert rel(gx, xr.grad) < GRAD_TOL
 
 
 def test_conv_winograd_epilogue_views_and_rng():
