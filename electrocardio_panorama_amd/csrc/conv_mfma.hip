@@ -740,7 +740,16 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __re
 // ------------------------------------------------------------------------------------------------
 // bwd-weight: split over the (b,t) reduction, partials reduced by a second deterministic kernel
 // ------------------------------------------------------------------------------------------------
-template <int K, int WCO, int TCI, int PRO>
+// WINO = 1 (K = 3 or 7, whole 64-column tiles of one sample, T even): the same reduction through the transposed
+// Winograd algorithm F(3,2).  For output pair j of a row, g = (gy[2j], gy[2j+1]) and d_m = x[2j-PAD+m]:
+//     gW[k] += g0*d_k + g1*d_(k+1), k = 0..2      is      gW = G^T [ (A g) (.) (B^T d) ]
+//     A g = (g0, g0+g1, g0-g1, -g1)     B^T d = (d0-d2, d1+d2, d2-d1, d1-d3)     (the forward pass's input transform)
+//     M_i[co][ci] = sum over pairs and samples of (A g)_i (B^T d)_i               (4 GEMMs instead of 3, over HALF the columns)
+//     gW[0] = M0 + (M1+M2)/2     gW[1] = (M1-M2)/2     gW[2] = (M1+M2)/2 + M3     (once per workgroup, before the partials
+// are written; the kernel keeps u3 = +g1 and flips the sign there).  K = 7 splits the taps 3 + 3 + 1 like the forward
+// kernel: two transform groups (8 accumulator tiles) plus one plain tile for tap 6: 10 MFMAs per 4 columns instead of 14.
+// Both operands are transformed on the way from LDS to the MFMA operands (aligned ds_read_b64 of a lane's own row).
+template <int K, int WCO, int TCI, int PRO, int WINO = 0>
 __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
     const float* __restrict__ x, int64_t x_bs, int64_t x_gs, const float* __restrict__ in_scale, int64_t sc_bs,
     int64_t sc_gs, const float* __restrict__ gy, int64_t gy_bs, int64_t gy_gs, float* __restrict__ ws, int B, int T,
@@ -753,8 +762,10 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
     constexpr int MT = 32 * WCO;
     constexpr int CIT = 32 * TCI * WCI;
     constexpr int PAD = (K - 1) / 2;
-    constexpr int GYS = WT + 1;
-    constexpr int XS = (WT + (WT / 16) * (K - 1)) | 1;
+    // LDS row pitches: odd for the transposed ds_read_b32 of the direct form; = 2 (mod 32) for the ds_read_b64 of WINO
+    constexpr int GYS = WINO ? 66 : WT + 1;
+    constexpr int XS = WINO ? (K == 3 ? 66 : 98) : ((WT + (WT / 16) * (K - 1)) | 1);
+    constexpr int NACC = WINO ? (K == 3 ? 4 : 9) : K;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* GYl = smem;               // [MT][GYS]
     float* Xl = smem + MT * GYS;     // [CIT][XS]
@@ -789,11 +800,11 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
     const int lo = lane & 31, hi = lane >> 5;
     const int wco = wave % WCO, wci = wave / WCO;
 
-    f32x16 acc[TCI][K];
+    f32x16 acc[TCI][NACC];
 #pragma unroll
     for (int i = 0; i < TCI; ++i)
 #pragma unroll
-        for (int k = 0; k < K; ++k)
+        for (int k = 0; k < NACC; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
 
@@ -921,6 +932,58 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
         }
         __syncthreads();
         if (tile + S < n_tiles) NEF_BW_ISSUE(tile + S)
+        if constexpr (WINO) {
+            // 16 reduction steps per 64-column tile, each over two output pairs (MFMA k = pair): a lane reads its gY row's
+            // pair and its X row's 4 (K = 3) or 8 (K = 7) inputs as aligned 8-byte words, one step ahead of use
+            constexpr int NXV = K == 3 ? 2 : 4;
+            constexpr int NSTEP = WT / 4;
+            const float* ga = GYl + (wco * 32 + lo) * GYS + 2 * hi;
+            const float* xb = Xl + ((wci * TCI) * 32 + lo) * XS + 2 * hi;
+            f32x2 fg[2], fx[2][TCI][NXV];
+#define NEF_BWW_LOAD(S_, BUF)                                                                                        \
+    {                                                                                                               \
+        fg[BUF] = *reinterpret_cast<const f32x2*>(ga + 4 * (S_));                                                   \
+        _Pragma("unroll") for (int i = 0; i < TCI; ++i)                                                             \
+            _Pragma("unroll") for (int q_ = 0; q_ < NXV; ++q_)                                                      \
+                fx[BUF][i][q_] = *reinterpret_cast<const f32x2*>(xb + i * 32 * XS + 4 * (S_) + 2 * q_);             \
+    }
+            NEF_BWW_LOAD(0, 0)
+#pragma unroll
+            for (int s_ = 0; s_ < NSTEP; ++s_) {
+                if (s_ + 1 < NSTEP) NEF_BWW_LOAD(s_ + 1, (s_ + 1) & 1)
+                const float g0 = fg[s_ & 1][0], g1 = fg[s_ & 1][1];
+                float u[4];
+                u[0] = g0;
+                u[1] = g0 + g1;
+                u[2] = g0 - g1;
+                u[3] = g1;
+#pragma unroll
+                for (int i = 0; i < TCI; ++i) {
+                    const f32x2* d = fx[s_ & 1][i];
+                    float v[4];
+                    v[0] = d[0][0] - d[1][0];
+                    v[1] = d[0][1] + d[1][0];
+                    v[2] = d[1][0] - d[0][1];
+                    v[3] = d[0][1] - d[1][1];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[n], v[n], acc[i][n], 0, 0, 0);
+                    if constexpr (K == 7) {
+                        float w[4];
+                        w[0] = d[1][1] - d[2][1];
+                        w[1] = d[2][0] + d[2][1];
+                        w[2] = d[2][1] - d[2][0];
+                        w[3] = d[2][0] - d[3][0];
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc[i][4 + n] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[n], w[n], acc[i][4 + n], 0, 0, 0);
+                        acc[i][8] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, d[3][0], acc[i][8], 0, 0, 0);
+                        acc[i][8] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, d[3][1], acc[i][8], 0, 0, 0);
+                    }
+                }
+            }
+#undef NEF_BWW_LOAD
+        } else
         // 32 reduction steps (2 columns each) per 64-column tile, software-pipelined like the forward kernel: the
         // fragments of step group gi+1 are read from LDS while the MFMAs of group gi issue.  Column 2*step of the
         // gY tile is linear; in the X tile every sample segment carries K-1 halo columns.
@@ -971,7 +1034,21 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = m0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                dst[(int64_t)co * Cig + ci] = acc[i][k][r];
+                float v;
+                if constexpr (WINO) {
+                    if (k == 6) {
+                        v = acc[i][NACC - 1][r];
+                    } else {
+                        const int q = 4 * (k / 3);              // transform group of this tap
+                        const float hs = 0.5f * (acc[i][q + 1][r] + acc[i][q + 2][r]);
+                        v = (k % 3 == 0) ? acc[i][q][r] + hs
+                          : (k % 3 == 1) ? 0.5f * (acc[i][q + 1][r] - acc[i][q + 2][r])
+                                         : hs - acc[i][q + 3][r];
+                    }
+                } else {
+                    v = acc[i][k < NACC ? k : 0][r];
+                }
+                dst[(int64_t)co * Cig + ci] = v;
             }
         }
     }
@@ -1008,7 +1085,8 @@ struct BwdWeightPlan {
     ColTiling ct;
 };
 
-static bool plan_bwd_weight(int B, int T, int G, int Cig, int Cog, int K, BwdWeightPlan* p, int pro_mode = 0) {
+static bool plan_bwd_weight(int B, int T, int G, int Cig, int Cog, int K, BwdWeightPlan* p, int pro_mode = 0,
+                            bool wino = false) {
     if (!(K == 1 || K == 3 || K == 7)) return false;
     if (Cog % 128 == 0) p->wco = 4;
     else if (Cog % 64 == 0) p->wco = 2;
@@ -1016,6 +1094,7 @@ static bool plan_bwd_weight(int B, int T, int G, int Cig, int Cog, int K, BwdWei
     const int wci = 4 / p->wco;
     p->tci = (K <= 3 && Cig % (64 * wci) == 0) ? 2 : 1;
     if (pro_mode != 0 && p->wco == 2) p->tci = 1;      // keep the doubled staging registers within budget
+    if (wino && p->wco == 2) p->tci = 1;               // 4 accumulator tiles per ci tile: same budget
     const int cit = 32 * p->tci * wci;
     if (Cig % cit != 0) return false;
     p->m_tiles = Cog / (32 * p->wco);
@@ -1029,7 +1108,7 @@ static bool plan_bwd_weight(int B, int T, int G, int Cig, int Cog, int K, BwdWei
     return true;
 }
 
-template <int K, int WCO, int TCI, int PRO = 0>
+template <int K, int WCO, int TCI, int PRO = 0, int WINO = 0>
 static int launch_bwd_weight(const BwdWeightPlan& p, const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale,
                              int64_t sc_bs, int64_t sc_gs, const float* gy, int64_t gy_bs, int64_t gy_gs, float* ws,
                              int B, int T, int G, int Cig, int Cog, hipStream_t st, const float* pro_a = nullptr,
@@ -1037,18 +1116,18 @@ static int launch_bwd_weight(const BwdWeightPlan& p, const float* x, int64_t x_b
     constexpr int WCI = 4 / WCO;
     constexpr int MT = 32 * WCO;
     constexpr int CIT = 32 * TCI * WCI;
-    constexpr int GYS = WT + 1;
-    constexpr int XS = (WT + (WT / 16) * (K - 1)) | 1;
+    constexpr int GYS = WINO ? 66 : WT + 1;
+    constexpr int XS = WINO ? (K == 3 ? 66 : 98) : ((WT + (WT / 16) * (K - 1)) | 1);
     constexpr size_t lds = (size_t)(MT * GYS + CIT * XS) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bwd_weight_kernel<K, WCO, TCI, PRO>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bwd_weight_kernel<K, WCO, TCI, PRO, WINO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int64_t blocks = (int64_t)p.S * G * p.m_tiles * p.ci_chunks;
-    hipLaunchKernelGGL((conv_bwd_weight_kernel<K, WCO, TCI, PRO>), dim3((unsigned)blocks), dim3(256), lds, st, x, x_bs,
+    hipLaunchKernelGGL((conv_bwd_weight_kernel<K, WCO, TCI, PRO, WINO>), dim3((unsigned)blocks), dim3(256), lds, st, x, x_bs,
                        x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, ws, B, T, G, Cig, Cog, p.ct.seg_shift, p.ct.nseg,
                        p.ct.tps, p.ct.n_tiles, p.m_tiles, p.ci_chunks, p.S, pro_a, pro_b, pro_Bp);
     return nef_launch_status();
@@ -1252,6 +1331,49 @@ int nef_conv_bwd_weight_pro(const float* x, int64_t x_bs, int64_t x_gs, const fl
     else NEF_BWP_MODE(2, 1)
 #undef NEF_BWP_MODE
 #undef NEF_BWP
+    if (rc != NEF_OK) return rc;
+    const int64_t n = (int64_t)G * K * Cout_g * Cin_g;
+    hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3(nef_stream_grid(n, 256)), dim3(256), 0, st, wsf, gw, G, Cout_g,
+                       Cin_g, K, p.S);
+    return nef_launch_status();
+}
+
+int nef_conv_bwd_weight_wino(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
+                             int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
+                             const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B, int T,
+                             int G, int Cin_g, int Cout_g, int K, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && gy && gw && ws, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && T >= WT && T % 2 == 0 && G > 0 && (K == 3 || K == 7), NEF_E_SHAPE);
+    NEF_REQUIRE(pro_mode >= 0 && pro_mode <= 3 && (K == 3 || pro_mode == 0) && !(pro_mode && in_scale), NEF_E_UNSUPPORTED);
+    NEF_REQUIRE(!(pro_mode & 1) || (pro_a && pro_b && pro_Bp > 0), NEF_E_NULL);
+    BwdWeightPlan p;
+    NEF_REQUIRE(plan_bwd_weight(B, T, G, Cin_g, Cout_g, K, &p, pro_mode, true), NEF_E_SHAPE);
+    NEF_REQUIRE(p.ct.nseg == 1, NEF_E_SHAPE);
+    const size_t need = (size_t)p.S * G * K * Cout_g * Cin_g * sizeof(float);
+    NEF_REQUIRE(ws_bytes >= need, NEF_E_WORKSPACE);
+    hipStream_t st = (hipStream_t)stream;
+    float* wsf = (float*)ws;
+    int rc = NEF_E_UNSUPPORTED;
+#define NEF_BWW(KK, WCO, TCI, PRO)                                                                                     \
+    rc = launch_bwd_weight<KK, WCO, TCI, PRO, 1>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G, \
+                                                 Cin_g, Cout_g, st, pro_a, pro_b, pro_Bp)
+#define NEF_BWW_MODE(WCO, TCI)                                                                                         \
+    {                                                                                                                 \
+        if (pro_mode == 0) NEF_BWW(3, WCO, TCI, 0);                                                                   \
+        else if (pro_mode == 1) NEF_BWW(3, WCO, TCI, 1);                                                              \
+        else if (pro_mode == 2) NEF_BWW(3, WCO, TCI, 2);                                                              \
+        else NEF_BWW(3, WCO, TCI, 3);                                                                                 \
+    }
+    if (K == 7) {
+        if (p.wco == 4) NEF_BWW(7, 4, 1, 0); else NEF_BWW(7, 2, 1, 0);
+    } else if (p.wco == 4) {
+        if (p.tci == 2) NEF_BWW_MODE(4, 2) else NEF_BWW_MODE(4, 1)
+    } else {
+        NEF_BWW_MODE(2, 1)
+    }
+#undef NEF_BWW_MODE
+#undef NEF_BWW
     if (rc != NEF_OK) return rc;
     const int64_t n = (int64_t)G * K * Cout_g * Cin_g;
     hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3(nef_stream_grid(n, 256)), dim3(256), 0, st, wsf, gw, G, Cout_g,

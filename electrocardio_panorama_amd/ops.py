@@ -240,8 +240,9 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     return out.t
 
 
-def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None):
-    """gw [G*Cog, Cig, K] for y = conv(prologue(x) * in_scale, w); `pro` as in conv()."""
+def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None):
+    """gw [G*Cog, Cig, K] for y = conv(prologue(x) * in_scale, w); `pro` as in conv().  `wino`: force / forbid the
+    Winograd F(3,2) form (default: wherever it applies, see WINOGRAD)."""
     L = _lib.load()
     B, T, G, Cig, Cog = xv.B, gyv.T, xv.G, xv.Cg, gyv.Cg
     gw = torch.empty(G * Cog, Cig, K, device=xv.t.device, dtype=torch.float32)
@@ -251,7 +252,14 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None):
     ws = workspace(n, xv.t.device)
     sc, sc_bs, sc_gs = (None, 0, 0) if in_scale is None else (_p(in_scale[0]), in_scale[1], in_scale[2])
     ev = _timed(("conv_bwd_weight", K, G, Cig, Cog, B, T))
-    if pro is not None and pro[0]:
+    if wino is None:
+        wino = WINOGRAD and K in (3, 7) and T % 2 == 0 and T >= 64 and not (K == 7 and pro is not None and pro[0])
+    if wino:
+        pm, pa, pb, pbp = (pro[0], _p(pro[1]), _p(pro[2]), pro[3]) if (pro is not None and pro[0]) else (0, None, None, 1)
+        _lib.check(L.nef_conv_bwd_weight_wino(xv.ptr, xv.bs, xv.gs, sc, sc_bs, sc_gs, pa, pb, pm, pbp, gyv.ptr, gyv.bs,
+                                              gyv.gs, _p(gw), _p(ws), n, B, T, G, Cig, Cog, K, _stream()),
+                   "nef_conv_bwd_weight_wino")
+    elif pro is not None and pro[0]:
         assert in_scale is None
         _lib.check(L.nef_conv_bwd_weight_pro(xv.ptr, xv.bs, xv.gs, _p(pro[1]), _p(pro[2]), pro[0], pro[3], gyv.ptr, gyv.bs,
                                              gyv.gs, _p(gw), _p(ws), n, B, T, G, Cig, Cog, K, _stream()),

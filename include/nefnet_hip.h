@@ -113,6 +113,15 @@ int nef_conv_bwd_weight_pro(const float* x, int64_t x_bs, int64_t x_gs, const fl
                             int pro_mode, int pro_Bp, const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws,
                             size_t ws_bytes, int B, int T, int G, int Cin_g, int Cout_g, int K, nef_stream_t stream);
 
+/* The same weight gradient (either form above: in_scale or the input prologue) through the transposed Winograd
+ * algorithm F(3,2) -- 2/3 (K == 3) resp. 5/7 (K == 7, taps split 3 + 3 + 1) of the multiplies; fp32 multiplies and adds
+ * on the matrix cores, results differ from the direct form by the rounding of the transforms.  Needs T even and
+ * T >= 64; K == 7: pro_mode 0.  Workspace as for nef_conv_bwd_weight. */
+int nef_conv_bwd_weight_wino(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
+                             int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
+                             const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B, int T,
+                             int G, int Cin_g, int Cout_g, int K, nef_stream_t stream);
+
 /* out[c] = sum_{b,t} x[b][c][t] (bias gradients).  ws: nef_chan_sum_ws_bytes(C). */
 size_t nef_chan_sum_ws_bytes(int C);
 int nef_chan_sum(const float* x, float* out, void* ws, size_t ws_bytes, int B, int C, int T, nef_stream_t stream);

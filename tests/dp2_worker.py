@@ -76,18 +76,51 @@ del model, optim, outs, losses
 dist.barrier()
 
 # ---------------------------------------------------------------- part 2: Solver.run_one_epoch over sharded loaders
-V, B, L, seed, steps = 3, 4, 512, 5, 2
+V, B, L, seed = 3, 4, 512, 5
 cfg = make_cfg(V)
 sol = Solver(cfg, use_tensorboardx=False)
 assert sol.device == dev
 sol.model.load_state_dict({**hw.hashed_params(V), **hw.hashed_buffers()})
 sol.model.dropout_p = 0.0
-batches = [synth.make_batch(B, V, L, seed=seed + s, Q=2) for s in range(steps)]
+sol.model.keep_saved = True
+full = synth.make_batch(B, V, L, seed=seed, Q=2)
 optim = get_optimizer(cfg, sol.model.parameters())
 random.seed(seed)
-res = sol.run_one_epoch(parallel.ShardedLoader(batches), "train", optim)
-assert len(res[2]) == steps * B // world and res[2][0].shape == (L,)        # predicted views of this rank's shards
-np.savez(os.path.join(out_dir, f"solver_rank{rank}.npz"), params=flat_params(sol.model), losses=np.array(res[0]))
+res = sol.run_one_epoch(parallel.ShardedLoader([full]), "train", optim)      # ONE iteration of the packaged driver
+assert len(res[2]) == B // world and res[2][0].shape == (L,)                  # predicted views of this rank's shard
+names = [n for n, p in sol.model.named_parameters() if n not in ("w_feature_extractor.0.weight", "w_feature_extractor.0.bias")
+         and not n.startswith("w_conv.0.residual_conv") and not n.startswith("z2_conv2.0.residual_conv")]
+avg_grad = (optim._flat[0]["g"] / world).cpu().numpy()
+# this rank's shard against the decision-replaying oracle: gradient = what this rank contributed to the all-reduce.  The
+# step has been applied already, so the shard gradient is not in p.grad any more; the oracle's shard gradients are handed
+# to the parent, which checks their average against the all-reduced buffer (and with it the parameter update).
+sv = sol.model.last_saved
+out3 = sv["dec"][2]
+Bs = B // world
+outs = (out3[0:Bs], out3[Bs:2 * Bs], out3[2 * Bs:3 * Bs])
+shard = parallel.shard_batch(full, rank, world)
+bc = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in shard.items()}
+from decisions import assert_flips_are_ties, gpu_decisions                   # noqa: E402
+from oracle import nefnet_oracle as orc                                      # noqa: E402
+dec = orc.Decisions(gpu_decisions(sol.model, outs, bc["target_view"].unsqueeze(1)))
+P = orc.require_grad(hw.hashed_params(V))
+random.seed(seed)
+ref = orc.forward(P, hw.hashed_buffers(), bc["data"], bc["input_theta"], bc["target_theta"], bc["rois"], phase="train",
+                  training=True, p=0.0, dec=dec)
+rl = orc.loss_v1(ref[0], ref[1], ref[2], bc["target_view"].unsqueeze(1), dec=dec)
+rl[0].backward()
+assert_flips_are_ties(dec)
+live = [n for n, p in sol.model.named_parameters() if P[n].grad is not None]
+oracle_grad = torch.cat([P[n].grad.reshape(-1) for n in live]).numpy()
+params_1 = flat_params(sol.model)
+# two more iterations (momentum carried) for the trajectory-level checks
+more = [synth.make_batch(B, V, L, seed=seed + 1 + s, Q=2) for s in range(2)]
+sol.model.keep_saved = False
+sol.model.last_saved = None
+res2 = sol.run_one_epoch(parallel.ShardedLoader(more), "train", optim)
+np.savez(os.path.join(out_dir, f"solver_rank{rank}.npz"), params_1=params_1, params_3=flat_params(sol.model),
+         losses=np.array(res[0] + res2[0]), oracle_losses=np.array([float(v) for v in rl]), avg_grad=avg_grad,
+         oracle_grad=oracle_grad, live=np.array(live), flips=np.array(dec.total_flips()))
 dist.barrier()
 dist.destroy_process_group()
 print("DP2_OK", rank)

@@ -93,31 +93,34 @@ def test_world2_step_8_leads_vs_per_shard_bn_oracle(dp_run):
 
 
 def test_world2_solver_epoch_sharded_loader_vs_oracle(dp_run):
-    """Solver.run_one_epoch over parallel.ShardedLoader on two ranks == the oracle's DataParallel iteration, twice
-    (momentum carried): per-rank losses are the shard means, parameters agree across ranks and with the oracle."""
+    """The packaged driver's path -- Solver.run_one_epoch over parallel.ShardedLoader with FusedSGD -- on two ranks: one
+    iteration checked like the 8-lead step above (each rank's shard against the decision-replaying oracle inside the
+    worker; here the all-reduced buffer and the parameter update against the average of the two oracle shard gradients),
+    then two more iterations with momentum: parameters stay bit-identical across ranks, losses are those of the shards."""
     from oracle import hashweights as hw
-    from oracle import nefnet_oracle as orc
-    from electrocardio_panorama_amd import parallel, synth
     from electrocardio_panorama_amd.network import build_model
     from test_model_gpu import make_cfg
     a, b = (np.load(os.path.join(dp_run, f"solver_rank{r}.npz")) for r in range(2))
-    assert np.array_equal(a["params"], b["params"])
-    V, B, L, seed, steps = 3, 4, 512, 5, 2
-    P = orc.require_grad(hw.hashed_params(V))
-    P0 = {k: v.detach().clone() for k, v in P.items()}
-    Bfs, opt = [hw.hashed_buffers(), hw.hashed_buffers()], orc.SGDState(0.1)
-    random.seed(seed)
-    for s in range(steps):
-        full = synth.make_batch(B, V, L, seed=seed + s, Q=2)
-        shards = [{k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in parallel.shard_batch(full, r, 2).items()}
-                  for r in range(2)]
-        vals, _ = orc.dp_train_step(P, Bfs, opt, shards, p=0.0, loss_factor=(0.5, 0.5, 1.0))
-        for r, z in enumerate((a, b)):
-            assert np.abs(z["losses"][s] - np.array(vals[r])).max() < 2e-5, (s, r)
+    assert np.array_equal(a["params_1"], b["params_1"]) and np.array_equal(a["params_3"], b["params_3"])
+    assert np.array_equal(a["avg_grad"], b["avg_grad"]) and not np.array_equal(a["params_1"], a["params_3"])
+    for z in (a, b):
+        assert np.abs(z["losses"][0] - z["oracle_losses"]).max() < 2e-6
+        assert z["losses"].shape == (3, 4) and np.isfinite(z["losses"]).all()
+    assert not np.array_equal(a["losses"][0], b["losses"][0])                 # different shards, different losses
+    want = 0.5 * (a["oracle_grad"].astype(np.float64) + b["oracle_grad"].astype(np.float64))
+    assert rel(a["avg_grad"], want) < 1e-4, rel(a["avg_grad"], want)
+    V = 3
+    P0 = hw.hashed_params(V)
     order = [n for n, _ in build_model(make_cfg(V)).named_parameters()]
-    new = torch.cat([P[n].detach().reshape(-1) for n in order]).numpy()
+    live = [str(n) for n in a["live"]]
+    upd = {n: np.zeros(P0[n].numel(), np.float64) for n in order}
+    off = 0
+    for n in live:
+        k = P0[n].numel()
+        upd[n] = -0.1 * want[off:off + k]
+        off += k
     old = torch.cat([P0[n].reshape(-1) for n in order]).numpy()
-    assert rel(a["params"] - old, new - old) < 5e-4, rel(a["params"] - old, new - old)
+    assert rel(a["params_1"].astype(np.float64) - old, np.concatenate([upd[n] for n in order])) < 2e-4
 
 
 def test_bench_two_ranks_prints_one_json_line():

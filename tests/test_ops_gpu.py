@@ -725,3 +725,65 @@ def test_conv_winograd_prologue_modes(mode, Cig, Cog, T_out):
     assert wp.nef_wino
     y = o.conv(GV.dense(g(x), 1), wp, Cog, 3, bias=g(bias), pro=pro)
     assert y.shape == ref.shape and rel(y, ref) < FWD_TOL
+
+
+@pytest.mark.parametrize("K,G,Cig,Cog,T,B", [
+    (3, 3, 128, 128, 128, 2), (3, 3, 64, 128, 130, 2), (3, 1, 256, 128, 250, 3), (3, 1, 128, 64, 500, 2),
+    (3, 1, 64, 64, 260, 3), (3, 2, 128, 128, 1250, 2), (3, 1, 32, 128, 64, 3), (3, 1, 128, 256, 66, 2),
+    (7, 3, 128, 128, 128, 2), (7, 1, 128, 128, 300, 2), (7, 2, 128, 128, 1250, 2), (7, 1, 128, 64, 500, 2),
+    (7, 1, 64, 128, 70, 5),
+])
+def test_conv_bwd_weight_winograd(K, G, Cig, Cog, T, B):
+    """The weight gradient through the transposed Winograd form F(3,2) against autograd, next to the direct kernel, and
+    both against fp64."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    x = rnd(B, G * Cig, T, seed=31)
+    w = rnd(G * Cog, Cig, K, seed=32, scale=(Cig * K) ** -0.5)
+    gy = rnd(B, G * Cog, T, seed=33)
+    wr = w.clone().requires_grad_(True)
+    F.conv1d(x, wr, None, 1, K // 2, 1, G).backward(gy)
+    w64 = w.double().requires_grad_(True)
+    F.conv1d(x.double(), w64, None, 1, K // 2, 1, G).backward(gy.double())
+    xd, gyd = g(x), g(gy)
+    gw = o.conv_bwd_weight(GV.dense(xd, G), GV.dense(gyd, G), K, wino=True)
+    gd = o.conv_bwd_weight(GV.dense(xd, G), GV.dense(gyd, G), K, wino=False)
+    assert rel(gw, wr.grad) < GRAD_TOL and rel(gd, wr.grad) < GRAD_TOL
+    e_w, e_d, e_t = rel(gw, w64.grad), rel(gd, w64.grad), rel(wr.grad, w64.grad)
+    assert e_w < 4 * max(e_d, e_t) + 1e-7, (e_w, e_d, e_t)
+    assert torch.equal(gw, o.conv_bwd_weight(GV.dense(xd, G), GV.dense(gyd, G), K, wino=True))      # deterministic
+
+
+def test_conv_bwd_weight_winograd_views_scale_and_prologues():
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    B, V, T, K = 2, 3, 250, 3
+    enc, scale = rnd(B, 128 * V, T, seed=8), rnd(B, 128 * V, seed=14)
+    w = rnd(128 * V, 64, K, seed=9, scale=0.1)
+    gy = rnd(B, 128 * V, T, seed=15)
+    encd, scd, gyd = g(enc), g(scale), g(gy)
+    for which in (0, 1):        # strided half-views + in_scale (the z1 / z2 split)
+        xin = enc.view(B, V, 2, 64, T)[:, :, which].reshape(B, 64 * V, T)
+        sc = scale.view(B, V, 2, 64)[:, :, which].reshape(B, 64 * V)
+        wr = w.clone().requires_grad_(True)
+        F.conv1d(xin * sc[:, :, None], wr, None, 1, 1, 1, V).backward(gy)
+        gw = o.conv_bwd_weight(GV.half(encd, V, which), GV.dense(gyd, V), K,
+                               in_scale=(scd.view(-1)[which * 64:], 128 * V, 128), wino=True)
+        assert rel(gw, wr.grad) < GRAD_TOL
+    P, Bp = 3, 2
+    for mode in (1, 2, 3):      # decoder prologues
+        for Cig, Cog, T_out in ((256, 128, 250), (128, 64, 500), (64, 64, 260), (128, 128, 128)):
+            Tin = T_out // 2 if mode & 2 else T_out
+            x = rnd(P * Bp, Cig, Tin, seed=80)
+            a, b = rnd(P, Cig, seed=81) + 1.2, rnd(P, Cig, seed=82) * 0.5
+            xin = x
+            if mode & 1:
+                xin = F.relu(x * a.repeat_interleave(Bp, 0)[:, :, None] + b.repeat_interleave(Bp, 0)[:, :, None])
+            if mode & 2:
+                xin = F.interpolate(xin, scale_factor=2, mode="linear", align_corners=False)
+            wr = rnd(Cog, Cig, 3, seed=83, scale=(3 * Cig) ** -0.5).requires_grad_(True)
+            gy2 = rnd(P * Bp, Cog, T_out, seed=85)
+            F.conv1d(xin, wr, None, 1, 1).backward(gy2)
+            pro = (mode, g(a) if mode & 1 else None, g(b) if mode & 1 else None, Bp)
+            gw = o.conv_bwd_weight(GV.dense(g(x), 1), GV.dense(g(gy2), 1), 3, pro=pro, wino=True)
+            assert rel(gw, wr.grad) < GRAD_TOL, (mode, Cig, Cog, T_out)

@@ -28,12 +28,15 @@ for name, K, G, Cig, Cog, B, T in SHAPES:
     wp = ops.pack_weight(w, G)
     wpw = ops.pack_weight(w, G, T=T)
     flops = 2.0 * B * G * Cog * T * Cig * K
-    for what in ("fwd", "wino", "bwd_w"):
+    for what in ("fwd", "wino", "bwd_w", "bwd_ww"):
         if what == "wino" and not getattr(wpw, "nef_wino", False):
             continue
         fn = (lambda: ops.conv(GV.dense(x, G), wp, Cog, K, relu=True)) if what == "fwd" else \
              (lambda: ops.conv(GV.dense(x, G), wpw, Cog, K, relu=True)) if what == "wino" else \
-             (lambda: ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K))
+             (lambda: ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, wino=False)) if what == "bwd_w" else \
+             (lambda: ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, wino=True))
+        if what == "bwd_ww" and (K not in (3, 7) or T < 64 or T % 2):
+            continue
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
