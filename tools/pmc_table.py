@@ -1,7 +1,7 @@
-"""profiles/r01_pmc_traffic.md + profiles/traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of
+"""profiles/rNN_pmc_traffic.md + profiles/traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of
 `python bench.py --steps 1 --warmup 1 --no-cpu-baseline` (2 steps).
 
-    python tools/pmc_table.py <fetch.db> <write.db> <out.md> <traffic.json>
+    python tools/pmc_table.py <fetch.db> <write.db> <out.md> <traffic.json> [dominant-kernel-prefix]
 
 HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: on gfx950 FETCH_SIZE counts half of the bytes read (MI355X guide);
 re-checked in every run on `bn_stats_partial`, a pure streaming read whose traffic is known (numel x 4 bytes).
@@ -11,6 +11,7 @@ import sqlite3
 import sys
 
 fetch_db, write_db, out_md, out_json = sys.argv[1:5]
+DOM = sys.argv[5] if len(sys.argv) > 5 else "conv_wino_kernel<7"
 
 
 def short(name):
@@ -33,7 +34,7 @@ for (n, g, f), (_, _, w) in zip(F, W):
 cal = [f for (n, g, f) in F if n == "bn_stats_partial"]
 cal_ratio = (sum(cal) / len(cal)) * 1024 / 983040000.0 if cal else float("nan")
 # dominant kernel, forward launches only: the first 6 launches of each step are the encoder's forward convs
-k7 = [(f, w) for (n, g, f), (_, _, w) in zip(F, W) if n.startswith("conv_fwd_kernel<7")]
+k7 = [(f, w) for (n, g, f), (_, _, w) in zip(F, W) if n.startswith(DOM)]
 per_step = len(k7) // 2
 fwd = k7[0:6] + k7[per_step:per_step + 6]
 fwd_bytes = sum((2 * f + w) * 1024 for f, w in fwd) / len(fwd)
@@ -45,7 +46,7 @@ with open(out_md, "w") as fh:
              "half of the bytes read (MI355X guide).  Calibration in this run: `bn_stats_partial` streams 983,040,000 bytes\n"
              f"per launch and FETCH_SIZE x 1024 reads {cal_ratio:.3f} of that.  Fabric-side counters: hits in the memory-side\n"
              "cache (MALL) are counted like HBM reads, so these are upper bounds on DRAM traffic.\n\n")
-    fh.write(f"Dominant kernel `conv_fwd_kernel<7,2,0>`: forward launches (6 per step: 3 read x, 3 read x + residual; "
+    fh.write(f"Dominant kernel `{DOM}...>`: forward launches (6 per step: 3 read x, 3 read x + residual; "
              f"algorithmic 0.984 / 1.476 GB) move {fwd_bytes/1e9:.3f} GB per launch on average; all 12 launches per step "
              f"(forward + backward-data, which also read a gate or residual operand) {all_bytes/1e9:.3f} GB.\n\n")
     fh.write("| kernel | launches | FETCH_SIZE avg (min..max) KB | WRITE_SIZE avg (min..max) KB | corrected bytes/launch (GB) |\n"
@@ -58,7 +59,8 @@ with open(out_md, "w") as fh:
                  f"{sum(ws)/len(ws):.0f} ({min(ws):.0f}..{max(ws):.0f}) | {gb:.3f} |\n")
 json.dump({"conv_fwd_k7_bytes_per_launch": int(fwd_bytes), "conv_fwd_k7_bytes_per_launch_all": int(all_bytes),
            "algorithmic_bytes_per_forward_launch": int((3 * 984416256 + 3 * 1475936256) / 6),
-           "note": "round 1: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, mean over the forward launches of conv_fwd_kernel<7,2,0> "
-                   "(the launches bench.py times for roofline.achieved); see profiles/r01_pmc_traffic.md"},
+           "source": out_md + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+           "note": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024, mean over the forward launches of the dominant k7 conv kernel "
+                   "(the launches bench.py times for roofline.achieved)"},
           open(out_json, "w"), indent=1)
 print(open(out_md).read()[:1800])
