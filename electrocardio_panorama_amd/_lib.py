@@ -37,6 +37,8 @@ class ConvArgs(C.Structure):
 SIGNATURES = {
     "nef_abi_version": (i32, []),
     "nef_stem_fwd": (i32, [p, p, p, i32, i32, i32, p]),
+    "nef_stem_fwd_code": (i32, [p, p, p, p, i32, i32, i32, p]),
+    "nef_stem_bwd_weight_code": (i32, [p, p, p, p, p, sz, i32, i32, i32, p]),
     "nef_stem_bwd_ws_bytes": (sz, [i32]),
     "nef_stem_bwd_weight": (i32, [p, p, p, p, p, sz, i32, i32, i32, p]),
     "nef_pack_weight": (i32, [p, p, i32, i32, i32, i32, i32, p]),
@@ -77,6 +79,8 @@ SIGNATURES = {
     "nef_mix_bwd_shared_up": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, i32, p]),
     "nef_pass_combine_fwd": (i32, [p, p, p, i32, i32, i32, p]),
     "nef_pass_combine_bwd": (i32, [p, p, i32, i32, i32, p]),
+    "nef_pass_combine_stats_ws_bytes": (sz, [i32, i32]),
+    "nef_pass_combine_fwd_stats": (i32, [p, p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, f32, f32, p]),
     "nef_mix_bwd_up": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, i32, p]),
     "nef_upsample2_fwd": (i32, [p, p, i64, i32, p]),
     "nef_upsample2_bwd": (i32, [p, p, i64, i32, p]),

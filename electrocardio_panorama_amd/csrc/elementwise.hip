@@ -418,7 +418,7 @@ __global__ void bn_stats_final(const double* __restrict__ part, const float* __r
                                const float* __restrict__ beta, float* __restrict__ running_mean,
                                float* __restrict__ running_var, float* __restrict__ mean, float* __restrict__ invstd,
                                float* __restrict__ a, float* __restrict__ b, int P, int Bp, int C, int L, float eps,
-                               float momentum) {
+                               float momentum, int nsplit) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const double n = (double)Bp * (double)L;
@@ -426,9 +426,9 @@ __global__ void bn_stats_final(const double* __restrict__ part, const float* __r
     float rv = running_var ? running_var[c] : 1.f;
     for (int p = 0; p < P; ++p) {
         double s1 = 0.0, s2 = 0.0;
-        for (int sp = 0; sp < BN_SPLIT; ++sp) {
-            s1 += part[((int64_t)(p * C + c) * BN_SPLIT + sp) * 2];
-            s2 += part[((int64_t)(p * C + c) * BN_SPLIT + sp) * 2 + 1];
+        for (int sp = 0; sp < nsplit; ++sp) {       // fixed order: deterministic
+            s1 += part[((int64_t)(p * C + c) * nsplit + sp) * 2];
+            s2 += part[((int64_t)(p * C + c) * nsplit + sp) * 2 + 1];
         }
         const double m = s1 / n;
         double var = s2 / n - m * m;
@@ -1114,6 +1114,62 @@ __global__ __launch_bounds__(256) void pass_combine_fwd_kernel(const float* __re
     }
 }
 
+// The same pass, also leaving the BatchNorm statistics of its output (decoder.1.double_conv.1, batch statistics per
+// Standin pass): per (sample, channel) row the three passes' sum and sum of squares in fp64,
+// part[((p*C + c)*B + b)*2 + {0,1}]; bn_stats_final adds them over b in a fixed order.  Saves the separate
+// statistics pass over c1.
+__global__ __launch_bounds__(256) void pass_combine_fwd_stats_kernel(const float* __restrict__ P2,
+                                                                     const float* __restrict__ bias,
+                                                                     float* __restrict__ c1, double* __restrict__ part,
+                                                                     int B, int C, int L) {
+    __shared__ double sm[4];
+    const int64_t row = blockIdx.x;                 // (b, c)
+    const int b = (int)(row / C), c = (int)(row % C);
+    const float bv = bias[c];
+    const float* am = P2 + ((int64_t)b * 2 * C + c) * L;
+    const float* bm = P2 + ((int64_t)b * 2 * C + C + c) * L;
+    const float* ap = P2 + ((int64_t)(B + b) * 2 * C + c) * L;
+    const float* bp = P2 + ((int64_t)(B + b) * 2 * C + C + c) * L;
+    float* o0 = c1 + ((int64_t)b * C + c) * L;
+    float* o1 = c1 + ((int64_t)(B + b) * C + c) * L;
+    float* o2 = c1 + ((int64_t)(2 * B + b) * C + c) * L;
+    double s[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+    for (int t = threadIdx.x; t < L; t += 256) {
+        const float a0 = am[t], b0 = bm[t], a1 = ap[t], b1 = bp[t];
+        const float v0 = a0 + b0 + bv, v1 = a1 + b0 + bv, v2 = a0 + b1 + bv;
+        o0[t] = v0;
+        o1[t] = v1;
+        o2[t] = v2;
+        s[0][0] += (double)v0; s[0][1] += (double)v0 * (double)v0;
+        s[1][0] += (double)v1; s[1][1] += (double)v1 * (double)v1;
+        s[2][0] += (double)v2; s[2][1] += (double)v2 * (double)v2;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const double r = nef_block_sum_d(s[p][q], sm);
+            if (threadIdx.x == 0) part[(((int64_t)p * C + c) * B + b) * 2 + q] = r;
+        }
+}
+
+// tot[pc][q] = sum_b rows[pc][b][q], one block per (pass, channel), fixed tree order (deterministic)
+__global__ __launch_bounds__(256) void bn_rows_reduce(const double* __restrict__ rows, double* __restrict__ tot, int B) {
+    __shared__ double sm[4];
+    const int64_t pc = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        s1 += rows[(pc * B + b) * 2];
+        s2 += rows[(pc * B + b) * 2 + 1];
+    }
+    s1 = nef_block_sum_d(s1, sm);
+    s2 = nef_block_sum_d(s2, sm);
+    if (threadIdx.x == 0) {
+        tot[pc * 2] = s1;
+        tot[pc * 2 + 1] = s2;
+    }
+}
+
 // adjoint: gP2 A-half[mean] = g0 + g2, A-half[pick] = g1, B-half[mean] = g0 + g1, B-half[pick] = g2
 __global__ __launch_bounds__(256) void pass_combine_bwd_kernel(const float* __restrict__ gc1, float* __restrict__ gP2,
                                                                int B, int C, int L) {
@@ -1311,7 +1367,27 @@ int nef_bn_train_stats(const float* x, const float* gamma, const float* beta, fl
     NEF_REQUIRE(ws_bytes >= nef_bn_ws_bytes(P, C), NEF_E_WORKSPACE);
     hipLaunchKernelGGL(bn_stats_partial, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, x, (double*)ws, P, Bp, C, L);
     hipLaunchKernelGGL(bn_stats_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)ws, gamma, beta,
-                       running_mean, running_var, mean, invstd, a, b, P, Bp, C, L, eps, momentum);
+                       running_mean, running_var, mean, invstd, a, b, P, Bp, C, L, eps, momentum, BN_SPLIT);
+    return nef_launch_status();
+}
+
+size_t nef_pass_combine_stats_ws_bytes(int B, int C) { return (size_t)3 * C * (B + 1) * 2 * sizeof(double); }
+
+int nef_pass_combine_fwd_stats(const float* P2, const float* bias, float* c1, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float* mean, float* invstd, float* a, float* b,
+                               void* ws, size_t ws_bytes, int B, int C, int L, float eps, float momentum,
+                               nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(P2 && bias && c1 && gamma && beta && mean && invstd && a && b && ws, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && C > 0 && L > 0 && (int64_t)B * C <= 0x7FFFFFFF && (int64_t)B * L > 1, NEF_E_SHAPE);
+    NEF_REQUIRE(ws_bytes >= nef_pass_combine_stats_ws_bytes(B, C), NEF_E_WORKSPACE);
+    double* rows = (double*)ws;                      // [3*C][B][2]
+    double* tot = rows + (size_t)3 * C * B * 2;      // [3*C][2]
+    hipLaunchKernelGGL(pass_combine_fwd_stats_kernel, dim3((unsigned)(B * C)), dim3(256), 0, NEF_ST, P2, bias, c1, rows, B,
+                       C, L);
+    hipLaunchKernelGGL(bn_rows_reduce, dim3((unsigned)(3 * C)), dim3(256), 0, NEF_ST, (const double*)rows, tot, B);
+    hipLaunchKernelGGL(bn_stats_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)tot, gamma, beta,
+                       running_mean, running_var, mean, invstd, a, b, 3, B, C, L, eps, momentum, 1);
     return nef_launch_status();
 }
 

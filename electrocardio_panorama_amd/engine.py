@@ -177,12 +177,21 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
             pro = (mode, pro_in[0], pro_in[1], pro_in[2]) if pro_in is not None else (mode, None, None, 1)
             up_after = bool(mode & 2)
         T_out = x_in.shape[2] * (2 if up_after and pro[0] & 2 else 1)
+        stats = None
         if li == 0 and shared_B is not None:
             p2 = ops.conv(GV.dense(x_in, 2), ops.pack_weight(_regroup_halves(P[wname]), 2, T=T_out), cout, 3, pro=pro)
-            c = ops.pass_combine_fwd(p2, P[bname], shared_B)
+            if training and passes == 3:      # the BatchNorm statistics of c1 come out of the same pass
+                c, *stats = ops.pass_combine_fwd_stats(p2, P[bname], shared_B, P[pre + ".weight"], P[pre + ".bias"],
+                                                       Bf[pre + ".running_mean"], Bf[pre + ".running_var"], BN_EPS, BN_MOM)
+            else:
+                c = ops.pass_combine_fwd(p2, P[bname], shared_B)
         else:
             c = ops.conv(GV.dense(x_in, 1), ops.pack_weight(P[wname], 1, T=T_out), cout, 3, bias=P[bname], pro=pro)
-        if training:
+        if stats is not None:
+            mean, invstd, a, b = stats
+            Bf[pre + ".num_batches_tracked"] += passes
+            Bp = N // passes
+        elif training:
             mean, invstd, a, b = ops.bn_train_stats(c, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
                                                     Bf[pre + ".running_var"], passes, BN_EPS, BN_MOM)
             Bf[pre + ".num_batches_tracked"] += passes
@@ -251,7 +260,10 @@ def _latents(P, x, in_theta, rois, drop, save):
     B, V, L = x.shape
     T = L // 4
     sv = {}
-    a = ops.stem_fwd(x, P["W_encoder.conv1.weight"])
+    if save:
+        a, sv["stem_code"] = ops.stem_fwd(x, P["W_encoder.conv1.weight"], with_code=True)
+    else:
+        a = ops.stem_fwd(x, P["W_encoder.conv1.weight"])
     sv["blk_enc"] = []
     for i in range(3):
         a, s = block_fwd(GV.dense(a, V), P, f"W_encoder.layer1.{i}", 7, 128, drop)
@@ -506,7 +518,7 @@ def _latents_bwd(P, sv, gz1, gz2r, grads, side, z1_pre_gated=False):
     grads["mlp1.weight"], grads["mlp1.bias"] = gW1, gb1
     for i in (2, 1, 0):
         g = block_bwd(sv["blk_enc"][i], g, P, grads, side=side, pre_gated=True, gate_input=(i > 0))
-    grads["W_encoder.conv1.weight"] = ops.stem_bwd_weight(sv["x"], P["W_encoder.conv1.weight"], g)
+    grads["W_encoder.conv1.weight"] = ops.stem_bwd_weight(sv["x"], P["W_encoder.conv1.weight"], g, code=sv["stem_code"])
 
 
 def backward(P, sv, g_outs):

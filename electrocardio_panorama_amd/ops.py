@@ -148,26 +148,33 @@ class GV:
 
 
 # ------------------------------------------------------------------ stem
-def stem_fwd(x, w):
+def stem_fwd(x, w, with_code=False):
+    """`with_code`: also return the uint8 decision tensor (pool arg-max + ReLU gate) the backward can use."""
     L = _lib.load()
     _chk(x), _chk(w)
     B, V, Ln = x.shape
     y = torch.empty(B, 128 * V, Ln // 4, device=x.device, dtype=torch.float32)
-    ev = _hbm("stem_fwd", x, y)
-    _lib.check(L.nef_stem_fwd(_p(x), _p(w), _p(y), B, V, Ln, _stream()), "nef_stem_fwd")
+    code = torch.empty(B, 128 * V, Ln // 4, device=x.device, dtype=torch.uint8) if with_code else None
+    ev = _hbm("stem_fwd", x, y, code)
+    _lib.check(L.nef_stem_fwd_code(_p(x), _p(w), _p(y), _p(code), B, V, Ln, _stream()), "nef_stem_fwd")
     _done(ev)
-    return y
+    return (y, code) if with_code else y
 
 
-def stem_bwd_weight(x, w, gy):
+def stem_bwd_weight(x, w, gy, code=None):
     L = _lib.load()
     _chk(x), _chk(w), _chk(gy)
     B, V, Ln = x.shape
     gw = torch.empty_like(w)
     n = L.nef_stem_bwd_ws_bytes(V)
     ws = workspace(n, x.device)
-    ev = _hbm("stem_bwd_weight", x, gy)
-    _lib.check(L.nef_stem_bwd_weight(_p(x), _p(w), _p(gy), _p(gw), _p(ws), n, B, V, Ln, _stream()), "nef_stem_bwd_weight")
+    ev = _hbm("stem_bwd_weight", x, gy, code)
+    if code is not None:
+        _chk(code, torch.uint8)
+        _lib.check(L.nef_stem_bwd_weight_code(_p(x), _p(code), _p(gy), _p(gw), _p(ws), n, B, V, Ln, _stream()),
+                   "nef_stem_bwd_weight_code")
+    else:
+        _lib.check(L.nef_stem_bwd_weight(_p(x), _p(w), _p(gy), _p(gw), _p(ws), n, B, V, Ln, _stream()), "nef_stem_bwd_weight")
     _done(ev)
     return gw
 
@@ -589,6 +596,24 @@ def pass_combine_fwd(P2, bias, B):
     _lib.check(L.nef_pass_combine_fwd(_p(P2), _p(bias), _p(c1), B, C2 // 2, Ln, _stream()), "nef_pass_combine_fwd")
     _done(ev)
     return c1
+
+
+def pass_combine_fwd_stats(P2, bias, B, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
+    """pass_combine_fwd + the train-mode BatchNorm statistics of its output: returns (c1, mean, invstd, a, b)."""
+    L = _lib.load()
+    _chk(P2), _chk(bias)
+    C2, Ln = P2.shape[1], P2.shape[2]
+    Ct = C2 // 2
+    c1 = torch.empty(3 * B, Ct, Ln, device=P2.device, dtype=torch.float32)
+    mean, invstd, a, b = (torch.empty(3, Ct, device=P2.device, dtype=torch.float32) for _ in range(4))
+    n = L.nef_pass_combine_stats_ws_bytes(B, Ct)
+    ws = workspace(n, P2.device)
+    ev = _hbm("pass_combine_fwd", P2, c1)
+    _lib.check(L.nef_pass_combine_fwd_stats(_p(P2), _p(bias), _p(c1), _p(gamma), _p(beta), _p(running_mean),
+                                            _p(running_var), _p(mean), _p(invstd), _p(a), _p(b), _p(ws), n, B, Ct, Ln, eps,
+                                            momentum, _stream()), "nef_pass_combine_fwd_stats")
+    _done(ev)
+    return c1, mean, invstd, a, b
 
 
 def pass_combine_bwd(gc1):

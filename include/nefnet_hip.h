@@ -42,6 +42,12 @@ int nef_abi_version(void);   /* 8 */
  * bwd_weight recomputes the conv, routes gy through the pool arg-max and the ReLU.
  *   ws: nef_stem_bwd_ws_bytes(V) bytes of scratch. */
 int nef_stem_fwd(const float* x, const float* w, float* y, int B, int V, int L, nef_stream_t stream);
+/* Same, also leaving one decision byte per output for the backward: code [B][128V][L/4], 0..2 = which conv position of
+ * the pool window won (first maximum in scan order), 3 = gradient gated off by the ReLU.  nef_stem_bwd_weight_code
+ * uses it instead of recomputing the conv (x, gy, gw, ws as nef_stem_bwd_weight; results are bit-identical). */
+int nef_stem_fwd_code(const float* x, const float* w, float* y, uint8_t* code, int B, int V, int L, nef_stream_t stream);
+int nef_stem_bwd_weight_code(const float* x, const uint8_t* code, const float* gy, float* gw, void* ws, size_t ws_bytes,
+                             int B, int V, int L, nef_stream_t stream);
 size_t nef_stem_bwd_ws_bytes(int V);
 int nef_stem_bwd_weight(const float* x, const float* w, const float* gy, float* gw, void* ws, size_t ws_bytes,
                         int B, int V, int L, nef_stream_t stream);
@@ -224,6 +230,14 @@ int nef_mix_bwd_shared_up(const float* gU2, const float* latent, const float* z1
                           float* gz1, float* gz2r, float* gq, int B, int V, int T, int c1, int c2,
                           const int32_t* choice_dev, int relu_z1, nef_stream_t stream);
 int nef_pass_combine_fwd(const float* P2, const float* bias, float* c1, int B, int C, int L, nef_stream_t stream);
+/* nef_pass_combine_fwd that also leaves the train-mode BatchNorm statistics of its output (3 passes of B samples; same
+ * outputs as nef_bn_train_stats(c1, ..., P = 3, Bp = B, ...), running statistics updated pass by pass): saves the separate
+ * statistics pass over c1.  ws: nef_pass_combine_stats_ws_bytes(B, C). */
+size_t nef_pass_combine_stats_ws_bytes(int B, int C);
+int nef_pass_combine_fwd_stats(const float* P2, const float* bias, float* c1, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float* mean, float* invstd, float* a, float* b,
+                               void* ws, size_t ws_bytes, int B, int C, int L, float eps, float momentum,
+                               nef_stream_t stream);
 int nef_pass_combine_bwd(const float* gc1, float* gP2, int B, int C, int L, nef_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -33,6 +33,9 @@ def test_stem(B, V, L):
     ref.backward(gy)
     gw = o.stem_bwd_weight(g(x), g(w), g(gy))
     assert rel(gw, wr.grad) < GRAD_TOL
+    y2, code = o.stem_fwd(g(x), g(w), with_code=True)       # decision bytes: same output, bit-identical gradient
+    assert torch.equal(y2, y) and code.dtype == torch.uint8 and int(code.max()) <= 3
+    assert torch.equal(o.stem_bwd_weight(g(x), g(w), g(gy), code=code), gw)
 
 
 def test_pack_weight():
@@ -480,6 +483,20 @@ def test_shared_first_conv_pieces():
     g0, g1, g2 = gc1[:B], gc1[B:2 * B], gc1[2 * B:]
     assert torch.equal(gP2[:B, :C], g0 + g2) and torch.equal(gP2[B:, :C], g1)
     assert torch.equal(gP2[:B, C:], g0 + g1) and torch.equal(gP2[B:, C:], g2)
+    # the fused form: same c1 and the BatchNorm statistics nef_bn_train_stats would compute from it
+    for Bq, Cq, Lq in ((3, 8, 37), (5, 16, 300)):
+        P2 = rnd(2 * Bq, 2 * Cq, Lq, seed=168)
+        bias, gamma, beta = rnd(Cq, seed=166), rnd(Cq, seed=169) + 1.2, rnd(Cq, seed=170) * 0.3
+        rm0, rv0 = rnd(Cq, seed=171) * 0.1, rnd(Cq, seed=172).abs() + 0.5
+        c_ref = o.pass_combine_fwd(g(P2), g(bias), Bq)
+        rm1, rv1 = g(rm0), g(rv0)
+        want = o.bn_train_stats(c_ref, g(gamma), g(beta), rm1, rv1, 3)
+        rm2, rv2 = g(rm0), g(rv0)
+        c_f, *got = o.pass_combine_fwd_stats(g(P2), g(bias), Bq, g(gamma), g(beta), rm2, rv2)
+        assert torch.equal(c_f, c_ref)
+        for a_, b_ in zip(got, want):
+            assert rel(a_, b_) < 1e-6
+        assert rel(rm2, rm1) < 1e-6 and rel(rv2, rv1) < 1e-6
 
 
 def test_bn_relu_bwd_combine3_equals_two_calls():
