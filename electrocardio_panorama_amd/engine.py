@@ -17,6 +17,10 @@ N_SEG, ROI_BINS = 7, 16
 DROP_P = 0.2           # every nn.Dropout on the path (model_nefnet.py:46, encoder/resnet_1d.py:37)
 BN_EPS, BN_MOM = 1e-5, 0.1
 
+# NEF_FUSE_L2=1: third decoder conv with the (affine + ReLU, x2) prologue instead of a materialised u2.  Measured again in
+# round 2 with the Winograd kernels: 60.2 ms/step against 58.8 ms/step with the materialised tensor -- stays off.
+_FUSE_L2 = os.environ.get("NEF_FUSE_L2", "0") == "1"
+
 DROPOUT_SITES = ("W_encoder.layer1.0", "W_encoder.layer1.1", "W_encoder.layer1.2", "w_conv.0", "z1_conv.0",
                  "z2_conv1.0", "z2_conv2.0", "z2_conv2.2")
 
@@ -165,7 +169,7 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
     N = D.shape[0] if shared_B is None else 3 * shared_B
     for li, (blk, cv, bn, cout) in enumerate(_DEC):
         wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
-        if li == 2:
+        if li == 2 and not _FUSE_L2:
             # measured: at 128->64 channels the staged (affine+ReLU, x2) prologue costs the two conv kernels more than
             # one fused elementwise pass, so this layer materialises u2 = up(relu(bn(c2))) and runs the plain conv
             x_in = ops.upsample2_aff_fwd(x, pro_in[0], pro_in[1], pro_in[2])
@@ -173,7 +177,7 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
             up_after = True
         else:
             x_in = x
-            mode = (2 if li == 0 else 0) | (1 if pro_in is not None else 0)
+            mode = (2 if li in (0, 2) else 0) | (1 if pro_in is not None else 0)
             pro = (mode, pro_in[0], pro_in[1], pro_in[2]) if pro_in is not None else (mode, None, None, 1)
             up_after = bool(mode & 2)
         T_out = x_in.shape[2] * (2 if up_after and pro[0] & 2 else 1)
