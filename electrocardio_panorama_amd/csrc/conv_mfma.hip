@@ -348,13 +348,8 @@ static int launch_conv_fwd(const nef_conv_args& a, hipStream_t st) {
     constexpr int MT = 64 * TM;
     constexpr int XRS = NT + (NT / 16) * (K - 1);
     constexpr size_t lds = (size_t)(K * KC * MT + KC * XRS) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<K, TM, PRO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long lds_set = 0;      // per-device bits, see nef_ensure_dyn_lds
+    if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_fwd_kernel<K, TM, PRO>), lds, &lds_set)) return e;
     const ColTiling ct = make_tiling(a.B, a.T, NT);
     const int m_tiles = a.Cout_g / MT;
     const int64_t blocks = (int64_t)a.G * m_tiles * ct.n_tiles;
@@ -684,13 +679,8 @@ static int launch_conv_wino(const nef_conv_args& a, hipStream_t st) {
     constexpr int MT = 64 * WM;
     constexpr int NTO = 64 * (4 / WM);
     constexpr size_t lds = (size_t)(2 * WKC * (NTO + 16)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<K, WM, PRO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long lds_set = 0;      // per-device bits, see nef_ensure_dyn_lds
+    if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_wino_kernel<K, WM, PRO>), lds, &lds_set)) return e;
     const int tps = (a.T + NTO - 1) / NTO;
     const int n_tiles = a.B * tps;
     const int m_tiles = a.Cout_g / MT;
@@ -1119,13 +1109,8 @@ static int launch_bwd_weight(const BwdWeightPlan& p, const float* x, int64_t x_b
     constexpr int GYS = WINO ? 66 : WT + 1;
     constexpr int XS = WINO ? (K == 3 ? 66 : 98) : ((WT + (WT / 16) * (K - 1)) | 1);
     constexpr size_t lds = (size_t)(MT * GYS + CIT * XS) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bwd_weight_kernel<K, WCO, TCI, PRO, WINO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long lds_set = 0;      // per-device bits, see nef_ensure_dyn_lds
+    if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_bwd_weight_kernel<K, WCO, TCI, PRO, WINO>), lds, &lds_set)) return e;
     const int64_t blocks = (int64_t)p.S * G * p.m_tiles * p.ci_chunks;
     hipLaunchKernelGGL((conv_bwd_weight_kernel<K, WCO, TCI, PRO, WINO>), dim3((unsigned)blocks), dim3(256), lds, st, x, x_bs,
                        x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, ws, B, T, G, Cig, Cog, p.ct.seg_shift, p.ct.nseg,
@@ -1213,8 +1198,6 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
     const int K = a->K;
     NEF_REQUIRE(K == 1 || K == 3 || K == 7, NEF_E_SHAPE);
     NEF_REQUIRE(a->Cout_g % 64 == 0 && a->Cin_g > 0, NEF_E_SHAPE);
-    const int KC = K == 7 ? 16 : (K == 3 ? 32 : 64);
-    NEF_REQUIRE(a->Cin_g % KC == 0, NEF_E_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     bool big = (a->Cout_g % 128 == 0);
     if (big) {
@@ -1223,6 +1206,11 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
         const ColTiling ct0 = make_tiling(a->B, a->T, NT);
         if ((int64_t)a->G * (a->Cout_g / 128) * ct0.n_tiles < 384) big = false;
     }
+    // input channels are staged in chunks: FwdStage<K, TM>::KC (8 for the 128-row K = 7 / K = 3 kernels, 16 for their
+    // 64-row variants, 64 for K = 1) -- that, not more, is what Cin_g must be a multiple of
+    const int KC = K == 1 ? FwdStage<1, 1>::KC : (big ? FwdStage<3, 2>::KC : FwdStage<3, 1>::KC);
+    static_assert(FwdStage<7, 2>::KC == FwdStage<3, 2>::KC && FwdStage<7, 1>::KC == FwdStage<3, 1>::KC, "stage sizes");
+    NEF_REQUIRE(a->Cin_g % KC == 0, NEF_E_SHAPE);
     if (a->wino) {       // weights packed by nef_pack_weight_wino: Winograd F(2,3) path, whole tiles of one sample only
         NEF_REQUIRE((K == 3 || K == 7) && a->T % 2 == 0 && a->Cin_g % WKC == 0, NEF_E_SHAPE);
         NEF_REQUIRE(a->pro_mode >= 0 && a->pro_mode <= 3 && !(a->pro_mode && a->in_scale), NEF_E_UNSUPPORTED);

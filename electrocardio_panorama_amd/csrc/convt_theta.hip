@@ -255,13 +255,8 @@ int nef_convt2_fwd(const float* x, const float* w, const float* bias, float* y, 
     NEF_REQUIRE(B > 0 && G > 0 && T > 0 && T <= 32, NEF_E_SHAPE);
     NEF_REQUIRE(Cig == CT_CIG && Cog == CT_COG, NEF_E_UNSUPPORTED);
     const size_t lds = (size_t)(CT_CIG * CT_COG * 2 + CT_NB * CT_CIG * T) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2_fwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long lds_set = 0;      // per-device bits, see nef_ensure_dyn_lds
+    if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&convt2_fwd_kernel), 160 * 1024, &lds_set)) return e;
     const int nbg = (B + CT_NB - 1) / CT_NB;
     hipLaunchKernelGGL(convt2_fwd_kernel, dim3(nbg * G), dim3(256), lds, NEF_ST, x, w, bias, y, B, G, T);
     return nef_launch_status();
@@ -274,13 +269,8 @@ int nef_convt2_bwd_data(const float* gy, const float* w, float* gx, int B, int G
     NEF_REQUIRE(B > 0 && G > 0 && T > 0 && T <= 32, NEF_E_SHAPE);
     NEF_REQUIRE(Cig == CT_CIG && Cog == CT_COG, NEF_E_UNSUPPORTED);
     const size_t lds = (size_t)(CT_CIG * (CT_COG * 2 + 1) + CT_NB * CT_COG * 2 * T) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2_bwd_data_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long lds_set = 0;      // per-device bits, see nef_ensure_dyn_lds
+    if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&convt2_bwd_data_kernel), 160 * 1024, &lds_set)) return e;
     const int nbg = (B + CT_NB - 1) / CT_NB;
     hipLaunchKernelGGL(convt2_bwd_data_kernel, dim3(nbg * G), dim3(256), lds, NEF_ST, gy, w, gx, B, G, T);
     return nef_launch_status();

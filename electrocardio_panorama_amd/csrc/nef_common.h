@@ -23,6 +23,20 @@ static inline int nef_launch_status() {
 
 static inline int64_t nef_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Raise a kernel's dynamic-LDS limit once per DEVICE.  `done` is a per-kernel bit mask (bit = device ordinal); the call is
+// idempotent, so two host threads racing on the first launch both succeed -- the entry points stay re-entrant and the
+// library keeps no other state.
+static inline int nef_ensure_dyn_lds(const void* fn, size_t lds, unsigned long long* done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(done, __ATOMIC_ACQUIRE) & bit) return 0;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    __atomic_fetch_or(done, bit, __ATOMIC_RELEASE);
+    return 0;
+}
+
 // Grid for an HBM-bound elementwise pass: enough blocks to fill 256 CUs, grid-stride beyond.
 static inline int nef_stream_grid(int64_t work_items, int block) {
     int64_t g = nef_cdiv(work_items, block);

@@ -422,16 +422,20 @@ static int launch_hconv(const void* x, const void* wp, const float* bias, const 
     const int64_t total = (int64_t)N * tiles;
     if (total > 0x7FFFFFFF) return NEF_E_SHAPE;
     auto k = hconv_kernel<CIN, COUT, PRO, OUT, NI, MINB>;
-    static int resident = 0;                 // blocks that fit the device at once (persistent grid)
+    // blocks that fit the device at once (persistent grid): per device, idempotent -> thread-safe without a lock
+    static int resident_dev[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int resident = __atomic_load_n(&resident_dev[dev & 63], __ATOMIC_ACQUIRE);
     if (resident == 0) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
-        int dev = 0, cus = 0, per_cu = 0;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
+        int cus = 0, per_cu = 0;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
         if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, 256, LDS)) != hipSuccess)
             return (int)e;
         resident = cus * (per_cu > 0 ? per_cu : 1);
+        __atomic_store_n(&resident_dev[dev & 63], resident, __ATOMIC_RELEASE);
     }
     const int grid = (int)(total < resident ? total : resident);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), LDS, st, (const _Float16*)x, (const nef_h8*)wp, bias, scale,

@@ -47,7 +47,9 @@ def losswrapper(predict, predict_shuffle_p, predict_shuffle_l, target, cfg, rest
 
 
 class MSELead(torch.nn.Module):
-    """Reference losses.py:53-64 (unused by the Nef-Net path; kept for API completeness)."""
+    """Reference losses.py:53-64: the mean over leads of the per-lead MSE (unused by the Nef-Net path).  Every lead has
+    the same number of elements, so this is the MSE over the whole tensor -- one pass of the loss kernels."""
 
     def forward(self, input, target):
-        raise NotImplementedError("MSELead is dead code in the reference's Nef-Net path")
+        target = target.to(torch.float32).expand_as(input)
+        return _LossFn.apply(input, input, input, target, (0.0, 0.0, 1.0), True, 4)[3]

@@ -8,7 +8,8 @@
  *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates;
  *   - activations are fp32 `[batch][channel][time]`, time contiguous; ROIs are int64 `[B][7][2]`;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises,
- *     every entry point is re-entrant and hipGraph-capturable;
+ *     every entry point is re-entrant and hipGraph-capturable; the only thing the library remembers is, per kernel and
+ *     per device, that its dynamic-LDS limit has been raised (an idempotent, atomically published flag);
  *   - return 0 on success, a negative NEF_E_* for a rejected call, a positive value = hipError_t.
  */
 #ifndef NEFNET_HIP_H
