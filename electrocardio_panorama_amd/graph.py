@@ -6,6 +6,11 @@ backward + momentum-SGD once per input shape (torch.cuda.CUDAGraph on the stream
 it: inputs are copied into static buffers, and the only per-step host decisions -- the two Standin lead choices
 (reference model_nefnet.py:154,156, drawn from Python's `random` in the reference's order) and the dropout seed --
 travel through device words that the kernels read at run time.  Same arithmetic as the eager path.
+
+One graph (with its own static input buffers) is kept per input shape, so a final partial batch or alternating shapes
+replay instead of re-capturing; the flat parameter / gradient / momentum buffers are shared by all of them and survive
+every re-capture (shape change, learning-rate change).  `state_dict()` / `load_state_dict()` carry the momentum buffer
+for checkpoints.
 """
 import random
 
@@ -26,20 +31,31 @@ class GraphedTrainStep:
         self.reg_l2 = {"l1_loss": False, "l2_loss": True}[cfg.SOLVER.reg_loss]
         u = cfg.SOLVER.loss_using
         self.use_mask = (1 if 1 in u else 0) | (2 if 2 in u else 0) | (4 if 3 in u else 0)
-        self.graph = None
-        self.shape = None
+        self.slots = {}          # input shape -> static input buffers + captured graph
+        self.flat_p = self.flat_g = self.flat_buf = None
+        self.live = None
+        self.choice_dev = None
         self.calls = 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
     # -------------------------------------------------------------------------------------------------
     def _flatten(self, live):
+        """Parameters become views of one flat buffer.  Done once: the live-parameter set does not depend on the input
+        shape, so later captures reuse the buffers -- and with them the momentum."""
         named = dict(self.model.named_parameters())
+        if self.live == live and self.flat_p is not None and all(
+                named[k].data.data_ptr() >= self.flat_p.data_ptr() and
+                named[k].data.data_ptr() < self.flat_p.data_ptr() + 4 * self.flat_p.numel() for k in live):
+            return
+        old_buf, old_live = self.flat_buf, self.live
         self.live = live
         n = sum(named[k].numel() for k in live)
         dev = self.data.device
         self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)
         self.flat_g = torch.empty(n, device=dev, dtype=torch.float32)
         self.flat_buf = torch.zeros(n, device=dev, dtype=torch.float32)
+        if old_buf is not None and old_live == live:       # parameters were re-pointed from outside: keep the momentum
+            self.flat_buf.copy_(old_buf)
         off = 0
         for k in live:
             p = named[k]
@@ -69,16 +85,22 @@ class GraphedTrainStep:
         if self.world == 1:
             self._sgd()
 
+    def _use(self, slot):
+        self.data, self.in_theta, self.q_theta, self.rois, self.target = (slot[k] for k in
+                                                                          ("data", "in_theta", "q_theta", "rois", "target"))
+
     def _build(self, data, in_theta, q_theta, rois, target):
         dev = data.device
-        self.data, self.in_theta, self.q_theta = (torch.empty_like(t, dtype=torch.float32) for t in (data, in_theta, q_theta))
-        self.rois = torch.empty_like(rois, dtype=torch.int64)
-        self.target = torch.empty(data.shape[0], 1, data.shape[2], device=dev, dtype=torch.float32)
-        self.choice_dev = torch.zeros(2, device=dev, dtype=torch.int32)
-        self.seed_dev = torch.zeros(1, device=dev, dtype=torch.int64)
-        self.status = torch.zeros(1, device=dev, dtype=torch.int32)
-        self.losses = torch.zeros(4, device=dev, dtype=torch.float32)
-        self._host = torch.zeros(4, dtype=torch.int64).pin_memory()
+        slot = dict(data=torch.empty_like(data, dtype=torch.float32), in_theta=torch.empty_like(in_theta, dtype=torch.float32),
+                    q_theta=torch.empty_like(q_theta, dtype=torch.float32), rois=torch.empty_like(rois, dtype=torch.int64),
+                    target=torch.empty(data.shape[0], 1, data.shape[2], device=dev, dtype=torch.float32))
+        self._use(slot)
+        if self.choice_dev is None:
+            self.choice_dev = torch.zeros(2, device=dev, dtype=torch.int32)
+            self.seed_dev = torch.zeros(1, device=dev, dtype=torch.int64)
+            self.status = torch.zeros(1, device=dev, dtype=torch.int32)
+            self.losses = torch.zeros(4, device=dev, dtype=torch.float32)
+            self._host = torch.zeros(4, dtype=torch.int64).pin_memory()
         self._stage(data, in_theta, q_theta, rois, target, draw=False)      # probe: no `random` consumed
         self.model.train()
         # eager probe (no update): which parameters are live, and every kernel variant gets its one-time setup
@@ -88,17 +110,18 @@ class GraphedTrainStep:
         for k, v in self.model.named_buffers():
             v.copy_(saved[k])
         torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
+        graph = torch.cuda.CUDAGraph()
         saved = {k: v.clone() for k, v in self.model.named_buffers()}
         p0, b0 = self.flat_p.clone(), self.flat_buf.clone()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(graph):
             self._body()
         # capture does not execute, but keep state exactly as before the capture regardless
         for k, v in self.model.named_buffers():
             v.copy_(saved[k])
         self.flat_p.copy_(p0)
         self.flat_buf.copy_(b0)
-        self.shape = (tuple(data.shape), tuple(in_theta.shape))
+        slot["graph"] = graph
+        return slot
 
     def _stage(self, data, in_theta, q_theta, rois, target, draw=True):
         self.data.copy_(data, non_blocking=True)
@@ -118,22 +141,44 @@ class GraphedTrainStep:
 
     # -------------------------------------------------------------------------------------------------
     def set_lr(self, lr):
-        """A captured launch freezes its scalar arguments: a new learning rate re-captures the graph."""
+        """A captured launch freezes its scalar arguments: a new learning rate re-captures the graphs (parameters and
+        momentum live in the shared flat buffers and are untouched)."""
         if float(lr) != self.lr:
             self.lr = float(lr)
-            self.graph = None
+            self.slots.clear()
+
+    def state_dict(self):
+        """The optimiser state of the graphed path: the flat momentum buffer and the parameter order it refers to."""
+        return {"lr": self.lr, "momentum": self.mu, "live": list(self.live or []),
+                "momentum_buffer": None if self.flat_buf is None else self.flat_buf.detach().cpu().clone()}
+
+    def load_state_dict(self, sd):
+        self.set_lr(sd["lr"])
+        self.mu = float(sd["momentum"])
+        self._pending_momentum = (list(sd["live"]), sd["momentum_buffer"])
+        if self.flat_buf is not None:
+            self._restore_momentum()
+
+    def _restore_momentum(self):
+        pend = getattr(self, "_pending_momentum", None)
+        if pend is None or pend[1] is None:
+            return
+        live, buf = pend
+        if live != self.live or buf.numel() != self.flat_buf.numel():
+            raise ValueError("momentum buffer does not match this model's live parameters")
+        self.flat_buf.copy_(buf.to(self.flat_buf.device))
+        self._pending_momentum = None
 
     def __call__(self, data, in_theta, q_theta, rois, target):
         """One train step; returns the device tensor [loss, f0*l1, f1*l2, f2*l3] (valid in stream order)."""
         shape = (tuple(data.shape), tuple(in_theta.shape))
-        if self.graph is None or self.shape != shape:
-            had_state = self.graph is None and self.shape == shape      # lr change: keep parameters / momentum
-            keep = (self.flat_p, self.flat_buf) if had_state else None
-            self._build(data, in_theta, q_theta, rois, target)
-            if keep is not None:
-                self.flat_buf.copy_(keep[1])
+        slot = self.slots.get(shape)
+        if slot is None:
+            slot = self.slots[shape] = self._build(data, in_theta, q_theta, rois, target)
+            self._restore_momentum()
+        self._use(slot)
         self._stage(data, in_theta, q_theta, rois, target)
-        self.graph.replay()
+        slot["graph"].replay()
         if self.world > 1:
             dist.all_reduce(self.flat_g)
             self._sgd()

@@ -572,6 +572,61 @@ def test_graphed_step_matches_eager(golden_dir):
     assert torch.isfinite(l1).all() and torch.isfinite(l2).all() and not torch.equal(l1, l2)
 
 
+def test_graphed_step_keeps_momentum_across_shapes_and_checkpoints():
+    """Alternating input shapes (a final partial batch) replay their own captured graphs and share ONE momentum buffer:
+    the trajectory equals the eager FusedSGD path step for step; state_dict() / load_state_dict() carry the momentum."""
+    import copy
+    from electrocardio_panorama_amd import synth
+    from electrocardio_panorama_amd.graph import GraphedTrainStep
+    from electrocardio_panorama_amd.network import build_loss
+    from electrocardio_panorama_amd.solver.optim_scheduler import get_optimizer
+    V = 3
+    cfg = make_cfg(V, lr=0.05)
+    shapes = [(4, 512), (2, 512), (4, 512), (2, 512)]
+    batches = [{k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in synth.make_batch(B, V, L, seed=70 + i).items()}
+               for i, (B, L) in enumerate(shapes)]
+    mg, me = hashed_model(V).train(), hashed_model(V).train()
+    mg.dropout_p = me.dropout_p = 0.0
+    step = GraphedTrainStep(mg, cfg)
+    lossf, optim = build_loss(cfg), get_optimizer(cfg, me.parameters())
+    random.seed(3)
+    got = [step(b["data"], b["input_theta"], b["target_theta"], b["rois"], b["target_view"]).cpu().numpy().copy()
+           for b in batches[:3]]
+    assert len(step.slots) == 2
+    random.seed(3)
+    want = []
+    for b in batches[:3]:
+        o = me(b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train")
+        ls = lossf(o[0], o[1], o[2], b["target_view"].unsqueeze(1), cfg)
+        ls[0].backward()
+        optim.step()
+        optim.zero_grad()
+        want.append(torch.stack([x.detach() for x in ls]).cpu().numpy())
+    assert np.abs(np.array(got) - np.array(want)).max() < 1e-6, (got, want)
+    pg, pe = dict(mg.named_parameters()), dict(me.named_parameters())
+    assert max(rel(pg[k], pe[k]) for k in pg) < 1e-6
+    # checkpoint the graphed path after three steps, restore into a fresh stepper on a copy of the model, take step four
+    sd = step.state_dict()
+    assert sd["momentum_buffer"] is not None and float(sd["momentum_buffer"].abs().sum()) > 0
+    m2 = hashed_model(V).train()
+    m2.dropout_p = 0.0
+    m2.load_state_dict(copy.deepcopy(mg.state_dict()))
+    step2 = GraphedTrainStep(m2, cfg)
+    step2.load_state_dict(sd)
+    b = batches[3]
+    st = random.getstate()
+    l_a = step(b["data"], b["input_theta"], b["target_theta"], b["rois"], b["target_view"]).clone()
+    random.setstate(st)
+    l_b = step2(b["data"], b["input_theta"], b["target_theta"], b["rois"], b["target_view"]).clone()
+    assert torch.equal(l_a, l_b)
+    p2 = dict(m2.named_parameters())
+    assert max(rel(p2[k], pg[k]) for k in pg) < 1e-7
+    # a new learning rate re-captures but keeps the momentum
+    before = step.flat_buf.clone()
+    step.set_lr(0.01)
+    assert not step.slots and torch.equal(step.flat_buf, before)
+
+
 def test_adversarial_rois_full_step_vs_oracle():
     """Zero-length and 1-sample segments, boundaries at every residue mod 4, through a full train step (forward,
     losses, flat gradient) against the oracle; the integer segment table is bit-exact."""
