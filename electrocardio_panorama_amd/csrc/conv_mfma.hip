@@ -375,7 +375,10 @@ static int launch_conv_fwd(const nef_conv_args& a, hipStream_t st) {
 // the result differs from the direct form by the rounding of the three transforms (transform entries are 0, +-1,
 // 1/2: a few ulp, measured in tests/test_ops_gpu.py::test_conv_winograd).  Sequences shorter than a tile keep the
 // direct kernel.  NEF_WINOGRAD=0 in the environment disables this path (ops.py).
-constexpr int WKC = 16;   // channels per activation stage: 64 MFMAs per wave between barriers
+#ifndef NEF_WKC
+#define NEF_WKC 16
+#endif
+constexpr int WKC = NEF_WKC;   // channels per activation stage: 64 MFMAs per wave between barriers
 
 // Operand paths.  B (activations): raw tile through LDS, DOUBLE-buffered -- the registers holding stage s+1 (fetched
 // during the MFMA loop of stage s) are written to the other buffer right after that loop, so there is ONE barrier per
@@ -549,6 +552,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
             if (s_ + 1 < SPK) NEF_WX_LOAD(s_ + 1, (s_ + 1) & 1)
             const f32x2* d = fx[s_ & 1];
             const float (*w)[2] = fa[s_ % NSET];
+            // One s_setprio per k-step.  Measured -3..5 % on the K = 3 shapes and -1 % on K = 7 (tools/bench_conv.py); a
+            // single s_setprio(1) in front of the loop does nothing, so the gain is not the priority itself: the
+            // instruction is a scheduling fence for the compiler and keeps each step's operand fetches, transforms and
+            // MFMAs together instead of letting them drift across steps.
+            __builtin_amdgcn_s_setprio(1);
             float v[4];
             v[0] = d[0][0] - d[1][0];
             v[1] = d[0][1] + d[1][0];
@@ -871,6 +879,9 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
         }                                                                                                           \
     }
     if (split < n_tiles) NEF_BW_ISSUE(split)
+#ifdef NEF_BW_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
     for (int tile = split; tile < n_tiles; tile += S) {
         __syncthreads();
 #pragma unroll
@@ -1091,7 +1102,10 @@ static bool plan_bwd_weight(int B, int T, int G, int Cig, int Cog, int K, BwdWei
     p->ci_chunks = Cig / cit;
     p->ct = make_tiling(B, T, WT);
     const int base = G * p->m_tiles * p->ci_chunks;
-    int S = (768 + base - 1) / base;
+#ifndef NEF_BW_TARGET
+#define NEF_BW_TARGET 768
+#endif
+    int S = (NEF_BW_TARGET + base - 1) / base;
     if (S > p->ct.n_tiles) S = p->ct.n_tiles;
     if (S < 1) S = 1;
     p->S = S;
@@ -1099,7 +1113,7 @@ static bool plan_bwd_weight(int B, int T, int G, int Cig, int Cog, int K, BwdWei
 }
 
 template <int K, int WCO, int TCI, int PRO = 0, int WINO = 0>
-static int launch_bwd_weight(const BwdWeightPlan& p, const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale,
+static int launch_bwd_weight(BwdWeightPlan& p, const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale,
                              int64_t sc_bs, int64_t sc_gs, const float* gy, int64_t gy_bs, int64_t gy_gs, float* ws,
                              int B, int T, int G, int Cig, int Cog, hipStream_t st, const float* pro_a = nullptr,
                              const float* pro_b = nullptr, int pro_Bp = 1) {
@@ -1111,6 +1125,30 @@ static int launch_bwd_weight(const BwdWeightPlan& p, const float* x, int64_t x_b
     constexpr size_t lds = (size_t)(MT * GYS + CIT * XS) * sizeof(float);
     static unsigned long long lds_set = 0;      // per-device bits, see nef_ensure_dyn_lds
     if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_bwd_weight_kernel<K, WCO, TCI, PRO, WINO>), lds, &lds_set)) return e;
+    // Split count: the workgroups are persistent over their share of the column tiles, so the launch should be exactly
+    // ONE round of resident workgroups (occupancy x CUs) -- a partial second round leaves half the chip idle for a whole
+    // workgroup lifetime (measured: 768 workgroups on 512 slots cost 5..8 % against 504..512).  Never more splits than the
+    // workspace was sized for (p.S from plan_bwd_weight is that bound).
+    {
+        static int resident_dev[64] = {0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        int resident = __atomic_load_n(&resident_dev[dev & 63], __ATOMIC_ACQUIRE);
+        if (resident == 0) {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                    &per_cu, reinterpret_cast<const void*>(&conv_bwd_weight_kernel<K, WCO, TCI, PRO, WINO>), 256, lds) !=
+                hipSuccess || per_cu <= 0)
+                per_cu = 2;
+            resident = per_cu * nef_cu_count();
+            __atomic_store_n(&resident_dev[dev & 63], resident, __ATOMIC_RELEASE);
+        }
+        const int base = G * p.m_tiles * p.ci_chunks;
+        int S = resident / base;
+        if (S > p.S) S = p.S;
+        if (S < 1) S = 1;
+        p.S = S;
+    }
     const int64_t blocks = (int64_t)p.S * G * p.m_tiles * p.ci_chunks;
     hipLaunchKernelGGL((conv_bwd_weight_kernel<K, WCO, TCI, PRO, WINO>), dim3((unsigned)blocks), dim3(256), lds, st, x, x_bs,
                        x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, ws, B, T, G, Cig, Cog, p.ct.seg_shift, p.ct.nseg,

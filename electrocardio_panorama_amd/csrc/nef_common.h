@@ -23,6 +23,19 @@ static inline int nef_launch_status() {
 
 static inline int64_t nef_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Compute units of the CURRENT device (256 on MI355X); queried once per device, idempotent -> thread-safe.
+static inline int nef_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    int n = __atomic_load_n(&cached[dev & 63], __ATOMIC_ACQUIRE);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        __atomic_store_n(&cached[dev & 63], n, __ATOMIC_RELEASE);
+    }
+    return n;
+}
+
 // Raise a kernel's dynamic-LDS limit once per DEVICE.  `done` is a per-kernel bit mask (bit = device ordinal); the call is
 // idempotent, so two host threads racing on the first launch both succeed -- the entry points stay re-entrant and the
 // library keeps no other state.

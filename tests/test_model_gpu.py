@@ -337,6 +337,39 @@ def test_full_baseline_batch_vs_oracle_rows():
     assert bool(torch.isfinite(g1).all()) and float(g1.norm()) > 0
 
 
+def test_config3_shard_full_size_is_deterministic_and_fits():
+    """BASELINE configs[2]: the per-GPU shard of the 8-GPU run (256 samples x 8 leads x 5000, Standin losses and dropout
+    on) -- the train step runs, is finite, bit-identical when repeated from the same state, and its memory footprint is
+    reported (the CPU oracle covers this shape at small batch in test_baseline_config_shapes_vs_oracle and with two
+    ranks in tests/test_dp_gpu.py)."""
+    from electrocardio_panorama_amd.network import build_loss
+    B, V, L = 256, 8, 5000
+    cfg = make_cfg(V)
+    m = hashed_model(V).train()
+    lossf = build_loss(cfg)
+    b = batch_t(B, V, L, 2718)
+    torch.cuda.reset_peak_memory_stats()
+
+    def step():
+        torch.manual_seed(11)
+        m._drop_calls = 0
+        random.seed(9)
+        m.zero_grad()
+        o = m(b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train")
+        ls = lossf(o[0], o[1], o[2], b["target_view"].unsqueeze(1), cfg)
+        ls[0].backward()
+        return torch.stack([x.detach() for x in ls]), torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
+
+    l1, g1 = step()
+    l2, g2 = step()
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)
+    assert g1.numel() == 18831041 and bool(torch.isfinite(g1).all()) and float(g1.norm()) > 0 and m.segment_status() == 0
+    gib = torch.cuda.max_memory_reserved() / 2 ** 30
+    print(f"configs[2] shard (256 x 8 x 5000): peak reserved {gib:.1f} GiB, peak allocated "
+          f"{torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
+    assert gib < 200
+
+
 def test_full_size_train_gradients_vs_oracle():
     """BASELINE configs[1] at FULL size in TRAIN mode (256 x 3 x 5000, dropout masks replayed, batch-statistics
     BatchNorm over 3.84 M elements per channel, split-K weight gradients over 320 k columns): outputs, losses, BN running
