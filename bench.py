@@ -45,6 +45,9 @@ def parse():
                          "256-core GPU box, profiles/r02_cpu_thread_sweep.md); the best one is headlined")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket launches with HIP events (roofline / hbm_bound are then null): at launch-bound "
+                         "shapes the ~250 event pairs per step cost more host time than the launches themselves")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (launch-bound shapes)")
     return ap.parse_args()
 
@@ -151,13 +154,13 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ops.PROFILE = [] if rank == 0 else None
+    ops.PROFILE = [] if (rank == 0 and not args.no_kernel_events and not args.graph) else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
+    prof, ops.PROFILE = ops.PROFILE or [], None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
