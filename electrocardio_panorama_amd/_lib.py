@@ -37,8 +37,6 @@ class ConvArgs(C.Structure):
 SIGNATURES = {
     "nef_abi_version": (i32, []),
     "nef_stem_fwd": (i32, [p, p, p, i32, i32, i32, p]),
-    "nef_stem_fwd_code": (i32, [p, p, p, p, i32, i32, i32, p]),
-    "nef_stem_bwd_weight_code": (i32, [p, p, p, p, p, sz, i32, i32, i32, p]),
     "nef_stem_bwd_ws_bytes": (sz, [i32]),
     "nef_stem_bwd_weight": (i32, [p, p, p, p, p, sz, i32, i32, i32, p]),
     "nef_pack_weight": (i32, [p, p, i32, i32, i32, i32, i32, p]),

@@ -1,10 +1,7 @@
 // Stem of the per-lead encoder, fused: Conv1d(1->128 per lead, k15, s2, p7, no bias) -> ReLU -> MaxPool1d(3,2,1).
 // Replaces reference codes/network/encoder/encoder.py:35-38 (conv1/relu/maxpool built at
 // codes/network/encoder/resnet_1d.py:102-105).  HBM-bound (AI ~7 FLOP/B): the [B,128V,L/2] conv output is never
-// materialised.  The forward can leave one byte per output with the pool's arg-max position and the ReLU gate
-// (0..2 = which of the three conv positions won, 3 = the gradient is gated off); the weight gradient then routes gy
-// straight to the winning input window (15 FMAs per output) instead of recomputing the three conv outputs (60 FMAs).
-// Without the code tensor the backward recomputes them from the 19-sample input window each lane already holds.
+// materialised; the backward recomputes it from the 19-sample input window each lane already holds.
 #include "nef_common.h"
 
 namespace {
@@ -25,8 +22,8 @@ __device__ __forceinline__ void load_window(const float* __restrict__ xrow, int 
 }
 
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       float* __restrict__ y, uint8_t* __restrict__ code, int B, int V,
-                                                       int L, int T, int tiles_per_row) {
+                                                       float* __restrict__ y, int B, int V, int L, int T,
+                                                       int tiles_per_row) {
     __shared__ float wl[CPL * 16];   // [co][16] (15 taps + pad) for 16-byte broadcast reads
     int bid = blockIdx.x;
     const int tile = bid % tiles_per_row;
@@ -66,19 +63,6 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
         if (has_l) m = fmaxf(m, fmaxf(c0, 0.f));
         if (has_r) m = fmaxf(m, fmaxf(c2, 0.f));
         yrow[(int64_t)co * T] = m;
-        if (code) {
-            // the backward's decision, taken once here: arg-max in scan order (first maximum wins), then the ReLU gate
-            float best = has_l ? fmaxf(c0, 0.f) : -INFINITY;
-            float pre = c0;
-            int sel = 0;
-            const float r1 = fmaxf(c1, 0.f);
-            if (r1 > best) { best = r1; sel = 1; pre = c1; }
-            if (has_r) {
-                const float r2 = fmaxf(c2, 0.f);
-                if (r2 > best) { best = r2; sel = 2; pre = c2; }
-            }
-            code[((int64_t)b * V * CPL + (int64_t)v * CPL + co) * T + tp] = (uint8_t)(pre > 0.f ? sel : 3);
-        }
     }
 }
 
@@ -159,52 +143,6 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
         }
 }
 
-// The same reduction with the forward's decision bytes: no conv recompute, no filter taps.
-__global__ __launch_bounds__(256) void stem_bwd_weight_code_kernel(const float* __restrict__ x,
-                                                                   const uint8_t* __restrict__ code,
-                                                                   const float* __restrict__ gy, float* __restrict__ part,
-                                                                   int B, int V, int L, int T, int tiles_per_row) {
-    int bid = blockIdx.x;
-    const int cg = bid % (CPL / BW_CPB);
-    bid /= (CPL / BW_CPB);
-    const int v = bid % V;
-    const int split = bid / V;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int ch0 = v * CPL + cg * BW_CPB + wave * BW_CPW;
-    float acc[BW_CPW][KW];
-#pragma unroll
-    for (int c = 0; c < BW_CPW; ++c)
-#pragma unroll
-        for (int k = 0; k < KW; ++k) acc[c][k] = 0.f;
-    const int n_units = B * tiles_per_row;
-    for (int unit = split; unit < n_units; unit += BW_SPLIT) {
-        const int b = unit / tiles_per_row;
-        const int tp = (unit - b * tiles_per_row) * TP + lane;
-        float xw[19];
-        load_window(x + ((int64_t)b * V + v) * L, L, tp, xw);
-        if (tp >= T) continue;
-#pragma unroll
-        for (int c = 0; c < BW_CPW; ++c) {
-            const int64_t o = ((int64_t)b * V * CPL + ch0 + c) * T + tp;
-            const int sel = code[o];
-            const float ge = sel < 3 ? gy[o] : 0.f;
-#pragma unroll
-            for (int k = 0; k < KW; ++k) {
-                const float xv = sel == 0 ? xw[k] : (sel == 1 ? xw[k + 2] : xw[k + 4]);
-                acc[c][k] = fmaf(ge, xv, acc[c][k]);
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < BW_CPW; ++c)
-#pragma unroll
-        for (int k = 0; k < KW; ++k) {
-            const float s = nef_wave_sum(acc[c][k]);
-            if (lane == 0) part[((int64_t)split * V * CPL + ch0 + c) * KW + k] = s;
-        }
-}
-
 __global__ void stem_bwd_weight_reduce(const float* __restrict__ part, float* __restrict__ gw, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -217,38 +155,18 @@ __global__ void stem_bwd_weight_reduce(const float* __restrict__ part, float* __
 
 extern "C" {
 
-size_t nef_stem_bwd_ws_bytes(int V) { return (size_t)BW_SPLIT * V * CPL * KW * sizeof(float); }
-
-int nef_stem_fwd_code(const float* x, const float* w, float* y, uint8_t* code, int B, int V, int L, nef_stream_t stream) {
+int nef_stem_fwd(const float* x, const float* w, float* y, int B, int V, int L, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(x && w && y, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && V > 0 && L >= 4 && L % 4 == 0, NEF_E_SHAPE);
     const int T = L / 4;
     const int tiles = (T + TP - 1) / TP;
     hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)((int64_t)B * V * tiles)), dim3(256), 0, (hipStream_t)stream, x,
-                       w, y, code, B, V, L, T, tiles);
+                       w, y, B, V, L, T, tiles);
     return nef_launch_status();
 }
 
-int nef_stem_fwd(const float* x, const float* w, float* y, int B, int V, int L, nef_stream_t stream) {
-    return nef_stem_fwd_code(x, w, y, nullptr, B, V, L, stream);
-}
-
-int nef_stem_bwd_weight_code(const float* x, const uint8_t* code, const float* gy, float* gw, void* ws, size_t ws_bytes,
-                             int B, int V, int L, nef_stream_t stream) {
-    NEF_ENTER();
-    NEF_REQUIRE(x && code && gy && gw && ws, NEF_E_NULL);
-    NEF_REQUIRE(B > 0 && V > 0 && L >= 4 && L % 4 == 0, NEF_E_SHAPE);
-    NEF_REQUIRE(ws_bytes >= nef_stem_bwd_ws_bytes(V), NEF_E_WORKSPACE);
-    const int T = L / 4;
-    const int tiles = (T + TP - 1) / TP;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(stem_bwd_weight_code_kernel, dim3((unsigned)(BW_SPLIT * V * (CPL / BW_CPB))), dim3(256), 0, st, x,
-                       code, gy, (float*)ws, B, V, L, T, tiles);
-    const int n = V * CPL * KW;
-    hipLaunchKernelGGL(stem_bwd_weight_reduce, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)ws, gw, n);
-    return nef_launch_status();
-}
+size_t nef_stem_bwd_ws_bytes(int V) { return (size_t)BW_SPLIT * V * CPL * KW * sizeof(float); }
 
 int nef_stem_bwd_weight(const float* x, const float* w, const float* gy, float* gw, void* ws, size_t ws_bytes, int B,
                         int V, int L, nef_stream_t stream) {

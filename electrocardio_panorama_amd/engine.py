@@ -264,10 +264,7 @@ def _latents(P, x, in_theta, rois, drop, save):
     B, V, L = x.shape
     T = L // 4
     sv = {}
-    if save:
-        a, sv["stem_code"] = ops.stem_fwd(x, P["W_encoder.conv1.weight"], with_code=True)
-    else:
-        a = ops.stem_fwd(x, P["W_encoder.conv1.weight"])
+    a = ops.stem_fwd(x, P["W_encoder.conv1.weight"])
     sv["blk_enc"] = []
     for i in range(3):
         a, s = block_fwd(GV.dense(a, V), P, f"W_encoder.layer1.{i}", 7, 128, drop)
@@ -522,7 +519,7 @@ def _latents_bwd(P, sv, gz1, gz2r, grads, side, z1_pre_gated=False):
     grads["mlp1.weight"], grads["mlp1.bias"] = gW1, gb1
     for i in (2, 1, 0):
         g = block_bwd(sv["blk_enc"][i], g, P, grads, side=side, pre_gated=True, gate_input=(i > 0))
-    grads["W_encoder.conv1.weight"] = ops.stem_bwd_weight(sv["x"], P["W_encoder.conv1.weight"], g, code=sv["stem_code"])
+    grads["W_encoder.conv1.weight"] = ops.stem_bwd_weight(sv["x"], P["W_encoder.conv1.weight"], g)
 
 
 def backward(P, sv, g_outs):

@@ -148,33 +148,26 @@ class GV:
 
 
 # ------------------------------------------------------------------ stem
-def stem_fwd(x, w, with_code=False):
-    """`with_code`: also return the uint8 decision tensor (pool arg-max + ReLU gate) the backward can use."""
+def stem_fwd(x, w):
     L = _lib.load()
     _chk(x), _chk(w)
     B, V, Ln = x.shape
     y = torch.empty(B, 128 * V, Ln // 4, device=x.device, dtype=torch.float32)
-    code = torch.empty(B, 128 * V, Ln // 4, device=x.device, dtype=torch.uint8) if with_code else None
-    ev = _hbm("stem_fwd", x, y, code)
-    _lib.check(L.nef_stem_fwd_code(_p(x), _p(w), _p(y), _p(code), B, V, Ln, _stream()), "nef_stem_fwd")
+    ev = _hbm("stem_fwd", x, y)
+    _lib.check(L.nef_stem_fwd(_p(x), _p(w), _p(y), B, V, Ln, _stream()), "nef_stem_fwd")
     _done(ev)
-    return (y, code) if with_code else y
+    return y
 
 
-def stem_bwd_weight(x, w, gy, code=None):
+def stem_bwd_weight(x, w, gy):
     L = _lib.load()
     _chk(x), _chk(w), _chk(gy)
     B, V, Ln = x.shape
     gw = torch.empty_like(w)
     n = L.nef_stem_bwd_ws_bytes(V)
     ws = workspace(n, x.device)
-    ev = _hbm("stem_bwd_weight", x, gy, code)
-    if code is not None:
-        _chk(code, torch.uint8)
-        _lib.check(L.nef_stem_bwd_weight_code(_p(x), _p(code), _p(gy), _p(gw), _p(ws), n, B, V, Ln, _stream()),
-                   "nef_stem_bwd_weight_code")
-    else:
-        _lib.check(L.nef_stem_bwd_weight(_p(x), _p(w), _p(gy), _p(gw), _p(ws), n, B, V, Ln, _stream()), "nef_stem_bwd_weight")
+    ev = _hbm("stem_bwd_weight", x, gy)
+    _lib.check(L.nef_stem_bwd_weight(_p(x), _p(w), _p(gy), _p(gw), _p(ws), n, B, V, Ln, _stream()), "nef_stem_bwd_weight")
     _done(ev)
     return gw
 

@@ -43,12 +43,6 @@ int nef_abi_version(void);   /* 8 */
  * bwd_weight recomputes the conv, routes gy through the pool arg-max and the ReLU.
  *   ws: nef_stem_bwd_ws_bytes(V) bytes of scratch. */
 int nef_stem_fwd(const float* x, const float* w, float* y, int B, int V, int L, nef_stream_t stream);
-/* Same, also leaving one decision byte per output for the backward: code [B][128V][L/4], 0..2 = which conv position of
- * the pool window won (first maximum in scan order), 3 = gradient gated off by the ReLU.  nef_stem_bwd_weight_code
- * uses it instead of recomputing the conv (x, gy, gw, ws as nef_stem_bwd_weight; results are bit-identical). */
-int nef_stem_fwd_code(const float* x, const float* w, float* y, uint8_t* code, int B, int V, int L, nef_stream_t stream);
-int nef_stem_bwd_weight_code(const float* x, const uint8_t* code, const float* gy, float* gw, void* ws, size_t ws_bytes,
-                             int B, int V, int L, nef_stream_t stream);
 size_t nef_stem_bwd_ws_bytes(int V);
 int nef_stem_bwd_weight(const float* x, const float* w, const float* gy, float* gw, void* ws, size_t ws_bytes,
                         int B, int V, int L, nef_stream_t stream);

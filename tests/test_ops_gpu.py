@@ -33,9 +33,6 @@ def test_stem(B, V, L):
     ref.backward(gy)
     gw = o.stem_bwd_weight(g(x), g(w), g(gy))
     assert rel(gw, wr.grad) < GRAD_TOL
-    y2, code = o.stem_fwd(g(x), g(w), with_code=True)       # decision bytes: same output, bit-identical gradient
-    assert torch.equal(y2, y) and code.dtype == torch.uint8 and int(code.max()) <= 3
-    assert torch.equal(o.stem_bwd_weight(g(x), g(w), g(gy), code=code), gw)
 
 
 def test_pack_weight():
