@@ -33,6 +33,12 @@ class ConvArgs(C.Structure):
     ]
 
 
+class PackDesc(C.Structure):
+    """Mirror of `nef_pack_desc` (include/nefnet_hip.h)."""
+    _fields_ = [("w", p), ("wp", p), ("G", i32), ("Cog", i32), ("Cig", i32), ("K", i32), ("transpose_flip", i32),
+                ("wino", i32)]
+
+
 # name -> (restype, argtypes); every symbol include/nefnet_hip.h declares
 SIGNATURES = {
     "nef_abi_version": (i32, []),
@@ -41,6 +47,7 @@ SIGNATURES = {
     "nef_stem_bwd_weight": (i32, [p, p, p, p, p, sz, i32, i32, i32, p]),
     "nef_pack_weight": (i32, [p, p, i32, i32, i32, i32, i32, p]),
     "nef_pack_weight_wino": (i32, [p, p, i32, i32, i32, i32, i32, p]),
+    "nef_pack_weights": (i32, [C.POINTER(PackDesc), i32, p]),
     "nef_conv_fwd": (i32, [C.POINTER(ConvArgs), p]),
     "nef_conv_bwd_weight_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "nef_conv_bwd_weight": (i32, [p, i64, i64, p, i64, i64, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32, i32, p]),

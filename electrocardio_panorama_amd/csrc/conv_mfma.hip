@@ -701,38 +701,43 @@ static int launch_conv_wino(const nef_conv_args& a, hipStream_t st) {
 // wp[g][plane][r][c]; (r, c) = (ci, co) forward, (co, ci) with the taps reversed for the backward-data operand.
 // K = 3: planes 0..3 = the F(2,3) weight transform (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) of the three taps.
 // K = 7: planes 0..3 / 4..7 = that transform of taps 0..2 / 3..5, plane 8 = tap 6, plane 9 = -tap 6.
-__global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog, int Cig,
-                                        int K, int flip) {
+__device__ __forceinline__ void pack_wino_elem(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog,
+                                               int Cig, int K, int flip, int64_t i) {
     const int64_t n = (int64_t)G * Cog * Cig;
     const int64_t plane = n / G;
     const int npl = K == 3 ? 4 : 10;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = i;
-        int co, ci;
-        if (!flip) {   // [g][.][ci][co]
-            co = (int)(r % Cog); r /= Cog;
-            ci = (int)(r % Cig); r /= Cig;
-        } else {       // [g][.][co][ci]
-            ci = (int)(r % Cig); r /= Cig;
-            co = (int)(r % Cog); r /= Cog;
-        }
-        const int g = (int)r;
-        const float* src = w + (((int64_t)g * Cog + co) * Cig + ci) * K;
-        float* dst = wp + (int64_t)g * npl * plane + (i - (int64_t)g * plane);
-        for (int grp = 0; grp < K / 3; ++grp) {
-            const float g0 = src[flip ? K - 1 - 3 * grp : 3 * grp], g1 = src[flip ? K - 2 - 3 * grp : 3 * grp + 1],
-                        g2 = src[flip ? K - 3 - 3 * grp : 3 * grp + 2];
-            dst[(4 * grp) * plane] = g0;
-            dst[(4 * grp + 1) * plane] = ((g0 + g1) + g2) * 0.5f;
-            dst[(4 * grp + 2) * plane] = ((g0 - g1) + g2) * 0.5f;
-            dst[(4 * grp + 3) * plane] = g2;
-        }
-        if (K == 7) {
-            const float g6 = src[flip ? 0 : 6];
-            dst[8 * plane] = g6;
-            dst[9 * plane] = -g6;
-        }
+    int64_t r = i;
+    int co, ci;
+    if (!flip) {   // [g][.][ci][co]
+        co = (int)(r % Cog); r /= Cog;
+        ci = (int)(r % Cig); r /= Cig;
+    } else {       // [g][.][co][ci]
+        ci = (int)(r % Cig); r /= Cig;
+        co = (int)(r % Cog); r /= Cog;
     }
+    const int g = (int)r;
+    const float* src = w + (((int64_t)g * Cog + co) * Cig + ci) * K;
+    float* dst = wp + (int64_t)g * npl * plane + (i - (int64_t)g * plane);
+    for (int grp = 0; grp < K / 3; ++grp) {
+        const float g0 = src[flip ? K - 1 - 3 * grp : 3 * grp], g1 = src[flip ? K - 2 - 3 * grp : 3 * grp + 1],
+                    g2 = src[flip ? K - 3 - 3 * grp : 3 * grp + 2];
+        dst[(4 * grp) * plane] = g0;
+        dst[(4 * grp + 1) * plane] = ((g0 + g1) + g2) * 0.5f;
+        dst[(4 * grp + 2) * plane] = ((g0 - g1) + g2) * 0.5f;
+        dst[(4 * grp + 3) * plane] = g2;
+    }
+    if (K == 7) {
+        const float g6 = src[flip ? 0 : 6];
+        dst[8 * plane] = g6;
+        dst[9 * plane] = -g6;
+    }
+}
+
+__global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog, int Cig,
+                                        int K, int flip) {
+    const int64_t n = (int64_t)G * Cog * Cig;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        pack_wino_elem(w, wp, G, Cog, Cig, K, flip, i);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1156,24 +1161,42 @@ static int launch_bwd_weight(BwdWeightPlan& p, const float* x, int64_t x_bs, int
     return nef_launch_status();
 }
 
+__device__ __forceinline__ void pack_plain_elem(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog,
+                                                int Cig, int K, int flip, int64_t i) {
+    // i indexes the PACKED tensor
+    int64_t r = i;
+    int co, ci;
+    if (!flip) {   // [g][k][ci][co]
+        co = (int)(r % Cog); r /= Cog;
+        ci = (int)(r % Cig); r /= Cig;
+    } else {       // [g][k][co][ci]
+        ci = (int)(r % Cig); r /= Cig;
+        co = (int)(r % Cog); r /= Cog;
+    }
+    const int k = (int)(r % K);
+    const int g = (int)(r / K);
+    const int ks = flip ? (K - 1 - k) : k;
+    wp[i] = w[(((int64_t)g * Cog + co) * Cig + ci) * K + ks];
+}
+
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog, int Cig, int K,
                                    int flip) {
     const int64_t n = (int64_t)G * Cog * Cig * K;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        pack_plain_elem(w, wp, G, Cog, Cig, K, flip, i);
+}
+
+// Every operand of a forward (or backward) pass in ONE launch: blockIdx.y selects the descriptor, which travels by value
+// in the kernel arguments (no device-side table to keep in sync).
+constexpr int PACK_MULTI_MAX = 48;
+struct PackTable { nef_pack_desc d[PACK_MULTI_MAX]; };
+
+__global__ void pack_weights_multi_kernel(PackTable t) {
+    const nef_pack_desc& d = t.d[blockIdx.y];
+    const int64_t n = (int64_t)d.G * d.Cog * d.Cig * (d.wino ? 1 : d.K);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        // i indexes the PACKED tensor
-        int64_t r = i;
-        int co, ci;
-        if (!flip) {   // [g][k][ci][co]
-            co = (int)(r % Cog); r /= Cog;
-            ci = (int)(r % Cig); r /= Cig;
-        } else {       // [g][k][co][ci]
-            ci = (int)(r % Cig); r /= Cig;
-            co = (int)(r % Cog); r /= Cog;
-        }
-        const int k = (int)(r % K);
-        const int g = (int)(r / K);
-        const int ks = flip ? (K - 1 - k) : k;
-        wp[i] = w[(((int64_t)g * Cog + co) * Cig + ci) * K + ks];
+        if (d.wino) pack_wino_elem(d.w, d.wp, d.G, d.Cog, d.Cig, d.K, d.transpose_flip, i);
+        else pack_plain_elem(d.w, d.wp, d.G, d.Cog, d.Cig, d.K, d.transpose_flip, i);
     }
 }
 
@@ -1226,6 +1249,31 @@ int nef_pack_weight_wino(const float* w, float* wp, int G, int Cog, int Cig, int
     const int64_t n = (int64_t)G * Cog * Cig;
     hipLaunchKernelGGL(pack_weight_wino_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, w, wp,
                        G, Cog, Cig, K, transpose_flip);
+    return nef_launch_status();
+}
+
+int nef_pack_weights(const nef_pack_desc* descs, int n, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(descs || n == 0, NEF_E_NULL);
+    NEF_REQUIRE(n >= 0, NEF_E_SHAPE);
+    for (int i = 0; i < n; ++i) {
+        const nef_pack_desc& d = descs[i];
+        NEF_REQUIRE(d.w && d.wp, NEF_E_NULL);
+        NEF_REQUIRE(d.G > 0 && d.Cog > 0 && d.Cig > 0 && d.K > 0 && (!d.wino || d.K == 3 || d.K == 7), NEF_E_SHAPE);
+    }
+    for (int i0 = 0; i0 < n; i0 += PACK_MULTI_MAX) {
+        PackTable t;
+        const int m = n - i0 < PACK_MULTI_MAX ? n - i0 : PACK_MULTI_MAX;
+        int64_t biggest = 1;
+        for (int i = 0; i < m; ++i) {
+            t.d[i] = descs[i0 + i];
+            const int64_t e = (int64_t)t.d[i].G * t.d[i].Cog * t.d[i].Cig * (t.d[i].wino ? 1 : t.d[i].K);
+            if (e > biggest) biggest = e;
+        }
+        int gx = (int)nef_cdiv(biggest, 256);
+        if (gx > 64) gx = 64;
+        hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)gx, (unsigned)m), dim3(256), 0, (hipStream_t)stream, t);
+    }
     return nef_launch_status();
 }
 

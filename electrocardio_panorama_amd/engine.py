@@ -70,6 +70,33 @@ def block_fwd(xv, P, prefix, K, Cog, drop):
     return y, (xv, h, y, prefix, K, Cog, res_conv, drop.scale)
 
 
+def _block_pack_requests(P, prefix, G, T, flip):
+    """The operands block_fwd / block_bwd will ask ops.pack_weight for, for ops.pack_many (one launch per pass)."""
+    reqs = [(P[prefix + ".conv1.weight"], G, flip, T), (P[prefix + ".conv2.weight"], G, flip, T)]
+    w1 = P[prefix + ".conv1.weight"]
+    if w1.shape[2] == 3 and w1.shape[0] // G != w1.shape[1]:          # block_fwd's res_conv condition
+        reqs.append((P[prefix + ".residual_conv.weight"], G, flip, None))
+    return reqs
+
+
+def _latent_pack_requests(P, V, T, win, flip):
+    reqs = []
+    for i in range(3):
+        reqs += _block_pack_requests(P, f"W_encoder.layer1.{i}", V, T, flip)
+    reqs += _block_pack_requests(P, "w_conv.0", V, T, flip)
+    reqs += _block_pack_requests(P, "z1_conv.0", V, T, flip)
+    reqs += _block_pack_requests(P, "z2_conv1.0", V, win[1] if win is not None else T, flip)
+    reqs += _block_pack_requests(P, "z2_conv2.0", N_SEG * V, ROI_BINS, flip)
+    reqs += _block_pack_requests(P, "z2_conv2.2", N_SEG * V, 2 * ROI_BINS, flip)
+    return reqs
+
+
+def _decoder_pack_requests(P, T_lat, flip):
+    """Decoder convs whose weight is used as stored (the first one is regrouped per call): output lengths 2T, 4T, 4T."""
+    return [(P["decoder.1.double_conv.3.weight"], 1, flip, 2 * T_lat), (P["decoder.3.double_conv.0.weight"], 1, flip, 4 * T_lat),
+            (P["decoder.3.double_conv.3.weight"], 1, flip, 4 * T_lat)]
+
+
 def _side(device):
     if os.environ.get("NEF_SIDE_STREAM", "1") == "0" or torch.cuda.is_current_stream_capturing():
         return ops._Inline()          # inside a hipGraph capture everything stays on the capturing stream
@@ -164,6 +191,7 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
         return _decoder_fwd_unfused(D, P, Bf, passes, training, save)
     x, pro_in = D, None                # pro_in: (a, b) of the BN whose output feeds the next conv
     saved = []
+    ops.pack_many(_decoder_pack_requests(P, D.shape[2], False))
     # shared_B: D holds only the two distinct inputs of the three Standin passes (ops.mix_fwd_shared); the first conv
     # runs once per distinct channel half (a 2-group conv) and pass_combine_fwd assembles the three pass outputs
     N = D.shape[0] if shared_B is None else 3 * shared_B
@@ -216,6 +244,8 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
     saved, c4, out, passes, pro4 = dsaved[:5]
     shared_B = dsaved[5] if len(dsaved) > 5 else None
     side = side or ops._Inline()
+    if len(dsaved) > 5:                # the fused decoder: its backward-data operands in one launch
+        ops.pack_many(_decoder_pack_requests(P, c4.shape[2] // 4, True))
     grads["decoder.4.weight"], grads["decoder.4.bias"] = side.run(
         lambda: ops.outconv_bwd_weight(g_out, out, c4, pro=pro4), g_out, out, c4)
     # the last BatchNorm's backward rebuilds the last conv's input gradient from go on the fly (never materialised)
@@ -264,6 +294,9 @@ def _latents(P, x, in_theta, rois, drop, save):
     B, V, L = x.shape
     T = L // 4
     sv = {}
+    r0 = (T - 1) // 2
+    win = (r0 - 2, 6) if (T % 2 == 0 and r0 - 2 >= 0 and r0 + 4 <= T) else None
+    ops.pack_many(_latent_pack_requests(P, V, T, win, False))       # every conv operand of this function in one launch
     a = ops.stem_fwd(x, P["W_encoder.conv1.weight"])
     sv["blk_enc"] = []
     for i in range(3):
@@ -275,8 +308,6 @@ def _latents(P, x, in_theta, rois, drop, save):
     z1, sv["blk_z1"] = block_fwd(GV.half(enc, V, 0), P, "z1_conv.0", 3, 128, drop)
     # z2_conv1 feeds only roi_algin, which reads exactly two time rows: run the block on the window of
     # six samples whose centre two are exact (k=3 twice -> 2 samples of context per side) instead of all T.
-    r0 = (T - 1) // 2
-    win = (r0 - 2, 6) if (T % 2 == 0 and r0 - 2 >= 0 and r0 + 4 <= T) else None
     if win is not None:
         xw = ops.window_crop(GV.half(enc, V, 1), win[0], win[1])
         wdrop = drop.windowed("z2_conv1.0", win[0], win[1])
@@ -494,6 +525,7 @@ def _head_bwd(P, sv, g_outs, grads, side, relu_z1=False):
 def _latents_bwd(P, sv, gz1, gz2r, grads, side, z1_pre_gated=False):
     """Back through `_latents` (+ the segment un-pooling that follows it): encoder-side parameter gradients."""
     B, V, T = sv["B"], sv["V"], sv["T"]
+    ops.pack_many(_latent_pack_requests(P, V, T, sv["z2_win"], True))
     gz2b = ops.roi_unpool_bwd(gz2r, sv["rois"])                                  # [B, 128V, 7, 32]
     gh3 = gz2b.view(B, 128 * V * N_SEG, 2 * ROI_BINS)
     gh2 = block_bwd(sv["blk_c22"], gh3, P, grads, side=side)

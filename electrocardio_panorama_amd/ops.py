@@ -183,15 +183,58 @@ def wino_ok(K, Cin_g, Cout_g, T_out, pro=0):
             ((Cout_g % 128 == 0 and T_out >= 128) or (Cout_g % 128 != 0 and Cout_g % 64 == 0 and T_out >= 256)))
 
 
+_PREPACKED = {}     # (weight data_ptr, G, flip, wino) -> operand packed by pack_many(), consumed by the next pack_weight()
+
+
+def _pack_shape(w, G, flip, T):
+    Cog, Cig, K = w.shape[0] // G, w.shape[1], w.shape[2]
+    cin_g, cout_g = (Cog, Cig) if flip else (Cig, Cog)          # roles in the launch that consumes the operand
+    wino = T is not None and wino_ok(K, cin_g, cout_g, T)
+    return Cog, Cig, K, wino
+
+
+def pack_many(requests):
+    """All operands of a pass in ONE launch.  `requests`: iterable of (w, G, flip, T) exactly as the later
+    pack_weight(w, G, flip=flip, T=T) calls will ask for them; those calls then return the pre-packed operand instead of
+    launching.  Anything not pre-packed still packs on demand, so a missing or surplus request costs time, never
+    correctness; the table is reset at every call."""
+    L = _lib.load()
+    _PREPACKED.clear()
+    reqs = []
+    for w, G, flip, T in requests:
+        _chk(w)
+        Cog, Cig, K, wino = _pack_shape(w, G, flip, T)
+        key = (w.data_ptr(), G, bool(flip), wino)
+        if key not in _PREPACKED:
+            _PREPACKED[key] = None
+            reqs.append((key, w, G, Cog, Cig, K, bool(flip), wino))
+    if not reqs:
+        return
+    sizes = [G * Cog * Cig * ((4 if K == 3 else 10) if wino else K) for _, _, G, Cog, Cig, K, _, wino in reqs]
+    arena = torch.empty(sum(sizes), device=reqs[0][1].device, dtype=torch.float32)
+    descs = (_lib.PackDesc * len(reqs))()
+    off = 0
+    for d, n, (key, w, G, Cog, Cig, K, flip, wino) in zip(descs, sizes, reqs):
+        wp = arena[off:off + n]
+        off += n
+        if wino:
+            wp.nef_wino = True
+        d.w, d.wp, d.G, d.Cog, d.Cig, d.K, d.transpose_flip, d.wino = w.data_ptr(), wp.data_ptr(), G, Cog, Cig, K, int(flip), int(wino)
+        _PREPACKED[key] = (wp, w)          # keep the source alive while its pointer is the key
+    _lib.check(L.nef_pack_weights(descs, len(reqs), _stream()), "nef_pack_weights")
+
+
 def pack_weight(w, G, flip=False, T=None):
     """w [G*Cog, Cig, K] -> packed operand (forward: [G][K][Cig][Cog]; flip: [G][K][Cog][Cig], taps reversed).
     `T`: output length of the conv launch this operand is for; when the Winograd F(2,3) path applies to that launch
-    the operand is packed for it ([G][4][.][.], marked with `.nef_wino`) and `conv()` takes that path."""
+    the operand is packed for it ([G][4 or 10][.][.], marked with `.nef_wino`) and `conv()` takes that path."""
     L = _lib.load()
     _chk(w)
-    Cog, Cig, K = w.shape[0] // G, w.shape[1], w.shape[2]
-    cin_g, cout_g = (Cog, Cig) if flip else (Cig, Cog)          # roles in the launch that consumes the operand
-    if T is not None and wino_ok(K, cin_g, cout_g, T):
+    Cog, Cig, K, wino = _pack_shape(w, G, flip, T)
+    hit = _PREPACKED.pop((w.data_ptr(), G, bool(flip), wino), None)
+    if hit is not None and hit[1] is w:
+        return hit[0]
+    if wino:
         wp = torch.empty(G * (4 if K == 3 else 10) * Cog * Cig, device=w.device, dtype=torch.float32)
         _lib.check(L.nef_pack_weight_wino(_p(w), _p(wp), G, Cog, Cig, K, int(flip), _stream()), "nef_pack_weight_wino")
         wp.nef_wino = True

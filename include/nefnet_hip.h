@@ -64,6 +64,15 @@ int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, i
 int nef_pack_weight_wino(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                          nef_stream_t stream);
 
+/* Any number of operands in one launch (a whole forward or backward pass packs ~25): each descriptor is one
+ * nef_pack_weight (wino = 0) or nef_pack_weight_wino (wino = 1) call.  `descs` is a HOST array. */
+typedef struct nef_pack_desc {
+    const float* w;
+    float* wp;
+    int32_t G, Cog, Cig, K, transpose_flip, wino;
+} nef_pack_desc;
+int nef_pack_weights(const nef_pack_desc* descs, int n, nef_stream_t stream);
+
 typedef struct nef_conv_args {
     const float* x;        /* input  [B][..][T]; element (b, g, ci, t) at x + b*x_bs + g*x_gs + ci*T + t */
     const float* wp;       /* packed weights [G][K][Cin_g][Cout_g] (nef_pack_weight) */

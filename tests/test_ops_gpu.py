@@ -47,6 +47,25 @@ def test_pack_weight():
     assert torch.equal(wf, expf.contiguous())
 
 
+def test_pack_many_equals_single_packs():
+    """One launch for a whole pass's operands (nef_pack_weights): every pre-packed operand equals the single-call pack,
+    is handed out exactly once, and anything that was not requested still packs on demand."""
+    o = ops()
+    ws = [(g(rnd(3 * 128, 128, 7, seed=40)), 3, False, 1250), (g(rnd(3 * 128, 64, 3, seed=41)), 3, True, 1250),
+          (g(rnd(3 * 128, 64, 1, seed=42)), 3, False, None), (g(rnd(21 * 128, 128, 3, seed=43)), 21, True, 16),
+          (g(rnd(64, 128, 3, seed=44)), 1, False, 5000), (g(rnd(128, 128, 7, seed=45)), 1, True, 300)]
+    want = [o.pack_weight(w, G, flip=f, T=T) for w, G, f, T in ws]
+    o.pack_many(ws + ws[:2])                         # duplicates are packed once
+    assert len(o._PREPACKED) == len(ws)
+    for (w, G, f, T), ref in zip(ws, want):
+        got = o.pack_weight(w, G, flip=f, T=T)
+        assert torch.equal(got, ref) and getattr(got, "nef_wino", False) == getattr(ref, "nef_wino", False)
+    assert not o._PREPACKED                          # consumed
+    other = g(rnd(128, 128, 3, seed=46))
+    assert torch.equal(o.pack_weight(other, 1, T=256), o.pack_weight(other, 1, T=256))
+    o.pack_many([])
+
+
 CONV_CASES = [  # K, G, Cig, Cog, T, B
     (7, 3, 128, 128, 128, 2), (7, 1, 128, 128, 300, 2), (7, 2, 128, 128, 125, 2),
     (3, 3, 128, 128, 125, 3), (3, 3, 64, 128, 130, 2), (1, 3, 64, 128, 125, 2), (1, 2, 128, 64, 70, 2),
