@@ -98,8 +98,10 @@ def _decoder_pack_requests(P, T_lat, flip):
 
 
 def _side(device):
-    if os.environ.get("NEF_SIDE_STREAM", "1") == "0" or torch.cuda.is_current_stream_capturing():
-        return ops._Inline()          # inside a hipGraph capture everything stays on the capturing stream
+    if os.environ.get("NEF_SIDE_STREAM", "1") == "0":
+        return ops._Inline()
+    if torch.cuda.is_current_stream_capturing() and os.environ.get("NEF_GRAPH_SIDE", "1") == "0":
+        return ops._Inline()          # NEF_GRAPH_SIDE=0: a captured step stays on the capturing stream
     return ops.SideStream.get(device)
 
 

@@ -96,12 +96,19 @@ class SideStream:
         """Run fn() on the side stream once everything enqueued so far on the current stream is done."""
         main = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(main)
+        capturing = torch.cuda.is_current_stream_capturing()
         with torch.cuda.stream(self.stream):
             out = fn()
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
+            if not capturing:
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+        if capturing:
+            # inside a hipGraph capture the fork / join become graph edges (the side kernels are parallel branches of the
+            # captured step); events cannot be polled there, so the inputs simply stay referenced until join()
+            self.pending.append((None, inputs))
+            return out
         self.pending.append((ev, inputs))
-        while self.pending and self.pending[0][0].query():
+        while self.pending and self.pending[0][0] is not None and self.pending[0][0].query():
             self.pending.pop(0)
         return out
 
