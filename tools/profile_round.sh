@@ -13,5 +13,7 @@ NEF_SIDE_STREAM=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/wr
 python tools/rocprof_summary.py $(find $O/one -name "*results.db" | head -1) $O/${R}_kernel_stats_serialized.md 4 > /dev/null
 python tools/rocprof_summary.py $(find $O/two -name "*results.db" | head -1) $O/${R}_kernel_stats.md 4 > /dev/null
 python tools/pmc_table.py $(find $O/fetch -name "*results.db" | head -1) $(find $O/write -name "*results.db" | head -1) $O/${R}_pmc_traffic.md $O/traffic.json > /dev/null 2> $O/pmc.err
+python tools/roofline_table.py $(find $O/one -name "*results.db" | head -1) $(find $O/fetch -name "*results.db" | head -1) $(find $O/write -name "*results.db" | head -1) $O/${R}_hbm_kernels.md 4 > /dev/null 2>> $O/pmc.err
+bash tools/pmc_sq.sh "enc k7" $R/sq > /dev/null 2>&1
 rm -rf $O/one $O/two $O/fetch $O/write
 ls -la $O
