@@ -32,10 +32,11 @@ _WS = {}
 # bench.py sets this to a list to collect (tag, start_event, end_event) around selected launches; the events are
 # recorded on the stream the kernel is launched on, so their difference is that kernel's device time.
 PROFILE = None
+PROFILE_ONLY = None     # optional predicate(tag): bracket only these launches (every event pair costs ~3 us of GPU idle)
 
 
 def _timed(tag):
-    if PROFILE is None:
+    if PROFILE is None or (PROFILE_ONLY is not None and not PROFILE_ONLY(tag)):
         return None
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     PROFILE.append((tag, s, e))
