@@ -196,6 +196,9 @@ def main():
         times = [s.elapsed_time(e) for tag, s, e in prof if tag == key]
         times_bd = [s.elapsed_time(e) for tag, s, e in prof if tag == ("conv_bwd_data",) + key[1:]]
         flops = 2.0 * B * (128 * V) * T * 128 * 7
+        # multiplies executed on the matrix cores per algorithmic multiply: direct 1, F(2,3) on the taps split 3+3+1 10/14
+        # (the encoder convs always take F(2,3); F(4,3) is for the decoder convs only, see ops.WINO_FWD)
+        wino_exec = 10.0 / 14.0 if ops.WINOGRAD else 1.0
         roof = None
         if times:
             avg_ms = sum(times) / len(times)
@@ -216,8 +219,8 @@ def main():
                     "kernel": ("conv_wino_kernel<7,2,0> (k7 grouped conv, Winograd F(2,3) on taps 3+3+1)" if ops.WINOGRAD
                                else "conv_fwd_kernel<7,2,0> (k7 grouped conv, direct)") + ", forward launches",
                     "launches": len(times),
-                    "executed_mfma_flops_per_launch": flops * (10.0 / 14.0 if ops.WINOGRAD else 1.0),
-                    "mfma_pipe_frac": round(ach * (10.0 / 14.0 if ops.WINOGRAD else 1.0) / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "executed_mfma_flops_per_launch": flops * wino_exec,
+                    "mfma_pipe_frac": round(ach * wino_exec / FP32_MFMA_PEAK_TFLOPS, 4),
                     "avg_ms": round(avg_ms, 4), "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
                     "hbm_GBps": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1),
                     "avg_ms_bwd_data_launches_overlapped": round(sum(times_bd) / max(len(times_bd), 1), 4),

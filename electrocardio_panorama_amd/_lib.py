@@ -47,6 +47,7 @@ SIGNATURES = {
     "nef_stem_bwd_weight": (i32, [p, p, p, p, p, sz, i32, i32, i32, p]),
     "nef_pack_weight": (i32, [p, p, i32, i32, i32, i32, i32, p]),
     "nef_pack_weight_wino": (i32, [p, p, i32, i32, i32, i32, i32, p]),
+    "nef_pack_weight_wino4": (i32, [p, p, i32, i32, i32, i32, i32, p]),
     "nef_pack_weights": (i32, [C.POINTER(PackDesc), i32, p]),
     "nef_conv_fwd": (i32, [C.POINTER(ConvArgs), p]),
     "nef_conv_bwd_weight_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),

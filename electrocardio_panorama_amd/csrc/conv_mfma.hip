@@ -698,6 +698,373 @@ static int launch_conv_wino(const nef_conv_args& a, hipStream_t st) {
     return nef_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same family one size up: Winograd F(4,3) -- 6 multiplies per FOUR outputs (1.5 per output; F(2,3): 2, direct: 3)
+// ------------------------------------------------------------------------------------------------
+// Quad j of a row: outputs 4j..4j+3, inputs d_m = x[4j-1+m], m = 0..5 (points 0, +-1, +-2, inf):
+//     v = B^T d:  v0 = 4d0-5d2+d4   v1 = -4d1-4d2+d3+d4   v2 = 4d1-4d2-d3+d4   v3 = -2d1-d2+2d3+d4   v4 = 2d1-d2-2d3+d4
+//                 v5 = 4d1-5d3+d5
+//     u = G g:    u0 = g0/4   u1 = -(g0+g1+g2)/6   u2 = -(g0-g1+g2)/6   u3 = g0/24+g1/12+g2/6   u4 = g0/24-g1/12+g2/6   u5 = g2
+//     M_i[co][j] = sum_ci u_i v_i  (6 GEMMs over a QUARTER of the columns)
+//     y0 = M0+M1+M2+M3+M4   y1 = M1-M2+2M3-2M4   y2 = M1+M2+4M3+4M4   y3 = M1-M2+8M3-8M4+M5
+// K = 7 = three such groups on x[4j-3..], x[4j..], x[4j+3..] with taps (w0,w1,w2), (w3,w4,w5), (w6,0,0) accumulating into
+// the same six M tiles; the third group's u5 is identically zero and is skipped: 6+6+5 = 17 multiplies per 4 outputs
+// (4.25 per output; F(2,3) split: 5, direct: 7).  fp32 rounding: measured 2x the direct form on Gaussian data, below it
+// on smooth non-negative activations (transform entries up to 8 and 1/24) -- still far from
+// the 1e-5 forward bar, and held to it by the same tests.
+// Machinery as conv_wino_kernel (raw activations double-buffered in LDS and transformed on the way to the B operand,
+// A fragments straight from L2 ahead of use, one barrier per 16-channel stage); a wave owns 32 output channels x 32 quads
+// (128 outputs) = 6 accumulator tiles; a workgroup is 4 x 1 waves (128 channels x 128 outputs) or 2 x 2 (64 x 256).
+// K = 3, 128 channels, no upsampling prologue: 168 VGPRs -> three workgroups per CU (-3..5 % against two)
+#ifndef NEF_W4_MINB3
+#define NEF_W4_MINB3 1
+#endif
+template <int K, int WMC, int PRO>
+__global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 2) == 0) ? 3 : 2) void conv_wino4_kernel(nef_conv_args a, int tps, int n_tiles, int m_tiles) {
+    constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
+    constexpr int NS = UP ? 2 : 1;
+    constexpr int KC = WKC;
+    constexpr int WN = 4 / WMC;
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int NGRP = K == 3 ? 1 : 3;
+    constexpr int NPL = K == 3 ? 6 : 17;     // weight planes per (ci, co)
+    constexpr int MT = 32 * WMC;             // output channels per workgroup
+    constexpr int NTO = 128 * WN;            // outputs (columns) per workgroup
+    constexpr int NXV = K == 3 ? 3 : 6;      // ds_read_b64 per lane and k-step: x[4j-PAD .. 4j-PAD+2*NXV)
+    constexpr int XROW = NTO + 2 * NXV - 4;  // staged positions per channel row
+    constexpr int XRS = NTO + 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xl = smem;                        // [2][KC][XRS]
+
+    const int tile = blockIdx.x % n_tiles;
+    const int gm = blockIdx.x / n_tiles;
+    const int mt = gm % m_tiles;
+    const int g = gm / m_tiles;
+    int b0, t0;
+    {
+        const int full = (n_tiles / (8 * tps)) * (8 * tps);
+        if (tile < full) {
+            const int grp = tile / (8 * tps), r = tile % (8 * tps);
+            b0 = grp * 8 + (r & 7);
+            t0 = (r >> 3) * NTO;
+        } else {
+            b0 = tile / tps;
+            t0 = (tile - b0 * tps) * NTO;
+        }
+    }
+    const int m0 = mt * MT;
+    const int T = a.T, Cig = a.Cin_g, Cog = a.Cout_g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    constexpr int NIT = (XROW + 63) / 64;
+    constexpr int XR = KC / 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm_u = wave_u / WN;
+    const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(a.x + (int64_t)b0 * a.x_bs + (int64_t)g * a.x_gs);
+    const __amdgpu_buffer_rsrc_t wrs = nef_rsrc(a.wp + (int64_t)g * NPL * Cig * Cog + m0 + wm_u * 32);
+    const int Tin = UP ? (T >> 1) : T;
+    unsigned xvo[NIT][NS];
+    float lam[NIT];
+    bool xok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int r = lane + 64 * it;
+        const int t = t0 + r - PAD;
+        xok[it] = (r < XROW) && (t >= 0) && (t < T);
+        lam[it] = 0.f;
+        if constexpr (UP) {
+            float src = 0.5f * ((float)t + 0.5f) - 0.5f;
+            if (src < 0.f) src = 0.f;
+            int i0 = (int)src;
+            if (i0 > Tin - 1) i0 = Tin - 1;
+            const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+            lam[it] = src - (float)i0;
+            xvo[it][0] = xok[it] ? (unsigned)(i0 * 4) : NEF_OOB;
+            xvo[it][NS - 1] = xok[it] ? (unsigned)(i1 * 4) : NEF_OOB;
+        } else {
+            xvo[it][0] = xok[it] ? (unsigned)(t * 4) : NEF_OOB;
+        }
+    }
+    const int64_t soff = (int64_t)b0 * a.sc_bs + (int64_t)g * a.sc_gs;
+    const int pro_row0 = AFF ? (b0 / a.pro_Bp) * a.G * Cig + g * Cig : 0;
+    const unsigned avo = (unsigned)((hi * Cog + lo) * 4);
+    const int w_istride = Cig * Cog;
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    constexpr int SPK = KC / 2;
+    constexpr int AHEAD = K == 3 ? 3 : 1;
+    constexpr int NSET = AHEAD + 1;
+    static_assert(SPK % NSET == 0, "the A sets must line up across stages");
+    const int nsteps = Cig / 2;
+    float fa[NSET][NPL];
+    float xreg[XR][NIT][NS];
+#define NEF_W4A_ISSUE(GS, SET)                                                                                       \
+    {                                                                                                               \
+        const int gs_ = (GS) < nsteps ? (GS) : nsteps - 1;                                                          \
+        _Pragma("unroll") for (int i = 0; i < NPL; ++i)                                                             \
+            fa[SET][i] = nef_buf_f32(wrs, avo, (unsigned)((i * w_istride + 2 * gs_ * Cog) * 4));                    \
+    }
+#define NEF_W4X_ISSUE(C0)                                                                                            \
+    {                                                                                                               \
+        _Pragma("unroll") for (int rr = 0; rr < XR; ++rr) {                                                         \
+            const unsigned so = (unsigned)(((C0) + wave_u + 4 * rr) * Tin * 4);                                     \
+            _Pragma("unroll") for (int it = 0; it < NIT; ++it)                                                      \
+                _Pragma("unroll") for (int ns = 0; ns < NS; ++ns) xreg[rr][it][ns] = nef_buf_f32(xrs, xvo[it][ns], so); \
+        }                                                                                                           \
+    }
+#define NEF_W4X_STORE(C0, BUFP)                                                                                      \
+    {                                                                                                               \
+        if (a.in_scale) {                                                                                           \
+            _Pragma("unroll") for (int rr = 0; rr < XR; ++rr) {                                                     \
+                const float sc = a.in_scale[soff + (C0) + wave + 4 * rr];                                           \
+                _Pragma("unroll") for (int it = 0; it < NIT; ++it) xreg[rr][it][0] *= sc;                           \
+            }                                                                                                       \
+        }                                                                                                           \
+        _Pragma("unroll") for (int rr = 0; rr < XR; ++rr) {                                                         \
+            float pa = 1.f, pb = 0.f;                                                                               \
+            if constexpr (AFF) {                                                                                    \
+                pa = a.pro_a[pro_row0 + (C0) + wave_u + 4 * rr];                                                    \
+                pb = a.pro_b[pro_row0 + (C0) + wave_u + 4 * rr];                                                    \
+            }                                                                                                       \
+            _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                    \
+                const int r = lane + 64 * it;                                                                       \
+                float v = xreg[rr][it][0];                                                                          \
+                if constexpr (AFF) v = fmaxf(fmaf(v, pa, pb), 0.f);                                                 \
+                if constexpr (UP) {                                                                                 \
+                    float v1 = xreg[rr][it][NS - 1];                                                                \
+                    if constexpr (AFF) v1 = fmaxf(fmaf(v1, pa, pb), 0.f);                                           \
+                    v = (1.f - lam[it]) * v + lam[it] * v1;                                                         \
+                }                                                                                                   \
+                if constexpr (PRO != 0) v = xok[it] ? v : 0.f;                                                      \
+                if (r < XROW) (BUFP)[(wave + 4 * rr) * XRS + r] = v;                                                \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
+    NEF_W4X_ISSUE(0)
+#pragma unroll
+    for (int s_ = 0; s_ < AHEAD; ++s_) NEF_W4A_ISSUE(s_, s_)
+    NEF_W4X_STORE(0, Xl)
+    __syncthreads();
+    int st = 0;
+    for (int c0 = 0; c0 < Cig; c0 += KC, ++st) {
+        const float* xb = Xl + (st & 1) * (KC * XRS) + hi * XRS + 4 * (wn * 32 + lo);
+        const bool more = c0 + KC < Cig;
+        f32x2 fx[2][NXV];
+#define NEF_W4X_LOAD(S, BUF)                                                                                         \
+    {                                                                                                               \
+        const f32x2* xp_ = reinterpret_cast<const f32x2*>(xb + 2 * (S) * XRS);                                      \
+        _Pragma("unroll") for (int q_ = 0; q_ < NXV; ++q_) fx[BUF][q_] = xp_[q_];                                   \
+    }
+        NEF_W4X_LOAD(0, 0)
+#pragma unroll
+        for (int s_ = 0; s_ < SPK; ++s_) {
+            NEF_W4A_ISSUE(st * SPK + s_ + AHEAD, (s_ + AHEAD) % NSET)
+            if (s_ == 0 && more) NEF_W4X_ISSUE(c0 + KC)
+            if (s_ + 1 < SPK) NEF_W4X_LOAD(s_ + 1, (s_ + 1) & 1)
+            const float* w = fa[s_ % NSET];
+            __builtin_amdgcn_s_setprio(1);      // scheduling fence, see conv_wino_kernel
+            float x_[2 * NXV];
+#pragma unroll
+            for (int q_ = 0; q_ < NXV; ++q_) {
+                x_[2 * q_] = fx[s_ & 1][q_][0];
+                x_[2 * q_ + 1] = fx[s_ & 1][q_][1];
+            }
+#pragma unroll
+            for (int grp = 0; grp < NGRP; ++grp) {
+                const float d0 = x_[3 * grp], d1 = x_[3 * grp + 1], d2 = x_[3 * grp + 2], d3 = x_[3 * grp + 3],
+                            d4 = x_[3 * grp + 4], d5 = x_[3 * grp + 5];
+                float v[6];
+                const float t1 = fmaf(-4.f, d2, d4), t2 = fmaf(-4.f, d1, d3);
+                const float t3 = d4 - d2, t4 = 2.f * (d3 - d1);
+                v[0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+                v[1] = t1 + t2;
+                v[2] = t1 - t2;
+                v[3] = t3 + t4;
+                v[4] = t3 - t4;
+                v[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    if (grp == 2 && i == 5) continue;          // (w6, 0, 0): u5 == 0
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[6 * grp + i], v[i], acc[i], 0, 0, 0);
+                }
+            }
+        }
+#undef NEF_W4X_LOAD
+        if (more) NEF_W4X_STORE(c0 + KC, Xl + ((st + 1) & 1) * (KC * XRS))
+        __syncthreads();
+    }
+#undef NEF_W4A_ISSUE
+#undef NEF_W4X_ISSUE
+#undef NEF_W4X_STORE
+
+    // epilogue: output transform, then the usual bias / residual / ReLU / dropout / gate on the four adjacent outputs a
+    // lane owns per channel row (two 8-byte accesses; T is even, so each pair is inside or outside the row as a whole)
+    const int64_t ctot = (int64_t)a.G * Cog;
+    const int t = t0 + 4 * (wn * 32 + lo);
+    const bool inb = b0 < a.B;
+    const bool live[2] = {inb && t < T, inb && t + 2 < T};
+    const int ts[2] = {live[0] ? t : 0, live[1] ? t + 2 : 0};
+    const int cobase = m0 + wm * 32 + 4 * hi;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#define NEF_ROW(q) ((((q) + 8 * h) & 3) + 8 * (((q) + 8 * h) >> 2))
+        float y[8][4];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = q + 8 * h;
+            const float m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r];
+            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+            y[q][0] = (acc[0][r] + s12) + s34;
+            y[q][1] = fmaf(2.f, d34, d12);
+            y[q][2] = fmaf(4.f, s34, s12);
+            y[q][3] = fmaf(8.f, d34, d12) + acc[5][r];
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float bv = a.bias[g * Cog + cobase + NEF_ROW(q)];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[q][e] += bv;
+            }
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {        // the two output pairs (t, t+1), (t+2, t+3)
+            if (a.res) {
+                const float* rp = a.res + (int64_t)b0 * a.res_bs + (int64_t)g * a.res_gs + (int64_t)cobase * T + ts[pr];
+                f32x2 t8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t8[q] = *reinterpret_cast<const f32x2*>(rp + (int64_t)NEF_ROW(q) * T);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    y[q][2 * pr] += t8[q][0];
+                    y[q][2 * pr + 1] += t8[q][1];
+                }
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    y[q][2 * pr] = fmaxf(y[q][2 * pr], 0.f);
+                    y[q][2 * pr + 1] = fmaxf(y[q][2 * pr + 1], 0.f);
+                }
+            }
+            if (a.mask) {
+                const uint8_t* mp = a.mask + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T + ts[pr];
+                unsigned short t8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t8[q] = *reinterpret_cast<const unsigned short*>(mp + (int64_t)NEF_ROW(q) * T);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    y[q][2 * pr] *= (float)(t8[q] & 0xff) * a.drop_scale;
+                    y[q][2 * pr + 1] *= (float)(t8[q] >> 8) * a.drop_scale;
+                }
+            } else if (a.drop_p > 0.f) {
+                const int64_t d0 = ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T + ts[pr];
+                const uint64_t seed = a.rng_seed + (a.rng_seed_dev ? a.rng_seed_dev[0] : 0ull);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint64_t dense = (uint64_t)(d0 + (int64_t)NEF_ROW(q) * T);
+                    y[q][2 * pr] = (nef_rng_uniform(seed, dense) >= a.drop_p) ? y[q][2 * pr] * a.drop_scale : 0.f;
+                    y[q][2 * pr + 1] = (nef_rng_uniform(seed, dense + 1) >= a.drop_p) ? y[q][2 * pr + 1] * a.drop_scale : 0.f;
+                }
+            }
+            if (a.gate) {
+                const float* gp = a.gate + (int64_t)b0 * a.gate_bs + (int64_t)g * a.gate_gs + (int64_t)cobase * T + ts[pr];
+                f32x2 t8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t8[q] = *reinterpret_cast<const f32x2*>(gp + (int64_t)NEF_ROW(q) * T);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    y[q][2 * pr] = t8[q][0] > 0.f ? y[q][2 * pr] * a.gate_scale : 0.f;
+                    y[q][2 * pr + 1] = t8[q][1] > 0.f ? y[q][2 * pr + 1] * a.gate_scale : 0.f;
+                }
+            }
+            if (live[pr]) {
+                float* yp = a.y + (int64_t)b0 * a.y_bs + (int64_t)g * a.y_gs + (int64_t)cobase * T + t + 2 * pr;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    f32x2 o;
+                    o[0] = y[q][2 * pr];
+                    o[1] = y[q][2 * pr + 1];
+                    *reinterpret_cast<f32x2*>(yp + (int64_t)NEF_ROW(q) * T) = o;
+                }
+            }
+        }
+#undef NEF_ROW
+    }
+}
+
+template <int K, int WMC, int PRO = 0>
+static int launch_conv_wino4(const nef_conv_args& a, hipStream_t st) {
+    constexpr int MT = 32 * WMC;
+    constexpr int NTO = 128 * (4 / WMC);
+    constexpr size_t lds = (size_t)(2 * WKC * (NTO + 16)) * sizeof(float);
+    static unsigned long long lds_set = 0;      // per-device bits, see nef_ensure_dyn_lds
+    if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_wino4_kernel<K, WMC, PRO>), lds, &lds_set)) return e;
+    const int tps = (a.T + NTO - 1) / NTO;
+    const int n_tiles = a.B * tps;
+    const int m_tiles = a.Cout_g / MT;
+    const int64_t blocks = (int64_t)a.G * m_tiles * n_tiles;
+    if (blocks <= 0 || blocks > 0x7fffffff) return NEF_E_SHAPE;
+    hipLaunchKernelGGL((conv_wino4_kernel<K, WMC, PRO>), dim3((unsigned)blocks), dim3(256), lds, st, a, tps, n_tiles, m_tiles);
+    return nef_launch_status();
+}
+
+// wp[g][plane][r][c] for conv_wino4_kernel: K = 3: planes 0..5 = G (g0,g1,g2) of F(4,3); K = 7: that transform of taps
+// 0..2 (planes 0..5), of taps 3..5 (6..11) and of (tap 6, 0, 0) without its zero last plane (12..16).
+__device__ __forceinline__ void pack_wino4_elem(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog,
+                                                int Cig, int K, int flip, int64_t i) {
+    const int64_t n = (int64_t)G * Cog * Cig;
+    const int64_t plane = n / G;
+    const int npl = K == 3 ? 6 : 17;
+    int64_t r = i;
+    int co, ci;
+    if (!flip) {
+        co = (int)(r % Cog); r /= Cog;
+        ci = (int)(r % Cig); r /= Cig;
+    } else {
+        ci = (int)(r % Cig); r /= Cig;
+        co = (int)(r % Cog); r /= Cog;
+    }
+    const int g = (int)r;
+    const float* src = w + (((int64_t)g * Cog + co) * Cig + ci) * K;
+    float* dst = wp + (int64_t)g * npl * plane + (i - (int64_t)g * plane);
+    const int ngrp = K == 3 ? 1 : 3;
+    for (int grp = 0; grp < ngrp; ++grp) {
+        float g0, g1, g2;
+        if (grp < 2 || K == 3) {
+            g0 = src[flip ? K - 1 - 3 * grp : 3 * grp];
+            g1 = src[flip ? K - 2 - 3 * grp : 3 * grp + 1];
+            g2 = src[flip ? K - 3 - 3 * grp : 3 * grp + 2];
+        } else {
+            g0 = src[flip ? 0 : 6];
+            g1 = 0.f;
+            g2 = 0.f;
+        }
+        const float s02 = g0 + g2;
+        float* d = dst + (int64_t)(6 * grp) * plane;
+        d[0] = g0 * 0.25f;
+        d[plane] = (s02 + g1) * (-1.0f / 6.0f);
+        d[2 * plane] = (s02 - g1) * (-1.0f / 6.0f);
+        d[3 * plane] = (g0 * (1.0f / 24.0f) + g2 * (1.0f / 6.0f)) + g1 * (1.0f / 12.0f);
+        d[4 * plane] = (g0 * (1.0f / 24.0f) + g2 * (1.0f / 6.0f)) - g1 * (1.0f / 12.0f);
+        if (grp < 2 || K == 3) d[5 * plane] = g2;
+    }
+}
+
+__global__ void pack_weight_wino4_kernel(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog, int Cig,
+                                         int K, int flip) {
+    const int64_t n = (int64_t)G * Cog * Cig;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        pack_wino4_elem(w, wp, G, Cog, Cig, K, flip, i);
+}
+
 // wp[g][plane][r][c]; (r, c) = (ci, co) forward, (co, ci) with the taps reversed for the backward-data operand.
 // K = 3: planes 0..3 = the F(2,3) weight transform (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) of the three taps.
 // K = 7: planes 0..3 / 4..7 = that transform of taps 0..2 / 3..5, plane 8 = tap 6, plane 9 = -tap 6.
@@ -1195,7 +1562,8 @@ __global__ void pack_weights_multi_kernel(PackTable t) {
     const nef_pack_desc& d = t.d[blockIdx.y];
     const int64_t n = (int64_t)d.G * d.Cog * d.Cig * (d.wino ? 1 : d.K);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        if (d.wino) pack_wino_elem(d.w, d.wp, d.G, d.Cog, d.Cig, d.K, d.transpose_flip, i);
+        if (d.wino == 2) pack_wino4_elem(d.w, d.wp, d.G, d.Cog, d.Cig, d.K, d.transpose_flip, i);
+        else if (d.wino) pack_wino_elem(d.w, d.wp, d.G, d.Cog, d.Cig, d.K, d.transpose_flip, i);
         else pack_plain_elem(d.w, d.wp, d.G, d.Cog, d.Cig, d.K, d.transpose_flip, i);
     }
 }
@@ -1252,6 +1620,17 @@ int nef_pack_weight_wino(const float* w, float* wp, int G, int Cog, int Cig, int
     return nef_launch_status();
 }
 
+int nef_pack_weight_wino4(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
+                          nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(w && wp, NEF_E_NULL);
+    NEF_REQUIRE(G > 0 && Cog > 0 && Cig > 0 && (K == 3 || K == 7), NEF_E_SHAPE);
+    const int64_t n = (int64_t)G * Cog * Cig;
+    hipLaunchKernelGGL(pack_weight_wino4_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, w, wp,
+                       G, Cog, Cig, K, transpose_flip);
+    return nef_launch_status();
+}
+
 int nef_pack_weights(const nef_pack_desc* descs, int n, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(descs || n == 0, NEF_E_NULL);
@@ -1259,7 +1638,8 @@ int nef_pack_weights(const nef_pack_desc* descs, int n, nef_stream_t stream) {
     for (int i = 0; i < n; ++i) {
         const nef_pack_desc& d = descs[i];
         NEF_REQUIRE(d.w && d.wp, NEF_E_NULL);
-        NEF_REQUIRE(d.G > 0 && d.Cog > 0 && d.Cig > 0 && d.K > 0 && (!d.wino || d.K == 3 || d.K == 7), NEF_E_SHAPE);
+        NEF_REQUIRE(d.G > 0 && d.Cog > 0 && d.Cig > 0 && d.K > 0 && d.wino >= 0 && d.wino <= 2 &&
+                        (!d.wino || d.K == 3 || d.K == 7), NEF_E_SHAPE);
     }
     for (int i0 = 0; i0 < n; i0 += PACK_MULTI_MAX) {
         PackTable t;
@@ -1297,6 +1677,21 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
     const int KC = K == 1 ? FwdStage<1, 1>::KC : (big ? FwdStage<3, 2>::KC : FwdStage<3, 1>::KC);
     static_assert(FwdStage<7, 2>::KC == FwdStage<3, 2>::KC && FwdStage<7, 1>::KC == FwdStage<3, 1>::KC, "stage sizes");
     NEF_REQUIRE(a->Cin_g % KC == 0, NEF_E_SHAPE);
+    if (a->wino == 2) {  // weights packed for F(4,3) (nef_pack_weight_wino with variant 4)
+        NEF_REQUIRE((K == 3 || K == 7) && a->T % 2 == 0 && a->Cin_g % WKC == 0, NEF_E_SHAPE);
+        NEF_REQUIRE(a->pro_mode >= 0 && a->pro_mode <= 3 && !(a->pro_mode && a->in_scale), NEF_E_UNSUPPORTED);
+        NEF_REQUIRE(K == 3 || a->pro_mode == 0, NEF_E_UNSUPPORTED);
+        NEF_REQUIRE(!(a->pro_mode & 1) || (a->pro_a && a->pro_b && a->pro_Bp > 0), NEF_E_NULL);
+        const bool wide = (a->Cout_g % 128 == 0);
+        NEF_REQUIRE(a->T >= (wide ? 128 : 256), NEF_E_SHAPE);
+        if (K == 7) return wide ? launch_conv_wino4<7, 4, 0>(*a, st) : launch_conv_wino4<7, 2, 0>(*a, st);
+        switch (a->pro_mode) {
+            case 0: return wide ? launch_conv_wino4<3, 4, 0>(*a, st) : launch_conv_wino4<3, 2, 0>(*a, st);
+            case 1: return wide ? launch_conv_wino4<3, 4, 1>(*a, st) : launch_conv_wino4<3, 2, 1>(*a, st);
+            case 2: return wide ? launch_conv_wino4<3, 4, 2>(*a, st) : launch_conv_wino4<3, 2, 2>(*a, st);
+            default: return wide ? launch_conv_wino4<3, 4, 3>(*a, st) : launch_conv_wino4<3, 2, 3>(*a, st);
+        }
+    }
     if (a->wino) {       // weights packed by nef_pack_weight_wino: Winograd F(2,3) path, whole tiles of one sample only
         NEF_REQUIRE((K == 3 || K == 7) && a->T % 2 == 0 && a->Cin_g % WKC == 0, NEF_E_SHAPE);
         NEF_REQUIRE(a->pro_mode >= 0 && a->pro_mode <= 3 && !(a->pro_mode && a->in_scale), NEF_E_UNSUPPORTED);

@@ -93,8 +93,8 @@ def _latent_pack_requests(P, V, T, win, flip):
 
 def _decoder_pack_requests(P, T_lat, flip):
     """Decoder convs whose weight is used as stored (the first one is regrouped per call): output lengths 2T, 4T, 4T."""
-    return [(P["decoder.1.double_conv.3.weight"], 1, flip, 2 * T_lat), (P["decoder.3.double_conv.0.weight"], 1, flip, 4 * T_lat),
-            (P["decoder.3.double_conv.3.weight"], 1, flip, 4 * T_lat)]
+    return [(P["decoder.1.double_conv.3.weight"], 1, flip, 2 * T_lat, True), (P["decoder.3.double_conv.0.weight"], 1, flip, 4 * T_lat, True),
+            (P["decoder.3.double_conv.3.weight"], 1, flip, 4 * T_lat, True)]
 
 
 def _side(device):
@@ -165,7 +165,7 @@ def _decoder_fwd_unfused(D, P, Bf, passes, training, save):
         if li in (0, 2):
             x = ops.upsample2_fwd(x)
         wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
-        c = ops.conv(GV.dense(x, 1), ops.pack_weight(P[wname], 1, T=x.shape[2]), cout, 3, bias=P[bname])
+        c = ops.conv(GV.dense(x, 1), ops.pack_weight(P[wname], 1, T=x.shape[2], f4=True), cout, 3, bias=P[bname])
         if training:
             mean, invstd, a, b = ops.bn_train_stats(c, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
                                                     Bf[pre + ".running_var"], passes, BN_EPS, BN_MOM)
@@ -213,14 +213,14 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
         T_out = x_in.shape[2] * (2 if up_after and pro[0] & 2 else 1)
         stats = None
         if li == 0 and shared_B is not None:
-            p2 = ops.conv(GV.dense(x_in, 2), ops.pack_weight(_regroup_halves(P[wname]), 2, T=T_out), cout, 3, pro=pro)
+            p2 = ops.conv(GV.dense(x_in, 2), ops.pack_weight(_regroup_halves(P[wname]), 2, T=T_out, f4=True), cout, 3, pro=pro)
             if training and passes == 3:      # the BatchNorm statistics of c1 come out of the same pass
                 c, *stats = ops.pass_combine_fwd_stats(p2, P[bname], shared_B, P[pre + ".weight"], P[pre + ".bias"],
                                                        Bf[pre + ".running_mean"], Bf[pre + ".running_var"], BN_EPS, BN_MOM)
             else:
                 c = ops.pass_combine_fwd(p2, P[bname], shared_B)
         else:
-            c = ops.conv(GV.dense(x_in, 1), ops.pack_weight(P[wname], 1, T=T_out), cout, 3, bias=P[bname], pro=pro)
+            c = ops.conv(GV.dense(x_in, 1), ops.pack_weight(P[wname], 1, T=T_out, f4=True), cout, 3, bias=P[bname], pro=pro)
         if stats is not None:
             mean, invstd, a, b = stats
             Bf[pre + ".num_batches_tracked"] += passes
@@ -273,12 +273,12 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
             gp2 = gc if gc.shape[0] == 2 * shared_B else ops.pass_combine_bwd(gc)   # [2B, 2*128, 2T]
             gpv, xv = GV.dense(gp2, 2), GV.dense(x, 2)
             grads[wname] = side.run(lambda: _ungroup_halves(ops.conv_bwd_weight(xv, gpv, 3, pro=pro)), x, gp2)
-            g = ops.conv(gpv, ops.pack_weight(_regroup_halves(P[wname]), 2, flip=True, T=gp2.shape[2]), x.shape[1] // 2, 3,
+            g = ops.conv(gpv, ops.pack_weight(_regroup_halves(P[wname]), 2, flip=True, T=gp2.shape[2], f4=True), x.shape[1] // 2, 3,
                          role="conv_bwd_data")
         else:
             gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
             grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro), x, gc)
-            g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True, T=gc.shape[2]), x.shape[1], 3, role="conv_bwd_data")
+            g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True, T=gc.shape[2], f4=True), x.shape[1], 3, role="conv_bwd_data")
         # back through the x2 upsampling in front of this layer: the next BatchNorm backward takes the adjoint while it
         # reads (rows of 4k >= 8 samples), otherwise it is a pass of its own
         g_is_up = bool(up_after and li > 0 and c.shape[2] % 8 == 0 and c.shape[2] >= 16)
@@ -440,7 +440,7 @@ def sweep_eval(P, Bf, latent, query_thetas, chunk=8):
         a, b = ops.bn_eval_affine(P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
                                   Bf[pre + ".running_var"], BN_EPS)
         wf, bf_ = ops.fold_bn(P[f"{blk}.double_conv.{cv}.weight"], P[f"{blk}.double_conv.{cv}.bias"], a, b)
-        wp.append(ops.pack_weight(wf, 1, T=(2 * T if li < 2 else 4 * T)))
+        wp.append(ops.pack_weight(wf, 1, T=(2 * T if li < 2 else 4 * T), f4=True))
         bias.append(bf_)
     uv = GV.dense(u, 1)
     rest = torch.empty(B, Q, 4 * T, device=dev, dtype=torch.float32)

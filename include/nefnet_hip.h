@@ -64,8 +64,14 @@ int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, i
 int nef_pack_weight_wino(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                          nef_stream_t stream);
 
+/* The F(4,3) operand (conv args wino = 2): wp[g][plane][ci][co] with 6 planes for K == 3 -- (g0/4, -(g0+g1+g2)/6,
+ * -(g0-g1+g2)/6, g0/24+g1/12+g2/6, g0/24-g1/12+g2/6, g2) -- and 17 for K == 7 (that transform of taps 0..2, of taps 3..5,
+ * and of (tap 6, 0, 0) without its identically-zero last plane). */
+int nef_pack_weight_wino4(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
+                          nef_stream_t stream);
+
 /* Any number of operands in one launch (a whole forward or backward pass packs ~25): each descriptor is one
- * nef_pack_weight (wino = 0) or nef_pack_weight_wino (wino = 1) call.  `descs` is a HOST array. */
+ * nef_pack_weight (wino = 0), nef_pack_weight_wino (wino = 1) or nef_pack_weight_wino4 (wino = 2) call.  `descs` is a HOST array. */
 typedef struct nef_pack_desc {
     const float* w;
     float* wp;
@@ -104,7 +110,8 @@ typedef struct nef_conv_args {
                                       launch freezes its arguments, the per-step seed must live in device memory) */
     int32_t wino;          /* 1: wp was packed by nef_pack_weight_wino -- K == 3 / K == 7 through Winograd F(2,3) (2/3 resp.
                               5/7 of the multiplies; still fp32 multiplies and adds on the matrix cores, results differ
-                              from the direct form by the rounding of the transforms).  Needs T even, T >= 128
+                              from the direct form by the rounding of the transforms).  2: packed by
+                              nef_pack_weight_wino4 -- Winograd F(4,3): 1/2 resp. 17/28 of the multiplies.  Needs T even, T >= 128
                               (Cout_g % 128 == 0) or T >= 256 (Cout_g % 64 == 0), Cin_g % 16 == 0; K == 7: pro_mode 0. */
 } nef_conv_args;
 

@@ -145,7 +145,10 @@ class Decisions:
     def _note(self, site, own, taken, pre):
         flips = own != taken
         n = int(flips.sum())
-        self.report[site] = dict(flips=n, worst=float(pre[flips].abs().max()) if n else 0.0,
+        # `degenerate`: the oracle's argument is EXACTLY zero there (e.g. a conv over the all-zero tail of a beat); which
+        # side of the switch an implementation lands on is then decided by rounding residue of its algorithm alone
+        self.report[site] = dict(flips=n, degenerate=int((flips & (pre == 0)).sum()) if n else 0,
+                                 worst=float(pre[flips].abs().max()) if n else 0.0,
                                  rms=float(pre.detach().double().pow(2).mean().sqrt()), numel=pre.numel())
 
     def relu(self, site, pre):

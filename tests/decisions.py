@@ -87,10 +87,15 @@ def gpu_decisions(model, outs, target, keep_masks=None, reg_l1=True, fold=None):
 
 
 def assert_flips_are_ties(dec):
+    """Replayed decisions that differ from the oracle's own must be ties: the oracle's argument within TIE_REL of the
+    switching point (relative to the site's rms) and -- unless that argument is EXACTLY zero -- rare.  Exact zeros are
+    the all-zero tail of a beat seen through a conv: the reference produces 0.0 there, a Winograd form whose quads
+    straddle the edge of the tail leaves +-1e-9 of rounding residue, and ReLU'(0) is a convention, not a value; such
+    positions carry no signal forward (the outputs are held to 1e-5 separately) and multiply zero activations backward."""
     for site, r in dec.report.items():
         if r["flips"] == 0:
             continue
-        assert r["flips"] <= TIE_FRAC * r["numel"] + 2, (site, r)
+        assert r["flips"] - r.get("degenerate", 0) <= TIE_FRAC * r["numel"] + 2, (site, r)
         assert r["worst"] <= TIE_REL * max(r["rms"], 1e-30), (site, r)
 
 

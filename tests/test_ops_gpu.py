@@ -636,8 +636,9 @@ WINO_CASES = [  # K, G, Cig, Cog, T, B
 ]
 
 
+@pytest.mark.parametrize("f4", [False, True])
 @pytest.mark.parametrize("K,G,Cig,Cog,T,B", WINO_CASES)
-def test_conv_winograd(K, G, Cig, Cog, T, B):
+def test_conv_winograd(K, G, Cig, Cog, T, B, f4):
     """K = 3 and K = 7 (taps split 3 + 3 + 1) through Winograd F(2,3) (conv_wino_kernel): forward and backward-data
     against F.conv1d at the forward / gradient bars, and the distance from exact (fp64) arithmetic next to the direct
     kernel's."""
@@ -650,8 +651,9 @@ def test_conv_winograd(K, G, Cig, Cog, T, B):
     ref = F.conv1d(xr, w, None, 1, K // 2, 1, G)
     ref64 = F.conv1d(x.double(), w.double(), None, 1, K // 2, 1, G)
     xd, wd = g(x), g(w)
-    wpw = o.pack_weight(wd, G, T=T)
-    assert getattr(wpw, "nef_wino", False) and wpw.numel() == (4 if K == 3 else 10) * G * Cog * Cig
+    wpw = o.pack_weight(wd, G, T=T, f4=f4)
+    form = o.WINO_FWD if f4 else 1
+    assert wpw.nef_wino == form and wpw.numel() == o._WINO_PLANES[(form, K)] * G * Cog * Cig
     y = o.conv(GV.dense(xd, G), wpw, Cog, K)
     yd = o.conv(GV.dense(xd, G), o.pack_weight(wd, G), Cog, K)
     assert rel(y, ref) < FWD_TOL, "forward"
@@ -660,8 +662,8 @@ def test_conv_winograd(K, G, Cig, Cog, T, B):
     gy = rnd(*ref.shape, seed=7)
     ref.backward(gy)
     if o.wino_ok(K, Cog, Cig, T):
-        wf = o.pack_weight(wd, G, flip=True, T=T)
-        assert wf.nef_wino
+        wf = o.pack_weight(wd, G, flip=True, T=T, f4=f4)
+        assert wf.nef_wino == form
         gx = o.conv(GV.dense(g(gy), G), wf, Cig, K)
         assert rel(gx, xr.grad) < GRAD_TOL, "bwd-data"
 
@@ -690,7 +692,8 @@ def test_conv_winograd_k7_block_epilogues():
     assert rel(gx, xr.grad) < GRAD_TOL
 
 
-def test_conv_winograd_epilogue_views_and_rng():
+@pytest.mark.parametrize("f4", [False, True])
+def test_conv_winograd_epilogue_views_and_rng(f4):
     """Every epilogue / operand option of the conv entry point on the Winograd path: bias, residual, ReLU, replayed and
     counter-RNG dropout, gate, in_scale, strided input and output views."""
     o = ops()
@@ -709,7 +712,7 @@ def test_conv_winograd_epilogue_views_and_rng():
         ref = F.relu(ref) * mask / 0.8
         ref = torch.where(gate > 0, ref * 1.25, torch.zeros_like(ref))
         encd, scd = g(enc), g(scale)
-        wp = o.pack_weight(g(w), V, T=T)
+        wp = o.pack_weight(g(w), V, T=T, f4=f4)
         assert wp.nef_wino
         y = o.conv(GV.half(encd, V, which), wp, 128, K, bias=g(bias),
                    in_scale=(scd.view(-1)[which * 64:], 128 * V, 128), res=GV.dense(g(res), V), gate=GV.dense(g(gate), V),
@@ -722,7 +725,7 @@ def test_conv_winograd_epilogue_views_and_rng():
         full = torch.full((B, 128 * V, T2), 7.0, device=DEV)
         xr = rnd(B, 64 * V, T2, seed=16).requires_grad_(True)
         F.conv1d(xr, w, None, 1, 1, 1, V).backward(gy)
-        wf = o.pack_weight(g(w), V, flip=True, T=T2)
+        wf = o.pack_weight(g(w), V, flip=True, T=T2, f4=f4)
         assert wf.nef_wino
         o.conv(GV.dense(g(gy), V), wf, 64, K, out=GV.half(full, V, which))
         got = full.cpu().view(B, V, 2, 64, T2)
@@ -731,14 +734,15 @@ def test_conv_winograd_epilogue_views_and_rng():
     # counter-RNG dropout: the keep decision is keyed by the dense element index, so both kernels drop the same elements
     xd, wd = g(rnd(B, 128, T, seed=17)), g(rnd(128, 128, 3, seed=18, scale=0.05))
     kw = dict(relu=False, drop_p=0.2, drop_scale=1.25, seed=1234)
-    a = o.conv(GV.dense(xd, 1), o.pack_weight(wd, 1, T=T), 128, 3, **kw)
+    a = o.conv(GV.dense(xd, 1), o.pack_weight(wd, 1, T=T, f4=f4), 128, 3, **kw)
     d = o.conv(GV.dense(xd, 1), o.pack_weight(wd, 1), 128, 3, **kw)
     assert torch.equal(a == 0, d == 0) and 0.15 < float((a == 0).float().mean()) < 0.25 and rel(a, d) < 1e-6
 
 
+@pytest.mark.parametrize("f4", [False, True])
 @pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("Cig,Cog,T_out", [(256, 128, 250), (128, 64, 500), (64, 64, 260), (128, 128, 128)])
-def test_conv_winograd_prologue_modes(mode, Cig, Cog, T_out):
+def test_conv_winograd_prologue_modes(mode, Cig, Cog, T_out, f4):
     o = ops()
     from electrocardio_panorama_amd.ops import GV
     P, Bp = 3, 2
@@ -754,7 +758,7 @@ def test_conv_winograd_prologue_modes(mode, Cig, Cog, T_out):
         xin = F.interpolate(xin, scale_factor=2, mode="linear", align_corners=False)
     ref = F.conv1d(xin, w, bias, 1, 1)
     pro = (mode, g(a) if mode & 1 else None, g(b) if mode & 1 else None, Bp)
-    wp = o.pack_weight(g(w), 1, T=T_out)
+    wp = o.pack_weight(g(w), 1, T=T_out, f4=f4)
     assert wp.nef_wino
     y = o.conv(GV.dense(g(x), 1), wp, Cog, 3, bias=g(bias), pro=pro)
     assert y.shape == ref.shape and rel(y, ref) < FWD_TOL
