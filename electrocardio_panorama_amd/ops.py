@@ -186,10 +186,13 @@ def stem_bwd_weight(x, w, gy):
 _WV = os.environ.get("NEF_WINOGRAD", "4")
 WINOGRAD = _WV != "0"
 # Forward / backward-data form where the caller allows the larger tile (`f4=True`: the decoder convs): 2 = F(4,3)
-# (default), 1 = F(2,3) everywhere (NEF_WINOGRAD=2).  The encoder-side convs always take F(2,3): their inputs end in the
-# all-zero tail of a beat, F(2,3) reproduces the reference's exact 0.0 there (every product feeding an output only sees
-# that output's own receptive field), F(4,3) leaves +-1e-9 of residue whose sign then decides ReLU gates that the
-# reference has closed -- measurable in the stem's weight gradient (3.7e-4 on the 3-step parameter trajectory).
+# (default), 1 = F(2,3) everywhere (NEF_WINOGRAD=2).  The encoder-side convs always take F(2,3), for two measured reasons:
+# (1) their inputs end in the all-zero tail of a beat; F(2,3) reproduces the reference's exact 0.0 there (every product
+# feeding an output only sees that output's own receptive field), F(4,3) leaves +-1e-9 of residue whose sign then
+# opens ReLU gates the reference keeps closed (705 of 512 k decisions in one block); (2) with that repaired by an
+# exact-zero fix-up in the kernel (built, 255 VGPRs), the larger rounding of F(4,3) still moved the stem's weights --
+# a heavily cancelling gradient -- by 3.7e-4 over the 3-step reference trajectory (bar 2e-4), and the fixed-up kernel
+# was no faster than F(2,3) (1.31 vs 1.33 ms on the K=7 conv).
 WINO_FWD = 1 if _WV in ("1", "2") else 2
 _WINO_PLANES = {(1, 3): 4, (1, 7): 10, (2, 3): 6, (2, 7): 17}
 
