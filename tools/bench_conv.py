@@ -26,7 +26,7 @@ for name, K, G, Cig, Cog, B, T in SHAPES:
     w = torch.randn(G * Cog, Cig, K, device="cuda") * 0.05
     gy = torch.randn(B, G * Cog, T, device="cuda")
     wp = ops.pack_weight(w, G)
-    wpw = ops.pack_weight(w, G, T=T)
+    wpw = ops.pack_weight(w, G, T=T, f4=os.environ.get("F4", "1") == "1")      # F4=0: the F(2,3) form
     flops = 2.0 * B * G * Cog * T * Cig * K
     for what in ("fwd", "wino", "bwd_w", "bwd_ww"):
         if what == "wino" and not getattr(wpw, "nef_wino", False):
