@@ -205,6 +205,48 @@ __global__ void mix_bwd_kernel(const float* __restrict__ gD, const float* __rest
         const float* g0 = gD + row * (UP ? 2 * T : T);
         const int64_t gpass = UP ? 2 * pass : pass;
         float acc = 0.f;
+        if (UP && SHARED && (T & 1) == 0 && T >= 8) {
+            // Vector path of the train step's launch (two passes, x2 adjoint, T even): a lane owns two consecutive
+            // positions (t, t+1), t even: the 2T-long gradient rows are read as one 16-byte word g[2t..2t+3] plus the two
+            // neighbours, everything else as 8-byte words.  Same expressions as the scalar path below (gz1 / gz2r are
+            // bit-identical; gq sums the same terms in a different lane order); the first and the last pair contain an edge
+            // position and take the scalar formulas.
+            const float* g1r = g0 + gpass;
+            for (int p = lane; p < T / 2; p += 64) {
+                const int t = 2 * p;
+                float ga[2], gb[2];
+                if (p == 0 || p == T / 2 - 1) {
+                    ga[0] = up2_adjoint(g0, T, t); ga[1] = up2_adjoint(g0, T, t + 1);
+                    gb[0] = up2_adjoint(g1r, T, t); gb[1] = up2_adjoint(g1r, T, t + 1);
+                } else {
+                    const nef_f32x4 a4 = *(const nef_f32x4*)(g0 + 2 * t), b4 = *(const nef_f32x4*)(g1r + 2 * t);
+                    const float al = g0[2 * t - 1], ar = g0[2 * t + 4], bl = g1r[2 * t - 1], br = g1r[2 * t + 4];
+                    ga[0] = 0.25f * al + 0.75f * a4[0] + 0.75f * a4[1] + 0.25f * a4[2];
+                    ga[1] = 0.25f * a4[1] + 0.75f * a4[2] + 0.75f * a4[3] + 0.25f * ar;
+                    gb[0] = 0.25f * bl + 0.75f * b4[0] + 0.75f * b4[1] + 0.25f * b4[2];
+                    gb[1] = 0.25f * b4[1] + 0.75f * b4[2] + 0.75f * b4[3] + 0.25f * br;
+                }
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const f2 l2 = *(const f2*)(lat + t);
+                const f2 pk2 = *(const f2*)(zsrc + (int64_t)pick_v * 128 * T + t);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) acc += ga[e] * l2[e] + gb[e] * pk2[e];
+                for (int v = 0; v < V; ++v) {
+                    f2 o;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) o[e] = f * ga[e] / fv + (v == pick_v ? f * gb[e] : 0.f);
+                    if (relu_z1 && first) {
+                        const f2 z = *(const f2*)(zsrc + (int64_t)v * 128 * T + t);
+                        if (!(z[0] > 0.f)) o[0] = 0.f;
+                        if (!(z[1] > 0.f)) o[1] = 0.f;
+                    }
+                    *(f2*)(gdst + (int64_t)v * 128 * T + t) = o;
+                }
+            }
+            acc = nef_wave_sum(acc);
+            if (lane == 0) gq[row] = acc;
+            continue;
+        }
         for (int t = lane; t < T; t += 64) {
             float ga, gb, gc;
             if (UP) {
