@@ -135,76 +135,164 @@ __device__ __forceinline__ void lerp_src(int i, float scale, int& i0, int& i1, f
     l0 = 1.f - l1;
 }
 
-// one wave per (b, c) row of the output; zseg [B][C][7][32] -> out [B][C][T]
+// one wave per (b, c) row of the output; zseg [B][C][7][32] -> out [B][C][T].
+// The pass is VALU-bound, not HBM-bound (PMC: 1.7e8 vector instructions for 1.2e8 outputs in the first version, which
+// searched the segment of every output with a 7-way select chain): the wave therefore walks the row SEGMENT BY SEGMENT --
+// the segment's offset, length and scale are wave-uniform (scalar registers), a lane only evaluates lerp_src for its
+// own output and gathers two of the segment's 32 samples.
 __global__ void roi_unpool_fwd_kernel(const float* __restrict__ zseg, const int64_t* __restrict__ rois,
                                       float* __restrict__ out, int32_t* __restrict__ status, int B, int C, int T) {
     const int64_t rows = (int64_t)B * C;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    // a wave takes a contiguous run of rows: they mostly belong to one sample, whose segment table (about 70 vector
+    // instructions per segment: i64 <-> f32 conversions and a division) is then derived once, not once per row
+    const int64_t per_wave = (rows + (int64_t)gridDim.x * 4 - 1) / ((int64_t)gridDim.x * 4);
+    const int64_t row_lo = ((int64_t)blockIdx.x * 4 + wave) * per_wave;
+    const int64_t row_hi = row_lo + per_wave < rows ? row_lo + per_wave : rows;
+    int b_cur = -1;
+    SegTable st;
+    for (int64_t row = row_lo; row < row_hi; ++row) {
         const int b = (int)(row / C);
-        SegTable st;
-        const bool ok = load_segments(rois + (int64_t)b * NSEG * 2, T, st);
-        if (!ok && status && lane == 0) status[0] = 1;
+        if (b != b_cur) {
+            b_cur = b;
+            const bool ok = load_segments(rois + (int64_t)b * NSEG * 2, T, st);
+            if (!ok && status && lane == 0) status[0] = 1;
+        }
         const float* zr = zseg + row * NSEG * SEGW;
         float* orow = out + row * T;
-        for (int t = lane; t < T; t += 64) {
-            // the last segment whose offset is <= t (zero-length segments share an offset and are skipped)
-            int j = 0, off_j = st.off[0], len_j = st.len[0];
-            float sc_j = st.scale[0];
+        // the row's 7 x 32 samples live in four registers of the wave (sample e in register e / 64, lane e % 64); the two
+        // taps of an output come over the cross-lane network (ds_bpermute) instead of two dependent memory gathers
+        float r[4];
 #pragma unroll
-            for (int k = 1; k < NSEG; ++k)
-                if (t >= st.off[k]) { j = k; off_j = st.off[k]; len_j = st.len[k]; sc_j = st.scale[k]; }
-            float v = 0.f;
-            const int i = t - off_j;
-            if (i < len_j) {
+        for (int q = 0; q < 4; ++q) r[q] = (q * 64 + lane < NSEG * SEGW) ? zr[q * 64 + lane] : 0.f;
+        int covered = 0;
+#pragma unroll
+        for (int j = 0; j < NSEG; ++j) {
+            const int len = st.len[j], off = st.off[j];
+            const float sc = st.scale[j];
+            const float reg = r[j >> 1];
+            const int base = (j & 1) * SEGW;
+            for (int ib = 0; ib < len; ib += 64) {                 // wave-uniform trip count: every lane feeds the shuffles
+                const int i = ib + lane;
                 int i0, i1;
                 float l0, l1;
-                lerp_src(i, sc_j, i0, i1, l0, l1);
-                v = l0 * zr[j * SEGW + i0] + l1 * zr[j * SEGW + i1];
+                lerp_src(i, sc, i0, i1, l0, l1);
+                const float v0 = __shfl(reg, base + i0), v1 = __shfl(reg, base + i1);
+                if (i < len) orow[off + i] = l0 * v0 + l1 * v1;
             }
-            orow[t] = v;
+            covered = off + len;
         }
+        for (int t = covered + lane; t < T; t += 64) orow[t] = 0.f;     // segments that do not reach T (flagged in status)
     }
 }
 
-// gather form of the transpose: lane s of segment j collects the outputs that read sample s
-__global__ void roi_unpool_bwd_kernel(const float* __restrict__ gout, const int64_t* __restrict__ rois,
-                                      float* __restrict__ gzseg, int B, int C, int T) {
+// first output i in [0, len] of a segment whose source index i0(i) reaches s (i0 is non-decreasing in i): the closed form
+// of lerp_src's `scale*(i+0.5)-0.5 >= s`, then corrected by evaluating lerp_src itself around the guess, so that the
+// transpose partitions the outputs exactly as the forward assigned them whatever the rounding of the closed form.
+// lerp_src's left tap alone (its clamp to 31 does not matter against s <= 31)
+__device__ __forceinline__ int unpool_left_tap(int i, float scale) {
+    float src = scale * ((float)i + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    return (int)src;
+}
+
+__device__ __forceinline__ int unpool_first_reaching(int s, int len, float scale, float inv_scale) {
+    if (s <= 0) return 0;
+    int i = (int)ceilf(((float)s + 0.5f) * inv_scale - 0.5f);
+    if (i < 0) i = 0;
+    if (i > len) i = len;
+    // the closed form and the forward's rounded expression can disagree by one position when the boundary falls within
+    // rounding of an integer: one verified step either way ...
+    if (i > 0 && unpool_left_tap(i - 1, scale) >= s) --i;
+    else if (i < len && unpool_left_tap(i, scale) < s) ++i;
+    // ... and, should that ever not be enough, the plain search (never taken in practice; keeps the partition exact)
+    if ((i > 0 && unpool_left_tap(i - 1, scale) >= s) || (i < len && unpool_left_tap(i, scale) < s)) {
+#pragma nounroll
+        while (i > 0 && unpool_left_tap(i - 1, scale) >= s) --i;
+#pragma nounroll
+        while (i < len && unpool_left_tap(i, scale) < s) ++i;
+    }
+    return i;
+}
+
+// gather form of the transpose: lane s of segment j collects the outputs that read sample s:
+//   gz[j][s] = sum_{i: i0(i)=s} l0(i) g[i] + sum_{i: i1(i)=s} l1(i) g[i],  {i0 = s} = [first(s), first(s+1)),
+//   {i1 = s} = {i0 = s-1} (plus {i0 = 31} for s = 31, where i1 is clamped) -- two short contiguous ranges instead of a
+//   widened candidate window with a test per candidate (VALU-bound before: 985 vector instructions per element).
+// STAGED = true: the wave first streams its gradient row into a private LDS strip (coalesced, all loads in flight at
+// once), then gathers from LDS -- the strided global gathers of the direct form are latency-bound (PMC: 60 % of wave
+// cycles parked).  STAGED = false reads the row in place and serves rows too long for the strip (T > 4096).
+template <bool STAGED>
+__global__ __launch_bounds__(256) void roi_unpool_bwd_kernel(const float* __restrict__ gout,
+                                                             const int64_t* __restrict__ rois,
+                                                             float* __restrict__ gzseg, int B, int C, int T) {
+    extern __shared__ float strip_lds[];
     const int64_t rows = (int64_t)B * C;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int s = lane & (SEGW - 1), half = lane >> 5;          // two segments per trip: lanes 0..31 and 32..63
+    const int64_t per_wave = (rows + (int64_t)gridDim.x * 4 - 1) / ((int64_t)gridDim.x * 4);     // see the forward
+    const int64_t row_lo = ((int64_t)blockIdx.x * 4 + wave) * per_wave;
+    const int64_t row_hi = row_lo + per_wave < rows ? row_lo + per_wave : rows;
+    int b_cur = -1;
+    SegTable st;
+    for (int64_t row = row_lo; row < row_hi; ++row) {
         const int b = (int)(row / C);
-        SegTable st;
-        load_segments(rois + (int64_t)b * NSEG * 2, T, st);
-        const float* gr = gout + row * T;
-        float* gz = gzseg + row * NSEG * SEGW;
-        for (int e = lane; e < NSEG * SEGW; e += 64) {
-            const int j = e / SEGW, s = e % SEGW;
-            int len = st.len[0], off_j = st.off[0];
-            float sc = st.scale[0];
+        if (b != b_cur) {
+            b_cur = b;
+            load_segments(rois + (int64_t)b * NSEG * 2, T, st);
+        }
+        const float* grow = gout + row * T;
+        const float* gr = grow;
+        if constexpr (STAGED) {
+            float* strip = strip_lds + wave * T;
+            for (int t0 = 0; t0 < T; t0 += 64 * 5) {
+                float v[5];
 #pragma unroll
-            for (int k = 1; k < NSEG; ++k)
-                if (j == k) { len = st.len[k]; off_j = st.off[k]; sc = st.scale[k]; }
+                for (int u = 0; u < 5; ++u) v[u] = (t0 + u * 64 + lane < T) ? grow[t0 + u * 64 + lane] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 5; ++u)
+                    if (t0 + u * 64 + lane < T) strip[t0 + u * 64 + lane] = v[u];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            gr = strip;
+        }
+        float* gz = gzseg + row * NSEG * SEGW;
+#pragma unroll
+        for (int jj = 0; jj < NSEG + 1; jj += 2) {
+            const int j = jj + half;
+            if (j >= NSEG) continue;
+            const int len = half ? st.len[jj + 1 < NSEG ? jj + 1 : jj] : st.len[jj];
+            const int off = half ? st.off[jj + 1 < NSEG ? jj + 1 : jj] : st.off[jj];
+            const float sc = half ? st.scale[jj + 1 < NSEG ? jj + 1 : jj] : st.scale[jj];
             float acc = 0.f;
             if (len > 0) {
-                // outputs whose source lies in (s-1, s+1): i in ((s-.5)len/32 - .5, (s+1.5)len/32 - .5), widened by 2
-                const float r = (float)len / (float)SEGW;
-                int lo = (int)floorf(((float)s - 0.5f) * r - 0.5f) - 2;
-                int hi = (int)ceilf(((float)s + 1.5f) * r - 0.5f) + 2;
-                if (lo < 0) lo = 0;
-                if (hi > len - 1) hi = len - 1;
-                if (s == 0) lo = 0;
-                for (int i = lo; i <= hi; ++i) {
-                    int i0, i1;
-                    float l0, l1;
-                    lerp_src(i, sc, i0, i1, l0, l1);
-                    const float g = gr[off_j + i];
-                    if (i0 == s) acc += l0 * g;
-                    if (i1 == s) acc += l1 * g;
+                const int b0 = unpool_first_reaching(s, len, sc, (float)len * (1.f / SEGW));
+                const int nb = __shfl_down(b0, 1), pb = __shfl_up(b0, 1);   // neighbours lie in the same 32-lane half
+                const int b1 = s + 1 < SEGW ? nb : len;
+                const int a0 = s > 0 ? pb : b0;
+                // outputs in [a0, b0) read s as their RIGHT tap: weight l1 = src - (s - 1), in [0, 1) without a clamp because
+                // their left tap is s - 1; outputs in [b0, b1) read it as their LEFT tap: weight l0 = 1 - (src - s) -- and at
+                // s = 31 the right tap is clamped onto the left one, the two weights add up to 1.  src is lerp_src's
+                // expression term for term ((float)i + 0.5f is exact, so the running fi below is too).
+                const float* gp = gr + off;
+                float fi = (float)a0 + 0.5f;
+                const float sm1 = (float)(s - 1);
+                for (int i = a0; i < b0; ++i, fi += 1.f) {
+                    float src = sc * fi - 0.5f;
+                    src = src < 0.f ? 0.f : src;
+                    acc += (src - sm1) * gp[i];
+                }
+                const float c0 = s == SEGW - 1 ? 1.f : (float)(s + 1), k = s == SEGW - 1 ? 0.f : 1.f;
+                for (int i = b0; i < b1; ++i, fi += 1.f) {
+                    float src = sc * fi - 0.5f;
+                    src = src < 0.f ? 0.f : src;
+                    acc += (c0 - k * src) * gp[i];
                 }
             }
-            gz[e] = acc;
+            gz[j * SEGW + s] = acc;
         }
+        if constexpr (STAGED) __builtin_amdgcn_wave_barrier();     // the strip is rewritten by the next row
     }
 }
 
@@ -265,8 +353,12 @@ int nef_roi_unpool_bwd(const float* gout, const int64_t* rois, float* gzseg, int
     NEF_ENTER();
     NEF_REQUIRE(gout && rois && gzseg, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
-    hipLaunchKernelGGL(roi_unpool_bwd_kernel, dim3(nef_stream_grid((int64_t)B * C, 4)), dim3(256), 0, NEF_ST, gout,
-                       rois, gzseg, B, C, T);
+    const dim3 grid(nef_stream_grid((int64_t)B * C, 4));
+    if (T <= 4096)
+        hipLaunchKernelGGL(roi_unpool_bwd_kernel<true>, grid, dim3(256), (size_t)4 * T * sizeof(float), NEF_ST, gout,
+                           rois, gzseg, B, C, T);
+    else
+        hipLaunchKernelGGL(roi_unpool_bwd_kernel<false>, grid, dim3(256), 0, NEF_ST, gout, rois, gzseg, B, C, T);
     return nef_launch_status();
 }
 

@@ -1,7 +1,8 @@
 // Stem of the per-lead encoder, fused: Conv1d(1->128 per lead, k15, s2, p7, no bias) -> ReLU -> MaxPool1d(3,2,1).
 // Replaces reference codes/network/encoder/encoder.py:35-38 (conv1/relu/maxpool built at
 // codes/network/encoder/resnet_1d.py:102-105).  HBM-bound (AI ~7 FLOP/B): the [B,128V,L/2] conv output is never
-// materialised; the backward recomputes it from the 19-sample input window each lane already holds.
+// materialised; the backward recomputes it from the 19-sample input window each lane already holds.  (In practice
+// the two kernels are bound by vector-instruction issue -- see the note above stem_fwd_kernel.)
 #include "nef_common.h"
 
 namespace {
@@ -21,6 +22,12 @@ __device__ __forceinline__ void load_window(const float* __restrict__ xrow, int 
     }
 }
 
+// Both kernels are bound by vector instructions, not by HBM (PMC: the SIMDs issue every cycle), so the conv value a
+// pooled output shares with its neighbour is computed once: c(2tp-1) of lane tp IS c(2tp+1) of lane tp-1 -- same taps, same
+// samples, same FMA order, hence the same bits -- and comes over the cross-lane network.  A tile therefore carries one
+// halo lane on the left (lane 0 computes, does not store): FWD_TP useful outputs per 64 lanes, 30 instead of 45 FMAs each.
+constexpr int FWD_TP = TP - 1;
+
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        float* __restrict__ y, int B, int V, int L, int T,
                                                        int tiles_per_row) {
@@ -35,14 +42,14 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
         wl[i] = k < KW ? w[(v * CPL + co) * KW + k] : 0.f;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tp = tile * TP + lane;
+    const int tp = tile * FWD_TP + lane - 1;
     float xw[19];
     load_window(x + ((int64_t)b * V + v) * L, L, tp, xw);
     __syncthreads();
-    if (tp >= T) return;
     const int Lc = L / 2;
     const bool has_l = (2 * tp - 1) >= 0;        // pool padding: window positions outside [0, Lc) are -inf
     const bool has_r = (2 * tp + 1) < Lc;
+    const bool owns = lane > 0 && tp < T;
     float* yrow = y + ((int64_t)b * V * CPL + (int64_t)v * CPL) * T + tp;
     for (int co = wave; co < CPL; co += 4) {
         const float4* w4 = reinterpret_cast<const float4*>(wl + co * 16);
@@ -52,25 +59,31 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             const float4 t4 = w4[q];
             wk[4 * q] = t4.x; wk[4 * q + 1] = t4.y; wk[4 * q + 2] = t4.z; wk[4 * q + 3] = t4.w;
         }
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int k = 0; k < KW; ++k) {
-            c0 = fmaf(wk[k], xw[k], c0);        // j = 2tp-1 : x[4tp-9+k]
             c1 = fmaf(wk[k], xw[k + 2], c1);    // j = 2tp   : x[4tp-7+k]
             c2 = fmaf(wk[k], xw[k + 4], c2);    // j = 2tp+1 : x[4tp-5+k]
         }
+        const float c0 = __shfl_up(c2, 1);      // j = 2tp-1 : the left neighbour's j = 2(tp-1)+1
         float m = fmaxf(c1, 0.f);
         if (has_l) m = fmaxf(m, fmaxf(c0, 0.f));
         if (has_r) m = fmaxf(m, fmaxf(c2, 0.f));
-        yrow[(int64_t)co * T] = m;
+        if (owns) yrow[(int64_t)co * T] = m;
     }
 }
 
 // Backward wrt the conv weight.  A workgroup owns 16 channels of one lead (4 per wave) and a strided share of the
 // (sample, time-tile) space; each lane keeps 4x15 partial sums, reduced across the wave once at the end.
+// The gradient is routed to the conv output the pool selected and accumulated PER CONV OUTPUT j, each owned by one lane
+// (j = 2tp and j = 2tp+1; what the right neighbour routes to its j = 2tp'-1 arrives over the cross-lane network), so a
+// pooled output costs 30 FMAs for the recomputed conv values and 30 for the accumulation instead of 45 + 15 + 30
+// selects.  Lane 0 is a left halo (supplies c(2tp+1)), lane 63 a right halo (supplies its routed gradient): BW_TP useful
+// outputs per 64 lanes.
 constexpr int BW_CPW = 4;                  // channels per wave
 constexpr int BW_CPB = 4 * BW_CPW;         // channels per workgroup
 constexpr int BW_SPLIT = 64;
+constexpr int BW_TP = TP - 2;
 
 __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ gy, float* __restrict__ part,
@@ -98,22 +111,23 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
     const int n_units = B * tiles_per_row;
     for (int unit = split; unit < n_units; unit += BW_SPLIT) {
         const int b = unit / tiles_per_row;
-        const int tp = (unit - b * tiles_per_row) * TP + lane;
+        const int tp = (unit - b * tiles_per_row) * BW_TP + lane - 1;
         float xw[19];
         load_window(x + ((int64_t)b * V + v) * L, L, tp, xw);
-        if (tp >= T) continue;
+        const bool valid = tp >= 0 && tp < T;
+        const bool owns = valid && lane > 0 && lane < 63;
         const bool has_l = (2 * tp - 1) >= 0;
         const bool has_r = (2 * tp + 1) < Lc;
 #pragma unroll
         for (int c = 0; c < BW_CPW; ++c) {
-            const float g = gy[((int64_t)b * V * CPL + ch0 + c) * T + tp];
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+            const float g = valid ? gy[((int64_t)b * V * CPL + ch0 + c) * T + tp] : 0.f;
+            float c1 = 0.f, c2 = 0.f;
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
-                c0 = fmaf(wk[c][k], xw[k], c0);
                 c1 = fmaf(wk[c][k], xw[k + 2], c1);
                 c2 = fmaf(wk[c][k], xw[k + 4], c2);
             }
+            const float c0 = __shfl_up(c2, 1);
             // arg-max over the pool window in scan order (first maximum wins), then the ReLU gate
             float best = has_l ? fmaxf(c0, 0.f) : -INFINITY;
             float pre = c0;
@@ -127,10 +141,13 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
                 if (r2 > best) { best = r2; sel = 2; pre = c2; }
             }
             const float ge = pre > 0.f ? g : 0.f;
+            const float from_right = __shfl_down(sel == 0 ? ge : 0.f, 1);      // the neighbour's j = 2tp'-1 is my 2tp+1
+            const float g1 = owns && sel == 1 ? ge : 0.f;
+            const float g2 = owns ? (sel == 2 ? ge : 0.f) + from_right : 0.f;
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
-                const float xv = sel == 0 ? xw[k] : (sel == 1 ? xw[k + 2] : xw[k + 4]);
-                acc[c][k] = fmaf(ge, xv, acc[c][k]);
+                acc[c][k] = fmaf(g1, xw[k + 2], acc[c][k]);
+                acc[c][k] = fmaf(g2, xw[k + 4], acc[c][k]);
             }
         }
     }
@@ -160,7 +177,7 @@ int nef_stem_fwd(const float* x, const float* w, float* y, int B, int V, int L, 
     NEF_REQUIRE(x && w && y, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && V > 0 && L >= 4 && L % 4 == 0, NEF_E_SHAPE);
     const int T = L / 4;
-    const int tiles = (T + TP - 1) / TP;
+    const int tiles = (T + FWD_TP - 1) / FWD_TP;
     hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)((int64_t)B * V * tiles)), dim3(256), 0, (hipStream_t)stream, x,
                        w, y, B, V, L, T, tiles);
     return nef_launch_status();
@@ -175,7 +192,7 @@ int nef_stem_bwd_weight(const float* x, const float* w, const float* gy, float* 
     NEF_REQUIRE(B > 0 && V > 0 && L >= 4 && L % 4 == 0, NEF_E_SHAPE);
     NEF_REQUIRE(ws_bytes >= nef_stem_bwd_ws_bytes(V), NEF_E_WORKSPACE);
     const int T = L / 4;
-    const int tiles = (T + TP - 1) / TP;
+    const int tiles = (T + BW_TP - 1) / BW_TP;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(stem_bwd_weight_kernel, dim3((unsigned)(BW_SPLIT * V * (CPL / BW_CPB))), dim3(256), 0, st, x, w,
                        gy, (float*)ws, B, V, L, T, tiles);

@@ -280,7 +280,7 @@ def test_roi_backward_and_status():
     from oracle import nefnet_oracle as orc
     from electrocardio_panorama_amd import synth
     rng = np.random.default_rng(3)
-    for L in (512, 1000, 5000):
+    for L in (512, 1000, 5000, 20000):        # 20000: rows longer than the transpose's LDS strip (in-place variant)
         B, C, T = 3, 5, L // 4
         rois = torch.from_numpy(synth.make_rois(rng, B, L))
         z = rnd(B, C, T, seed=28).requires_grad_(True)
