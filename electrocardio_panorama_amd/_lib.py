@@ -30,6 +30,7 @@ class ConvArgs(C.Structure):
         ("B", i32), ("T", i32), ("G", i32), ("Cin_g", i32), ("Cout_g", i32), ("K", i32),
         ("relu", i32), ("gate_scale", f32), ("drop_scale", f32), ("drop_p", f32), ("rng_seed", C.c_uint64),
         ("pro_a", p), ("pro_b", p), ("pro_mode", i32), ("pro_Bp", i32), ("rng_seed_dev", p), ("wino", i32),
+        ("stats", p),
     ]
 
 
@@ -93,6 +94,8 @@ SIGNATURES = {
     "nef_upsample2_aff_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, p]),
     "nef_bn_ws_bytes": (sz, [i32, i32]),
     "nef_bn_train_stats": (i32, [p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, f32, f32, p]),
+    "nef_conv_stats_slots": (i32, [i32, i32]),
+    "nef_bn_stats_from_slots": (i32, [p, i32, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, f32, f32, p]),
     "nef_bn_eval_affine": (i32, [p, p, p, p, p, p, i32, f32, p]),
     "nef_fold_bn": (i32, [p, p, p, p, p, p, i32, i32, p]),
     "nef_affine_relu_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, p]),

@@ -912,6 +912,7 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
     const bool live[2] = {inb && t < T, inb && t + 2 < T};
     const int ts[2] = {live[0] ? t : 0, live[1] ? t + 2 : 0};
     const int cobase = m0 + wm * 32 + 4 * hi;
+    float sv[32];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #define NEF_ROW(q) ((((q) + 8 * h) & 3) + 8 * (((q) + 8 * h) >> 2))
@@ -997,6 +998,36 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
             }
         }
 #undef NEF_ROW
+        if (a.stats) {          // this lane's share of the slot sums: its (up to) four live outputs of each of its 8 rows
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float y0 = live[0] ? y[q][0] : 0.f, y1 = live[0] ? y[q][1] : 0.f;
+                const float y2 = live[1] ? y[q][2] : 0.f, y3 = live[1] ? y[q][3] : 0.f;
+                sv[2 * (q + 8 * h)] = (y0 + y1) + (y2 + y3);
+                sv[2 * (q + 8 * h) + 1] = fmaf(y0, y0, y1 * y1) + fmaf(y2, y2, y3 * y3);
+            }
+        }
+    }
+    if (a.stats) {
+        // 32 values (16 rows x {sum, sum of squares}) summed over the 32 lanes that share `hi`: a halving butterfly -- each
+        // step a lane passes on the half it does not keep, 16+8+4+2+1 shuffles instead of 32 x 5 -- after which lane `lo`
+        // holds the slot total of value `lo` = 2*r + {0,1}, row r = q + 8h.  Fixed order: deterministic.
+#pragma unroll
+        for (int step = 0; step < 5; ++step) {
+            const int off = 16 >> step;
+            const bool up = (lo & off) != 0;
+#pragma unroll
+            for (int i = 0; i < off; ++i) {
+                const float send = up ? sv[i] : sv[i + off];
+                const float keep = up ? sv[i + off] : sv[i];
+                sv[i] = keep + __shfl_xor(send, off, 64);
+            }
+        }
+        const int r = lo >> 1;
+        const int ch = g * Cog + cobase + (r & 3) + 8 * (r >> 2);
+        const int64_t nslot = (int64_t)tps * WN;
+        const int64_t slot = (int64_t)b0 * nslot + (int64_t)(t0 / NTO) * WN + wn;
+        if (inb) a.stats[((int64_t)ch * a.B * nslot + slot) * 2 + (lo & 1)] = sv[0];
     }
 }
 
@@ -1596,7 +1627,7 @@ constexpr int CHAN_SUM_SPLIT = 16;
 
 extern "C" {
 
-int nef_abi_version(void) { return 8; }
+int nef_abi_version(void) { return 9; }
 
 int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                     nef_stream_t stream) {
@@ -1665,6 +1696,7 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
     NEF_REQUIRE(K == 1 || K == 3 || K == 7, NEF_E_SHAPE);
     NEF_REQUIRE(a->Cout_g % 64 == 0 && a->Cin_g > 0, NEF_E_SHAPE);
     hipStream_t st = (hipStream_t)stream;
+    NEF_REQUIRE(!a->stats || a->wino == 2, NEF_E_UNSUPPORTED);       // only the F(4,3) epilogue leaves the slot sums
     bool big = (a->Cout_g % 128 == 0);
     if (big) {
         // small problems (reference-native batch 32, L=512): a 128-row tile gives fewer workgroups than the chip has
@@ -1726,6 +1758,14 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
         case 3: return big ? launch_conv_fwd<3, 2>(*a, st) : launch_conv_fwd<3, 1>(*a, st);
         default: return big ? launch_conv_fwd<1, 2>(*a, st) : launch_conv_fwd<1, 1>(*a, st);
     }
+}
+
+int nef_conv_stats_slots(int T, int Cout_g) {
+    if (T <= 0 || T % 2 != 0 || Cout_g <= 0 || Cout_g % 64 != 0) return 0;
+    const bool wide = (Cout_g % 128 == 0);
+    if (T < (wide ? 128 : 256)) return 0;
+    const int nto = wide ? 128 : 256;                    // columns per workgroup; a slot is one wave's 128 of them
+    return ((T + nto - 1) / nto) * (nto / 128);
 }
 
 size_t nef_conv_bwd_weight_ws_bytes(int B, int T, int G, int Cin_g, int Cout_g, int K) {

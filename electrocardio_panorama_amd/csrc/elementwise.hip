@@ -1212,6 +1212,27 @@ __global__ __launch_bounds__(256) void bn_rows_reduce(const double* __restrict__
     }
 }
 
+// tot[(p*C + c)*2 + q] = sum over the slots of pass p of slots[c][p*per_pass + i][q] (the conv epilogue's fp32 slot sums,
+// nef_conv_args.stats), in fp64 and in a fixed order
+__global__ __launch_bounds__(256) void bn_slots_reduce(const float* __restrict__ slots, double* __restrict__ tot, int P,
+                                                       int C, int per_pass) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x % C, p = blockIdx.x / C;
+    const float2* src = (const float2*)slots + ((int64_t)c * P + p) * per_pass;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < per_pass; i += 256) {
+        const float2 v = src[i];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+    }
+    s1 = nef_block_sum_d(s1, sm);
+    s2 = nef_block_sum_d(s2, sm);
+    if (threadIdx.x == 0) {
+        tot[((int64_t)p * C + c) * 2] = s1;
+        tot[((int64_t)p * C + c) * 2 + 1] = s2;
+    }
+}
+
 // adjoint: gP2 A-half[mean] = g0 + g2, A-half[pick] = g1, B-half[mean] = g0 + g1, B-half[pick] = g2
 __global__ __launch_bounds__(256) void pass_combine_bwd_kernel(const float* __restrict__ gc1, float* __restrict__ gP2,
                                                                int B, int C, int L) {
@@ -1410,6 +1431,22 @@ int nef_bn_train_stats(const float* x, const float* gamma, const float* beta, fl
     hipLaunchKernelGGL(bn_stats_partial, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, x, (double*)ws, P, Bp, C, L);
     hipLaunchKernelGGL(bn_stats_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)ws, gamma, beta,
                        running_mean, running_var, mean, invstd, a, b, P, Bp, C, L, eps, momentum, BN_SPLIT);
+    return nef_launch_status();
+}
+
+int nef_bn_stats_from_slots(const float* slots, int nslot, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float* mean, float* invstd, float* a, float* b, void* ws,
+                            size_t ws_bytes, int P, int Bp, int C, int L, float eps, float momentum,
+                            nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(slots && gamma && beta && mean && invstd && a && b && ws, NEF_E_NULL);
+    NEF_REQUIRE(P > 0 && Bp > 0 && C > 0 && L > 0 && nslot > 0 && (int64_t)Bp * L > 1 &&
+                    (int64_t)Bp * nslot <= 0x7FFFFFFF && (int64_t)P * C <= 0x7FFFFFFF, NEF_E_SHAPE);
+    NEF_REQUIRE(ws_bytes >= nef_bn_ws_bytes(P, C), NEF_E_WORKSPACE);
+    hipLaunchKernelGGL(bn_slots_reduce, dim3((unsigned)(P * C)), dim3(256), 0, NEF_ST, slots, (double*)ws, P, C,
+                       Bp * nslot);
+    hipLaunchKernelGGL(bn_stats_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)ws, gamma, beta,
+                       running_mean, running_var, mean, invstd, a, b, P, Bp, C, L, eps, momentum, 1);
     return nef_launch_status();
 }
 

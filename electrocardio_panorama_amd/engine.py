@@ -21,6 +21,9 @@ BN_EPS, BN_MOM = 1e-5, 0.1
 # round 2 with the Winograd kernels: 60.2 ms/step against 58.8 ms/step with the materialised tensor -- stays off.
 _FUSE_L2 = os.environ.get("NEF_FUSE_L2", "0") == "1"
 
+# NEF_FUSE_STATS=0: BatchNorm statistics by a pass over the conv output (nef_bn_train_stats) instead of the conv epilogue
+_FUSE_STATS = os.environ.get("NEF_FUSE_STATS", "1") == "1"
+
 DROPOUT_SITES = ("W_encoder.layer1.0", "W_encoder.layer1.1", "W_encoder.layer1.2", "w_conv.0", "z1_conv.0",
                  "z2_conv1.0", "z2_conv2.0", "z2_conv2.2")
 
@@ -220,7 +223,13 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
             else:
                 c = ops.pass_combine_fwd(p2, P[bname], shared_B)
         else:
-            c = ops.conv(GV.dense(x_in, 1), ops.pack_weight(P[wname], 1, T=T_out, f4=True), cout, 3, bias=P[bname], pro=pro)
+            wp = ops.pack_weight(P[wname], 1, T=T_out, f4=True)
+            # train mode: the F(4,3) epilogue leaves the BatchNorm slot sums of c -- no statistics pass over c
+            slots = ops.conv_stats_buffer(wp, N, 1, cout, T_out, D.device) if (training and _FUSE_STATS) else None
+            c = ops.conv(GV.dense(x_in, 1), wp, cout, 3, bias=P[bname], pro=pro, stats=slots)
+            if slots is not None:
+                stats = ops.bn_stats_from_slots(slots, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
+                                                Bf[pre + ".running_var"], passes, N, T_out, BN_EPS, BN_MOM)
         if stats is not None:
             mean, invstd, a, b = stats
             Bf[pre + ".num_batches_tracked"] += passes

@@ -264,12 +264,38 @@ def pack_weight(w, G, flip=False, T=None, f4=False):
     return wp
 
 
+def conv_stats_buffer(wp, B, G, Cog, T_out, device):
+    """(slots tensor, slots per sample) for conv(..., stats=...) -- or None when the conv would not run on the F(4,3)
+    kernel, whose epilogue is the one that leaves the BatchNorm slot sums."""
+    if int(getattr(wp, "nef_wino", 0)) != 2:
+        return None
+    nslot = _lib.load().nef_conv_stats_slots(T_out, Cog)
+    if nslot <= 0:
+        return None
+    return torch.empty(G * Cog, B * nslot, 2, device=device, dtype=torch.float32), nslot
+
+
+def bn_stats_from_slots(stats, gamma, beta, running_mean, running_var, P, N, Ln, eps=1e-5, momentum=0.1):
+    """bn_train_stats from the slot sums a conv epilogue left (x [N, C, Ln] itself is not read)."""
+    L = _lib.load()
+    slots, nslot = stats
+    Ct = slots.shape[0]
+    mean, invstd, a, b = (torch.empty(P, Ct, device=slots.device, dtype=torch.float32) for _ in range(4))
+    n = L.nef_bn_ws_bytes(P, Ct)
+    ws = workspace(n, slots.device)
+    _lib.check(L.nef_bn_stats_from_slots(_p(slots), nslot, _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(mean),
+                                         _p(invstd), _p(a), _p(b), _p(ws), n, P, N // P, Ct, Ln, eps, momentum, _stream()),
+               "nef_bn_stats_from_slots")
+    return mean, invstd, a, b
+
+
 def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None, gate_scale=1.0, relu=False,
-         mask=None, drop_p=0.0, drop_scale=1.0, seed=0, role="conv_fwd", pro=None, seed_dev=None):
+         mask=None, drop_p=0.0, drop_scale=1.0, seed=0, role="conv_fwd", pro=None, seed_dev=None, stats=None):
     """out = epilogue(conv1d(prologue(x) * in_scale, w) + bias + res).  `xv`, `res`, `gate`, `out` are GV views;
     `in_scale` is (tensor, batch_stride, group_stride).  `pro` = (mode, a, b, Bp): input prologue applied while
     staging -- bit0 BatchNorm affine + ReLU with a/b [P, C_in], bit1 x2 linear upsampling of a half-resolution input
-    (the output is then 2*xv.T long).  Returns the output tensor."""
+    (the output is then 2*xv.T long).  `stats`: a conv_stats_buffer() the epilogue fills with the per-slot sum and sum
+    of squares of the outputs.  Returns the output tensor."""
     L = _lib.load()
     T_out = xv.T * 2 if (pro is not None and pro[0] & 2) else xv.T
     if out is None:
@@ -296,6 +322,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     a.gate_scale, a.drop_scale, a.drop_p, a.rng_seed = gate_scale, drop_scale, drop_p, seed
     a.rng_seed_dev = _p(seed_dev)
     a.wino = int(getattr(wp, "nef_wino", 0))
+    a.stats = _p(stats[0]) if stats is not None else None
     ev = _timed((role, K, xv.G, xv.Cg, Cog, xv.B, T_out))
     _lib.check(L.nef_conv_fwd(C.byref(a), _stream()), "nef_conv_fwd")
     if ev is not None:

@@ -113,6 +113,11 @@ typedef struct nef_conv_args {
                               from the direct form by the rounding of the transforms).  2: packed by
                               nef_pack_weight_wino4 -- Winograd F(4,3): 1/2 resp. 17/28 of the multiplies.  Needs T even, T >= 128
                               (Cout_g % 128 == 0) or T >= 256 (Cout_g % 64 == 0), Cin_g % 16 == 0; K == 7: pro_mode 0. */
+    float* stats;          /* NULL, or (wino == 2 only) the epilogue also leaves, per output channel and per 128-column slot
+                              of a sample, the sum and the sum of squares of the final outputs of that slot:
+                              stats[(ch * B * nslot + b * nslot + slot) * 2 + {0,1}], ch = g*Cout_g + co, nslot =
+                              nef_conv_stats_slots(T, Cout_g) -- the train-mode BatchNorm statistics of the conv output
+                              (model_nefnet.py:19,22) without a second pass over it; finished by nef_bn_stats_from_slots */
 } nef_conv_args;
 
 /* y = epilogue(conv(x * in_scale, wp) + bias + res).  Also the bwd-data pass (pack with transpose_flip=1,
@@ -270,6 +275,14 @@ int nef_upsample2_aff_fwd(const float* x, const float* a, const float* b, float*
  *   gx_chan_sum != NULL, gx_chan_sum[c] = sum_{b,t} gx (the bias gradient of the conv that feeds this BN), fused into
  *   the same pass.  ws: nef_bn_bwd_ws_bytes(P, Bp, C). */
 size_t nef_bn_ws_bytes(int P, int C);
+/* Slots per sample of nef_conv_args.stats (0: the F(4,3) kernel does not take this shape), and the statistics pass that
+ * replaces nef_bn_train_stats when the producing conv left them: same outputs (fp64 from the slot sums on, fixed
+ * order), x is not read.  slots: [C][P*Bp*nslot][2] floats.  ws: nef_bn_ws_bytes(P, C). */
+int nef_conv_stats_slots(int T, int Cout_g);
+int nef_bn_stats_from_slots(const float* slots, int nslot, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float* mean, float* invstd, float* a, float* b, void* ws,
+                            size_t ws_bytes, int P, int Bp, int C, int L, float eps, float momentum,
+                            nef_stream_t stream);
 int nef_bn_train_stats(const float* x, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, float* mean, float* invstd, float* a, float* b, void* ws, size_t ws_bytes,
                        int P, int Bp, int C, int L, float eps, float momentum, nef_stream_t stream);

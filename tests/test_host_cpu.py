@@ -23,8 +23,8 @@ def test_header_symbols_exported():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().nef_abi_version() == 8
-    assert ctypes.sizeof(_lib.ConvArgs) == 232
+    assert _lib.load().nef_abi_version() == 9
+    assert ctypes.sizeof(_lib.ConvArgs) == 240
 
 
 def test_rejects_bad_calls_without_touching_the_gpu():

@@ -515,6 +515,38 @@ def test_shared_first_conv_pieces():
         assert rel(rm2, rm1) < 1e-6 and rel(rv2, rv1) < 1e-6
 
 
+@pytest.mark.parametrize("B,Cin,Cout,T,pro", [(6, 128, 128, 300, 1), (6, 128, 64, 600, 0), (3, 64, 64, 514, 1),
+                                              (6, 256, 128, 128, 2)])
+def test_conv_epilogue_bn_slot_sums(B, Cin, Cout, T, pro):
+    """The F(4,3) conv epilogue's slot sums (nef_conv_args.stats) + nef_bn_stats_from_slots against nef_bn_train_stats on
+    the conv output: same mean / invstd / affine / running statistics (three passes), ragged last tile included."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    if o.WINO_FWD != 2:
+        pytest.skip("F(4,3) switched off (NEF_WINOGRAD)")
+    Tin = T // 2 if pro & 2 else T
+    x, w, bias = g(rnd(B, Cin, Tin, seed=180)), g(rnd(Cout, Cin, 3, seed=181, scale=0.05)), g(rnd(Cout, seed=182))
+    gamma, beta = g(rnd(Cout, seed=183) + 1.2), g(rnd(Cout, seed=184, scale=0.3))
+    rm0, rv0 = rnd(Cout, seed=185) * 0.1, rnd(Cout, seed=186).abs() + 0.5
+    pa, pb = g(rnd(3, Cin, seed=187) * 0.5 + 1.0), g(rnd(3, Cin, seed=188) * 0.2)
+    prol = (pro, pa, pb, B // 3) if pro & 1 else (pro, None, None, 1)
+    wp = o.pack_weight(w, 1, T=T, f4=True)
+    slots = o.conv_stats_buffer(wp, B, 1, Cout, T, x.device)
+    assert slots is not None and slots[0].shape == (Cout, B * slots[1], 2)
+    slots[0].fill_(float("nan"))                     # every slot must be written
+    c = o.conv(GV.dense(x, 1), wp, Cout, 3, bias=bias, pro=prol, stats=slots)
+    c_plain = o.conv(GV.dense(x, 1), wp, Cout, 3, bias=bias, pro=prol)
+    assert torch.equal(c, c_plain)
+    rm1, rv1, rm2, rv2 = g(rm0), g(rv0), g(rm0), g(rv0)
+    want = o.bn_train_stats(c, gamma, beta, rm1, rv1, 3)
+    got = o.bn_stats_from_slots(slots, gamma, beta, rm2, rv2, 3, B, T)
+    for a_, b_ in zip(got, want):
+        assert rel(a_, b_) < 1e-6
+    assert rel(rm2, rm1) < 1e-6 and rel(rv2, rv1) < 1e-6
+    # the other conv kernels do not leave slot sums: the boundary says so instead of ignoring the request
+    assert o.conv_stats_buffer(o.pack_weight(w, 1, T=T), B, 1, Cout, T, x.device) is None
+
+
 def test_bn_relu_bwd_combine3_equals_two_calls():
     o = ops()
     Bp, C, L = 2, 16, 301
