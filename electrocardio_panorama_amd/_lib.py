@@ -56,6 +56,8 @@ SIGNATURES = {
     "nef_conv_bwd_weight_pro": (i32, [p, i64, i64, p, p, i32, i32, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32, i32, p]),
     "nef_conv_bwd_weight_wino": (i32, [p, i64, i64, p, i64, i64, p, p, i32, i32, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32,
                                        i32, p]),
+    "nef_conv_bwd_weight_wino4": (i32, [p, i64, i64, p, i64, i64, p, p, i32, i32, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32,
+                                        i32, p]),
     "nef_chan_sum_ws_bytes": (sz, [i32]),
     "nef_chan_sum": (i32, [p, p, p, sz, i32, i32, i32, p]),
     "nef_convt2_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, i32, p]),
@@ -83,6 +85,7 @@ SIGNATURES = {
     "nef_mix_fwd": (i32, [p, p, p, p, p, i32, i32, i32, i32, i32, p, p]),
     "nef_mix_bwd": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, i32, p]),
     "nef_mix_fwd_shared": (i32, [p, p, p, p, p, i32, i32, i32, i32, i32, p, p]),
+    "nef_lead_mean_mix_shared": (i32, [p, p, p, p, p, i32, i32, i32, i32, i32, p, p]),
     "nef_mix_bwd_shared_up": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, i32, p]),
     "nef_pass_combine_fwd": (i32, [p, p, p, i32, i32, i32, p]),
     "nef_pass_combine_bwd": (i32, [p, p, i32, i32, i32, p]),

@@ -1166,7 +1166,8 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
     // LDS row pitches: odd for the transposed ds_read_b32 of the direct form; = 2 (mod 32) for the ds_read_b64 of WINO
     constexpr int GYS = WINO ? 66 : WT + 1;
     constexpr int XS = WINO ? (K == 3 ? 66 : 98) : ((WT + (WT / 16) * (K - 1)) | 1);
-    constexpr int NACC = WINO ? (K == 3 ? 4 : 9) : K;
+    constexpr int NACC = WINO == 2 ? 6 : (WINO ? (K == 3 ? 4 : 9) : K);
+    static_assert(WINO != 2 || K == 3, "the F(3,4) form is for three taps");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* GYl = smem;               // [MT][GYS]
     float* Xl = smem + MT * GYS;     // [CIT][XS]
@@ -1336,7 +1337,58 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
         }
         __syncthreads();
         if (tile + S < n_tiles) NEF_BW_ISSUE(tile + S)
-        if constexpr (WINO) {
+        if constexpr (WINO == 2) {
+            // transposed F(3,4): 8 reduction steps per 64-column tile, each over two output QUADS (MFMA k = quad): a lane
+            // reads its gY row's quad (two aligned 8-byte words) and its X row's six inputs x[4j-1 .. 4j+4] (three), one
+            // step ahead of use; 6 MFMAs per 8 columns where F(3,2) issues 8 and the direct form 12
+            constexpr int NSTEP = WT / 8;
+            const float* ga = GYl + (wco * 32 + lo) * GYS + 4 * hi;
+            const float* xb = Xl + ((wci * TCI) * 32 + lo) * XS + 4 * hi;
+            f32x2 fg[2][2], fx[2][TCI][3];
+#define NEF_BW4_LOAD(S_, BUF)                                                                                        \
+    {                                                                                                               \
+        fg[BUF][0] = *reinterpret_cast<const f32x2*>(ga + 8 * (S_));                                                \
+        fg[BUF][1] = *reinterpret_cast<const f32x2*>(ga + 8 * (S_) + 2);                                            \
+        _Pragma("unroll") for (int i = 0; i < TCI; ++i)                                                             \
+            _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_)                                                        \
+                fx[BUF][i][q_] = *reinterpret_cast<const f32x2*>(xb + i * 32 * XS + 8 * (S_) + 2 * q_);             \
+    }
+            NEF_BW4_LOAD(0, 0)
+#pragma unroll
+            for (int s_ = 0; s_ < NSTEP; ++s_) {
+                if (s_ + 1 < NSTEP) NEF_BW4_LOAD(s_ + 1, (s_ + 1) & 1)
+                const float g0 = fg[s_ & 1][0][0], g1 = fg[s_ & 1][0][1], g2 = fg[s_ & 1][1][0], g3 = fg[s_ & 1][1][1];
+                float u[6];
+                {
+                    const float e02 = g0 + g2, e13 = g1 + g3;
+                    const float f02 = fmaf(4.f, g2, g0), f13 = 2.f * fmaf(4.f, g3, g1);
+                    u[0] = g0;
+                    u[1] = e02 + e13;
+                    u[2] = e02 - e13;
+                    u[3] = f02 + f13;
+                    u[4] = f02 - f13;
+                    u[5] = g3;
+                }
+#pragma unroll
+                for (int i = 0; i < TCI; ++i) {
+                    const f32x2* d = fx[s_ & 1][i];
+                    const float d0 = d[0][0], d1 = d[0][1], d2 = d[1][0], d3 = d[1][1], d4 = d[2][0], d5 = d[2][1];
+                    float v[6];
+                    const float t1 = fmaf(-4.f, d2, d4), t2 = fmaf(-4.f, d1, d3);
+                    const float t3 = d4 - d2, t4 = 2.f * (d3 - d1);
+                    v[0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+                    v[1] = t1 + t2;
+                    v[2] = t1 - t2;
+                    v[3] = t3 + t4;
+                    v[4] = t3 - t4;
+                    v[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+#pragma unroll
+                    for (int n = 0; n < 6; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[n], v[n], acc[i][n], 0, 0, 0);
+                }
+            }
+#undef NEF_BW4_LOAD
+        } else if constexpr (WINO) {
             // 16 reduction steps per 64-column tile, each over two output pairs (MFMA k = pair): a lane reads its gY row's
             // pair and its X row's 4 (K = 3) or 8 (K = 7) inputs as aligned 8-byte words, one step ahead of use
             constexpr int NXV = K == 3 ? 2 : 4;
@@ -1439,7 +1491,13 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int co = m0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 float v;
-                if constexpr (WINO) {
+                if constexpr (WINO == 2) {      // gW = G^T M with the F(4,3) filter-transform matrix G
+                    const float s12 = acc[i][1][r] + acc[i][2][r], d12 = acc[i][1][r] - acc[i][2][r];
+                    const float s34 = acc[i][3][r] + acc[i][4][r], d34 = acc[i][3][r] - acc[i][4][r];
+                    v = (k == 0) ? fmaf(0.25f, acc[i][0][r], fmaf(s34, 1.f / 24.f, -s12 * (1.f / 6.f)))
+                      : (k == 1) ? fmaf(d34, 1.f / 12.f, -d12 * (1.f / 6.f))
+                                 : (s34 - s12) * (1.f / 6.f) + acc[i][5][r];
+                } else if constexpr (WINO) {
                     if (k == 6) {
                         v = acc[i][NACC - 1][r];
                     } else {
@@ -1490,15 +1548,17 @@ struct BwdWeightPlan {
 };
 
 static bool plan_bwd_weight(int B, int T, int G, int Cig, int Cog, int K, BwdWeightPlan* p, int pro_mode = 0,
-                            bool wino = false) {
+                            int wino = 0) {
     if (!(K == 1 || K == 3 || K == 7)) return false;
     if (Cog % 128 == 0) p->wco = 4;
     else if (Cog % 64 == 0) p->wco = 2;
     else return false;
+    if (wino == 2 && getenv("NEF_BW4_WCO2")) p->wco = 2;
     const int wci = 4 / p->wco;
     p->tci = (K <= 3 && Cig % (64 * wci) == 0) ? 2 : 1;
     if (pro_mode != 0 && p->wco == 2) p->tci = 1;      // keep the doubled staging registers within budget
     if (wino && p->wco == 2) p->tci = 1;               // 4 accumulator tiles per ci tile: same budget
+    if (wino == 2) p->tci = 1;                         // F(3,4): 6 accumulator tiles per ci tile
     const int cit = 32 * p->tci * wci;
     if (Cig % cit != 0) return false;
     p->m_tiles = Cog / (32 * p->wco);
@@ -1857,7 +1917,7 @@ int nef_conv_bwd_weight_wino(const float* x, int64_t x_bs, int64_t x_gs, const f
     NEF_REQUIRE(pro_mode >= 0 && pro_mode <= 3 && (K == 3 || pro_mode == 0) && !(pro_mode && in_scale), NEF_E_UNSUPPORTED);
     NEF_REQUIRE(!(pro_mode & 1) || (pro_a && pro_b && pro_Bp > 0), NEF_E_NULL);
     BwdWeightPlan p;
-    NEF_REQUIRE(plan_bwd_weight(B, T, G, Cin_g, Cout_g, K, &p, pro_mode, true), NEF_E_SHAPE);
+    NEF_REQUIRE(plan_bwd_weight(B, T, G, Cin_g, Cout_g, K, &p, pro_mode, 1), NEF_E_SHAPE);
     NEF_REQUIRE(p.ct.nseg == 1, NEF_E_SHAPE);
     const size_t need = (size_t)p.S * G * K * Cout_g * Cin_g * sizeof(float);
     NEF_REQUIRE(ws_bytes >= need, NEF_E_WORKSPACE);
@@ -1883,6 +1943,43 @@ int nef_conv_bwd_weight_wino(const float* x, int64_t x_bs, int64_t x_gs, const f
     }
 #undef NEF_BWW_MODE
 #undef NEF_BWW
+    if (rc != NEF_OK) return rc;
+    const int64_t n = (int64_t)G * K * Cout_g * Cin_g;
+    hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3(nef_stream_grid(n, 256)), dim3(256), 0, st, wsf, gw, G, Cout_g,
+                       Cin_g, K, p.S);
+    return nef_launch_status();
+}
+
+int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
+                              int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
+                              const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B,
+                              int T, int G, int Cin_g, int Cout_g, int K, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && gy && gw && ws, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && T >= WT && T % 2 == 0 && G > 0 && K == 3, NEF_E_SHAPE);
+    NEF_REQUIRE(pro_mode >= 0 && pro_mode <= 3 && !(pro_mode && in_scale), NEF_E_UNSUPPORTED);
+    NEF_REQUIRE(!(pro_mode & 1) || (pro_a && pro_b && pro_Bp > 0), NEF_E_NULL);
+    BwdWeightPlan p;
+    NEF_REQUIRE(plan_bwd_weight(B, T, G, Cin_g, Cout_g, K, &p, pro_mode, 2), NEF_E_SHAPE);
+    NEF_REQUIRE(p.ct.nseg == 1, NEF_E_SHAPE);
+    const size_t need = (size_t)p.S * G * K * Cout_g * Cin_g * sizeof(float);
+    NEF_REQUIRE(ws_bytes >= need, NEF_E_WORKSPACE);
+    hipStream_t st = (hipStream_t)stream;
+    float* wsf = (float*)ws;
+    int rc = NEF_E_UNSUPPORTED;
+#define NEF_BW4(WCO, PRO)                                                                                              \
+    rc = launch_bwd_weight<3, WCO, 1, PRO, 2>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G,  \
+                                              Cin_g, Cout_g, st, pro_a, pro_b, pro_Bp)
+#define NEF_BW4_MODE(WCO)                                                                                              \
+    {                                                                                                                 \
+        if (pro_mode == 0) NEF_BW4(WCO, 0);                                                                           \
+        else if (pro_mode == 1) NEF_BW4(WCO, 1);                                                                      \
+        else if (pro_mode == 2) NEF_BW4(WCO, 2);                                                                      \
+        else NEF_BW4(WCO, 3);                                                                                         \
+    }
+    if (p.wco == 4) NEF_BW4_MODE(4) else NEF_BW4_MODE(2)
+#undef NEF_BW4_MODE
+#undef NEF_BW4
     if (rc != NEF_OK) return rc;
     const int64_t n = (int64_t)G * K * Cout_g * Cin_g;
     hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3(nef_stream_grid(n, 256)), dim3(256), 0, st, wsf, gw, G, Cout_g,

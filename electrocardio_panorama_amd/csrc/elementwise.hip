@@ -152,6 +152,47 @@ __global__ void mix_fwd_kernel(const float* __restrict__ latent, const float* __
     }
 }
 
+// lead_mean + mix_fwd<SHARED> in one pass: a (sample, channel) row of all V leads is read once and leaves the lead mean
+// (latent), q*mean (D2 pass 0) and q*lead[c1 or c2] (D2 pass 1) -- the picked lead is one of the rows just averaged.
+// Same expressions in the same order as the two kernels above: bit-identical outputs.  W floats per access (1 or 2).
+template <int W>
+__global__ __launch_bounds__(256) void lead_mean_mix_shared_kernel(const float* __restrict__ z1,
+                                                                   const float* __restrict__ z2r,
+                                                                   const float* __restrict__ q,
+                                                                   float* __restrict__ latent, float* __restrict__ D2,
+                                                                   int B, int V, int T, int c1, int c2,
+                                                                   const int32_t* __restrict__ choice_dev) {
+    typedef float vec __attribute__((ext_vector_type(W)));
+    if (choice_dev) { c1 = choice_dev[0]; c2 = choice_dev[1]; }
+    const int64_t rows = (int64_t)B * 256;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float fv = (float)V;
+    const int TW = T / W;
+    const int64_t pass = rows * TW;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int b = (int)(row >> 8), c = (int)(row & 255);
+        const vec* src = (const vec*)((c < 128 ? z1 : z2r) + ((int64_t)b * V * 128 + (c & 127)) * T);
+        const int cp = c < 128 ? c1 : c2;
+        const int64_t lead = (int64_t)128 * TW;
+        const float f = q[row];
+        vec* lat = (vec*)latent + row * TW;
+        vec* d0 = (vec*)D2 + row * TW;
+        for (int t = lane; t < TW; t += 64) {
+            vec s = src[t];
+            vec pk = s;
+            for (int v = 1; v < V; ++v) {
+                const vec x = src[(int64_t)v * lead + t];
+                s += x;
+                if (v == cp) pk = x;
+            }
+            const vec m = s / fv;
+            lat[t] = m;
+            d0[t] = f * m;
+            d0[pass + t] = f * pk;
+        }
+    }
+}
+
 __device__ __forceinline__ float up2_bwd_edge(const float* __restrict__ gr, int Tin, int m) {
     const int To = 2 * Tin;
     float s = 0.f;
@@ -1357,6 +1398,21 @@ int nef_mix_fwd_shared(const float* latent, const float* z1, const float* z2r, c
     NEF_REQUIRE(B > 0 && V > 0 && T > 0 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
     hipLaunchKernelGGL(mix_fwd_kernel<true>, dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, latent, z1,
                        z2r, q, D2, B, V, T, c1, c2, choice_dev);
+    return nef_launch_status();
+}
+
+int nef_lead_mean_mix_shared(const float* z1, const float* z2r, const float* q, float* latent, float* D2, int B, int V,
+                             int T, int c1, int c2, const int32_t* choice_dev, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(z1 && z2r && q && latent && D2, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && V > 0 && T > 0 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
+    const dim3 grid(nef_stream_grid((int64_t)B * 256, 4));
+    if (T % 2 == 0)
+        hipLaunchKernelGGL(lead_mean_mix_shared_kernel<2>, grid, dim3(256), 0, NEF_ST, z1, z2r, q, latent, D2, B, V, T, c1,
+                           c2, choice_dev);
+    else
+        hipLaunchKernelGGL(lead_mean_mix_shared_kernel<1>, grid, dim3(256), 0, NEF_ST, z1, z2r, q, latent, D2, B, V, T, c1,
+                           c2, choice_dev);
     return nef_launch_status();
 }
 

@@ -342,12 +342,12 @@ def _head_fwd(P, Bf, z1, z2r, q_theta, V, rest_theta, phase, training, lead_choi
     """model_nefnet.py:146-190: lead means, Standin mixes, query scaling, the three decoder passes (+ the sweep)."""
     B = z1.shape[0]
     save = sv is not None
-    latent = ops.lead_mean(z1, z2r, V)
     q = ops.theta_mlp_fwd(q_theta, P["mlp2.weight"], P["mlp2.bias"])             # [B, 256]
-    if 2 * latent.shape[2] >= 128:     # (_fusable) the first decoder conv sees each distinct channel half once
-        D2 = ops.mix_fwd_shared(latent, z1, z2r, q, V, lead_choice)               # [2B, 256, T]
+    if 2 * z1.shape[2] >= 128:         # (_fusable) the first decoder conv sees each distinct channel half once
+        latent, D2 = ops.lead_mean_mix_shared(z1, z2r, q, V, lead_choice)         # [B, 256, T], [2B, 256, T]
         out3, dsv = decoder_fwd(D2, P, Bf, 3, training, save, shared_B=B)
     else:
+        latent = ops.lead_mean(z1, z2r, V)
         D = ops.mix_fwd(latent, z1, z2r, q, V, lead_choice)                       # [3B, 256, T]
         out3, dsv = decoder_fwd(D, P, Bf, 3, training, save)
     outs = (out3[0:B], out3[B:2 * B], out3[2 * B:3 * B])

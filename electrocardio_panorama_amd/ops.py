@@ -194,6 +194,8 @@ WINOGRAD = _WV != "0"
 # a heavily cancelling gradient -- by 3.7e-4 over the 3-step reference trajectory (bar 2e-4), and the fixed-up kernel
 # was no faster than F(2,3) (1.31 vs 1.33 ms on the K=7 conv).
 WINO_FWD = 1 if _WV in ("1", "2") else 2
+# K=3 weight gradients through the transposed F(3,4) (6 MFMAs per 8 columns instead of F(3,2)'s 8); NEF_BW_WINO4=0: F(3,2)
+WINO_BW4 = os.environ.get("NEF_BW_WINO4", "1") == "1" and _WV not in ("1", "2")
 _WINO_PLANES = {(1, 3): 4, (1, 7): 10, (2, 3): 6, (2, 7): 17}
 
 
@@ -332,7 +334,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
 
 def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None):
     """gw [G*Cog, Cig, K] for y = conv(prologue(x) * in_scale, w); `pro` as in conv().  `wino`: force / forbid the
-    Winograd F(3,2) form (default: wherever it applies, see WINOGRAD)."""
+    Winograd F(3,2) form (default: wherever it applies, see WINOGRAD); 4 = the transposed F(3,4) (K == 3)."""
     L = _lib.load()
     B, T, G, Cig, Cog = xv.B, gyv.T, xv.G, xv.Cg, gyv.Cg
     gw = torch.empty(G * Cog, Cig, K, device=xv.t.device, dtype=torch.float32)
@@ -344,9 +346,12 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None):
     ev = _timed(("conv_bwd_weight", K, G, Cig, Cog, B, T))
     if wino is None:
         wino = WINOGRAD and K in (3, 7) and T % 2 == 0 and T >= 64 and not (K == 7 and pro is not None and pro[0])
+        if wino and K == 3 and WINO_BW4:
+            wino = 4
     if wino:
         pm, pa, pb, pbp = (pro[0], _p(pro[1]), _p(pro[2]), pro[3]) if (pro is not None and pro[0]) else (0, None, None, 1)
-        _lib.check(L.nef_conv_bwd_weight_wino(xv.ptr, xv.bs, xv.gs, sc, sc_bs, sc_gs, pa, pb, pm, pbp, gyv.ptr, gyv.bs,
+        fn = L.nef_conv_bwd_weight_wino4 if (wino == 4 and K == 3) else L.nef_conv_bwd_weight_wino
+        _lib.check(fn(xv.ptr, xv.bs, xv.gs, sc, sc_bs, sc_gs, pa, pb, pm, pbp, gyv.ptr, gyv.bs,
                                               gyv.gs, _p(gw), _p(ws), n, B, T, G, Cig, Cog, K, _stream()),
                    "nef_conv_bwd_weight_wino")
     elif pro is not None and pro[0]:
@@ -651,6 +656,21 @@ def mix_fwd_shared(latent, z1, z2r, q, V, c1, c2=None):
                "nef_mix_fwd_shared")
     _done(ev)
     return D2
+
+
+def lead_mean_mix_shared(z1, z2r, q, V, c1, c2=None):
+    """lead_mean + mix_fwd_shared in one pass: (latent [B,256,T], D2 [2B,256,T]), bit-identical to the two calls."""
+    L = _lib.load()
+    c1, c2, cdev = _choice(c1 if c2 is None else (c1, c2))
+    _chk(z1), _chk(z2r), _chk(q)
+    B, _, T = z1.shape
+    latent = torch.empty(B, 256, T, device=z1.device, dtype=torch.float32)
+    D2 = torch.empty(2 * B, 256, T, device=z1.device, dtype=torch.float32)
+    ev = _hbm("lead_mean_mix_shared", z1, z2r, latent, D2)
+    _lib.check(L.nef_lead_mean_mix_shared(_p(z1), _p(z2r), _p(q), _p(latent), _p(D2), B, V, T, c1, c2, cdev, _stream()),
+               "nef_lead_mean_mix_shared")
+    _done(ev)
+    return latent, D2
 
 
 def mix_bwd_shared_up(gU2, latent, z1, z2r, q, V, c1, c2=None, relu_z1=False):

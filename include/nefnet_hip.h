@@ -143,6 +143,13 @@ int nef_conv_bwd_weight_wino(const float* x, int64_t x_bs, int64_t x_gs, const f
                              int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
                              const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B, int T,
                              int G, int Cin_g, int Cout_g, int K, nef_stream_t stream);
+/* ... and through the transposed F(3,4) (K == 3 only): 6 multiplies per four columns -- 1/2 of the direct form's, 3/4 of
+ * F(3,2)'s; transform entries up to 8 and 1/24 (the F(4,3) matrices of the forward kernels, roles exchanged): measured
+ * rounding 1..6x the direct form's on the reduced sum.  Same arguments, workspace and constraints. */
+int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
+                              int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
+                              const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B, int T,
+                              int G, int Cin_g, int Cout_g, int K, nef_stream_t stream);
 
 /* out[c] = sum_{b,t} x[b][c][t] (bias gradients).  ws: nef_chan_sum_ws_bytes(C). */
 size_t nef_chan_sum_ws_bytes(int C);
@@ -242,6 +249,10 @@ int nef_mix_bwd_up(const float* gU, const float* latent, const float* z1, const 
  *   nef_mix_bwd_shared_up: nef_mix_bwd_up for the two-pass gradient gU2 [2B][256][2T] (wrt the upsampled D2). */
 int nef_mix_fwd_shared(const float* latent, const float* z1, const float* z2r, const float* q, float* D2, int B, int V,
                        int T, int c1, int c2, const int32_t* choice_dev, nef_stream_t stream);
+/* nef_lead_mean + nef_mix_fwd_shared in one pass over z1 / z2r (the picked lead is one of the rows being averaged):
+ * bit-identical latent and D2, 0.65 GB less traffic per step at config 2. */
+int nef_lead_mean_mix_shared(const float* z1, const float* z2r, const float* q, float* latent, float* D2, int B, int V,
+                             int T, int c1, int c2, const int32_t* choice_dev, nef_stream_t stream);
 int nef_mix_bwd_shared_up(const float* gU2, const float* latent, const float* z1, const float* z2r, const float* q,
                           float* gz1, float* gz2r, float* gq, int B, int V, int T, int c1, int c2,
                           const int32_t* choice_dev, int relu_z1, nef_stream_t stream);
