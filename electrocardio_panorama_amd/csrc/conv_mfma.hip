@@ -912,6 +912,7 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
     const bool live[2] = {inb && t < T, inb && t + 2 < T};
     const int ts[2] = {live[0] ? t : 0, live[1] ? t + 2 : 0};
     const int cobase = m0 + wm * 32 + 4 * hi;
+#define NEF_ROW4(q, h) ((((q) + 8 * (h)) & 3) + 8 * (((q) + 8 * (h)) >> 2))
     float sv[32];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -998,7 +999,25 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
             }
         }
 #undef NEF_ROW
-        if (a.stats) {          // this lane's share of the slot sums: its (up to) four live outputs of each of its 8 rows
+        if (a.bnb_slots) {      // BatchNorm-backward sums of the layer below: g*m and g*m*xhat over this lane's live outputs
+            const int prow = (b0 / a.bnb_Bp) * (int)ctot + g * Cog + cobase;
+            const float* xp = a.bnb_x + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = NEF_ROW4(q, h);
+                const float af = a.bnb_a[prow + row], bf = a.bnb_b[prow + row];
+                const float mf = a.bnb_mean[prow + row], is = a.bnb_invstd[prow + row];
+                const f32x2 x01 = *reinterpret_cast<const f32x2*>(xp + (int64_t)row * T + ts[0]);
+                const f32x2 x23 = *reinterpret_cast<const f32x2*>(xp + (int64_t)row * T + ts[1]);
+                const float g0 = (live[0] && fmaf(x01[0], af, bf) > 0.f) ? y[q][0] : 0.f;
+                const float g1 = (live[0] && fmaf(x01[1], af, bf) > 0.f) ? y[q][1] : 0.f;
+                const float g2 = (live[1] && fmaf(x23[0], af, bf) > 0.f) ? y[q][2] : 0.f;
+                const float g3 = (live[1] && fmaf(x23[1], af, bf) > 0.f) ? y[q][3] : 0.f;
+                sv[2 * (q + 8 * h)] = (g0 + g1) + (g2 + g3);
+                sv[2 * (q + 8 * h) + 1] = fmaf(g0, (x01[0] - mf) * is, g1 * ((x01[1] - mf) * is)) +
+                                          fmaf(g2, (x23[0] - mf) * is, g3 * ((x23[1] - mf) * is));
+            }
+        } else if (a.stats) {   // this lane's share of the slot sums: its (up to) four live outputs of each of its 8 rows
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float y0 = live[0] ? y[q][0] : 0.f, y1 = live[0] ? y[q][1] : 0.f;
@@ -1008,7 +1027,8 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
             }
         }
     }
-    if (a.stats) {
+    float* const slot_out = a.bnb_slots ? a.bnb_slots : a.stats;
+    if (slot_out) {
         // 32 values (16 rows x {sum, sum of squares}) summed over the 32 lanes that share `hi`: a halving butterfly -- each
         // step a lane passes on the half it does not keep, 16+8+4+2+1 shuffles instead of 32 x 5 -- after which lane `lo`
         // holds the slot total of value `lo` = 2*r + {0,1}, row r = q + 8h.  Fixed order: deterministic.
@@ -1027,7 +1047,8 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
         const int ch = g * Cog + cobase + (r & 3) + 8 * (r >> 2);
         const int64_t nslot = (int64_t)tps * WN;
         const int64_t slot = (int64_t)b0 * nslot + (int64_t)(t0 / NTO) * WN + wn;
-        if (inb) a.stats[((int64_t)ch * a.B * nslot + slot) * 2 + (lo & 1)] = sv[0];
+#undef NEF_ROW4
+        if (inb) slot_out[((int64_t)ch * a.B * nslot + slot) * 2 + (lo & 1)] = sv[0];
     }
 }
 
@@ -1553,7 +1574,6 @@ static bool plan_bwd_weight(int B, int T, int G, int Cig, int Cog, int K, BwdWei
     if (Cog % 128 == 0) p->wco = 4;
     else if (Cog % 64 == 0) p->wco = 2;
     else return false;
-    if (wino == 2 && getenv("NEF_BW4_WCO2")) p->wco = 2;
     const int wci = 4 / p->wco;
     p->tci = (K <= 3 && Cig % (64 * wci) == 0) ? 2 : 1;
     if (pro_mode != 0 && p->wco == 2) p->tci = 1;      // keep the doubled staging registers within budget
@@ -1756,7 +1776,10 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
     NEF_REQUIRE(K == 1 || K == 3 || K == 7, NEF_E_SHAPE);
     NEF_REQUIRE(a->Cout_g % 64 == 0 && a->Cin_g > 0, NEF_E_SHAPE);
     hipStream_t st = (hipStream_t)stream;
-    NEF_REQUIRE(!a->stats || a->wino == 2, NEF_E_UNSUPPORTED);       // only the F(4,3) epilogue leaves the slot sums
+    NEF_REQUIRE((!a->stats && !a->bnb_slots) || a->wino == 2, NEF_E_UNSUPPORTED);   // only the F(4,3) epilogue leaves slot sums
+    NEF_REQUIRE(!(a->stats && a->bnb_slots), NEF_E_UNSUPPORTED);
+    NEF_REQUIRE(!a->bnb_slots || (a->bnb_x && a->bnb_mean && a->bnb_invstd && a->bnb_a && a->bnb_b), NEF_E_NULL);
+    NEF_REQUIRE(!a->bnb_slots || a->bnb_Bp > 0, NEF_E_SHAPE);
     bool big = (a->Cout_g % 128 == 0);
     if (big) {
         // small problems (reference-native batch 32, L=512): a 128-row tile gives fewer workgroups than the chip has

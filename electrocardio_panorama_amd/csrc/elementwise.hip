@@ -670,16 +670,16 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
 
 // coef[(p*C+c)*2] = s1/n, s2/n ; ggamma[c] = sum_p s2 ; gbeta[c] = sum_p s1
 __global__ void bn_bwd_final(const double* __restrict__ part, float* __restrict__ coef, float* __restrict__ ggamma,
-                             float* __restrict__ gbeta, int P, int Bp, int C, int L) {
+                             float* __restrict__ gbeta, int P, int Bp, int C, int L, int nsplit = BN_SPLIT) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const double n = (double)Bp * (double)L;
     double g1 = 0.0, g2 = 0.0;
     for (int p = 0; p < P; ++p) {
         double s1 = 0.0, s2 = 0.0;
-        for (int sp = 0; sp < BN_SPLIT; ++sp) {
-            s1 += part[((int64_t)(p * C + c) * BN_SPLIT + sp) * 2];
-            s2 += part[((int64_t)(p * C + c) * BN_SPLIT + sp) * 2 + 1];
+        for (int sp = 0; sp < nsplit; ++sp) {
+            s1 += part[((int64_t)(p * C + c) * nsplit + sp) * 2];
+            s2 += part[((int64_t)(p * C + c) * nsplit + sp) * 2 + 1];
         }
         coef[(p * C + c) * 2] = (float)(s1 / n);
         coef[(p * C + c) * 2 + 1] = (float)(s2 / n);
@@ -1560,19 +1560,26 @@ size_t nef_bn_bwd_ws_bytes(int P, int Bp, int C) { return nef_bn_ws_bytes(P, C) 
 
 int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* invstd,
                     const float* a, const float* b, float* gx, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
-                    size_t ws_bytes, int P, int Bp, int C, int L, nef_stream_t stream) {
+                    size_t ws_bytes, int P, int Bp, int C, int L, const float* slots, int nslot, nef_stream_t stream) {
     NEF_ENTER();
     (void)gamma;
     NEF_REQUIRE(gy && x && mean && invstd && a && b && gx && ggamma && gbeta && ws, NEF_E_NULL);
     NEF_REQUIRE(P > 0 && Bp > 0 && C > 0 && L > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(!slots || (nslot > 0 && (int64_t)Bp * nslot <= 0x7FFFFFFF), NEF_E_SHAPE);
     NEF_REQUIRE(ws_bytes >= nef_bn_bwd_ws_bytes(P, Bp, C), NEF_E_WORKSPACE);
     double* part = (double*)ws;
     float* coef = (float*)((char*)ws + (size_t)P * C * BN_SPLIT * 2 * sizeof(double));
     double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(P, C)) : nullptr;
-    hipLaunchKernelGGL(bn_bwd_partial<0>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part,
-                       P, Bp, C, L, (const float*)nullptr);
-    hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma, gbeta,
-                       P, Bp, C, L);
+    if (slots) {        // the producing conv left the sums per slot: add them up in fp64, fixed order
+        hipLaunchKernelGGL(bn_slots_reduce, dim3((unsigned)(P * C)), dim3(256), 0, NEF_ST, slots, part, P, C, Bp * nslot);
+        hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma,
+                           gbeta, P, Bp, C, L, 1);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_partial<0>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part,
+                           P, Bp, C, L, (const float*)nullptr);
+        hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma,
+                           gbeta, P, Bp, C, L, BN_SPLIT);
+    }
     const int64_t rows = (int64_t)P * Bp * C;
     if ((L & 3) == 0 && rows <= 0x7FFFFFFF)
         hipLaunchKernelGGL(bn_bwd_apply_rows<0>, dim3((unsigned)rows), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b,
@@ -1612,18 +1619,26 @@ int nef_bn_relu_bwd_up(const float* gu, const float* x, const float* mean, const
 
 int nef_bn_relu_bwd_combine3(const float* gy, const float* x, const float* mean, const float* invstd, const float* a,
                              const float* b, float* gP2, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
-                             size_t ws_bytes, int Bp, int C, int L, nef_stream_t stream) {
+                             size_t ws_bytes, int Bp, int C, int L, const float* slots, int nslot,
+                             nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(gy && x && mean && invstd && a && b && gP2 && ggamma && gbeta && ws, NEF_E_NULL);
     NEF_REQUIRE(Bp > 0 && C > 0 && L > 0 && (int64_t)Bp * C <= 0x7FFFFFFF, NEF_E_SHAPE);
+    NEF_REQUIRE(!slots || (nslot > 0 && (int64_t)Bp * nslot <= 0x7FFFFFFF), NEF_E_SHAPE);
     NEF_REQUIRE(ws_bytes >= nef_bn_bwd_ws_bytes(3, Bp, C), NEF_E_WORKSPACE);
     double* part = (double*)ws;
     float* coef = (float*)((char*)ws + (size_t)3 * C * BN_SPLIT * 2 * sizeof(double));
     double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(3, C)) : nullptr;
-    hipLaunchKernelGGL(bn_bwd_partial<0>, dim3(3 * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part, 3,
-                       Bp, C, L, (const float*)nullptr);
-    hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma, gbeta,
-                       3, Bp, C, L);
+    if (slots) {
+        hipLaunchKernelGGL(bn_slots_reduce, dim3((unsigned)(3 * C)), dim3(256), 0, NEF_ST, slots, part, 3, C, Bp * nslot);
+        hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma,
+                           gbeta, 3, Bp, C, L, 1);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_partial<0>, dim3(3 * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part,
+                           3, Bp, C, L, (const float*)nullptr);
+        hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma,
+                           gbeta, 3, Bp, C, L, BN_SPLIT);
+    }
     hipLaunchKernelGGL(bn_bwd_apply_combine3, dim3((unsigned)(Bp * C)), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b,
                        (const float*)coef, gP2, rowsum, Bp, C, L);
     if (gx_chan_sum)

@@ -263,6 +263,7 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
     fuse_last = c4.shape[2] % 4 == 0
     g_is_up = False
     g = None if fuse_last else ops.outconv_bwd_data(g_out, out, P["decoder.4.weight"], c4.shape[1])
+    g_slots = None            # BatchNorm-backward sums the conv that produced g left in its epilogue
     for li in (3, 2, 1, 0):
         blk, cv, bn, cout = _DEC[li]
         x, c, mean, invstd, a, b, pro, up_after = saved[li]
@@ -271,12 +272,12 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
             gc, gg, gbeta, gbias = ops.bn_relu_bwd_outconv(g_out, out, P["decoder.4.weight"], c, mean, invstd, a, b, passes)
         elif li == 0 and shared_B is not None and not g_is_up:
             # gc is the per-half gradient [2B, 2*128, 2T] straight away (pass_combine_bwd fused into the apply pass)
-            gc, gg, gbeta, gbias = ops.bn_relu_bwd_combine3(g, c, mean, invstd, a, b)
+            gc, gg, gbeta, gbias = ops.bn_relu_bwd_combine3(g, c, mean, invstd, a, b, slots=g_slots)
         elif g_is_up:
             gc, gg, gbeta, gbias = ops.bn_relu_bwd_up(g, c, mean, invstd, a, b, passes)
         else:
             gc, gg, gbeta, gbias = ops.bn_relu_bwd(g, c, P[pre + ".weight"], mean, invstd, a, b, passes,
-                                                   with_chan_sum=True)
+                                                   with_chan_sum=True, slots=g_slots)
         grads[pre + ".weight"], grads[pre + ".bias"], grads[bname] = gg, gbeta, gbias
         if li == 0 and shared_B is not None:
             gp2 = gc if gc.shape[0] == 2 * shared_B else ops.pass_combine_bwd(gc)   # [2B, 2*128, 2T]
@@ -287,7 +288,17 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
         else:
             gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
             grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro), x, gc)
-            g = ops.conv(gcv, ops.pack_weight(P[wname], 1, flip=True, T=gc.shape[2], f4=True), x.shape[1], 3, role="conv_bwd_data")
+            wpf = ops.pack_weight(P[wname], 1, flip=True, T=gc.shape[2], f4=True)
+            # g is the gradient wrt relu(bn(c_below)) when no upsampling sits in between: the epilogue then leaves the
+            # reduction sums of that BatchNorm's backward (it reads c_below's tile for the ReLU decision and xhat)
+            g_slots = bnb = None
+            if li > 0 and not up_after and _FUSE_STATS:
+                cb, mb, ib, ab, bb = saved[li - 1][1:6]
+                if cb.shape[2] == gc.shape[2] and mb is not None:
+                    g_slots = ops.conv_stats_buffer(wpf, cb.shape[0], 1, x.shape[1], gc.shape[2], gc.device)
+                    if g_slots is not None:
+                        bnb = (cb, mb, ib, ab, bb, cb.shape[0] // passes, g_slots)
+            g = ops.conv(gcv, wpf, x.shape[1], 3, role="conv_bwd_data", bnb=bnb)
         # back through the x2 upsampling in front of this layer: the next BatchNorm backward takes the adjoint while it
         # reads (rows of 4k >= 8 samples), otherwise it is a pass of its own
         g_is_up = bool(up_after and li > 0 and c.shape[2] % 8 == 0 and c.shape[2] >= 16)

@@ -292,12 +292,14 @@ def bn_stats_from_slots(stats, gamma, beta, running_mean, running_var, P, N, Ln,
 
 
 def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None, gate_scale=1.0, relu=False,
-         mask=None, drop_p=0.0, drop_scale=1.0, seed=0, role="conv_fwd", pro=None, seed_dev=None, stats=None):
+         mask=None, drop_p=0.0, drop_scale=1.0, seed=0, role="conv_fwd", pro=None, seed_dev=None, stats=None, bnb=None):
     """out = epilogue(conv1d(prologue(x) * in_scale, w) + bias + res).  `xv`, `res`, `gate`, `out` are GV views;
     `in_scale` is (tensor, batch_stride, group_stride).  `pro` = (mode, a, b, Bp): input prologue applied while
     staging -- bit0 BatchNorm affine + ReLU with a/b [P, C_in], bit1 x2 linear upsampling of a half-resolution input
     (the output is then 2*xv.T long).  `stats`: a conv_stats_buffer() the epilogue fills with the per-slot sum and sum
-    of squares of the outputs.  Returns the output tensor."""
+    of squares of the outputs; `bnb` = (x, mean, invstd, a, b, Bp, conv_stats_buffer()): the epilogue leaves the
+    BatchNorm-backward sums sum(g*m), sum(g*m*xhat) of the layer this backward-data launch propagates into.  Returns the
+    output tensor."""
     L = _lib.load()
     T_out = xv.T * 2 if (pro is not None and pro[0] & 2) else xv.T
     if out is None:
@@ -325,6 +327,9 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     a.rng_seed_dev = _p(seed_dev)
     a.wino = int(getattr(wp, "nef_wino", 0))
     a.stats = _p(stats[0]) if stats is not None else None
+    if bnb is not None:      # (x, mean, invstd, a, b, Bp, slots buffer): BatchNorm-backward sums of the layer below
+        a.bnb_x, a.bnb_mean, a.bnb_invstd, a.bnb_a, a.bnb_b = (_p(t) for t in bnb[:5])
+        a.bnb_Bp, a.bnb_slots = bnb[5], _p(bnb[6][0])
     ev = _timed((role, K, xv.G, xv.Cg, Cog, xv.B, T_out))
     _lib.check(L.nef_conv_fwd(C.byref(a), _stream()), "nef_conv_fwd")
     if ev is not None:
@@ -821,8 +826,9 @@ def affine_relu_fwd(x, a, b, P):
     return y
 
 
-def bn_relu_bwd(gy, x, gamma, mean, invstd, a, b, P, with_chan_sum=False):
-    """Returns (gx, ggamma, gbeta[, sum_{b,t} gx per channel])."""
+def bn_relu_bwd(gy, x, gamma, mean, invstd, a, b, P, with_chan_sum=False, slots=None):
+    """Returns (gx, ggamma, gbeta[, sum_{b,t} gx per channel]).  `slots`: the conv_stats_buffer() the conv that produced
+    `gy` filled (conv(..., bnb=...)) -- the reduction pass over (gy, x) is then skipped."""
     L = _lib.load()
     _chk(gy), _chk(x)
     N, Ct, Ln = x.shape
@@ -834,12 +840,13 @@ def bn_relu_bwd(gy, x, gamma, mean, invstd, a, b, P, with_chan_sum=False):
     ws = workspace(n, x.device)
     ev = _hbm("bn_relu_bwd", gy, x, gx)
     _lib.check(L.nef_bn_relu_bwd(_p(gy), _p(x), _p(gamma), _p(mean), _p(invstd), _p(a), _p(b), _p(gx), _p(gg), _p(gb),
-                                 _p(gs), _p(ws), n, P, N // P, Ct, Ln, _stream()), "nef_bn_relu_bwd")
+                                 _p(gs), _p(ws), n, P, N // P, Ct, Ln, _p(slots[0]) if slots else None,
+                                 slots[1] if slots else 0, _stream()), "nef_bn_relu_bwd")
     _done(ev)
     return (gx, gg, gb, gs) if with_chan_sum else (gx, gg, gb)
 
 
-def bn_relu_bwd_combine3(gy, x, mean, invstd, a, b):
+def bn_relu_bwd_combine3(gy, x, mean, invstd, a, b, slots=None):
     """pass_combine_bwd(bn_relu_bwd(gy, x, ..., P=3)) in one pass: returns (gP2 [2B,2C,L], ggamma, gbeta, chan sum of gx)."""
     L = _lib.load()
     _chk(gy), _chk(x)
@@ -853,7 +860,8 @@ def bn_relu_bwd_combine3(gy, x, mean, invstd, a, b):
     ws = workspace(n, x.device)
     ev = _hbm("bn_relu_bwd_combine3", gy, x, gP2)
     _lib.check(L.nef_bn_relu_bwd_combine3(_p(gy), _p(x), _p(mean), _p(invstd), _p(a), _p(b), _p(gP2), _p(gg), _p(gb),
-                                          _p(gs), _p(ws), n, Bp, Ct, Ln, _stream()), "nef_bn_relu_bwd_combine3")
+                                          _p(gs), _p(ws), n, Bp, Ct, Ln, _p(slots[0]) if slots else None,
+                                          slots[1] if slots else 0, _stream()), "nef_bn_relu_bwd_combine3")
     _done(ev)
     return gP2, gg, gb, gs
 

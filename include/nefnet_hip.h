@@ -118,6 +118,18 @@ typedef struct nef_conv_args {
                               stats[(ch * B * nslot + b * nslot + slot) * 2 + {0,1}], ch = g*Cout_g + co, nslot =
                               nef_conv_stats_slots(T, Cout_g) -- the train-mode BatchNorm statistics of the conv output
                               (model_nefnet.py:19,22) without a second pass over it; finished by nef_bn_stats_from_slots */
+    /* BatchNorm-BACKWARD sums of the layer this (backward-data) launch propagates into, wino == 2 only, not together with
+     * `stats`: with bnb_slots != NULL the epilogue also leaves, in the same slot layout, sum(g*m) and sum(g*m*xhat) of its
+     * final outputs g, where m = [bnb_x*bnb_a + bnb_b > 0] and xhat = (bnb_x - bnb_mean)*bnb_invstd -- the reduction pass
+     * of nef_bn_relu_bwd over (g, x), which then takes `slots` instead.  bnb_x: the BatchNorm input, dense
+     * [B][G*Cout_g][T]; bnb_mean/invstd/a/b: [P][G*Cout_g], pass p = sample / bnb_Bp. */
+    const float* bnb_x;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    const float* bnb_a;
+    const float* bnb_b;
+    float* bnb_slots;
+    int32_t bnb_Bp;
 } nef_conv_args;
 
 /* y = epilogue(conv(x * in_scale, wp) + bias + res).  Also the bwd-data pass (pack with transpose_flip=1,
@@ -308,7 +320,9 @@ int nef_affine_relu_fwd(const float* x, const float* a, const float* b, float* y
 size_t nef_bn_bwd_ws_bytes(int P, int Bp, int C);
 int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* invstd,
                     const float* a, const float* b, float* gx, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
-                    size_t ws_bytes, int P, int Bp, int C, int L, nef_stream_t stream);
+                    size_t ws_bytes, int P, int Bp, int C, int L, const float* slots, int nslot, nef_stream_t stream);
+/* `slots` (here and in nef_bn_relu_bwd_combine3): NULL, or the sums the conv that produced gy left in its epilogue
+ * (nef_conv_args.bnb_slots, nslot = nef_conv_stats_slots): the reduction pass over (gy, x) is then skipped. */
 
 /* Final Conv1d(64->1,k3,p1,bias) + sigmoid(x/3).  model_nefnet.py:106,168.
  *   x [N][C][L], w [1][C][3], bias [1], out [N][L]. */
@@ -326,7 +340,7 @@ int nef_bn_relu_bwd_up(const float* gu, const float* x, const float* mean, const
  * instead of gx (only gx's per-channel sum is kept).  ws: nef_bn_bwd_ws_bytes(3, Bp, C). */
 int nef_bn_relu_bwd_combine3(const float* gy, const float* x, const float* mean, const float* invstd, const float* a,
                              const float* b, float* gP2, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
-                             size_t ws_bytes, int Bp, int C, int L, nef_stream_t stream);
+                             size_t ws_bytes, int Bp, int C, int L, const float* slots, int nslot, nef_stream_t stream);
 size_t nef_bn_bwd_outconv_ws_bytes(int P, int Bp, int C, int L);
 int nef_bn_relu_bwd_outconv(const float* gout, const float* out, const float* wout, const float* x, const float* mean,
                             const float* invstd, const float* a, const float* b, float* gx, float* ggamma, float* gbeta,

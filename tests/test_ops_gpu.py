@@ -556,6 +556,37 @@ def test_conv_epilogue_bn_slot_sums(B, Cin, Cout, T, pro):
     assert o.conv_stats_buffer(o.pack_weight(w, 1, T=T), B, 1, Cout, T, x.device) is None
 
 
+@pytest.mark.parametrize("B,Cin,Cout,T", [(6, 128, 128, 300), (6, 64, 64, 514), (3, 128, 64, 256)])
+def test_conv_epilogue_bn_backward_slot_sums(B, Cin, Cout, T):
+    """A backward-data launch on the F(4,3) kernel that also leaves the BatchNorm-backward sums of the layer below
+    (nef_conv_args.bnb_*): bn_relu_bwd / bn_relu_bwd_combine3 fed with those slots against their own reduction pass."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    if o.WINO_FWD != 2:
+        pytest.skip("F(4,3) switched off (NEF_WINOGRAD)")
+    gc = g(rnd(B, Cin, T, seed=190))                       # gradient at the upper layer's conv output
+    w = g(rnd(Cin, Cout, 3, seed=191, scale=0.05))         # upper conv weight [Cout_upper = Cin here][Cin_upper = Cout]
+    c_below = g(rnd(B, Cout, T, seed=192))                 # the lower layer's conv output (BatchNorm input)
+    gamma, beta = g(rnd(Cout, seed=193) + 1.2), g(rnd(Cout, seed=194, scale=0.3))
+    mean, invstd, a_, b_ = o.bn_train_stats(c_below, gamma, beta, torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV), 3)
+    wpf = o.pack_weight(w, 1, flip=True, T=T, f4=True)
+    slots = o.conv_stats_buffer(wpf, B, 1, Cout, T, gc.device)
+    assert slots is not None
+    slots[0].fill_(float("nan"))
+    gref = o.conv(GV.dense(gc, 1), wpf, Cout, 3, role="conv_bwd_data")
+    gv = o.conv(GV.dense(gc, 1), wpf, Cout, 3, role="conv_bwd_data", bnb=(c_below, mean, invstd, a_, b_, B // 3, slots))
+    assert torch.equal(gv, gref)
+    want = o.bn_relu_bwd(gv, c_below, gamma, mean, invstd, a_, b_, 3, with_chan_sum=True)
+    got = o.bn_relu_bwd(gv, c_below, gamma, mean, invstd, a_, b_, 3, with_chan_sum=True, slots=slots)
+    for x_, y_ in zip(got[:3], want[:3]):
+        assert rel(x_, y_) < 2e-6
+    assert maxabs(got[3], want[3]) < 1e-4 * float(want[0].abs().sum() / Cout) + 1e-6     # a cancelled sum: absolute bar
+    want3 = o.bn_relu_bwd_combine3(gv, c_below, mean, invstd, a_, b_)
+    got3 = o.bn_relu_bwd_combine3(gv, c_below, mean, invstd, a_, b_, slots=slots)
+    for x_, y_ in zip(got3[:3], want3[:3]):
+        assert rel(x_, y_) < 2e-6
+
+
 def test_bn_relu_bwd_combine3_equals_two_calls():
     o = ops()
     Bp, C, L = 2, 16, 301
