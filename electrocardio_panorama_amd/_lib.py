@@ -52,6 +52,7 @@ SIGNATURES = {
     "nef_pack_weight_wino4": (i32, [p, p, i32, i32, i32, i32, i32, p]),
     "nef_pack_weights": (i32, [C.POINTER(PackDesc), i32, p]),
     "nef_conv_fwd": (i32, [C.POINTER(ConvArgs), p]),
+    "nef_conv_args_bytes": (sz, []),
     "nef_conv_bwd_weight_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "nef_conv_bwd_weight": (i32, [p, i64, i64, p, i64, i64, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32, i32, p]),
     "nef_conv_bwd_weight_pro": (i32, [p, i64, i64, p, p, i32, i32, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32, i32, p]),
@@ -148,6 +149,9 @@ def load():
         fn = getattr(lib, name)        # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.nef_conv_args_bytes() != C.sizeof(ConvArgs):      # a stale .so next to a newer binding (or the reverse)
+        raise NefLibraryError(f"{LIB_PATH}: nef_conv_args is {lib.nef_conv_args_bytes()} bytes, the binding mirrors "
+                              f"{C.sizeof(ConvArgs)}; rebuild with `python -m electrocardio_panorama_amd.csrc.build`")
     _lib = lib
     return lib
 

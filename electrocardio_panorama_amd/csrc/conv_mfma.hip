@@ -1768,6 +1768,8 @@ int nef_pack_weights(const nef_pack_desc* descs, int n, nef_stream_t stream) {
     return nef_launch_status();
 }
 
+size_t nef_conv_args_bytes(void) { return sizeof(nef_conv_args); }
+
 int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(a && a->x && a->wp && a->y, NEF_E_NULL);

@@ -135,6 +135,8 @@ typedef struct nef_conv_args {
 /* y = epilogue(conv(x * in_scale, wp) + bias + res).  Also the bwd-data pass (pack with transpose_flip=1,
  * swap Cin_g/Cout_g). */
 int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream);
+/* sizeof(nef_conv_args) as the library was built: a binding checks its mirror of the struct against it. */
+size_t nef_conv_args_bytes(void);
 
 /* gw[g*Cog+co][ci][k] = sum_{b,t} gy[b][g][co][t] * (x*in_scale)[b][g][ci][t+k-pad].  gw is overwritten.
  * ws: nef_conv_bwd_weight_ws_bytes(...) bytes of scratch (split-K partials, reduced deterministically). */

@@ -24,7 +24,7 @@ def test_header_symbols_exported():
     for name in declared:
         assert hasattr(lib, name), name
     assert _lib.load().nef_abi_version() == 9
-    assert ctypes.sizeof(_lib.ConvArgs) == 296
+    assert ctypes.sizeof(_lib.ConvArgs) == 296 == _lib.load().nef_conv_args_bytes()
 
 
 def test_rejects_bad_calls_without_touching_the_gpu():
