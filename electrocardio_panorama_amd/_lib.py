@@ -32,6 +32,7 @@ class ConvArgs(C.Structure):
         ("pro_a", p), ("pro_b", p), ("pro_mode", i32), ("pro_Bp", i32), ("rng_seed_dev", p), ("wino", i32),
         ("stats", p),
         ("bnb_x", p), ("bnb_mean", p), ("bnb_invstd", p), ("bnb_a", p), ("bnb_b", p), ("bnb_slots", p), ("bnb_Bp", i32),
+        ("bnb_up", i32),
     ]
 
 
@@ -106,7 +107,7 @@ SIGNATURES = {
     "nef_affine_relu_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, p]),
     "nef_bn_bwd_ws_bytes": (sz, [i32, i32, i32]),
     "nef_bn_relu_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p, i32, p]),
-    "nef_bn_relu_bwd_up": (i32, [p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p]),
+    "nef_bn_relu_bwd_up": (i32, [p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p, i32, p]),
     "nef_bn_relu_bwd_combine3": (i32, [p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, p, i32, p]),
     "nef_bn_bwd_outconv_ws_bytes": (sz, [i32, i32, i32, i32]),
     "nef_bn_relu_bwd_outconv": (i32, [p, p, p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p]),

@@ -999,7 +999,34 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
             }
         }
 #undef NEF_ROW
-        if (a.bnb_slots) {      // BatchNorm-backward sums of the layer below: g*m and g*m*xhat over this lane's live outputs
+        if (a.bnb_slots && a.bnb_up) {
+            // ... with a x2 upsampling between that layer and this launch's output: sum_t' m[t'] (U^T g)[t'] = sum_t g[t] (U m)[t],
+            // so the lane weighs its four outputs t = 4j..4j+3 with the upsampled decision (and decision * xhat) rows,
+            // built from the half-resolution tile x[2j-1 .. 2j+2] (indices clamped as nn.Upsample clamps them)
+            const int prow = (b0 / a.bnb_Bp) * (int)ctot + g * Cog + cobase;
+            const int Lh = T >> 1;
+            const float* xp = a.bnb_x + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * Lh;
+            const int j2 = live[0] ? (t >> 1) : 0;
+            const int im1 = j2 > 0 ? j2 - 1 : 0, i1 = j2 + 1 < Lh ? j2 + 1 : Lh - 1, ip2 = j2 + 2 < Lh ? j2 + 2 : Lh - 1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = NEF_ROW4(q, h);
+                const float af = a.bnb_a[prow + row], bf = a.bnb_b[prow + row];
+                const float mf = a.bnb_mean[prow + row], is = a.bnb_invstd[prow + row];
+                const float* xr = xp + (int64_t)row * Lh;
+                const float xa = xr[im1], xb = xr[j2], xc = xr[i1], xd = xr[ip2];
+                const float ma = fmaf(xa, af, bf) > 0.f ? 1.f : 0.f, mb = fmaf(xb, af, bf) > 0.f ? 1.f : 0.f;
+                const float mc = fmaf(xc, af, bf) > 0.f ? 1.f : 0.f, md = fmaf(xd, af, bf) > 0.f ? 1.f : 0.f;
+                const float ha = ma * ((xa - mf) * is), hb = mb * ((xb - mf) * is);
+                const float hc = mc * ((xc - mf) * is), hd = md * ((xd - mf) * is);
+                const float g0 = live[0] ? y[q][0] : 0.f, g1 = live[0] ? y[q][1] : 0.f;
+                const float g2 = live[1] ? y[q][2] : 0.f, g3 = live[1] ? y[q][3] : 0.f;
+                sv[2 * (q + 8 * h)] = fmaf(g0, fmaf(0.75f, mb, 0.25f * ma), g1 * fmaf(0.75f, mb, 0.25f * mc)) +
+                                      fmaf(g2, fmaf(0.75f, mc, 0.25f * mb), g3 * fmaf(0.75f, mc, 0.25f * md));
+                sv[2 * (q + 8 * h) + 1] = fmaf(g0, fmaf(0.75f, hb, 0.25f * ha), g1 * fmaf(0.75f, hb, 0.25f * hc)) +
+                                          fmaf(g2, fmaf(0.75f, hc, 0.25f * hb), g3 * fmaf(0.75f, hc, 0.25f * hd));
+            }
+        } else if (a.bnb_slots) {   // BatchNorm-backward sums of the layer below: g*m and g*m*xhat over this lane's live outputs
             const int prow = (b0 / a.bnb_Bp) * (int)ctot + g * Cog + cobase;
             const float* xp = a.bnb_x + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T;
 #pragma unroll

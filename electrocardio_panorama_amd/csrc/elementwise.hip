@@ -1595,20 +1595,27 @@ int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const f
 
 int nef_bn_relu_bwd_up(const float* gu, const float* x, const float* mean, const float* invstd, const float* a,
                        const float* b, float* gx, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
-                       size_t ws_bytes, int P, int Bp, int C, int L, nef_stream_t stream) {
+                       size_t ws_bytes, int P, int Bp, int C, int L, const float* slots, int nslot, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(gu && x && mean && invstd && a && b && gx && ggamma && gbeta && ws, NEF_E_NULL);
     NEF_REQUIRE(P > 0 && Bp > 0 && C > 0 && L >= 8 && (L & 3) == 0, NEF_E_SHAPE);
+    NEF_REQUIRE(!slots || (nslot > 0 && (int64_t)Bp * nslot <= 0x7FFFFFFF), NEF_E_SHAPE);
     const int64_t rows = (int64_t)P * Bp * C;
     NEF_REQUIRE(rows <= 0x7FFFFFFF, NEF_E_SHAPE);
     NEF_REQUIRE(ws_bytes >= nef_bn_bwd_ws_bytes(P, Bp, C), NEF_E_WORKSPACE);
     double* part = (double*)ws;
     float* coef = (float*)((char*)ws + (size_t)P * C * BN_SPLIT * 2 * sizeof(double));
     double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(P, C)) : nullptr;
-    hipLaunchKernelGGL(bn_bwd_partial<2>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gu, x, mean, invstd, a, b, part, P,
-                       Bp, C, L, (const float*)nullptr);
-    hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma, gbeta,
-                       P, Bp, C, L);
+    if (slots) {
+        hipLaunchKernelGGL(bn_slots_reduce, dim3((unsigned)(P * C)), dim3(256), 0, NEF_ST, slots, part, P, C, Bp * nslot);
+        hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma,
+                           gbeta, P, Bp, C, L, 1);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_partial<2>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gu, x, mean, invstd, a, b, part,
+                           P, Bp, C, L, (const float*)nullptr);
+        hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma,
+                           gbeta, P, Bp, C, L, BN_SPLIT);
+    }
     hipLaunchKernelGGL(bn_bwd_apply_rows<2>, dim3((unsigned)rows), dim3(256), 0, NEF_ST, gu, x, mean, invstd, a, b,
                        (const float*)coef, gx, rowsum, Bp, C, L >> 2, (const float*)nullptr);
     if (gx_chan_sum)

@@ -274,7 +274,7 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
             # gc is the per-half gradient [2B, 2*128, 2T] straight away (pass_combine_bwd fused into the apply pass)
             gc, gg, gbeta, gbias = ops.bn_relu_bwd_combine3(g, c, mean, invstd, a, b, slots=g_slots)
         elif g_is_up:
-            gc, gg, gbeta, gbias = ops.bn_relu_bwd_up(g, c, mean, invstd, a, b, passes)
+            gc, gg, gbeta, gbias = ops.bn_relu_bwd_up(g, c, mean, invstd, a, b, passes, slots=g_slots)
         else:
             gc, gg, gbeta, gbias = ops.bn_relu_bwd(g, c, P[pre + ".weight"], mean, invstd, a, b, passes,
                                                    with_chan_sum=True, slots=g_slots)
@@ -291,13 +291,17 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
             wpf = ops.pack_weight(P[wname], 1, flip=True, T=gc.shape[2], f4=True)
             # g is the gradient wrt relu(bn(c_below)) when no upsampling sits in between: the epilogue then leaves the
             # reduction sums of that BatchNorm's backward (it reads c_below's tile for the ReLU decision and xhat)
+            # (with the x2 upsampling in between, the sums are those of its adjoint -- what bn_relu_bwd_up reduces)
             g_slots = bnb = None
-            if li > 0 and not up_after and _FUSE_STATS:
+            if li > 0 and _FUSE_STATS:
                 cb, mb, ib, ab, bb = saved[li - 1][1:6]
-                if cb.shape[2] == gc.shape[2] and mb is not None:
-                    g_slots = ops.conv_stats_buffer(wpf, cb.shape[0], 1, x.shape[1], gc.shape[2], gc.device)
+                Tg = gc.shape[2]
+                plain = not up_after and cb.shape[2] == Tg
+                upv = bool(up_after) and 2 * cb.shape[2] == Tg and Tg % 8 == 0 and Tg >= 16     # the g_is_up case below
+                if (plain or upv) and mb is not None:
+                    g_slots = ops.conv_stats_buffer(wpf, cb.shape[0], 1, x.shape[1], Tg, gc.device)
                     if g_slots is not None:
-                        bnb = (cb, mb, ib, ab, bb, cb.shape[0] // passes, g_slots)
+                        bnb = (cb, mb, ib, ab, bb, cb.shape[0] // passes, g_slots, upv)
             g = ops.conv(gcv, wpf, x.shape[1], 3, role="conv_bwd_data", bnb=bnb)
         # back through the x2 upsampling in front of this layer: the next BatchNorm backward takes the adjoint while it
         # reads (rows of 4k >= 8 samples), otherwise it is a pass of its own

@@ -297,7 +297,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     `in_scale` is (tensor, batch_stride, group_stride).  `pro` = (mode, a, b, Bp): input prologue applied while
     staging -- bit0 BatchNorm affine + ReLU with a/b [P, C_in], bit1 x2 linear upsampling of a half-resolution input
     (the output is then 2*xv.T long).  `stats`: a conv_stats_buffer() the epilogue fills with the per-slot sum and sum
-    of squares of the outputs; `bnb` = (x, mean, invstd, a, b, Bp, conv_stats_buffer()): the epilogue leaves the
+    of squares of the outputs; `bnb` = (x, mean, invstd, a, b, Bp, conv_stats_buffer()[, up]): the epilogue leaves the
     BatchNorm-backward sums sum(g*m), sum(g*m*xhat) of the layer this backward-data launch propagates into.  Returns the
     output tensor."""
     L = _lib.load()
@@ -330,6 +330,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     if bnb is not None:      # (x, mean, invstd, a, b, Bp, slots buffer): BatchNorm-backward sums of the layer below
         a.bnb_x, a.bnb_mean, a.bnb_invstd, a.bnb_a, a.bnb_b = (_p(t) for t in bnb[:5])
         a.bnb_Bp, a.bnb_slots = bnb[5], _p(bnb[6][0])
+        a.bnb_up = int(bnb[7]) if len(bnb) > 7 else 0
     ev = _timed((role, K, xv.G, xv.Cg, Cog, xv.B, T_out))
     _lib.check(L.nef_conv_fwd(C.byref(a), _stream()), "nef_conv_fwd")
     if ev is not None:
@@ -866,7 +867,7 @@ def bn_relu_bwd_combine3(gy, x, mean, invstd, a, b, slots=None):
     return gP2, gg, gb, gs
 
 
-def bn_relu_bwd_up(gu, x, mean, invstd, a, b, P):
+def bn_relu_bwd_up(gu, x, mean, invstd, a, b, P, slots=None):
     """bn_relu_bwd(upsample2_bwd(gu), x, ...) with the upsampling adjoint taken on the fly; gu [N,C,2L].
     Returns (gx, ggamma, gbeta, sum_{b,t} gx per channel)."""
     L = _lib.load()
@@ -881,7 +882,8 @@ def bn_relu_bwd_up(gu, x, mean, invstd, a, b, P):
     ws = workspace(n, x.device)
     ev = _hbm("bn_relu_bwd_up", gu, x, gx)
     _lib.check(L.nef_bn_relu_bwd_up(_p(gu), _p(x), _p(mean), _p(invstd), _p(a), _p(b), _p(gx), _p(gg), _p(gb), _p(gs),
-                                    _p(ws), n, P, N // P, Ct, Ln, _stream()), "nef_bn_relu_bwd_up")
+                                    _p(ws), n, P, N // P, Ct, Ln, _p(slots[0]) if slots else None,
+                                    slots[1] if slots else 0, _stream()), "nef_bn_relu_bwd_up")
     _done(ev)
     return gx, gg, gb, gs
 

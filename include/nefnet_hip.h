@@ -130,6 +130,9 @@ typedef struct nef_conv_args {
     const float* bnb_b;
     float* bnb_slots;
     int32_t bnb_Bp;
+    int32_t bnb_up;        /* 1: a x2 linear upsampling (nn.Upsample, align_corners=False) sits between that BatchNorm's ReLU
+                              and this launch's output: bnb_x is [B][G*Cout_g][T/2] and the sums are those of the
+                              upsampling's adjoint (what nef_bn_relu_bwd_up reduces); T % 4 == 0 */
 } nef_conv_args;
 
 /* y = epilogue(conv(x * in_scale, wp) + bias + res).  Also the bwd-data pass (pack with transpose_flip=1,
@@ -337,7 +340,7 @@ int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const f
  * while reading.  L % 4 == 0, L >= 8.  ws: nef_bn_bwd_ws_bytes. */
 int nef_bn_relu_bwd_up(const float* gu, const float* x, const float* mean, const float* invstd, const float* a,
                        const float* b, float* gx, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
-                       size_t ws_bytes, int P, int Bp, int C, int L, nef_stream_t stream);
+                       size_t ws_bytes, int P, int Bp, int C, int L, const float* slots, int nslot, nef_stream_t stream);
 /* nef_bn_relu_bwd_combine3: nef_bn_relu_bwd (P = 3) followed by nef_pass_combine_bwd in one pass: writes gP2 [2Bp][2C][L]
  * instead of gx (only gx's per-channel sum is kept).  ws: nef_bn_bwd_ws_bytes(3, Bp, C). */
 int nef_bn_relu_bwd_combine3(const float* gy, const float* x, const float* mean, const float* invstd, const float* a,

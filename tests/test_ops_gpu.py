@@ -587,6 +587,33 @@ def test_conv_epilogue_bn_backward_slot_sums(B, Cin, Cout, T):
         assert rel(x_, y_) < 2e-6
 
 
+@pytest.mark.parametrize("B,Cin,Cout,T", [(6, 64, 128, 304), (3, 64, 64, 520), (3, 128, 128, 136)])
+def test_conv_epilogue_bn_backward_slot_sums_through_upsampling(B, Cin, Cout, T):
+    """The same with a x2 upsampling between the BatchNorm below and this launch's output (bnb_up): the slots carry the
+    sums of the upsampling's adjoint, i.e. what bn_relu_bwd_up reduces from (g, x) itself."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    if o.WINO_FWD != 2:
+        pytest.skip("F(4,3) switched off (NEF_WINOGRAD)")
+    gc = g(rnd(B, Cin, T, seed=195))
+    w = g(rnd(Cin, Cout, 3, seed=196, scale=0.05))
+    c_below = g(rnd(B, Cout, T // 2, seed=197))
+    gamma, beta = g(rnd(Cout, seed=198) + 1.2), g(rnd(Cout, seed=199, scale=0.3))
+    mean, invstd, a_, b_ = o.bn_train_stats(c_below, gamma, beta, torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV), 3)
+    wpf = o.pack_weight(w, 1, flip=True, T=T, f4=True)
+    slots = o.conv_stats_buffer(wpf, B, 1, Cout, T, gc.device)
+    slots[0].fill_(float("nan"))
+    gref = o.conv(GV.dense(gc, 1), wpf, Cout, 3, role="conv_bwd_data")
+    gv = o.conv(GV.dense(gc, 1), wpf, Cout, 3, role="conv_bwd_data",
+                bnb=(c_below, mean, invstd, a_, b_, B // 3, slots, True))
+    assert torch.equal(gv, gref)
+    want = o.bn_relu_bwd_up(gv, c_below, mean, invstd, a_, b_, 3)
+    got = o.bn_relu_bwd_up(gv, c_below, mean, invstd, a_, b_, 3, slots=slots)
+    for x_, y_ in zip(got[:3], want[:3]):
+        assert rel(x_, y_) < 2e-6
+    assert maxabs(got[3], want[3]) < 1e-4 * float(want[0].abs().sum() / Cout) + 1e-6
+
+
 def test_bn_relu_bwd_combine3_equals_two_calls():
     o = ops()
     Bp, C, L = 2, 16, 301
