@@ -1203,7 +1203,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
     const float* __restrict__ x, int64_t x_bs, int64_t x_gs, const float* __restrict__ in_scale, int64_t sc_bs,
     int64_t sc_gs, const float* __restrict__ gy, int64_t gy_bs, int64_t gy_gs, float* __restrict__ ws, int B, int T,
     int G, int Cig, int Cog, int seg_shift, int nseg, int tps, int n_tiles, int m_tiles, int ci_chunks, int S,
-    const float* __restrict__ pro_a, const float* __restrict__ pro_b, int pro_Bp, int contig) {
+    const float* __restrict__ pro_a, const float* __restrict__ pro_b, int pro_Bp) {
     constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;   // same input prologue as conv_fwd_kernel
     constexpr int NS = UP ? 2 : 1;
     const int Tin = UP ? (T >> 1) : T;
@@ -1330,17 +1330,11 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
             if (in_scale && ok) xh[h][0] *= in_scale[(int64_t)(b0 + sg) * sc_bs + (int64_t)g * sc_gs + c0 + row];   \
         }                                                                                                           \
     }
-    // A split's share of the column tiles: `contig` = a contiguous run (consecutive tiles of a row share the cache line
-    // at their boundary and the K-1 halo columns: the second touch hits this XCD's L2), else every S-th tile.
-    const int chunk = (n_tiles + S - 1) / S;
-    const int tile_first = contig ? split * chunk : split;
-    const int tile_step = contig ? 1 : S;
-    const int tile_end = contig ? (tile_first + chunk < n_tiles ? tile_first + chunk : n_tiles) : n_tiles;
-    if (tile_first < tile_end) NEF_BW_ISSUE(tile_first)
+    if (split < n_tiles) NEF_BW_ISSUE(split)
 #ifdef NEF_BW_SETPRIO
     __builtin_amdgcn_s_setprio(1);
 #endif
-    for (int tile = tile_first; tile < tile_end; tile += tile_step) {
+    for (int tile = split; tile < n_tiles; tile += S) {
         __syncthreads();
 #pragma unroll
         for (int rr = 0; rr < GR; ++rr) GYl[(wave + 4 * rr) * GYS + lane] = greg[rr];
@@ -1390,7 +1384,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
             }
         }
         __syncthreads();
-        if (tile + tile_step < tile_end) NEF_BW_ISSUE(tile + tile_step)
+        if (tile + S < n_tiles) NEF_BW_ISSUE(tile + S)
         if constexpr (WINO == 2) {
             // transposed F(3,4): 8 reduction steps per 64-column tile, each over two output QUADS (MFMA k = quad): a lane
             // reads its gY row's quad (two aligned 8-byte words) and its X row's six inputs x[4j-1 .. 4j+4] (three), one
@@ -1596,16 +1590,6 @@ __global__ void conv_bwd_weight_reduce(const float* __restrict__ ws, float* __re
     }
 }
 
-// NEF_BW_CONTIG=1: contiguous instead of strided tile shares (measurement switch)
-static int nef_bw_contig() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("NEF_BW_CONTIG");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v;
-}
-
 struct BwdWeightPlan {
     int wco, tci, m_tiles, ci_chunks, S;
     ColTiling ct;
@@ -1678,7 +1662,7 @@ static int launch_bwd_weight(BwdWeightPlan& p, const float* x, int64_t x_bs, int
     const int64_t blocks = (int64_t)p.S * G * p.m_tiles * p.ci_chunks;
     hipLaunchKernelGGL((conv_bwd_weight_kernel<K, WCO, TCI, PRO, WINO>), dim3((unsigned)blocks), dim3(256), lds, st, x, x_bs,
                        x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, ws, B, T, G, Cig, Cog, p.ct.seg_shift, p.ct.nseg,
-                       p.ct.tps, p.ct.n_tiles, p.m_tiles, p.ci_chunks, p.S, pro_a, pro_b, pro_Bp, nef_bw_contig());
+                       p.ct.tps, p.ct.n_tiles, p.m_tiles, p.ci_chunks, p.S, pro_a, pro_b, pro_Bp);
     return nef_launch_status();
 }
 
