@@ -24,6 +24,8 @@ _FUSE_L2 = os.environ.get("NEF_FUSE_L2", "0") == "1"
 # NEF_FUSE_STATS=0: BatchNorm statistics by a pass over the conv output (nef_bn_train_stats) instead of the conv epilogue
 _FUSE_STATS = os.environ.get("NEF_FUSE_STATS", "1") == "1"
 
+_BWD_F4 = os.environ.get("NEF_BWD_F4", "1")
+
 DROPOUT_SITES = ("W_encoder.layer1.0", "W_encoder.layer1.1", "W_encoder.layer1.2", "w_conv.0", "z1_conv.0",
                  "z2_conv1.0", "z2_conv2.0", "z2_conv2.2")
 
@@ -73,10 +75,19 @@ def block_fwd(xv, P, prefix, K, Cog, drop):
     return y, (xv, h, y, prefix, K, Cog, res_conv, drop.scale)
 
 
+def _bwd_f4(K):
+    """Backward-data launches of the encoder-side blocks take F(4,3) (K=3; K=7 as 3+3+1): no ReLU decision is ever taken
+    on a gradient, so the exact-zero / decision-flip argument that keeps their FORWARD convs on F(2,3) does not apply.
+    Measured on the reference's 3-step SGD trajectory: worst parameter 1.4e-5 (bar 2e-4), stem weight 1.8e-6.
+    NEF_BWD_F4=0: F(2,3) there too; =3: K=3 only."""
+    return _BWD_F4 != "0" and (K == 3 or (K == 7 and _BWD_F4 != "3"))
+
+
 def _block_pack_requests(P, prefix, G, T, flip):
     """The operands block_fwd / block_bwd will ask ops.pack_weight for, for ops.pack_many (one launch per pass)."""
-    reqs = [(P[prefix + ".conv1.weight"], G, flip, T), (P[prefix + ".conv2.weight"], G, flip, T)]
     w1 = P[prefix + ".conv1.weight"]
+    f4 = bool(flip) and _bwd_f4(w1.shape[2])
+    reqs = [(P[prefix + ".conv1.weight"], G, flip, T, f4), (P[prefix + ".conv2.weight"], G, flip, T, f4)]
     if w1.shape[2] == 3 and w1.shape[0] // G != w1.shape[1]:          # block_fwd's res_conv condition
         reqs.append((P[prefix + ".residual_conv.weight"], G, flip, None))
     return reqs
@@ -121,8 +132,8 @@ def block_bwd(saved, gy, P, grads, out=None, side=None, pre_gated=False, gate_in
     g2v, hv = GV.dense(g2, G), GV.dense(h, G)
     grads[prefix + ".conv2.weight"] = side.run(lambda: ops.conv_bwd_weight(hv, g2v, K), h, g2)
     # through conv2, then dropout and the inner ReLU: h > 0 <=> ReLU active and kept
-    gc1 = ops.conv(g2v, ops.pack_weight(P[prefix + ".conv2.weight"], G, flip=True, T=xv.T), Cog, K, gate=hv, gate_scale=dscale,
-                   role="conv_bwd_data")
+    gc1 = ops.conv(g2v, ops.pack_weight(P[prefix + ".conv2.weight"], G, flip=True, T=xv.T, f4=_bwd_f4(K)), Cog, K, gate=hv,
+                   gate_scale=dscale, role="conv_bwd_data")
     gc1v = GV.dense(gc1, G)
     grads[prefix + ".conv1.weight"] = side.run(lambda: ops.conv_bwd_weight(xv, gc1v, K), xv.t, gc1)
     if res_conv:
@@ -133,8 +144,8 @@ def block_bwd(saved, gy, P, grads, out=None, side=None, pre_gated=False, gate_in
         resv = GV.dense(gres, G)
     else:
         resv = g2v
-    return ops.conv(gc1v, ops.pack_weight(P[prefix + ".conv1.weight"], G, flip=True, T=xv.T), Cig, K, res=resv, out=out,
-                    gate=xv if gate_input else None, gate_scale=1.0, role="conv_bwd_data")
+    return ops.conv(gc1v, ops.pack_weight(P[prefix + ".conv1.weight"], G, flip=True, T=xv.T, f4=_bwd_f4(K)), Cig, K, res=resv,
+                    out=out, gate=xv if gate_input else None, gate_scale=1.0, role="conv_bwd_data")
 
 
 # ----------------------------------------------------------------------------------------------
