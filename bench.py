@@ -184,10 +184,10 @@ def main():
 
     if rank == 0:
         # dominant kernel: the K=7 grouped conv over the encoder's [B,128V,T] activations (conv_wino_kernel<7,..>: Winograd
-        # F(2,3) on the taps split 3+3+1; conv_fwd_kernel<7,..> with NEF_WINOGRAD=0).  The same kernel runs the forward
-        # (6 launches/step) and the backward-data pass (6 launches/step).  In the backward pass it shares the matrix
-        # pipes with the bwd-weight kernels that run concurrently on the side stream, so its own speed is read from the
-        # forward launches of the timed region; the all-launch average is reported next to it.
+        # F(2,3) on the taps split 3+3+1; conv_fwd_kernel<7,..> with NEF_WINOGRAD=0): the 6 forward launches per step.  The 6
+        # backward-data launches of the same shape run on conv_wino4_kernel<7,..> (F(4,3)) and share the matrix pipes with
+        # the bwd-weight kernels of the side stream, so the roofline is read from the forward launches of the timed region;
+        # the backward-data average is reported next to it.
         # `achieved` counts ALGORITHMIC flops (2*B*Cout*T*Cin_g*K, the direct-convolution count every conv is priced
         # with); the Winograd form executes 10/14 of them on the matrix cores, so `frac` can exceed 1 --
         # `mfma_pipe_frac` is the executed matrix-core work against the same peak.
@@ -224,6 +224,7 @@ def main():
                     "avg_ms": round(avg_ms, 4), "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
                     "hbm_GBps": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1),
                     "avg_ms_bwd_data_launches_overlapped": round(sum(times_bd) / max(len(times_bd), 1), 4),
+                    "bwd_data_kernel": "conv_wino4_kernel<7,4,0> (F(4,3) on taps 3+3+1: no decision is taken on a gradient)",
                     "side_stream": os.environ.get("NEF_SIDE_STREAM", "1") != "0"}
         by_kernel = {}
         hbm = {}
