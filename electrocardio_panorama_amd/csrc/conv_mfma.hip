@@ -1216,6 +1216,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
     constexpr int XS = WINO ? (K == 3 ? 66 : 98) : ((WT + (WT / 16) * (K - 1)) | 1);
     constexpr int NACC = WINO == 2 ? 6 : (WINO ? (K == 3 ? 4 : 9) : K);
     static_assert(WINO != 2 || K == 3, "the F(3,4) form is for three taps");
+    static_assert(WINO != 3 || K == 7, "WINO = 3 is the 4 + 3 split of seven taps");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* GYl = smem;               // [MT][GYS]
     float* Xl = smem + MT * GYS;     // [CIT][XS]
@@ -1464,6 +1465,33 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
 #pragma unroll
                 for (int i = 0; i < TCI; ++i) {
                     const f32x2* d = fx[s_ & 1][i];
+                    if constexpr (WINO == 3) {
+                        // K = 7 split 4 + 3: taps 0..3 through the transposed F(4,2) (points 0, 1, -1, 2, inf: 5 products
+                        // per pair for 4 taps), taps 4..6 through F(3,2) on x[4..7]: 9 MFMAs per 4 columns instead of 10
+                        const float x0 = d[0][0], x1 = d[0][1], x2 = d[1][0], x3 = d[1][1], x4 = d[2][0], x5 = d[2][1],
+                                    x6 = d[3][0], x7 = d[3][1];
+                        float va[5], vb[4];
+                        const float p13 = x3 - x1;
+                        va[0] = fmaf(2.f, x0 - x2, p13);                 // 2x0 - x1 - 2x2 + x3
+                        va[1] = fmaf(-2.f, x1, x3 - x2);                 // -2x1 - x2 + x3
+                        va[2] = fmaf(2.f, x1, fmaf(-3.f, x2, x3));       // 2x1 - 3x2 + x3
+                        va[3] = p13;                                     // -x1 + x3
+                        va[4] = fmaf(2.f, x1 - x3, x4 - x2);             // 2x1 - x2 - 2x3 + x4
+                        const float ua3 = fmaf(2.f, g1, g0);
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[0], va[0], acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[1], va[1], acc[i][1], 0, 0, 0);
+                        acc[i][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[2], va[2], acc[i][2], 0, 0, 0);
+                        acc[i][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua3, va[3], acc[i][3], 0, 0, 0);
+                        acc[i][4] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[3], va[4], acc[i][4], 0, 0, 0);
+                        vb[0] = x4 - x6;
+                        vb[1] = x5 + x6;
+                        vb[2] = x6 - x5;
+                        vb[3] = x5 - x7;
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc[i][5 + n] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[n], vb[n], acc[i][5 + n], 0, 0, 0);
+                        continue;
+                    }
                     float v[4];
                     v[0] = d[0][0] - d[1][0];
                     v[1] = d[0][1] + d[1][0];
@@ -1545,6 +1573,17 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
                     v = (k == 0) ? fmaf(0.25f, acc[i][0][r], fmaf(s34, 1.f / 24.f, -s12 * (1.f / 6.f)))
                       : (k == 1) ? fmaf(d34, 1.f / 12.f, -d12 * (1.f / 6.f))
                                  : (s34 - s12) * (1.f / 6.f) + acc[i][5][r];
+                } else if constexpr (WINO == 3) {
+                    if (k < 4) {        // gW = G^T M with F(2,4)'s filter-transform matrix G (points 0, 1, -1, 2, inf)
+                        const float m0 = acc[i][0][r], m1 = acc[i][1][r], m2 = acc[i][2][r], m3 = acc[i][3][r];
+                        v = (k == 0) ? 0.5f * (m0 - m1) + (m3 - m2) * (1.f / 6.f)
+                          : (k == 1) ? fmaf(m2, 1.f / 6.f, fmaf(m3, 1.f / 3.f, -0.5f * m1))
+                          : (k == 2) ? fmaf(m3, 2.f / 3.f, fmaf(m2, -1.f / 6.f, -0.5f * m1))
+                                     : fmaf(m3, 4.f / 3.f, fmaf(m2, 1.f / 6.f, -0.5f * m1)) + acc[i][4][r];
+                    } else {            // taps 4..6: the F(3,2) output transform on tiles 5..8
+                        const float hs = 0.5f * (acc[i][6][r] + acc[i][7][r]);
+                        v = (k == 4) ? acc[i][5][r] + hs : (k == 5) ? 0.5f * (acc[i][6][r] - acc[i][7][r]) : hs - acc[i][8][r];
+                    }
                 } else if constexpr (WINO) {
                     if (k == 6) {
                         v = acc[i][NACC - 1][r];
@@ -2008,11 +2047,11 @@ int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const 
                               int T, int G, int Cin_g, int Cout_g, int K, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(x && gy && gw && ws, NEF_E_NULL);
-    NEF_REQUIRE(B > 0 && T >= WT && T % 2 == 0 && G > 0 && K == 3, NEF_E_SHAPE);
-    NEF_REQUIRE(pro_mode >= 0 && pro_mode <= 3 && !(pro_mode && in_scale), NEF_E_UNSUPPORTED);
+    NEF_REQUIRE(B > 0 && T >= WT && T % 2 == 0 && G > 0 && (K == 3 || K == 7), NEF_E_SHAPE);
+    NEF_REQUIRE(pro_mode >= 0 && pro_mode <= 3 && (K == 3 || pro_mode == 0) && !(pro_mode && in_scale), NEF_E_UNSUPPORTED);
     NEF_REQUIRE(!(pro_mode & 1) || (pro_a && pro_b && pro_Bp > 0), NEF_E_NULL);
     BwdWeightPlan p;
-    NEF_REQUIRE(plan_bwd_weight(B, T, G, Cin_g, Cout_g, K, &p, pro_mode, 2), NEF_E_SHAPE);
+    NEF_REQUIRE(plan_bwd_weight(B, T, G, Cin_g, Cout_g, K, &p, pro_mode, K == 7 ? 1 : 2), NEF_E_SHAPE);
     NEF_REQUIRE(p.ct.nseg == 1, NEF_E_SHAPE);
     const size_t need = (size_t)p.S * G * K * Cout_g * Cin_g * sizeof(float);
     NEF_REQUIRE(ws_bytes >= need, NEF_E_WORKSPACE);
@@ -2029,7 +2068,14 @@ int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const 
         else if (pro_mode == 2) NEF_BW4(WCO, 2);                                                                      \
         else NEF_BW4(WCO, 3);                                                                                         \
     }
-    if (p.wco == 4) NEF_BW4_MODE(4) else NEF_BW4_MODE(2)
+    if (K == 7) {       // seven taps split 4 + 3: transposed F(4,2) + F(3,2), 9 instead of 10 MFMAs per 4 columns
+        if (p.wco == 4)
+            rc = launch_bwd_weight<7, 4, 1, 0, 3>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G,
+                                                  Cin_g, Cout_g, st);
+        else
+            rc = launch_bwd_weight<7, 2, 1, 0, 3>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G,
+                                                  Cin_g, Cout_g, st);
+    } else if (p.wco == 4) NEF_BW4_MODE(4) else NEF_BW4_MODE(2)
 #undef NEF_BW4_MODE
 #undef NEF_BW4
     if (rc != NEF_OK) return rc;

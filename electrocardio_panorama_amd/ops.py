@@ -196,6 +196,8 @@ WINOGRAD = _WV != "0"
 WINO_FWD = 1 if _WV in ("1", "2") else 2
 # K=3 weight gradients through the transposed F(3,4) (6 MFMAs per 8 columns instead of F(3,2)'s 8); NEF_BW_WINO4=0: F(3,2)
 WINO_BW4 = os.environ.get("NEF_BW_WINO4", "1") == "1" and _WV not in ("1", "2")
+# K=7 weight gradients with the taps split 4 + 3 (transposed F(4,2) + F(3,2): 9 MFMAs per 4 columns instead of 3+3+1's 10)
+WINO_BW7 = os.environ.get("NEF_BW7_F42", "1") == "1" and _WV not in ("1", "2")
 _WINO_PLANES = {(1, 3): 4, (1, 7): 10, (2, 3): 6, (2, 7): 17}
 
 
@@ -340,7 +342,8 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
 
 def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None):
     """gw [G*Cog, Cig, K] for y = conv(prologue(x) * in_scale, w); `pro` as in conv().  `wino`: force / forbid the
-    Winograd F(3,2) form (default: wherever it applies, see WINOGRAD); 4 = the transposed F(3,4) (K == 3)."""
+    Winograd F(3,2) form (default: wherever it applies, see WINOGRAD); 4 = the transposed F(3,4) (K == 3) resp. the
+    4 + 3 split through F(4,2) + F(3,2) (K == 7)."""
     L = _lib.load()
     B, T, G, Cig, Cog = xv.B, gyv.T, xv.G, xv.Cg, gyv.Cg
     gw = torch.empty(G * Cog, Cig, K, device=xv.t.device, dtype=torch.float32)
@@ -352,11 +355,11 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None):
     ev = _timed(("conv_bwd_weight", K, G, Cig, Cog, B, T))
     if wino is None:
         wino = WINOGRAD and K in (3, 7) and T % 2 == 0 and T >= 64 and not (K == 7 and pro is not None and pro[0])
-        if wino and K == 3 and WINO_BW4:
+        if wino and ((K == 3 and WINO_BW4) or (K == 7 and WINO_BW7)):
             wino = 4
     if wino:
         pm, pa, pb, pbp = (pro[0], _p(pro[1]), _p(pro[2]), pro[3]) if (pro is not None and pro[0]) else (0, None, None, 1)
-        fn = L.nef_conv_bwd_weight_wino4 if (wino == 4 and K == 3) else L.nef_conv_bwd_weight_wino
+        fn = L.nef_conv_bwd_weight_wino4 if wino == 4 else L.nef_conv_bwd_weight_wino
         _lib.check(fn(xv.ptr, xv.bs, xv.gs, sc, sc_bs, sc_gs, pa, pb, pm, pbp, gyv.ptr, gyv.bs,
                                               gyv.gs, _p(gw), _p(ws), n, B, T, G, Cig, Cog, K, _stream()),
                    "nef_conv_bwd_weight_wino")

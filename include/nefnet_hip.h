@@ -160,9 +160,11 @@ int nef_conv_bwd_weight_wino(const float* x, int64_t x_bs, int64_t x_gs, const f
                              int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
                              const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B, int T,
                              int G, int Cin_g, int Cout_g, int K, nef_stream_t stream);
-/* ... and through the transposed F(3,4) (K == 3 only): 6 multiplies per four columns -- 1/2 of the direct form's, 3/4 of
+/* ... and one size up.  K == 3: the transposed F(3,4), 6 multiplies per four columns -- 1/2 of the direct form's, 3/4 of
  * F(3,2)'s; transform entries up to 8 and 1/24 (the F(4,3) matrices of the forward kernels, roles exchanged): measured
- * rounding 1..6x the direct form's on the reduced sum.  Same arguments, workspace and constraints. */
+ * rounding 1..6x the direct form's on the reduced sum.  K == 7 (pro_mode 0): the taps split 4 + 3 -- transposed F(4,2)
+ * (points 0, 1, -1, 2, inf) + F(3,2): 9 instead of 10 multiplies per column pair.  Same arguments, workspace and
+ * constraints. */
 int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
                               int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
                               const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B, int T,

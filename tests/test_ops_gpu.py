@@ -871,11 +871,10 @@ def test_conv_winograd_prologue_modes(mode, Cig, Cog, T_out, f4):
 ])
 @pytest.mark.parametrize("form", [True, 4])
 def test_conv_bwd_weight_winograd(K, G, Cig, Cog, T, B, form):
-    """The weight gradient through the transposed Winograd forms F(3,2) (`form` True) and F(3,4) (`form` 4, K = 3) against
-    autograd, next to the direct kernel, and all against fp64: within 4x (F(3,2)) resp. 8x (F(3,4), whose transforms
+    """The weight gradient through the transposed Winograd forms F(3,2) (`form` True) and F(3,4) (`form` 4, K = 3; K = 7:
+    the 4 + 3 split through F(4,2) + F(3,2)) against autograd, next to the direct kernel, and all against fp64: within 4x (F(3,2)) resp. 8x (F(3,4), whose transforms
     carry entries up to 8 and 1/24) of the larger of the direct kernel's and torch-CPU's own distance from exact."""
-    if form == 4 and K != 3:
-        pytest.skip("F(3,4) is the three-tap form")
+
     o = ops()
     from electrocardio_panorama_amd.ops import GV
     x = rnd(B, G * Cig, T, seed=31)
