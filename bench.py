@@ -225,7 +225,7 @@ def main():
                     "hbm_GBps": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1),
                     "avg_ms_bwd_data_launches_overlapped": round(sum(times_bd) / max(len(times_bd), 1), 4),
                     "bwd_data_kernel": "conv_wino4_kernel<7,4,0> (F(4,3) on taps 3+3+1: no decision is taken on a gradient)",
-                    "side_stream": os.environ.get("NEF_SIDE_STREAM", "1") != "0"}
+                    "side_stream": os.environ.get("NEF_SIDE_STREAM", "auto") != "0"}
         by_kernel = {}
         hbm = {}
         for tag, s, e in prof_all:

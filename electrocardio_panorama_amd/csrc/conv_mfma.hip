@@ -1751,9 +1751,12 @@ __global__ void chan_sum_partial(const float* __restrict__ x, double* __restrict
     const int c = blockIdx.x % C;
     const int sp = blockIdx.x / C;
     double s = 0.0;
-    for (int b = sp; b < B; b += nsplit) {
-        const float* row = x + ((int64_t)b * C + c) * T;
-        for (int t = threadIdx.x; t < T; t += blockDim.x) s += (double)row[t];
+    // the split's rows b = sp, sp + nsplit, .. as ONE index space (row, t): short rows (the 16/32-sample ROI latents, the
+    // 6-sample z2 window) keep all 256 threads busy instead of T of them
+    const int nb = sp < B ? (B - sp + nsplit - 1) / nsplit : 0;
+    for (int i = threadIdx.x; i < nb * T; i += blockDim.x) {
+        const int bi = i / T, t = i - bi * T;
+        s += (double)x[((int64_t)(sp + bi * nsplit) * C + c) * T + t];
     }
     s = nef_block_sum_d(s, sm);
     if (threadIdx.x == 0) part[(int64_t)sp * C + c] = s;

@@ -106,6 +106,21 @@ def _train_once(V, B, L, seed, reg, masked):
     return m, outs, losses
 
 
+def test_side_stream_modes_are_bit_identical(monkeypatch):
+    """NEF_SIDE_STREAM: weight gradients on a second stream (forced on here; `auto` keeps launch-bound shapes like this
+    one on a single stream) or inline -- the same kernels on the same operands, so every gradient is bit-identical."""
+    grads = {}
+    for mode in ("1", "0", "auto"):
+        monkeypatch.setenv("NEF_SIDE_STREAM", mode)
+        m, outs, losses = _train_once(3, 3, 512, 11, "l1_loss", True)
+        torch.cuda.synchronize()
+        grads[mode] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    for mode in ("0", "auto"):
+        assert grads[mode].keys() == grads["1"].keys()
+        for k in grads["1"]:
+            assert torch.equal(grads[mode][k], grads["1"][k]), (mode, k)
+
+
 def oracle_replaying(m, outs, b, V, seed, masks=None, dt=torch.float32, reg="l1_loss", model2=False, fold=None,
                      lead_choice=None):
     """Run the CPU oracle on the same inputs while it REPLAYS the discrete decisions (ReLU on/off, L1 signs) the HIP

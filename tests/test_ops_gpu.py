@@ -196,10 +196,11 @@ def test_conv_dropout_rng():
     assert set(torch.unique(y1).cpu().tolist()) == {0.0, 1.25}
 
 
-def test_chan_sum():
+@pytest.mark.parametrize("shape", [(5, 37, 333), (40, 21, 32), (3, 8, 6), (33, 5, 1), (2, 3, 1250)])
+def test_chan_sum(shape):
     o = ops()
-    x = rnd(5, 37, 333, seed=16)
-    assert rel(o.chan_sum(g(x)), x.sum(dim=(0, 2))) < 1e-6
+    x = rnd(*shape, seed=16)
+    assert rel(o.chan_sum(g(x)), x.double().sum(dim=(0, 2))) < 1e-6
 
 
 @pytest.mark.parametrize("fma", [False, True])      # matrix-core path (1x1 conv + interleave) and the plain-FMA kernel
