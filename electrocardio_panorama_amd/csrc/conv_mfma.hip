@@ -1851,6 +1851,7 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
     NEF_REQUIRE(!(a->stats && a->bnb_slots), NEF_E_UNSUPPORTED);
     NEF_REQUIRE(!a->bnb_slots || (a->bnb_x && a->bnb_mean && a->bnb_invstd && a->bnb_a && a->bnb_b), NEF_E_NULL);
     NEF_REQUIRE(!a->bnb_slots || a->bnb_Bp > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(!a->bnb_slots || !a->bnb_up || a->T % 4 == 0, NEF_E_SHAPE);
     bool big = (a->Cout_g % 128 == 0);
     if (big) {
         // small problems (reference-native batch 32, L=512): a 128-row tile gives fewer workgroups than the chip has
