@@ -172,6 +172,12 @@ def main():
     prof_all, extra_steps = [], 2
     if not args.no_kernel_events and not args.graph:       # every rank takes the extra steps (they contain the all-reduce)
         ops.PROFILE = [] if rank == 0 else None
+        # one more bracketed step first, whose events are dropped: the first event pair recorded behind a cross-stream
+        # wait can come back with the wait inside it (seen once: 52 ms on a 0.23 ms launch of the first bracketed step)
+        step()
+        fence()
+        if rank == 0:
+            ops.PROFILE = []
         for _ in range(extra_steps):
             step()
         fence()
@@ -239,6 +245,9 @@ def main():
         # the set BASELINE.json's ">= 40 % of the HBM roofline" applies to; times are HIP events around each
         # launch in the live (two-stream) schedule, so a pass that shares the chip with a side-stream MFMA kernel reads low;
         # profiles/r02_hbm_kernels.md has the same table with every launch alone
+        if os.environ.get("NEF_BENCH_DUMP"):        # per-launch event times of the untimed breakdown steps
+            with open(os.environ["NEF_BENCH_DUMP"], "w") as f:
+                json.dump([["/".join(str(x) for x in tag), round(s.elapsed_time(e), 4)] for tag, s, e in prof_all], f)
         hbm_bound = {k: {"GBps": round(v[0] / (v[1] * 1e-3) / 1e9, 1), "frac": round(v[0] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
                          "ms_per_step": round(v[1] / extra_steps, 3), "launches_per_step": v[2] // extra_steps}
                      for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1]) if v[1] > 0}
