@@ -32,6 +32,7 @@
 // matrix pipes busy 36 % of SIMD cycles at an effective 1.5 GHz, 31 % of wave time waiting on memory -- the layer-wise
 // pipeline is within 25 % of its HBM floor; the next step is keeping c1 / c3 on chip (layer pairs fused).
 #include "nef_common.h"
+#include <stdlib.h>
 
 typedef _Float16 nef_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 nef_h4 __attribute__((ext_vector_type(4)));
@@ -340,6 +341,240 @@ __global__ __launch_bounds__(256, MINB) void hconv_kernel(const _Float16* __rest
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// hconv_wide_kernel<CIN,PRO>: the two 128-output-channel layers (256 -> 128 behind the x2 upsampling and the query
+// scaling, 128 -> 128).  hconv_kernel spends more LDS cycles than matrix-core cycles on these (gfx950: ds_write_b128
+// moves ~79 B/clk/CU, so re-staging the 48 KB weight chunk of every 128-column tile alone costs 620 of the tile's
+// 1536 matrix cycles; reads run at 256 B/clk).  Here
+//   wave    = 64 co x 128 t (2 x 4 accumulator tiles, 128 accumulator registers): half the A bytes per MFMA
+//   tile    = 128 co x 256 t of one pair; 4 waves = 2 (co) x 2 (t); persistent blocks, 2 per CU
+//   A       = weight fragments straight from L2 into registers (lane-linear 1 KB fragments, 2 per k-step, ring of three
+//             k-steps in flight): the weights never touch LDS
+//   B       = X chunk [258 rows][64 ch + pad] DOUBLE-buffered in LDS: the next (tile, chunk) is fetched into registers
+//             at the top of a chunk and stored into the other buffer behind its 96 MFMAs -> one barrier per chunk
+//   x2 upsample: a thread blends 8 (9 at the tile edges) output rows from 6 source rows in registers -- no raw-row
+//             LDS round trip; same packed-half arithmetic as hconv_kernel (0.25*b exact, one fma rounding)
+//   epilogue: per time half (128 rows x 128 co) through the consumed X buffer, whole 256-byte rows out
+// ------------------------------------------------------------------------------------------------------------
+#define PHW_ORS 272   // bytes per staged output row: 128 halfs + 16 B pad
+
+template <int CIN, int COUT, int PRO>
+__global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __restrict__ x, const nef_h8* __restrict__ wp,
+                                                         const float* __restrict__ bias, const float* __restrict__ scale,
+                                                         _Float16* __restrict__ y, int T, int tiles_per_n, int total_tiles,
+                                                         int x_div, int nq, long sc_bs, long sc_is) {
+    constexpr int WM = COUT / 64, WN = 4 / WM;   // waves along the output channels / along time
+    constexpr int NT = 256, NI = NT / (32 * WN); // wave = 64 co x 128 t (COUT = 128) or 64 co x 64 t (COUT = 64)
+    constexpr int MT = COUT / 32;                // A fragments per k-step in the packed weights
+    constexpr int XROWS = NT + 2;
+    constexpr int XBYTES = XROWS * PH_XRS;
+    constexpr int NCC = CIN / 64;
+    constexpr bool UP = (PRO & 2) != 0, SC = (PRO & 1) != 0;
+    constexpr int XIT = UP ? 6 : 9;          // 16-byte fetches per thread and chunk ...
+    constexpr int XB1 = UP ? 6 : 5;          // ... in two batches (0..XB1, XB1..XIT) when not upsampling: fewer registers
+    constexpr int AD = 4;                    // A ring: fragments of AD - 1 k-steps in flight
+    static_assert(COUT == 64 || COUT == 128, "one or two waves along the output channels");
+    static_assert(128 * PHW_ORS <= XBYTES, "the output staging of one time half lives in one X buffer");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // two X buffers
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int seg = tid & 7, rg = tid >> 3;
+    const int Tin = UP ? T / 2 : T;
+
+    nef_f16acc acc[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    nef_h8 xr[XB1];
+    float qr[8];
+    int ft0 = 0;                             // t0 of the tile held in xr
+    nef_h8 hzero;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hzero[e] = (_Float16)0.f;
+
+#define PHW_FETCH(tile_, cc_, J0_, J1_)                                                                       \
+    {                                                                                                         \
+        const int n_ = (tile_) / tiles_per_n, t0_ = ((tile_) % tiles_per_n) * NT;                             \
+        ft0 = t0_;                                                                                            \
+        const __amdgpu_buffer_rsrc_t xd_ = __builtin_amdgcn_make_buffer_rsrc(                                 \
+            const_cast<_Float16*>(x + (size_t)(n_ / x_div) * Tin * CIN), 0, Tin * CIN * 2, 0x00020000);       \
+        if (UP) {                                                                                             \
+            const int rb_ = t0_ / 2 + 4 * rg - 1;                                                             \
+            _Pragma("unroll") for (int k = 0; k < XIT; ++k) {                                                 \
+                int r_ = rb_ + k;                                                                             \
+                r_ = r_ < 0 ? 0 : (r_ > Tin - 1 ? Tin - 1 : r_);                                              \
+                xr[k] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(                     \
+                    xd_, r_ * (CIN * 2) + seg * 16, (cc_) * 128, 0));                                         \
+            }                                                                                                 \
+        } else {                                                                                              \
+            /* the whole offset in the per-lane operand: only that one takes part in the hardware range check */ \
+            const unsigned o_ = (unsigned)((t0_ - 1 + rg) * (CIN * 2) + seg * 16 + (cc_) * 128);              \
+            _Pragma("unroll") for (int j = (J0_); j < (J1_); ++j)                                             \
+                xr[j - (J0_)] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(             \
+                    xd_, (int)((j == XIT - 1 && tid + j * 256 >= XROWS * 8) ? NEF_OOB : o_ + j * 32 * CIN * 2), 0, 0)); \
+        }                                                                                                     \
+        if (SC && (J0_) == 0) {                                                                               \
+            const float* sc_ = scale + (size_t)(n_ / nq) * sc_bs + (size_t)(n_ % nq) * sc_is + (cc_) * 64;    \
+            const __amdgpu_buffer_rsrc_t sd_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sc_), 0, 256, 0x00020000); \
+            const nef_f32x4 q0_ = nef_buf_f32x4(sd_, seg * 32, 0), q1_ = nef_buf_f32x4(sd_, seg * 32 + 16, 0); \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) { qr[e] = q0_[e]; qr[4 + e] = q1_[e]; }             \
+        }                                                                                                     \
+    }
+    // registers -> X buffer `Xn_` (row r of the buffer is output time ft0 - 1 + r)
+#define PHW_STAGE(Xn_, J0_, J1_)                                                                              \
+    {                                                                                                         \
+        if (UP) {                                                                                             \
+            nef_h8 qh, c75;                                                                                   \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) { c75[e] = (_Float16)0.75f; qh[e] = SC ? (_Float16)qr[e] : (_Float16)1.f; } \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
+                const nef_h8 a_ = xr[(j >> 1) + 1], b_ = (j & 1) ? xr[(j >> 1) + 2] : xr[j >> 1];             \
+                nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);                         \
+                if (SC) v_ = v_ * qh;                                                                         \
+                if (ft0 + 8 * rg + j >= T) v_ = hzero;                                                        \
+                *(nef_h8*)((Xn_) + (8 * rg + 1 + j) * PH_XRS + seg * 16) = v_;                                \
+            }                                                                                                 \
+            if (rg == 0 || rg == 31) {   /* the two halo rows: t = ft0 - 1 (odd) and t = ft0 + 256 (even) */  \
+                const nef_h8 a_ = rg == 0 ? xr[0] : xr[5], b_ = rg == 0 ? xr[1] : xr[4];                      \
+                nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);                         \
+                if (SC) v_ = v_ * qh;                                                                         \
+                if (rg == 0 ? ft0 == 0 : ft0 + NT >= T) v_ = hzero;                                           \
+                *(nef_h8*)((Xn_) + (rg == 0 ? 0 : XROWS - 1) * PH_XRS + seg * 16) = v_;                       \
+            }                                                                                                 \
+        } else {                                                                                              \
+            _Pragma("unroll") for (int j = (J0_); j < (J1_); ++j) {                                           \
+                nef_h8 v_ = xr[j - (J0_)];                                                                    \
+                if (SC) {                                                                                     \
+                    _Pragma("unroll") for (int e = 0; e < 8; ++e) v_[e] = (_Float16)((float)v_[e] * qr[e]);   \
+                }                                                                                             \
+                if (j < XIT - 1 || tid + j * 256 < XROWS * 8)                                                 \
+                    *(nef_h8*)((Xn_) + (rg + 32 * j) * PH_XRS + seg * 16) = v_;                               \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+    // A fragments of k-step s_ (= tap * 4 + kq) of chunk ccv_: stage-major packing, 4 fragments of 1 KB per stage
+    const __amdgpu_buffer_rsrc_t wd = nef_rsrc(wp);
+    const int avoff = lane * 16 + wm * 2048;
+    nef_h8 a[AD][2];
+#define PHW_A(slot_, ccv_, s_)                                                                                \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                          \
+        a[slot_][mi] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(                      \
+            wd, avoff, ((ccv_) * 12 + (s_)) * (MT * 1024) + mi * 1024, 0));
+
+    int tile = blockIdx.x;
+    int p = 0;
+    PHW_A(0, 0, 0)
+    PHW_A(1, 0, 1)
+    PHW_A(2, 0, 2)
+    if (tile < total_tiles) {
+        PHW_FETCH(tile, 0, 0, XB1)
+        PHW_STAGE(smem, 0, XB1)
+        if (XB1 < XIT) {
+            PHW_FETCH(tile, 0, XB1, XIT)
+            PHW_STAGE(smem, XB1, XIT)
+        }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (; tile < total_tiles; tile += gridDim.x) {
+        const int n = tile / tiles_per_n, t0 = (tile % tiles_per_n) * NT;
+#pragma unroll 1
+        for (int cc = 0; cc < NCC; ++cc) {
+            const char* Xc = smem + p * XBYTES;
+            char* Xn = smem + (p ^ 1) * XBYTES;
+            const bool more = cc + 1 < NCC || tile + (int)gridDim.x < total_tiles;
+            const int ccn = cc + 1 < NCC ? cc + 1 : 0;
+            const int tile_n = cc + 1 < NCC ? tile : tile + (int)gridDim.x;   // the (tile, chunk) staged behind this one
+            const char* Xs = Xc + (wn * (NI * 32) + lo) * PH_XRS + 16 * hi;
+            nef_h8 b[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *(const nef_h8*)(Xs + ni * 32 * PH_XRS);
+#pragma unroll
+            for (int s = 0; s < 12; ++s) {
+                // the A fragments AD - 1 k-steps ahead (wrapping into the next chunk: the weights are the same for every
+                // tile).  Loads return in order, so a wait for A also waits for every X fetch issued before it: the X
+                // batches go out right BEHIND an A issue and get AD - 1 k-steps before a wait reaches them.
+                if (s + AD - 1 < 12) {
+                    PHW_A((s + AD - 1) % AD, cc, s + AD - 1)
+                } else {
+                    PHW_A((s + AD - 1) % AD, ccn, s + AD - 1 - 12)
+                }
+                if (s == 1 && more) PHW_FETCH(tile_n, ccn, 0, XB1)
+                if (XB1 < XIT && s == 6 && more) {
+                    PHW_STAGE(Xn, 0, XB1)
+                    PHW_FETCH(tile_n, ccn, XB1, XIT)
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the fetches where they are
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % AD][mi], b[ni], acc[mi][ni], 0, 0, 0);
+                    if (s + 1 < 12)       // this B register is free again: next k-step's fragment
+                        b[ni] = *(const nef_h8*)(Xs + (ni * 32 + (s + 1) / 4) * PH_XRS + ((s + 1) % 4) * 32);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {    // issue order: 2 MFMAs, the LDS read that refills their B register, ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) PHW_STAGE(Xn, XB1 < XIT ? XB1 : 0, XIT)
+            __syncthreads();                 // next chunk staged; every wave is done reading Xc
+            p ^= 1;
+        }
+
+        // epilogue: bias + ReLU -> fp16 through the buffer the last chunk consumed; whole rows leave as 16-byte vectors
+        char* Ol = smem + (p ^ 1) * XBYTES;
+        _Float16* yb = y + (size_t)n * T * COUT;
+        constexpr int NPS = COUT / 64;           // 128 channels: one time half (128 rows x 256 B) per pass
+        constexpr int ORS = COUT == 128 ? PHW_ORS : PH_XRS;
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+            if (NPS == 1 || wn == ps) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = wm * 64 + mi * 32 + 8 * g + 4 * hi;
+                        const nef_f32x4 bv = *(const nef_f32x4*)(bias + co);
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            nef_h4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                o[e] = (_Float16)fmaxf(acc[mi][ni][g * 4 + e] + bv[e], 0.f);
+                                acc[mi][ni][g * 4 + e] = 0.f;
+                            }
+                            *(nef_h4*)(Ol + ((NPS == 1 ? wn * NI * 32 : 0) + ni * 32 + lo) * ORS + co * 2) = o;
+                        }
+                    }
+            }
+            __syncthreads();
+            constexpr int VPR = COUT / 8;        // 16-byte vectors per output row
+            constexpr int ROWS = NT / NPS;
+#pragma unroll
+            for (int k = 0; k < ROWS * VPR / 256; ++k) {
+                const int idx = tid + k * 256, r = idx / VPR, v = idx % VPR;
+                const int t = t0 + ps * ROWS + r;
+                if (t < T)
+                    *(nef_h8*)(yb + (size_t)t * COUT + v * 8) = *(const nef_h8*)(Ol + r * ORS + v * 16);
+            }
+            __syncthreads();                 // staging read: the next pass / the next chunk's X may overwrite it
+        }
+    }
+#undef PHW_FETCH
+#undef PHW_STAGE
+#undef PHW_A
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Last conv 64 -> 1 (k3, bias) + sigmoid(x/3) (model_nefnet.py:106,:168/:186): HBM-bound.  8 lanes share one time
 // step (8 channels x 3 taps each), a block covers 256 consecutive time steps of one pair.
 // ------------------------------------------------------------------------------------------------------------
@@ -443,6 +678,35 @@ static int launch_hconv(const void* x, const void* wp, const float* bias, const 
     return nef_launch_status();
 }
 
+template <int CIN, int COUT, int PRO>
+static int launch_hconv_wide(const void* x, const void* wp, const float* bias, const float* scale, void* y, int N, int T,
+                             int x_div, int nq, long sc_bs, long sc_is, hipStream_t st) {
+    constexpr int NT = 256;
+    constexpr int LDS = 2 * (NT + 2) * PH_XRS;
+    const int tiles = (T + NT - 1) / NT;
+    const int64_t total = (int64_t)N * tiles;
+    if (total > 0x7FFFFFFF) return NEF_E_SHAPE;
+    auto k = hconv_wide_kernel<CIN, COUT, PRO>;
+    static int resident_dev[64] = {0};       // per device, idempotent -> thread-safe without a lock
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int resident = __atomic_load_n(&resident_dev[dev & 63], __ATOMIC_ACQUIRE);
+    if (resident == 0) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        int cus = 0, per_cu = 0;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, 256, LDS)) != hipSuccess)
+            return (int)e;
+        resident = cus * (per_cu > 0 ? per_cu : 1);
+        __atomic_store_n(&resident_dev[dev & 63], resident, __ATOMIC_RELEASE);
+    }
+    const int grid = (int)(total < resident ? total : resident);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), LDS, st, (const _Float16*)x, (const nef_h8*)wp, bias, scale,
+                       (_Float16*)y, T, tiles, (int)total, x_div, nq, sc_bs, sc_is);
+    return nef_launch_status();
+}
+
 extern "C" {
 
 int nef_pano_h_from_f32(const float* x, void* y, int B, int C, int T, nef_stream_t stream) {
@@ -475,6 +739,15 @@ int nef_pano_h_conv(const void* x, const void* wp, const float* bias, const floa
 #define PH_CASE(ci, co, pro) \
     if (Cin == ci && Cout == co && pro_mode == pro) \
         return launch_hconv<ci, co, pro>(x, wp, bias, scale, y, N, T, x_div, nq, sc_bs, sc_is, st)
+#define PHW_CASE(ci, co, pro) \
+    if (Cin == ci && Cout == co && pro_mode == pro && !getenv("NEF_PANO_NARROW")) \
+        return launch_hconv_wide<ci, co, pro>(x, wp, bias, scale, y, N, T, x_div, nq, sc_bs, sc_is, st)
+    PHW_CASE(256, 128, 3);
+    PHW_CASE(256, 128, 1);
+    PHW_CASE(128, 128, 0);
+    PHW_CASE(128, 64, 2);
+    PHW_CASE(128, 64, 0);
+#undef PHW_CASE
     PH_CASE(256, 128, 3);
     PH_CASE(256, 128, 1);
     PH_CASE(128, 128, 0);

@@ -48,6 +48,9 @@ def test_from_f32_is_a_rounding_transpose():
     (128, 64, 200, 1, True, False),
     (256, 128, 256, 6, True, True),        # layer 1: shared latent, per-(sample, angle) channel scale
     (256, 128, 40, 3, True, True),         # shorter than one tile
+    (256, 128, 600, 6, True, True),        # layer 1 over several 256-column tiles: blended halo rows, ragged tail
+    (256, 128, 512, 3, False, True),       # query scaling without the upsampling
+    (128, 128, 700, 2, False, False),      # 128 -> 128 over three tiles
 ])
 def test_h_conv_matches_fp64_on_the_same_operands(Cin, Cout, T, N, upsample, scaled):
     o = ops()
