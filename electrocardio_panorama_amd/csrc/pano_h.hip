@@ -374,13 +374,14 @@ __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __re
     constexpr int AD = 4;                    // A ring: fragments of AD - 1 k-steps in flight
     static_assert(COUT == 64 || COUT == 128, "one or two waves along the output channels");
     static_assert(128 * PHW_ORS <= XBYTES, "the output staging of one time half lives in one X buffer");
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // two X buffers
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // two X buffers + a 16-byte dump slot per thread
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int lo = lane & 31, hi = lane >> 5;
     const int seg = tid & 7, rg = tid >> 3;
     const int Tin = UP ? T / 2 : T;
+    char* const dump = smem + 2 * XBYTES + tid * 16;
 
     nef_f16acc acc[2][NI];
 #pragma unroll
@@ -425,34 +426,37 @@ __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __re
             _Pragma("unroll") for (int e = 0; e < 4; ++e) { qr[e] = q0_[e]; qr[4 + e] = q1_[e]; }             \
         }                                                                                                     \
     }
-    // registers -> X buffer `Xn_` (row r of the buffer is output time ft0 - 1 + r)
-#define PHW_STAGE(Xn_, J0_, J1_)                                                                              \
+    // registers -> X buffer `Xn_` (row r of the buffer is output time ft0 - 1 + r), pieces J0_ <= j < J1_.  Upsampling:
+    // j = 0..7 are the thread's eight blended rows, j = 8 the tile's two halo rows (threads of the first / last row
+    // group); otherwise j counts the fetched vectors and JB_ is the first one of the batch held in xr.
+#define PHW_STAGE(Xn_, J0_, J1_, JB_)                                                                         \
     {                                                                                                         \
         if (UP) {                                                                                             \
             nef_h8 qh, c75;                                                                                   \
             _Pragma("unroll") for (int e = 0; e < 8; ++e) { c75[e] = (_Float16)0.75f; qh[e] = SC ? (_Float16)qr[e] : (_Float16)1.f; } \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
+            _Pragma("unroll") for (int j = (J0_); j < (J1_) && j < 8; ++j) {                                  \
                 const nef_h8 a_ = xr[(j >> 1) + 1], b_ = (j & 1) ? xr[(j >> 1) + 2] : xr[j >> 1];             \
                 nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);                         \
                 if (SC) v_ = v_ * qh;                                                                         \
                 if (ft0 + 8 * rg + j >= T) v_ = hzero;                                                        \
                 *(nef_h8*)((Xn_) + (8 * rg + 1 + j) * PH_XRS + seg * 16) = v_;                                \
             }                                                                                                 \
-            if (rg == 0 || rg == 31) {   /* the two halo rows: t = ft0 - 1 (odd) and t = ft0 + 256 (even) */  \
-                const nef_h8 a_ = rg == 0 ? xr[0] : xr[5], b_ = rg == 0 ? xr[1] : xr[4];                      \
-                nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);                         \
+            if ((J1_) > 8) {   /* t = ft0 - 1 (odd) and t = ft0 + 256 (even); the other row groups store into */ \
+                const nef_h8 a_ = rg == 0 ? xr[0] : xr[5], b_ = rg == 0 ? xr[1] : xr[4];   /* their dump slot: */ \
+                nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);   /* no branch among the MFMAs */ \
                 if (SC) v_ = v_ * qh;                                                                         \
                 if (rg == 0 ? ft0 == 0 : ft0 + NT >= T) v_ = hzero;                                           \
-                *(nef_h8*)((Xn_) + (rg == 0 ? 0 : XROWS - 1) * PH_XRS + seg * 16) = v_;                       \
+                char* d_ = (Xn_) + (rg == 0 ? 0 : XROWS - 1) * PH_XRS + seg * 16;                             \
+                *(nef_h8*)((rg == 0 || rg == 31) ? d_ : dump) = v_;                                           \
             }                                                                                                 \
         } else {                                                                                              \
             _Pragma("unroll") for (int j = (J0_); j < (J1_); ++j) {                                           \
-                nef_h8 v_ = xr[j - (J0_)];                                                                    \
+                nef_h8 v_ = xr[j - (JB_)];                                                                    \
                 if (SC) {                                                                                     \
                     _Pragma("unroll") for (int e = 0; e < 8; ++e) v_[e] = (_Float16)((float)v_[e] * qr[e]);   \
                 }                                                                                             \
-                if (j < XIT - 1 || tid + j * 256 < XROWS * 8)                                                 \
-                    *(nef_h8*)((Xn_) + (rg + 32 * j) * PH_XRS + seg * 16) = v_;                               \
+                char* d_ = (Xn_) + (rg + 32 * j) * PH_XRS + seg * 16;                                         \
+                *(nef_h8*)((j < XIT - 1 || tid + j * 256 < XROWS * 8) ? d_ : dump) = v_;                      \
             }                                                                                                 \
         }                                                                                                     \
     }
@@ -472,10 +476,10 @@ __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __re
     PHW_A(2, 0, 2)
     if (tile < total_tiles) {
         PHW_FETCH(tile, 0, 0, XB1)
-        PHW_STAGE(smem, 0, XB1)
+        PHW_STAGE(smem, 0, UP ? 9 : XB1, 0)
         if (XB1 < XIT) {
             PHW_FETCH(tile, 0, XB1, XIT)
-            PHW_STAGE(smem, XB1, XIT)
+            PHW_STAGE(smem, XB1, XIT, XB1)
         }
     }
     __syncthreads();
@@ -489,7 +493,9 @@ __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __re
             char* Xn = smem + (p ^ 1) * XBYTES;
             const bool more = cc + 1 < NCC || tile + (int)gridDim.x < total_tiles;
             const int ccn = cc + 1 < NCC ? cc + 1 : 0;
-            const int tile_n = cc + 1 < NCC ? tile : tile + (int)gridDim.x;   // the (tile, chunk) staged behind this one
+            // the (tile, chunk) staged behind this one; the block's very last chunk re-stages its own tile (unread) so
+            // that the k-steps carry no branch
+            const int tile_n = (cc + 1 < NCC || !more) ? tile : tile + (int)gridDim.x;
             const char* Xs = Xc + (wn * (NI * 32) + lo) * PH_XRS + 16 * hi;
             nef_h8 b[NI];
 #pragma unroll
@@ -504,12 +510,20 @@ __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __re
                 } else {
                     PHW_A((s + AD - 1) % AD, ccn, s + AD - 1 - 12)
                 }
-                if (s == 1 && more) PHW_FETCH(tile_n, ccn, 0, XB1)
-                if (XB1 < XIT && s == 6 && more) {
-                    PHW_STAGE(Xn, 0, XB1)
-                    PHW_FETCH(tile_n, ccn, XB1, XIT)
-                }
+                if (s == 1) PHW_FETCH(tile_n, ccn, 0, XB1)
+                if (!UP && s == 7) PHW_FETCH(tile_n, ccn, XB1, XIT)
                 __builtin_amdgcn_sched_barrier(0);   // keep the fetches where they are
+                // the staging of the fetched rows rides in the shadow of the MFMAs, a few rows per k-step: by k-step 5
+                // (10) a wait for A has already covered the first (second) batch
+                if (UP) {
+                    if (s >= 6 && s <= 9) PHW_STAGE(Xn, 2 * (s - 6), 2 * (s - 6) + 2, 0)
+                    if (s == 10) PHW_STAGE(Xn, 8, 9, 0)
+                } else {
+                    if (s == 5) PHW_STAGE(Xn, 0, 2, 0)
+                    if (s == 6) PHW_STAGE(Xn, 2, XB1, 0)
+                    if (s == 10) PHW_STAGE(Xn, XB1, XB1 + 2, XB1)
+                    if (s == 11) PHW_STAGE(Xn, XB1 + 2, XIT, XB1)
+                }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
@@ -519,13 +533,14 @@ __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __re
                         b[ni] = *(const nef_h8*)(Xs + (ni * 32 + (s + 1) / 4) * PH_XRS + ((s + 1) % 4) * 32);
                 }
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {    // issue order: 2 MFMAs, the LDS read that refills their B register, ...
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                for (int ni = 0; ni < NI; ++ni) {    // issue order: 2 MFMAs, the LDS read that refills their B register,
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // a share of the staging arithmetic / stores, ...
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 40 / NI, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 4 / NI, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (more) PHW_STAGE(Xn, XB1 < XIT ? XB1 : 0, XIT)
             __syncthreads();                 // next chunk staged; every wave is done reading Xc
             p ^= 1;
         }
@@ -682,7 +697,7 @@ template <int CIN, int COUT, int PRO>
 static int launch_hconv_wide(const void* x, const void* wp, const float* bias, const float* scale, void* y, int N, int T,
                              int x_div, int nq, long sc_bs, long sc_is, hipStream_t st) {
     constexpr int NT = 256;
-    constexpr int LDS = 2 * (NT + 2) * PH_XRS;
+    constexpr int LDS = 2 * (NT + 2) * PH_XRS + 256 * 16;
     const int tiles = (T + NT - 1) / NT;
     const int64_t total = (int64_t)N * tiles;
     if (total > 0x7FFFFFFF) return NEF_E_SHAPE;
