@@ -27,12 +27,11 @@
 //   epilogue: + bias, ReLU, -> fp16, transposed through LDS (over the X chunk, 64 channels per pass) so that every
 //             output row leaves as 16-byte vectors
 //   OUT=1   : the 64->64 layer also evaluates the last conv (64 -> 1) on its staged tile (see below)
-// Measured (MI355X, BASELINE config 4: 1024 samples x 360 angles, len 512): 62 ms per sweep against 377 ms on the fp32
-// path; per 4096 pairs L1 250 us (0.82 PFLOP/s), L2 126 us (4.2 TB/s), L3 150 us, L4 + last conv 80 us.  PMC on L2:
-// matrix pipes busy 36 % of SIMD cycles at an effective 1.5 GHz, 31 % of wave time waiting on memory -- the layer-wise
-// pipeline is within 25 % of its HBM floor; the next step is keeping c1 / c3 on chip (layer pairs fused).
+// Round 2: layers 1-3 (Cin >= 128) run on hconv_wide_kernel below; hconv_kernel keeps the 64 -> 64 layer with the fused
+// last conv.  Measured (MI355X, BASELINE config 4: 1024 samples x 360 angles, len 512): 53.9 ms per sweep against 377 ms
+// on the fp32 path; per 16384 pairs L1 736 us (1.11 PFLOP/s), L2 472 us, L3 543 us, L4 + last conv 324 us
+// (profiles/r02_pano_fp16_kernel_stats.md).
 #include "nef_common.h"
-#include <stdlib.h>
 
 typedef _Float16 nef_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 nef_h4 __attribute__((ext_vector_type(4)));
@@ -354,6 +353,7 @@ __global__ __launch_bounds__(256, MINB) void hconv_kernel(const _Float16* __rest
 //   x2 upsample: a thread blends 8 (9 at the tile edges) output rows from 6 source rows in registers -- no raw-row
 //             LDS round trip; same packed-half arithmetic as hconv_kernel (0.25*b exact, one fma rounding)
 //   epilogue: per time half (128 rows x 128 co) through the consumed X buffer, whole 256-byte rows out
+//   COUT = 64 (128 -> 64 behind the second upsampling): 4 waves along time, 64 co x 64 t each, one epilogue pass
 // ------------------------------------------------------------------------------------------------------------
 #define PHW_ORS 272   // bytes per staged output row: 128 halfs + 16 B pad
 
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __re
         ft0 = t0_;                                                                                            \
         const __amdgpu_buffer_rsrc_t xd_ = __builtin_amdgcn_make_buffer_rsrc(                                 \
             const_cast<_Float16*>(x + (size_t)(n_ / x_div) * Tin * CIN), 0, Tin * CIN * 2, 0x00020000);       \
-        if (UP) {                                                                                             \
+        if constexpr (UP) {                                                                                   \
             const int rb_ = t0_ / 2 + 4 * rg - 1;                                                             \
             _Pragma("unroll") for (int k = 0; k < XIT; ++k) {                                                 \
                 int r_ = rb_ + k;                                                                             \
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __re
     // group); otherwise j counts the fetched vectors and JB_ is the first one of the batch held in xr.
 #define PHW_STAGE(Xn_, J0_, J1_, JB_)                                                                         \
     {                                                                                                         \
-        if (UP) {                                                                                             \
+        if constexpr (UP) {                                                                                   \
             nef_h8 qh, c75;                                                                                   \
             _Pragma("unroll") for (int e = 0; e < 8; ++e) { c75[e] = (_Float16)0.75f; qh[e] = SC ? (_Float16)qr[e] : (_Float16)1.f; } \
             _Pragma("unroll") for (int j = (J0_); j < (J1_) && j < 8; ++j) {                                  \
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __re
                 __builtin_amdgcn_sched_barrier(0);   // keep the fetches where they are
                 // the staging of the fetched rows rides in the shadow of the MFMAs, a few rows per k-step: by k-step 5
                 // (10) a wait for A has already covered the first (second) batch
-                if (UP) {
+                if constexpr (UP) {
                     if (s >= 6 && s <= 9) PHW_STAGE(Xn, 2 * (s - 6), 2 * (s - 6) + 2, 0)
                     if (s == 10) PHW_STAGE(Xn, 8, 9, 0)
                 } else {
@@ -755,7 +755,7 @@ int nef_pano_h_conv(const void* x, const void* wp, const float* bias, const floa
     if (Cin == ci && Cout == co && pro_mode == pro) \
         return launch_hconv<ci, co, pro>(x, wp, bias, scale, y, N, T, x_div, nq, sc_bs, sc_is, st)
 #define PHW_CASE(ci, co, pro) \
-    if (Cin == ci && Cout == co && pro_mode == pro && !getenv("NEF_PANO_NARROW")) \
+    if (Cin == ci && Cout == co && pro_mode == pro) \
         return launch_hconv_wide<ci, co, pro>(x, wp, bias, scale, y, N, T, x_div, nq, sc_bs, sc_is, st)
     PHW_CASE(256, 128, 3);
     PHW_CASE(256, 128, 1);
@@ -763,11 +763,6 @@ int nef_pano_h_conv(const void* x, const void* wp, const float* bias, const floa
     PHW_CASE(128, 64, 2);
     PHW_CASE(128, 64, 0);
 #undef PHW_CASE
-    PH_CASE(256, 128, 3);
-    PH_CASE(256, 128, 1);
-    PH_CASE(128, 128, 0);
-    PH_CASE(128, 64, 2);
-    PH_CASE(128, 64, 0);
     PH_CASE(64, 64, 0);
 #undef PH_CASE
     return NEF_E_UNSUPPORTED;
