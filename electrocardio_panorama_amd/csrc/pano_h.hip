@@ -590,6 +590,198 @@ __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// hconv_pair_kernel: layers 1 and 2 in ONE pass for sequences of one tile (T <= 256, i.e. L <= 512 -- BASELINE config 4):
+//   c1 = ReLU(conv(256 -> 128)(q * up2(x)) + b1)  stays in LDS as fp16 [258 rows][128 ch] (rows 0 / 257 = the conv's
+//   zero padding), y = ReLU(conv(128 -> 128)(c1) + b2) reads its B operand straight from those rows: c1 is neither
+//   written to nor read from memory (2 x 64 KB per pair), layer 2 needs no staging and no barrier inside its 24 k-steps.
+//   block   = 512 threads = 8 waves (2 per SIMD), one pair at a time, persistent, 1 block per CU:
+//             LDS = two X buffers (74 KB) + the c1 tile (70 KB)
+//   wave    = 64 co x 64 t (2 x 2 accumulator tiles) in both layers; 8 waves = 2 (co) x 4 (t)
+//   A       = weight fragments from L2 in a ring of AD k-steps that runs on across chunks, layers and pairs
+//   layer 1 = hconv_wide_kernel's scheme (double-buffered 64-channel chunks, staging pieces among the MFMAs); the
+//             next pair's first chunk is fetched and staged during layer 2
+//   y       = staged over the c1 rows after layer 2, whole 256-byte rows out; the stores drain under the next pair
+// Same k order per output as the two-launch sequence and the same fp16 rounding of c1 -> bit-identical results.
+// ------------------------------------------------------------------------------------------------------------
+#define PHP_CRS 272   // bytes per c1 / y row in LDS: 128 halfs + 16 B pad (conflict-free ds_read_b128 across 16 rows)
+
+__global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __restrict__ x, const nef_h8* __restrict__ wp1,
+                                                         const float* __restrict__ bias1, const float* __restrict__ scale,
+                                                         const nef_h8* __restrict__ wp2, const float* __restrict__ bias2,
+                                                         _Float16* __restrict__ y, int T, int N, int x_div, int nq,
+                                                         long sc_bs, long sc_is) {
+    constexpr int CIN = 256, COUT = 128, NT = 256, NI = 2;
+    constexpr int XROWS = NT + 2;
+    constexpr int XBYTES = XROWS * PH_XRS;
+    constexpr int AD = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const C1 = smem + 2 * XBYTES;      // [258][PHP_CRS]: row r = time r - 1
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int seg = tid & 7, rg = tid >> 3;  // staging: 8-channel segment, group of 4 output rows (0..63)
+    const int Tin = T / 2;
+
+    nef_f16acc acc[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    nef_h8 hzero;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hzero[e] = (_Float16)0.f;
+
+    // the padding rows of both X buffers and of the c1 tile are zero for the whole kernel (one tile per pair)
+    if (tid < 32) {
+        const int bsel = tid >> 4, r = ((tid >> 3) & 1) ? XROWS - 1 : 0;
+        *(nef_h8*)(smem + bsel * XBYTES + r * PH_XRS + seg * 16) = hzero;
+    }
+    if (tid < 32) {
+        const int r = (tid >> 4) ? XROWS - 1 : 0;
+        *(nef_h8*)(C1 + r * PHP_CRS + (tid & 15) * 16) = hzero;
+    }
+
+    nef_h8 xr[4];
+    float qr[8];
+    // source rows 2 rg - 1 .. 2 rg + 2 (clamped to the sequence: the align_corners=False edge rule) of chunk cc_ of pair n_
+#define PHP_FETCH(n_, cc_)                                                                                    \
+    {                                                                                                         \
+        const __amdgpu_buffer_rsrc_t xd_ = __builtin_amdgcn_make_buffer_rsrc(                                 \
+            const_cast<_Float16*>(x + (size_t)((n_) / x_div) * Tin * CIN), 0, Tin * CIN * 2, 0x00020000);     \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                       \
+            int r_ = 2 * rg - 1 + k;                                                                          \
+            r_ = r_ < 0 ? 0 : (r_ > Tin - 1 ? Tin - 1 : r_);                                                  \
+            xr[k] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(                         \
+                xd_, r_ * (CIN * 2) + seg * 16, (cc_) * 128, 0));                                             \
+        }                                                                                                     \
+        const float* sc_ = scale + (size_t)((n_) / nq) * sc_bs + (size_t)((n_) % nq) * sc_is + (cc_) * 64;    \
+        const __amdgpu_buffer_rsrc_t sd_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sc_), 0, 256, 0x00020000); \
+        const nef_f32x4 q0_ = nef_buf_f32x4(sd_, seg * 32, 0), q1_ = nef_buf_f32x4(sd_, seg * 32 + 16, 0);    \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) { qr[e] = q0_[e]; qr[4 + e] = q1_[e]; }                 \
+    }
+    // blended rows j (of this thread's 4: t = 4 rg + j) -> X buffer; same arithmetic as hconv_wide_kernel
+#define PHP_STAGE(Xn_, J0_, J1_)                                                                              \
+    {                                                                                                         \
+        nef_h8 qh, c75;                                                                                       \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) { c75[e] = (_Float16)0.75f; qh[e] = (_Float16)qr[e]; }  \
+        _Pragma("unroll") for (int j = (J0_); j < (J1_); ++j) {                                               \
+            const nef_h8 a_ = xr[(j >> 1) + 1], b_ = (j & 1) ? xr[(j >> 1) + 2] : xr[j >> 1];                 \
+            nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);                             \
+            v_ = v_ * qh;                                                                                     \
+            if (4 * rg + j >= T) v_ = hzero;                                                                  \
+            *(nef_h8*)((Xn_) + (4 * rg + 1 + j) * PH_XRS + seg * 16) = v_;                                    \
+        }                                                                                                     \
+    }
+    const __amdgpu_buffer_rsrc_t wd1 = nef_rsrc(wp1), wd2 = nef_rsrc(wp2);
+    const int avoff = lane * 16 + wm * 2048;
+    nef_h8 a[AD][2];
+#define PHP_A(wd_, slot_, stage_)                                                                             \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                          \
+        a[slot_][mi] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(                      \
+            wd_, avoff, (stage_) * 4096 + mi * 1024, 0));
+    // 12 k-steps (3 taps x 4 x 16 channels) of one 64-channel chunk: B fragments at Bp_ + (ni*32 + tap) * PITCH_ + kq*32;
+    // A of k-step s + AD - 1 comes from (WDC_, stage SC_ + .) or, past the chunk, from (WDN_, stage SN_ + .);
+    // FE_: fetch (pair, chunk) for the staging at k-step 1; ST_: stage into XN_ during k-steps 6..9
+#define PHP_STEPS(Bp_, PITCH_, WDC_, SC_, WDN_, SN_, FE_, FN_, FC_, ST_, XN_)                                 \
+    {                                                                                                         \
+        nef_h8 b[NI];                                                                                         \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) b[ni] = *(const nef_h8*)((Bp_) + ni * 32 * (PITCH_)); \
+        _Pragma("unroll") for (int s = 0; s < 12; ++s) {                                                      \
+            if (s + AD - 1 < 12) {                                                                            \
+                PHP_A(WDC_, (s + AD - 1) % AD, (SC_) + s + AD - 1)                                            \
+            } else {                                                                                          \
+                PHP_A(WDN_, (s + AD - 1) % AD, (SN_) + s + AD - 1 - 12)                                       \
+            }                                                                                                 \
+            if ((FE_) && s == 1) PHP_FETCH(FN_, FC_)                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            if ((ST_) && s >= 6 && s <= 9) PHP_STAGE(XN_, s - 6, s - 5)                                       \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
+                _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                              \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % AD][mi], b[ni], acc[mi][ni], 0, 0, 0); \
+                if (s + 1 < 12)                                                                               \
+                    b[ni] = *(const nef_h8*)((Bp_) + (ni * 32 + (s + 1) / 4) * (PITCH_) + ((s + 1) % 4) * 32); \
+            }                                                                                                 \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                            \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
+                __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                                           \
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                            \
+            }                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+        }                                                                                                     \
+    }
+    // accumulators -> bias + ReLU -> fp16 rows of the c1 region (row 1 + t); ZERO_: rows t >= T are the next conv's padding
+#define PHP_TO_LDS(bias_, ZERO_)                                                                              \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                          \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                       \
+            const int co = wm * 64 + mi * 32 + 8 * g + 4 * hi;                                                \
+            const nef_f32x4 bv = *(const nef_f32x4*)((bias_) + co);                                           \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
+                const int t = wn * 64 + ni * 32 + lo;                                                         \
+                nef_h4 o;                                                                                     \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
+                    o[e] = ((ZERO_) && t >= T) ? (_Float16)0.f : (_Float16)fmaxf(acc[mi][ni][g * 4 + e] + bv[e], 0.f); \
+                    acc[mi][ni][g * 4 + e] = 0.f;                                                             \
+                }                                                                                             \
+                *(nef_h4*)(C1 + (1 + t) * PHP_CRS + co * 2) = o;                                              \
+            }                                                                                                 \
+        }
+
+    int n = blockIdx.x;
+    PHP_A(wd1, 0, 0)
+    PHP_A(wd1, 1, 1)
+    PHP_A(wd1, 2, 2)
+    if (n < N) {
+        PHP_FETCH(n, 0)
+        PHP_STAGE(smem, 0, 4)
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (; n < N; n += gridDim.x) {
+        const int n_next = n + (int)gridDim.x < N ? n + (int)gridDim.x : n;   // last pair: re-stage itself (unread)
+        // ---- layer 1: four 64-channel chunks, buffers 0 1 0 1; chunk cc + 1 staged during chunk cc
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const char* Bp = smem + (cc & 1) * XBYTES + (wn * 64 + lo) * PH_XRS + 16 * hi;
+            char* Xn = smem + ((cc + 1) & 1) * XBYTES;
+            if (cc < 3) {
+                PHP_STEPS(Bp, PH_XRS, wd1, cc * 12, wd1, (cc + 1) * 12, true, n, cc + 1, true, Xn)
+            } else {
+                PHP_STEPS(Bp, PH_XRS, wd1, cc * 12, wd2, 0, false, n, 0, false, Xn)
+            }
+            __syncthreads();
+        }
+        PHP_TO_LDS(bias1, true)
+        __syncthreads();                     // c1 complete
+        // ---- layer 2: two 64-channel chunks straight from the c1 rows; the next pair's first X chunk rides along
+        {
+            const char* Bp = C1 + (wn * 64 + lo) * PHP_CRS + 16 * hi;
+            PHP_STEPS(Bp, PHP_CRS, wd2, 0, wd2, 12, false, n, 0, false, smem)
+            PHP_STEPS(Bp + 128, PHP_CRS, wd2, 12, wd1, 0, true, n_next, 0, true, smem)
+        }
+        __syncthreads();                     // every wave is done reading c1; X chunk 0 of the next pair is staged
+        PHP_TO_LDS(bias2, false)
+        __syncthreads();
+        _Float16* yb = y + (size_t)n * T * COUT;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = tid + k * 512, r = idx >> 4, v = idx & 15;
+            if (r < T) *(nef_h8*)(yb + (size_t)r * COUT + v * 8) = *(const nef_h8*)(C1 + (1 + r) * PHP_CRS + v * 16);
+        }
+        // no barrier: the c1 rows are next written four chunk barriers from here
+    }
+#undef PHP_FETCH
+#undef PHP_STAGE
+#undef PHP_A
+#undef PHP_STEPS
+#undef PHP_TO_LDS
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Last conv 64 -> 1 (k3, bias) + sigmoid(x/3) (model_nefnet.py:106,:168/:186): HBM-bound.  8 lanes share one time
 // step (8 channels x 3 taps each), a block covers 256 consecutive time steps of one pair.
 // ------------------------------------------------------------------------------------------------------------
@@ -722,6 +914,25 @@ static int launch_hconv_wide(const void* x, const void* wp, const float* bias, c
     return nef_launch_status();
 }
 
+static int launch_hconv_pair(const void* x, const void* wp1, const float* b1, const float* scale, const void* wp2,
+                             const float* b2, void* y, int N, int T, int x_div, int nq, long sc_bs, long sc_is,
+                             hipStream_t st) {
+    constexpr int LDS = 2 * 258 * PH_XRS + 258 * PHP_CRS;
+    static int cus_dev[64] = {0};            // per device, idempotent -> thread-safe without a lock
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int cus = __atomic_load_n(&cus_dev[dev & 63], __ATOMIC_ACQUIRE);
+    if (cus == 0) {
+        hipError_t e = hipFuncSetAttribute((const void*)hconv_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
+        __atomic_store_n(&cus_dev[dev & 63], cus, __ATOMIC_RELEASE);
+    }
+    hipLaunchKernelGGL(hconv_pair_kernel, dim3(N < cus ? N : cus), dim3(512), LDS, st, (const _Float16*)x,
+                       (const nef_h8*)wp1, b1, scale, (const nef_h8*)wp2, b2, (_Float16*)y, T, N, x_div, nq, sc_bs, sc_is);
+    return nef_launch_status();
+}
+
 extern "C" {
 
 int nef_pano_h_from_f32(const float* x, void* y, int B, int C, int T, nef_stream_t stream) {
@@ -766,6 +977,16 @@ int nef_pano_h_conv(const void* x, const void* wp, const float* bias, const floa
     PH_CASE(64, 64, 0);
 #undef PH_CASE
     return NEF_E_UNSUPPORTED;
+}
+
+int nef_pano_h_conv_pair(const void* x, const void* wp1, const float* bias1, const float* scale, const void* wp2,
+                         const float* bias2, void* y, int N, int T, int x_div, int nq, int64_t sc_bs, int64_t sc_is,
+                         nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && wp1 && bias1 && scale && wp2 && bias2 && y, NEF_E_NULL);
+    NEF_REQUIRE(N > 0 && T > 0 && T <= 256 && T % 2 == 0 && x_div > 0 && nq > 0, NEF_E_SHAPE);
+    return launch_hconv_pair(x, wp1, bias1, scale, wp2, bias2, y, N, T, x_div, nq, (long)sc_bs, (long)sc_is,
+                             (hipStream_t)stream);
 }
 
 int nef_pano_h_conv_outconv(const void* x, const void* wp, const float* bias, const float* wout, const float* bout,
