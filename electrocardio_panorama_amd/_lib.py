@@ -125,6 +125,7 @@ SIGNATURES = {
     "nef_pano_h_from_f32": (i32, [p, p, i32, i32, i32, p]),
     "nef_pano_h_pack_weight": (i32, [p, p, i32, i32, p]),
     "nef_pano_h_conv": (i32, [p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i64, i64, p]),
+    "nef_pano_h_conv_pair": (i32, [p, p, p, p, p, p, p, i32, i32, i32, i32, i64, i64, p]),
     "nef_pano_h_conv_outconv": (i32, [p, p, p, p, p, p, i32, i32, i32, i64, i64, p]),
     "nef_pano_h_outconv": (i32, [p, p, p, p, i32, i32, i32, i64, i64, p]),
 }

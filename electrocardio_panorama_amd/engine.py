@@ -501,6 +501,9 @@ def sweep_eval(P, Bf, latent, query_thetas, chunk=8):
     return rest
 
 
+PANO_FUSE_PAIR = os.environ.get("NEF_PANO_FUSE_PAIR", "1") != "0"   # measurement switch: 0 = two launches
+
+
 def sweep_eval_h(P, Bf, latent, query_thetas, pair_budget=16384):
     """The eval-mode sweep on the fp16 matrix cores (pano_h.hip; SURVEY 8-f2, BASELINE configs 4/5).  Same folding as
     sweep_eval; activations are fp16 [pair][time][channel] with pair = (sample, angle) sample-major, so the result
@@ -528,9 +531,13 @@ def sweep_eval_h(P, Bf, latent, query_thetas, pair_budget=16384):
             bufs = (torch.empty(N, 2 * T, 128, device=dev, dtype=torch.float16),
                     torch.empty(N, 2 * T, 128, device=dev, dtype=torch.float16),
                     torch.empty(N, 4 * T, 64, device=dev, dtype=torch.float16))
-        c1 = ops.pano_h_conv(lat_h, wp[0], bias[0], 128, N=N, upsample=True, scale=(rq[:, q0:], Q * 256, 256),
-                             x_div=n, nq=n, out=bufs[0])
-        c2 = ops.pano_h_conv(c1, wp[1], bias[1], 128, out=bufs[1])
+        if 2 * T <= ops.PANO_PAIR_MAX_T and PANO_FUSE_PAIR:     # one tile per pair: layers 1 + 2 in one pass
+            c2 = ops.pano_h_conv_pair(lat_h, wp[0], bias[0], (rq[:, q0:], Q * 256, 256), wp[1], bias[1], N, n, n,
+                                      out=bufs[1])
+        else:
+            c1 = ops.pano_h_conv(lat_h, wp[0], bias[0], 128, N=N, upsample=True, scale=(rq[:, q0:], Q * 256, 256),
+                                 x_div=n, nq=n, out=bufs[0])
+            c2 = ops.pano_h_conv(c1, wp[1], bias[1], 128, out=bufs[1])
         c3 = ops.pano_h_conv(c2, wp[2], bias[2], 64, upsample=True, out=bufs[2])
         ops.pano_h_conv_outconv(c3, wp[3], bias[3], P["decoder.4.weight"], P["decoder.4.bias"], rest[:, q0:], n,
                                 Q * 4 * T, 4 * T)

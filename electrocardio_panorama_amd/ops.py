@@ -1034,6 +1034,27 @@ def pano_h_conv(x, wp, bias, Cout, N=None, upsample=False, scale=None, x_div=1, 
     return y
 
 
+PANO_PAIR_MAX_T = 256     # nef_pano_h_conv_pair: one 256-column tile per (sample, angle)
+
+
+def pano_h_conv_pair(x, wp1, bias1, scale, wp2, bias2, N, x_div, nq, out=None):
+    """Decoder layers 1 + 2 in one pass (c1 stays on chip): x fp16 [.,Tin,256] -> fp16 [N,2*Tin,128]; 2*Tin <= 256.
+    `scale` = (tensor, sc_bs, sc_is) as in pano_h_conv."""
+    L = _lib.load()
+    _chk(x, torch.float16), _chk(bias1), _chk(bias2)
+    Tin, Ci = x.shape[1], x.shape[2]
+    T = 2 * Tin
+    assert Ci == 256 and T <= PANO_PAIR_MAX_T
+    y = torch.empty(N, T, 128, device=x.device, dtype=torch.float16) if out is None else out
+    sc, sc_bs, sc_is = scale
+    e = _timed(("pano_h_conv_pair", N, T))
+    _lib.check(L.nef_pano_h_conv_pair(_p(x), _p(wp1), _p(bias1), _p(sc), _p(wp2), _p(bias2), _p(y), N, T, x_div, nq,
+                                      sc_bs, sc_is, _stream()), "nef_pano_h_conv_pair")
+    if e is not None:
+        e.record()
+    return y
+
+
 def pano_h_outconv(x, w, bias, out, nq, out_bs, out_is):
     """out[(n/nq)*out_bs + (n%nq)*out_is + t] = sigmoid((conv_k3(x[n]) + bias)/3); x fp16 [N,T,64], out fp32 view base."""
     L = _lib.load()

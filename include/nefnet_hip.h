@@ -413,6 +413,14 @@ int nef_pano_h_from_f32(const float* x, void* y, int B, int C, int T, nef_stream
 int nef_pano_h_pack_weight(const float* w, void* wp, int Cout, int Cin, nef_stream_t stream);
 int nef_pano_h_conv(const void* x, const void* wp, const float* bias, const float* scale, void* y, int N, int T, int Cin,
                     int Cout, int pro_mode, int x_div, int nq, int64_t sc_bs, int64_t sc_is, nef_stream_t stream);
+ /* nef_pano_h_conv_pair: layers 1 and 2 of the decoder (model_nefnet.py:102-103: Upsample, DoubleConv(256,128)) in one
+ * pass for sequences of one tile (T <= 256, T even; L <= 512):
+ *   y[n] = ReLU(conv_k3(ReLU(conv_k3(scale[n] * up2(x[n / x_div])) + bias1)) + bias2),  x fp16 [.][T/2][256],
+ * y fp16 [N][T][128]; the 128-channel intermediate stays on chip and is rounded to fp16 exactly as the two-call
+ * sequence nef_pano_h_conv(pro_mode 3) + nef_pano_h_conv(pro_mode 0) rounds it (bit-identical results). */
+int nef_pano_h_conv_pair(const void* x, const void* wp1, const float* bias1, const float* scale, const void* wp2,
+                         const float* bias2, void* y, int N, int T, int x_div, int nq, int64_t sc_bs, int64_t sc_is,
+                         nef_stream_t stream);
  /* nef_pano_h_conv_outconv: the 64->64 layer and the last conv in one pass: out = sigmoid((conv_k3(ReLU(conv_k3(x) +
  * bias); wout) + bout)/3); the 64-channel intermediate never reaches memory (it is rounded to fp16 exactly as the
  * two-call sequence nef_pano_h_conv + nef_pano_h_outconv rounds it). */

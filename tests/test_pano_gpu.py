@@ -40,6 +40,27 @@ def test_from_f32_is_a_rounding_transpose():
     assert torch.equal(y.cpu(), x.transpose(1, 2).to(torch.float16))
 
 
+@pytest.mark.parametrize("T,NB,nq", [(256, 3, 4), (40, 2, 3), (254, 70, 5)])
+def test_fused_layer_pair_is_bit_identical_to_two_launches(T, NB, nq):
+    """nef_pano_h_conv_pair (layers 1 + 2 with c1 on chip) against nef_pano_h_conv twice: same k order per output and
+    the same fp16 rounding of the intermediate, so the bytes must match; more pairs than CUs in the last case, so a
+    block walks several pairs and re-uses its c1 rows."""
+    o = ops()
+    N, Tin = NB * nq, T // 2
+    xh = rnd(NB, Tin, 256, seed=11).to(torch.float16).to(DEV)
+    w1 = (rnd(128, 256, 3, seed=12) * (2.0 / (3 * 256)) ** 0.5).to(DEV)
+    w2 = (rnd(128, 128, 3, seed=13) * (2.0 / (3 * 128)) ** 0.5).to(DEV)
+    b1, b2 = rnd(128, seed=14, scale=0.1).to(DEV), rnd(128, seed=15, scale=0.1).to(DEV)
+    sc = rnd(NB, nq + 2, 256, seed=16, scale=1.5).to(DEV)
+    scale = (sc[:, 1:], (nq + 2) * 256, 256)
+    wp1, wp2 = o.pano_h_pack_weight(w1), o.pano_h_pack_weight(w2)
+    c1 = o.pano_h_conv(xh, wp1, b1, 128, N=N, upsample=True, scale=scale, x_div=nq, nq=nq)
+    ref = o.pano_h_conv(c1, wp2, b2, 128)
+    y = o.pano_h_conv_pair(xh, wp1, b1, scale, wp2, b2, N, nq, nq)
+    assert y.shape == ref.shape == (N, T, 128)
+    assert torch.equal(y, ref), float((y.float() - ref.float()).abs().max())
+
+
 @pytest.mark.parametrize("Cin,Cout,T,N,upsample,scaled", [
     (128, 128, 256, 2, False, False),      # whole tiles
     (128, 128, 300, 3, False, False),      # ragged last tile
