@@ -9,8 +9,10 @@ One process per GPU; each rank trains on its own shard of the synthetic batch (w
 fixed), gradients are summed with ONE RCCL all-reduce of the flat gradient buffer per step.  A step is
 forward + losswrapper + backward + fused momentum-SGD on inputs already resident in HBM.  Rank 0 prints one
 JSON line.  At N=1 the line also carries the CPU baseline (the torch-CPU oracle timed on this box's host cores on
-a bounded sample of the same workload) and the roofline of the dominant kernel (the k=7 grouped-conv MFMA
-kernel), timed live with HIP events on the launch stream.
+a bounded sample of the same workload), the roofline of the dominant kernel (the k=7 grouped-conv MFMA kernel: EXECUTED
+matrix-core flops over its HIP-event time on the launch stream, against the fp32 MFMA peak) and `secondary`: the two
+inference configs of BASELINE.json (configs[3] panorama sweep, configs[4] per-GPU share of gen_ecg) timed after the
+train step.
 """
 import argparse
 import json
@@ -27,6 +29,7 @@ import torch                # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FP16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_f16, dense
 HBM_PEAK_GBS = 8000.0
 
 
@@ -49,6 +52,7 @@ def parse():
                     help="do not bracket launches with HIP events (roofline / hbm_bound are then null): at launch-bound "
                          "shapes the ~250 event pairs per step cost more host time than the launches themselves")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (launch-bound shapes)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[3] / configs[4] inference timings")
     return ap.parse_args()
 
 
@@ -97,6 +101,73 @@ def cpu_baseline(V, L, B, steps, pools):
                       f"(1 warm-up step untimed), best of the thread pools listed in `pools`",
             "ms_per_step": best["ms_per_step"], "pools": runs,
             "one_thread_samples_per_s": one[0]["samples_per_s"] if one else None}
+
+
+def secondary(dev):
+    """BASELINE configs[3] and configs[4] on one GPU, through the fp16 panorama decoder (Model_nefnet.panorama_dtype =
+    'fp16'; encoder, ROI path and angular encoding stay fp32).  configs[3]: eval-mode sweep, 1 view in -> 360 queried
+    angles, batch 1024, L=512 (reference model_nefnet.py:181-192); configs[4]: gen_ecg on one GPU's share of the global
+    batch 4096 = 512 samples x 3 leads x 12 angles, L=5000 (model_nefnet.py:196-218).  Inputs resident in HBM, random-init
+    weights, synthetic data.  Rates: views = (sample, angle) pairs; out_GBps = fp32 output bytes / time; hbm_frac /
+    mfma_frac price the four wide decoder convs' ALGORITHMIC bytes (450 KB per view at L=512: one fp16 write + one fp16
+    read of each conv output) and flops (113.5 MFLOP per view at L=512) against 8 TB/s and the dense fp16 MFMA peak."""
+    from electrocardio_panorama_amd import synth
+    from electrocardio_panorama_amd.network import build_model
+
+    def rates(n_views, L, Q, dt, B):
+        flops, byts = n_views * 113.5e6 * (L / 512), n_views * 450e3 * (L / 512)
+        return {"ms": round(dt * 1e3, 3), "views_per_s": round(n_views / dt, 1), "samples_per_s": round(B / dt, 1),
+                "out_GBps": round(4.0 * n_views * L / dt / 1e9, 2),
+                "hbm_frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 4), "mfma_frac": round(flops / dt / 1e12 / FP16_MFMA_PEAK_TFLOPS, 4)}
+
+    out = {}
+    # configs[3]
+    B, V, L, Q = 1024, 1, 512, 360
+    torch.manual_seed(123)
+    m = build_model(make_cfg(V)).float().to(dev).eval()
+    m.panorama_dtype = "fp16"
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in synth.make_batch(B, V, L, seed=123, Q=Q).items()
+         if k in ("data", "input_theta", "target_theta", "rois", "rest_theta")}
+
+    def sweep():
+        random.seed(0)
+        return m(t["data"], t["input_theta"], t["target_theta"], t["rois"], rest_theta=t["rest_theta"], phase="test")
+    sweep()
+    torch.cuda.synchronize(dev)
+    n, t0 = 3, time.perf_counter()
+    for _ in range(n):
+        res = sweep()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / n
+    out["configs[3]"] = dict(rates(B * Q, L, Q, dt, B), workload=f"panorama sweep, batch={B}, {V} lead in -> {Q} angles, "
+                             f"len={L}, fp16 decoder, whole forward (encoder + ROI path + {Q}-angle decoder)", sweeps=n,
+                             finite=bool(torch.isfinite(res[1] if isinstance(res, (tuple, list)) else res).all()))
+    del m, t, res
+    torch.cuda.empty_cache()
+    # configs[4], one GPU's share
+    B, V, L, Q = 512, 3, 5000, 12
+    torch.manual_seed(123)
+    m = build_model(make_cfg(V)).float().to(dev).eval()
+    m.panorama_dtype = "fp16"
+    meta = synth.make_batch(B, V, L, seed=123, Q=Q)
+    rois = torch.from_numpy(np.ascontiguousarray(meta["rois"])).to(dev)
+    theta = torch.from_numpy(np.ascontiguousarray(meta["rest_theta"])).to(dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    z1 = torch.randn(B, 128 * V, L // 4, device=dev, generator=g) * 0.1
+    z2 = torch.randn(B, 128 * V, 7, 32, device=dev, generator=g) * 0.1
+    res = m.gen_ecg(z1, z2, theta, rois)
+    torch.cuda.synchronize(dev)
+    n, t0 = 5, time.perf_counter()
+    for _ in range(n):
+        res = m.gen_ecg(z1, z2, theta, rois)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / n
+    out["configs[4] share"] = dict(rates(B * Q, L, Q, dt, B), workload=f"gen_ecg from latents, one GPU's share of the global "
+                                   f"batch 4096: {B} samples x {V} leads x {Q} angles, len={L}, fp16 decoder", calls=n,
+                                   finite=bool(torch.isfinite(res).all()))
+    del m, res, z1, z2
+    torch.cuda.empty_cache()
+    return out
 
 
 def _config_name(V, B, L):
@@ -171,6 +242,12 @@ def main():
     final_loss_t = loss
     prof_all, extra_steps = [], 2
     if not args.no_kernel_events and not args.graph:       # every rank takes the extra steps (they contain the all-reduce)
+        # Per-kernel breakdown: untimed extra steps with EVERY launch bracketed, on ONE stream (NEF_SIDE_STREAM=0 is read per
+        # step by engine._side), so each kernel has the chip to itself and its event time is its own duration -- in the
+        # default two-stream schedule a chain kernel that shares the chip with a side-stream weight-gradient kernel reads
+        # up to 2x long.  The timed region above ran the real (two-stream) schedule.
+        side_env = os.environ.get("NEF_SIDE_STREAM")
+        os.environ["NEF_SIDE_STREAM"] = "0"
         ops.PROFILE = [] if rank == 0 else None
         # one more bracketed step first, whose events are dropped: the first event pair recorded behind a cross-stream
         # wait can come back with the wait inside it (seen once: 52 ms on a 0.23 ms launch of the first bracketed step)
@@ -182,6 +259,10 @@ def main():
             step()
         fence()
         prof_all, ops.PROFILE = ops.PROFILE or [], None
+        if side_env is None:
+            os.environ.pop("NEF_SIDE_STREAM")
+        else:
+            os.environ["NEF_SIDE_STREAM"] = side_env
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -189,26 +270,29 @@ def main():
     final_loss = float(final_loss_t.item())
 
     if rank == 0:
-        # dominant kernel: the K=7 grouped conv over the encoder's [B,128V,T] activations (conv_wino_kernel<7,..>: Winograd
-        # F(2,3) on the taps split 3+3+1; conv_fwd_kernel<7,..> with NEF_WINOGRAD=0): the 6 forward launches per step.  The 6
-        # backward-data launches of the same shape run on conv_wino4_kernel<7,..> (F(4,3)) and share the matrix pipes with
-        # the bwd-weight kernels of the side stream, so the roofline is read from the forward launches of the timed region;
-        # the backward-data average is reported next to it.
-        # `achieved` counts ALGORITHMIC flops (2*B*Cout*T*Cin_g*K, the direct-convolution count every conv is priced
-        # with); the Winograd form executes 10/14 of them on the matrix cores, so `frac` can exceed 1 --
-        # `mfma_pipe_frac` is the executed matrix-core work against the same peak.
+        # Dominant kernel: the K=7 grouped conv over the encoder's [B,128V,T] activations, 18 launches per step: 6 forward
+        # (conv_wino_kernel<7,2,0>: Winograd F(2,3) on the taps split 3+3+1 -- the one `roofline` prices, from the launches of
+        # the TIMED region), 6 backward-data (conv_wino4_kernel<7,4,0>: F(4,3) on 3+3+1) and 6 weight gradients
+        # (conv_bwd_weight_kernel<7,4,1,0,3>: taps split 4+3 through transposed F(4,2)+F(3,2)).
+        # roofline.achieved / frac = EXECUTED matrix-core flops (what the MFMA pipes really did) over the kernel's time,
+        # against the dense fp32 MFMA peak.  The algorithmic (direct-convolution) rate 2*B*Cout*T*Cin_g*K / time is
+        # reported beside it as `algorithmic_TFLOPs`: it exceeds the executed rate by the Winograd saving and is NOT a
+        # roofline fraction.
         T = L // 4
         key = ("conv_fwd", 7, V, 128, 128, B, T)
         times = [s.elapsed_time(e) for tag, s, e in prof if tag == key]
         times_bd = [s.elapsed_time(e) for tag, s, e in prof if tag == ("conv_bwd_data",) + key[1:]]
         flops = 2.0 * B * (128 * V) * T * 128 * 7
-        # multiplies executed on the matrix cores per algorithmic multiply: direct 1, F(2,3) on the taps split 3+3+1 10/14
-        # (the encoder convs always take F(2,3); F(4,3) is for the decoder convs only, see ops.WINO_FWD)
-        wino_exec = 10.0 / 14.0 if ops.WINOGRAD else 1.0
+        # multiplies executed on the matrix cores per algorithmic multiply
+        from electrocardio_panorama_amd import engine as _eng
+        ex_fwd = 10.0 / 14.0 if ops.WINOGRAD else 1.0
+        ex_bd = (17.0 / 28.0 if _eng._bwd_f4(7) else 10.0 / 14.0) if ops.WINOGRAD else 1.0
+        ex_bw = (9.0 / 14.0 if ops.WINO_BW7 else 10.0 / 14.0) if ops.WINOGRAD else 1.0
         roof = None
         if times:
             avg_ms = sum(times) / len(times)
-            ach = flops / (avg_ms * 1e-3) / 1e12
+            alg = flops / (avg_ms * 1e-3) / 1e12
+            ach = alg * ex_fwd
             traffic = traffic_source = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath) and (V, B, L) == (3, 256, 5000):     # PMC pass was taken at configs[1] only
@@ -220,17 +304,30 @@ def main():
             # forward launches: conv1 of a block reads x and writes h; conv2 reads h AND the residual x, writes y
             act = 4.0 * B * 128 * V * T
             alg_bytes = ((2 * act) + (3 * act)) / 2 + 4.0 * 128 * V * 128 * 7
+            # the same kernel family one launch at a time (single-stream breakdown steps): its own duration per kernel
+            def _serial(role, ex):
+                ts = [s.elapsed_time(e) for tag, s, e in prof_all if tag == (role,) + key[1:]]
+                if not ts:
+                    return None
+                ms = sum(ts) / len(ts)
+                return {"avg_ms": round(ms, 4), "launches": len(ts), "executed_over_algorithmic": round(ex, 4),
+                        "executed_TFLOPs": round(flops * ex / ms / 1e9, 2),
+                        "frac": round(flops * ex / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": ("conv_wino_kernel<7,2,0> (k7 grouped conv, Winograd F(2,3) on taps 3+3+1)" if ops.WINOGRAD
-                               else "conv_fwd_kernel<7,2,0> (k7 grouped conv, direct)") + ", forward launches",
-                    "launches": len(times),
-                    "executed_mfma_flops_per_launch": flops * wino_exec,
-                    "mfma_pipe_frac": round(ach * wino_exec / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "avg_ms": round(avg_ms, 4), "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+                               else "conv_fwd_kernel<7,2,0> (k7 grouped conv, direct)") + ", forward launches of the timed region",
+                    "launches": len(times), "avg_ms": round(avg_ms, 4),
+                    "executed_mfma_flops_per_launch": flops * ex_fwd,
+                    "algorithmic_flops_per_launch": flops, "algorithmic_TFLOPs": round(alg, 2),
+                    "algorithmic_over_peak": round(alg / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "algorithmic_bytes_per_launch": alg_bytes,
                     "hbm_GBps": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1),
                     "avg_ms_bwd_data_launches_overlapped": round(sum(times_bd) / max(len(times_bd), 1), 4),
-                    "bwd_data_kernel": "conv_wino4_kernel<7,4,0> (F(4,3) on taps 3+3+1: no decision is taken on a gradient)",
+                    "k7_kernels_one_at_a_time": {
+                        "conv_wino_kernel<7,2,0> fwd F(2,3) 3+3+1": _serial("conv_fwd", ex_fwd),
+                        "conv_wino4_kernel<7,4,0> bwd-data F(4,3) 3+3+1": _serial("conv_bwd_data", ex_bd),
+                        "conv_bwd_weight_kernel<7,4,1,0,3> 4+3 (+ its split-K reduce)": _serial("conv_bwd_weight", ex_bw)},
                     "side_stream": os.environ.get("NEF_SIDE_STREAM", "auto") != "0"}
         by_kernel = {}
         hbm = {}
@@ -243,8 +340,7 @@ def main():
                 continue
             by_kernel.setdefault(tag, []).append(s.elapsed_time(e))
         # the set BASELINE.json's ">= 40 % of the HBM roofline" applies to; times are HIP events around each
-        # launch in the live (two-stream) schedule, so a pass that shares the chip with a side-stream MFMA kernel reads low;
-        # profiles/r02_hbm_kernels.md has the same table with every launch alone
+        # launch of the single-stream breakdown steps: every pass alone on the chip
         if os.environ.get("NEF_BENCH_DUMP"):        # per-launch event times of the untimed breakdown steps
             with open(os.environ["NEF_BENCH_DUMP"], "w") as f:
                 json.dump([["/".join(str(x) for x in tag), round(s.elapsed_time(e), 4)] for tag, s, e in prof_all], f)
@@ -253,6 +349,14 @@ def main():
                      for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1]) if v[1] > 0}
         breakdown = {"/".join(str(x) for x in k): round(sum(v) / extra_steps, 3) for k, v in sorted(
             by_kernel.items(), key=lambda kv: -sum(kv[1]))[:12]}
+        sec = None
+        if world == 1 and not args.no_secondary:
+            del model, optim, data, loss, final_loss_t
+            torch.cuda.empty_cache()
+            try:
+                sec = secondary(dev)
+            except Exception as exc:  # the headline stays valid; the failure is visible in the line
+                sec = {"error": f"{type(exc).__name__}: {exc}"}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(V, L, args.cpu_batch, args.cpu_steps, args.cpu_threads.split(","))
@@ -266,7 +370,8 @@ def main():
                                    f"{'off' if args.no_dropout else 'on'}",
                        "global_batch": world * B, "seq_len": L, "leads": V, "parallelism": f"dp{world}"},
             "roofline": roof, "cpu_baseline": cpu, "final_loss": final_loss, "conv_ms_per_step": breakdown,
-            "hbm_bound": hbm_bound,
+            "hbm_bound": hbm_bound, "hbm_bound_schedule": "single stream, every launch alone (untimed breakdown steps)",
+            "secondary": sec,
             "hip_graph": bool(args.graph),
         }
         if cpu:

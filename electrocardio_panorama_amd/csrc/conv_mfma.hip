@@ -17,6 +17,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
+// NEF_ABL: timing-only ablation builds (tools/ablate_k7.py; results are WRONG by construction, never shipped): bit0 = no
+// weight (A) fetches inside the main loop, bit1 = no activation fetches / LDS staging stores inside the loop, bit2 = no LDS
+// fragment reads and no transform arithmetic inside the loop (operands are loop-invariant registers of random data),
+// bit3 = no epilogue (the accumulators stay live behind a run-time-false branch).  15 = the MFMA stream and its barriers.
+#ifndef NEF_ABL
+#define NEF_ABL 0
+#endif
 constexpr int NT = 128;   // forward: columns per workgroup
 constexpr int WT = 64;    // bwd-weight: reduction columns per staged tile
 
@@ -527,29 +534,34 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
     }
     NEF_WX_ISSUE(0)
 #pragma unroll
-    for (int s_ = 0; s_ < AHEAD; ++s_) NEF_WA_ISSUE(s_, s_)
+    for (int s_ = 0; s_ < ((NEF_ABL & 1) ? NSET : AHEAD); ++s_) NEF_WA_ISSUE(s_, s_)
     NEF_WX_STORE(0, Xl)
     __syncthreads();
     int st = 0;
-    for (int c0 = 0; c0 < Cig; c0 += KC, ++st) {
-        const float* xb = Xl + (st & 1) * (KC * XRS) + hi * XRS + 2 * (wn * 32 + lo);
-        const bool more = c0 + KC < Cig;
-        constexpr int NXV = K == 3 ? 2 : 4;        // ds_read_b64 per lane and k-step: x[2j-PAD .. 2j-PAD+2*NXV)
-        f32x2 fx[2][NXV];
+    constexpr int NXV = K == 3 ? 2 : 4;        // ds_read_b64 per lane and k-step: x[2j-PAD .. 2j-PAD+2*NXV)
+    f32x2 fx[2][NXV];
 #define NEF_WX_LOAD(S, BUF)                                                                                          \
     {                                                                                                               \
         const f32x2* xp_ = reinterpret_cast<const f32x2*>(xb + 2 * (S) * XRS);                                      \
         _Pragma("unroll") for (int q_ = 0; q_ < NXV; ++q_) fx[BUF][q_] = xp_[q_];                                   \
     }
+    if constexpr ((NEF_ABL & 4) != 0) {
+        const float* xb = Xl + hi * XRS + 2 * (wn * 32 + lo);
         NEF_WX_LOAD(0, 0)
+        NEF_WX_LOAD(1, 1)
+    }
+    for (int c0 = 0; c0 < Cig; c0 += KC, ++st) {
+        const float* xb = Xl + ((NEF_ABL & 2) ? 0 : (st & 1)) * (KC * XRS) + hi * XRS + 2 * (wn * 32 + lo);
+        const bool more = c0 + KC < Cig;
+        if constexpr (!(NEF_ABL & 4)) NEF_WX_LOAD(0, 0)
 #pragma unroll
         for (int s_ = 0; s_ < SPK; ++s_) {
-            NEF_WA_ISSUE(st * SPK + s_ + AHEAD, (s_ + AHEAD) % NSET)
+            if constexpr (!(NEF_ABL & 1)) NEF_WA_ISSUE(st * SPK + s_ + AHEAD, (s_ + AHEAD) % NSET)
             // the activation rows of the next stage are requested once per stage, right behind an A request: the first
             // A fragment that is YOUNGER than them is consumed later in the stage, by when they have long arrived
             // (vector-memory results return in order)
-            if (s_ == 0 && more) NEF_WX_ISSUE(c0 + KC)
-            if (s_ + 1 < SPK) NEF_WX_LOAD(s_ + 1, (s_ + 1) & 1)
+            if constexpr (!(NEF_ABL & 2)) if (s_ == 0 && more) NEF_WX_ISSUE(c0 + KC)
+            if constexpr (!(NEF_ABL & 4)) if (s_ + 1 < SPK) NEF_WX_LOAD(s_ + 1, (s_ + 1) & 1)
             const f32x2* d = fx[s_ & 1];
             const float (*w)[2] = fa[s_ % NSET];
             // One s_setprio per k-step.  Measured -3..5 % on the K = 3 shapes and -1 % on K = 7 (tools/bench_conv.py); a
@@ -586,13 +598,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
                 }
             }
         }
-#undef NEF_WX_LOAD
-        if (more) NEF_WX_STORE(c0 + KC, Xl + ((st + 1) & 1) * (KC * XRS))
+        if constexpr (!(NEF_ABL & 2)) if (more) NEF_WX_STORE(c0 + KC, Xl + ((st + 1) & 1) * (KC * XRS))
         __syncthreads();
     }
+#undef NEF_WX_LOAD
 #undef NEF_WA_ISSUE
 #undef NEF_WX_ISSUE
 #undef NEF_WX_STORE
+    if constexpr ((NEF_ABL & 8) != 0) if (a.T >= 0) return;      // run-time true: the epilogue below is dead at run time only
 
     // epilogue: output transform, then bias / residual / ReLU / dropout / gate exactly as conv_fwd_kernel, on the two
     // adjacent outputs (2j, 2j+1) a lane owns per channel row: 8-byte loads and stores, 256 contiguous bytes per row.
@@ -849,25 +862,30 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
     }
     NEF_W4X_ISSUE(0)
 #pragma unroll
-    for (int s_ = 0; s_ < AHEAD; ++s_) NEF_W4A_ISSUE(s_, s_)
+    for (int s_ = 0; s_ < ((NEF_ABL & 1) ? NSET : AHEAD); ++s_) NEF_W4A_ISSUE(s_, s_)
     NEF_W4X_STORE(0, Xl)
     __syncthreads();
     int st = 0;
-    for (int c0 = 0; c0 < Cig; c0 += KC, ++st) {
-        const float* xb = Xl + (st & 1) * (KC * XRS) + hi * XRS + 4 * (wn * 32 + lo);
-        const bool more = c0 + KC < Cig;
-        f32x2 fx[2][NXV];
+    f32x2 fx[2][NXV];
 #define NEF_W4X_LOAD(S, BUF)                                                                                         \
     {                                                                                                               \
         const f32x2* xp_ = reinterpret_cast<const f32x2*>(xb + 2 * (S) * XRS);                                      \
         _Pragma("unroll") for (int q_ = 0; q_ < NXV; ++q_) fx[BUF][q_] = xp_[q_];                                   \
     }
+    if constexpr ((NEF_ABL & 4) != 0) {
+        const float* xb = Xl + hi * XRS + 4 * (wn * 32 + lo);
         NEF_W4X_LOAD(0, 0)
+        NEF_W4X_LOAD(1, 1)
+    }
+    for (int c0 = 0; c0 < Cig; c0 += KC, ++st) {
+        const float* xb = Xl + ((NEF_ABL & 2) ? 0 : (st & 1)) * (KC * XRS) + hi * XRS + 4 * (wn * 32 + lo);
+        const bool more = c0 + KC < Cig;
+        if constexpr (!(NEF_ABL & 4)) NEF_W4X_LOAD(0, 0)
 #pragma unroll
         for (int s_ = 0; s_ < SPK; ++s_) {
-            NEF_W4A_ISSUE(st * SPK + s_ + AHEAD, (s_ + AHEAD) % NSET)
-            if (s_ == 0 && more) NEF_W4X_ISSUE(c0 + KC)
-            if (s_ + 1 < SPK) NEF_W4X_LOAD(s_ + 1, (s_ + 1) & 1)
+            if constexpr (!(NEF_ABL & 1)) NEF_W4A_ISSUE(st * SPK + s_ + AHEAD, (s_ + AHEAD) % NSET)
+            if constexpr (!(NEF_ABL & 2)) if (s_ == 0 && more) NEF_W4X_ISSUE(c0 + KC)
+            if constexpr (!(NEF_ABL & 4)) if (s_ + 1 < SPK) NEF_W4X_LOAD(s_ + 1, (s_ + 1) & 1)
             const float* w = fa[s_ % NSET];
             __builtin_amdgcn_s_setprio(1);      // scheduling fence, see conv_wino_kernel
             float x_[2 * NXV];
@@ -896,13 +914,14 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
                 }
             }
         }
-#undef NEF_W4X_LOAD
-        if (more) NEF_W4X_STORE(c0 + KC, Xl + ((st + 1) & 1) * (KC * XRS))
+        if constexpr (!(NEF_ABL & 2)) if (more) NEF_W4X_STORE(c0 + KC, Xl + ((st + 1) & 1) * (KC * XRS))
         __syncthreads();
     }
+#undef NEF_W4X_LOAD
 #undef NEF_W4A_ISSUE
 #undef NEF_W4X_ISSUE
 #undef NEF_W4X_STORE
+    if constexpr ((NEF_ABL & 8) != 0) if (a.T >= 0) return;      // run-time true: the epilogue below is dead at run time only
 
     // epilogue: output transform, then the usual bias / residual / ReLU / dropout / gate on the four adjacent outputs a
     // lane owns per channel row (two 8-byte accesses; T is even, so each pair is inside or outside the row as a whole)
@@ -1337,6 +1356,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
 #endif
     for (int tile = split; tile < n_tiles; tile += S) {
         __syncthreads();
+        if (!(NEF_ABL & 2) || tile == split) {
 #pragma unroll
         for (int rr = 0; rr < GR; ++rr) GYl[(wave + 4 * rr) * GYS + lane] = greg[rr];
         {
@@ -1384,8 +1404,9 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
                 if (nh > 0 && row < CIT) Xl[row * XS + 64 + idx - row * nh] = v;
             }
         }
+        }
         __syncthreads();
-        if (tile + S < n_tiles) NEF_BW_ISSUE(tile + S)
+        if constexpr (!(NEF_ABL & 1)) if (tile + S < n_tiles) NEF_BW_ISSUE(tile + S)
         if constexpr (WINO == 2) {
             // transposed F(3,4): 8 reduction steps per 64-column tile, each over two output QUADS (MFMA k = quad): a lane
             // reads its gY row's quad (two aligned 8-byte words) and its X row's six inputs x[4j-1 .. 4j+4] (three), one
@@ -1405,7 +1426,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
             NEF_BW4_LOAD(0, 0)
 #pragma unroll
             for (int s_ = 0; s_ < NSTEP; ++s_) {
-                if (s_ + 1 < NSTEP) NEF_BW4_LOAD(s_ + 1, (s_ + 1) & 1)
+                if ((NEF_ABL & 4) ? s_ == 0 : s_ + 1 < NSTEP) NEF_BW4_LOAD(s_ + 1, (s_ + 1) & 1)
                 const float g0 = fg[s_ & 1][0][0], g1 = fg[s_ & 1][0][1], g2 = fg[s_ & 1][1][0], g3 = fg[s_ & 1][1][1];
                 float u[6];
                 {
@@ -1455,7 +1476,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
             NEF_BWW_LOAD(0, 0)
 #pragma unroll
             for (int s_ = 0; s_ < NSTEP; ++s_) {
-                if (s_ + 1 < NSTEP) NEF_BWW_LOAD(s_ + 1, (s_ + 1) & 1)
+                if ((NEF_ABL & 4) ? s_ == 0 : s_ + 1 < NSTEP) NEF_BWW_LOAD(s_ + 1, (s_ + 1) & 1)
                 const float g0 = fg[s_ & 1][0], g1 = fg[s_ & 1][1];
                 float u[4];
                 u[0] = g0;
@@ -1556,6 +1577,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
     }
 #undef NEF_BW_ISSUE
 #undef NEF_BW_TAPS
+    if constexpr ((NEF_ABL & 8) != 0) if (T >= 0) return;      // run-time true: the stores below are dead at run time only
     // partials: ws[split][g][k][co][ci]
 #pragma unroll
     for (int i = 0; i < TCI; ++i) {

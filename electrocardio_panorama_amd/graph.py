@@ -121,6 +121,11 @@ class GraphedTrainStep:
         self.flat_p.copy_(p0)
         self.flat_buf.copy_(b0)
         slot["graph"] = graph
+        # The graph bakes in the pointers of every scratch buffer its launches used (ops.workspace, incl. the side
+        # stream's, which the eager probe allocated from the general pool).  ops.workspace() REPLACES a buffer when a later
+        # probe of a larger shape outgrows it; holding the buffers here keeps the replaced ones alive for as long as this
+        # graph can be replayed.
+        slot["workspaces"] = list(ops._WS.values())
         return slot
 
     def _stage(self, data, in_theta, q_theta, rois, target, draw=True):
@@ -135,7 +140,10 @@ class GraphedTrainStep:
             # Python `random` consumed exactly twice per step, z1 choice first (model_nefnet.py:154,156)
             self._host[0], self._host[1] = random.randint(0, V - 1), random.randint(0, V - 1)
         rank = dist.get_rank() if self.world > 1 else 0
-        self._host[2] = (torch.initial_seed() + self.calls + rank * 0x9E3779B1) & 0x7FFFFFFFFFFF
+        # same ingredients as the eager path (model_nefnet.py: initial seed + call counter + epoch + rank): a resumed run
+        # (Solver sets model.dropout_epoch; `calls` travels in state_dict) does not replay the masks of step 1
+        self._host[2] = (torch.initial_seed() + self.calls + int(getattr(self.model, "dropout_epoch", 0)) * 0x1000003
+                         + rank * 0x9E3779B1) & 0x7FFFFFFFFFFF
         self.choice_dev.copy_(self._host[:2].to(torch.int32), non_blocking=False)
         self.seed_dev.copy_(self._host[2:3], non_blocking=False)
 
@@ -149,12 +157,13 @@ class GraphedTrainStep:
 
     def state_dict(self):
         """The optimiser state of the graphed path: the flat momentum buffer and the parameter order it refers to."""
-        return {"lr": self.lr, "momentum": self.mu, "live": list(self.live or []),
+        return {"lr": self.lr, "momentum": self.mu, "live": list(self.live or []), "calls": int(self.calls),
                 "momentum_buffer": None if self.flat_buf is None else self.flat_buf.detach().cpu().clone()}
 
     def load_state_dict(self, sd):
         self.set_lr(sd["lr"])
         self.mu = float(sd["momentum"])
+        self.calls = int(sd.get("calls", 0))        # the dropout seed's step counter
         self._pending_momentum = (list(sd["live"]), sd["momentum_buffer"])
         if self.flat_buf is not None:
             self._restore_momentum()

@@ -52,4 +52,6 @@ class MSELead(torch.nn.Module):
 
     def forward(self, input, target):
         target = target.to(torch.float32).expand_as(input)
-        return _LossFn.apply(input, input, input, target, (0.0, 0.0, 1.0), True, 4)[3]
+        # element [0] (the total) is the one _LossFn back-propagates through; with factors (0, 0, 1) and only the
+        # reconstruction term enabled it IS the MSE (element [3] carries the same number but no gradient)
+        return _LossFn.apply(input, input, input, target, (0.0, 0.0, 1.0), True, 4)[0]

@@ -56,22 +56,45 @@ def make_summary_writer(logdir):
 
 
 class _HostSink:
-    """Device tensors queued for the host: each is copied into pinned memory on the current stream (no sync); `rows()`
-    waits once and returns them."""
+    """Device tensors queued for the host without a per-iteration synchronisation: each is copied into a pinned staging
+    buffer on the current stream; the staging buffers form a bounded ring (RING entries per sink), and a buffer is drained
+    into pageable numpy memory -- after waiting for ITS copy event only -- when the ring comes round to it again.  The
+    pinned footprint is therefore RING tensors per sink, not an epoch's worth, and after the first RING adds no
+    hipHostMalloc happens (buffers are reused when the shape matches)."""
+    RING = 4
 
     def __init__(self):
-        self.items = []
+        self.done = []           # pageable numpy arrays, in order
+        self.ring = []           # [pinned buffer, event, filled?]
+        self.pos = 0
+
+    def _drain(self, slot):
+        if slot[2]:
+            slot[1].synchronize()
+            self.done.append(slot[0].numpy().copy())
+            slot[2] = False
 
     def add(self, t):
         t = t.detach()
-        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-        h.copy_(t, non_blocking=True)
-        self.items.append(h)
+        if len(self.ring) < self.RING:
+            self.ring.append([torch.empty(t.shape, dtype=t.dtype, pin_memory=True), torch.cuda.Event(), False])
+            slot = self.ring[-1]
+        else:
+            slot = self.ring[self.pos]
+            self._drain(slot)
+            if slot[0].shape != t.shape or slot[0].dtype != t.dtype:       # e.g. the final partial batch
+                slot[0] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        self.pos = (self.pos + 1) % self.RING
+        slot[0].copy_(t, non_blocking=True)
+        slot[1].record()
+        slot[2] = True
 
     def arrays(self):
-        if self.items:
-            torch.cuda.synchronize()
-        return [h.numpy() for h in self.items]
+        n = len(self.ring)
+        start = self.pos if n == self.RING else 0
+        for i in range(n):           # oldest first
+            self._drain(self.ring[(start + i) % n])
+        return self.done
 
     def rows(self):
         return [x for a in self.arrays() for x in a]
@@ -121,7 +144,7 @@ class Solver:
             if hasattr(getattr(dl_train, 'sampler', None), 'set_epoch'):
                 dl_train.sampler.set_epoch(epoch)         # DistributedSampler: a new shuffle per epoch
             self.model.dropout_epoch = epoch
-            train_losses = self.run_one_epoch(dl_train, phase='train', optim=optimizer)[0]
+            train_losses = self.run_one_epoch(dl_train, phase='train', optim=optimizer, collect_views=False)[0]
             scheduler.step()
             parallel.broadcast_buffers(self.model)        # rank 0's BatchNorm running statistics are the model's
             tl = np.mean(train_losses, axis=0)
@@ -131,7 +154,7 @@ class Solver:
             psnr_gen = psnr_reg = 0.
             msg = 'Epoch {}: train_loss: {}'.format(epoch, train_loss_all)
             if dl_test is not None:
-                test_losses, _, _, _, mertics_all, _, single = self.run_one_epoch(dl_test, phase='test')
+                test_losses, _, _, _, mertics_all, _, single = self.run_one_epoch(dl_test, phase='test', collect_views=False)
                 te = np.mean(test_losses, axis=0)
                 psnr_gen, psnr_reg, ssim_gen, ssim_reg = (float(v) for v in np.mean(mertics_all, axis=0))
                 # the reference's scalar set and names (solver.py:82-100)
@@ -174,7 +197,7 @@ class Solver:
         print('the latest best_test_psnr_gen is {:06f} of epoch {}'.format(extra.get('best_test_psnr_gen', 0.),
                                                                            extra.get('epoch', 0)))
         with torch.no_grad():
-            mertics_all = self.run_one_epoch(dl_test, phase='test')[4]
+            mertics_all = self.run_one_epoch(dl_test, phase='test', collect_views=False)[4]
         psnr_gen, psnr_reg, ssim_gen, ssim_reg = (float(v) for v in np.mean(mertics_all, axis=0))
         print('psnr_gen:{}, psnr_reg:{}, ssim_gen:{}, ssim_reg:{}'.format(psnr_gen, psnr_reg, ssim_gen, ssim_reg))
         return psnr_gen, psnr_reg, ssim_gen, ssim_reg
@@ -190,20 +213,28 @@ class Solver:
         (solver.py:197-203)."""
         gen_num = 6 if self.cfg.DATA.lead_num == 336 else 4
         super_mode = str(self.cfg.DATA.get('super_mode', 'normal'))
-        if super_mode != 'normal':
-            gen_num = int(super_mode[-1])
         whole = self.cfg.DATA.get('dataset', 'tianchi') == 'mit' or super_mode[-1] == '0' or super_mode == '_mit'
+        # the reference eval()s the last character before it looks at `whole` (solver.py:198) and would crash on '_mit';
+        # the split count is only consumed when `whole` is false, so it is only parsed then
+        if super_mode != 'normal' and not whole:
+            if not super_mode[-1].isdigit():
+                raise ValueError(f"DATA.super_mode {super_mode!r}: the last character must be the number of generated views")
+            gen_num = int(super_mode[-1])
         return gen_num, whole
 
-    def run_one_epoch(self, dl, phase, optim=None):
+    def run_one_epoch(self, dl, phase, optim=None, collect_views=None):
+        """solver.py:139-246.  `collect_views` (default: the Solver's setting) = also return the per-view host lists the
+        reference returns (inputs, ground truth, predictions, rois); train() / val() only consume losses and metrics and
+        pass False, so an epoch stages nothing but a few scalars per step."""
         if phase == 'train':
             self.model.train()
         elif phase == 'test':
             self.model.eval()
         else:
             raise ValueError('phase param not found.')
-        keep = self.collect_views
+        keep = self.collect_views if collect_views is None else bool(collect_views)
         losses_s, pred_s, gt_s, in_s, rest_s, rois_s, psnr_s, ssim_s = (_HostSink() for _ in range(8))
+        gen_num, whole = self._gen_num() if phase == 'test' else (0, True)
         for meta in dl:
             source_data, rois, input_theta, target_view, target_theta, noise = self._to_device(meta)
             rest_theta = torch.as_tensor(meta['rest_theta']).to(self.device) if 'rest_theta' in meta else None
@@ -226,12 +257,12 @@ class Solver:
                 losses = self.loss(out, shuf_p, shuf_l, target_view, self.cfg, rest_out[:, -4:, :].contiguous(),
                                    rest_view[:, -4:, :].contiguous())
                 losses_s.add(torch.stack([l_.detach() for l_ in losses]))
-                whole = self._gen_num()[1]
                 ps, ss = ops.view_metrics(rest_out.contiguous(), rest_view, None if whole else rois.contiguous())
                 psnr_s.add(ps)
                 ssim_s.add(ss)
-                pred_s.add(rest_out)                               # solver.py:182
-                rest_s.add(rest_view)
+                if keep:
+                    pred_s.add(rest_out)                           # solver.py:182
+                    rest_s.add(rest_view)
             if keep:
                 gt_s.add(target_view.squeeze(1))
                 in_s.add(source_data)
@@ -239,7 +270,6 @@ class Solver:
         losses = [a.tolist() for a in losses_s.arrays()]
         if phase == 'train':
             return losses, gt_s.rows(), pred_s.rows(), in_s.rows(), [], rois_s.rows()
-        gen_num, whole = self._gen_num()
         mertics_all, mertics_gen_singlelead = [], []
         for ps, ss in zip(psnr_s.arrays(), ssim_s.arrays()):
             if np.isnan(ss).any():

@@ -58,7 +58,19 @@ def build_loaders(cfg, batch_size=32, phases=('train', 'test')):
     for ph in phases:
         ds = build_dataset(cfg, phase=ph)
         if ph == 'train':
-            if world > 1:
+            if cfg.DATA.get('weighted_sample', False):
+                # reference train_net.py:21-25: WeightedRandomSampler(train_dataset.get_label_weight(), num_samples=5000),
+                # num_workers=0.  None of the reference's dataset classes defines get_label_weight(), so the option only
+                # works with a dataset that brings it; never fall back to uniform shuffling silently.
+                if world > 1:
+                    raise NotImplementedError("DATA.weighted_sample under data parallelism: the weighted draw is not sharded")
+                if not hasattr(ds, 'get_label_weight'):
+                    raise NotImplementedError(f"DATA.weighted_sample needs {type(ds).__name__}.get_label_weight() "
+                                              "(the reference's datasets do not define it either)")
+                from torch.utils.data import WeightedRandomSampler
+                dl = DataLoader(ds, batch_size=batch_size, sampler=WeightedRandomSampler(ds.get_label_weight(), num_samples=5000),
+                                num_workers=0, drop_last=True, collate_fn=_collate, pin_memory=True)
+            elif world > 1:
                 sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=cfg.seed, drop_last=True)
                 dl = DataLoader(ds, batch_size=batch_size // world, sampler=sampler, num_workers=16, drop_last=True,
                                 collate_fn=_collate, pin_memory=True)

@@ -15,3 +15,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """NEF_TIE_LOG=<path>: dump the tie ratios the decision-replaying tests saw (tests/decisions.py: |pre-activation| / rms
+    of every site with a flipped decision) -- the evidence behind decisions.TIE_REL (profiles/r03_tie_ratios.md)."""
+    path = os.environ.get("NEF_TIE_LOG")
+    if not path:
+        return
+    try:
+        import json
+        import decisions
+        with open(path, "w") as fh:
+            json.dump([[s, float(r), int(f), int(n)] for s, r, f, n in decisions.TIE_LOG], fh)
+    except Exception as exc:       # diagnostics must never fail a run
+        sys.stderr.write(f"NEF_TIE_LOG: {exc}\n")

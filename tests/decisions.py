@@ -10,7 +10,10 @@ import torch
 from util import rel
 
 FLAT_TOL, TENSOR_TOL = 1e-4, 1e-3
-TIE_REL = 1e-4            # a flipped decision must have |pre-activation| <= TIE_REL * rms(pre-activation of its site)
+# A flipped decision must have |pre-activation| <= TIE_REL * rms(pre-activation of its site).  2e-5 = twice the largest
+# ratio seen over every replaying test incl. the 5e9 decisions of the full-size step (profiles/r03_tie_ratios.md); the
+# round-2 value was 1e-4.
+TIE_REL = 2e-5
 TIE_FRAC = 1e-5           # and flips must be rare: <= TIE_FRAC * numel + 2 per site
 
 
@@ -86,16 +89,25 @@ def gpu_decisions(model, outs, target, keep_masks=None, reg_l1=True, fold=None):
     return dm
 
 
+TIE_LOG = []              # (site, worst / rms, flips, numel) of every site with a flip, for tools/tie_ratios.py
+
+
 def assert_flips_are_ties(dec):
     """Replayed decisions that differ from the oracle's own must be ties: the oracle's argument within TIE_REL of the
-    switching point (relative to the site's rms) and -- unless that argument is EXACTLY zero -- rare.  Exact zeros are
-    the all-zero tail of a beat seen through a conv: the reference produces 0.0 there, a Winograd form whose quads
-    straddle the edge of the tail leaves +-1e-9 of rounding residue, and ReLU'(0) is a convention, not a value; such
-    positions carry no signal forward (the outputs are held to 1e-5 separately) and multiply zero activations backward."""
+    switching point (relative to the site's rms) and rare.  Flips where the oracle's argument is EXACTLY zero (the
+    all-zero tail of a beat seen through a conv) are exempt from the rarity bound only on sites whose forward conv runs
+    through F(4,3) -- the decoder passes -- and on the L1 sign sites: F(4,3) computes such an output from products that
+    cancel only analytically.  Every encoder-side forward conv takes F(2,3) or the direct form, which keep the reference's
+    exact 0.0 by construction (each product feeding an output only sees that output's receptive field), so there the
+    claim is a test: no exact-zero flip at all."""
     for site, r in dec.report.items():
         if r["flips"] == 0:
             continue
-        assert r["flips"] - r.get("degenerate", 0) <= TIE_FRAC * r["numel"] + 2, (site, r)
+        TIE_LOG.append((site, r["worst"] / max(r["rms"], 1e-30), r["flips"], r["numel"]))
+        f4_forward = site.startswith("pass") or site.startswith("loss")
+        if not f4_forward:
+            assert r.get("degenerate", 0) == 0, (site, r)
+        assert r["flips"] - (r.get("degenerate", 0) if f4_forward else 0) <= TIE_FRAC * r["numel"] + 2, (site, r)
         assert r["worst"] <= TIE_REL * max(r["rms"], 1e-30), (site, r)
 
 

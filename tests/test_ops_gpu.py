@@ -644,6 +644,22 @@ def test_loss(reg):
     assert rel(g_pred, pr.grad) < 1e-5 and rel(g_p, ppr.grad) < 1e-5 and rel(g_l, plr.grad) < 1e-5
 
 
+def test_mse_lead_value_and_gradient():
+    """Reference losses.py:53-64: mean over leads of nn.MSELoss per lead -- value AND gradient (round-2 advisor: the
+    returned element used to be the one no gradient flows through)."""
+    from electrocardio_panorama_amd.network.loss.losses import MSELead
+    x, tgt = rnd(3, 4, 200, seed=54), rnd(3, 4, 200, seed=55)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.stack([F.mse_loss(xr[:, i], tgt[:, i]) for i in range(x.size(1))]).mean()
+    ref.backward()
+    xd = g(x).requires_grad_(True)
+    got = MSELead()(xd, g(tgt))
+    assert abs(float(got) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+    (2.5 * got).backward()
+    assert xd.grad is not None and float(xd.grad.abs().max()) > 0
+    assert rel(xd.grad, 2.5 * xr.grad) < 1e-5
+
+
 def test_sgd_momentum():
     o = ops()
     p, buf = rnd(1000, seed=52), torch.zeros(1000)

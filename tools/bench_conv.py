@@ -19,6 +19,7 @@ SHAPES = [  # (name, K, G, Cig, Cog, B, T)
 ]
 only = sys.argv[1] if len(sys.argv) > 1 else None
 iters = int(os.environ.get("ITERS", 10))
+whats = os.environ.get("ONLY_WHAT", "fwd,wino,bwd_w,bwd_ww").split(",")
 for name, K, G, Cig, Cog, B, T in SHAPES:
     if only and only not in name:
         continue
@@ -29,6 +30,8 @@ for name, K, G, Cig, Cog, B, T in SHAPES:
     wpw = ops.pack_weight(w, G, T=T, f4=os.environ.get("F4", "1") == "1")      # F4=0: the F(2,3) form
     flops = 2.0 * B * G * Cog * T * Cig * K
     for what in ("fwd", "wino", "bwd_w", "bwd_ww"):
+        if what not in whats:
+            continue
         if what == "wino" and not getattr(wpw, "nef_wino", False):
             continue
         fn = (lambda: ops.conv(GV.dense(x, G), wp, Cog, K, relu=True)) if what == "fwd" else \

@@ -5,15 +5,18 @@ R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
+# bench.py --steps 3 --warmup 1 --no-kernel-events runs exactly 4 train steps (no breakdown steps, no inference configs):
+# the summarisers divide by THIS number (round 2 passed 6 while the run did 7 steps: its per-step totals were 7/6 too high)
+STEPS=4
 rm -rf $O && mkdir -p $O
-NEF_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $O/one -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/one.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/two -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/two.log 2>&1
-NEF_SIDE_STREAM=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o t -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
-NEF_SIDE_STREAM=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o t -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1
-python tools/rocprof_summary.py $(find $O/one -name "*results.db" | head -1) $O/${R}_kernel_stats_serialized.md 6 > /dev/null
-python tools/rocprof_summary.py $(find $O/two -name "*results.db" | head -1) $O/${R}_kernel_stats.md 6 > /dev/null
+NEF_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $O/one -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary > $O/one.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/two -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary > $O/two.log 2>&1
+NEF_SIDE_STREAM=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o t -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary > $O/fetch.log 2>&1
+NEF_SIDE_STREAM=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o t -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary > $O/write.log 2>&1
+python tools/rocprof_summary.py $(find $O/one -name "*results.db" | head -1) $O/${R}_kernel_stats_serialized.md $STEPS > /dev/null
+python tools/rocprof_summary.py $(find $O/two -name "*results.db" | head -1) $O/${R}_kernel_stats.md $STEPS > /dev/null
 python tools/pmc_table.py $(find $O/fetch -name "*results.db" | head -1) $(find $O/write -name "*results.db" | head -1) $O/${R}_pmc_traffic.md $O/traffic.json > /dev/null 2> $O/pmc.err
-python tools/roofline_table.py $(find $O/one -name "*results.db" | head -1) $(find $O/fetch -name "*results.db" | head -1) $(find $O/write -name "*results.db" | head -1) $O/${R}_hbm_kernels.md 6 > /dev/null 2>> $O/pmc.err
+python tools/roofline_table.py $(find $O/one -name "*results.db" | head -1) $(find $O/fetch -name "*results.db" | head -1) $(find $O/write -name "*results.db" | head -1) $O/${R}_hbm_kernels.md $STEPS > /dev/null 2>> $O/pmc.err
 bash tools/pmc_sq.sh "enc k7" $R/sq > /dev/null 2>&1
 rm -rf $O/one $O/two $O/fetch $O/write
 ls -la $O
