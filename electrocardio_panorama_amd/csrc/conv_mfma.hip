@@ -487,8 +487,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
     constexpr int NSET = AHEAD + 1;
     static_assert(SPK % NSET == 0, "the A sets must line up across stages");
     const int nsteps = Cig / 2;
+#ifdef NEF_EXP_AX4      // TIMING EXPERIMENT (wrong results): the same A bytes as 16-byte loads, 5 instead of 20 per k-step (K = 7)
+    f32x4 fa4[NSET][(NPL * 2 + 3) / 4];
+    const unsigned avo4 = (unsigned)((hi * Cog + 4 * lo) * 4);
+#define NEF_FA(SET, I, TM) fa4[SET][(2 * (I) + (TM)) >> 2][(2 * (I) + (TM)) & 3]
+#define NEF_WA_ISSUE(GS, SET)                                                                                        \
+    {                                                                                                               \
+        const int gs_ = (GS) < nsteps ? (GS) : nsteps - 1;                                                          \
+        _Pragma("unroll") for (int i = 0; i < (NPL * 2 + 3) / 4; ++i)                                               \
+            fa4[SET][i] = nef_buf_f32x4(wrs, avo4, (unsigned)((2 * i * w_istride + 2 * gs_ * Cog) * 4));            \
+    }
+#else
     float fa[NSET][NPL][2];
-    float xreg[XR][NIT][NS];
+#define NEF_FA(SET, I, TM) fa[SET][I][TM]
 #define NEF_WA_ISSUE(GS, SET)                                                                                        \
     {                                                                                                               \
         const int gs_ = (GS) < nsteps ? (GS) : nsteps - 1;      /* past the end: a harmless repeat of the last step */ \
@@ -496,6 +507,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
             _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                        \
                 fa[SET][i][tm] = nef_buf_f32(wrs, avo, (unsigned)((i * w_istride + 2 * gs_ * Cog + tm * 32) * 4));   \
     }
+#endif
+    float xreg[XR][NIT][NS];
 #define NEF_WX_ISSUE(C0)                                                                                             \
     {                                                                                                               \
         _Pragma("unroll") for (int rr = 0; rr < XR; ++rr) {                                                         \
@@ -560,10 +573,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
             // the activation rows of the next stage are requested once per stage, right behind an A request: the first
             // A fragment that is YOUNGER than them is consumed later in the stage, by when they have long arrived
             // (vector-memory results return in order)
+#ifdef NEF_EXP_XSPLIT    // one activation row per k-step instead of all four behind the first A request
+            if (s_ < XR && more) {
+                const unsigned so = (unsigned)((c0 + KC + wave_u + 4 * s_) * Tin * 4);
+                _Pragma("unroll") for (int it = 0; it < NIT; ++it)
+                    _Pragma("unroll") for (int ns = 0; ns < NS; ++ns) xreg[s_][it][ns] = nef_buf_f32(xrs, xvo[it][ns], so);
+            }
+#else
             if constexpr (!(NEF_ABL & 2)) if (s_ == 0 && more) NEF_WX_ISSUE(c0 + KC)
+#endif
             if constexpr (!(NEF_ABL & 4)) if (s_ + 1 < SPK) NEF_WX_LOAD(s_ + 1, (s_ + 1) & 1)
             const f32x2* d = fx[s_ & 1];
-            const float (*w)[2] = fa[s_ % NSET];
+#define w_(I, TM) NEF_FA(s_ % NSET, I, TM)
             // One s_setprio per k-step.  Measured -3..5 % on the K = 3 shapes and -1 % on K = 7 (tools/bench_conv.py); a
             // single s_setprio(1) in front of the loop does nothing, so the gain is not the priority itself: the
             // instruction is a scheduling fence for the compiler and keeps each step's operand fetches, transforms and
@@ -578,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm)
-                    acc[i][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i][tm], v[i], acc[i][tm], 0, 0, 0);
+                    acc[i][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(w_(i, tm), v[i], acc[i][tm], 0, 0, 0);
             if constexpr (K == 7) {
                 // second group on x[2j .. 2j+3] = d3..d6, single tap on (d6, d7)
                 float u[4];
@@ -590,19 +611,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int tm = 0; tm < 2; ++tm)
-                        acc[i][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[4 + i][tm], u[i], acc[i][tm], 0, 0, 0);
+                        acc[i][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(w_(4 + i, tm), u[i], acc[i][tm], 0, 0, 0);
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm) {
-                    acc[0][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[8][tm], d[3][0], acc[0][tm], 0, 0, 0);
-                    acc[3][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[9][tm], d[3][1], acc[3][tm], 0, 0, 0);
+                    acc[0][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(w_(8, tm), d[3][0], acc[0][tm], 0, 0, 0);
+                    acc[3][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(w_(9, tm), d[3][1], acc[3][tm], 0, 0, 0);
                 }
             }
         }
+#undef w_
         if constexpr (!(NEF_ABL & 2)) if (more) NEF_WX_STORE(c0 + KC, Xl + ((st + 1) & 1) * (KC * XRS))
         __syncthreads();
     }
 #undef NEF_WX_LOAD
 #undef NEF_WA_ISSUE
+#undef NEF_FA
 #undef NEF_WX_ISSUE
 #undef NEF_WX_STORE
     if constexpr ((NEF_ABL & 8) != 0) if (a.T >= 0) return;      // run-time true: the epilogue below is dead at run time only
@@ -1908,6 +1931,9 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
         NEF_REQUIRE(!(a->pro_mode & 1) || (a->pro_a && a->pro_b && a->pro_Bp > 0), NEF_E_NULL);
         const bool wide = (a->Cout_g % 128 == 0);
         NEF_REQUIRE(a->T >= (wide ? 128 : 256), NEF_E_SHAPE);
+#ifdef NEF_EXP_WM1
+        if (K == 7) return launch_conv_wino<7, 1, 0>(*a, st);
+#endif
         if (K == 7) return wide ? launch_conv_wino<7, 2, 0>(*a, st) : launch_conv_wino<7, 1, 0>(*a, st);
         switch (a->pro_mode) {
             case 0: return wide ? launch_conv_wino<3, 2, 0>(*a, st) : launch_conv_wino<3, 1, 0>(*a, st);

@@ -94,19 +94,19 @@ TIE_LOG = []              # (site, worst / rms, flips, numel) of every site with
 
 def assert_flips_are_ties(dec):
     """Replayed decisions that differ from the oracle's own must be ties: the oracle's argument within TIE_REL of the
-    switching point (relative to the site's rms) and rare.  Flips where the oracle's argument is EXACTLY zero (the
-    all-zero tail of a beat seen through a conv) are exempt from the rarity bound only on sites whose forward conv runs
-    through F(4,3) -- the decoder passes -- and on the L1 sign sites: F(4,3) computes such an output from products that
-    cancel only analytically.  Every encoder-side forward conv takes F(2,3) or the direct form, which keep the reference's
-    exact 0.0 by construction (each product feeding an output only sees that output's receptive field), so there the
-    claim is a test: no exact-zero flip at all."""
+    switching point (relative to the site's rms) and rare (<= TIE_FRAC * numel + 2 per site).  Flips where the oracle's
+    argument is EXACTLY zero (the all-zero tail of a beat seen through a conv) are exempt from the rarity bound only on
+    sites whose forward conv runs through F(4,3) -- the decoder passes -- and on the L1 sign sites: F(4,3) computes such
+    an output from products that cancel only analytically.  Every encoder-side forward conv takes F(2,3) or the direct
+    form, which keep the reference's exact 0.0 by construction (each product feeding an output only sees that output's
+    receptive field): there an exact-zero flip is counted like any other flip.  (It cannot be required to be absent: one
+    genuine tie upstream that the HIP path resolved as 1e-9 instead of 0 turns an exact 0 of the oracle one layer
+    down into a +-1e-9 -- 1 such position among 1.2e8 in the full-size step.)"""
     for site, r in dec.report.items():
         if r["flips"] == 0:
             continue
         TIE_LOG.append((site, r["worst"] / max(r["rms"], 1e-30), r["flips"], r["numel"]))
         f4_forward = site.startswith("pass") or site.startswith("loss")
-        if not f4_forward:
-            assert r.get("degenerate", 0) == 0, (site, r)
         assert r["flips"] - (r.get("degenerate", 0) if f4_forward else 0) <= TIE_FRAC * r["numel"] + 2, (site, r)
         assert r["worst"] <= TIE_REL * max(r["rms"], 1e-30), (site, r)
 
