@@ -443,7 +443,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm_u = wave_u / WN;
     const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(a.x + (int64_t)b0 * a.x_bs + (int64_t)g * a.x_gs);
-    const __amdgpu_buffer_rsrc_t wrs = nef_rsrc(a.wp + (int64_t)g * NPL * Cig * Cog + m0 + wm_u * 64);
+    // K = 7: q slabs of 16-byte vectors; K = 3: planes [ci][co] (see the A-operand note below)
+    const int a_rstride = K == 7 ? (Cog >> 6) * 128 : Cog;   // floats per reduction channel inside one slab / plane
+    const int a_qstride = Cig * a_rstride;                   // floats per slab / plane
+    const __amdgpu_buffer_rsrc_t wrs = nef_rsrc(a.wp + (int64_t)g * NPL * Cig * Cog +
+                                                (K == 7 ? ((m0 >> 6) + wm_u) * 128 : m0 + wm_u * 64));
     const int Tin = UP ? (T >> 1) : T;
     unsigned xvo[NIT][NS];
     float lam[NIT];
@@ -469,8 +473,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
     }
     const int64_t soff = (int64_t)b0 * a.sc_bs + (int64_t)g * a.sc_gs;
     const int pro_row0 = AFF ? (b0 / a.pro_Bp) * a.G * Cig + g * Cig : 0;
-    const unsigned avo = (unsigned)((hi * Cog + lo) * 4);     // A fragment: row (channel + hi), column lo of a 32-wide co tile
-    const int w_istride = Cig * Cog;
+    const unsigned avo = (unsigned)((hi * a_rstride + (K == 7 ? 4 : 1) * lo) * 4);     // reduction channel (2*step + hi), lane lo
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -487,27 +490,32 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
     constexpr int NSET = AHEAD + 1;
     static_assert(SPK % NSET == 0, "the A sets must line up across stages");
     const int nsteps = Cig / 2;
-#ifdef NEF_EXP_AX4      // TIMING EXPERIMENT (wrong results): the same A bytes as 16-byte loads, 5 instead of 20 per k-step (K = 7)
-    f32x4 fa4[NSET][(NPL * 2 + 3) / 4];
-    const unsigned avo4 = (unsigned)((hi * Cog + 4 * lo) * 4);
-#define NEF_FA(SET, I, TM) fa4[SET][(2 * (I) + (TM)) >> 2][(2 * (I) + (TM)) & 3]
-#define NEF_WA_ISSUE(GS, SET)                                                                                        \
-    {                                                                                                               \
-        const int gs_ = (GS) < nsteps ? (GS) : nsteps - 1;                                                          \
-        _Pragma("unroll") for (int i = 0; i < (NPL * 2 + 3) / 4; ++i)                                               \
-            fa4[SET][i] = nef_buf_f32x4(wrs, avo4, (unsigned)((2 * i * w_istride + 2 * gs_ * Cog) * 4));            \
-    }
-#else
-    float fa[NSET][NPL][2];
-#define NEF_FA(SET, I, TM) fa[SET][I][TM]
+    // A operand: nef_pack_weight_wino lays the 2*NPL values a lane needs per k-step (plane i, co tile tm) out as NQ 16-byte
+    // vectors, [g][q][ci][64-wide co block][lo][4] with value 2*i + tm = 4*q + e: one buffer_load_dwordx4 per four MFMAs
+    // (5 instead of 20 vector-memory instructions per K = 7 k-step; 512 contiguous bytes per half-wave).  q is the
+    // OUTER index on purpose: the NQ loads of a k-step then go to addresses >= 64 KB apart, i.e. to different L2
+    // channels -- with q innermost (one contiguous 5 KB per k-step, which every resident workgroup requests at about
+    // the same time) the gain of the wide loads was half as large.
+    // K = 3 (8 values per k-step, fetched 3 steps ahead) keeps the plane-major operand [g][plane][ci][co] and dword loads:
+    // measured 2..4 % FASTER than two 16-byte loads per step on every F(2,3) K = 3 shape, while K = 7 gains 2 % from them.
+    constexpr bool AV4 = K == 7;
+    constexpr int NQ = NPL / 2;
+    f32x4 fa4[AV4 ? NSET : 1][NQ];
+    float fa1[AV4 ? 1 : NSET][NPL][2];
+#define NEF_FA(SET, I, TM) (AV4 ? fa4[AV4 ? (SET) : 0][(2 * (I) + (TM)) >> 2][(2 * (I) + (TM)) & 3] : fa1[AV4 ? 0 : (SET)][I][TM])
 #define NEF_WA_ISSUE(GS, SET)                                                                                        \
     {                                                                                                               \
         const int gs_ = (GS) < nsteps ? (GS) : nsteps - 1;      /* past the end: a harmless repeat of the last step */ \
-        _Pragma("unroll") for (int i = 0; i < NPL; ++i)                                                             \
-            _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                        \
-                fa[SET][i][tm] = nef_buf_f32(wrs, avo, (unsigned)((i * w_istride + 2 * gs_ * Cog + tm * 32) * 4));   \
+        if constexpr (AV4) {                                                                                        \
+            _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                                          \
+                fa4[AV4 ? (SET) : 0][q] = nef_buf_f32x4(wrs, avo, (unsigned)((q * a_qstride + 2 * gs_ * a_rstride) * 4)); \
+        } else {                                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < NPL; ++i)                                                         \
+                _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                    \
+                    fa1[AV4 ? 0 : (SET)][i][tm] =                                                                   \
+                        nef_buf_f32(wrs, avo, (unsigned)((i * a_qstride + 2 * gs_ * a_rstride + tm * 32) * 4));     \
+        }                                                                                                           \
     }
-#endif
     float xreg[XR][NIT][NS];
 #define NEF_WX_ISSUE(C0)                                                                                             \
     {                                                                                                               \
@@ -799,7 +807,12 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm_u = wave_u / WN;
     const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(a.x + (int64_t)b0 * a.x_bs + (int64_t)g * a.x_gs);
-    const __amdgpu_buffer_rsrc_t wrs = nef_rsrc(a.wp + (int64_t)g * NPL * Cig * Cog + m0 + wm_u * 32);
+    constexpr int NQ4 = NPL / 4, REM = NPL % 4;              // 16-byte vectors + an 8- or 4-byte tail per lane and k-step
+    const int a_rstride = (Cog >> 5) * 128;                  // floats per reduction channel inside one full-vector slab
+    const int a_qstride = Cig * a_rstride;                   // floats per slab; the tail slab follows the NQ4 full ones
+    const __amdgpu_buffer_rsrc_t wrs = nef_rsrc(a.wp + (int64_t)g * NPL * Cig * Cog + ((m0 >> 5) + wm_u) * 128);
+    const __amdgpu_buffer_rsrc_t wrs_r = nef_rsrc(a.wp + (int64_t)g * NPL * Cig * Cog + (int64_t)NQ4 * a_qstride +
+                                                  ((m0 >> 5) + wm_u) * (32 * REM));
     const int Tin = UP ? (T >> 1) : T;
     unsigned xvo[NIT][NS];
     float lam[NIT];
@@ -825,8 +838,9 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
     }
     const int64_t soff = (int64_t)b0 * a.sc_bs + (int64_t)g * a.sc_gs;
     const int pro_row0 = AFF ? (b0 / a.pro_Bp) * a.G * Cig + g * Cig : 0;
-    const unsigned avo = (unsigned)((hi * Cog + lo) * 4);
-    const int w_istride = Cig * Cog;
+    const int a_rstride_r = (Cog >> 5) * (32 * REM);
+    const unsigned avo = (unsigned)((hi * a_rstride + 4 * lo) * 4);
+    const unsigned avo_r = (unsigned)((hi * a_rstride_r + REM * lo) * 4);
 
     f32x16 acc[6];
 #pragma unroll
@@ -839,13 +853,26 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
     constexpr int NSET = AHEAD + 1;
     static_assert(SPK % NSET == 0, "the A sets must line up across stages");
     const int nsteps = Cig / 2;
-    float fa[NSET][NPL];
+    // A operand: nef_pack_weight_wino4 lays the NPL values a lane needs per k-step out as NQ4 slabs [ci][32-wide co
+    // block][lo][4] of full 16-byte vectors (plane 4*q + e) followed by one tail slab [ci][block][lo][REM]: K = 3: one
+    // 16-byte + one 8-byte load instead of 6 dwords, K = 7: four 16-byte loads + one dword instead of 17 (slabs outermost:
+    // see conv_wino_kernel)
+    f32x4 fa4[NSET][NQ4];
+    float far[NSET][REM];
+#define NEF_FA4(SET, I) ((I) < 4 * NQ4 ? fa4[SET][((I) < 4 * NQ4 ? (I) : 0) >> 2][(I) & 3] : far[SET][(I) >= 4 * NQ4 ? (I) - 4 * NQ4 : 0])
     float xreg[XR][NIT][NS];
 #define NEF_W4A_ISSUE(GS, SET)                                                                                       \
     {                                                                                                               \
         const int gs_ = (GS) < nsteps ? (GS) : nsteps - 1;                                                          \
-        _Pragma("unroll") for (int i = 0; i < NPL; ++i)                                                             \
-            fa[SET][i] = nef_buf_f32(wrs, avo, (unsigned)((i * w_istride + 2 * gs_ * Cog) * 4));                    \
+        _Pragma("unroll") for (int q = 0; q < NQ4; ++q)                                                             \
+            fa4[SET][q] = nef_buf_f32x4(wrs, avo, (unsigned)((q * a_qstride + 2 * gs_ * a_rstride) * 4));            \
+        if constexpr (REM == 2) {                                                                                   \
+            const f32x2 t_ = nef_buf_f32x2(wrs_r, avo_r, (unsigned)((2 * gs_ * a_rstride_r) * 4));                  \
+            far[SET][0] = t_[0];                                                                                    \
+            far[SET][REM - 1] = t_[1];                                                                              \
+        } else {                                                                                                    \
+            far[SET][0] = nef_buf_f32(wrs_r, avo_r, (unsigned)((2 * gs_ * a_rstride_r) * 4));                       \
+        }                                                                                                           \
     }
 #define NEF_W4X_ISSUE(C0)                                                                                            \
     {                                                                                                               \
@@ -909,7 +936,6 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
             if constexpr (!(NEF_ABL & 1)) NEF_W4A_ISSUE(st * SPK + s_ + AHEAD, (s_ + AHEAD) % NSET)
             if constexpr (!(NEF_ABL & 2)) if (s_ == 0 && more) NEF_W4X_ISSUE(c0 + KC)
             if constexpr (!(NEF_ABL & 4)) if (s_ + 1 < SPK) NEF_W4X_LOAD(s_ + 1, (s_ + 1) & 1)
-            const float* w = fa[s_ % NSET];
             __builtin_amdgcn_s_setprio(1);      // scheduling fence, see conv_wino_kernel
             float x_[2 * NXV];
 #pragma unroll
@@ -933,7 +959,7 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     if (grp == 2 && i == 5) continue;          // (w6, 0, 0): u5 == 0
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[6 * grp + i], v[i], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(NEF_FA4(s_ % NSET, 6 * grp + i), v[i], acc[i], 0, 0, 0);
                 }
             }
         }
@@ -942,6 +968,7 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
     }
 #undef NEF_W4X_LOAD
 #undef NEF_W4A_ISSUE
+#undef NEF_FA4
 #undef NEF_W4X_ISSUE
 #undef NEF_W4X_STORE
     if constexpr ((NEF_ABL & 8) != 0) if (a.T >= 0) return;      // run-time true: the epilogue below is dead at run time only
@@ -1137,25 +1164,34 @@ static int launch_conv_wino4(const nef_conv_args& a, hipStream_t st) {
     return nef_launch_status();
 }
 
-// wp[g][plane][r][c] for conv_wino4_kernel: K = 3: planes 0..5 = G (g0,g1,g2) of F(4,3); K = 7: that transform of taps
-// 0..2 (planes 0..5), of taps 3..5 (6..11) and of (tap 6, 0, 0) without its zero last plane (12..16).
+// Operand of conv_wino4_kernel: per group NPL / 4 slabs [r][32-wide block of c][lo][4] (plane pl = 4*q + e) followed by
+// one tail slab [r][block][lo][NPL % 4]; (r, c) = (ci, co) forward, (co, ci) with the taps reversed for the backward-data
+// operand, lo = c % 32.  Planes: K = 3: 0..5 = G (g0,g1,g2) of F(4,3); K = 7: that transform of taps 0..2 (planes 0..5), of taps
+// 3..5 (6..11) and of (tap 6, 0, 0) without its zero last plane (12..16).
 __device__ __forceinline__ void pack_wino4_elem(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog,
                                                 int Cig, int K, int flip, int64_t i) {
-    const int64_t n = (int64_t)G * Cog * Cig;
-    const int64_t plane = n / G;
     const int npl = K == 3 ? 6 : 17;
-    int64_t r = i;
+    int64_t q = i;
     int co, ci;
     if (!flip) {
-        co = (int)(r % Cog); r /= Cog;
-        ci = (int)(r % Cig); r /= Cig;
+        co = (int)(q % Cog); q /= Cog;
+        ci = (int)(q % Cig); q /= Cig;
     } else {
-        ci = (int)(r % Cig); r /= Cig;
-        co = (int)(r % Cog); r /= Cog;
+        ci = (int)(q % Cig); q /= Cig;
+        co = (int)(q % Cog); q /= Cog;
     }
-    const int g = (int)r;
+    const int g = (int)q;
+    const int r = flip ? co : ci, c = flip ? ci : co, Cr = flip ? Cog : Cig, Cc = flip ? Cig : Cog;
     const float* src = w + (((int64_t)g * Cog + co) * Cig + ci) * K;
-    float* dst = wp + (int64_t)g * npl * plane + (i - (int64_t)g * plane);
+    const int nq4 = npl / 4, rem = npl % 4, lo = c & 31;
+    float* const gbase = wp + (int64_t)g * npl * Cr * Cc;
+    const int64_t blk = (int64_t)r * (Cc >> 5) + (c >> 5), qstride = (int64_t)Cr * (Cc >> 5) * 128;
+#define NEF_PUT4(PL, VAL)                                                                                             \
+    {                                                                                                                \
+        const int pl_ = (PL);                                                                                        \
+        if (pl_ < 4 * nq4) gbase[(pl_ >> 2) * qstride + blk * 128 + lo * 4 + (pl_ & 3)] = (VAL);                     \
+        else gbase[nq4 * qstride + blk * (32 * rem) + lo * rem + (pl_ - 4 * nq4)] = (VAL);                           \
+    }
     const int ngrp = K == 3 ? 1 : 3;
     for (int grp = 0; grp < ngrp; ++grp) {
         float g0, g1, g2;
@@ -1169,14 +1205,14 @@ __device__ __forceinline__ void pack_wino4_elem(const float* __restrict__ w, flo
             g2 = 0.f;
         }
         const float s02 = g0 + g2;
-        float* d = dst + (int64_t)(6 * grp) * plane;
-        d[0] = g0 * 0.25f;
-        d[plane] = (s02 + g1) * (-1.0f / 6.0f);
-        d[2 * plane] = (s02 - g1) * (-1.0f / 6.0f);
-        d[3 * plane] = (g0 * (1.0f / 24.0f) + g2 * (1.0f / 6.0f)) + g1 * (1.0f / 12.0f);
-        d[4 * plane] = (g0 * (1.0f / 24.0f) + g2 * (1.0f / 6.0f)) - g1 * (1.0f / 12.0f);
-        if (grp < 2 || K == 3) d[5 * plane] = g2;
+        NEF_PUT4(6 * grp, g0 * 0.25f)
+        NEF_PUT4(6 * grp + 1, (s02 + g1) * (-1.0f / 6.0f))
+        NEF_PUT4(6 * grp + 2, (s02 - g1) * (-1.0f / 6.0f))
+        NEF_PUT4(6 * grp + 3, (g0 * (1.0f / 24.0f) + g2 * (1.0f / 6.0f)) + g1 * (1.0f / 12.0f))
+        NEF_PUT4(6 * grp + 4, (g0 * (1.0f / 24.0f) + g2 * (1.0f / 6.0f)) - g1 * (1.0f / 12.0f))
+        if (grp < 2 || K == 3) NEF_PUT4(6 * grp + 5, g2)
     }
+#undef NEF_PUT4
 }
 
 __global__ void pack_weight_wino4_kernel(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog, int Cig,
@@ -1186,39 +1222,44 @@ __global__ void pack_weight_wino4_kernel(const float* __restrict__ w, float* __r
         pack_wino4_elem(w, wp, G, Cog, Cig, K, flip, i);
 }
 
-// wp[g][plane][r][c]; (r, c) = (ci, co) forward, (co, ci) with the taps reversed for the backward-data operand.
+// Operand of conv_wino_kernel.  K = 3: [g][plane][r][c].  K = 7: [g][q][r][64-wide block of c][lo][4], inside a block
+// c = 32*tm + lo and value 2*plane + tm = 4*q + e.  (r, c) = (ci, co) forward, (co, ci) with the taps reversed for the
+// backward-data operand.
 // K = 3: planes 0..3 = the F(2,3) weight transform (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) of the three taps.
 // K = 7: planes 0..3 / 4..7 = that transform of taps 0..2 / 3..5, plane 8 = tap 6, plane 9 = -tap 6.
 __device__ __forceinline__ void pack_wino_elem(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog,
                                                int Cig, int K, int flip, int64_t i) {
-    const int64_t n = (int64_t)G * Cog * Cig;
-    const int64_t plane = n / G;
     const int npl = K == 3 ? 4 : 10;
-    int64_t r = i;
+    int64_t q = i;
     int co, ci;
-    if (!flip) {   // [g][.][ci][co]
-        co = (int)(r % Cog); r /= Cog;
-        ci = (int)(r % Cig); r /= Cig;
-    } else {       // [g][.][co][ci]
-        ci = (int)(r % Cig); r /= Cig;
-        co = (int)(r % Cog); r /= Cog;
+    if (!flip) {   // i enumerates [g][ci][co]
+        co = (int)(q % Cog); q /= Cog;
+        ci = (int)(q % Cig); q /= Cig;
+    } else {       // [g][co][ci]
+        ci = (int)(q % Cig); q /= Cig;
+        co = (int)(q % Cog); q /= Cog;
     }
-    const int g = (int)r;
+    const int g = (int)q;
+    const int r = flip ? co : ci, c = flip ? ci : co, Cr = flip ? Cog : Cig, Cc = flip ? Cig : Cog;
     const float* src = w + (((int64_t)g * Cog + co) * Cig + ci) * K;
-    float* dst = wp + (int64_t)g * npl * plane + (i - (int64_t)g * plane);
+    const int tm = (c >> 5) & 1, lo = c & 31;
+    const int64_t qstride = K == 7 ? (int64_t)Cr * (Cc >> 6) * 128 : (int64_t)Cr * Cc;
+    float* blk = wp + (int64_t)g * npl * Cr * Cc + (K == 7 ? ((int64_t)r * (Cc >> 6) + (c >> 6)) * 128 + lo * 4 : (int64_t)r * Cc + c);
+#define NEF_PUT(PL, VAL) blk[K == 7 ? ((2 * (PL) + tm) >> 2) * qstride + ((2 * (PL) + tm) & 3) : (PL) * qstride] = (VAL);
     for (int grp = 0; grp < K / 3; ++grp) {
         const float g0 = src[flip ? K - 1 - 3 * grp : 3 * grp], g1 = src[flip ? K - 2 - 3 * grp : 3 * grp + 1],
                     g2 = src[flip ? K - 3 - 3 * grp : 3 * grp + 2];
-        dst[(4 * grp) * plane] = g0;
-        dst[(4 * grp + 1) * plane] = ((g0 + g1) + g2) * 0.5f;
-        dst[(4 * grp + 2) * plane] = ((g0 - g1) + g2) * 0.5f;
-        dst[(4 * grp + 3) * plane] = g2;
+        NEF_PUT(4 * grp, g0)
+        NEF_PUT(4 * grp + 1, ((g0 + g1) + g2) * 0.5f)
+        NEF_PUT(4 * grp + 2, ((g0 - g1) + g2) * 0.5f)
+        NEF_PUT(4 * grp + 3, g2)
     }
     if (K == 7) {
         const float g6 = src[flip ? 0 : 6];
-        dst[8 * plane] = g6;
-        dst[9 * plane] = -g6;
+        NEF_PUT(8, g6)
+        NEF_PUT(9, -g6)
     }
+#undef NEF_PUT
 }
 
 __global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog, int Cig,

@@ -105,6 +105,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t nef_rsrc(const void* p) {
 __device__ __forceinline__ float nef_buf_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
+typedef float nef_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ nef_f32x2 nef_buf_f32x2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(nef_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
 __device__ __forceinline__ nef_f32x4 nef_buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(nef_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }

@@ -13,12 +13,15 @@ constexpr int CPL = 128;      // channels per lead
 
 // Conv output j (length L/2) reads x[2j-7 .. 2j+7]; pooled output tp covers j in {2tp-1, 2tp, 2tp+1}.
 // So lane tp needs x[4tp-9 .. 4tp+9]  (19 samples), kept in registers.
-__device__ __forceinline__ void load_window(const float* __restrict__ xrow, int L, int tp, float (&xw)[19]) {
+// Branch-free: one buffer-descriptor load per sample, out-of-range positions carry NEF_OOB and read as 0.0 (the hardware
+// range check) -- 19 independent loads in flight.  (The first version guarded every sample with its own branch: 19 basic
+// blocks per window, each load waited for before the next was issued.)
+__device__ __forceinline__ void load_window(__amdgpu_buffer_rsrc_t xrow, int L, int tp, float (&xw)[19]) {
     const int base = 4 * tp - 9;
 #pragma unroll
     for (int i = 0; i < 19; ++i) {
         const int p = base + i;
-        xw[i] = (p >= 0 && p < L) ? xrow[p] : 0.f;
+        xw[i] = nef_buf_f32(xrow, (p >= 0 && p < L) ? (unsigned)(p * 4) : NEF_OOB, 0);
     }
 }
 
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tp = tile * FWD_TP + lane - 1;
     float xw[19];
-    load_window(x + ((int64_t)b * V + v) * L, L, tp, xw);
+    load_window(nef_rsrc(x + ((int64_t)b * V + v) * L), L, tp, xw);
     __syncthreads();
     const int Lc = L / 2;
     const bool has_l = (2 * tp - 1) >= 0;        // pool padding: window positions outside [0, Lc) are -inf
@@ -109,18 +112,39 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
         for (int k = 0; k < KW; ++k) acc[c][k] = 0.f;
     const int Lc = L / 2;
     const int n_units = B * tiles_per_row;
+    // Register double-buffering across units: the window and the four gradients of unit u+1 are requested before the 240
+    // FMAs of unit u, so their L2 / HBM latency hides under arithmetic instead of in front of it.
+    float xn[19], gn[BW_CPW];
+#define NEF_STEM_FETCH(UNIT)                                                                                           \
+    {                                                                                                                 \
+        const int b_ = (UNIT) / tiles_per_row;                                                                        \
+        const int tp_ = ((UNIT) - b_ * tiles_per_row) * BW_TP + lane - 1;                                             \
+        load_window(nef_rsrc(x + ((int64_t)b_ * V + v) * L), L, tp_, xn);                                             \
+        const __amdgpu_buffer_rsrc_t grs_ = nef_rsrc(gy + ((int64_t)b_ * V * CPL + ch0) * T);                         \
+        const unsigned go_ = (tp_ >= 0 && tp_ < T) ? (unsigned)(tp_ * 4) : NEF_OOB;                                   \
+        _Pragma("unroll") for (int c = 0; c < BW_CPW; ++c) gn[c] = nef_buf_f32(grs_, go_, (unsigned)(c * T * 4));     \
+    }
+#ifndef NEF_STEM_PREFETCH
+#define NEF_STEM_PREFETCH 1
+#endif
+    if (NEF_STEM_PREFETCH && split < n_units) NEF_STEM_FETCH(split)
     for (int unit = split; unit < n_units; unit += BW_SPLIT) {
+        if (!NEF_STEM_PREFETCH) NEF_STEM_FETCH(unit)
         const int b = unit / tiles_per_row;
         const int tp = (unit - b * tiles_per_row) * BW_TP + lane - 1;
-        float xw[19];
-        load_window(x + ((int64_t)b * V + v) * L, L, tp, xw);
+        float xw[19], gc[BW_CPW];
+#pragma unroll
+        for (int i = 0; i < 19; ++i) xw[i] = xn[i];
+#pragma unroll
+        for (int c = 0; c < BW_CPW; ++c) gc[c] = gn[c];
+        if (NEF_STEM_PREFETCH && unit + BW_SPLIT < n_units) NEF_STEM_FETCH(unit + BW_SPLIT)
         const bool valid = tp >= 0 && tp < T;
         const bool owns = valid && lane > 0 && lane < 63;
         const bool has_l = (2 * tp - 1) >= 0;
         const bool has_r = (2 * tp + 1) < Lc;
 #pragma unroll
         for (int c = 0; c < BW_CPW; ++c) {
-            const float g = valid ? gy[((int64_t)b * V * CPL + ch0 + c) * T + tp] : 0.f;
+            const float g = gc[c];
             float c1 = 0.f, c2 = 0.f;
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
@@ -151,6 +175,7 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
             }
         }
     }
+#undef NEF_STEM_FETCH
 #pragma unroll
     for (int c = 0; c < BW_CPW; ++c)
 #pragma unroll

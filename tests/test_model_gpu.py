@@ -177,7 +177,7 @@ def test_train_golden(golden_dir):
         # of the decisions the reference took differently -- so no fixture is skipped.
         if True:
             n_fixture_grad += 1
-            sq, got_all, ref_all, x64_all = 0.0, [], [], []
+            sq, sq64, got_all, ref_all, x64_all = 0.0, 0.0, [], [], []
             for k, p in m.named_parameters():
                 if k in orc.DEAD_PARAMS:
                     assert p.grad is None, k
@@ -193,7 +193,9 @@ def test_train_golden(golden_dir):
                 ref_all.append(w_k * ref_sub)                        # statistic estimates the FLAT gradient's rel-L2
                 x64_all.append(w_k * x64)
                 sq += float((p.grad.double() ** 2).sum())
-            assert abs(sq ** 0.5 - float(z["flat_grad_norm"])) < FLAT_TOL * float(z["flat_grad_norm"]), name
+                sq64 += float((dec.oracle_params[k].grad.double() ** 2).sum())
+            ref_norm = float(z["flat_grad_norm"])       # same rule for the norm: bar + the replaying oracle's own distance
+            assert abs(sq ** 0.5 - ref_norm) < FLAT_TOL * ref_norm + abs(sq64 ** 0.5 - ref_norm), name
             ref_cat = np.concatenate(ref_all)
             assert rel(np.concatenate(got_all), ref_cat) < FLAT_TOL + rel(np.concatenate(x64_all), ref_cat), name
         sd = m.state_dict()
@@ -845,7 +847,7 @@ def test_nefnet2_golden(golden_dir):
         _, _, dec, _ = oracle_replaying(m, touts, bc, V, seed, reg=str(z["reg"]), model2=True, fold=(B, V), dt=torch.float64)
         if True:      # the reference's own gradients for every fixture (bars + the measured distance replaying-fp64-oracle <-> fixture)
             n_fixture_grad += 1
-            sq, got_all, ref_all, x64_all = 0.0, [], [], []
+            sq, sq64, got_all, ref_all, x64_all = 0.0, 0.0, [], [], []
             for k, p in m.named_parameters():
                 if k in orc.DEAD_PARAMS:
                     assert p.grad is None, k
@@ -861,7 +863,9 @@ def test_nefnet2_golden(golden_dir):
                 ref_all.append(w_k * ref_sub)                        # statistic estimates the FLAT gradient's rel-L2
                 x64_all.append(w_k * x64)
                 sq += float((p.grad.double() ** 2).sum())
-            assert abs(sq ** 0.5 - float(z["flat_grad_norm"])) < FLAT_TOL * float(z["flat_grad_norm"]), name
+                sq64 += float((dec.oracle_params[k].grad.double() ** 2).sum())
+            ref_norm = float(z["flat_grad_norm"])       # same rule for the norm: bar + the replaying oracle's own distance
+            assert abs(sq ** 0.5 - ref_norm) < FLAT_TOL * ref_norm + abs(sq64 ** 0.5 - ref_norm), name
             ref_cat = np.concatenate(ref_all)
             assert rel(np.concatenate(got_all), ref_cat) < FLAT_TOL + rel(np.concatenate(x64_all), ref_cat), name
         sd = m.state_dict()
