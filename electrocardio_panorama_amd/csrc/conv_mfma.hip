@@ -751,11 +751,17 @@ static int launch_conv_wino(const nef_conv_args& a, hipStream_t st) {
 //     u = G g:    u0 = g0/4   u1 = -(g0+g1+g2)/6   u2 = -(g0-g1+g2)/6   u3 = g0/24+g1/12+g2/6   u4 = g0/24-g1/12+g2/6   u5 = g2
 //     M_i[co][j] = sum_ci u_i v_i  (6 GEMMs over a QUARTER of the columns)
 //     y0 = M0+M1+M2+M3+M4   y1 = M1-M2+2M3-2M4   y2 = M1+M2+4M3+4M4   y3 = M1-M2+8M3-8M4+M5
-// K = 7 = three such groups on x[4j-3..], x[4j..], x[4j+3..] with taps (w0,w1,w2), (w3,w4,w5), (w6,0,0) accumulating into
-// the same six M tiles; the third group's u5 is identically zero and is skipped: 6+6+5 = 17 multiplies per 4 outputs
-// (4.25 per output; F(2,3) split: 5, direct: 7).  fp32 rounding: measured 2x the direct form on Gaussian data, below it
-// on smooth non-negative activations (transform entries up to 8 and 1/24) -- still far from
-// the 1e-5 forward bar, and held to it by the same tests.
+// K = 7 (round 3) = taps split 4 + 3: F(4,4) on taps 0..3 and inputs d_m = x[4j-3+m], m = 0..6 (points 0, +-1, +-2, 1/2, inf:
+// 7 products), F(4,3) on taps 4..6 and inputs x[4j+1 .. 4j+6].  The output-transform columns of the six points the two
+// share are identical, so both groups accumulate into the SAME six M tiles and the point 1/2 gets a seventh:
+//     y0 += M6   y1 += M6/2   y2 += M6/4   y3 += M6/8
+// 7 + 6 = 13 multiplies per 4 outputs (3.25 per output; rounds 1-2: three F(4,3) groups 3+3+1 = 17, F(2,3) split: 20,
+// direct: 28).  B^T of F(4,4) (rows in accumulator order 0, 1, -1, 2, -2, inf, 1/2):
+//     (-2, 4, 2.5, -5, -0.5, 1, 0)  (0, 2, -2, -4.5, 0.5, 1, 0)  (0, -2, 6, -3.5, -1.5, 1, 0)  (0, 1, -1.5, -2, 1.5, 1, 0)
+//     (0, -1, 2.5, 0, -2.5, 1, 0)   (0, -2, 4, 2.5, -5, -0.5, 1)  (0, 4, 0, -5, 0, 1, 0)
+// G rows: -g0/2, -(g0+g1+g2+g3)/3, (g0-g1+g2-g3)/9, g0/36+g1/18+g2/9+2g3/9, -g0/60+g1/30-g2/15+2g3/15, g3, (32g0+16g1+8g2+4g3)/45.
+// fp32 rounding (numpy model of the whole pipeline, 128 channels): 1.2x the 3+3+1 F(4,3) form, 1.6x the direct form --
+// used for backward-data launches only (no decision is taken on a gradient); the whole-model gradient bars are unchanged.
 // Machinery as conv_wino_kernel (raw activations double-buffered in LDS and transformed on the way to the B operand,
 // A fragments straight from L2 ahead of use, one barrier per 16-channel stage); a wave owns 32 output channels x 32 quads
 // (128 outputs) = 6 accumulator tiles; a workgroup is 4 x 1 waves (128 channels x 128 outputs) or 2 x 2 (64 x 256).
@@ -770,11 +776,11 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
     constexpr int KC = WKC;
     constexpr int WN = 4 / WMC;
     constexpr int PAD = (K - 1) / 2;
-    constexpr int NGRP = K == 3 ? 1 : 3;
-    constexpr int NPL = K == 3 ? 6 : 17;     // weight planes per (ci, co)
+    constexpr int NPL = K == 3 ? 6 : 13;     // weight planes per (ci, co)
+    constexpr int NACC = K == 3 ? 6 : 7;     // M tiles
     constexpr int MT = 32 * WMC;             // output channels per workgroup
     constexpr int NTO = 128 * WN;            // outputs (columns) per workgroup
-    constexpr int NXV = K == 3 ? 3 : 6;      // ds_read_b64 per lane and k-step: x[4j-PAD .. 4j-PAD+2*NXV)
+    constexpr int NXV = K == 3 ? 3 : 5;      // ds_read_b64 per lane and k-step: x[4j-PAD .. 4j-PAD+2*NXV)
     constexpr int XROW = NTO + 2 * NXV - 4;  // staged positions per channel row
     constexpr int XRS = NTO + 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -842,9 +848,9 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
     const unsigned avo = (unsigned)((hi * a_rstride + 4 * lo) * 4);
     const unsigned avo_r = (unsigned)((hi * a_rstride_r + REM * lo) * 4);
 
-    f32x16 acc[6];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
@@ -943,10 +949,27 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
                 x_[2 * q_] = fx[s_ & 1][q_][0];
                 x_[2 * q_ + 1] = fx[s_ & 1][q_][1];
             }
+            if constexpr (K == 7) {     // F(4,4) on taps 0..3, inputs x_[0..6]; planes 0..6 in accumulator order
+                const float d0 = x_[0], d1 = x_[1], d2 = x_[2], d3 = x_[3], d4 = x_[4], d5 = x_[5], d6 = x_[6];
+                float v[7];
+                v[6] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));                                   // point 1/2
+                v[0] = fmaf(-2.f, d0, fmaf(2.5f, d2, fmaf(-0.5f, d4, v[6])));
+                v[5] = fmaf(-2.f, d1, fmaf(2.5f, d3, fmaf(-0.5f, d5, fmaf(4.f, d2, fmaf(-5.f, d4, d6)))));   // infinity
+                const float p = fmaf(2.f, d2, fmaf(-4.f, d3, fmaf(-0.5f, d4, d5)));
+                const float q = fmaf(2.f, d1, fmaf(-4.f, d2, fmaf(-0.5f, d3, d4)));
+                v[1] = p + q;
+                v[2] = p - q;
+                const float d24 = d2 - d4;
+                const float p2 = fmaf(0.5f, d24, d5 - d3), q2 = fmaf(-2.f, d24, d1 - d3);
+                v[3] = p2 + q2;
+                v[4] = p2 - q2;
 #pragma unroll
-            for (int grp = 0; grp < NGRP; ++grp) {
-                const float d0 = x_[3 * grp], d1 = x_[3 * grp + 1], d2 = x_[3 * grp + 2], d3 = x_[3 * grp + 3],
-                            d4 = x_[3 * grp + 4], d5 = x_[3 * grp + 5];
+                for (int i = 0; i < 7; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(NEF_FA4(s_ % NSET, i), v[i], acc[i], 0, 0, 0);
+            }
+            {                           // F(4,3): K = 3 on x_[0..5]; K = 7 on taps 4..6, inputs x_[4..9], planes 7..12
+                constexpr int X0 = K == 3 ? 0 : 4, P0 = K == 3 ? 0 : 7;
+                const float d0 = x_[X0], d1 = x_[X0 + 1], d2 = x_[X0 + 2], d3 = x_[X0 + 3], d4 = x_[X0 + 4], d5 = x_[X0 + 5];
                 float v[6];
                 const float t1 = fmaf(-4.f, d2, d4), t2 = fmaf(-4.f, d1, d3);
                 const float t3 = d4 - d2, t4 = 2.f * (d3 - d1);
@@ -957,10 +980,8 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
                 v[4] = t3 - t4;
                 v[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    if (grp == 2 && i == 5) continue;          // (w6, 0, 0): u5 == 0
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(NEF_FA4(s_ % NSET, 6 * grp + i), v[i], acc[i], 0, 0, 0);
-                }
+                for (int i = 0; i < 6; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(NEF_FA4(s_ % NSET, P0 + i), v[i], acc[i], 0, 0, 0);
             }
         }
         if constexpr (!(NEF_ABL & 2)) if (more) NEF_W4X_STORE(c0 + KC, Xl + ((st + 1) & 1) * (KC * XRS))
@@ -996,6 +1017,13 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
             y[q][1] = fmaf(2.f, d34, d12);
             y[q][2] = fmaf(4.f, s34, s12);
             y[q][3] = fmaf(8.f, d34, d12) + acc[5][r];
+            if constexpr (K == 7) {      // the F(4,4) group's point 1/2
+                const float m6 = acc[NACC - 1][r];
+                y[q][0] += m6;
+                y[q][1] = fmaf(0.5f, m6, y[q][1]);
+                y[q][2] = fmaf(0.25f, m6, y[q][2]);
+                y[q][3] = fmaf(0.125f, m6, y[q][3]);
+            }
         }
         if (a.bias) {
 #pragma unroll
@@ -1166,11 +1194,11 @@ static int launch_conv_wino4(const nef_conv_args& a, hipStream_t st) {
 
 // Operand of conv_wino4_kernel: per group NPL / 4 slabs [r][32-wide block of c][lo][4] (plane pl = 4*q + e) followed by
 // one tail slab [r][block][lo][NPL % 4]; (r, c) = (ci, co) forward, (co, ci) with the taps reversed for the backward-data
-// operand, lo = c % 32.  Planes: K = 3: 0..5 = G (g0,g1,g2) of F(4,3); K = 7: that transform of taps 0..2 (planes 0..5), of taps
-// 3..5 (6..11) and of (tap 6, 0, 0) without its zero last plane (12..16).
+// operand, lo = c % 32.  Planes: K = 3: 0..5 = G (g0,g1,g2) of F(4,3).  K = 7: 0..6 = G of F(4,4) applied to taps 0..3
+// (accumulator order: points 0, 1, -1, 2, -2, inf, 1/2), 7..12 = G of F(4,3) applied to taps 4..6.
 __device__ __forceinline__ void pack_wino4_elem(const float* __restrict__ w, float* __restrict__ wp, int G, int Cog,
                                                 int Cig, int K, int flip, int64_t i) {
-    const int npl = K == 3 ? 6 : 17;
+    const int npl = K == 3 ? 6 : 13;
     int64_t q = i;
     int co, ci;
     if (!flip) {
@@ -1192,26 +1220,31 @@ __device__ __forceinline__ void pack_wino4_elem(const float* __restrict__ w, flo
         if (pl_ < 4 * nq4) gbase[(pl_ >> 2) * qstride + blk * 128 + lo * 4 + (pl_ & 3)] = (VAL);                     \
         else gbase[nq4 * qstride + blk * (32 * rem) + lo * rem + (pl_ - 4 * nq4)] = (VAL);                           \
     }
-    const int ngrp = K == 3 ? 1 : 3;
-    for (int grp = 0; grp < ngrp; ++grp) {
-        float g0, g1, g2;
-        if (grp < 2 || K == 3) {
-            g0 = src[flip ? K - 1 - 3 * grp : 3 * grp];
-            g1 = src[flip ? K - 2 - 3 * grp : 3 * grp + 1];
-            g2 = src[flip ? K - 3 - 3 * grp : 3 * grp + 2];
-        } else {
-            g0 = src[flip ? 0 : 6];
-            g1 = 0.f;
-            g2 = 0.f;
-        }
-        const float s02 = g0 + g2;
-        NEF_PUT4(6 * grp, g0 * 0.25f)
-        NEF_PUT4(6 * grp + 1, (s02 + g1) * (-1.0f / 6.0f))
-        NEF_PUT4(6 * grp + 2, (s02 - g1) * (-1.0f / 6.0f))
-        NEF_PUT4(6 * grp + 3, (g0 * (1.0f / 24.0f) + g2 * (1.0f / 6.0f)) + g1 * (1.0f / 12.0f))
-        NEF_PUT4(6 * grp + 4, (g0 * (1.0f / 24.0f) + g2 * (1.0f / 6.0f)) - g1 * (1.0f / 12.0f))
-        if (grp < 2 || K == 3) NEF_PUT4(6 * grp + 5, g2)
+#define NEF_TAP(k) src[flip ? K - 1 - (k) : (k)]
+    int p0 = 0, t0 = 0;      // first plane / first tap of the F(4,3) group
+    if (K == 7) {
+        const float g0 = NEF_TAP(0), g1 = NEF_TAP(1), g2 = NEF_TAP(2), g3 = NEF_TAP(3);
+        NEF_PUT4(0, g0 * -0.5f)
+        NEF_PUT4(1, ((g0 + g1) + (g2 + g3)) * (-1.0f / 3.0f))
+        NEF_PUT4(2, ((g0 - g1) + (g2 - g3)) * (1.0f / 9.0f))
+        NEF_PUT4(3, (g0 * (1.0f / 36.0f) + g1 * (1.0f / 18.0f)) + (g2 * (1.0f / 9.0f) + g3 * (2.0f / 9.0f)))
+        NEF_PUT4(4, (g1 * (1.0f / 30.0f) - g0 * (1.0f / 60.0f)) + (g3 * (2.0f / 15.0f) - g2 * (1.0f / 15.0f)))
+        NEF_PUT4(5, g3)
+        NEF_PUT4(6, (g0 * (32.0f / 45.0f) + g1 * (16.0f / 45.0f)) + (g2 * (8.0f / 45.0f) + g3 * (4.0f / 45.0f)))
+        p0 = 7;
+        t0 = 4;
     }
+    {
+        const float g0 = NEF_TAP(t0), g1 = NEF_TAP(t0 + 1), g2 = NEF_TAP(t0 + 2);
+        const float s02 = g0 + g2;
+        NEF_PUT4(p0, g0 * 0.25f)
+        NEF_PUT4(p0 + 1, (s02 + g1) * (-1.0f / 6.0f))
+        NEF_PUT4(p0 + 2, (s02 - g1) * (-1.0f / 6.0f))
+        NEF_PUT4(p0 + 3, (g0 * (1.0f / 24.0f) + g2 * (1.0f / 6.0f)) + g1 * (1.0f / 12.0f))
+        NEF_PUT4(p0 + 4, (g0 * (1.0f / 24.0f) + g2 * (1.0f / 6.0f)) - g1 * (1.0f / 12.0f))
+        NEF_PUT4(p0 + 5, g2)
+    }
+#undef NEF_TAP
 #undef NEF_PUT4
 }
 

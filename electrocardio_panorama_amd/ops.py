@@ -198,7 +198,7 @@ WINO_FWD = 1 if _WV in ("1", "2") else 2
 WINO_BW4 = os.environ.get("NEF_BW_WINO4", "1") == "1" and _WV not in ("1", "2")
 # K=7 weight gradients with the taps split 4 + 3 (transposed F(4,2) + F(3,2): 9 MFMAs per 4 columns instead of 3+3+1's 10)
 WINO_BW7 = os.environ.get("NEF_BW7_F42", "1") == "1" and _WV not in ("1", "2")
-_WINO_PLANES = {(1, 3): 4, (1, 7): 10, (2, 3): 6, (2, 7): 17}
+_WINO_PLANES = {(1, 3): 4, (1, 7): 10, (2, 3): 6, (2, 7): 13}
 
 
 def wino_ok(K, Cin_g, Cout_g, T_out, pro=0):

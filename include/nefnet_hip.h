@@ -58,15 +58,19 @@ int nef_stem_bwd_weight(const float* x, const float* w, const float* gy, float* 
 int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                     nef_stream_t stream);
 
-/* Winograd F(2,3) operand, wp[g][plane][ci][co] (transpose_flip = 1: the backward-data operand wp[g][plane][co][ci] of
- * the reversed taps).  K == 3: 4 planes (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) of the taps w[g*Cog+co][ci][0..2].
- * K == 7 (taps split 3 + 3 + 1): 10 planes = that transform of taps 0..2, of taps 3..5, then tap 6 and -tap 6. */
+/* Winograd F(2,3) operand (transpose_flip = 1: the backward-data operand, (ci, co) exchanged and the taps reversed).
+ * K == 3: wp[g][plane][ci][co], 4 planes (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) of the taps w[g*Cog+co][ci][0..2].
+ * K == 7 (taps split 3 + 3 + 1): 10 planes = that transform of taps 0..2, of taps 3..5, then tap 6 and -tap 6, laid out for
+ * 16-byte fragment loads: wp[g][q][ci][co / 64][co % 32][4] with value 2*plane + (co % 64) / 32 = 4*q + e (conv_mfma.hip).
+ * The layout is private to nef_conv_fwd; the size is planes * G * Cog * Cig floats either way. */
 int nef_pack_weight_wino(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                          nef_stream_t stream);
 
-/* The F(4,3) operand (conv args wino = 2): wp[g][plane][ci][co] with 6 planes for K == 3 -- (g0/4, -(g0+g1+g2)/6,
- * -(g0-g1+g2)/6, g0/24+g1/12+g2/6, g0/24-g1/12+g2/6, g2) -- and 17 for K == 7 (that transform of taps 0..2, of taps 3..5,
- * and of (tap 6, 0, 0) without its identically-zero last plane). */
+/* The F(4,3) operand (conv args wino = 2): 6 planes for K == 3 -- (g0/4, -(g0+g1+g2)/6, -(g0-g1+g2)/6, g0/24+g1/12+g2/6,
+ * g0/24-g1/12+g2/6, g2) -- and 13 for K == 7: taps split 4 + 3, the F(4,4) transform of taps 0..3 (7 planes, points 0, +-1,
+ * +-2, inf, 1/2) followed by the F(4,3) transform of taps 4..6.  Stored as slabs of 16-byte vectors,
+ * wp[g][plane / 4][ci][co / 32][co % 32][4] plus a tail slab for the planes % 4 last planes (conv_mfma.hip); planes * G *
+ * Cog * Cig floats. */
 int nef_pack_weight_wino4(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                           nef_stream_t stream);
 
@@ -111,7 +115,7 @@ typedef struct nef_conv_args {
     int32_t wino;          /* 1: wp was packed by nef_pack_weight_wino -- K == 3 / K == 7 through Winograd F(2,3) (2/3 resp.
                               5/7 of the multiplies; still fp32 multiplies and adds on the matrix cores, results differ
                               from the direct form by the rounding of the transforms).  2: packed by
-                              nef_pack_weight_wino4 -- Winograd F(4,3): 1/2 resp. 17/28 of the multiplies.  Needs T even, T >= 128
+                              nef_pack_weight_wino4 -- Winograd F(4,3) resp. F(4,4) + F(4,3): 1/2 resp. 13/28 of the multiplies.  Needs T even, T >= 128
                               (Cout_g % 128 == 0) or T >= 256 (Cout_g % 64 == 0), Cin_g % 16 == 0; K == 7: pro_mode 0. */
     float* stats;          /* NULL, or (wino == 2 only) the epilogue also leaves, per output channel and per 128-column slot
                               of a sample, the sum and the sum of squares of the final outputs of that slot:
