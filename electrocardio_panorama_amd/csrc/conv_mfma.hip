@@ -1325,14 +1325,23 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
     const int Tin = UP ? (T >> 1) : T;
     constexpr int WCI = 4 / WCO;
     constexpr int MT = 32 * WCO;
+    // WINO = 4 / 5 (K = 7, round 3): the seven taps are split 4 + 3 ACROSS TWO LAUNCHES of this kernel -- WINO = 4 computes taps
+    // 0..3 through the transposed F(4,4) (7 products per column quad, 7 accumulator tiles per wave), WINO = 5 taps 4..6
+    // through the transposed F(3,4) (6 products, 6 tiles): 13 matrix multiplies per 8 columns where the 4 + 3 split inside
+    // one wave (WINO = 3: F(4,2) + F(3,2), 9 tiles) issues 18 and the direct form 28.  One wave cannot hold the 13 tiles.
+    // Built and measured slower: the split by WAVE PAIR inside a 64 co x 32 ci workgroup (1.77 vs 1.37 ms: half the matrix
+    // work between two barriers for the same staging) and by WORKGROUP TWINS inside one launch (two bodies behind a
+    // workgroup-uniform branch: 256 VGPRs + 280 bytes of scratch, whose reloads serialise behind the prefetched tile).
+    // gW = G^T [ (A^T gy) (.) (B^T d) ] with the F(4,4) matrices of conv_wino4_kernel.
     constexpr int CIT = 32 * TCI * WCI;
     constexpr int PAD = (K - 1) / 2;
     // LDS row pitches: odd for the transposed ds_read_b32 of the direct form; = 2 (mod 32) for the ds_read_b64 of WINO
     constexpr int GYS = WINO ? 66 : WT + 1;
     constexpr int XS = WINO ? (K == 3 ? 66 : 98) : ((WT + (WT / 16) * (K - 1)) | 1);
-    constexpr int NACC = WINO == 2 ? 6 : (WINO ? (K == 3 ? 4 : 9) : K);
+    constexpr int NACC = WINO == 4 ? 7 : (WINO == 2 || WINO == 5) ? 6 : (WINO ? (K == 3 ? 4 : 9) : K);
     static_assert(WINO != 2 || K == 3, "the F(3,4) form is for three taps");
     static_assert(WINO != 3 || K == 7, "WINO = 3 is the 4 + 3 split of seven taps");
+    static_assert((WINO != 4 && WINO != 5) || (K == 7 && TCI == 1 && PRO == 0), "WINO = 4 / 5 are the two halves of the K = 7 tap split");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* GYl = smem;               // [MT][GYS]
     float* Xl = smem + MT * GYS;     // [CIT][XS]
@@ -1380,7 +1389,9 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
     constexpr int XRW = CIT / 4;      // X rows per wave
     float greg[GR];
     float xreg[XRW][NS];
-    constexpr int NH = (CIT * ((WT / 16) * (K - 1)) + 255) / 256;   // halo positions (beyond 64) per thread, upper bound
+    // halo positions (beyond 64) per thread, upper bound: the Winograd forms only run on whole tiles of one sample (one
+    // segment, K - 1 halo positions per row); the direct form also packs up to four short samples into a tile
+    constexpr int NH = WINO ? (CIT * (K - 1) + 255) / 256 : (CIT * ((WT / 16) * (K - 1)) + 255) / 256;
     float xh[NH > 0 ? NH : 1][NS];
     // per-position state of the tile held in registers (needed again when the prologue is applied at the LDS store)
     bool xk_m = false, xk_h[NH > 0 ? NH : 1];
@@ -1447,15 +1458,98 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
             if (in_scale && ok) xh[h][0] *= in_scale[(int64_t)(b0 + sg) * sc_bs + (int64_t)g * sc_gs + c0 + row];   \
         }                                                                                                           \
     }
-    if (split < n_tiles) NEF_BW_ISSUE(split)
+    // The Winograd forms run on whole 64-column tiles of ONE sample (nseg == 1), which allows a much shorter issue phase --
+    // with only 48..56 matrix instructions per wave between two barriers (F(3,4) / F(4,4)) the ~200 instructions the generic
+    // macro spends per tile were 17..19 % of the kernel (timing-only builds, profiles/r03_bwd_weight_ablation.md):
+    //   * tile -> (sample, column) coordinates advance incrementally (no division per tile);
+    //   * the gY tile comes in as 16-byte vectors -- a lane fetches 4 consecutive columns of one row, an instruction
+    //     covers 4 rows: GR / 4 loads per wave instead of GR, and as many 16-byte LDS stores (two aligned 8-byte halves:
+    //     rows are 8-byte aligned because T is even).  The last tile of a sample, whose columns end inside a vector,
+    //     takes the dword path (reading past the row end would leave the tensor on its very last row);
+    //   * the K - 1 halo positions per X row are addressed with compile-time divisors.
+    constexpr bool FASTW = WINO != 0 && !UP;
+    bool g_vec = false;                  // layout of greg: [q][4] vectors (rows wave*GR + 4q + lane/16) or one row per entry
+    int nb0 = 0, ntq = 0, s_div = 0, s_mod = 0;
+    if constexpr (FASTW) {
+        nb0 = split / tps;
+        ntq = split - nb0 * tps;
+        s_div = S / tps;
+        s_mod = S - s_div * tps;
+    }
+    const unsigned gq_vo = (unsigned)(((lane >> 4) * T + 4 * (lane & 15)) * 4);
+#define NEF_BW_ISSUE_W()                                                                                              \
+    {                                                                                                               \
+        const int b0 = nb0, t0 = ntq * WT;                                                                          \
+        pass_ld = AFF ? b0 / pro_Bp : 0;                                                                            \
+        const __amdgpu_buffer_rsrc_t grs = nef_rsrc(gy + (int64_t)b0 * gy_bs + (int64_t)g * gy_gs + (int64_t)m0 * T); \
+        const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(x + (int64_t)b0 * x_bs + (int64_t)g * x_gs + (int64_t)c0 * Tin); \
+        g_vec = t0 + WT <= T;                                                                                       \
+        if (g_vec) {                                                                                                \
+            _Pragma("unroll") for (int q = 0; q < GR / 4; ++q) {                                                    \
+                const f32x4 v4_ = nef_buf_f32x4(grs, gq_vo, (unsigned)(((wave_u * GR + 4 * q) * T + t0) * 4));       \
+                greg[4 * q] = v4_[0];                                                                               \
+                greg[4 * q + 1] = v4_[1];                                                                           \
+                greg[4 * q + 2] = v4_[2];                                                                           \
+                greg[4 * q + 3] = v4_[3];                                                                           \
+            }                                                                                                       \
+        } else {                                                                                                    \
+            const unsigned vo = (t0 + lane < T) ? (unsigned)((t0 + lane) * 4) : NEF_OOB;                            \
+            _Pragma("unroll") for (int rr = 0; rr < GR; ++rr)                                                       \
+                greg[rr] = nef_buf_f32(grs, vo, (unsigned)((wave_u + 4 * rr) * T * 4));                             \
+        }                                                                                                           \
+        {                                                                                                           \
+            const int t = t0 + lane - PAD;                                                                          \
+            const bool ok = (t >= 0) && (t < T);                                                                    \
+            xk_m = ok;                                                                                              \
+            const unsigned vo0 = ok ? (unsigned)(t * 4) : NEF_OOB;                                                  \
+            _Pragma("unroll") for (int rr = 0; rr < XRW; ++rr)                                                      \
+                xreg[rr][0] = nef_buf_f32(xrs, vo0, (unsigned)((wave_u + 4 * rr) * Tin * 4));                       \
+            if (in_scale) {                                                                                         \
+                const int64_t so = ok ? (int64_t)b0 * sc_bs + (int64_t)g * sc_gs + c0 : 0;                          \
+                _Pragma("unroll") for (int rr = 0; rr < XRW; ++rr) xreg[rr][0] *= in_scale[so + (ok ? wave + 4 * rr : 0)]; \
+            }                                                                                                       \
+        }                                                                                                           \
+        _Pragma("unroll") for (int h = 0; h < NH; ++h) {                                                            \
+            const int idx = (int)threadIdx.x + 256 * h;                                                             \
+            const int row = idx / (K > 1 ? K - 1 : 1);                                                              \
+            const int t = t0 + 64 + (idx - row * (K - 1)) - PAD;                                                    \
+            const bool ok = (row < CIT) && (t < T);                                                                 \
+            xk_h[h] = ok;                                                                                           \
+            xh[h][0] = nef_buf_f32(xrs, ok ? (unsigned)((row * Tin + t) * 4) : NEF_OOB, 0);                         \
+            if (in_scale && ok) xh[h][0] *= in_scale[(int64_t)b0 * sc_bs + (int64_t)g * sc_gs + c0 + row];          \
+        }                                                                                                           \
+        nb0 += s_div;                                                                                               \
+        ntq += s_mod;                                                                                               \
+        if (ntq >= tps) {                                                                                           \
+            ntq -= tps;                                                                                             \
+            ++nb0;                                                                                                  \
+        }                                                                                                           \
+    }
+    if (split < n_tiles) {
+        if constexpr (FASTW) NEF_BW_ISSUE_W() else NEF_BW_ISSUE(split)
+    }
 #ifdef NEF_BW_SETPRIO
     __builtin_amdgcn_s_setprio(1);
 #endif
     for (int tile = split; tile < n_tiles; tile += S) {
         __syncthreads();
         if (!(NEF_ABL & 2) || tile == split) {
+        if (FASTW && g_vec) {
+            float* gp = GYl + (wave * GR + (lane >> 4)) * GYS + 4 * (lane & 15);
 #pragma unroll
-        for (int rr = 0; rr < GR; ++rr) GYl[(wave + 4 * rr) * GYS + lane] = greg[rr];
+            for (int q = 0; q < GR / 4; ++q) {
+                f32x2 lo2, hi2;
+                lo2[0] = greg[4 * q];
+                lo2[1] = greg[4 * q + 1];
+                hi2[0] = greg[4 * q + 2];
+                hi2[1] = greg[4 * q + 3];
+                *reinterpret_cast<f32x2*>(gp + 4 * q * GYS) = lo2;
+                *reinterpret_cast<f32x2*>(gp + 4 * q * GYS + 2) = hi2;
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < GR; ++rr) GYl[(wave + 4 * rr) * GYS + lane] = greg[rr];
+        }
         {
             const int prow0 = AFF ? pass_ld * G * Cig + g * Cig + c0 : 0;
 #pragma unroll
@@ -1480,7 +1574,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 const int idx = (int)threadIdx.x + 256 * h;
-                const int row = nh > 0 ? idx / nh : 0;
+                const int row = FASTW ? idx / (K > 1 ? K - 1 : 1) : (nh > 0 ? idx / nh : 0);
                 float v = xh[h][0];
                 if constexpr (PRO != 0) {
                     float pa = 1.f, pb = 0.f;
@@ -1503,8 +1597,104 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
         }
         }
         __syncthreads();
-        if constexpr (!(NEF_ABL & 1)) if (tile + S < n_tiles) NEF_BW_ISSUE(tile + S)
-        if constexpr (WINO == 2) {
+        if constexpr (!(NEF_ABL & 1)) if (tile + S < n_tiles) {
+            if constexpr (FASTW) NEF_BW_ISSUE_W() else NEF_BW_ISSUE(tile + S)
+        }
+        if constexpr (WINO == 4 || WINO == 5) {
+            constexpr int NSTEP = WT / 8;
+            const float* ga = GYl + (wco * 32 + lo) * GYS + 4 * hi;
+            const float* xb = Xl + ((wci * TCI) * 32 + lo) * XS + 4 * hi;          // position p of a staged row holds x[t0 + p - 3]
+            if constexpr (WINO == 4) {
+                // taps 0..3: quad j, gy[4j..4j+3] against d_m = x[4j-3+m], m = 0..6 (four aligned 8-byte words)
+                f32x2 fg[2][2], fx[2][4];
+#define NEF_BW7A_LOAD(S_, BUF)                                                                                       \
+    {                                                                                                               \
+        fg[BUF][0] = *reinterpret_cast<const f32x2*>(ga + 8 * (S_));                                                \
+        fg[BUF][1] = *reinterpret_cast<const f32x2*>(ga + 8 * (S_) + 2);                                            \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                            \
+            fx[BUF][q_] = *reinterpret_cast<const f32x2*>(xb + 8 * (S_) + 2 * q_);                                  \
+    }
+                NEF_BW7A_LOAD(0, 0)
+#pragma unroll
+                for (int s_ = 0; s_ < NSTEP; ++s_) {
+                    if ((NEF_ABL & 4) ? s_ == 0 : s_ + 1 < NSTEP) NEF_BW7A_LOAD(s_ + 1, (s_ + 1) & 1)
+                    const float g0 = fg[s_ & 1][0][0], g1 = fg[s_ & 1][0][1], g2 = fg[s_ & 1][1][0], g3 = fg[s_ & 1][1][1];
+                    const f32x2* d = fx[s_ & 1];
+                    const float d0 = d[0][0], d1 = d[0][1], d2 = d[1][0], d3 = d[1][1], d4 = d[2][0], d5 = d[2][1], d6 = d[3][0];
+                    float u[7], v[7];
+                    {
+                        const float e02 = g0 + g2, e13 = g1 + g3;
+                        const float f02 = fmaf(4.f, g2, g0), f13 = 2.f * fmaf(4.f, g3, g1);
+                        u[0] = g0;
+                        u[1] = e02 + e13;
+                        u[2] = e02 - e13;
+                        u[3] = f02 + f13;
+                        u[4] = f02 - f13;
+                        u[5] = fmaf(0.125f, g3, fmaf(0.25f, g2, fmaf(0.5f, g1, g0)));      // point 1/2
+                        u[6] = g3;                                                          // infinity
+                    }
+                    v[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+                    v[0] = fmaf(-2.f, d0, fmaf(2.5f, d2, fmaf(-0.5f, d4, v[5])));
+                    v[6] = fmaf(-2.f, d1, fmaf(2.5f, d3, fmaf(-0.5f, d5, fmaf(4.f, d2, fmaf(-5.f, d4, d6)))));
+                    {
+                        const float p = fmaf(2.f, d2, fmaf(-4.f, d3, fmaf(-0.5f, d4, d5)));
+                        const float q = fmaf(2.f, d1, fmaf(-4.f, d2, fmaf(-0.5f, d3, d4)));
+                        v[1] = p + q;
+                        v[2] = p - q;
+                        const float d24 = d2 - d4;
+                        const float p2 = fmaf(0.5f, d24, d5 - d3), q2 = fmaf(-2.f, d24, d1 - d3);
+                        v[3] = p2 + q2;
+                        v[4] = p2 - q2;
+                    }
+#pragma unroll
+                    for (int n = 0; n < 7; ++n)
+                        acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[n], v[n], acc[0][n], 0, 0, 0);
+                }
+#undef NEF_BW7A_LOAD
+            } else {
+                // taps 4..6: the transposed F(3,4) of the K = 3 gradients on the window x[4j+1 .. 4j+6] (three aligned words)
+                f32x2 fg[2][2], fx[2][3];
+#define NEF_BW7B_LOAD(S_, BUF)                                                                                       \
+    {                                                                                                               \
+        fg[BUF][0] = *reinterpret_cast<const f32x2*>(ga + 8 * (S_));                                                \
+        fg[BUF][1] = *reinterpret_cast<const f32x2*>(ga + 8 * (S_) + 2);                                            \
+        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_)                                                            \
+            fx[BUF][q_] = *reinterpret_cast<const f32x2*>(xb + 8 * (S_) + 4 + 2 * q_);                              \
+    }
+                NEF_BW7B_LOAD(0, 0)
+#pragma unroll
+                for (int s_ = 0; s_ < NSTEP; ++s_) {
+                    if ((NEF_ABL & 4) ? s_ == 0 : s_ + 1 < NSTEP) NEF_BW7B_LOAD(s_ + 1, (s_ + 1) & 1)
+                    const float g0 = fg[s_ & 1][0][0], g1 = fg[s_ & 1][0][1], g2 = fg[s_ & 1][1][0], g3 = fg[s_ & 1][1][1];
+                    float u[6];
+                    {
+                        const float e02 = g0 + g2, e13 = g1 + g3;
+                        const float f02 = fmaf(4.f, g2, g0), f13 = 2.f * fmaf(4.f, g3, g1);
+                        u[0] = g0;
+                        u[1] = e02 + e13;
+                        u[2] = e02 - e13;
+                        u[3] = f02 + f13;
+                        u[4] = f02 - f13;
+                        u[5] = g3;
+                    }
+                    const f32x2* d = fx[s_ & 1];
+                    const float d0 = d[0][0], d1 = d[0][1], d2 = d[1][0], d3 = d[1][1], d4 = d[2][0], d5 = d[2][1];
+                    float v[6];
+                    const float t1 = fmaf(-4.f, d2, d4), t2 = fmaf(-4.f, d1, d3);
+                    const float t3 = d4 - d2, t4 = 2.f * (d3 - d1);
+                    v[0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+                    v[1] = t1 + t2;
+                    v[2] = t1 - t2;
+                    v[3] = t3 + t4;
+                    v[4] = t3 - t4;
+                    v[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+#pragma unroll
+                    for (int n = 0; n < 6; ++n)
+                        acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[n], v[n], acc[0][n], 0, 0, 0);
+                }
+#undef NEF_BW7B_LOAD
+            }
+        } else if constexpr (WINO == 2) {
             // transposed F(3,4): 8 reduction steps per 64-column tile, each over two output QUADS (MFMA k = quad): a lane
             // reads its gY row's quad (two aligned 8-byte words) and its X row's six inputs x[4j-1 .. 4j+4] (three), one
             // step ahead of use; 6 MFMAs per 8 columns where F(3,2) issues 8 and the direct form 12
@@ -1673,6 +1863,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
         }
     }
 #undef NEF_BW_ISSUE
+#undef NEF_BW_ISSUE_W
 #undef NEF_BW_TAPS
     if constexpr ((NEF_ABL & 8) != 0) if (T >= 0) return;      // run-time true: the stores below are dead at run time only
     // partials: ws[split][g][k][co][ci]
@@ -1681,12 +1872,26 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
         const int ci = c0 + (wci * TCI + i) * 32 + lo;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
+            if constexpr (WINO == 4 || WINO == 5) if ((k < 4) != (WINO == 4)) continue;      // a launch owns its tap group only
             float* dst = ws + ((((int64_t)split * G + g) * K + k) * Cog) * Cig;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = m0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 float v;
-                if constexpr (WINO == 2) {      // gW = G^T M with the F(4,3) filter-transform matrix G
+                if constexpr (WINO == 4 || WINO == 5) {
+                    const float m1 = acc[i][1][r], m2 = acc[i][2][r], m3 = acc[i][3][r], m4 = acc[i][4][r], m5 = acc[i][5][r];
+                    if (k < 4) {        // gW = G^T M with the F(4,4) filter-transform matrix (points 0, 1, -1, 2, -2, 1/2, inf)
+                        v = (k == 0) ? fmaf(-0.5f, acc[i][0][r], fmaf(m5, 32.f / 45.f, fmaf(m3, 1.f / 36.f, fmaf(m4, -1.f / 60.f, (m2 * (1.f / 9.f) - m1 * (1.f / 3.f))))))
+                          : (k == 1) ? fmaf(m5, 16.f / 45.f, fmaf(m3, 1.f / 18.f, fmaf(m4, 1.f / 30.f, -(m2 * (1.f / 9.f) + m1 * (1.f / 3.f)))))
+                          : (k == 2) ? fmaf(m5, 8.f / 45.f, fmaf(m3, 1.f / 9.f, fmaf(m4, -1.f / 15.f, (m2 * (1.f / 9.f) - m1 * (1.f / 3.f)))))
+                                     : fmaf(m5, 4.f / 45.f, fmaf(m3, 2.f / 9.f, fmaf(m4, 2.f / 15.f, -(m2 * (1.f / 9.f) + m1 * (1.f / 3.f))))) + acc[i][NACC - 1][r];
+                    } else {            // taps 4..6: G^T of F(4,3) on tiles 0..5, as WINO = 2
+                        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                        v = (k == 4) ? fmaf(0.25f, acc[i][0][r], fmaf(s34, 1.f / 24.f, -s12 * (1.f / 6.f)))
+                          : (k == 5) ? fmaf(d34, 1.f / 12.f, -d12 * (1.f / 6.f))
+                                     : (s34 - s12) * (1.f / 6.f) + m5;
+                    }
+                } else if constexpr (WINO == 2) {      // gW = G^T M with the F(4,3) filter-transform matrix G
                     const float s12 = acc[i][1][r] + acc[i][2][r], d12 = acc[i][1][r] - acc[i][2][r];
                     const float s34 = acc[i][3][r] + acc[i][4][r], d34 = acc[i][3][r] - acc[i][4][r];
                     v = (k == 0) ? fmaf(0.25f, acc[i][0][r], fmaf(s34, 1.f / 24.f, -s12 * (1.f / 6.f)))
@@ -1764,7 +1969,8 @@ static bool plan_bwd_weight(int B, int T, int G, int Cig, int Cog, int K, BwdWei
     if (pro_mode != 0 && p->wco == 2) p->tci = 1;      // keep the doubled staging registers within budget
     if (wino && p->wco == 2) p->tci = 1;               // 4 accumulator tiles per ci tile: same budget
     if (wino == 2) p->tci = 1;                         // F(3,4): 6 accumulator tiles per ci tile
-    const int cit = 32 * p->tci * wci;
+    if (wino == 4 && K != 7) return false;             // K = 7 tap split across two launches (7 resp. 6 tiles per wave)
+    const int cit = 32 * p->tci * (4 / p->wco);
     if (Cig % cit != 0) return false;
     p->m_tiles = Cog / (32 * p->wco);
     p->ci_chunks = Cig / cit;
@@ -1784,7 +1990,7 @@ template <int K, int WCO, int TCI, int PRO = 0, int WINO = 0>
 static int launch_bwd_weight(BwdWeightPlan& p, const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale,
                              int64_t sc_bs, int64_t sc_gs, const float* gy, int64_t gy_bs, int64_t gy_gs, float* ws,
                              int B, int T, int G, int Cig, int Cog, hipStream_t st, const float* pro_a = nullptr,
-                             const float* pro_b = nullptr, int pro_Bp = 1) {
+                             const float* pro_b = nullptr, int pro_Bp = 1, int fixed_S = 0) {
     constexpr int WCI = 4 / WCO;
     constexpr int MT = 32 * WCO;
     constexpr int CIT = 32 * TCI * WCI;
@@ -1797,7 +2003,9 @@ static int launch_bwd_weight(BwdWeightPlan& p, const float* x, int64_t x_bs, int
     // ONE round of resident workgroups (occupancy x CUs) -- a partial second round leaves half the chip idle for a whole
     // workgroup lifetime (measured: 768 workgroups on 512 slots cost 5..8 % against 504..512).  Never more splits than the
     // workspace was sized for (p.S from plan_bwd_weight is that bound).
-    {
+    if (fixed_S > 0) {       // second half of a two-launch gradient: the split count of the first half, whatever fits
+        p.S = fixed_S;
+    } else {
         static int resident_dev[64] = {0};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -2177,7 +2385,10 @@ int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const 
     NEF_REQUIRE(pro_mode >= 0 && pro_mode <= 3 && (K == 3 || pro_mode == 0) && !(pro_mode && in_scale), NEF_E_UNSUPPORTED);
     NEF_REQUIRE(!(pro_mode & 1) || (pro_a && pro_b && pro_Bp > 0), NEF_E_NULL);
     BwdWeightPlan p;
-    NEF_REQUIRE(plan_bwd_weight(B, T, G, Cin_g, Cout_g, K, &p, pro_mode, K == 7 ? 1 : 2), NEF_E_SHAPE);
+#ifndef NEF_BW7_SPLIT
+#define NEF_BW7_SPLIT 1      // 0: the round-2 form (4 + 3 inside one wave, F(4,2) + F(3,2))
+#endif
+    NEF_REQUIRE(plan_bwd_weight(B, T, G, Cin_g, Cout_g, K, &p, pro_mode, K == 7 ? (NEF_BW7_SPLIT ? 4 : 1) : 2), NEF_E_SHAPE);
     NEF_REQUIRE(p.ct.nseg == 1, NEF_E_SHAPE);
     const size_t need = (size_t)p.S * G * K * Cout_g * Cin_g * sizeof(float);
     NEF_REQUIRE(ws_bytes >= need, NEF_E_WORKSPACE);
@@ -2194,7 +2405,21 @@ int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const 
         else if (pro_mode == 2) NEF_BW4(WCO, 2);                                                                      \
         else NEF_BW4(WCO, 3);                                                                                         \
     }
-    if (K == 7) {       // seven taps split 4 + 3: transposed F(4,2) + F(3,2), 9 instead of 10 MFMAs per 4 columns
+    if (K == 7 && NEF_BW7_SPLIT) {      // taps split 4 + 3 across two launches: transposed F(4,4), then transposed F(3,4)
+        if (p.wco == 4) {
+            rc = launch_bwd_weight<7, 4, 1, 0, 4>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G, Cin_g,
+                                                  Cout_g, st);
+            if (rc == NEF_OK)
+                rc = launch_bwd_weight<7, 4, 1, 0, 5>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G,
+                                                      Cin_g, Cout_g, st, nullptr, nullptr, 1, p.S);
+        } else {
+            rc = launch_bwd_weight<7, 2, 1, 0, 4>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G, Cin_g,
+                                                  Cout_g, st);
+            if (rc == NEF_OK)
+                rc = launch_bwd_weight<7, 2, 1, 0, 5>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G,
+                                                      Cin_g, Cout_g, st, nullptr, nullptr, 1, p.S);
+        }
+    } else if (K == 7) {       // seven taps split 4 + 3: transposed F(4,2) + F(3,2), 9 instead of 10 MFMAs per 4 columns
         if (p.wco == 4)
             rc = launch_bwd_weight<7, 4, 1, 0, 3>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G,
                                                   Cin_g, Cout_g, st);
