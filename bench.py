@@ -233,12 +233,14 @@ def main():
     dom = {("conv_fwd", 7, V, 128, 128, B, T_lat), ("conv_bwd_data", 7, V, 128, 128, B, T_lat)}
     timing = rank == 0 and not args.no_kernel_events and not args.graph
     ops.PROFILE, ops.PROFILE_ONLY = ([] if timing else None), (lambda tag: tag in dom)
+    parallel.TIMING = [] if (world > 1 and rank == 0) else None      # events around the exposed part of the gradient all-reduce
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE, ops.PROFILE_ONLY = ops.PROFILE or [], None, None
+    ar_events, parallel.TIMING = parallel.TIMING or [], None
     final_loss_t = loss
     prof_all, extra_steps = [], 2
     if not args.no_kernel_events and not args.graph:       # every rank takes the extra steps (they contain the all-reduce)
@@ -373,6 +375,10 @@ def main():
             "hbm_bound": hbm_bound, "hbm_bound_schedule": "single stream, every launch alone (untimed breakdown steps)",
             "secondary": sec,
             "hip_graph": bool(args.graph),
+            # N > 1: time the launching stream spends waiting for gradient collectives per step (the encoder bucket's
+            # all-reduce + whatever is left of the early bucket's, which runs under the encoder's backward pass)
+            "allreduce_ms_exposed": (round(sum(a.elapsed_time(b) for a, b in ar_events) / max(args.steps, 1), 4)
+                                     if ar_events else None),
         }
         if cpu:
             line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)

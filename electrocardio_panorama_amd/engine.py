@@ -573,7 +573,7 @@ def _head_bwd(P, sv, g_outs, grads, side, relu_z1=False):
     return gz1, gz2r
 
 
-def _latents_bwd(P, sv, gz1, gz2r, grads, side, z1_pre_gated=False):
+def _latents_bwd(P, sv, gz1, gz2r, grads, side, z1_pre_gated=False, early=False):
     """Back through `_latents` (+ the segment un-pooling that follows it): encoder-side parameter gradients."""
     B, V, T = sv["B"], sv["V"], sv["T"]
     ops.pack_many(_latent_pack_requests(P, V, T, sv["z2_win"], True))
@@ -600,6 +600,9 @@ def _latents_bwd(P, sv, gz1, gz2r, grads, side, z1_pre_gated=False):
     g, ge = ops.chscale_bwd(gew, sv["w"], sv["e"], relu_x=True)      # sv["w"]: ReLU output of the last encoder block
     gW1, gb1 = side.run(lambda: ops.theta_mlp_bwd(sv["in_theta"], ge, 128), ge)
     grads["mlp1.weight"], grads["mlp1.bias"] = gW1, gb1
+    if early:      # data parallel: everything but the encoder blocks' gradients is final -- start summing it across ranks now
+        from . import parallel
+        parallel.early_reduce(P, grads, getattr(side, "stream", None))
     for i in (2, 1, 0):
         g = block_bwd(sv["blk_enc"][i], g, P, grads, side=side, pre_gated=True, gate_input=(i > 0))
     grads["W_encoder.conv1.weight"] = ops.stem_bwd_weight(sv["x"], P["W_encoder.conv1.weight"], g)
@@ -610,7 +613,7 @@ def backward(P, sv, g_outs):
     grads = {}
     side = _side(sv["z1"].device, sv["z1"].numel())
     gz1, gz2r = _head_bwd(P, sv, g_outs, grads, side, relu_z1=True)
-    _latents_bwd(P, sv, gz1, gz2r, grads, side, z1_pre_gated=True)
+    _latents_bwd(P, sv, gz1, gz2r, grads, side, z1_pre_gated=True, early=True)
     side.join()
     return grads
 

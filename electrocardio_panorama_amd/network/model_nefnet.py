@@ -95,6 +95,8 @@ class Model_nefnet(nn.Module):
         self.decoder = nn.Sequential(nn.Identity(), _DoubleConv(256, 128), nn.Identity(), _DoubleConv(128, 64),
                                      nn.Conv1d(64, 1, 3, padding=1))
         self._extra_layers()
+        for n, p in self.named_parameters():
+            p._nef_name = n                # lets FusedSGD line its flat buffer up with the early gradient bucket (parallel.py)
         self.dropout_p = engine.DROP_P
         self.dropout_masks = None      # test hook: {site: uint8 keep-mask} replayed instead of the RNG
         self.keep_saved = False        # test hook: expose the saved forward state of the last train-phase call

@@ -8,7 +8,7 @@ import torch.distributed as dist
 from torch.optim import Adam
 from torch.optim.lr_scheduler import StepLR, MultiStepLR
 
-from .. import ops
+from .. import ops, parallel
 from ..parallel import reduce_flat_grads
 
 
@@ -40,6 +40,46 @@ class FusedSGD(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self._flat = {}
 
+    @staticmethod
+    def _reduce(live, flat, world):
+        """Sum of the flat gradient buffer across ranks (RCCL over xGMI).  When engine.backward already started the
+        all-reduce of the gradients that were final early (parallel.early_reduce: a SUFFIX of the parameter order --
+        everything behind the per-lead encoder), only the encoder bucket is reduced here and the early bucket's result
+        is copied in behind it; otherwise one all-reduce of the whole buffer."""
+        early = parallel.take_early() if world > 1 else None
+        names = [getattr(p, "_nef_name", None) for p in live]
+        split = None
+        if early is not None:
+            k = len(names) - len(early["names"])
+            if k >= 0 and names[k:] == early["names"] and [p.numel() for p in live[k:]] == early["sizes"]:
+                split = sum(p.numel() for p in live[:k])
+        if split is None:
+            if early is not None:
+                early["work"].wait()          # a bucket that does not line up with this optimiser's parameters: drop it
+            ev = None
+            if parallel.TIMING is not None and world > 1:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            reduce_flat_grads([p.grad for p in live], flat)             # one RCCL sum all-reduce over xGMI
+            if ev is not None:
+                ev[1].record()
+                parallel.TIMING.append(ev)
+            return
+        k = len(names) - len(early["names"])
+        if k:
+            torch.cat([p.grad.reshape(-1) for p in live[:k]], out=flat[:split])
+        ev = None
+        if parallel.TIMING is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        if k:
+            dist.all_reduce(flat[:split])
+        early["work"].wait()                  # the launching stream now waits for the early bucket's collective
+        if ev is not None:
+            ev[1].record()
+            parallel.TIMING.append(ev)
+        flat[split:].copy_(early["flat"])
+
     @torch.no_grad()
     def step(self, closure=None):
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -53,7 +93,7 @@ class FusedSGD(torch.optim.Optimizer):
                     p.data.data_ptr() >= fl["p"].data_ptr() + fl["p"].numel() * 4 for p in live):
                 self._build(gi, live)
                 fl = self._flat[gi]
-            reduce_flat_grads([p.grad for p in live], fl["g"])             # one RCCL sum all-reduce over xGMI
+            self._reduce(live, fl["g"], world)
             # buf starts at zero, so mu*buf + g reproduces torch's first-step "buf = g" exactly
             ops.sgd_momentum(fl["p"], fl["g"], fl["buf"], float(group["lr"]), float(group["momentum"]), 1.0 / world,
                              False)
@@ -69,6 +109,9 @@ class DataParallelAdam(Adam):
     def step(self, closure=None):
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         if world > 1:
+            early = parallel.take_early()          # this optimiser reduces everything itself: retire the early bucket
+            if early is not None:
+                early["work"].wait()
             live = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
             if live:
                 flat = torch.empty(sum(p.numel() for p in live), device=live[0].device, dtype=torch.float32)

@@ -73,14 +73,24 @@ def build_loaders(cfg, batch_size=32, phases=('train', 'test')):
             elif world > 1:
                 sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=cfg.seed, drop_last=True)
                 dl = DataLoader(ds, batch_size=batch_size // world, sampler=sampler, num_workers=16, drop_last=True,
-                                collate_fn=_collate, pin_memory=True)
+                                collate_fn=_collate_train, pin_memory=True, persistent_workers=True, prefetch_factor=4)
             else:
                 dl = DataLoader(ds, batch_size=batch_size, shuffle=True, num_workers=16, drop_last=True,
-                                collate_fn=_collate, pin_memory=True)
+                                collate_fn=_collate_train, pin_memory=True, persistent_workers=True, prefetch_factor=4)
         else:
             dl = DataLoader(ds, batch_size=batch_size, num_workers=8, drop_last=True, collate_fn=_collate, pin_memory=True)
         out.append(dl)
     return out
+
+
+# what Solver.run_one_epoch(phase='train') reads of a `meta` batch (solver.py:157-189); the per-item dict of the dataset keeps
+# the reference's full schema, but shipping the unused 12-lead float64 fields (`ori_data`, `rest_view`: 100 KB per item)
+# from the workers to the trainer halves the loader's throughput
+_TRAIN_FIELDS = ('data', 'rois', 'input_theta', 'target_view', 'target_theta', 'noise', 'rest_theta')
+
+
+def _collate_train(items):
+    return _collate([{k: it[k] for k in _TRAIN_FIELDS if k in it} for it in items])
 
 
 def _collate(items):

@@ -24,7 +24,7 @@ from test_model_gpu import make_cfg, oracle_replaying                        # n
 
 out_dir = sys.argv[1]
 rank, world, local = parallel.init_from_env()
-assert world == 2 and dist.is_initialized() and local == 0
+assert world == 2 and dist.is_initialized() and local == (0 if os.environ.get("NEF_SHARE_GPU") == "1" else rank)
 dev = torch.device("cuda", local)
 
 
@@ -62,6 +62,12 @@ bc = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in shard.items()}
 _, _, dec, shard_flat = oracle_replaying(model, outs, bc, V, seed, masks=shard_masks)
 oracle_grad = torch.cat([dec.oracle_params[n].grad.reshape(-1) for n in names]).numpy()
 model.last_saved = None
+# reference result: ONE all-reduce of the whole flat gradient (what FusedSGD did before the early bucket existed)
+single = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+dist.all_reduce(single)
+avg_grad_single = (single / world).cpu().numpy()
+pend = parallel._EARLY["pending"]
+early_params = 0 if pend is None else len(pend["names"])
 optim.step()
 avg_grad = (optim._flat[0]["g"] / world).cpu().numpy()          # the all-reduced sum / world, in `names` order
 optim.zero_grad()
@@ -70,7 +76,8 @@ parallel.broadcast_buffers(model)
 buf_after = buffers(model)
 np.savez(os.path.join(out_dir, f"step_rank{rank}.npz"), params=flat_params(model), avg_grad=avg_grad,
          names=np.array(names), losses=np.array([float(v) for v in losses]), idx=np.array(idx), oracle_grad=oracle_grad,
-         flips=np.array(dec.total_flips()), shard_flat=np.array(shard_flat),
+         flips=np.array(dec.total_flips()), shard_flat=np.array(shard_flat), avg_grad_single=avg_grad_single,
+         early_params=np.array(early_params),
          **{"before:" + k: v for k, v in buf_before.items()}, **{"after:" + k: v for k, v in buf_after.items()})
 del model, optim, outs, losses
 dist.barrier()

@@ -123,6 +123,38 @@ def test_world2_solver_epoch_sharded_loader_vs_oracle(dp_run):
     assert rel(a["params_1"].astype(np.float64) - old, np.concatenate([upd[n] for n in order])) < 2e-4
 
 
+def test_world2_rccl_on_two_devices(tmp_path):
+    """The same worker over backend 'nccl' (= RCCL) with one rank per device -- the production transport -- whenever the box
+    has two GPUs (the single-GPU test box skips): both ranks must end with bit-identical parameters, and the averaged
+    gradient must equal the gloo run's contract (mean of the two oracle shard gradients)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices (RCCL between two ranks)")
+    out = str(tmp_path)
+    env = _env(29685)
+    env.pop("NEF_DIST_BACKEND")
+    env.pop("NEF_SHARE_GPU")
+    script = os.path.join(ROOT, "tests", "dp2_worker.py")
+    procs = [subprocess.Popen([sys.executable, script, out], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(lg[-3000:] for lg in logs)
+    a, b = (np.load(os.path.join(out, f"step_rank{r}.npz")) for r in range(2))
+    assert np.array_equal(a["params"], b["params"]) and np.array_equal(a["avg_grad"], b["avg_grad"])
+    want = 0.5 * (a["oracle_grad"].astype(np.float64) + b["oracle_grad"].astype(np.float64))
+    assert rel(a["avg_grad"], want) < 1e-4, rel(a["avg_grad"], want)
+    sa, sb = (np.load(os.path.join(out, f"solver_rank{r}.npz")) for r in range(2))
+    assert np.array_equal(sa["params_3"], sb["params_3"])
+
+
+def test_early_bucket_is_used_and_matches_single_bucket(dp_run):
+    """FusedSGD with the early gradient bucket (everything behind the per-lead encoder is all-reduced while the encoder
+    blocks are still being back-propagated) must give bit-for-bit the buffer a single all-reduce gives: the sums are the
+    same pairs of numbers.  The worker records both."""
+    a, b = (np.load(os.path.join(dp_run, f"step_rank{r}.npz")) for r in range(2))
+    assert int(a["early_params"]) > 0 and int(a["early_params"]) == int(b["early_params"])
+    assert np.array_equal(a["avg_grad"], a["avg_grad_single"]) and np.array_equal(b["avg_grad"], b["avg_grad_single"])
+
+
 def test_bench_two_ranks_prints_one_json_line():
     """bench.py's torchrun branch (barrier, max-over-ranks timing, whole-job value) with world_size 2."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
@@ -138,3 +170,4 @@ def test_bench_two_ranks_prints_one_json_line():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 16
     assert line["value"] > 0 and abs(line["value"] - 16 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-3 * line["value"]
     assert line["cpu_baseline"] is None and np.isfinite(line["final_loss"])
+    assert line["allreduce_ms_exposed"] is not None and line["allreduce_ms_exposed"] >= 0

@@ -205,3 +205,69 @@ def test_panorama_dtype_is_validated():
     b = batch_t(2, 1, 512, 5, 3)
     with pytest.raises(ValueError):
         m(b["data"], b["input_theta"], b["target_theta"], b["rois"], rest_theta=b["rest_theta"], phase="test")
+
+
+def _oracle_rest(V, b, rows, seed):
+    """The CPU oracle's eval-mode sweep (reference model_nefnet.py:181-192) on the selected rows of a host batch."""
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    P, Bf = hw.hashed_params(V), hw.hashed_buffers()
+    sub = {k: v[rows] for k, v in b.items()}
+    with torch.no_grad():
+        random.seed(seed)
+        return orc.forward(P, Bf, sub["data"], sub["input_theta"], sub["target_theta"], sub["rois"],
+                           rest_theta=sub["rest_theta"], phase="test", training=False)[3]
+
+
+def test_config3_full_size_sweep_rows_vs_oracle():
+    """BASELINE configs[3] AT SIZE: batch 1024, 1 lead in -> 360 queried angles, len 512, fp16 decoder -- the whole
+    sweep runs (chunked by the default pair budget), rows 0 / 511 / 1023 x all 360 angles are held to the CPU oracle at the
+    half-precision gate, and the same rows of the fp32 product path to 1e-5 (eval mode is batch-independent: running
+    BatchNorm statistics)."""
+    from electrocardio_panorama_amd import synth
+    B, V, L, Q, seed = 1024, 1, 512, 360, 77
+    host = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.make_batch(B, V, L, seed=seed, Q=Q).items()
+            if k in ("data", "input_theta", "target_theta", "rois", "rest_theta")}
+    d = {k: v.to(DEV) for k, v in host.items()}
+    m = hashed_model(V).eval()
+    m.panorama_dtype = "fp16"
+    random.seed(seed)
+    rest = m(d["data"], d["input_theta"], d["target_theta"], d["rois"], rest_theta=d["rest_theta"], phase="test")[3]
+    assert rest.shape == (B, Q, L) and rest.dtype == torch.float32 and bool(torch.isfinite(rest).all())
+    rows = [0, 511, 1023]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = _oracle_rest(V, host, rows, seed)
+    for i, r in enumerate(rows):
+        assert rel(rest[r], ref[i]) < HALF_TOL, (r, rel(rest[r], ref[i]))
+    m.panorama_dtype = "fp32"            # the reference-arithmetic path on the same three rows
+    random.seed(seed)
+    sub = {k: v[rows] for k, v in d.items()}
+    r32 = m(sub["data"], sub["input_theta"], sub["target_theta"], sub["rois"], rest_theta=sub["rest_theta"], phase="test")[3]
+    assert rel(r32, ref) < 1e-5, rel(r32, ref)
+    # rows of one sweep do not depend on which other samples share the batch: a 3-row batch takes other tile shapes in
+    # the fp32 encoder (1e-7 apart), which flips a few fp16 roundings in the decoder -- nothing more
+    m.panorama_dtype = "fp16"
+    random.seed(seed)
+    r16 = m(sub["data"], sub["input_theta"], sub["target_theta"], sub["rois"], rest_theta=sub["rest_theta"], phase="test")[3]
+    assert rel(r16, rest[rows]) < 1e-4, rel(r16, rest[rows])
+
+
+def test_config4_gen_ecg_fp16_len5000_vs_fp32_and_oracle():
+    """BASELINE configs[4] shape (decoder-only synthesis, len 5000, 3 leads, 12 angles, fp16) at a batch the CPU oracle
+    finishes in seconds: gen_ecg through the fp16 decoder (multi-tile sequences, both x2 upsamplings, ROI un-pooling at
+    len 5000) against the fp32 product path and the oracle's sweep (reference model_nefnet.py:196-218)."""
+    B, V, L, Q, seed = 4, 3, 5000, 12, 78
+    host = batch_t(B, V, L, seed, Q, dev="cpu")
+    d = {k: v.to(DEV) for k, v in host.items()}
+    m = hashed_model(V).eval()
+    z1, z2 = m(d["data"], d["input_theta"], d["target_theta"], d["rois"], phase="gen")
+    m.panorama_dtype = "fp16"
+    g16 = m.gen_ecg(z1, z2, d["rest_theta"], d["rois"])
+    m.panorama_dtype = "fp32"
+    g32 = m.gen_ecg(z1, z2, d["rest_theta"], d["rois"])
+    assert g16.shape == (B, Q, L) and bool(torch.isfinite(g16).all())
+    ref = _oracle_rest(V, host, list(range(B)), seed)
+    assert rel(g32, ref) < 1e-5, rel(g32, ref)
+    assert rel(g16, g32) < HALF_TOL, rel(g16, g32)
+    assert rel(g16, ref) < HALF_TOL, rel(g16, ref)
+    assert rel(_logit3(g16), _logit3(g32)) < 2 * HALF_TOL
