@@ -185,11 +185,142 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
         }
 }
 
-__global__ void stem_bwd_weight_reduce(const float* __restrict__ part, float* __restrict__ gw, int n) {
+// ------------------------------------------------------------------------------------------------------------
+// Round 3: the same gradient on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, an fmaf chain over k).
+// The VALU kernel above spends 60 FMAs + ~40 routing instructions per (pooled output, channel) and is bound by vector
+// issue (~490 us at config 2: 400 vector instructions per 62-output unit and wave, 6 waves per SIMD) -- the kernel is
+// COMPUTE-bound, not HBM-bound: 14.8 GFLOP over 0.51 GB is 29 FLOP/B, above the 19.7 FLOP/B ridge of the fp32 pipes.
+// The matrix pipe runs beside the vector pipe, so both GEMMs of the gradient move there and the vector units keep only
+// the pool / ReLU routing:
+//   GEMM 1 (recompute, transposed so that no data has to move between the two GEMMs):
+//       C_i^T[tp][co] = sum_tap x[4tp - 9 + 2i + tap] * w[co][tap],   i = 0, 1, 2  (conv outputs j = 2tp - 1 + i)
+//       A = the x window (m = tp, k = tap), B = w^T (k = tap, n = co); 4 k-steps of 4 taps (tap 15 is a zero weight).
+//       A lane then holds C_i for ONE channel (n = lane % 16) and the four pooled outputs tp = 4 * (lane / 16) + r.
+//   routing (vector): arg-max over (c0, c1, c2) in scan order, ReLU gate, g_i[tp][co] = gy[tp][co] if i was selected.
+//   GEMM 2: gW^T[tap][co] += sum_tp x[4tp - 9 + 2i + tap] * g_i[tp][co]: A = x (m = tap, k = tp), B = g_i -- the reduction
+//       index of an MFMA may be enumerated in any order as long as A and B agree, and k-step r with tp = 4 * (lane / 16)
+//       + r is exactly register r of the routing result: B comes straight out of the accumulator layout of GEMM 1.
+// A workgroup owns one (sample, lead) row: the 5000 input samples sit in LDS (zero-filled halo), every A fragment is a
+// conflict-free ds_read_b32 shared by the wave's two 16-channel tiles; 24 matrix instructions per (16 outputs x 16
+// channels).  One partial [128][15] per row slot, reduced by stem_bwd_weight_reduce.
+constexpr int MB_SPLIT = 256;              // partial slots: rows b = slot, slot + 256, ...
+constexpr int MB_HALO = 16;                // LDS index of x[0]
+constexpr int MB_TAIL = 96;                // the last 16-output tile reads up to x[L + 66]
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void stem_bwd_weight_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ gy, float* __restrict__ part,
+                                                                   int B, int V, int L, int T) {
+    extern __shared__ float xs[];          // [MB_HALO + L + MB_TAIL]: xs[MB_HALO + p] = x[p], zeros outside [0, L)
+    const int v = blockIdx.x % V, slot = blockIdx.x / V;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n16 = lane & 15, kk = lane >> 4;
+    const int Lc = L / 2;
+    const int xlen = MB_HALO + L + MB_TAIL;
+    // B operand of GEMM 1: w^T[tap = 4s + kk][co], two 16-channel tiles per wave (channels 32 * wave + 16 * ct + n16)
+    float wb[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int tap = 4 * s + kk;
+            wb[ct][s] = tap < KW ? w[(v * CPL + 32 * wave + 16 * ct + n16) * KW + tap] : 0.f;
+        }
+    f32x4s acc[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) acc[ct] = f32x4s{0.f, 0.f, 0.f, 0.f};
+    for (int b = slot; b < B; b += MB_SPLIT) {
+        __syncthreads();                   // the previous row's readers are done
+        const float* xrow = x + ((int64_t)b * V + v) * L;
+        for (int i = threadIdx.x; i < xlen; i += 256) {
+            const int p = i - MB_HALO;
+            xs[i] = (p >= 0 && p < L) ? xrow[p] : 0.f;
+        }
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t grs = nef_rsrc(gy + ((int64_t)b * V * CPL + v * CPL + 32 * wave) * T);     // wave-uniform
+        // gradients of the lane's four pooled outputs of its two channels (16 bytes each; rows are 8-byte aligned), fetched one
+        // tile ahead; the ragged last tile of a row goes element by element
+#define NEF_STEM_GLOAD(TP0, DST)                                                                                       \
+    _Pragma("unroll") for (int ct_ = 0; ct_ < 2; ++ct_) {                                                           \
+        const int tpl_ = (TP0) + 4 * kk;                                                                            \
+        DST[ct_] = nef_buf_f32x4(grs, tpl_ + 3 < T ? (unsigned)((n16 * T + tpl_) * 4) : NEF_OOB, (unsigned)(16 * ct_ * T * 4)); \
+        if (tpl_ + 3 >= T && tpl_ < T) {                                                                            \
+            _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                        \
+                DST[ct_][r_] = nef_buf_f32(grs, tpl_ + r_ < T ? (unsigned)((n16 * T + tpl_ + r_) * 4) : NEF_OOB,    \
+                                           (unsigned)(16 * ct_ * T * 4));                                           \
+        }                                                                                                           \
+    }
+        f32x4s gnext[2];
+        NEF_STEM_GLOAD(0, gnext)
+        for (int tp0 = 0; tp0 < T; tp0 += 16) {
+            f32x4s gcur[2] = {gnext[0], gnext[1]};
+            if (tp0 + 16 < T) NEF_STEM_GLOAD(tp0 + 16, gnext)
+            // A fragments: GEMM 1 lane (m = tp = n16, k = kk) reads x[4(tp0 + n16) - 9 + o + kk], o = 2i + 4s in {0, 2, .., 16};
+            // GEMM 2 lane (m = tap = n16, k = kk) reads x[4(tp0 + 4kk + r) - 9 + o' + n16], o' = 2i in {0, 2, 4}
+            const float* p1 = xs + MB_HALO + 4 * (tp0 + n16) - 9 + kk;
+            const float* p2 = xs + MB_HALO + 4 * (tp0 + 4 * kk) - 9 + n16;
+            float a1[9], a2[9];
+#pragma unroll
+            for (int o = 0; o < 9; ++o) {
+                a1[o] = p1[2 * o];
+                a2[o] = p2[2 * o];
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int tpl = tp0 + 4 * kk;
+                const f32x4s g4 = gcur[ct];
+                f32x4s c[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    c[i] = f32x4s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i + 2 * s], wb[ct][s], c[i], 0, 0, 0);
+                }
+                f32x4s gsel[3];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int tp = tpl + r;
+                    const bool has_l = (2 * tp - 1) >= 0, has_r = (2 * tp + 1) < Lc;
+                    // arg-max over the pool window in scan order (first maximum wins), then the ReLU gate -- as the forward
+                    float best = has_l ? fmaxf(c[0][r], 0.f) : -INFINITY;
+                    float pre = c[0][r];
+                    int sel = 0;
+                    const float r1 = fmaxf(c[1][r], 0.f);
+                    if (r1 > best) { best = r1; sel = 1; pre = c[1][r]; }
+                    if (has_r) {
+                        const float r2 = fmaxf(c[2][r], 0.f);
+                        if (r2 > best) { best = r2; sel = 2; pre = c[2][r]; }
+                    }
+                    const float ge = (tp < T && pre > 0.f) ? g4[r] : 0.f;
+                    gsel[0][r] = sel == 0 ? ge : 0.f;
+                    gsel[1][r] = sel == 1 ? ge : 0.f;
+                    gsel[2][r] = sel == 2 ? ge : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[i + 2 * r], gsel[i][r], acc[ct], 0, 0, 0);
+            }
+        }
+    }
+#undef NEF_STEM_GLOAD
+    // acc[ct][r] = gW^T[tap = 4kk + r][co = n16]
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tap = 4 * kk + r;
+            if (tap < KW) part[((int64_t)slot * V * CPL + v * CPL + 32 * wave + 16 * ct + n16) * KW + tap] = acc[ct][r];
+        }
+}
+
+__global__ void stem_bwd_weight_reduce(const float* __restrict__ part, float* __restrict__ gw, int n, int nsplit) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
-    for (int sp = 0; sp < BW_SPLIT; ++sp) s += part[(int64_t)sp * n + i];
+    for (int sp = 0; sp < nsplit; ++sp) s += part[(int64_t)sp * n + i];       // fixed order: deterministic
     gw[i] = s;
 }
 
@@ -208,7 +339,7 @@ int nef_stem_fwd(const float* x, const float* w, float* y, int B, int V, int L, 
     return nef_launch_status();
 }
 
-size_t nef_stem_bwd_ws_bytes(int V) { return (size_t)BW_SPLIT * V * CPL * KW * sizeof(float); }
+size_t nef_stem_bwd_ws_bytes(int V) { return (size_t)(MB_SPLIT > BW_SPLIT ? MB_SPLIT : BW_SPLIT) * V * CPL * KW * sizeof(float); }
 
 int nef_stem_bwd_weight(const float* x, const float* w, const float* gy, float* gw, void* ws, size_t ws_bytes, int B,
                         int V, int L, nef_stream_t stream) {
@@ -217,12 +348,23 @@ int nef_stem_bwd_weight(const float* x, const float* w, const float* gy, float* 
     NEF_REQUIRE(B > 0 && V > 0 && L >= 4 && L % 4 == 0, NEF_E_SHAPE);
     NEF_REQUIRE(ws_bytes >= nef_stem_bwd_ws_bytes(V), NEF_E_WORKSPACE);
     const int T = L / 4;
-    const int tiles = (T + BW_TP - 1) / BW_TP;
     hipStream_t st = (hipStream_t)stream;
+    const int n = V * CPL * KW;
+#ifndef NEF_STEM_MFMA
+#define NEF_STEM_MFMA 1
+#endif
+    const size_t lds = (size_t)(MB_HALO + L + MB_TAIL) * sizeof(float);
+    if (NEF_STEM_MFMA && T % 2 == 0 && lds <= 64 * 1024) {       // a whole input row in LDS; gy rows 8-byte aligned
+        const int slots = B < MB_SPLIT ? B : MB_SPLIT;
+        hipLaunchKernelGGL(stem_bwd_weight_mfma_kernel, dim3((unsigned)(slots * V)), dim3(256), lds, st, x, w, gy, (float*)ws, B,
+                           V, L, T);
+        hipLaunchKernelGGL(stem_bwd_weight_reduce, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)ws, gw, n, slots);
+        return nef_launch_status();
+    }
+    const int tiles = (T + BW_TP - 1) / BW_TP;
     hipLaunchKernelGGL(stem_bwd_weight_kernel, dim3((unsigned)(BW_SPLIT * V * (CPL / BW_CPB))), dim3(256), 0, st, x, w,
                        gy, (float*)ws, B, V, L, T, tiles);
-    const int n = V * CPL * KW;
-    hipLaunchKernelGGL(stem_bwd_weight_reduce, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)ws, gw, n);
+    hipLaunchKernelGGL(stem_bwd_weight_reduce, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)ws, gw, n, BW_SPLIT);
     return nef_launch_status();
 }
 
