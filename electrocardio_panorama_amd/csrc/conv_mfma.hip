@@ -1035,26 +1035,44 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
                 for (int e = 0; e < 4; ++e) y[q][e] += bv;
             }
         }
+        // residual and gate operands: 16-byte fetches (one per row instead of two 8-byte ones) on every tile that lies
+        // inside the row; the ragged last tile of a row keeps the pair loads (safe coordinates for dead lanes).  Each
+        // operand is consumed right after its fetch, so only one of them occupies registers at a time.
+        const bool ragged = t0 + NTO > T;                    // workgroup-uniform
+#define NEF_EPI_FETCH4(PTR, BS, GS, DST)                                                                              \
+    if (!ragged) {                                                                                                  \
+        const __amdgpu_buffer_rsrc_t rs_ = nef_rsrc((PTR) + (int64_t)b0 * (BS) + (int64_t)g * (GS) + (int64_t)(m0 + wm * 32) * T); \
+        const unsigned vo_ = inb ? (unsigned)((4 * hi * T + t) * 4) : NEF_OOB;                                      \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                             \
+            const f32x4 t4 = nef_buf_f32x4(rs_, vo_, (unsigned)(NEF_ROW(q) * T * 4));                               \
+            DST[q][0] = t4[0]; DST[q][1] = t4[1]; DST[q][2] = t4[2]; DST[q][3] = t4[3];                             \
+        }                                                                                                           \
+    } else {                                                                                                        \
+        _Pragma("unroll") for (int pr = 0; pr < 2; ++pr) {                                                          \
+            const float* p_ = (PTR) + (int64_t)b0 * (BS) + (int64_t)g * (GS) + (int64_t)cobase * T + ts[pr];        \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                         \
+                const f32x2 t2 = *reinterpret_cast<const f32x2*>(p_ + (int64_t)NEF_ROW(q) * T);                     \
+                DST[q][2 * pr] = t2[0];                                                                             \
+                DST[q][2 * pr + 1] = t2[1];                                                                         \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
+        if (a.res) {
+            float rv[8][4];
+            NEF_EPI_FETCH4(a.res, a.res_bs, a.res_gs, rv)
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {        // the two output pairs (t, t+1), (t+2, t+3)
-            if (a.res) {
-                const float* rp = a.res + (int64_t)b0 * a.res_bs + (int64_t)g * a.res_gs + (int64_t)cobase * T + ts[pr];
-                f32x2 t8[8];
+            for (int q = 0; q < 8; ++q)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) t8[q] = *reinterpret_cast<const f32x2*>(rp + (int64_t)NEF_ROW(q) * T);
+                for (int e = 0; e < 4; ++e) y[q][e] += rv[q][e];
+        }
+        if (a.relu) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    y[q][2 * pr] += t8[q][0];
-                    y[q][2 * pr + 1] += t8[q][1];
-                }
-            }
-            if (a.relu) {
+            for (int q = 0; q < 8; ++q)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    y[q][2 * pr] = fmaxf(y[q][2 * pr], 0.f);
-                    y[q][2 * pr + 1] = fmaxf(y[q][2 * pr + 1], 0.f);
-                }
-            }
+                for (int e = 0; e < 4; ++e) y[q][e] = fmaxf(y[q][e], 0.f);
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {        // dropout works on the two output pairs (t, t+1), (t+2, t+3)
             if (a.mask) {
                 const uint8_t* mp = a.mask + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T + ts[pr];
                 unsigned short t8[8];
@@ -1077,18 +1095,21 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
                     y[q][2 * pr + 1] = (u1 >= a.drop_p) ? y[q][2 * pr + 1] * a.drop_scale : 0.f;
                 }
             }
-            if (a.gate) {
-                const float* gp = a.gate + (int64_t)b0 * a.gate_bs + (int64_t)g * a.gate_gs + (int64_t)cobase * T + ts[pr];
-                f32x2 t8[8];
+        }
+        if (a.gate) {
+            float gv[8][4];
+            NEF_EPI_FETCH4(a.gate, a.gate_bs, a.gate_gs, gv)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) t8[q] = *reinterpret_cast<const f32x2*>(gp + (int64_t)NEF_ROW(q) * T);
+            for (int q = 0; q < 8; ++q)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    y[q][2 * pr] = t8[q][0] > 0.f ? y[q][2 * pr] * a.gate_scale : 0.f;
-                    y[q][2 * pr + 1] = t8[q][1] > 0.f ? y[q][2 * pr + 1] * a.gate_scale : 0.f;
-                }
-            }
-            if (live[pr]) {
+                for (int e = 0; e < 4; ++e) y[q][e] = gv[q][e] > 0.f ? y[q][e] * a.gate_scale : 0.f;
+        }
+#undef NEF_EPI_FETCH4
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            // a quad that ends inside the row is stored below as ONE 16-byte vector; only the half-live quad at the end of
+            // a row with T % 4 == 2 goes out as a pair
+            if (live[pr] && !live[1]) {
                 float* yp = a.y + (int64_t)b0 * a.y_bs + (int64_t)g * a.y_gs + (int64_t)cobase * T + t + 2 * pr;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -1097,6 +1118,22 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
                     o[1] = y[q][2 * pr + 1];
                     *reinterpret_cast<f32x2*>(yp + (int64_t)NEF_ROW(q) * T) = o;
                 }
+            }
+        }
+        {   // output stores: the epilogue is the largest single cost of the K = 3 launches (timing-only builds: 14..29 %), and it
+            // is bound by store ISSUE, not bandwidth -- one buffer_store_dwordx4 per row (512 contiguous bytes per half-wave)
+            // instead of two 8-byte stores; lanes outside the row carry NEF_OOB and store nothing
+            const __amdgpu_buffer_rsrc_t yrs =
+                nef_rsrc(a.y + (int64_t)b0 * a.y_bs + (int64_t)g * a.y_gs + (int64_t)(m0 + wm * 32) * T);
+            const unsigned yvo = live[1] ? (unsigned)((4 * hi * T + t) * 4) : NEF_OOB;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                f32x4 o;
+                o[0] = y[q][0];
+                o[1] = y[q][1];
+                o[2] = y[q][2];
+                o[3] = y[q][3];
+                nef_buf_store_f32x4(o, yrs, yvo, (unsigned)(NEF_ROW(q) * T * 4));
             }
         }
 #undef NEF_ROW
@@ -1471,6 +1508,9 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
     //     rows are 8-byte aligned because T is even).  The last tile of a sample, whose columns end inside a vector,
     //     takes the dword path (reading past the row end would leave the tensor on its very last row);
     //   * the K - 1 halo positions per X row are addressed with compile-time divisors.
+#ifndef NEF_EXP_SAMETILE
+#define NEF_EXP_SAMETILE 0      // timing experiment: every iteration re-reads the workgroup's FIRST tile (L2-resident after one pass)
+#endif
     constexpr bool FASTW = WINO != 0 && !UP;
     bool g_vec = false;                  // layout of greg: [q][4] vectors (rows wave*GR + 4q + lane/16) or one row per entry
     int nb0 = 0, ntq = 0, s_div = 0, s_mod = 0;
@@ -1522,8 +1562,10 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
             xh[h][0] = nef_buf_f32(xrs, ok ? (unsigned)((row * Tin + t) * 4) : NEF_OOB, 0);                         \
             if (in_scale && ok) xh[h][0] *= in_scale[(int64_t)b0 * sc_bs + (int64_t)g * sc_gs + c0 + row];          \
         }                                                                                                           \
+        if constexpr (!NEF_EXP_SAMETILE) {                                                                          \
         nb0 += s_div;                                                                                               \
         ntq += s_mod;                                                                                               \
+        }                                                                                                           \
         if (ntq >= tps) {                                                                                           \
             ntq -= tps;                                                                                             \
             ++nb0;                                                                                                  \

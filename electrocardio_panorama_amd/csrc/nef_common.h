@@ -121,6 +121,9 @@ typedef float nef_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ nef_f32x2 nef_buf_f32x2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(nef_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
 }
+__device__ __forceinline__ void nef_buf_store_f32x4(nef_f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(nef_u32x4, v), r, (int)voff, (int)soff, 0);      // NEF_OOB lanes store nothing
+}
 __device__ __forceinline__ nef_f32x4 nef_buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(nef_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
