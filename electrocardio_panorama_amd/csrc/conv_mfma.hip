@@ -581,15 +581,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
             // the activation rows of the next stage are requested once per stage, right behind an A request: the first
             // A fragment that is YOUNGER than them is consumed later in the stage, by when they have long arrived
             // (vector-memory results return in order)
-#ifdef NEF_EXP_XSPLIT    // one activation row per k-step instead of all four behind the first A request
-            if (s_ < XR && more) {
-                const unsigned so = (unsigned)((c0 + KC + wave_u + 4 * s_) * Tin * 4);
-                _Pragma("unroll") for (int it = 0; it < NIT; ++it)
-                    _Pragma("unroll") for (int ns = 0; ns < NS; ++ns) xreg[s_][it][ns] = nef_buf_f32(xrs, xvo[it][ns], so);
-            }
-#else
             if constexpr (!(NEF_ABL & 2)) if (s_ == 0 && more) NEF_WX_ISSUE(c0 + KC)
-#endif
             if constexpr (!(NEF_ABL & 4)) if (s_ + 1 < SPK) NEF_WX_LOAD(s_ + 1, (s_ + 1) & 1)
             const f32x2* d = fx[s_ & 1];
 #define w_(I, TM) NEF_FA(s_ % NSET, I, TM)
@@ -1508,9 +1500,6 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
     //     rows are 8-byte aligned because T is even).  The last tile of a sample, whose columns end inside a vector,
     //     takes the dword path (reading past the row end would leave the tensor on its very last row);
     //   * the K - 1 halo positions per X row are addressed with compile-time divisors.
-#ifndef NEF_EXP_SAMETILE
-#define NEF_EXP_SAMETILE 0      // timing experiment: every iteration re-reads the workgroup's FIRST tile (L2-resident after one pass)
-#endif
     constexpr bool FASTW = WINO != 0 && !UP;
     bool g_vec = false;                  // layout of greg: [q][4] vectors (rows wave*GR + 4q + lane/16) or one row per entry
     int nb0 = 0, ntq = 0, s_div = 0, s_mod = 0;
@@ -1562,10 +1551,8 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(
             xh[h][0] = nef_buf_f32(xrs, ok ? (unsigned)((row * Tin + t) * 4) : NEF_OOB, 0);                         \
             if (in_scale && ok) xh[h][0] *= in_scale[(int64_t)b0 * sc_bs + (int64_t)g * sc_gs + c0 + row];          \
         }                                                                                                           \
-        if constexpr (!NEF_EXP_SAMETILE) {                                                                          \
         nb0 += s_div;                                                                                               \
         ntq += s_mod;                                                                                               \
-        }                                                                                                           \
         if (ntq >= tps) {                                                                                           \
             ntq -= tps;                                                                                             \
             ++nb0;                                                                                                  \
@@ -2282,9 +2269,6 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
         NEF_REQUIRE(!(a->pro_mode & 1) || (a->pro_a && a->pro_b && a->pro_Bp > 0), NEF_E_NULL);
         const bool wide = (a->Cout_g % 128 == 0);
         NEF_REQUIRE(a->T >= (wide ? 128 : 256), NEF_E_SHAPE);
-#ifdef NEF_EXP_WM1
-        if (K == 7) return launch_conv_wino<7, 1, 0>(*a, st);
-#endif
         if (K == 7) return wide ? launch_conv_wino<7, 2, 0>(*a, st) : launch_conv_wino<7, 1, 0>(*a, st);
         switch (a->pro_mode) {
             case 0: return wide ? launch_conv_wino<3, 2, 0>(*a, st) : launch_conv_wino<3, 1, 0>(*a, st);
