@@ -107,6 +107,10 @@ def early_reduce(P, grads, side_stream=None):
     names = [n for n in P if grads.get(n) is not None]
     if not names:
         return
+    if side_stream is not None:
+        # some of the bucket's gradients (BatchNorm affine, theta MLP inputs) come off the launching stream: order the side
+        # stream behind it before packing
+        side_stream.wait_stream(torch.cuda.current_stream(side_stream.device))
     ctx = torch.cuda.stream(side_stream) if side_stream is not None else _Null()
     with ctx:
         flat = torch.cat([grads[n].reshape(-1) for n in names])
