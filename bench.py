@@ -273,7 +273,7 @@ def main():
 
     if rank == 0:
         # Dominant kernel: the K=7 grouped conv over the encoder's [B,128V,T] activations, 18 launches per step: 6 forward
-        # (conv_wino_kernel<7,2,0>: Winograd F(2,3) on the taps split 3+3+1 -- the one `roofline` prices, from the launches of
+        # (conv_wino_kernel<7,2,0>: Winograd F(2,4)+F(2,3) on the taps split 4+3 -- the one `roofline` prices, from the launches of
         # the TIMED region), 6 backward-data (conv_wino4_kernel<7,4,0>: F(4,4) + F(4,3) on the taps split 4+3) and 6 weight gradients
         # (conv_bwd_weight_kernel<7,4,1,0,4> + <7,4,1,0,5>: taps split 4+3 over two launches, transposed F(4,4) + F(3,4)).
         # roofline.achieved / frac = EXECUTED matrix-core flops (what the MFMA pipes really did) over the kernel's time,
@@ -287,7 +287,7 @@ def main():
         flops = 2.0 * B * (128 * V) * T * 128 * 7
         # multiplies executed on the matrix cores per algorithmic multiply
         from electrocardio_panorama_amd import engine as _eng
-        ex_fwd = 10.0 / 14.0 if ops.WINOGRAD else 1.0
+        ex_fwd = 9.0 / 14.0 if ops.WINOGRAD else 1.0
         ex_bd = (13.0 / 28.0 if _eng._bwd_f4(7) else 10.0 / 14.0) if ops.WINOGRAD else 1.0
         ex_bw = (13.0 / 28.0 if ops.WINO_BW7 else 10.0 / 14.0) if ops.WINOGRAD else 1.0
         roof = None
@@ -317,7 +317,7 @@ def main():
                         "frac": round(flops * ex / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                    "kernel": ("conv_wino_kernel<7,2,0> (k7 grouped conv, Winograd F(2,3) on taps 3+3+1)" if ops.WINOGRAD
+                    "kernel": ("conv_wino_kernel<7,2,0> (k7 grouped conv, Winograd F(2,4)+F(2,3) on taps 4+3)" if ops.WINOGRAD
                                else "conv_fwd_kernel<7,2,0> (k7 grouped conv, direct)") + ", forward launches of the timed region",
                     "launches": len(times), "avg_ms": round(avg_ms, 4),
                     "executed_mfma_flops_per_launch": flops * ex_fwd,
@@ -327,7 +327,7 @@ def main():
                     "hbm_GBps": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1),
                     "avg_ms_bwd_data_launches_overlapped": round(sum(times_bd) / max(len(times_bd), 1), 4),
                     "k7_kernels_one_at_a_time": {
-                        "conv_wino_kernel<7,2,0> fwd F(2,3) 3+3+1": _serial("conv_fwd", ex_fwd),
+                        "conv_wino_kernel<7,2,0> fwd F(2,4)+F(2,3) on taps 4+3": _serial("conv_fwd", ex_fwd),
                         "conv_wino4_kernel<7,4,0> bwd-data F(4,4)+F(4,3) on taps 4+3": _serial("conv_bwd_data", ex_bd),
                         "conv_bwd_weight_kernel<7,4,1,0,4> + <7,4,1,0,5>: taps 4+3 as two launches, transposed F(4,4) + F(3,4) (+ the split-K reduce)": _serial("conv_bwd_weight", ex_bw)},
                     "side_stream": os.environ.get("NEF_SIDE_STREAM", "auto") != "0"}

@@ -60,7 +60,8 @@ int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, i
 
 /* Winograd F(2,3) operand (transpose_flip = 1: the backward-data operand, (ci, co) exchanged and the taps reversed).
  * K == 3: wp[g][plane][ci][co], 4 planes (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) of the taps w[g*Cog+co][ci][0..2].
- * K == 7 (taps split 3 + 3 + 1): 10 planes = that transform of taps 0..2, of taps 3..5, then tap 6 and -tap 6, laid out for
+ * K == 7 (taps split 4 + 3): 10 planes = the F(2,4) transform of taps 0..3 (g0/2, -(g0+g1+g2+g3)/2, (-g0+g1-g2+g3)/6,
+ * (g0+2g1+4g2+8g3)/6, g3), the F(2,3) transform of taps 4..6 with its last plane negated, one plane of padding, laid out for
  * 16-byte fragment loads: wp[g][q][ci][co / 64][co % 32][4] with value 2*plane + (co % 64) / 32 = 4*q + e (conv_mfma.hip).
  * The layout is private to nef_conv_fwd; the size is planes * G * Cog * Cig floats either way. */
 int nef_pack_weight_wino(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
@@ -112,8 +113,8 @@ typedef struct nef_conv_args {
     int32_t pro_Bp;
     const uint64_t* rng_seed_dev;  /* NULL, or a device word added to rng_seed at run time (hipGraph replay: a captured
                                       launch freezes its arguments, the per-step seed must live in device memory) */
-    int32_t wino;          /* 1: wp was packed by nef_pack_weight_wino -- K == 3 / K == 7 through Winograd F(2,3) (2/3 resp.
-                              5/7 of the multiplies; still fp32 multiplies and adds on the matrix cores, results differ
+    int32_t wino;          /* 1: wp was packed by nef_pack_weight_wino -- K == 3 through Winograd F(2,3), K == 7 through
+                              F(2,4) + F(2,3) (2/3 resp. 9/14 of the multiplies; still fp32 multiplies and adds on the matrix cores, results differ
                               from the direct form by the rounding of the transforms).  2: packed by
                               nef_pack_weight_wino4 -- Winograd F(4,3) resp. F(4,4) + F(4,3): 1/2 resp. 13/28 of the multiplies.  Needs T even, T >= 128
                               (Cout_g % 128 == 0) or T >= 256 (Cout_g % 64 == 0), Cin_g % 16 == 0; K == 7: pro_mode 0. */

@@ -239,9 +239,15 @@ def test_sgd_steps_golden(golden_dir):
     losses = sol.run_one_epoch(batches, "train", opt)[0]
     assert np.abs(np.array(losses) - z["losses"]).max() < 2e-5, (losses, z["losses"])
     sd = sol.model.state_dict()
+    worst = (0.0, None)
     for k in orc.param_shapes(V):
         tol = 1e-6 if k in orc.DEAD_PARAMS else 2e-4
-        assert rel(sub(sd[k], 128), z["psub:" + k]) < tol, (k, rel(sub(sd[k], 128), z["psub:" + k]))
+        e = rel(sub(sd[k], 128), z["psub:" + k])
+        assert e < tol, (k, e)
+        if k not in orc.DEAD_PARAMS and e > worst[0]:
+            worst = (e, k)
+    with open(os.path.join(os.environ.get("NEF_TEST_LOG_DIR", "/tmp"), "sgd_trajectory.txt"), "w") as fh:
+        fh.write(f"3-step SGD trajectory vs the reference Solver: worst parameter {worst[1]} rel-L2 {worst[0]:.2e} (bar 2e-4)\n")
     for k in orc.buffer_shapes():
         if "running" in k:
             assert rel(sd[k], z["buf:" + k]) < 1e-4, k
