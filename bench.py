@@ -373,6 +373,10 @@ def main():
                        "global_batch": world * B, "seq_len": L, "leads": V, "parallelism": f"dp{world}"},
             "roofline": roof, "cpu_baseline": cpu, "final_loss": final_loss, "conv_ms_per_step": breakdown,
             "hbm_bound": hbm_bound, "hbm_bound_schedule": "single stream, every launch alone (untimed breakdown steps)",
+            "hbm_bound_notes": {"stem_bwd_weight": "listed for its traffic only: 2 x 28.8 MFLOP over 1.98 MB per sample = 29 FLOP/B, "
+                                                   "above the 19.7 FLOP/B ridge -- fp32-compute-bound, runs its two GEMMs on the "
+                                                   "matrix cores (DESIGN 3.7)",
+                                "roi_unpool_bwd": "adjoint of a variable-length linear resampling: gather arithmetic, latency-bound"},
             "secondary": sec,
             "hip_graph": bool(args.graph),
             # N > 1: time the launching stream spends waiting for gradient collectives per step (the encoder bucket's
