@@ -76,7 +76,7 @@ def block_fwd(xv, P, prefix, K, Cog, drop):
 
 
 def _bwd_f4(K):
-    """Backward-data launches of the encoder-side blocks take F(4,3) (K=3; K=7 as 3+3+1): no ReLU decision is ever taken
+    """Backward-data launches of the encoder-side blocks take F(4,3) (K=3) resp. F(4,4) + F(4,3) (K=7): no ReLU decision is ever taken
     on a gradient, so the exact-zero / decision-flip argument that keeps their FORWARD convs on F(2,3) does not apply.
     Measured on the reference's 3-step SGD trajectory: worst parameter 1.4e-5 (bar 2e-4), stem weight 1.8e-6.
     NEF_BWD_F4=0: F(2,3) there too; =3: K=3 only."""

@@ -181,7 +181,8 @@ def stem_bwd_weight(x, w, gy):
 
 
 # ------------------------------------------------------------------ grouped conv
-# K = 3 and K = 7 convs through Winograd F(2,3) (conv_mfma.hip: conv_wino_kernel) wherever a whole output tile of one
+# K = 3 convs through Winograd F(2,3), K = 7 convs through F(2,4) + F(2,3) on the taps split 4 + 3 (conv_mfma.hip:
+# conv_wino_kernel; "F(2,3)" below stands for this F(2,.) family) wherever a whole output tile of one
 # sample exists; NEF_WINOGRAD=0 keeps every conv on the direct kernel.
 _WV = os.environ.get("NEF_WINOGRAD", "4")
 WINOGRAD = _WV != "0"
@@ -196,7 +197,8 @@ WINOGRAD = _WV != "0"
 WINO_FWD = 1 if _WV in ("1", "2") else 2
 # K=3 weight gradients through the transposed F(3,4) (6 MFMAs per 8 columns instead of F(3,2)'s 8); NEF_BW_WINO4=0: F(3,2)
 WINO_BW4 = os.environ.get("NEF_BW_WINO4", "1") == "1" and _WV not in ("1", "2")
-# K=7 weight gradients with the taps split 4 + 3 (transposed F(4,2) + F(3,2): 9 MFMAs per 4 columns instead of 3+3+1's 10)
+# K=7 weight gradients with the taps split 4 + 3 (two launches: transposed F(4,4) + F(3,4), 13 MFMAs per 8 columns; a build
+# with -DNEF_BW7_SPLIT=0 runs the round-2 form, transposed F(4,2) + F(3,2) in one launch); 0: 3 + 3 + 1 through F(3,2)
 WINO_BW7 = os.environ.get("NEF_BW7_F42", "1") == "1" and _WV not in ("1", "2")
 _WINO_PLANES = {(1, 3): 4, (1, 7): 10, (2, 3): 6, (2, 7): 13}
 
