@@ -2466,6 +2466,12 @@ int nef_conv_bwd_weight_wino(const float* x, int64_t x_bs, int64_t x_gs, const f
     return nef_launch_status();
 }
 
+// conv_bww_glds.hip: the same forms with the tiles streamed by LDS-DMA through a ring of LDS buffers
+__attribute__((visibility("hidden"))) bool nef_bww_glds_ok(int B, int T, int Cig, int Cog, int K, int pro_mode, int pro_Bp, bool in_scale);
+__attribute__((visibility("hidden"))) int nef_bww_glds_launch(const float* x, int64_t x_bs, int64_t x_gs, const float* gy, int64_t gy_bs, int64_t gy_gs, float* ws,
+                        int B, int T, int G, int Cig, int Cog, int K, int half, const float* pro_a, const float* pro_b,
+                        int pro_mode, int pro_Bp, int S_max, int fixed_S, int* S_used, hipStream_t st);
+
 int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
                               int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
                               const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B,
@@ -2496,7 +2502,20 @@ int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const 
         else if (pro_mode == 2) NEF_BW4(WCO, 2);                                                                      \
         else NEF_BW4(WCO, 3);                                                                                         \
     }
-    if (K == 7 && NEF_BW7_SPLIT) {      // taps split 4 + 3 across two launches: transposed F(4,4), then transposed F(3,4)
+    if (NEF_BW7_SPLIT && nef_bww_glds_ok(B, T, Cin_g, Cout_g, K, pro_mode, pro_Bp, in_scale != nullptr)) {
+        int S_used = 0;
+        if (K == 3) {
+            rc = nef_bww_glds_launch(x, x_bs, x_gs, gy, gy_bs, gy_gs, wsf, B, T, G, Cin_g, Cout_g, 3, 0, pro_a, pro_b, pro_mode,
+                                     pro_Bp, p.S, 0, &S_used, st);
+        } else {
+            rc = nef_bww_glds_launch(x, x_bs, x_gs, gy, gy_bs, gy_gs, wsf, B, T, G, Cin_g, Cout_g, 7, 4, nullptr, nullptr, 0, 1, p.S,
+                                     0, &S_used, st);
+            if (rc == NEF_OK)
+                rc = nef_bww_glds_launch(x, x_bs, x_gs, gy, gy_bs, gy_gs, wsf, B, T, G, Cin_g, Cout_g, 7, 5, nullptr, nullptr, 0, 1,
+                                         p.S, S_used, &S_used, st);
+        }
+        p.S = S_used;
+    } else if (K == 7 && NEF_BW7_SPLIT) {      // taps split 4 + 3 across two launches: transposed F(4,4), then transposed F(3,4)
         if (p.wco == 4) {
             rc = launch_bwd_weight<7, 4, 1, 0, 4>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G, Cin_g,
                                                   Cout_g, st);

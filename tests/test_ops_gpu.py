@@ -944,3 +944,48 @@ def test_conv_bwd_weight_winograd_views_scale_and_prologues(form):
             pro = (mode, g(a) if mode & 1 else None, g(b) if mode & 1 else None, Bp)
             gw = o.conv_bwd_weight(GV.dense(g(x), 1), GV.dense(g(gy2), 1), 3, pro=pro, wino=form)
             assert rel(gw, wr.grad) < GRAD_TOL, (mode, Cig, Cog, T_out)
+
+
+@pytest.mark.parametrize("K,T,B,G,C", [(3, 64, 1, 1, 64), (3, 66, 1, 1, 64), (3, 98, 2, 1, 64), (7, 64, 1, 1, 64), (7, 66, 1, 1, 64),
+                                       (7, 70, 2, 1, 64), (7, 130, 1, 2, 64), (3, 1250, 1, 1, 128), (7, 1250, 1, 1, 128)])
+def test_conv_bwd_weight_dma_edges(K, T, B, G, C):
+    """The LDS-DMA weight-gradient kernel (conv_bww_glds.hip) at the ends of a sample and of the whole operand: tiles whose
+    image reaches outside [0, T) are patched (zeros), chunks that reach outside the tensor are not fetched and their valid
+    elements come in lane by lane.  Tiny operands, so one lost or foreign element shows as >= 1e-3; both operands carry
+    large values in their first and last columns, and the row after / before each sample row is the neighbour whose
+    columns a missing patch would pick up."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    x, gy = rnd(B, G * C, T, seed=90), rnd(B, G * C, T, seed=91)
+    for t in (x, gy):
+        t[:, :, :4] *= 8.0
+        t[:, :, -4:] *= 8.0
+    w64 = torch.zeros(G * C, C, K, dtype=torch.float64, requires_grad=True)
+    F.conv1d(x.double(), w64, None, 1, K // 2, 1, G).backward(gy.double())
+    gw = o.conv_bwd_weight(GV.dense(g(x), G), GV.dense(g(gy), G), K, wino=4)
+    assert rel(gw, w64.grad) < 2e-5
+    # the same rows as the second half of a twice-as-tall tensor: the kernel's operand now ends exactly where the
+    # allocation's view does, and starts after foreign rows
+    x2 = torch.cat([rnd(B, G * C, T, seed=92) * 100.0, x], 0)
+    gy2 = torch.cat([rnd(B, G * C, T, seed=93) * 100.0, gy], 0)
+    gw2 = o.conv_bwd_weight(GV.dense(g(x2)[B:], G), GV.dense(g(gy2)[B:], G), K, wino=4)
+    assert torch.equal(gw2, gw)
+
+
+@pytest.mark.parametrize("K,T", [(3, 66), (7, 66), (3, 70), (7, 98)])
+def test_conv_bwd_weight_dma_stays_inside_the_operand(K, T):
+    """An out-of-bounds READ does not change results, so it is made fatal instead: both operands are exact multiples of
+    2 MiB, allocated after the cache was emptied -- each is a segment of its own whose last byte is the last byte the
+    driver mapped.  (This is how a fetch of x[T] on the operand's last row was found: 256 x 8 x 5000 happened to end on a
+    page boundary.)  T = 66 / 70 / 98: the tile BEFORE the last one already fetches a chunk that crosses T."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    B, G, C = 256, 16, 64
+    assert (B * G * C * T * 4) % (2 << 20) == 0
+    torch.cuda.empty_cache()
+    x = torch.randn(B, G * C, T, device=DEV)
+    gy = torch.randn(B, G * C, T, device=DEV)
+    gw = o.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, wino=4)
+    torch.cuda.synchronize()
+    want = o.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, wino=False)
+    assert rel(gw, want) < 1e-4
