@@ -169,7 +169,11 @@ int nef_conv_bwd_weight_wino(const float* x, int64_t x_bs, int64_t x_gs, const f
  * F(3,2)'s; transform entries up to 8 and 1/24 (the F(4,3) matrices of the forward kernels, roles exchanged): measured
  * rounding 1..6x the direct form's on the reduced sum.  K == 7 (pro_mode 0): the taps split 4 + 3 -- transposed F(4,2)
  * (points 0, 1, -1, 2, inf) + F(3,2): 9 instead of 10 multiplies per column pair.  Same arguments, workspace and
- * constraints. */
+ * constraints.  Round 3: the seven taps split 4 + 3 across two launches (transposed F(4,4) + F(3,4): 13 multiplies per 8
+ * columns), and wherever the channel counts are multiples of 64, T >= 64, in_scale == NULL and pro_mode has no upsampling
+ * bit, the (gy, x) tiles are streamed by LDS-DMA through a ring of LDS buffers (csrc/conv_bww_glds.hip; same arithmetic,
+ * same partial-sum layout, results differ from the register-staged kernel only by the summation order across splits).
+ * The kernel never reads outside [x, x + (B-1)*x_bs + (G-1)*x_gs + Cin_g*T) resp. the same extent of gy. */
 int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
                               int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
                               const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B, int T,
