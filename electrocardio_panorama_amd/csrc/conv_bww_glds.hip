@@ -54,15 +54,21 @@ __device__ __forceinline__ void wait_vm() {
 // WINO: 2 = K 3, transposed F(3,4); 4 / 5 = the two launches of K 7 (taps 0..3 through the transposed F(4,4), taps 4..6
 // through the transposed F(3,4)) -- the matrices of conv_bwd_weight_kernel.  AFF (K = 3): the BatchNorm affine + ReLU of
 // the producing layer is applied to the X fragments (nef_conv_bwd_weight_wino's pro_mode 1).
-template <int K, bool AFF, int WINO, int NBUF>
+// UP (K = 3, not with AFF): x is stored at half resolution [..][T/2] and upsampled x2 while the fragments are formed
+// (nn.Upsample(scale_factor=2, mode='linear', align_corners=False): pro_mode 2) -- the X image then holds the T/2-resolution
+// samples x[t0/2 - 1 .. t0/2 + 18), and a quad's six inputs are interpolated from four of them.
+template <int K, bool AFF, int WINO, int NBUF, bool UP = false>
 __global__ __launch_bounds__(256, NEF_GL_OCC) void conv_bww_glds_kernel(
     const float* __restrict__ x, int64_t x_bs, int64_t x_gs, const float* __restrict__ gy, int64_t gy_bs, int64_t gy_gs,
     float* __restrict__ ws, int B, int T, int G, int Cig, int Cog, int tps, int n_tiles, int m_tiles, int ci_chunks, int S,
     const float* __restrict__ pro_a, const float* __restrict__ pro_b, int pro_Bp, int n_pass, int64_t x_extent,
     int64_t gy_extent) {
     static_assert((WINO == 2 && K == 3) || ((WINO == 4 || WINO == 5) && K == 7 && !AFF), "forms");
-    constexpr int PAD = (K - 1) / 2;
-    constexpr int XUSE = (TW + K - 1 + 3) / 4;             // chunks of an X row that are fetched
+    static_assert(!UP || (K == 3 && !AFF), "the upsampling prologue: K = 3, no affine");
+    constexpr int PAD = (K - 1) / 2;       // UP: the image starts one half-resolution sample before t0 / 2, also PAD = 1
+    constexpr int XN = UP ? TW / 2 + 2 : TW + K - 1;       // positions of an X image row that are used
+    constexpr int XUSE = (XN + 3) / 4;                      // chunks of an X row that are fetched
+    const int Tin = UP ? (T >> 1) : T;                      // stored row length of x
     constexpr int XCH = XUSE | 1;                           // ... and its (odd) chunk pitch
     constexpr int GP = ROWS * GCH / 64, XP = ROWS * XCH / 64;      // DMA instructions ("pieces") per image
     constexpr int NP = GP + XP;
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256, NEF_GL_OCC) void conv_bww_glds_kernel(
         const int pitch = isx ? XCH : GCH;
         const int row = id / pitch, c = id - row * pitch;
         const bool dead = p >= NP || c >= (isx ? XUSE : TW / 4);
-        vo[i] = dead ? NEF_OOB : (unsigned)((row * T + 4 * c) * 4);
+        vo[i] = dead ? NEF_OOB : (unsigned)((row * (isx ? Tin : T) + 4 * c) * 4);
     }
 
     f32x16 acc[NACC];
@@ -139,11 +145,11 @@ __global__ __launch_bounds__(256, NEF_GL_OCC) void conv_bww_glds_kernel(
     int cb0 = ib0, ctq = itq;                             // compute side
 #define NEF_GL_ISSUE(BUFI)                                                                                            \
     {                                                                                                               \
-        const int t0_ = itq * TW;                                                                                   \
-        const int64_t xoff_ = (int64_t)ib0 * x_bs + (int64_t)g * x_gs + (int64_t)c0 * T - PAD;                      \
+        const int t0_ = itq * TW, xt0_ = UP ? (t0_ >> 1) : t0_;                                                     \
+        const int64_t xoff_ = (int64_t)ib0 * x_bs + (int64_t)g * x_gs + (int64_t)c0 * Tin - PAD;                    \
         const int64_t goff_ = (int64_t)ib0 * gy_bs + (int64_t)g * gy_gs + (int64_t)m0 * T;                          \
         const __amdgpu_buffer_rsrc_t xr_ = nef_rsrc(x + xoff_), gr_ = nef_rsrc(gy + goff_);                         \
-        const bool edge_ = (itq == 0) || (t0_ - PAD + 4 * XUSE > T);    /* the FETCHED image reaches outside [0, T) */ \
+        const bool edge_ = (itq == 0) || (xt0_ - PAD + 4 * XUSE > Tin) || (t0_ + TW > T);    /* a FETCHED image reaches outside its row */ \
         float* dst_ = smem + (BUFI) * BUF;                                                                          \
         _Pragma("unroll") for (int i = 0; i < NPW; ++i) {                                                           \
             const int p = wave_u + 4 * i;                                                                           \
@@ -151,11 +157,11 @@ __global__ __launch_bounds__(256, NEF_GL_OCC) void conv_bww_glds_kernel(
                 unsigned v_ = vo[i];                                                                                \
                 const bool isx = p >= GP;                                                                           \
                 if (edge_ && v_ != NEF_OOB) {      /* a chunk that is not entirely inside the operand is not fetched */ \
-                    const int64_t e0 = (isx ? xoff_ : goff_) + (int64_t)(v_ >> 2) + t0_;                            \
+                    const int64_t e0 = (isx ? xoff_ + xt0_ : goff_ + t0_) + (int64_t)(v_ >> 2);                     \
                     if (e0 < 0 || e0 + 3 >= (isx ? x_extent : gy_extent)) v_ = NEF_OOB;                             \
                 }                                                                                                   \
                 auto* l_ = (__attribute__((address_space(3))) void*)(dst_ + p * 256);                               \
-                if (isx) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_, l_, 16, (int)v_, t0_ * 4, 0, 0);             \
+                if (isx) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_, l_, 16, (int)v_, xt0_ * 4, 0, 0);            \
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(gr_, l_, 16, (int)v_, t0_ * 4, 0, 0);                 \
             }                                                                                                       \
         }                                                                                                           \
@@ -191,16 +197,18 @@ __global__ __launch_bounds__(256, NEF_GL_OCC) void conv_bww_glds_kernel(
         }
         float* gimg = smem + buf * BUF;
         float* ximg = gimg + GIMG;
-        const int t0 = ctq * TW;
-        if (ctq == 0 || t0 - PAD + 4 * XUSE > T) {      // same predicate as the issue side: the last tile, and the one before
-                                                         // it when its halo (or the tail of its last chunk) crosses T
+        const int t0 = ctq * TW, xt0 = UP ? (t0 >> 1) : t0;
+        const bool edge_c = ctq == 0 || xt0 - PAD + 4 * XUSE > Tin || t0 + TW > T;      // same predicate as the issue side: the last
+                                                         // tile, and the one before it when its halo (or the tail of its last chunk) crosses T
+        if (edge_c) {
             // patch pass: columns outside [0, T) came from the neighbouring rows (or were not fetched): zero them -- a NaN
             // where the affine + ReLU prologue follows (max(NaN, 0) = 0: zero padding comes AFTER the prologue)
             const int row = (int)threadIdx.x >> 2, sub = (int)threadIdx.x & 3;
-            for (int p = sub; p < TW + K - 1; p += 4) {
-                const int t = t0 - PAD + p;
-                if (t < 0 || t >= T) ximg[row * (XCH * 4) + p] = AFF ? __builtin_nanf("") : 0.f;
-            }
+            if constexpr (!UP)      // (UP: the fragment code clamps and masks by index instead)
+                for (int p = sub; p < XN; p += 4) {
+                    const int t = t0 - PAD + p;
+                    if (t < 0 || t >= T) ximg[row * (XCH * 4) + p] = AFF ? __builtin_nanf("") : 0.f;
+                }
             for (int p = sub; p < TW; p += 4)
                 if (t0 + p >= T) gimg[row * (GCH * 4) + p] = 0.f;
             // ... and the valid elements of the (at most three) chunks the issue side did not fetch because they reach outside
@@ -215,9 +223,9 @@ __global__ __launch_bounds__(256, NEF_GL_OCC) void conv_bww_glds_kernel(
                     any = true;
                 }
                 if (ctq != 0 && cb0 == B - 1 && g == G - 1) {
-                    const int nx = T - t0 + PAD, ng = T - t0;          // valid leading positions of an image row
+                    const int nx = Tin - xt0 + PAD, ng = T - t0;          // valid leading positions of an image row
                     if (c0 + ROWS == Cig && nx < 4 * XUSE && (nx & 3)) {
-                        const float* src = x + (int64_t)cb0 * x_bs + (int64_t)g * x_gs + (int64_t)(Cig - 1) * T + t0 - PAD + (nx & ~3);
+                        const float* src = x + (int64_t)cb0 * x_bs + (int64_t)g * x_gs + (int64_t)(Cig - 1) * Tin + xt0 - PAD + (nx & ~3);
                         if (lane < (nx & 3))
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                                 nef_rsrc(src), (__attribute__((address_space(3))) void*)(ximg + (ROWS - 1) * (XCH * 4) + (nx & ~3)), 4,
@@ -299,11 +307,19 @@ __global__ __launch_bounds__(256, NEF_GL_OCC) void conv_bww_glds_kernel(
             constexpr int XO = WINO == 5 ? 4 : 0;
             f32x4 fg[2], fa[2];
             f32x2 fb[2];
+            const float* xh = ximg + (wci * 32 + lo) * (XCH * 4) + 2 * hi;      // UP: quad j = 2s + hi reads image positions 2j .. 2j+3
 #define NEF_GL_LOAD(S_, BI)                                                                                          \
     {                                                                                                               \
         fg[BI] = *reinterpret_cast<const f32x4*>(ga + 8 * (S_));                                                    \
-        fa[BI] = *reinterpret_cast<const f32x4*>(xb + 8 * (S_) + XO);                                               \
-        fb[BI] = *reinterpret_cast<const f32x2*>(xb + 8 * (S_) + XO + 4);                                           \
+        if constexpr (UP) {                                                                                         \
+            const f32x2 h01_ = *reinterpret_cast<const f32x2*>(xh + 4 * (S_));                                      \
+            fb[BI] = *reinterpret_cast<const f32x2*>(xh + 4 * (S_) + 2);                                            \
+            fa[BI][0] = h01_[0];                                                                                    \
+            fa[BI][1] = h01_[1];                                                                                    \
+        } else {                                                                                                    \
+            fa[BI] = *reinterpret_cast<const f32x4*>(xb + 8 * (S_) + XO);                                           \
+            fb[BI] = *reinterpret_cast<const f32x2*>(xb + 8 * (S_) + XO + 4);                                       \
+        }                                                                                                           \
     }
             if (NSTEP) NEF_GL_LOAD(0, 0)
 #pragma unroll
@@ -312,6 +328,36 @@ __global__ __launch_bounds__(256, NEF_GL_OCC) void conv_bww_glds_kernel(
                 const float g0 = fg[s_ & 1][0], g1 = fg[s_ & 1][1], g2 = fg[s_ & 1][2], g3 = fg[s_ & 1][3];
                 float d0 = fa[s_ & 1][0], d1 = fa[s_ & 1][1], d2 = fa[s_ & 1][2], d3 = fa[s_ & 1][3];
                 float d4 = fb[s_ & 1][0], d5 = fb[s_ & 1][1];
+                if constexpr (UP) {
+                    // h0..h3 = x[m0 .. m0+3], m0 = tb/2 - 1 for the quad's first column tb; column t = tb - 1 + m is
+                    // 0.75 * x[(t-1)/2] + 0.25 * x[(t+1)/2] for odd t, 0.25 * x[t/2 - 1] + 0.75 * x[t/2] for even t, indices clamped
+                    // to [0, T/2) -- (1 - lambda) * x[i0] + lambda * x[i1] of conv_bwd_weight_kernel, same rounding
+                    float h0 = d0, h1 = d1, h2 = d4, h3 = d5;
+                    const int tb = t0 + 4 * (2 * s_ + hi);
+                    if (edge_c) {
+                        const int m0 = (tb >> 1) - 1;
+                        if (m0 < 0) h0 = h1;
+                        if (m0 + 1 > Tin - 1) h1 = h0;
+                        if (m0 + 2 > Tin - 1) h2 = h1;
+                        if (m0 + 3 > Tin - 1) h3 = h2;
+                    }
+                    d0 = 0.75f * h0 + 0.25f * h1;
+                    d1 = 0.25f * h0 + 0.75f * h1;
+                    d2 = 0.75f * h1 + 0.25f * h2;
+                    d3 = 0.25f * h1 + 0.75f * h2;
+                    d4 = 0.75f * h2 + 0.25f * h3;
+                    d5 = 0.25f * h2 + 0.75f * h3;
+                    if (edge_c) {      // the two clamped columns are the sample itself (lambda = 0), columns outside [0, T) are the conv's zero padding
+                        const float w75[6] = {h0, h1, h1, h2, h2, h3};
+                        float* dm[6] = {&d0, &d1, &d2, &d3, &d4, &d5};
+#pragma unroll
+                        for (int m = 0; m < 6; ++m) {
+                            const int t = tb - 1 + m;
+                            if (t == 0 || t == T - 1) *dm[m] = w75[m];
+                            if (t < 0 || t >= T) *dm[m] = 0.f;
+                        }
+                    }
+                }
                 if constexpr (AFF) {
                     d0 = fmaxf(fmaf(d0, pa, pb), 0.f);
                     d1 = fmaxf(fmaf(d1, pa, pb), 0.f);
@@ -380,14 +426,14 @@ __global__ __launch_bounds__(256, NEF_GL_OCC) void conv_bww_glds_kernel(
     }
 }
 
-template <int K, bool AFF, int WINO, int NBUF>
+template <int K, bool AFF, int WINO, int NBUF, bool UP = false>
 int launch(const float* x, int64_t x_bs, int64_t x_gs, const float* gy, int64_t gy_bs, int64_t gy_gs, float* ws, int B, int T,
            int G, int Cig, int Cog, const float* pro_a, const float* pro_b, int pro_Bp, int n_pass, int S_max, int fixed_S,
            int* S_used, hipStream_t st) {
-    constexpr int XCH = ((TW + K - 1 + 3) / 4) | 1;
+    constexpr int XCH = (((UP ? TW / 2 + 2 : TW + K - 1) + 3) / 4) | 1;
     constexpr size_t lds_tiles = (size_t)NBUF * (ROWS * GCH + ROWS * XCH) * 16;
     const size_t lds = lds_tiles + (AFF ? (size_t)n_pass * 128 * sizeof(float) : 0);
-    const void* fn = reinterpret_cast<const void*>(&conv_bww_glds_kernel<K, AFF, WINO, NBUF>);
+    const void* fn = reinterpret_cast<const void*>(&conv_bww_glds_kernel<K, AFF, WINO, NBUF, UP>);
     static unsigned long long lds_set = 0;
     if (int e = nef_ensure_dyn_lds(fn, lds_tiles + 8 * 128 * sizeof(float), &lds_set)) return e;
     const int m_tiles = Cog / ROWS, ci_chunks = Cig / ROWS;
@@ -411,10 +457,10 @@ int launch(const float* x, int64_t x_bs, int64_t x_gs, const float* gy, int64_t 
         if (S < 1) S = 1;
     }
     *S_used = S;
-    const int64_t x_extent = (int64_t)(B - 1) * x_bs + (int64_t)(G - 1) * x_gs + (int64_t)Cig * T;
+    const int64_t x_extent = (int64_t)(B - 1) * x_bs + (int64_t)(G - 1) * x_gs + (int64_t)Cig * (UP ? T / 2 : T);
     const int64_t gy_extent = (int64_t)(B - 1) * gy_bs + (int64_t)(G - 1) * gy_gs + (int64_t)Cog * T;
     const int64_t blocks = (int64_t)S * G * m_tiles * ci_chunks;
-    hipLaunchKernelGGL((conv_bww_glds_kernel<K, AFF, WINO, NBUF>), dim3((unsigned)blocks), dim3(256), lds, st, x, x_bs, x_gs, gy,
+    hipLaunchKernelGGL((conv_bww_glds_kernel<K, AFF, WINO, NBUF, UP>), dim3((unsigned)blocks), dim3(256), lds, st, x, x_bs, x_gs, gy,
                        gy_bs, gy_gs, ws, B, T, G, Cig, Cog, tps, n_tiles, m_tiles, ci_chunks, S, pro_a, pro_b, pro_Bp, n_pass,
                        x_extent, gy_extent);
     return nef_launch_status();
@@ -430,14 +476,16 @@ int launch(const float* x, int64_t x_bs, int64_t x_gs, const float* gy, int64_t 
 #endif
 
 // Shapes the LDS-DMA kernel takes (everything else stays on conv_bwd_weight_kernel): whole 64-channel slabs, at least two
-// tiles per sample, no in_scale, no upsampling prologue; at most 8 BatchNorm passes in the prologue table.
+// tiles per sample, no in_scale, the affine and the upsampling prologue one at a time (T % 4 == 0 for the latter); at most 8
+// BatchNorm passes in the prologue table.
 extern "C" __attribute__((visibility("hidden"))) bool nef_bww_glds_ok(int B, int T, int Cig, int Cog, int K, int pro_mode, int pro_Bp,
                                                                       bool in_scale) {
     static const int on = [] {
         const char* e = getenv("NEF_BWW_GLDS");
         return (e && e[0] == '0') ? 0 : 1;
     }();
-    if (!on || in_scale || (K != 3 && K != 7) || (K == 7 && pro_mode != 0) || (pro_mode & 2)) return false;
+    if (!on || in_scale || (K != 3 && K != 7) || (K == 7 && pro_mode != 0) || pro_mode == 3) return false;
+    if ((pro_mode & 2) && T % 4 != 0) return false;
     if (Cig % ROWS != 0 || Cog % ROWS != 0 || T < 2 * TW || T % 2 != 0) return false;
     if ((int64_t)(ROWS - 1) * T * 4 + 4 * 11 * 4 >= 0x7FFFFFFCll) return false;      // per-lane offsets are 32-bit
     if ((pro_mode & 1) && (pro_Bp <= 0 || (B + pro_Bp - 1) / pro_Bp > 8)) return false;
@@ -452,6 +500,9 @@ extern "C" __attribute__((visibility("hidden"))) int nef_bww_glds_launch(
     int* S_used, hipStream_t st) {
     const int n_pass = (pro_mode & 1) ? (B + pro_Bp - 1) / pro_Bp : 0;
     if (K == 3) {
+        if (pro_mode & 2)
+            return launch<3, false, 2, NEF_GLDS_NBUF, true>(x, x_bs, x_gs, gy, gy_bs, gy_gs, ws, B, T, G, Cig, Cog, nullptr, nullptr, 1,
+                                                            0, S_max, fixed_S, S_used, st);
         if (pro_mode & 1)
             return launch<3, true, 2, NEF_GLDS_NBUF>(x, x_bs, x_gs, gy, gy_bs, gy_gs, ws, B, T, G, Cig, Cog, pro_a, pro_b, pro_Bp,
                                                      n_pass, S_max, fixed_S, S_used, st);

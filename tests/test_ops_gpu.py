@@ -989,3 +989,42 @@ def test_conv_bwd_weight_dma_stays_inside_the_operand(K, T):
     torch.cuda.synchronize()
     want = o.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, wino=False)
     assert rel(gw, want) < 1e-4
+
+
+@pytest.mark.parametrize("T,B,Cig,Cog", [(64, 1, 64, 64), (68, 2, 64, 64), (100, 1, 64, 128), (132, 2, 128, 64), (2500, 1, 256, 128)])
+def test_conv_bwd_weight_dma_upsampling_prologue(T, B, Cig, Cog):
+    """The x2-upsampling prologue inside the LDS-DMA weight gradient: the half-resolution samples are staged and a quad's six
+    inputs interpolated from four of them; the two clamped columns (t = 0, T - 1), the conv's zero padding and the ends of
+    the operand are handled by index in the edge tiles.  Against F.interpolate + autograd in fp64, tiny operands."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    x, gy = rnd(B, Cig, T // 2, seed=95), rnd(B, Cog, T, seed=96)
+    for t in (x, gy):
+        t[:, :, :3] *= 8.0
+        t[:, :, -3:] *= 8.0
+    w64 = torch.zeros(Cog, Cig, 3, dtype=torch.float64, requires_grad=True)
+    xin = F.interpolate(x.double(), scale_factor=2, mode="linear", align_corners=False)
+    F.conv1d(xin, w64, None, 1, 1).backward(gy.double())
+    pro = (2, None, None, 1)
+    gw = o.conv_bwd_weight(GV.dense(g(x), 1), GV.dense(g(gy), 1), 3, pro=pro, wino=4)
+    assert rel(gw, w64.grad) < 2e-5
+    x2 = torch.cat([rnd(B, Cig, T // 2, seed=97) * 100.0, x], 0)
+    gy2 = torch.cat([rnd(B, Cog, T, seed=98) * 100.0, gy], 0)
+    gw2 = o.conv_bwd_weight(GV.dense(g(x2)[B:], 1), GV.dense(g(gy2)[B:], 1), 3, pro=pro, wino=4)
+    assert torch.equal(gw2, gw)
+
+
+def test_conv_bwd_weight_dma_upsampling_stays_inside_the_operand():
+    """As test_conv_bwd_weight_dma_stays_inside_the_operand, for the half-resolution operand of the upsampling prologue."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    B, C, T = 256, 1024, 132
+    assert (B * C * (T // 2) * 4) % (2 << 20) == 0
+    torch.cuda.empty_cache()
+    x = torch.randn(B, C, T // 2, device=DEV)
+    gy = torch.randn(B, 64, T, device=DEV)
+    pro = (2, None, None, 1)
+    gw = o.conv_bwd_weight(GV.dense(x, 1), GV.dense(gy, 1), 3, pro=pro, wino=4)
+    torch.cuda.synchronize()
+    want = o.conv_bwd_weight(GV.dense(x, 1), GV.dense(gy, 1), 3, pro=pro, wino=False)
+    assert rel(gw, want) < 1e-4
