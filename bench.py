@@ -275,7 +275,7 @@ def main():
         # Dominant kernel: the K=7 grouped conv over the encoder's [B,128V,T] activations, 18 launches per step: 6 forward
         # (conv_wino_kernel<7,2,0>: Winograd F(2,4)+F(2,3) on the taps split 4+3 -- the one `roofline` prices, from the launches of
         # the TIMED region), 6 backward-data (conv_wino4_kernel<7,4,0>: F(4,4) + F(4,3) on the taps split 4+3) and 6 weight gradients
-        # (conv_bwd_weight_kernel<7,4,1,0,4> + <7,4,1,0,5>: taps split 4+3 over two launches, transposed F(4,4) + F(3,4)).
+        # (conv_bww_glds_kernel<7,.,4> + <7,.,5>: taps split 4+3 over two launches, transposed F(4,4) + F(3,4), tiles by LDS-DMA).
         # roofline.achieved / frac = EXECUTED matrix-core flops (what the MFMA pipes really did) over the kernel's time,
         # against the dense fp32 MFMA peak.  The algorithmic (direct-convolution) rate 2*B*Cout*T*Cin_g*K / time is
         # reported beside it as `algorithmic_TFLOPs`: it exceeds the executed rate by the Winograd saving and is NOT a
@@ -329,7 +329,7 @@ def main():
                     "k7_kernels_one_at_a_time": {
                         "conv_wino_kernel<7,2,0> fwd F(2,4)+F(2,3) on taps 4+3": _serial("conv_fwd", ex_fwd),
                         "conv_wino4_kernel<7,4,0> bwd-data F(4,4)+F(4,3) on taps 4+3": _serial("conv_bwd_data", ex_bd),
-                        "conv_bwd_weight_kernel<7,4,1,0,4> + <7,4,1,0,5>: taps 4+3 as two launches, transposed F(4,4) + F(3,4) (+ the split-K reduce)": _serial("conv_bwd_weight", ex_bw)},
+                        "conv_bww_glds_kernel<7,.,4> + <7,.,5>: taps 4+3 as two launches, transposed F(4,4) + F(3,4), tiles by LDS-DMA (+ the split-K reduce)": _serial("conv_bwd_weight", ex_bw)},
                     "side_stream": os.environ.get("NEF_SIDE_STREAM", "auto") != "0"}
         by_kernel = {}
         hbm = {}

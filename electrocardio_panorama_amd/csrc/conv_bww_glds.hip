@@ -80,24 +80,28 @@ __global__ __launch_bounds__(256, NEF_GL_OCC) void conv_bww_glds_kernel(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tab = smem + NBUF * BUF;       // AFF: [n_pass][2][64] prologue constants of this workgroup's input channels
 
-    // workgroup -> (unit, ci chunk) as conv_bwd_weight_kernel: the ci chunks of a unit share gY tiles, same XCD
+    // workgroup -> (unit = (split, group), member = (co tile, ci chunk)).  The members of a unit walk the SAME tiles -- co tiles
+    // share the X tile, ci chunks the gY tile -- and workgroup ids go round-robin over the 8 XCDs (one L2 each): members are
+    // placed 8 ids apart, i.e. on one XCD, dispatched together, so that all but the first find a tile in that L2.  (With
+    // only the ci chunks co-located, as in conv_bwd_weight_kernel, the two co tiles of a 128-channel layer fetched every X
+    // tile from HBM twice: 1.69 GB per launch of the K = 7 gradient for 0.98 GB of operands.)
     int bid = blockIdx.x;
-    int cc;
+    int member;
     {
-        const int units = (int)gridDim.x / ci_chunks;
-        const int full = (units / 8) * 8 * ci_chunks;
+        const int members = ci_chunks * m_tiles;
+        const int units = (int)gridDim.x / members;
+        const int full = (units / 8) * 8 * members;
         if (bid < full) {
-            const int grp = bid / (8 * ci_chunks), r = bid % (8 * ci_chunks);
-            cc = r / 8;
+            const int grp = bid / (8 * members), r = bid % (8 * members);
+            member = r / 8;
             bid = grp * 8 + (r % 8);
         } else {
             const int r = bid - full;
-            cc = r % ci_chunks;
-            bid = (units / 8) * 8 + r / ci_chunks;
+            member = r % members;
+            bid = (units / 8) * 8 + r / members;
         }
     }
-    const int mt = bid % m_tiles;
-    bid /= m_tiles;
+    const int cc = member % ci_chunks, mt = member / ci_chunks;
     const int g = bid % G;
     const int split = bid / G;
     const int m0 = mt * ROWS, c0 = cc * ROWS;
