@@ -245,12 +245,15 @@ __global__ __launch_bounds__(256) void roi_unpool_bwd_kernel(const float* __rest
         const float* gr = grow;
         if constexpr (STAGED) {
             float* strip = strip_lds + wave * T;
-            for (int t0 = 0; t0 < T; t0 += 64 * 5) {
-                float v[5];
+            // NU loads per lane in flight at once: a T = 1250 row (20 x 64 floats) is one trip -- with 5 per trip the wave
+            // paid four HBM round trips per row (33 % of the HBM roof, round 2)
+            constexpr int NU = 20;
+            for (int t0 = 0; t0 < T; t0 += 64 * NU) {
+                float v[NU];
 #pragma unroll
-                for (int u = 0; u < 5; ++u) v[u] = (t0 + u * 64 + lane < T) ? grow[t0 + u * 64 + lane] : 0.f;
+                for (int u = 0; u < NU; ++u) v[u] = (t0 + u * 64 + lane < T) ? grow[t0 + u * 64 + lane] : 0.f;
 #pragma unroll
-                for (int u = 0; u < 5; ++u)
+                for (int u = 0; u < NU; ++u)
                     if (t0 + u * 64 + lane < T) strip[t0 + u * 64 + lane] = v[u];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
