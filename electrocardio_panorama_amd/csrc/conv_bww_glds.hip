@@ -54,7 +54,7 @@ __device__ __forceinline__ void wait_vm() {
 // WINO: 2 = K 3, transposed F(3,4); 4 / 5 = the two launches of K 7 (taps 0..3 through the transposed F(4,4), taps 4..6
 // through the transposed F(3,4)) -- the matrices of conv_bwd_weight_kernel.  AFF (K = 3): the BatchNorm affine + ReLU of
 // the producing layer is applied to the X fragments (nef_conv_bwd_weight_wino's pro_mode 1).
-// UP (K = 3, not with AFF): x is stored at half resolution [..][T/2] and upsampled x2 while the fragments are formed
+// UP (K = 3): x is stored at half resolution [..][T/2] and upsampled x2 while the fragments are formed
 // (nn.Upsample(scale_factor=2, mode='linear', align_corners=False): pro_mode 2) -- the X image then holds the T/2-resolution
 // samples x[t0/2 - 1 .. t0/2 + 18), and a quad's six inputs are interpolated from four of them.
 template <int K, bool AFF, int WINO, int NBUF, bool UP = false>
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, NEF_GL_OCC) void conv_bww_glds_kernel(
     const float* __restrict__ pro_a, const float* __restrict__ pro_b, int pro_Bp, int n_pass, int64_t x_extent,
     int64_t gy_extent) {
     static_assert((WINO == 2 && K == 3) || ((WINO == 4 || WINO == 5) && K == 7 && !AFF), "forms");
-    static_assert(!UP || (K == 3 && !AFF), "the upsampling prologue: K = 3, no affine");
+    static_assert(!UP || K == 3, "the upsampling prologue: K = 3");
     constexpr int PAD = (K - 1) / 2;       // UP: the image starts one half-resolution sample before t0 / 2, also PAD = 1
     constexpr int XN = UP ? TW / 2 + 2 : TW + K - 1;       // positions of an X image row that are used
     constexpr int XUSE = (XN + 3) / 4;                      // chunks of an X row that are fetched
@@ -337,6 +337,12 @@ __global__ __launch_bounds__(256, NEF_GL_OCC) void conv_bww_glds_kernel(
                     // 0.75 * x[(t-1)/2] + 0.25 * x[(t+1)/2] for odd t, 0.25 * x[t/2 - 1] + 0.75 * x[t/2] for even t, indices clamped
                     // to [0, T/2) -- (1 - lambda) * x[i0] + lambda * x[i1] of conv_bwd_weight_kernel, same rounding
                     float h0 = d0, h1 = d1, h2 = d4, h3 = d5;
+                    if constexpr (AFF) {      // the producing layer's affine + ReLU acts on the stored samples, before the interpolation
+                        h0 = fmaxf(fmaf(h0, pa, pb), 0.f);
+                        h1 = fmaxf(fmaf(h1, pa, pb), 0.f);
+                        h2 = fmaxf(fmaf(h2, pa, pb), 0.f);
+                        h3 = fmaxf(fmaf(h3, pa, pb), 0.f);
+                    }
                     const int tb = t0 + 4 * (2 * s_ + hi);
                     if (edge_c) {
                         const int m0 = (tb >> 1) - 1;
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(256, NEF_GL_OCC) void conv_bww_glds_kernel(
                         }
                     }
                 }
-                if constexpr (AFF) {
+                if constexpr (AFF && !UP) {
                     d0 = fmaxf(fmaf(d0, pa, pb), 0.f);
                     d1 = fmaxf(fmaf(d1, pa, pb), 0.f);
                     d2 = fmaxf(fmaf(d2, pa, pb), 0.f);
@@ -480,15 +486,14 @@ int launch(const float* x, int64_t x_bs, int64_t x_gs, const float* gy, int64_t 
 #endif
 
 // Shapes the LDS-DMA kernel takes (everything else stays on conv_bwd_weight_kernel): whole 64-channel slabs, at least two
-// tiles per sample, no in_scale, the affine and the upsampling prologue one at a time (T % 4 == 0 for the latter); at most 8
-// BatchNorm passes in the prologue table.
+// tiles per sample, no in_scale, T % 4 == 0 with the upsampling prologue; at most 8 BatchNorm passes in the prologue table.
 extern "C" __attribute__((visibility("hidden"))) bool nef_bww_glds_ok(int B, int T, int Cig, int Cog, int K, int pro_mode, int pro_Bp,
                                                                       bool in_scale) {
     static const int on = [] {
         const char* e = getenv("NEF_BWW_GLDS");
         return (e && e[0] == '0') ? 0 : 1;
     }();
-    if (!on || in_scale || (K != 3 && K != 7) || (K == 7 && pro_mode != 0) || pro_mode == 3) return false;
+    if (!on || in_scale || (K != 3 && K != 7) || (K == 7 && pro_mode != 0)) return false;
     if ((pro_mode & 2) && T % 4 != 0) return false;
     if (Cig % ROWS != 0 || Cog % ROWS != 0 || T < 2 * TW || T % 2 != 0) return false;
     if ((int64_t)(ROWS - 1) * T * 4 + 4 * 11 * 4 >= 0x7FFFFFFCll) return false;      // per-lane offsets are 32-bit
@@ -504,6 +509,9 @@ extern "C" __attribute__((visibility("hidden"))) int nef_bww_glds_launch(
     int* S_used, hipStream_t st) {
     const int n_pass = (pro_mode & 1) ? (B + pro_Bp - 1) / pro_Bp : 0;
     if (K == 3) {
+        if (pro_mode == 3)
+            return launch<3, true, 2, NEF_GLDS_NBUF, true>(x, x_bs, x_gs, gy, gy_bs, gy_gs, ws, B, T, G, Cig, Cog, pro_a, pro_b, pro_Bp,
+                                                           n_pass, S_max, fixed_S, S_used, st);
         if (pro_mode & 2)
             return launch<3, false, 2, NEF_GLDS_NBUF, true>(x, x_bs, x_gs, gy, gy_bs, gy_gs, ws, B, T, G, Cig, Cog, nullptr, nullptr, 1,
                                                             0, S_max, fixed_S, S_used, st);

@@ -17,9 +17,11 @@ N_SEG, ROI_BINS = 7, 16
 DROP_P = 0.2           # every nn.Dropout on the path (model_nefnet.py:46, encoder/resnet_1d.py:37)
 BN_EPS, BN_MOM = 1e-5, 0.1
 
-# NEF_FUSE_L2=1: third decoder conv with the (affine + ReLU, x2) prologue instead of a materialised u2.  Measured again in
-# round 2 with the Winograd kernels: 60.2 ms/step against 58.8 ms/step with the materialised tensor -- stays off.
-_FUSE_L2 = os.environ.get("NEF_FUSE_L2", "0") == "1"
+# NEF_FUSE_L2=0: third decoder conv on a materialised u2 = up2(relu(bn(c2))) instead of the (affine + ReLU, x2) prologue on c2.
+# Round 2 measured the prologue form slower (60.2 against 58.8 ms/step: the register-staged weight gradient paid for the
+# prologue per staged element); since the LDS-DMA weight gradient interpolates while it forms its fragments it is the
+# faster one: 47.85 -> 47.36 ms/step, and the 1.97 GB tensor is never written.
+_FUSE_L2 = os.environ.get("NEF_FUSE_L2", "1") == "1"
 
 # NEF_FUSE_STATS=0: BatchNorm statistics by a pass over the conv output (nef_bn_train_stats) instead of the conv epilogue
 _FUSE_STATS = os.environ.get("NEF_FUSE_STATS", "1") == "1"
@@ -221,8 +223,7 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
     for li, (blk, cv, bn, cout) in enumerate(_DEC):
         wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
         if li == 2 and not _FUSE_L2:
-            # measured: at 128->64 channels the staged (affine+ReLU, x2) prologue costs the two conv kernels more than
-            # one fused elementwise pass, so this layer materialises u2 = up(relu(bn(c2))) and runs the plain conv
+            # NEF_FUSE_L2=0 (the round-2 form): this layer materialises u2 = up(relu(bn(c2))) and runs the plain conv
             x_in = ops.upsample2_aff_fwd(x, pro_in[0], pro_in[1], pro_in[2])
             pro = (0, None, None, 1)
             up_after = True
