@@ -177,7 +177,27 @@ __global__ __launch_bounds__(256) void lead_mean_mix_shared_kernel(const float* 
         const float f = q[row];
         vec* lat = (vec*)latent + row * TW;
         vec* d0 = (vec*)D2 + row * TW;
-        for (int t = lane; t < TW; t += 64) {
+        // two column groups per trip: 2 V loads in flight per lane before the first add (the row loop is latency-bound
+        // otherwise: one dependent load chain per trip); same expressions per element
+        int t = lane;
+        for (; t + 64 < TW; t += 128) {
+            vec s0 = src[t], s1 = src[t + 64];
+            vec p0 = s0, p1 = s1;
+            for (int v = 1; v < V; ++v) {
+                const vec x0 = src[(int64_t)v * lead + t], x1 = src[(int64_t)v * lead + t + 64];
+                s0 += x0;
+                s1 += x1;
+                if (v == cp) { p0 = x0; p1 = x1; }
+            }
+            const vec m0 = s0 / fv, m1 = s1 / fv;
+            lat[t] = m0;
+            lat[t + 64] = m1;
+            d0[t] = f * m0;
+            d0[t + 64] = f * m1;
+            d0[pass + t] = f * p0;
+            d0[pass + t + 64] = f * p1;
+        }
+        for (; t < TW; t += 64) {
             vec s = src[t];
             vec pk = s;
             for (int v = 1; v < V; ++v) {
