@@ -20,7 +20,9 @@ LABEL = {0: "full kernel", 8: "no epilogue", 1: "no A / global fetch in loop", 2
          3: "no fetches, no staging", 7: "MFMA + barriers + epilogue", 15: "MFMA stream + barriers only"}
 # executed MFMA flops per launch of the [256, 384, 1250] K=7 grouped conv: algorithmic 220.2 GFLOP x executed/algorithmic
 ALG = 2.0 * 256 * 384 * 1250 * 128 * 7
-EXEC = {"wino F(2,3) fwd": 10 / 14, "wino4 F(4,3) bwd-data": 17 / 28, "bwd-weight 4+3": 9 / 14}
+# (round 3, final forms: forward F(2,4)+F(2,3) executes 9/14, backward-data F(4,4)+F(4,3) 13/28 of the algorithmic multiplies; the weight
+# gradient has its own builds -- NEF_GL_ABL in conv_bww_glds.hip, profiles/r03_glds_weight_gradient.md)
+EXEC = {"fwd F(2,4)+F(2,3)": 9 / 14, "bwd-data F(4,4)+F(4,3)": 13 / 28}
 
 
 def build():
@@ -31,7 +33,7 @@ def build():
 
 
 def bench(lib, f4):
-    env = dict(os.environ, NEF_LIB=lib, F4=f4, ITERS="20", ONLY_WHAT="wino,bwd_ww")
+    env = dict(os.environ, NEF_LIB=lib, F4=f4, ITERS="20", WARM="40", ONLY_WHAT="wino")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_conv.py"), "enc k7"], env=env, text=True,
                          capture_output=True)
     res = {}
@@ -53,9 +55,8 @@ def run():
             a = bench(lib, "0")
             b = bench(lib, "1")
             r = rows.setdefault(m, {k: [] for k in EXEC})
-            r["wino F(2,3) fwd"].append(a.get("wino"))
-            r["bwd-weight 4+3"].append(a.get("bwd_ww"))
-            r["wino4 F(4,3) bwd-data"].append(b.get("wino"))
+            r["fwd F(2,4)+F(2,3)"].append(a.get("wino"))
+            r["bwd-data F(4,4)+F(4,3)"].append(b.get("wino"))
     print("| NEF_ABL | variant | " + " | ".join(f"{k}: ms (executed TFLOP/s, frac of 157.3)" for k in EXEC) + " |")
     print("|---|---|" + "---|" * len(EXEC))
     for m in MASKS:
