@@ -2,6 +2,7 @@
 """Nef-Net train-step benchmark (BASELINE.json metric: ECG-samples/sec of one train step).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8 --steps 10 --warmup 3        (re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -176,8 +177,27 @@ def _config_name(V, B, L):
         (V, B, L), "custom shape")
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment (how the round driver may call it): re-execute under
+    torch.distributed.run, one rank per GPU on 127.0.0.1 with a free port, and hand its exit code on.  Rank 0 of that job
+    prints the JSON line.  The explicit `python -m torch.distributed.run ... bench.py --gpus N` form keeps working."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
     from electrocardio_panorama_amd import ops, parallel, synth
     from electrocardio_panorama_amd.network import build_loss, build_model
     from electrocardio_panorama_amd.solver.optim_scheduler import get_optimizer
@@ -185,7 +205,10 @@ def main():
 
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the two must agree (plain `python bench.py --gpus N` "
+                         f"launches its own ranks)")
+    if world > 1 and not parallel._hook("NEF_SHARE_GPU") and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} HIP device(s) are visible")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     V, L, B = args.leads, args.length, args.batch

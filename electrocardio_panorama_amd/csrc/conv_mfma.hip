@@ -10,6 +10,7 @@
 // A column tile never straddles a sample: long sequences are cut into 128(64)-column tiles, short ones
 // (the fixed 16/32-sample ROI latents) pack several whole samples per tile, each with its own zero halo in LDS.
 #include "nef_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -23,6 +24,14 @@ namespace {
 // bit3 = no epilogue (the accumulators stay live behind a run-time-false branch).  15 = the MFMA stream and its barriers.
 #ifndef NEF_ABL
 #define NEF_ABL 0
+#endif
+// NEF_TRACE: measurement builds only (tools/trace_conv.py).  Wave 0 of every 16th workgroup of conv_wino4_kernel keeps
+// s_memtime stamps of its phases (entry, first tile staged, every stage's barrier, epilogue done) and writes them out at exit.
+#ifdef NEF_TRACE
+__device__ unsigned long long* nef_trace_ptr = nullptr;
+#define NEF_TR(I) if (tr_on) tr_t[(I)] = __builtin_readcyclecounter();
+#else
+#define NEF_TR(I)
 #endif
 constexpr int NT = 128;   // forward: columns per workgroup
 constexpr int WT = 64;    // bwd-weight: reduction columns per staged tile
@@ -386,6 +395,7 @@ static int launch_conv_fwd(const nef_conv_args& a, hipStream_t st) {
 #define NEF_WKC 16
 #endif
 constexpr int WKC = NEF_WKC;   // channels per activation stage: 64 MFMAs per wave between barriers
+constexpr int PRO_MAX_CIN = 512; // input channels per group the LDS table of the affine prologue holds
 
 // Operand paths.  B (activations): raw tile through LDS, DOUBLE-buffered -- the registers holding stage s+1 (fetched
 // during the MFMA loop of stage s) are written to the other buffer right after that loop, so there is ONE barrier per
@@ -422,6 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
     constexpr int XRS = NTO + 16;        // LDS row pitch (even: rows stay 8-byte aligned for ds_read_b64)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xl = smem;                    // [2][KC][XRS]
+    float* Pl = smem + 2 * KC * XRS;     // [2][Cin_g]: prologue affine of this tile's pass (AFF only)
 
     const int tile = blockIdx.x % n_tiles;
     const int gm = blockIdx.x / n_tiles;
@@ -449,7 +460,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
     constexpr int XR = KC / 4;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm_u = wave_u / WN;
-    const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(a.x + (int64_t)b0 * a.x_bs + (int64_t)g * a.x_gs);
+    const float* const xbase = a.x + (int64_t)b0 * a.x_bs + (int64_t)g * a.x_gs;
+    const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(xbase);
     // K = 7: q slabs of 16-byte vectors; K = 3: planes [ci][co] (see the A-operand note below)
     const int a_rstride = K == 7 ? (Cog >> 6) * 128 : Cog;   // floats per reduction channel inside one slab / plane
     const int a_qstride = Cig * a_rstride;                   // floats per slab / plane
@@ -525,12 +537,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
         }                                                                                                           \
     }
     float xreg[XR][NIT][NS];
-#define NEF_WX_ISSUE(C0)                                                                                             \
+#define NEF_WX_ISSUE(C0, RS)                                                                                         \
     {                                                                                                               \
         _Pragma("unroll") for (int rr = 0; rr < XR; ++rr) {                                                         \
             const unsigned so = (unsigned)(((C0) + wave_u + 4 * rr) * Tin * 4);                                     \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it)                                                      \
-                _Pragma("unroll") for (int ns = 0; ns < NS; ++ns) xreg[rr][it][ns] = nef_buf_f32(xrs, xvo[it][ns], so); \
+                _Pragma("unroll") for (int ns = 0; ns < NS; ++ns) xreg[rr][it][ns] = nef_buf_f32(RS, xvo[it][ns], so); \
         }                                                                                                           \
     }
 #define NEF_WX_STORE(C0, BUFP)                                                                                       \
@@ -544,8 +556,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
         _Pragma("unroll") for (int rr = 0; rr < XR; ++rr) {                                                         \
             float pa = 1.f, pb = 0.f;                                                                               \
             if constexpr (AFF) {                                                                                    \
-                pa = a.pro_a[pro_row0 + (C0) + wave_u + 4 * rr];                                                    \
-                pb = a.pro_b[pro_row0 + (C0) + wave_u + 4 * rr];                                                    \
+                pa = Pl[(C0) + wave_u + 4 * rr];                                                                    \
+                pb = Pl[Cig + (C0) + wave_u + 4 * rr];                                                              \
             }                                                                                                       \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                    \
                 const int r = lane + 64 * it;                                                                       \
@@ -561,9 +573,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
             }                                                                                                       \
         }                                                                                                           \
     }
-    NEF_WX_ISSUE(0)
+    NEF_WX_ISSUE(0, xrs)
 #pragma unroll
     for (int s_ = 0; s_ < ((NEF_ABL & 1) ? NSET : AHEAD); ++s_) NEF_WA_ISSUE(s_, s_)
+    if constexpr (AFF) {     // the producing BatchNorm's (a, b) of this tile's pass: one table in LDS instead of a global load per
+                             // staged row (each of those was waited for with the queue drained)
+        for (int i = threadIdx.x; i < Cig; i += 256) {
+            Pl[i] = a.pro_a[pro_row0 + i];
+            Pl[Cig + i] = a.pro_b[pro_row0 + i];
+        }
+        __syncthreads();
+    }
     NEF_WX_STORE(0, Xl)
     __syncthreads();
     int st = 0;
@@ -582,6 +602,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
     for (int c0 = 0; c0 < Cig; c0 += KC, ++st) {
         const float* xb = Xl + ((NEF_ABL & 2) ? 0 : (st & 1)) * (KC * XRS) + hi * XRS + 2 * (wn * 32 + lo);
         const bool more = c0 + KC < Cig;
+        const __amdgpu_buffer_rsrc_t xrs_n = nef_rsrc_n(xbase, more ? 0x7FFFFFFCu : 0u);
         if constexpr (!(NEF_ABL & 4)) NEF_WX_LOAD(0, 0)
 #pragma unroll
         for (int s_ = 0; s_ < SPK; ++s_) {
@@ -589,7 +610,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(nef_conv_args a, int 
             // the activation rows of the next stage are requested once per stage, right behind an A request: the first
             // A fragment that is YOUNGER than them is consumed later in the stage, by when they have long arrived
             // (vector-memory results return in order)
-            if constexpr (!(NEF_ABL & 2)) if (s_ == 0 && more) NEF_WX_ISSUE(c0 + KC)
+            // (branch-free on purpose: past the last stage the burst goes through an empty descriptor.  With `if (more)`
+            // around it the compiler's s_waitcnt bookkeeping took the smaller count of the two paths and made every wave sit
+            // on the burst within the first k-step of the stage)
+            if constexpr (!(NEF_ABL & 2)) if (s_ == 0) NEF_WX_ISSUE(c0 + KC, xrs_n)
             if constexpr (!(NEF_ABL & 4)) if (s_ + 1 < SPK) NEF_WX_LOAD(s_ + 1, (s_ + 1) & 1)
             const f32x2* d = fx[s_ & 1];
 #define w_(I, TM) NEF_FA(s_ % NSET, I, TM)
@@ -751,7 +775,8 @@ template <int K, int WM, int PRO = 0>
 static int launch_conv_wino(const nef_conv_args& a, hipStream_t st) {
     constexpr int MT = 64 * WM;
     constexpr int NTO = 64 * (4 / WM);
-    constexpr size_t lds = (size_t)(2 * WKC * (NTO + 16)) * sizeof(float);
+    constexpr size_t lds = (size_t)(2 * WKC * (NTO + 16) + ((PRO & 1) ? 2 * PRO_MAX_CIN : 0)) * sizeof(float);
+    if ((PRO & 1) && a.Cin_g > PRO_MAX_CIN) return NEF_E_SHAPE;
     static unsigned long long lds_set = 0;      // per-device bits, see nef_ensure_dyn_lds
     if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_wino_kernel<K, WM, PRO>), lds, &lds_set)) return e;
     const int tps = (a.T + NTO - 1) / NTO;
@@ -790,8 +815,23 @@ static int launch_conv_wino(const nef_conv_args& a, hipStream_t st) {
 #ifndef NEF_W4_MINB3
 #define NEF_W4_MINB3 1
 #endif
+#ifndef NEF_W4_AHEAD3_W2
+#define NEF_W4_AHEAD3_W2 3
+#endif
+#ifndef NEF_W4_AHEAD3_W4
+#define NEF_W4_AHEAD3_W4 3
+#endif
+#ifndef NEF_W4_AHEAD7
+#define NEF_W4_AHEAD7 1
+#endif
+#ifndef NEF_W4_MINB3_W2
+#define NEF_W4_MINB3_W2 0
+#endif
+constexpr int w4_wgs_per_cu(int K, int WMC, int PRO) {
+    return (K == 3 && (PRO & 2) == 0 && ((WMC == 4 && NEF_W4_MINB3) || (WMC == 2 && NEF_W4_MINB3_W2))) ? 3 : 2;
+}
 template <int K, int WMC, int PRO>
-__global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 2) == 0) ? 3 : 2) void conv_wino4_kernel(nef_conv_args a, int tps, int n_tiles, int m_tiles) {
+__global__ __launch_bounds__(256, w4_wgs_per_cu(K, WMC, PRO)) void conv_wino4_kernel(nef_conv_args a, int tps, int n_tiles, int m_tiles) {
     constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
     constexpr int NS = UP ? 2 : 1;
     constexpr int KC = WKC;
@@ -806,6 +846,21 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
     constexpr int XRS = NTO + 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xl = smem;                        // [2][KC][XRS]
+    float* Pl = smem + 2 * KC * XRS;         // [2][Cin_g]: prologue affine of this tile's pass (AFF only)
+    // [5][MT]: what the epilogue needs per output channel (bias; mean, invstd, a, b of the BatchNorm below for the bnb sums),
+    // fetched while the first tile is in flight -- in the epilogue each of these was a dependent global load with the
+    // memory latency of a loaded chip in front of the output stores
+    float* El = Pl + (AFF ? 2 * PRO_MAX_CIN : 0);
+#ifdef NEF_TRACE
+    const bool tr_on = nef_trace_ptr != nullptr && (blockIdx.x & 15) == 0;
+    unsigned long long tr_t[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) tr_t[i] = 0;
+#endif
+    NEF_TR(0)
+#ifdef NEF_TRACE
+    if (tr_on) tr_t[22] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+#endif
 
     const int tile = blockIdx.x % n_tiles;
     const int gm = blockIdx.x / n_tiles;
@@ -833,7 +888,8 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
     constexpr int XR = KC / 4;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm_u = wave_u / WN;
-    const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(a.x + (int64_t)b0 * a.x_bs + (int64_t)g * a.x_gs);
+    const float* const xbase = a.x + (int64_t)b0 * a.x_bs + (int64_t)g * a.x_gs;
+    const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(xbase);
     constexpr int NQ4 = NPL / 4, REM = NPL % 4;              // 16-byte vectors + an 8- or 4-byte tail per lane and k-step
     const int a_rstride = (Cog >> 5) * 128;                  // floats per reduction channel inside one full-vector slab
     const int a_qstride = Cig * a_rstride;                   // floats per slab; the tail slab follows the NQ4 full ones
@@ -876,7 +932,11 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     constexpr int SPK = KC / 2;
-    constexpr int AHEAD = K == 3 ? 3 : 1;
+    // A ring depth.  Vector-memory results return IN ORDER, so the wait for an A fragment that was requested after the
+    // activation rows of the next stage also waits for those rows: the ring depth is the cover (in k-steps) the activation
+    // fetch gets before the wave is made to sit on it -- and with it the share of a stage during which a workgroup has
+    // bytes in flight at all (the 64-channel layers are bound by exactly that: ~17 KB per workgroup, 40 % of the time).
+    constexpr int AHEAD = K == 3 ? (WMC == 2 ? NEF_W4_AHEAD3_W2 : NEF_W4_AHEAD3_W4) : NEF_W4_AHEAD7;
     constexpr int NSET = AHEAD + 1;
     static_assert(SPK % NSET == 0, "the A sets must line up across stages");
     const int nsteps = Cig / 2;
@@ -901,12 +961,12 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
             far[SET][0] = nef_buf_f32(wrs_r, avo_r, (unsigned)((2 * gs_ * a_rstride_r) * 4));                       \
         }                                                                                                           \
     }
-#define NEF_W4X_ISSUE(C0)                                                                                            \
+#define NEF_W4X_ISSUE(C0, RS)                                                                                        \
     {                                                                                                               \
         _Pragma("unroll") for (int rr = 0; rr < XR; ++rr) {                                                         \
             const unsigned so = (unsigned)(((C0) + wave_u + 4 * rr) * Tin * 4);                                     \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it)                                                      \
-                _Pragma("unroll") for (int ns = 0; ns < NS; ++ns) xreg[rr][it][ns] = nef_buf_f32(xrs, xvo[it][ns], so); \
+                _Pragma("unroll") for (int ns = 0; ns < NS; ++ns) xreg[rr][it][ns] = nef_buf_f32(RS, xvo[it][ns], so); \
         }                                                                                                           \
     }
 #define NEF_W4X_STORE(C0, BUFP)                                                                                      \
@@ -920,8 +980,8 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
         _Pragma("unroll") for (int rr = 0; rr < XR; ++rr) {                                                         \
             float pa = 1.f, pb = 0.f;                                                                               \
             if constexpr (AFF) {                                                                                    \
-                pa = a.pro_a[pro_row0 + (C0) + wave_u + 4 * rr];                                                    \
-                pb = a.pro_b[pro_row0 + (C0) + wave_u + 4 * rr];                                                    \
+                pa = Pl[(C0) + wave_u + 4 * rr];                                                                    \
+                pb = Pl[Cig + (C0) + wave_u + 4 * rr];                                                              \
             }                                                                                                       \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                    \
                 const int r = lane + 64 * it;                                                                       \
@@ -937,11 +997,31 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
             }                                                                                                       \
         }                                                                                                           \
     }
-    NEF_W4X_ISSUE(0)
+    NEF_W4X_ISSUE(0, xrs)
 #pragma unroll
     for (int s_ = 0; s_ < ((NEF_ABL & 1) ? NSET : AHEAD); ++s_) NEF_W4A_ISSUE(s_, s_)
+    if (threadIdx.x < MT) {     // published by the barrier behind the first tile's LDS stores
+        const int ch_ = g * Cog + m0 + (int)threadIdx.x;
+        El[threadIdx.x] = a.bias ? a.bias[ch_] : 0.f;
+        if (a.bnb_slots) {
+            const int pr_ = (b0 / a.bnb_Bp) * a.G * Cog + ch_;
+            El[MT + threadIdx.x] = a.bnb_mean[pr_];
+            El[2 * MT + threadIdx.x] = a.bnb_invstd[pr_];
+            El[3 * MT + threadIdx.x] = a.bnb_a[pr_];
+            El[4 * MT + threadIdx.x] = a.bnb_b[pr_];
+        }
+    }
+    if constexpr (AFF) {     // see conv_wino_kernel
+        for (int i = threadIdx.x; i < Cig; i += 256) {
+            Pl[i] = a.pro_a[pro_row0 + i];
+            Pl[Cig + i] = a.pro_b[pro_row0 + i];
+        }
+        __syncthreads();
+    }
+    NEF_TR(1)
     NEF_W4X_STORE(0, Xl)
     __syncthreads();
+    NEF_TR(2)
     int st = 0;
     f32x2 fx[2][NXV];
 #define NEF_W4X_LOAD(S, BUF)                                                                                         \
@@ -957,11 +1037,12 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
     for (int c0 = 0; c0 < Cig; c0 += KC, ++st) {
         const float* xb = Xl + ((NEF_ABL & 2) ? 0 : (st & 1)) * (KC * XRS) + hi * XRS + 4 * (wn * 32 + lo);
         const bool more = c0 + KC < Cig;
+        const __amdgpu_buffer_rsrc_t xrs_n = nef_rsrc_n(xbase, more ? 0x7FFFFFFCu : 0u);     // see conv_wino_kernel
         if constexpr (!(NEF_ABL & 4)) NEF_W4X_LOAD(0, 0)
 #pragma unroll
         for (int s_ = 0; s_ < SPK; ++s_) {
             if constexpr (!(NEF_ABL & 1)) NEF_W4A_ISSUE(st * SPK + s_ + AHEAD, (s_ + AHEAD) % NSET)
-            if constexpr (!(NEF_ABL & 2)) if (s_ == 0 && more) NEF_W4X_ISSUE(c0 + KC)
+            if constexpr (!(NEF_ABL & 2)) if (s_ == 0) NEF_W4X_ISSUE(c0 + KC, xrs_n)
             if constexpr (!(NEF_ABL & 4)) if (s_ + 1 < SPK) NEF_W4X_LOAD(s_ + 1, (s_ + 1) & 1)
             __builtin_amdgcn_s_setprio(1);      // scheduling fence, see conv_wino_kernel
             float x_[2 * NXV];
@@ -1005,14 +1086,36 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(NEF_FA4(s_ % NSET, P0 + i), v[i], acc[i], 0, 0, 0);
             }
         }
+#ifdef NEF_TRACE
+        if (tr_on) {      // stage st: [3 + 2*st] = MFMA loop done, [4 + 2*st] = next tile stored + barrier passed
+#pragma unroll
+            for (int q_ = 0; q_ < 8; ++q_) if (q_ == st) tr_t[3 + 2 * q_] = __builtin_readcyclecounter();
+        }
+#endif
         if constexpr (!(NEF_ABL & 2)) if (more) NEF_W4X_STORE(c0 + KC, Xl + ((st + 1) & 1) * (KC * XRS))
         __syncthreads();
+#ifdef NEF_TRACE
+        if (tr_on) {
+#pragma unroll
+            for (int q_ = 0; q_ < 8; ++q_) if (q_ == st) tr_t[4 + 2 * q_] = __builtin_readcyclecounter();
+        }
+#endif
     }
 #undef NEF_W4X_LOAD
 #undef NEF_W4A_ISSUE
 #undef NEF_FA4
 #undef NEF_W4X_ISSUE
 #undef NEF_W4X_STORE
+#ifdef NEF_TRACE
+    if constexpr ((NEF_ABL & 8) != 0) {
+        if (tr_on && threadIdx.x == 0) {
+            unsigned long long* o = nef_trace_ptr + (size_t)(blockIdx.x >> 4) * 24;
+            tr_t[20] = tr_t[21] = __builtin_readcyclecounter();
+#pragma unroll
+            for (int i = 0; i < 24; ++i) o[i] = tr_t[i];
+        }
+    }
+#endif
     if constexpr ((NEF_ABL & 8) != 0) if (a.T >= 0) return;      // run-time true: the epilogue below is dead at run time only
 
     // epilogue: output transform, then the usual bias / residual / ReLU / dropout / gate on the four adjacent outputs a
@@ -1049,7 +1152,7 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
         if (a.bias) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float bv = a.bias[g * Cog + cobase + NEF_ROW(q)];
+                const float bv = El[wm * 32 + 4 * hi + NEF_ROW(q)];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[q][e] += bv;
             }
@@ -1160,7 +1263,6 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
             // ... with a x2 upsampling between that layer and this launch's output: sum_t' m[t'] (U^T g)[t'] = sum_t g[t] (U m)[t],
             // so the lane weighs its four outputs t = 4j..4j+3 with the upsampled decision (and decision * xhat) rows,
             // built from the half-resolution tile x[2j-1 .. 2j+2] (indices clamped as nn.Upsample clamps them)
-            const int prow = (b0 / a.bnb_Bp) * (int)ctot + g * Cog + cobase;
             const int Lh = T >> 1;
             const float* xp = a.bnb_x + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * Lh;
             const int j2 = live[0] ? (t >> 1) : 0;
@@ -1168,8 +1270,9 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int row = NEF_ROW4(q, h);
-                const float af = a.bnb_a[prow + row], bf = a.bnb_b[prow + row];
-                const float mf = a.bnb_mean[prow + row], is = a.bnb_invstd[prow + row];
+                const int er = wm * 32 + 4 * hi + row;
+                const float af = El[3 * MT + er], bf = El[4 * MT + er];
+                const float mf = El[MT + er], is = El[2 * MT + er];
                 const float* xr = xp + (int64_t)row * Lh;
                 const float xa = xr[im1], xb = xr[j2], xc = xr[i1], xd = xr[ip2];
                 const float ma = fmaf(xa, af, bf) > 0.f ? 1.f : 0.f, mb = fmaf(xb, af, bf) > 0.f ? 1.f : 0.f;
@@ -1184,13 +1287,13 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
                                           fmaf(g2, fmaf(0.75f, hc, 0.25f * hb), g3 * fmaf(0.75f, hc, 0.25f * hd));
             }
         } else if (a.bnb_slots) {   // BatchNorm-backward sums of the layer below: g*m and g*m*xhat over this lane's live outputs
-            const int prow = (b0 / a.bnb_Bp) * (int)ctot + g * Cog + cobase;
             const float* xp = a.bnb_x + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int row = NEF_ROW4(q, h);
-                const float af = a.bnb_a[prow + row], bf = a.bnb_b[prow + row];
-                const float mf = a.bnb_mean[prow + row], is = a.bnb_invstd[prow + row];
+                const int er = wm * 32 + 4 * hi + row;
+                const float af = El[3 * MT + er], bf = El[4 * MT + er];
+                const float mf = El[MT + er], is = El[2 * MT + er];
                 const f32x2 x01 = *reinterpret_cast<const f32x2*>(xp + (int64_t)row * T + ts[0]);
                 const f32x2 x23 = *reinterpret_cast<const f32x2*>(xp + (int64_t)row * T + ts[1]);
                 const float g0 = (live[0] && fmaf(x01[0], af, bf) > 0.f) ? y[q][0] : 0.f;
@@ -1234,21 +1337,41 @@ __global__ __launch_bounds__(256, (NEF_W4_MINB3 && K == 3 && WMC == 4 && (PRO & 
 #undef NEF_ROW4
         if (inb) slot_out[((int64_t)ch * a.B * nslot + slot) * 2 + (lo & 1)] = sv[0];
     }
+#ifdef NEF_TRACE
+    NEF_TR(20)
+    if (tr_on) {
+        __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0): the output stores have left the wave's queue
+        tr_t[21] = __builtin_readcyclecounter();
+        if (threadIdx.x == 0) {
+            unsigned long long* o = nef_trace_ptr + (size_t)(blockIdx.x >> 4) * 24;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) o[i] = tr_t[i];
+        }
+    }
+#endif
 }
 
 template <int K, int WMC, int PRO = 0>
 static int launch_conv_wino4(const nef_conv_args& a, hipStream_t st) {
     constexpr int MT = 32 * WMC;
     constexpr int NTO = 128 * (4 / WMC);
-    constexpr size_t lds = (size_t)(2 * WKC * (NTO + 16)) * sizeof(float);
+    constexpr size_t lds = (size_t)(2 * WKC * (NTO + 16) + ((PRO & 1) ? 2 * PRO_MAX_CIN : 0) + 5 * MT) * sizeof(float);
+    if ((PRO & 1) && a.Cin_g > PRO_MAX_CIN) return NEF_E_SHAPE;
     static unsigned long long lds_set = 0;      // per-device bits, see nef_ensure_dyn_lds
+#ifdef NEF_TRACE
+    size_t lds_launch = lds;       // NEF_DEBUG_LDS=<bytes>: inflate the LDS request to force fewer workgroups per CU
+    if (const char* e_ = getenv("NEF_DEBUG_LDS")) lds_launch = (size_t)atol(e_);
+    if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_wino4_kernel<K, WMC, PRO>), 160 * 1024, &lds_set)) return e;
+#else
+    constexpr size_t lds_launch = lds;
     if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_wino4_kernel<K, WMC, PRO>), lds, &lds_set)) return e;
+#endif
     const int tps = (a.T + NTO - 1) / NTO;
     const int n_tiles = a.B * tps;
     const int m_tiles = a.Cout_g / MT;
     const int64_t blocks = (int64_t)a.G * m_tiles * n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffff) return NEF_E_SHAPE;
-    hipLaunchKernelGGL((conv_wino4_kernel<K, WMC, PRO>), dim3((unsigned)blocks), dim3(256), lds, st, a, tps, n_tiles, m_tiles);
+    hipLaunchKernelGGL((conv_wino4_kernel<K, WMC, PRO>), dim3((unsigned)blocks), dim3(256), lds_launch, st, a, tps, n_tiles, m_tiles);
     return nef_launch_status();
 }
 
@@ -2259,6 +2382,13 @@ int nef_pack_weights(const nef_pack_desc* descs, int n, nef_stream_t stream) {
 }
 
 size_t nef_conv_args_bytes(void) { return sizeof(nef_conv_args); }
+
+#ifdef NEF_TRACE
+int nef_debug_set_trace(void* p) {
+    unsigned long long* v = (unsigned long long*)p;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(nef_trace_ptr), &v, sizeof(v));
+}
+#endif
 
 int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
     NEF_ENTER();

@@ -114,6 +114,12 @@ typedef float nef_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t nef_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFC, 0x00020000);
 }
+// descriptor with a run-time extent: `bytes` = 0 turns every load through it into a no-op that returns 0.0 without a memory
+// access -- a branch-free way to switch a burst of loads off (see conv_wino4_kernel: a branch around the burst makes the
+// compiler's s_waitcnt bookkeeping conservative and the burst synchronous)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t nef_rsrc_n(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
 __device__ __forceinline__ float nef_buf_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }

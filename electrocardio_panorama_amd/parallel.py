@@ -8,10 +8,30 @@ import torch
 import torch.distributed as dist
 
 
+_HOOK_VARS = ("NEF_SHARE_GPU", "NEF_DIST_BACKEND", "NEF_DIST_FORCE")
+_warned = []
+
+
+def _hook(name):
+    """Test hooks (two ranks on one GPU, gradients over gloo, a one-rank RCCL group) are honoured ONLY under
+    NEF_TEST_HOOKS=1, so that a stray variable cannot put a production run on gloo; without the guard they are ignored
+    with one warning."""
+    v = os.environ.get(name)
+    if v is None:
+        return None
+    if os.environ.get("NEF_TEST_HOOKS") == "1":
+        return v
+    if name not in _warned:
+        _warned.append(name)
+        import sys
+        sys.stderr.write(f"[nefnet] {name}={v} ignored: test hooks need NEF_TEST_HOOKS=1\n")
+    return None
+
+
 def local_rank():
     """Index of the HIP device this process drives: torchrun's LOCAL_RANK (0 when ranks share one GPU under the
     NEF_SHARE_GPU test hook, or when not launched by torchrun)."""
-    if os.environ.get("NEF_SHARE_GPU") == "1":
+    if _hook("NEF_SHARE_GPU") == "1":
         return 0
     return int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -28,12 +48,13 @@ def init_from_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    force = os.environ.get("NEF_DIST_FORCE") == "1"      # test hook: a 1-rank group still goes through RCCL
+    force = _hook("NEF_DIST_FORCE") == "1"      # test hook: a 1-rank group still goes through RCCL
+    share = _hook("NEF_SHARE_GPU") == "1"
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("NEF_DIST_BACKEND")          # test hook: "gloo" lets two ranks share one GPU
-        if os.environ.get("NEF_SHARE_GPU") == "1":
+        backend = _hook("NEF_DIST_BACKEND")          # test hook: "gloo" lets two ranks share one GPU
+        if share:
             local = 0
         if torch.cuda.is_available() and backend != "gloo":
             torch.cuda.set_device(local)
@@ -43,7 +64,7 @@ def init_from_env():
             if torch.cuda.is_available():
                 torch.cuda.set_device(local)
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    elif os.environ.get("NEF_SHARE_GPU") == "1":
+    elif share:
         local = 0
     return rank, world, local
 

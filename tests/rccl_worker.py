@@ -16,6 +16,7 @@ from electrocardio_panorama_amd.solver.optim_scheduler import get_optimizer  # n
 from test_model_gpu import make_cfg                                          # noqa: E402
 
 os.environ["NEF_DIST_FORCE"] = "1"
+os.environ["NEF_TEST_HOOKS"] = "1"
 rank, world, local = parallel.init_from_env()
 assert dist.is_initialized() and dist.get_backend() == "nccl", dist.get_backend()
 dev = torch.device("cuda", local)

@@ -1,7 +1,7 @@
 """Data parallelism with world_size 2 on the REAL train step (BASELINE configs[2] semantics).
 
 The test box has one GPU, so two ranks share cuda:0 and exchange gradients over gloo (test hooks NEF_SHARE_GPU /
-NEF_DIST_BACKEND of parallel.init_from_env); everything else -- sharding, per-shard BatchNorm, the flat-gradient
+NEF_DIST_BACKEND of parallel.init_from_env, honoured only under NEF_TEST_HOOKS=1); everything else -- sharding, per-shard BatchNorm, the flat-gradient
 all-reduce folded into the fused SGD kernel, rank-0 buffers, bench.py's multi-rank branch -- is the production path.
 The oracle side restates the reference's nn.DataParallel semantics (oracle.dp_train_step)."""
 import json
@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _env(port):
     return dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", NEF_DIST_BACKEND="gloo",
-                NEF_SHARE_GPU="1", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                NEF_SHARE_GPU="1", NEF_TEST_HOOKS="1", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
 
 
 @pytest.fixture(scope="module")
@@ -171,3 +171,20 @@ def test_bench_two_ranks_prints_one_json_line():
     assert line["value"] > 0 and abs(line["value"] - 16 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-3 * line["value"]
     assert line["cpu_baseline"] is None and np.isfinite(line["final_loss"])
     assert line["allreduce_ms_exposed"] is not None and line["allreduce_ms_exposed"] >= 0
+
+
+def test_bench_self_launches_two_ranks():
+    """Plain `python bench.py --gpus 2` (no torchrun environment -- how the round driver calls it): bench.py re-executes
+    itself under torch.distributed.run and rank 0 still prints exactly one JSON line for the whole job."""
+    env = _env(0)
+    for k in ("WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--len", "1000", "--leads", "3"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
+    assert line["value"] > 0 and line["allreduce_ms_exposed"] is not None and np.isfinite(line["final_loss"])
