@@ -11,9 +11,10 @@ fixed), gradients are summed with ONE RCCL all-reduce of the flat gradient buffe
 forward + losswrapper + backward + fused momentum-SGD on inputs already resident in HBM.  Rank 0 prints one
 JSON line.  At N=1 the line also carries the CPU baseline (the torch-CPU oracle timed on this box's host cores on
 a bounded sample of the same workload), the roofline of the dominant kernel (the k=7 grouped-conv MFMA kernel: EXECUTED
-matrix-core flops over its HIP-event time on the launch stream, against the fp32 MFMA peak) and `secondary`: the two
-inference configs of BASELINE.json (configs[3] panorama sweep, configs[4] per-GPU share of gen_ecg) timed after the
-train step.
+matrix-core flops over its HIP-event time on the launch stream, against the fp32 MFMA peak; `roofline.whole_step`: the
+executed matrix work of the WHOLE step over ms_per_step against the same peak) and `secondary`: the reference's own training
+shape (batch 32, 3 leads, len 512) eager and graph-replayed, and the two inference configs of BASELINE.json (configs[3] panorama
+sweep, configs[4] per-GPU share of gen_ecg), all timed after the train step.
 """
 import argparse
 import json
@@ -122,6 +123,7 @@ def secondary(dev):
                 "hbm_frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 4), "mfma_frac": round(flops / dt / 1e12 / FP16_MFMA_PEAK_TFLOPS, 4)}
 
     out = {}
+    out["reference-native 32x3x512"] = native_shape(dev)
     # configs[3]
     B, V, L, Q = 1024, 1, 512, 360
     torch.manual_seed(123)
@@ -169,6 +171,54 @@ def secondary(dev):
     del m, res, z1, z2
     torch.cuda.empty_cache()
     return out
+
+
+def native_shape(dev, steps=40, warmup=10):
+    """The only shape the reference itself trains (codes/config/nef_net.yml:8-13, codes/train_net.py:27-28: batch 32, 3 leads,
+    beats of 512 samples): the train step eager and replayed as one captured hipGraph (graph.GraphedTrainStep -- what
+    Solver.run_one_epoch uses at this size).  Launch-bound: ~250 launches for ~0.8 ms of matrix work."""
+    from electrocardio_panorama_amd import synth
+    from electrocardio_panorama_amd.graph import GraphedTrainStep
+    from electrocardio_panorama_amd.network import build_loss, build_model
+    from electrocardio_panorama_amd.solver.optim_scheduler import get_optimizer
+    from electrocardio_panorama_amd.utils import seed_torch
+    B, V, L = 32, 3, 512
+    cfg = make_cfg(V)
+    res = {"workload": f"Nef-Net train step at the reference's own training shape: batch={B}, {V}-lead, len={L}, Standin losses "
+                       f"on, dropout on", "steps": steps}
+    meta = synth.make_batch(B, V, L, seed=123)
+    data, rois, in_theta, tgt_view, tgt_theta = (torch.from_numpy(np.ascontiguousarray(meta[k])).to(dev) for k in
+                                                 ("data", "rois", "input_theta", "target_view", "target_theta"))
+    tgt_view = tgt_view.unsqueeze(1)
+    for mode in ("eager", "graph"):
+        seed_torch(cfg.seed)
+        model = build_model(cfg).float().to(dev).train()
+        lossf = build_loss(cfg)
+        if mode == "graph":
+            g = GraphedTrainStep(model, cfg)
+            step = lambda: g(data, in_theta, tgt_theta, rois, tgt_view)[0]
+        else:
+            optim = get_optimizer(cfg, model.parameters())
+
+            def step():
+                o, sp, sl = model(data, in_theta, tgt_theta, rois, phase="train")
+                ls = lossf(o, sp, sl, tgt_view, cfg)
+                ls[0].backward()
+                optim.step()
+                optim.zero_grad()
+                return ls[0]
+        for _ in range(warmup):
+            loss = step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        res[mode] = {"ms_per_step": round(dt * 1e3, 3), "samples_per_s": round(B / dt, 1), "final_loss": float(loss)}
+        del model
+    torch.cuda.empty_cache()
+    return res
 
 
 def _config_name(V, B, L):
@@ -312,7 +362,7 @@ def main():
         from electrocardio_panorama_amd import engine as _eng
         ex_fwd = 9.0 / 14.0 if ops.WINOGRAD else 1.0
         ex_bd = (13.0 / 28.0 if _eng._bwd_f4(7) else 10.0 / 14.0) if ops.WINOGRAD else 1.0
-        ex_bw = (13.0 / 28.0 if ops.WINO_BW7 else 10.0 / 14.0) if ops.WINOGRAD else 1.0
+        ex_bw = 13.0 / 28.0 if (ops.WINOGRAD and ops.WINO_BW7) else 1.0
         roof = None
         if times:
             avg_ms = sum(times) / len(times)
@@ -354,6 +404,28 @@ def main():
                         "conv_wino4_kernel<7,4,0> bwd-data F(4,4)+F(4,3) on taps 4+3": _serial("conv_bwd_data", ex_bd),
                         "conv_bww_glds_kernel<7,.,4> + <7,.,5>: taps 4+3 as two launches, transposed F(4,4) + F(3,4), tiles by LDS-DMA (+ the split-K reduce)": _serial("conv_bwd_weight", ex_bw)},
                     "side_stream": os.environ.get("NEF_SIDE_STREAM", "auto") != "0"}
+        # Whole step against the same roof: EXECUTED matrix-core flops of every tagged conv launch of one (single-stream,
+        # untimed) breakdown step -- algorithmic 2*B*Cout*T*Cin_g*K times the executed fraction ops.EXEC_FRAC recorded for
+        # the form that ran -- over the TIMED ms_per_step.  The stem, the transposed conv and the theta MLPs are not in the sum
+        # (< 1 % of the step's matrix work), so the figure is a slight under-count.
+        ex_flops = alg_flops = 0.0
+        for tag, s_, e_ in prof_all:
+            if tag[0] in ("conv_fwd", "conv_bwd_data", "conv_bwd_weight"):
+                _, k_, g_, cig_, cog_, b_, t_ = tag
+                f_ = 2.0 * b_ * g_ * cog_ * t_ * cig_ * k_
+                alg_flops += f_
+                ex_flops += f_ * ops.EXEC_FRAC.get(tag, 1.0)
+        ex_flops /= max(extra_steps, 1)
+        alg_flops /= max(extra_steps, 1)
+        if roof is not None and ex_flops > 0:
+            ms_step = 1e3 * dt / args.steps
+            roof["whole_step"] = {
+                "executed_mfma_TFLOP_per_step": round(ex_flops / 1e12, 4),
+                "algorithmic_TFLOP_per_step": round(alg_flops / 1e12, 4),
+                "executed_TFLOPs": round(ex_flops / ms_step / 1e9, 2),
+                "frac": round(ex_flops / ms_step / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "floor_ms_at_peak": round(ex_flops / FP32_MFMA_PEAK_TFLOPS / 1e9, 3),
+                "basis": "executed matrix-core flops of the tagged conv launches of one step / timed ms_per_step / fp32 MFMA peak"}
         by_kernel = {}
         hbm = {}
         for tag, s, e in prof_all:

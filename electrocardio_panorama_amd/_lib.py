@@ -57,8 +57,6 @@ SIGNATURES = {
     "nef_conv_bwd_weight_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "nef_conv_bwd_weight": (i32, [p, i64, i64, p, i64, i64, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32, i32, p]),
     "nef_conv_bwd_weight_pro": (i32, [p, i64, i64, p, p, i32, i32, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32, i32, p]),
-    "nef_conv_bwd_weight_wino": (i32, [p, i64, i64, p, i64, i64, p, p, i32, i32, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32,
-                                       i32, p]),
     "nef_conv_bwd_weight_wino4": (i32, [p, i64, i64, p, i64, i64, p, p, i32, i32, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32,
                                         i32, p]),
     "nef_chan_sum_ws_bytes": (sz, [i32]),

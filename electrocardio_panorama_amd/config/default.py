@@ -42,6 +42,9 @@ _DEFAULTS = {
         "loss_using": [1, 2, 3],
         "part_loss_no_grad": False,
         "loss_factor": [1, 1, 1],
+        # train step as one captured hipGraph (graph.GraphedTrainStep): None = automatic, i.e. when the step is bound by launch
+        # issue (fewer than 2^24 latent elements B*128V*L/4 -- the reference's own batch 32 x 512 samples is); True / False force it
+        "graph": None,
     },
 }
 

@@ -457,7 +457,11 @@ int launch(const float* x, int64_t x_bs, int64_t x_gs, const float* gy, int64_t 
         int resident = __atomic_load_n(&resident_dev[dev & 63], __ATOMIC_ACQUIRE);
         if (resident == 0) {
             int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu <= 0) per_cu = 2;
+            // cached per device: priced with the LARGEST request this instantiation can make (8 passes of prologue table), so
+            // the cached figure holds for every later call whatever its n_pass
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_tiles + 8 * 128 * sizeof(float)) != hipSuccess ||
+                per_cu <= 0)
+                per_cu = 2;
             resident = per_cu * nef_cu_count();
             __atomic_store_n(&resident_dev[dev & 63], resident, __ATOMIC_RELEASE);
         }

@@ -2320,7 +2320,7 @@ constexpr int CHAN_SUM_SPLIT = 16;
 
 extern "C" {
 
-int nef_abi_version(void) { return 11; }
+int nef_abi_version(void) { return 12; }
 
 int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                     nef_stream_t stream) {
@@ -2553,49 +2553,6 @@ int nef_conv_bwd_weight_pro(const float* x, int64_t x_bs, int64_t x_gs, const fl
     return nef_launch_status();
 }
 
-int nef_conv_bwd_weight_wino(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
-                             int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
-                             const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B, int T,
-                             int G, int Cin_g, int Cout_g, int K, nef_stream_t stream) {
-    NEF_ENTER();
-    NEF_REQUIRE(x && gy && gw && ws, NEF_E_NULL);
-    NEF_REQUIRE(B > 0 && T >= WT && T % 2 == 0 && G > 0 && (K == 3 || K == 7), NEF_E_SHAPE);
-    NEF_REQUIRE(pro_mode >= 0 && pro_mode <= 3 && (K == 3 || pro_mode == 0) && !(pro_mode && in_scale), NEF_E_UNSUPPORTED);
-    NEF_REQUIRE(!(pro_mode & 1) || (pro_a && pro_b && pro_Bp > 0), NEF_E_NULL);
-    BwdWeightPlan p;
-    NEF_REQUIRE(plan_bwd_weight(B, T, G, Cin_g, Cout_g, K, &p, pro_mode, 1), NEF_E_SHAPE);
-    NEF_REQUIRE(p.ct.nseg == 1, NEF_E_SHAPE);
-    const size_t need = (size_t)p.S * G * K * Cout_g * Cin_g * sizeof(float);
-    NEF_REQUIRE(ws_bytes >= need, NEF_E_WORKSPACE);
-    hipStream_t st = (hipStream_t)stream;
-    float* wsf = (float*)ws;
-    int rc = NEF_E_UNSUPPORTED;
-#define NEF_BWW(KK, WCO, TCI, PRO)                                                                                     \
-    rc = launch_bwd_weight<KK, WCO, TCI, PRO, 1>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G, \
-                                                 Cin_g, Cout_g, st, pro_a, pro_b, pro_Bp)
-#define NEF_BWW_MODE(WCO, TCI)                                                                                         \
-    {                                                                                                                 \
-        if (pro_mode == 0) NEF_BWW(3, WCO, TCI, 0);                                                                   \
-        else if (pro_mode == 1) NEF_BWW(3, WCO, TCI, 1);                                                              \
-        else if (pro_mode == 2) NEF_BWW(3, WCO, TCI, 2);                                                              \
-        else NEF_BWW(3, WCO, TCI, 3);                                                                                 \
-    }
-    if (K == 7) {
-        if (p.wco == 4) NEF_BWW(7, 4, 1, 0); else NEF_BWW(7, 2, 1, 0);
-    } else if (p.wco == 4) {
-        if (p.tci == 2) NEF_BWW_MODE(4, 2) else NEF_BWW_MODE(4, 1)
-    } else {
-        NEF_BWW_MODE(2, 1)
-    }
-#undef NEF_BWW_MODE
-#undef NEF_BWW
-    if (rc != NEF_OK) return rc;
-    const int64_t n = (int64_t)G * K * Cout_g * Cin_g;
-    hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3(nef_stream_grid(n, 256)), dim3(256), 0, st, wsf, gw, G, Cout_g,
-                       Cin_g, K, p.S);
-    return nef_launch_status();
-}
-
 // conv_bww_glds.hip: the same forms with the tiles streamed by LDS-DMA through a ring of LDS buffers
 __attribute__((visibility("hidden"))) bool nef_bww_glds_ok(int B, int T, int Cig, int Cog, int K, int pro_mode, int pro_Bp, bool in_scale);
 __attribute__((visibility("hidden"))) int nef_bww_glds_launch(const float* x, int64_t x_bs, int64_t x_gs, const float* gy, int64_t gy_bs, int64_t gy_gs, float* ws,
@@ -2612,10 +2569,7 @@ int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const 
     NEF_REQUIRE(pro_mode >= 0 && pro_mode <= 3 && (K == 3 || pro_mode == 0) && !(pro_mode && in_scale), NEF_E_UNSUPPORTED);
     NEF_REQUIRE(!(pro_mode & 1) || (pro_a && pro_b && pro_Bp > 0), NEF_E_NULL);
     BwdWeightPlan p;
-#ifndef NEF_BW7_SPLIT
-#define NEF_BW7_SPLIT 1      // 0: the round-2 form (4 + 3 inside one wave, F(4,2) + F(3,2))
-#endif
-    NEF_REQUIRE(plan_bwd_weight(B, T, G, Cin_g, Cout_g, K, &p, pro_mode, K == 7 ? (NEF_BW7_SPLIT ? 4 : 1) : 2), NEF_E_SHAPE);
+    NEF_REQUIRE(plan_bwd_weight(B, T, G, Cin_g, Cout_g, K, &p, pro_mode, K == 7 ? 4 : 2), NEF_E_SHAPE);
     NEF_REQUIRE(p.ct.nseg == 1, NEF_E_SHAPE);
     const size_t need = (size_t)p.S * G * K * Cout_g * Cin_g * sizeof(float);
     NEF_REQUIRE(ws_bytes >= need, NEF_E_WORKSPACE);
@@ -2632,7 +2586,7 @@ int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const 
         else if (pro_mode == 2) NEF_BW4(WCO, 2);                                                                      \
         else NEF_BW4(WCO, 3);                                                                                         \
     }
-    if (NEF_BW7_SPLIT && nef_bww_glds_ok(B, T, Cin_g, Cout_g, K, pro_mode, pro_Bp, in_scale != nullptr)) {
+    if (nef_bww_glds_ok(B, T, Cin_g, Cout_g, K, pro_mode, pro_Bp, in_scale != nullptr)) {
         int S_used = 0;
         if (K == 3) {
             rc = nef_bww_glds_launch(x, x_bs, x_gs, gy, gy_bs, gy_gs, wsf, B, T, G, Cin_g, Cout_g, 3, 0, pro_a, pro_b, pro_mode,
@@ -2645,7 +2599,7 @@ int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const 
                                          p.S, S_used, &S_used, st);
         }
         p.S = S_used;
-    } else if (K == 7 && NEF_BW7_SPLIT) {      // taps split 4 + 3 across two launches: transposed F(4,4), then transposed F(3,4)
+    } else if (K == 7) {      // taps split 4 + 3 across two launches: transposed F(4,4), then transposed F(3,4)
         if (p.wco == 4) {
             rc = launch_bwd_weight<7, 4, 1, 0, 4>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G, Cin_g,
                                                   Cout_g, st);
@@ -2659,13 +2613,6 @@ int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const 
                 rc = launch_bwd_weight<7, 2, 1, 0, 5>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G,
                                                       Cin_g, Cout_g, st, nullptr, nullptr, 1, p.S);
         }
-    } else if (K == 7) {       // seven taps split 4 + 3: transposed F(4,2) + F(3,2), 9 instead of 10 MFMAs per 4 columns
-        if (p.wco == 4)
-            rc = launch_bwd_weight<7, 4, 1, 0, 3>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G,
-                                                  Cin_g, Cout_g, st);
-        else
-            rc = launch_bwd_weight<7, 2, 1, 0, 3>(p, x, x_bs, x_gs, in_scale, sc_bs, sc_gs, gy, gy_bs, gy_gs, wsf, B, T, G,
-                                                  Cin_g, Cout_g, st);
     } else if (p.wco == 4) NEF_BW4_MODE(4) else NEF_BW4_MODE(2)
 #undef NEF_BW4_MODE
 #undef NEF_BW4

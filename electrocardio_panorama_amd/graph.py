@@ -21,10 +21,18 @@ from . import engine, ops
 
 
 class GraphedTrainStep:
-    def __init__(self, model, cfg, lr=None, momentum=0.9):
+    def __init__(self, model, cfg, lr=None, momentum=0.9, optimizer=None):
+        """`optimizer`: a solver.optim_scheduler.FusedSGD over model.parameters() -- the graph then steps THAT optimiser's flat
+        parameter / momentum buffers (so checkpoints, a learning-rate scheduler and eager steps in between see one state) and
+        takes lr / momentum from its parameter group; without it the stepper owns its buffers (lr / momentum arguments)."""
         if cfg.DATA.noise:
             raise NotImplementedError("cfg.DATA.noise adds a host-side tensor op between model and loss")
         self.model, self.cfg = model, cfg
+        self.optimizer = optimizer
+        if optimizer is not None:
+            if len(optimizer.param_groups) != 1 or not hasattr(optimizer, "_flat"):
+                raise NotImplementedError("the graphed step drives FusedSGD with one parameter group")
+            lr, momentum = optimizer.param_groups[0]["lr"], optimizer.param_groups[0]["momentum"]
         self.lr = float(cfg.SOLVER.lr if lr is None else lr)
         self.mu = float(momentum)
         self.factors = tuple(float(f) for f in cfg.SOLVER.loss_factor)
@@ -43,6 +51,19 @@ class GraphedTrainStep:
         """Parameters become views of one flat buffer.  Done once: the live-parameter set does not depend on the input
         shape, so later captures reuse the buffers -- and with them the momentum."""
         named = dict(self.model.named_parameters())
+        if self.optimizer is not None:
+            # the optimiser's own flat buffers (FusedSGD._build: parameters become views of fl["p"], the momentum views of
+            # fl["buf"] live in optimizer.state): nothing to copy, nothing to keep in sync
+            opt, params = self.optimizer, [named[k] for k in live]
+            fl = opt._flat.get(0)
+            if fl is None or fl["ids"] != [id(p) for p in params] or any(
+                    p.data.data_ptr() < fl["p"].data_ptr() or
+                    p.data.data_ptr() >= fl["p"].data_ptr() + fl["p"].numel() * 4 for p in params):
+                opt._build(0, params)
+                fl = opt._flat[0]
+            self.live = live
+            self.flat_p, self.flat_g, self.flat_buf = fl["p"], fl["g"], fl["buf"]
+            return
         if self.live == live and self.flat_p is not None and all(
                 named[k].data.data_ptr() >= self.flat_p.data_ptr() and
                 named[k].data.data_ptr() < self.flat_p.data_ptr() + 4 * self.flat_p.numel() for k in live):
@@ -91,8 +112,11 @@ class GraphedTrainStep:
 
     def _build(self, data, in_theta, q_theta, rois, target):
         dev = data.device
-        slot = dict(data=torch.empty_like(data, dtype=torch.float32), in_theta=torch.empty_like(in_theta, dtype=torch.float32),
-                    q_theta=torch.empty_like(q_theta, dtype=torch.float32), rois=torch.empty_like(rois, dtype=torch.int64),
+        # static input buffers: contiguous whatever the caller's strides are (a sharded loader hands out slices)
+        slot = dict(data=torch.empty(data.shape, device=dev, dtype=torch.float32),
+                    in_theta=torch.empty(in_theta.shape, device=dev, dtype=torch.float32),
+                    q_theta=torch.empty(q_theta.shape, device=dev, dtype=torch.float32),
+                    rois=torch.empty(rois.shape, device=dev, dtype=torch.int64),
                     target=torch.empty(data.shape[0], 1, data.shape[2], device=dev, dtype=torch.float32))
         self._use(slot)
         if self.choice_dev is None:
@@ -106,6 +130,11 @@ class GraphedTrainStep:
         # eager probe (no update): which parameters are live, and every kernel variant gets its one-time setup
         saved = {k: v.clone() for k, v in self.model.named_buffers()}
         grads = self._fwd_bwd()
+        if self.world > 1:                   # the eager probe may have started an early gradient bucket: retire it
+            from . import parallel
+            pend = parallel.take_early()
+            if pend is not None:
+                pend["work"].wait()
         self._flatten([k for k, _ in self.model.named_parameters() if grads.get(k) is not None])
         for k, v in self.model.named_buffers():
             v.copy_(saved[k])
@@ -180,6 +209,14 @@ class GraphedTrainStep:
 
     def __call__(self, data, in_theta, q_theta, rois, target):
         """One train step; returns the device tensor [loss, f0*l1, f1*l2, f2*l3] (valid in stream order)."""
+        if self.optimizer is not None:
+            g = self.optimizer.param_groups[0]
+            if float(g["lr"]) != self.lr or float(g["momentum"]) != self.mu:      # a scheduler stepped: re-capture
+                self.lr, self.mu = float(g["lr"]), float(g["momentum"])
+                self.slots.clear()
+            fl = self.optimizer._flat.get(0)
+            if self.flat_p is not None and (fl is None or fl["p"] is not self.flat_p):   # e.g. optimizer.load_state_dict
+                self.slots.clear()
         shape = (tuple(data.shape), tuple(in_theta.shape))
         slot = self.slots.get(shape)
         if slot is None:

@@ -33,6 +33,20 @@ _WS = {}
 # recorded on the stream the kernel is launched on, so their difference is that kernel's device time.
 PROFILE = None
 PROFILE_ONLY = None     # optional predicate(tag): bracket only these launches (every event pair costs ~3 us of GPU idle)
+# matrix-core multiplies EXECUTED per algorithmic multiply of a tagged conv launch (tag -> fraction), filled while PROFILE
+# is on: 1 direct; K=3: 2/3 through F(2,3), 1/2 through F(4,3) / the transposed F(3,4); K=7: 9/14 forward (F(2,4)+F(2,3)),
+# 13/28 backward-data (F(4,4)+F(4,3)) and weight gradient (transposed F(4,4)+F(3,4)), 10/14 for the 3+3+1 forms
+EXEC_FRAC = {}
+
+
+def _exec_frac(K, form):
+    """form: 0 direct, 1 the F(2,.) family, 2 the F(4,.) family (forward / backward-data: nef_conv_args.wino; weight
+    gradient: 1 = transposed F(3,2), 2 = the round-2/3 forms ops.conv_bwd_weight calls `wino=4`)."""
+    if not form or K == 1:
+        return 1.0
+    if K == 3:
+        return 2.0 / 3.0 if form == 1 else 0.5
+    return 9.0 / 14.0 if form == 1 else 13.0 / 28.0
 
 
 def _timed(tag):
@@ -195,10 +209,9 @@ WINOGRAD = _WV != "0"
 # a heavily cancelling gradient -- by 3.7e-4 over the 3-step reference trajectory (bar 2e-4), and the fixed-up kernel
 # was no faster than F(2,3) (1.31 vs 1.33 ms on the K=7 conv).
 WINO_FWD = 1 if _WV in ("1", "2") else 2
-# K=3 weight gradients through the transposed F(3,4) (6 MFMAs per 8 columns instead of F(3,2)'s 8); NEF_BW_WINO4=0: F(3,2)
+# Winograd weight gradients (nef_conv_bwd_weight_wino4): K=3 through the transposed F(3,4), K=7 with the taps split 4 + 3 over
+# two launches (transposed F(4,4) + F(3,4)).  NEF_BW_WINO4=0 / NEF_BW7_F42=0 put K=3 / K=7 back on the direct kernel.
 WINO_BW4 = os.environ.get("NEF_BW_WINO4", "1") == "1" and _WV not in ("1", "2")
-# K=7 weight gradients with the taps split 4 + 3 (two launches: transposed F(4,4) + F(3,4), 13 MFMAs per 8 columns; a build
-# with -DNEF_BW7_SPLIT=0 runs the round-2 form, transposed F(4,2) + F(3,2) in one launch); 0: 3 + 3 + 1 through F(3,2)
 WINO_BW7 = os.environ.get("NEF_BW7_F42", "1") == "1" and _WV not in ("1", "2")
 _WINO_PLANES = {(1, 3): 4, (1, 7): 10, (2, 3): 6, (2, 7): 13}
 
@@ -336,6 +349,8 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
         a.bnb_Bp, a.bnb_slots = bnb[5], _p(bnb[6][0])
         a.bnb_up = int(bnb[7]) if len(bnb) > 7 else 0
     ev = _timed((role, K, xv.G, xv.Cg, Cog, xv.B, T_out))
+    if ev is not None:
+        EXEC_FRAC[(role, K, xv.G, xv.Cg, Cog, xv.B, T_out)] = _exec_frac(K, a.wino)
     _lib.check(L.nef_conv_fwd(C.byref(a), _stream()), "nef_conv_fwd")
     if ev is not None:
         ev.record()
@@ -343,9 +358,9 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
 
 
 def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None):
-    """gw [G*Cog, Cig, K] for y = conv(prologue(x) * in_scale, w); `pro` as in conv().  `wino`: force / forbid the
-    Winograd F(3,2) form (default: wherever it applies, see WINOGRAD); 4 = the transposed F(3,4) (K == 3) resp. the
-    4 + 3 split through F(4,2) + F(3,2) (K == 7)."""
+    """gw [G*Cog, Cig, K] for y = conv(prologue(x) * in_scale, w); `pro` as in conv().  `wino`: force (True / 4) or forbid
+    (False) the transposed-Winograd form -- F(3,4) for K == 3, the 4 + 3 split through F(4,4) + F(3,4) for K == 7; default:
+    wherever it applies (see WINOGRAD, WINO_BW4, WINO_BW7)."""
     L = _lib.load()
     B, T, G, Cig, Cog = xv.B, gyv.T, xv.G, xv.Cg, gyv.Cg
     gw = torch.empty(G * Cog, Cig, K, device=xv.t.device, dtype=torch.float32)
@@ -356,15 +371,16 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None):
     sc, sc_bs, sc_gs = (None, 0, 0) if in_scale is None else (_p(in_scale[0]), in_scale[1], in_scale[2])
     ev = _timed(("conv_bwd_weight", K, G, Cig, Cog, B, T))
     if wino is None:
-        wino = WINOGRAD and K in (3, 7) and T % 2 == 0 and T >= 64 and not (K == 7 and pro is not None and pro[0])
-        if wino and ((K == 3 and WINO_BW4) or (K == 7 and WINO_BW7)):
-            wino = 4
+        wino = (WINOGRAD and ((K == 3 and WINO_BW4) or (K == 7 and WINO_BW7)) and T % 2 == 0 and T >= 64
+                and not (K == 7 and pro is not None and pro[0]))
+    wino = 4 if wino else False
+    if ev is not None:
+        EXEC_FRAC[("conv_bwd_weight", K, G, Cig, Cog, B, T)] = _exec_frac(K, 2) if wino else 1.0
     if wino:
         pm, pa, pb, pbp = (pro[0], _p(pro[1]), _p(pro[2]), pro[3]) if (pro is not None and pro[0]) else (0, None, None, 1)
-        fn = L.nef_conv_bwd_weight_wino4 if wino == 4 else L.nef_conv_bwd_weight_wino
-        _lib.check(fn(xv.ptr, xv.bs, xv.gs, sc, sc_bs, sc_gs, pa, pb, pm, pbp, gyv.ptr, gyv.bs,
+        _lib.check(L.nef_conv_bwd_weight_wino4(xv.ptr, xv.bs, xv.gs, sc, sc_bs, sc_gs, pa, pb, pm, pbp, gyv.ptr, gyv.bs,
                                               gyv.gs, _p(gw), _p(ws), n, B, T, G, Cig, Cog, K, _stream()),
-                   "nef_conv_bwd_weight_wino")
+                   "nef_conv_bwd_weight_wino4")
     elif pro is not None and pro[0]:
         assert in_scale is None
         _lib.check(L.nef_conv_bwd_weight_pro(xv.ptr, xv.bs, xv.gs, _p(pro[1]), _p(pro[2]), pro[0], pro[3], gyv.ptr, gyv.bs,
@@ -905,7 +921,9 @@ def bn_relu_bwd_outconv(gout, out, wout, x, mean, invstd, a, b, P):
     gs = torch.empty(Ct, device=x.device, dtype=torch.float32)
     n = L.nef_bn_bwd_outconv_ws_bytes(P, N // P, Ct, Ln)
     ws = workspace(n, x.device)
-    ev = _hbm("bn_relu_bwd_outconv", gout, out, x, gx)
+    # a two-pass pair by construction (the reduction pass reads x, the apply pass reads it again and writes gx): priced by
+    # what the pair has to move -- 2 reads + 1 write of the [N, C, L] tensor (+ the small gout / out rows twice)
+    ev = _hbm("bn_relu_bwd_outconv", gout, out, x, gout, out, x, gx)
     _lib.check(L.nef_bn_relu_bwd_outconv(_p(gout), _p(out), _p(wout), _p(x), _p(mean), _p(invstd), _p(a), _p(b), _p(gx),
                                          _p(gg), _p(gb), _p(gs), _p(ws), n, P, N // P, Ct, Ln, _stream()),
                "nef_bn_relu_bwd_outconv")

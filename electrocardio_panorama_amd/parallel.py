@@ -113,17 +113,33 @@ def reduce_flat_grads(grads, flat):
 # Early bucket: the gradients that are final long before the backward pass ends (everything except the per-lead
 # encoder's: 71 % of the bytes at 3 leads) are summed across ranks WHILE the encoder blocks are still being
 # back-propagated, so only the encoder bucket's all-reduce is exposed at the optimiser step.
-_EARLY = {"pending": None}
+_EARLY = {"pending": None, "backwards": 0}
 TIMING = None        # bench.py: a list collecting (start_event, end_event) around the EXPOSED part of the step's all-reduce
+# The early bucket makes engine.backward COLLECTIVE (every rank must run the same backward passes in the same order), so it is
+# opt-in: FusedSGD -- the consumer that knows how to line the bucket up with its flat buffer -- switches it on when it is built.
+# NEF_EARLY_REDUCE=0 keeps it off (one all-reduce per step).
+EARLY_ENABLED = False
+
+
+def enable_early_reduce():
+    global EARLY_ENABLED
+    EARLY_ENABLED = os.environ.get("NEF_EARLY_REDUCE", "1") != "0"
 
 
 def early_reduce(P, grads, side_stream=None):
     """Called by engine.backward in front of the encoder blocks: packs every gradient computed so far (parameter order)
     into one buffer and starts its sum all-reduce without blocking the launching stream.  `side_stream`: the stream the
-    weight gradients were issued on (the collective is ordered behind it).  No-op for a single process."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    weight gradients were issued on (the collective is ordered behind it).  No-op for a single process, under graph capture,
+    and unless an optimiser opted in (enable_early_reduce).
+    The bucket is a SNAPSHOT of this backward pass: it is only valid for an optimiser step that follows exactly one backward.
+    A second backward before the bucket was taken (gradient accumulation, a skipped step) starts no new collective and
+    poisons the pending one -- take_early() then retires it and the optimiser falls back to its single all-reduce."""
+    if not EARLY_ENABLED or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return
     if torch.cuda.is_current_stream_capturing():
+        return
+    _EARLY["backwards"] += 1
+    if _EARLY["backwards"] > 1:
         return
     names = [n for n in P if grads.get(n) is not None]
     if not names:
@@ -140,7 +156,12 @@ def early_reduce(P, grads, side_stream=None):
 
 
 def take_early():
-    pend, _EARLY["pending"] = _EARLY["pending"], None
+    """The pending early bucket, or None.  A bucket that more than one backward pass ran against is waited for and dropped."""
+    pend, n = _EARLY["pending"], _EARLY["backwards"]
+    _EARLY["pending"], _EARLY["backwards"] = None, 0
+    if pend is not None and n != 1:
+        pend["work"].wait()
+        return None
     return pend
 
 

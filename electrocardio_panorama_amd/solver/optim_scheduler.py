@@ -16,6 +16,7 @@ class FusedSGD(torch.optim.Optimizer):
     def __init__(self, params, lr, momentum=0.9):
         super().__init__(params, dict(lr=lr, momentum=momentum))
         self._flat = {}      # group index -> dict(params, p, g, buf)
+        parallel.enable_early_reduce()      # this optimiser consumes engine.backward's early gradient bucket (see _reduce)
 
     def _build(self, gi, live):
         n = sum(p.numel() for p in live)
@@ -51,7 +52,12 @@ class FusedSGD(torch.optim.Optimizer):
         split = None
         if early is not None:
             k = len(names) - len(early["names"])
-            if k >= 0 and names[k:] == early["names"] and [p.numel() for p in live[k:]] == early["sizes"]:
+            # the bucket is the raw gradient of ONE backward pass: it stands in for p.grad only while p.grad is still that
+            # gradient -- a fresh tensor nobody has written to since autograd set it (clip_grad_norm_, loss-scale unscaling or
+            # accumulation into an existing .grad bump its version counter; parallel.take_early already dropped a bucket that
+            # saw two backward passes)
+            if (k >= 0 and names[k:] == early["names"] and [p.numel() for p in live[k:]] == early["sizes"]
+                    and all(p.grad._version == 0 for p in live[k:])):
                 split = sum(p.numel() for p in live[:k])
         if split is None:
             if early is not None:

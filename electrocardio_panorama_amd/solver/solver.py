@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .. import ops, parallel
+from .. import engine, ops, parallel
 from ..network import build_model, build_loss
 from ..utils import CheckPointer
 from .optim_scheduler import get_optimizer, get_lr_scheduler
@@ -222,6 +222,27 @@ class Solver:
             gen_num = int(super_mode[-1])
         return gen_num, whole
 
+    def _graphed_step(self, optim, data, keep):
+        """The hipGraph stepper for this batch, or None when the step runs eagerly: `cfg.SOLVER.graph` False, or 'auto' and the
+        step is GPU-bound (engine._SIDE_MIN_WORK), the per-view host lists are wanted (the graph returns losses only), the
+        model is not the plain Model_nefnet train path, DATA.noise, or the optimiser is not FusedSGD."""
+        mode = self.cfg.SOLVER.get('graph', None)
+        mode = 'auto' if mode is None or mode == 'auto' else bool(mode)
+        if mode is False or keep or self.cfg.DATA.noise:
+            return None
+        if not hasattr(optim, '_flat') or len(optim.param_groups) != 1:
+            return None
+        if type(self.model).__name__ != 'Model_nefnet' or os.environ.get('NEF_SOLVER_GRAPH', '1') == '0':
+            return None
+        B, V, L = data.shape
+        if mode == 'auto' and B * 128 * V * (L // 4) >= engine._SIDE_MIN_WORK:
+            return None
+        st = getattr(self, '_graph_stepper', None)
+        if st is None or st.optimizer is not optim:
+            from ..graph import GraphedTrainStep
+            st = self._graph_stepper = GraphedTrainStep(self.model, self.cfg, optimizer=optim)
+        return st
+
     def run_one_epoch(self, dl, phase, optim=None, collect_views=None):
         """solver.py:139-246.  `collect_views` (default: the Solver's setting) = also return the per-view host lists the
         reference returns (inputs, ground truth, predictions, rois); train() / val() only consume losses and metrics and
@@ -238,7 +259,13 @@ class Solver:
         for meta in dl:
             source_data, rois, input_theta, target_view, target_theta, noise = self._to_device(meta)
             rest_theta = torch.as_tensor(meta['rest_theta']).to(self.device) if 'rest_theta' in meta else None
-            if phase == 'train':
+            stepper = self._graphed_step(optim, source_data, keep) if phase == 'train' else None
+            if stepper is not None:
+                # forward + losswrapper + backward + SGD as ONE replayed hipGraph (one graph per batch shape: the final partial
+                # batch has its own; a learning-rate change re-captures); data parallel: the flat gradient travels as one
+                # all-reduce behind the replay (no early bucket under capture)
+                losses_s.add(stepper(source_data, input_theta, target_theta, rois, target_view))
+            elif phase == 'train':
                 out, shuf_p, shuf_l = self.model(source_data, input_theta, target_theta, rois, rest_theta=rest_theta,
                                                  phase='train')
                 if keep:

@@ -34,7 +34,7 @@ extern "C" {
 typedef void* nef_stream_t;
 
 /* ABI version of this header; bumped on any signature change. */
-int nef_abi_version(void);   /* 11 (round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
+int nef_abi_version(void);   /* 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
 
 /* ---------------------------------------------------------------------------------------------
  * Stem: Conv1d(1->128 per lead, k15, s2, p7, no bias) + ReLU + MaxPool1d(3,2,1), fused.
@@ -157,23 +157,19 @@ int nef_conv_bwd_weight_pro(const float* x, int64_t x_bs, int64_t x_gs, const fl
                             int pro_mode, int pro_Bp, const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws,
                             size_t ws_bytes, int B, int T, int G, int Cin_g, int Cout_g, int K, nef_stream_t stream);
 
-/* The same weight gradient (either form above: in_scale or the input prologue) through the transposed Winograd
- * algorithm F(3,2) -- 2/3 (K == 3) resp. 5/7 (K == 7, taps split 3 + 3 + 1) of the multiplies; fp32 multiplies and adds
- * on the matrix cores, results differ from the direct form by the rounding of the transforms.  Needs T even and
- * T >= 64; K == 7: pro_mode 0.  Workspace as for nef_conv_bwd_weight. */
-int nef_conv_bwd_weight_wino(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
-                             int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
-                             const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B, int T,
-                             int G, int Cin_g, int Cout_g, int K, nef_stream_t stream);
-/* ... and one size up.  K == 3: the transposed F(3,4), 6 multiplies per four columns -- 1/2 of the direct form's, 3/4 of
- * F(3,2)'s; transform entries up to 8 and 1/24 (the F(4,3) matrices of the forward kernels, roles exchanged): measured
- * rounding 1..6x the direct form's on the reduced sum.  K == 7 (pro_mode 0): the taps split 4 + 3 -- transposed F(4,2)
- * (points 0, 1, -1, 2, inf) + F(3,2): 9 instead of 10 multiplies per column pair.  Same arguments, workspace and
- * constraints.  Round 3: the seven taps split 4 + 3 across two launches (transposed F(4,4) + F(3,4): 13 multiplies per 8
- * columns), and wherever the channel counts are multiples of 64, T >= 64, in_scale == NULL and pro_mode has no upsampling
- * bit, the (gy, x) tiles are streamed by LDS-DMA through a ring of LDS buffers (csrc/conv_bww_glds.hip; same arithmetic,
- * same partial-sum layout, results differ from the register-staged kernel only by the summation order across splits).
- * The kernel never reads outside [x, x + (B-1)*x_bs + (G-1)*x_gs + Cin_g*T) resp. the same extent of gy. */
+/* The same weight gradient (either form above: in_scale or the input prologue) through the TRANSPOSED Winograd algorithm;
+ * fp32 multiplies and adds on the matrix cores, results differ from the direct form by the rounding of the transforms.
+ * Needs T even and T >= 64; K == 7: pro_mode 0.  Workspace as for nef_conv_bwd_weight.
+ *   K == 3: transposed F(3,4), 6 multiplies per four columns -- 1/2 of the direct form's; transform entries up to 8 and 1/24
+ *           (the F(4,3) matrices of the forward kernels, roles exchanged): measured rounding 1..6x the direct form's.
+ *   K == 7: the taps split 4 + 3 across TWO launches, transposed F(4,4) + transposed F(3,4): 13 multiplies per 8 columns
+ *           (direct: 28).
+ * Which kernel runs: the (gy, x) tiles are streamed by LDS-DMA through a ring of LDS buffers (csrc/conv_bww_glds.hip) when
+ * in_scale == NULL, both channel counts are multiples of 64, T >= 64, T % 4 == 0 if pro_mode has the upsampling bit, not
+ * both prologue bits at once, and at most 8 BatchNorm passes (B / pro_Bp); otherwise the register-staged kernel of
+ * csrc/conv_mfma.hip.  Same arithmetic and partial-sum layout; the two differ only by the summation order across splits.
+ * The kernel never reads outside [x, x + (B-1)*x_bs + (G-1)*x_gs + Cin_g*T) resp. the same extent of gy.
+ * (ABI <= 11 also had nef_conv_bwd_weight_wino, the transposed F(3,2): removed, this entry covers every shape it took.) */
 int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
                               int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
                               const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B, int T,

@@ -17,6 +17,22 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
+REPORT = []       # one-line facts the parity tests want in the run's tail whatever the verbosity (`conftest.REPORT.append`)
+
+
+def report(line):
+    REPORT.append(str(line))
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Printed after the result lines even under -q: which full-size batch really ran, its flat-gradient rel-L2 and the
+    number of replayed ties, the 3-step SGD trajectory's worst parameter, ... (captured `print`s of passing tests are not)."""
+    if REPORT:
+        terminalreporter.write_line("---- parity facts ----")
+        for line in REPORT:
+            terminalreporter.write_line(line)
+
+
 def pytest_sessionfinish(session, exitstatus):
     """NEF_TIE_LOG=<path>: dump the tie ratios the decision-replaying tests saw (tests/decisions.py: |pre-activation| / rms
     of every site with a flipped decision) -- the evidence behind decisions.TIE_REL (profiles/r03_tie_ratios.md)."""

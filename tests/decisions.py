@@ -15,6 +15,7 @@ FLAT_TOL, TENSOR_TOL = 1e-4, 1e-3
 # round-2 value was 1e-4.
 TIE_REL = 2e-5
 TIE_FRAC = 1e-5           # and flips must be rare: <= TIE_FRAC * numel + 2 per site
+DEGENERATE_FRAC = 1e-4    # cap on the exact-zero flips that are exempt from TIE_FRAC on the F(4,3)-forward sites
 
 
 def _pos(t):
@@ -108,6 +109,9 @@ def assert_flips_are_ties(dec):
         TIE_LOG.append((site, r["worst"] / max(r["rms"], 1e-30), r["flips"], r["numel"]))
         f4_forward = site.startswith("pass") or site.startswith("loss")
         assert r["flips"] - (r.get("degenerate", 0) if f4_forward else 0) <= TIE_FRAC * r["numel"] + 2, (site, r)
+        # the exemption is not a blank cheque: exact-zero flips are bounded too (largest share seen: 705 of 512 k = 1.4e-3 in
+        # one encoder block when F(4,3) was tried there; on the decoder sites of the shipped path <= 2e-5)
+        assert r.get("degenerate", 0) <= DEGENERATE_FRAC * r["numel"] + 2, (site, r)
         assert r["worst"] <= TIE_REL * max(r["rms"], 1e-30), (site, r)
 
 

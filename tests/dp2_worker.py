@@ -79,7 +79,20 @@ np.savez(os.path.join(out_dir, f"step_rank{rank}.npz"), params=flat_params(model
          flips=np.array(dec.total_flips()), shard_flat=np.array(shard_flat), avg_grad_single=avg_grad_single,
          early_params=np.array(early_params),
          **{"before:" + k: v for k, v in buf_before.items()}, **{"after:" + k: v for k, v in buf_after.items()})
-del model, optim, outs, losses
+# gradient accumulation: TWO backward passes before one optimiser step.  The early bucket (a snapshot of the first pass) must be
+# dropped and the step must reduce what is in p.grad -- the sum of both passes
+lossf = build_loss(cfg)
+for _ in range(2):
+    random.seed(seed)
+    o2 = model(b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train")
+    lossf(o2[0], o2[1], o2[2], b["target_view"].unsqueeze(1), cfg)[0].backward()
+expect = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+dist.all_reduce(expect)
+optim.step()
+np.savez(os.path.join(out_dir, f"accum_rank{rank}.npz"), ok=np.array(bool(torch.equal(optim._flat[0]["g"], expect))),
+         pending=np.array(parallel._EARLY["pending"] is None and parallel._EARLY["backwards"] == 0))
+optim.zero_grad()
+del model, optim, outs, losses, o2
 dist.barrier()
 
 # ---------------------------------------------------------------- part 2: Solver.run_one_epoch over sharded loaders
@@ -128,6 +141,23 @@ res2 = sol.run_one_epoch(parallel.ShardedLoader(more), "train", optim)
 np.savez(os.path.join(out_dir, f"solver_rank{rank}.npz"), params_1=params_1, params_3=flat_params(sol.model),
          losses=np.array(res[0] + res2[0]), oracle_losses=np.array([float(v) for v in rl]), avg_grad=avg_grad,
          oracle_grad=oracle_grad, live=np.array(live), flips=np.array(dec.total_flips()))
+dist.barrier()
+
+# ---------------------------------------------------------------- part 3: the same three iterations through the GRAPHED Solver
+# (cfg.SOLVER.graph: forward + loss + backward captured once per shape, the flat gradient as ONE all-reduce behind the replay,
+# FusedSGD's own flat buffers stepped): bit-identical parameters to the eager, two-bucket run above
+cfg_g = make_cfg(V)
+cfg_g.SOLVER["graph"] = True
+sol_g = Solver(cfg_g, use_tensorboardx=False)
+sol_g.model.load_state_dict({**hw.hashed_params(V), **hw.hashed_buffers()})
+sol_g.model.dropout_p = 0.0
+optim_g = get_optimizer(cfg_g, sol_g.model.parameters())
+random.seed(seed)
+res_g = sol_g.run_one_epoch(parallel.ShardedLoader([full]), "train", optim_g, collect_views=False)
+res_g2 = sol_g.run_one_epoch(parallel.ShardedLoader(more), "train", optim_g, collect_views=False)
+assert sol_g._graph_stepper is not None and sol_g._graph_stepper.calls == 3
+np.savez(os.path.join(out_dir, f"graph_rank{rank}.npz"), params_3=flat_params(sol_g.model),
+         losses=np.array(res_g[0] + res_g2[0]))
 dist.barrier()
 dist.destroy_process_group()
 print("DP2_OK", rank)

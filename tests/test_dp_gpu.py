@@ -155,6 +155,26 @@ def test_early_bucket_is_used_and_matches_single_bucket(dp_run):
     assert np.array_equal(a["avg_grad"], a["avg_grad_single"]) and np.array_equal(b["avg_grad"], b["avg_grad_single"])
 
 
+def test_early_bucket_is_dropped_after_two_backward_passes(dp_run):
+    """Gradient accumulation (two backward passes, one step): the early bucket is a snapshot of ONE pass, so the optimiser must
+    fall back to the single all-reduce of p.grad -- bit for bit the manual all-reduce of the accumulated gradients -- and leave
+    no pending collective behind."""
+    for r in range(2):
+        z = np.load(os.path.join(dp_run, f"accum_rank{r}.npz"))
+        assert bool(z["ok"]) and bool(z["pending"])
+
+
+def test_world2_graphed_solver_is_bit_identical_to_eager(dp_run):
+    """Solver.run_one_epoch with cfg.SOLVER.graph (hipGraph replay + one flat all-reduce) vs the eager two-bucket path on the
+    same three sharded iterations: bit-identical parameters on both ranks, losses equal."""
+    for r in range(2):
+        e, g = np.load(os.path.join(dp_run, f"solver_rank{r}.npz")), np.load(os.path.join(dp_run, f"graph_rank{r}.npz"))
+        assert np.array_equal(e["params_3"], g["params_3"])
+        assert np.abs(e["losses"] - g["losses"]).max() < 1e-6
+    a, b = (np.load(os.path.join(dp_run, f"graph_rank{r}.npz")) for r in range(2))
+    assert np.array_equal(a["params_3"], b["params_3"])
+
+
 def test_bench_two_ranks_prints_one_json_line():
     """bench.py's torchrun branch (barrier, max-over-ranks timing, whole-job value) with world_size 2."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",

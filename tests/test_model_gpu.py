@@ -14,6 +14,17 @@ from util import FWD_TOL, maxabs, rel, stats, sub
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+# Caps on the measured allowance of the fixture-gradient checks (test_train_golden, test_nefnet2_golden).  A step in which the
+# GPU took every ReLU / L1 decision the way the fp64 oracle does (no replayed flip) gets the fixtures' own distance from exact
+# arithmetic only: up to 2e-4 on the flat statistic.  A step WITH replayed flips -- each one asserted to be a tie within fp32
+# round-off and rare by assert_flips_are_ties -- may differ from the fixture by what those ties move when the reference
+# resolved them the other way: up to ~1.3e-3 on the flat gradient of these tiny shapes (tools/debug_tie.py).
+SLACK_CAPS_NO_FLIP = (3e-4, 3e-3)       # (flat, per tensor)
+SLACK_CAPS_TIES = (3e-3, 1e-2)      # largest seen: 1.87e-3 flat (nefnet2_B3_V1_L1000_Q3, 3 ties)
+
+
+def slack_caps(dec):
+    return SLACK_CAPS_TIES if dec.total_flips() > 0 else SLACK_CAPS_NO_FLIP
 
 
 class Cfg(dict):
@@ -178,6 +189,7 @@ def test_train_golden(golden_dir):
         if True:
             n_fixture_grad += 1
             sq, sq64, got_all, ref_all, x64_all = 0.0, 0.0, [], [], []
+            SLACK_CAP_FLAT, SLACK_CAP_TENSOR = slack_caps(dec)
             for k, p in m.named_parameters():
                 if k in orc.DEAD_PARAMS:
                     assert p.grad is None, k
@@ -187,7 +199,12 @@ def test_train_golden(golden_dir):
                     assert maxabs(sub(p.grad, 256), ref_sub) < 1e-6, (name, k)      # analytically zero
                     continue
                 x64 = sub(dec.oracle_params[k].grad, 256)
-                assert rel(sub(p.grad, 256), ref_sub) < TENSOR_TOL + rel(x64, ref_sub), (name, k, rel(sub(p.grad, 256), ref_sub))
+                # bar = the fixed tolerance + the MEASURED distance between the decision-replaying fp64 oracle and the fixture,
+                # capped: a GPU-side decision bug must not be able to widen its own bar (the replaying oracle follows the
+                # GPU's decisions); the uncapped, fixed-bar check against that oracle is oracle_replaying() above
+                slack = min(rel(x64, ref_sub), SLACK_CAP_TENSOR)
+                assert rel(sub(p.grad, 256), ref_sub) < TENSOR_TOL + slack, (
+                    name, k, rel(sub(p.grad, 256), ref_sub), f"bar {TENSOR_TOL} + measured oracle-to-fixture distance {slack:.2e}")
                 w_k = (p.grad.numel() / len(ref_sub)) ** 0.5        # the fixture holds <= 256 entries per tensor:
                 got_all.append(w_k * sub(p.grad, 256))               # weight them back to the tensor's size, so the
                 ref_all.append(w_k * ref_sub)                        # statistic estimates the FLAT gradient's rel-L2
@@ -195,9 +212,17 @@ def test_train_golden(golden_dir):
                 sq += float((p.grad.double() ** 2).sum())
                 sq64 += float((dec.oracle_params[k].grad.double() ** 2).sum())
             ref_norm = float(z["flat_grad_norm"])       # same rule for the norm: bar + the replaying oracle's own distance
-            assert abs(sq ** 0.5 - ref_norm) < FLAT_TOL * ref_norm + abs(sq64 ** 0.5 - ref_norm), name
+            nslack = min(abs(sq64 ** 0.5 - ref_norm), SLACK_CAP_FLAT * ref_norm)
+            assert abs(sq ** 0.5 - ref_norm) < FLAT_TOL * ref_norm + nslack, (
+                name, f"bar {FLAT_TOL} + measured oracle-to-fixture distance {nslack / ref_norm:.2e} (capped at {SLACK_CAP_FLAT})")
             ref_cat = np.concatenate(ref_all)
-            assert rel(np.concatenate(got_all), ref_cat) < FLAT_TOL + rel(np.concatenate(x64_all), ref_cat), name
+            fslack = min(rel(np.concatenate(x64_all), ref_cat), SLACK_CAP_FLAT)
+            assert rel(np.concatenate(got_all), ref_cat) < FLAT_TOL + fslack, (
+                name, f"bar {FLAT_TOL} + measured oracle-to-fixture distance {fslack:.2e} (capped at {SLACK_CAP_FLAT})")
+            if dec.total_flips() > 0:
+                import conftest
+                conftest.report(f"{name}: {dec.total_flips()} replayed tie(s); replaying fp64 oracle to fixture {fslack:.2e}, "
+                                f"HIP to fixture {rel(np.concatenate(got_all), ref_cat):.2e} on the flat statistic")
         sd = m.state_dict()
         for k in sd:
             if "running" in k:
@@ -220,8 +245,10 @@ def test_train_vs_oracle_live():
         assert flat < 2e-5, flat         # fp32 round-off against fp64 once ties are out of the picture
 
 
-def test_sgd_steps_golden(golden_dir):
-    """Three iterations of Solver.run_one_epoch(phase='train') vs the reference Solver's trajectory."""
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graphed"])
+def test_sgd_steps_golden(golden_dir, graph):
+    """Three iterations of Solver.run_one_epoch(phase='train') vs the reference Solver's trajectory -- eagerly, and through
+    the captured hipGraph the Solver uses at launch-bound shapes (cfg.SOLVER.graph; FusedSGD's flat buffers stepped)."""
     from electrocardio_panorama_amd import synth
     from electrocardio_panorama_amd.solver import Solver
     from electrocardio_panorama_amd.solver.optim_scheduler import get_optimizer
@@ -230,13 +257,17 @@ def test_sgd_steps_golden(golden_dir):
     z = np.load(golden(golden_dir, "sgd_*.npz")[0])
     B, V, L, seed, steps = (int(z[k]) for k in ("B", "V", "L", "seed", "steps"))
     cfg = make_cfg(V, lr=float(z["lr"]))
+    cfg.SOLVER["graph"] = bool(graph)
     sol = Solver(cfg, use_tensorboardx=False)
     sol.model.load_state_dict({**hw.hashed_params(V), **hw.hashed_buffers()})
     sol.model.dropout_p = 0.0
     batches = [synth.make_batch(B, V, L, seed=seed + s, Q=2) for s in range(steps)]
     opt = get_optimizer(cfg, sol.model.parameters())
     random.seed(seed)
-    losses = sol.run_one_epoch(batches, "train", opt)[0]
+    losses = sol.run_one_epoch(batches, "train", opt, collect_views=not graph)[0]
+    assert (getattr(sol, "_graph_stepper", None) is not None) == bool(graph)
+    if graph:      # the momentum lives in the optimiser's state (checkpoints see it), not in a private buffer
+        assert sol._graph_stepper.calls == steps and sol._graph_stepper.flat_buf is opt._flat[0]["buf"]
     assert np.abs(np.array(losses) - z["losses"]).max() < 2e-5, (losses, z["losses"])
     sd = sol.model.state_dict()
     worst = (0.0, None)
@@ -246,6 +277,9 @@ def test_sgd_steps_golden(golden_dir):
         assert e < tol, (k, e)
         if k not in orc.DEAD_PARAMS and e > worst[0]:
             worst = (e, k)
+    import conftest
+    conftest.report(f"3-step SGD trajectory vs the reference Solver ({'graphed' if graph else 'eager'}): worst parameter "
+                    f"{worst[1]} rel-L2 {worst[0]:.2e} (bar 2e-4)")
     with open(os.path.join(os.environ.get("NEF_TEST_LOG_DIR", "/tmp"), "sgd_trajectory.txt"), "w") as fh:
         fh.write(f"3-step SGD trajectory vs the reference Solver: worst parameter {worst[1]} rel-L2 {worst[0]:.2e} (bar 2e-4)\n")
     for k in orc.buffer_shapes():
@@ -397,18 +431,22 @@ def test_config3_shard_full_size_is_deterministic_and_fits():
     assert gib < 200
 
 
-def test_full_size_train_gradients_vs_oracle(record_property):
+@pytest.mark.parametrize("B", [256], ids=["B256"])
+def test_full_size_train_gradients_vs_oracle(record_property, B):
     """BASELINE configs[1] at FULL size in TRAIN mode (256 x 3 x 5000, dropout masks replayed, batch-statistics
     BatchNorm over 3.84 M elements per channel, split-K weight gradients over 320 k columns): outputs, losses, BN running
     statistics and EVERY gradient tensor against the CPU oracle on the same batch, at the tie-free bars.  The oracle
-    needs ~40 GB of host memory for this batch; on a smaller host the same test runs at batch 64."""
+    needs ~40 GB of host memory for this batch; a host with less than 90 GB available SKIPS (it does not shrink the batch:
+    the test id says which size ran, and the run's tail repeats it with the measured numbers)."""
+    import conftest
     import psutil
     from electrocardio_panorama_amd.network import build_loss
     from oracle import hashweights as hw
     V, L, seed = 3, 5000, 271
-    B = 256 if psutil.virtual_memory().available > 90e9 else 64
-    if os.environ.get("NEF_REQUIRE_FULL") == "1":
-        assert B == 256, f"NEF_REQUIRE_FULL=1: host has {psutil.virtual_memory().available / 1e9:.0f} GB available, need 90"
+    avail = psutil.virtual_memory().available
+    if avail < 90e9:
+        conftest.report(f"full-size train parity (B={B}): SKIPPED, host has {avail / 1e9:.0f} GB available, the oracle needs 90")
+        pytest.skip(f"the CPU oracle needs ~90 GB of host memory at B={B}; {avail / 1e9:.0f} GB available")
     record_property("batch", B)            # junit / --report-log: which size really ran (256 = configs[1])
     T, C = L // 4, 128 * V
     g = torch.Generator().manual_seed(seed)
@@ -437,8 +475,10 @@ def test_full_size_train_gradients_vs_oracle(record_property):
             assert rel(sd[k], v) < 1e-5, (f"batch {B}", k)
     record_property("flat_gradient_rel_l2", float(flat))
     record_property("replayed_ties", int(dec.total_flips()))
-    msg = f"full-size train parity: B={B}, flat gradient rel-L2 {flat:.2e}, replayed ties {dec.total_flips()}"
+    msg = (f"full-size train parity: B={B} (configs[1] = 256), flat gradient rel-L2 {flat:.2e} (bar {FLAT_TOL}), "
+           f"replayed ties {dec.total_flips()}")
     print(msg)
+    conftest.report(msg)
     with open(os.path.join(os.environ.get("NEF_TEST_LOG_DIR", "/tmp"), "full_size_parity.txt"), "w") as fh:
         fh.write(msg + "\n")
     m.last_saved = None
@@ -854,6 +894,7 @@ def test_nefnet2_golden(golden_dir):
         if True:      # the reference's own gradients for every fixture (bars + the measured distance replaying-fp64-oracle <-> fixture)
             n_fixture_grad += 1
             sq, sq64, got_all, ref_all, x64_all = 0.0, 0.0, [], [], []
+            SLACK_CAP_FLAT, SLACK_CAP_TENSOR = slack_caps(dec)
             for k, p in m.named_parameters():
                 if k in orc.DEAD_PARAMS:
                     assert p.grad is None, k
@@ -863,7 +904,9 @@ def test_nefnet2_golden(golden_dir):
                     assert maxabs(sub(p.grad, 256), ref_sub) < 1e-6, (name, k)
                     continue
                 x64 = sub(dec.oracle_params[k].grad, 256)
-                assert rel(sub(p.grad, 256), ref_sub) < TENSOR_TOL + rel(x64, ref_sub), (name, k, rel(sub(p.grad, 256), ref_sub))
+                slack = min(rel(x64, ref_sub), SLACK_CAP_TENSOR)      # capped measured allowance, see test_train_golden
+                assert rel(sub(p.grad, 256), ref_sub) < TENSOR_TOL + slack, (
+                    name, k, rel(sub(p.grad, 256), ref_sub), f"bar {TENSOR_TOL} + measured oracle-to-fixture distance {slack:.2e}")
                 w_k = (p.grad.numel() / len(ref_sub)) ** 0.5        # the fixture holds <= 256 entries per tensor:
                 got_all.append(w_k * sub(p.grad, 256))               # weight them back to the tensor's size, so the
                 ref_all.append(w_k * ref_sub)                        # statistic estimates the FLAT gradient's rel-L2
@@ -871,9 +914,17 @@ def test_nefnet2_golden(golden_dir):
                 sq += float((p.grad.double() ** 2).sum())
                 sq64 += float((dec.oracle_params[k].grad.double() ** 2).sum())
             ref_norm = float(z["flat_grad_norm"])       # same rule for the norm: bar + the replaying oracle's own distance
-            assert abs(sq ** 0.5 - ref_norm) < FLAT_TOL * ref_norm + abs(sq64 ** 0.5 - ref_norm), name
+            nslack = min(abs(sq64 ** 0.5 - ref_norm), SLACK_CAP_FLAT * ref_norm)
+            assert abs(sq ** 0.5 - ref_norm) < FLAT_TOL * ref_norm + nslack, (
+                name, f"bar {FLAT_TOL} + measured oracle-to-fixture distance {nslack / ref_norm:.2e} (capped at {SLACK_CAP_FLAT})")
             ref_cat = np.concatenate(ref_all)
-            assert rel(np.concatenate(got_all), ref_cat) < FLAT_TOL + rel(np.concatenate(x64_all), ref_cat), name
+            fslack = min(rel(np.concatenate(x64_all), ref_cat), SLACK_CAP_FLAT)
+            assert rel(np.concatenate(got_all), ref_cat) < FLAT_TOL + fslack, (
+                name, f"bar {FLAT_TOL} + measured oracle-to-fixture distance {fslack:.2e} (capped at {SLACK_CAP_FLAT})")
+            if dec.total_flips() > 0:
+                import conftest
+                conftest.report(f"{name}: {dec.total_flips()} replayed tie(s); replaying fp64 oracle to fixture {fslack:.2e}, "
+                                f"HIP to fixture {rel(np.concatenate(got_all), ref_cat):.2e} on the flat statistic")
         sd = m.state_dict()
         for k in sd:
             if "running" in k:

@@ -886,11 +886,11 @@ def test_conv_winograd_prologue_modes(mode, Cig, Cog, T_out, f4):
     (7, 3, 128, 128, 128, 2), (7, 1, 128, 128, 300, 2), (7, 2, 128, 128, 1250, 2), (7, 1, 128, 64, 500, 2),
     (7, 1, 64, 128, 70, 5),
 ])
-@pytest.mark.parametrize("form", [True, 4])
+@pytest.mark.parametrize("form", [4])
 def test_conv_bwd_weight_winograd(K, G, Cig, Cog, T, B, form):
-    """The weight gradient through the transposed Winograd forms F(3,2) (`form` True) and F(3,4) (`form` 4, K = 3; K = 7:
-    the 4 + 3 split through F(4,2) + F(3,2)) against autograd, next to the direct kernel, and all against fp64: within 4x (F(3,2)) resp. 8x (F(3,4), whose transforms
-    carry entries up to 8 and 1/24) of the larger of the direct kernel's and torch-CPU's own distance from exact."""
+    """The weight gradient through the transposed Winograd forms -- F(3,4) for K = 3, the 4 + 3 split through F(4,4) + F(3,4) for
+    K = 7 -- against autograd, next to the direct kernel, and all against fp64: within 8x (transform entries up to 8 and 1/24)
+    of the larger of the direct kernel's and torch-CPU's own distance from exact."""
 
     o = ops()
     from electrocardio_panorama_amd.ops import GV
@@ -910,7 +910,7 @@ def test_conv_bwd_weight_winograd(K, G, Cig, Cog, T, B, form):
     assert torch.equal(gw, o.conv_bwd_weight(GV.dense(xd, G), GV.dense(gyd, G), K, wino=form))      # deterministic
 
 
-@pytest.mark.parametrize("form", [True, 4])
+@pytest.mark.parametrize("form", [4])
 def test_conv_bwd_weight_winograd_views_scale_and_prologues(form):
     o = ops()
     from electrocardio_panorama_amd.ops import GV

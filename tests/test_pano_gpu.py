@@ -252,6 +252,35 @@ def test_config3_full_size_sweep_rows_vs_oracle():
     assert rel(r16, rest[rows]) < 1e-4, rel(r16, rest[rows])
 
 
+def test_config4_full_share_gen_ecg_rows_vs_oracle():
+    """BASELINE configs[4] AT ITS PER-GPU SIZE: one GPU's share of the global batch 4096 = 512 samples x 3 leads x 12 angles,
+    len 5000, fp16 decoder (what bench.py's `secondary` times): the whole share runs through gen_ecg, rows 0 / 255 / 511 x all
+    12 angles are held to the CPU oracle's sweep at the half-precision gate, and the fp32 product path on the same rows to 1e-5
+    (reference model_nefnet.py:196-218)."""
+    from electrocardio_panorama_amd import synth
+    B, V, L, Q, seed = 512, 3, 5000, 12, 79
+    host = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.make_batch(B, V, L, seed=seed, Q=Q).items()
+            if k in ("data", "input_theta", "target_theta", "rois", "rest_theta")}
+    d = {k: v.to(DEV) for k, v in host.items()}
+    m = hashed_model(V).eval()
+    with torch.no_grad():
+        z1, z2 = m(d["data"], d["input_theta"], d["target_theta"], d["rois"], phase="gen")
+        m.panorama_dtype = "fp16"
+        g16 = m.gen_ecg(z1, z2, d["rest_theta"], d["rois"])
+    assert g16.shape == (B, Q, L) and g16.dtype == torch.float32 and bool(torch.isfinite(g16).all())
+    rows = [0, 255, 511]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = _oracle_rest(V, host, rows, seed)
+    for i, r in enumerate(rows):
+        assert rel(g16[r], ref[i]) < HALF_TOL, (r, rel(g16[r], ref[i]))
+    m.panorama_dtype = "fp32"
+    with torch.no_grad():
+        g32 = m.gen_ecg(z1[rows].contiguous(), z2[rows].contiguous(), d["rest_theta"][rows].contiguous(),
+                        d["rois"][rows].contiguous())
+    assert rel(g32, ref) < 1e-5, rel(g32, ref)
+    assert rel(_logit3(g16[rows]), _logit3(g32)) < 2 * HALF_TOL
+
+
 def test_config4_gen_ecg_fp16_len5000_vs_fp32_and_oracle():
     """BASELINE configs[4] shape (decoder-only synthesis, len 5000, 3 leads, 12 angles, fp16) at a batch the CPU oracle
     finishes in seconds: gen_ecg through the fp16 decoder (multi-tile sequences, both x2 upsamplings, ROI un-pooling at

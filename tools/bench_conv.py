@@ -37,7 +37,7 @@ for name, K, G, Cig, Cog, B, T in SHAPES:
         fn = (lambda: ops.conv(GV.dense(x, G), wp, Cog, K, relu=True)) if what == "fwd" else \
              (lambda: ops.conv(GV.dense(x, G), wpw, Cog, K, relu=True)) if what == "wino" else \
              (lambda: ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, wino=False)) if what == "bwd_w" else \
-             (lambda: ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, wino=(4 if ((K == 3 and ops.WINO_BW4) or (K == 7 and ops.WINO_BW7)) else True)))
+             (lambda: ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, wino=4))
         if what == "bwd_ww" and (K not in (3, 7) or T < 64 or T % 2):
             continue
         for _ in range(int(os.environ.get("WARM", 30))):      # the first kernel timed in a process runs ~10 % slow for a few dozen launches

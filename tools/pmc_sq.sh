@@ -1,27 +1,44 @@
 #!/bin/bash
 # SQ / GRBM counters of the conv micro-benchmark (one shape): where the waves' cycles go.   usage: tools/pmc_sq.sh "enc k7" out
+# Two passes: F4=1 (direct forward, F(4,.) forward / backward-data form, both weight-gradient forms) and F4=0 ONLY_WHAT=wino
+# (the F(2,.) forward kernel -- conv_wino_kernel<7,2,0> for "enc k7", the kernel bench.py's roofline prices).
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${2:-sq}
 rm -rf $O && mkdir -p $O
-rocprofv3 -L > $O/counters.txt 2>&1
-ITERS=3 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -d $O/p -o t -- python tools/bench_conv.py "$1" > $O/run.log 2>&1
+CNT="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
+ITERS=3 F4=1 timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d $O/p1 -o t -- python tools/bench_conv.py "$1" > $O/run1.log 2>&1
+ITERS=3 F4=0 ONLY_WHAT=wino timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d $O/p2 -o t -- python tools/bench_conv.py "$1" > $O/run2.log 2>&1
 python - <<PY
 import sqlite3, glob
-db = glob.glob("$O/p/**/*results.db", recursive=True)[0]
-cur = sqlite3.connect(db).cursor()
-rows = cur.execute("select kernel_name, counter_name, avg(v), count(*) from (select dispatch_id, kernel_name, counter_name, sum(value) v from counters_collection group by dispatch_id, counter_name) group by kernel_name, counter_name").fetchall()
-dur = dict(cur.execute("select name, avg(duration) from kernels group by name").fetchall())
 out = {}
-for k, c, v, n in rows:
-    out.setdefault(k, {})[c] = v
+dur = {}
+for d in ("$O/p1", "$O/p2"):
+    dbs = glob.glob(d + "/**/*results.db", recursive=True)
+    if not dbs:
+        continue
+    cur = sqlite3.connect(dbs[0]).cursor()
+    rows = cur.execute("select kernel_name, counter_name, avg(v), count(*) from (select dispatch_id, kernel_name, counter_name, sum(value) v from counters_collection group by dispatch_id, counter_name) group by kernel_name, counter_name").fetchall()
+    dur.update(dict(cur.execute("select name, avg(duration) from kernels group by name").fetchall()))
+    for k, c, v, n in rows:
+        out.setdefault(k, {})[c] = v
+def short(k):
+    return k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
 with open("$O/sq.md", "w") as f:
+    f.write("# SQ / GRBM counters, tools/bench_conv.py \"$1\" (rocprofv3 --pmc, per-dispatch sums averaged over the launches of a kernel)\n\n")
+    direct = None
+    for k, d in out.items():
+        if "conv_fwd_kernel" in k and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+            direct = d["SQ_VALU_MFMA_BUSY_CYCLES"]
     for k, d in out.items():
         if "conv" not in k: continue
-        short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-        f.write(f"{short}  avg_dur_us={dur.get(k,0)/1e3:.1f}\n")
+        f.write(f"{short(k)}  avg_dur_us={dur.get(k,0)/1e3:.1f}\n")
         for c, v in sorted(d.items()):
             f.write(f"    {c:28s} {v:.4g}\n")
+        if direct and "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["SQ_VALU_MFMA_BUSY_CYCLES"] > 0:
+            f.write(f"    MFMA_BUSY / direct forward's   {d['SQ_VALU_MFMA_BUSY_CYCLES'] / direct:.4f}   (9/14 = 0.6429 F(2,4)+F(2,3); 13/28 = 0.4643 F(4,4)+F(4,3); 1/2 F(4,3); 2/3 F(2,3))\n")
+        if "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["GRBM_GUI_ACTIVE"] > 0:
+            f.write(f"    matrix-pipe occupancy          {d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}   (busy cycles / (cycles per XCD x 1024 SIMDs))\n")
 print(open("$O/sq.md").read())
 PY
-rm -rf $O/p
+rm -rf $O/p1 $O/p2

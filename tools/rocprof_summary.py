@@ -1,23 +1,42 @@
 """Turn a rocprofv3 (rocpd sqlite) kernel trace into the per-kernel summary table committed under profiles/.
 
-    python tools/rocprof_summary.py gpurun_out/prof_r01/r01_results.db profiles/r01_kernel_stats.md [steps]
+    python tools/rocprof_summary.py <results.db> <out.md> [steps] [warm]
+
+`steps` = train steps the profiled command ran in all, `warm` (default 1) = how many of them, from the start, are warm-up and
+are DROPPED: per kernel name the launches are ordered by start time and the first calls*warm/steps of them are left out (the
+first step's launches read 3-10 % long: cold instruction caches, first-touch page faults, the clocks ramping), so averages and
+the per-step total are over steady-state steps only.  Kernels whose launch count is not a multiple of `steps` (one-off setup
+work) are kept whole and divided by the profiled steps like the rest.
 """
 import sqlite3
 import sys
 
 db, out = sys.argv[1], sys.argv[2]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+warm = int(sys.argv[4]) if len(sys.argv) > 4 else (1 if steps > 1 else 0)
 cur = sqlite3.connect(db).cursor()
-rows = list(cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
-                        "group by name order by sum(duration) desc"))
+try:
+    raw = list(cur.execute("select name, start, duration from kernels order by start"))
+except sqlite3.OperationalError:
+    raw = [(n, i, d) for i, (n, d) in enumerate(cur.execute("select name, duration from kernels"))]
+by = {}
+for name, _, dur in raw:
+    by.setdefault(name, []).append(dur)
+kept_steps = steps - warm
+rows = []
+for name, durs in by.items():
+    if warm and len(durs) % steps == 0:
+        durs = durs[len(durs) * warm // steps:]
+    rows.append((name, len(durs), sum(durs), sum(durs) / len(durs), min(durs), max(durs)))
+rows.sort(key=lambda r: -r[2])
 total = sum(r[2] for r in rows)
 with open(out, "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace summary ({db.split('/')[-1]}); durations in microseconds, "
-            f"{steps} profiled steps (warm-up included)\n\n")
+    f.write(f"# rocprofv3 --kernel-trace summary ({db.split('/')[-1]}); durations in microseconds, {kept_steps} steady-state "
+            f"steps ({steps} profiled, the first {warm} dropped as warm-up)\n\n")
     f.write("| kernel | calls | total us | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n")
     for name, n, tot, avg, mn, mx in rows:
         short = name.replace("(anonymous namespace)::", "").replace("void ", "")
         short = short.split("(")[0]
         f.write(f"| `{short}` | {n} | {tot/1e3:.1f} | {avg/1e3:.2f} | {mn/1e3:.2f} | {mx/1e3:.2f} | {100*tot/total:.2f} |\n")
-    f.write(f"\nTotal kernel time {total/1e6:.2f} ms over {steps} steps = {total/1e6/steps:.2f} ms/step\n")
+    f.write(f"\nTotal kernel time {total/1e6:.2f} ms over {kept_steps} steps = {total/1e6/max(kept_steps, 1):.2f} ms/step\n")
 print(open(out).read()[:3000])

@@ -28,8 +28,14 @@ def pmc(path, counter):
 f, w = pmc(fetch, "FETCH_SIZE"), pmc(write, "WRITE_SIZE")
 cur = sqlite3.connect(trace).cursor()
 rows = {}
-for name, gx, gy, gz, dur in cur.execute("select name, grid_x, grid_y, grid_z, duration from kernels"):
+for name, gx, gy, gz, dur in cur.execute("select name, grid_x, grid_y, grid_z, duration from kernels order by start"):
     rows.setdefault((short(name), gx * gy * gz), []).append(dur)
+# the first profiled step is warm-up (3-10 % long): per launch shape, drop its share of the launches when the count allows
+STEPS = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+WARM = 1 if STEPS > 1 else 0
+for k in list(rows):
+    if WARM and len(rows[k]) % STEPS == 0:
+        rows[k] = rows[k][len(rows[k]) * WARM // STEPS:]
 total = sum(sum(v) for v in rows.values())
 lines = []
 for key, durs in rows.items():
@@ -40,7 +46,7 @@ for key, durs in rows.items():
     lines.append((sum(durs), key, len(durs), avg, by))
 lines.sort(reverse=True)
 with open(out, "w") as fh:
-    fh.write("# Measured HBM traffic and achieved bandwidth per launch shape (config 2, one-stream run: launches alone)\n\n")
+    fh.write("# Measured HBM traffic and achieved bandwidth per launch shape (config 2, one-stream run: launches alone; warm-up step dropped)\n\n")
     fh.write("bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from the PMC passes; time from the kernel trace; peak 8 TB/s.\n"
              "MFMA-bound kernels (conv_*) are listed for their traffic only -- their roof is the fp32 matrix peak.\n\n")
     fh.write("| kernel | workitems | launches | avg us | HBM MB / launch | TB/s | % of 8 TB/s | % of kernel time |\n"
