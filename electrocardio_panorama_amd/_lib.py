@@ -32,7 +32,7 @@ class ConvArgs(C.Structure):
         ("pro_a", p), ("pro_b", p), ("pro_mode", i32), ("pro_Bp", i32), ("rng_seed_dev", p), ("wino", i32),
         ("stats", p),
         ("bnb_x", p), ("bnb_mean", p), ("bnb_invstd", p), ("bnb_a", p), ("bnb_b", p), ("bnb_slots", p), ("bnb_Bp", i32),
-        ("bnb_up", i32),
+        ("bnb_up", i32), ("x_scale", f32), ("reserved0", i32), ("x_amax", p), ("x_amax_next", p),
     ]
 
 
@@ -52,6 +52,8 @@ SIGNATURES = {
     "nef_pack_weight_wino": (i32, [p, p, i32, i32, i32, i32, i32, p]),
     "nef_pack_weight_wino4": (i32, [p, p, i32, i32, i32, i32, i32, p]),
     "nef_pack_weights": (i32, [C.POINTER(PackDesc), i32, p]),
+    "nef_pack_weight_h2": (i32, [p, p, i32, i32, i32, i32, i32, p]),
+    "nef_pack_weight_h2_bytes": (sz, [i32, i32, i32, i32, i32]),
     "nef_conv_fwd": (i32, [C.POINTER(ConvArgs), p]),
     "nef_conv_args_bytes": (sz, []),
     "nef_conv_bwd_weight_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),

@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["conv_mfma.hip", "conv_bww_glds.hip", "stem.hip", "elementwise.hip", "roi.hip", "convt_theta.hip", "pano_h.hip", "metrics.hip"]
+SOURCES = ["conv_mfma.hip", "conv_h2.hip", "conv_bww_glds.hip", "stem.hip", "elementwise.hip", "roi.hip", "convt_theta.hip", "pano_h.hip", "metrics.hip"]
 LIB = os.path.join(HERE, "libnefnet_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include"), "-I", HERE]

@@ -1,0 +1,611 @@
+// conv_h2.hip -- the grouped 1-D convolutions (K = 3, K = 7; forward and backward-data) as DIRECT convolutions whose fp32
+// operands are split EXACTLY into two fp16 terms each and multiplied on the fp16 matrix cores with fp32 accumulation:
+//
+//     x = xh + xl + ex,  xh = fp16(x),  xl = fp16(x - xh)            |ex| <= 2^-23 |x|   (22..23 significant bits kept)
+//     w = wh + wl + ew   (after an exact power-of-two scaling of each output row, undone in the epilogue)
+//     x * w  ~  xh*wh + xh*wl + xl*wh                                (the dropped xl*wl is 2^-22 of the product)
+//
+// Every fp16 x fp16 product is exact in fp32 and the sums run in fp32 accumulators, so the result carries the rounding of an
+// fp32 dot product plus the 2^-22..2^-23 of the operand split: measured 1.1e-7 rel-L2 on a 128-channel K = 7 layer against
+// fp64 (torch's fp32 conv: 1.3e-7; the Winograd F(4,.) forms of conv_mfma.hip: 4..10e-7) -- tests/test_ops_gpu.py::test_conv_h2.
+// Three `v_mfma_f32_32x32x16_f16` (16 channels each) replace eight `v_mfma_f32_32x32x2f32` per 16 channels and tap: 3 x 32
+// cycles instead of 8 x 64 on a SIMD's matrix pipe (5.3x fewer; against the Winograd forms 2.5..3.4x fewer), which turns every
+// conv of the train step from matrix-bound into HBM-bound.
+//
+// Range: fp16 holds |v| < 65504 and loses relative precision below 6.1e-5.  Weights are scaled per output row at pack time
+// (row maximum -> [2^14, 2^15)), so their split is always at full precision.  Activations are taken as they are: tiles are
+// clamped to +-65000 before the split (no infinities), and an element below 2^-3 keeps an ABSOLUTE error of <= 2^-25 in its
+// low term -- relative to tensors of magnitude O(1), which is what reaches these launches (post-ReLU activations, BatchNorm
+// outputs), that is below fp32's own rounding.  Gradient operands (backward-data) span any range: the engine passes their
+// power-of-two pre-scale in `x_scale` (see nef_conv_args) -- exact, undone in the epilogue.
+//
+// Tiling: one workgroup = 128 (TM = 2; 64 with TM = 1) output channels x 256 outputs of one sample and group, 4 waves as
+// 2 (co) x 2 (t), a wave owns 32 TM x 128 = TM x 4 accumulator tiles of 32 x 32.  MFMA column n of t-tile j is output t = 4 n + j, so a lane ends up with FOUR
+// ADJACENT outputs of each of its rows (16-byte stores, as the F(4,3) epilogue) and the B fragment of (tap kk, t-tile j) depends
+// on s = kk + j only: a stage reads K + 3 fragment pairs from LDS instead of 4 K (K = 7: 10 instead of 28).
+// B (activations): raw fp32 rows fetched through buffer descriptors a stage (16 channels) ahead, split in registers, stored to
+// LDS as fp16 [plane][position][16 channels] with the positions de-interleaved by t mod 4 (fragment reads = 1 KB contiguous,
+// conflict-free), double-buffered: one barrier per stage.  A (weights): never in LDS -- nef_pack_weight_h2 lays the fragments
+// out in lane order, so a wave's four fragments of a (tap, 16-channel chunk) are one contiguous 4 KB read from L2, fetched a
+// tap ahead.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "nefnet_hip.h"
+#include "nef_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int KC = 16;            // input channels per stage = the k extent of one matrix instruction
+constexpr int NTO = 256;          // outputs per workgroup
+constexpr int PRO_MAX_CIN = 512;  // input channels per group the LDS table of the affine prologue holds
+
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& l) {
+    x0 = __builtin_amdgcn_fmed3f(x0, -65000.f, 65000.f);
+    x1 = __builtin_amdgcn_fmed3f(x1, -65000.f, 65000.f);
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;
+    const h16x2 hh = {h0, h1};
+    const h16x2 ll = {(_Float16)r0, (_Float16)r1};
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight operand.  Logical operand of the launch: W[co][ci][kk] (forward: w[g*Cog+co][ci][kk]; transpose_flip: the
+// backward-data operand, W[co' = ci][ci' = co][kk] = w[g*Cog+ci'][co'][K-1-kk]).  Packed as fp16 fragments
+//     wp[g][ci'/16][kk][co'/32][plane h|l][lane = co'%32 + 32*((ci'%16)/8)][ci'%8]        (halves)
+// followed by the per-row descale factors [g][co'] (floats): row co' was multiplied by 2^e, e = 14 - floor(log2(max |row|)).
+// One wave per output row.
+// ------------------------------------------------------------------------------------------------------------------
+struct H2PackDesc {
+    const float* w;
+    _Float16* wp;
+    int G, Cog, Cig, K, flip;      // Cog / Cig: dimensions of w itself ([G*Cog][Cig][K])
+};
+constexpr int H2_PACK_MAX = 48;
+struct H2PackTable { H2PackDesc d[H2_PACK_MAX]; };
+
+__global__ __launch_bounds__(256) void pack_h2_kernel(H2PackTable tab) {
+    const H2PackDesc& d = tab.d[blockIdx.y];
+    const int co_n = d.flip ? d.Cig : d.Cog;       // rows / reduction channels of the launch operand
+    const int ci_n = d.flip ? d.Cog : d.Cig;
+    const int K = d.K;
+    const int lane = threadIdx.x & 63;
+    const int rows = d.G * co_n;
+    const int ncot = co_n / 32, nc16 = ci_n / 16;
+    float* const dsc = reinterpret_cast<float*>(d.wp + (int64_t)d.G * K * co_n * ci_n * 2);
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const int g = row / co_n, co = row % co_n;
+        float m = 0.f;
+        for (int i = lane; i < ci_n * K; i += 64) {
+            const int ci = i / K, kk = i % K;
+            const float v = d.flip ? d.w[(((int64_t)g * d.Cog + ci) * d.Cig + co) * K + (K - 1 - kk)]
+                                   : d.w[(((int64_t)g * d.Cog + co) * d.Cig + ci) * K + kk];
+            m = fmaxf(m, fabsf(v));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        int e = 0;
+        if (m > 0.f && m < 3e38f) {
+            int ex;
+            (void)frexpf(m, &ex);          // m = f * 2^ex, f in [0.5, 1)  ->  floor(log2 m) = ex - 1
+            e = 14 - (ex - 1);
+            e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        }
+        const float sc = ldexpf(1.f, e);
+        if (lane == 0) dsc[row] = ldexpf(1.f, -e);
+        for (int i = lane; i < ci_n * K; i += 64) {
+            const int ci = i / K, kk = i % K;
+            const float v = sc * (d.flip ? d.w[(((int64_t)g * d.Cog + ci) * d.Cig + co) * K + (K - 1 - kk)]
+                                         : d.w[(((int64_t)g * d.Cog + co) * d.Cig + ci) * K + kk]);
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)(v - (float)h);
+            const int64_t frag = ((((int64_t)g * nc16 + ci / 16) * K + kk) * ncot + co / 32) * 2;
+            const int fl = (co & 31) + 32 * ((ci & 15) >> 3);
+            d.wp[(frag * 64 + fl) * 8 + (ci & 7)] = h;
+            d.wp[((frag + 1) * 64 + fl) * 8 + (ci & 7)] = l;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// PRO as in conv_fwd_kernel (bit0: BatchNorm affine + ReLU of the producing layer, bit1: x2 linear upsampling of a
+// half-resolution input), applied to the fp32 values before the split.
+// ------------------------------------------------------------------------------------------------------------------
+template <int K, int PRO, int TM>
+__global__ __launch_bounds__(256, 2) void conv_h2_kernel(nef_conv_args a, int tps, int n_tiles, int m_tiles) {
+    constexpr int MT = 64 * TM;                    // output channels per workgroup: 2 (co) x 2 (t) waves of TM x 4 tiles
+    constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
+    constexpr int NS = UP ? 2 : 1;
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int XROW = NTO + K - 1;              // staged positions per channel: t0 - PAD .. t0 + NTO + PAD - 1
+    constexpr int P4 = (XROW + 3) / 4 + 1;         // positions per (t mod 4) class
+    constexpr int PLANE = 4 * P4 * 32;             // bytes of one fp16 plane of a stage: [4][P4][16 channels]
+    constexpr int NIT = (XROW + 63) / 64;
+    constexpr int NSF = K + 3;                     // distinct B fragments per stage (s = tap + t-tile)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
+    unsigned char* const Xl = smem_h2;             // [2 buffers][2 planes][PLANE]
+    float* const Pl = reinterpret_cast<float*>(smem_h2 + 4 * PLANE);      // [2][Cin_g] prologue affine (AFF)
+    float* const El = Pl + (AFF ? 2 * PRO_MAX_CIN : 0);                    // [6][MT] epilogue tables
+
+    const int tile = blockIdx.x % n_tiles;
+    const int gm = blockIdx.x / n_tiles;
+    const int mt = gm % m_tiles;
+    const int g = gm / m_tiles;
+    int b0, t0;
+    {      // tiles of one sample 8 workgroup ids apart: same XCD, back to back (see conv_fwd_kernel)
+        const int full = (n_tiles / (8 * tps)) * (8 * tps);
+        if (tile < full) {
+            const int grp = tile / (8 * tps), r = tile % (8 * tps);
+            b0 = grp * 8 + (r & 7);
+            t0 = (r >> 3) * NTO;
+        } else {
+            b0 = tile / tps;
+            t0 = (tile - b0 * tps) * NTO;
+        }
+    }
+    const int m0 = mt * MT;
+    const int T = a.T, Cig = a.Cin_g, Cog = a.Cout_g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave_u >> 1, wn = wave_u & 1;
+    const int Tin = UP ? (T >> 1) : T;
+
+    const float* const xbase = a.x + (int64_t)b0 * a.x_bs + (int64_t)g * a.x_gs;
+    const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(xbase);
+    const _Float16* const wph = reinterpret_cast<const _Float16*>(a.wp);
+    const int ncot = Cog / 32, nc16 = Cig / 16;
+    // this wave's 2 TM A fragments of (chunk c, tap kk): contiguous at ((g*nc16 + c)*K + kk)*ncot*2 KB + (m0/32 + TM wm)*2 KB
+    const __amdgpu_buffer_rsrc_t wrs = nef_rsrc(wph + ((int64_t)g * nc16 * K * ncot * 2 + (int64_t)(m0 / 32 + TM * wm) * 2) * 512);
+    const unsigned a_tap = (unsigned)(ncot * 2 * 1024);      // bytes between taps of one chunk
+    const unsigned avo = (unsigned)(lane * 16);
+
+    unsigned xvo[NIT][NS];
+    float lam[NIT];
+    bool xok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int r = lane + 64 * it;
+        const int t = t0 + r - PAD;
+        xok[it] = (r < XROW) && (t >= 0) && (t < T);
+        lam[it] = 0.f;
+        if constexpr (UP) {
+            float src = 0.5f * ((float)t + 0.5f) - 0.5f;
+            if (src < 0.f) src = 0.f;
+            int i0 = (int)src;
+            if (i0 > Tin - 1) i0 = Tin - 1;
+            const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+            lam[it] = src - (float)i0;
+            xvo[it][0] = xok[it] ? (unsigned)(i0 * 4) : NEF_OOB;
+            xvo[it][NS - 1] = xok[it] ? (unsigned)(i1 * 4) : NEF_OOB;
+        } else {
+            xvo[it][0] = xok[it] ? (unsigned)(t * 4) : NEF_OOB;
+        }
+    }
+    const int64_t soff = (int64_t)b0 * a.sc_bs + (int64_t)g * a.sc_gs;
+    // input scale (an exact power of two, undone in the epilogue): from the magnitude this operand had at the call site's previous
+    // launch (*x_amax -> [2^8, 2^9): room for a 128x jump before anything is clamped, full precision for elements within 2^-9 of the
+    // largest), else the caller's x_scale, else 1
+    float xs_ = a.x_scale != 0.f ? a.x_scale : 1.f;
+    if (a.x_amax) {
+        const float m_ = a.x_amax[0];
+        if (m_ > 0.f && m_ < 3e38f) {
+            int e_;
+            (void)frexpf(m_, &e_);
+            xs_ = ldexpf(1.f, 9 - e_);
+        }
+    }
+    float amax_ = 0.f;
+    const int pro_row0 = AFF ? (b0 / a.pro_Bp) * a.G * Cig + g * Cig : 0;
+
+    f32x16 acc[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- operand streams
+    float xreg[4][NIT][NS];          // this wave's 4 channels (4 wave + 0..3) of the stage in flight
+#define NEF_H2X_ISSUE(C0, RS)                                                                                        \
+    {                                                                                                               \
+        _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                          \
+            const unsigned so = (unsigned)(((C0) + 4 * wave_u + rr) * Tin * 4);                                     \
+            _Pragma("unroll") for (int it = 0; it < NIT; ++it)                                                      \
+                _Pragma("unroll") for (int ns = 0; ns < NS; ++ns) xreg[rr][it][ns] = nef_buf_f32(RS, xvo[it][ns], so); \
+        }                                                                                                           \
+    }
+    // split the stage in registers and store it: position r of channel c -> plane[(r & 3) * P4 + (r >> 2)][c]
+#define NEF_H2X_STORE(C0, BUFP)                                                                                      \
+    {                                                                                                               \
+        float sa_[4], pa_[4], pb_[4];                                                                               \
+        _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                          \
+            sa_[rr] = a.in_scale ? a.in_scale[soff + (C0) + 4 * wave + rr] : 1.f;                                   \
+            pa_[rr] = 1.f, pb_[rr] = 0.f;                                                                           \
+            if constexpr (AFF) {                                                                                    \
+                pa_[rr] = Pl[(C0) + 4 * wave_u + rr];                                                               \
+                pb_[rr] = Pl[Cig + (C0) + 4 * wave_u + rr];                                                         \
+            }                                                                                                       \
+        }                                                                                                           \
+        _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                        \
+            float v_[4];                                                                                            \
+            _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                      \
+                float v = xreg[rr][it][0];                                                                          \
+                if constexpr (AFF) v = fmaxf(fmaf(v, pa_[rr], pb_[rr]), 0.f);                                       \
+                if constexpr (UP) {                                                                                 \
+                    float v1 = xreg[rr][it][NS - 1];                                                                \
+                    if constexpr (AFF) v1 = fmaxf(fmaf(v1, pa_[rr], pb_[rr]), 0.f);                                 \
+                    v = (1.f - lam[it]) * v + lam[it] * v1;                                                         \
+                }                                                                                                   \
+                if constexpr (PRO != 0) v = xok[it] ? v : 0.f;                                                      \
+                v *= sa_[rr];                                                                                       \
+                amax_ = fmaxf(amax_, fabsf(v));                                                                     \
+                v_[rr] = v * xs_;                                                                                   \
+            }                                                                                                       \
+            const int r = lane + 64 * it;                                                                           \
+            unsigned h0_, l0_, h1_, l1_;                                                                            \
+            split2(v_[0], v_[1], h0_, l0_);                                                                         \
+            split2(v_[2], v_[3], h1_, l1_);                                                                         \
+            const u32x2 hv = {h0_, h1_}, lv = {l0_, l1_};                                                           \
+            if (r < XROW) {                                                                                         \
+                unsigned char* p_ = (BUFP) + (((r & 3) * P4 + (r >> 2)) * 32 + 8 * wave);                           \
+                *reinterpret_cast<u32x2*>(p_) = hv;                                                                 \
+                *reinterpret_cast<u32x2*>(p_ + PLANE) = lv;                                                         \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
+    h16x8 fa[2][2 * TM];             // [set][2 * co-tile + plane]
+#define NEF_H2A_ISSUE(CH, KK, SET)                                                                                   \
+    {                                                                                                               \
+        const unsigned so_ = (unsigned)(((CH) * K + (KK)) * a_tap);                                                 \
+        _Pragma("unroll") for (int q = 0; q < 2 * TM; ++q)                                                          \
+            fa[SET][q] = __builtin_bit_cast(h16x8, nef_buf_f32x4(wrs, avo, so_ + (unsigned)(q * 1024)));            \
+    }
+
+    NEF_H2X_ISSUE(0, xrs)
+    NEF_H2A_ISSUE(0, 0, 0)
+    if (threadIdx.x < MT) {     // epilogue tables, published by the barrier behind the first stage's LDS stores
+        const int ch_ = g * Cog + m0 + (int)threadIdx.x;
+        const float* const dsc = reinterpret_cast<const float*>(wph + (int64_t)a.G * K * Cog * Cig * 2);
+        El[threadIdx.x] = a.bias ? a.bias[ch_] : 0.f;
+        El[5 * MT + threadIdx.x] = dsc[ch_] / xs_;
+        if (a.bnb_slots) {
+            const int pr_ = (b0 / a.bnb_Bp) * a.G * Cog + ch_;
+            El[MT + threadIdx.x] = a.bnb_mean[pr_];
+            El[2 * MT + threadIdx.x] = a.bnb_invstd[pr_];
+            El[3 * MT + threadIdx.x] = a.bnb_a[pr_];
+            El[4 * MT + threadIdx.x] = a.bnb_b[pr_];
+        }
+    }
+    if constexpr (AFF) {
+        for (int i = threadIdx.x; i < Cig; i += 256) {
+            Pl[i] = a.pro_a[pro_row0 + i];
+            Pl[Cig + i] = a.pro_b[pro_row0 + i];
+        }
+        __syncthreads();
+    }
+    NEF_H2X_STORE(0, Xl)
+    __syncthreads();
+
+    const int nst = Cig / KC;
+    // this lane's fragment address inside a plane: position wn * 32 + lo (+ the s-dependent constant), channels 8 hi ..
+    const unsigned fb_lane = (unsigned)((wn * 32 + lo) * 32 + hi * 16);
+    for (int st = 0; st < nst; ++st) {
+        const unsigned char* const xb = Xl + (st & 1) * (2 * PLANE) + fb_lane;
+        const bool more = st + 1 < nst;
+        const __amdgpu_buffer_rsrc_t xrs_n = nef_rsrc_n(xbase, more ? 0x7FFFFFFCu : 0u);      // branch-free: see conv_wino4_kernel
+        NEF_H2X_ISSUE((st + 1) * KC, xrs_n)
+        h16x8 fb[5][2];              // ring over s: [slot][plane]
+#define NEF_H2B_LOAD(S)                                                                                              \
+    {                                                                                                               \
+        const unsigned char* p_ = xb + ((((S) & 3) * P4 + ((S) >> 2)) * 32);                                        \
+        fb[(S) % 5][0] = *reinterpret_cast<const h16x8*>(p_);                                                       \
+        fb[(S) % 5][1] = *reinterpret_cast<const h16x8*>(p_ + PLANE);                                               \
+    }
+        NEF_H2B_LOAD(0)
+        NEF_H2B_LOAD(1)
+        NEF_H2B_LOAD(2)
+        NEF_H2B_LOAD(3)
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            // next tap's A fragments (the next stage's first tap behind the last one; past the end: a repeat, harmless)
+            if (kk + 1 < K) NEF_H2A_ISSUE(st, kk + 1, (kk + 1) & 1)
+            else NEF_H2A_ISSUE(more ? st + 1 : st, 0, (kk + 1) & 1)
+            if (kk + 4 < NSF) NEF_H2B_LOAD(kk + 4)
+            __builtin_amdgcn_s_setprio(1);      // scheduling fence (see conv_wino_kernel)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const h16x8 bh = fb[(kk + j) % 5][0], bl = fb[(kk + j) % 5][1];
+                const int s_ = kk & 1;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s_][2 * i], bh, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s_][2 * i], bl, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s_][2 * i + 1], bh, acc[i][j], 0, 0, 0);
+            }
+        }
+#undef NEF_H2B_LOAD
+        // K odd: the set toggles K times per stage, so stage st + 1 finds its tap 0 in set (K & 1) ^ ... -- keep it simple:
+        // the last issue above wrote set (K & 1); with K odd that is set 1, but tap 0 of the next stage reads set 0
+        if constexpr ((K & 1) != 0) {
+#pragma unroll
+            for (int q = 0; q < 2 * TM; ++q) fa[0][q] = fa[1][q];
+        }
+        if (more) NEF_H2X_STORE((st + 1) * KC, Xl + ((st + 1) & 1) * (2 * PLANE))
+        __syncthreads();
+    }
+#undef NEF_H2X_ISSUE
+#undef NEF_H2X_STORE
+#undef NEF_H2A_ISSUE
+
+    if (a.x_amax_next) {      // this launch's own input magnitude, for the call site's next launch
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax_ = fmaxf(amax_, __shfl_xor(amax_, o, 64));
+        if (lane == 0 && amax_ < 3e38f) {
+            unsigned* const p_ = reinterpret_cast<unsigned*>(a.x_amax_next);
+            const unsigned b_ = __builtin_bit_cast(unsigned, amax_);       // non-negative floats order like their bit patterns
+            if (b_ > __atomic_load_n(p_, __ATOMIC_RELAXED)) atomicMax(p_, b_);
+        }
+    }
+    // ---- epilogue: descale, then bias / residual / ReLU / dropout / gate on the four adjacent outputs a lane owns per row
+    const int64_t ctot = (int64_t)a.G * Cog;
+    const int t = t0 + wn * 128 + 4 * lo;
+    const bool inb = b0 < a.B;
+    const bool live[2] = {inb && t < T, inb && t + 2 < T};
+    const int ts[2] = {live[0] ? t : 0, live[1] ? t + 2 : 0};
+    const bool ragged = t0 + NTO > T;                    // workgroup-uniform
+    float* const slot_out = a.bnb_slots ? a.bnb_slots : a.stats;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int cobase = m0 + wm * (32 * TM) + i * 32 + 4 * hi;
+        const int erow0 = wm * (32 * TM) + i * 32 + 4 * hi;
+        float sv[32];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#define NEF_ROW(q) ((((q) + 8 * h) & 3) + 8 * (((q) + 8 * h) >> 2))
+            float y[8][4];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float ds = El[5 * MT + erow0 + NEF_ROW(q)];
+                const float bv = El[erow0 + NEF_ROW(q)];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[q][e] = fmaf(acc[i][e][q + 8 * h], ds, bv);
+            }
+#define NEF_EPI_FETCH4(PTR, BS, GS, DST)                                                                              \
+    if (!ragged) {                                                                                                  \
+        const __amdgpu_buffer_rsrc_t rs_ =                                                                          \
+            nef_rsrc((PTR) + (int64_t)b0 * (BS) + (int64_t)g * (GS) + (int64_t)(m0 + wm * (32 * TM) + i * 32) * T);        \
+        const unsigned vo_ = inb ? (unsigned)((4 * hi * T + t) * 4) : NEF_OOB;                                      \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                             \
+            const f32x4 t4 = nef_buf_f32x4(rs_, vo_, (unsigned)(NEF_ROW(q) * T * 4));                               \
+            DST[q][0] = t4[0]; DST[q][1] = t4[1]; DST[q][2] = t4[2]; DST[q][3] = t4[3];                             \
+        }                                                                                                           \
+    } else {                                                                                                        \
+        _Pragma("unroll") for (int pr = 0; pr < 2; ++pr) {                                                          \
+            const float* p_ = (PTR) + (int64_t)b0 * (BS) + (int64_t)g * (GS) + (int64_t)cobase * T + ts[pr];        \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                         \
+                const f32x2 t2 = *reinterpret_cast<const f32x2*>(p_ + (int64_t)NEF_ROW(q) * T);                     \
+                DST[q][2 * pr] = t2[0];                                                                             \
+                DST[q][2 * pr + 1] = t2[1];                                                                         \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
+            if (a.res) {
+                float rv[8][4];
+                NEF_EPI_FETCH4(a.res, a.res_bs, a.res_gs, rv)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[q][e] += rv[q][e];
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[q][e] = fmaxf(y[q][e], 0.f);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {        // dropout works on the two output pairs (t, t+1), (t+2, t+3)
+                if (a.mask) {
+                    const uint8_t* mp = a.mask + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T + ts[pr];
+                    unsigned short t8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) t8[q] = *reinterpret_cast<const unsigned short*>(mp + (int64_t)NEF_ROW(q) * T);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        y[q][2 * pr] *= (float)(t8[q] & 0xff) * a.drop_scale;
+                        y[q][2 * pr + 1] *= (float)(t8[q] >> 8) * a.drop_scale;
+                    }
+                } else if (a.drop_p > 0.f) {
+                    const int64_t d0 = ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T + ts[pr];
+                    const uint64_t seed = a.rng_seed + (a.rng_seed_dev ? a.rng_seed_dev[0] : 0ull);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const uint64_t dense = (uint64_t)(d0 + (int64_t)NEF_ROW(q) * T);
+                        float u0, u1;
+                        nef_rng_uniform2(seed, dense, u0, u1);
+                        y[q][2 * pr] = (u0 >= a.drop_p) ? y[q][2 * pr] * a.drop_scale : 0.f;
+                        y[q][2 * pr + 1] = (u1 >= a.drop_p) ? y[q][2 * pr + 1] * a.drop_scale : 0.f;
+                    }
+                }
+            }
+            if (a.gate) {
+                float gv[8][4];
+                NEF_EPI_FETCH4(a.gate, a.gate_bs, a.gate_gs, gv)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[q][e] = gv[q][e] > 0.f ? y[q][e] * a.gate_scale : 0.f;
+            }
+#undef NEF_EPI_FETCH4
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                if (live[pr] && !live[1]) {      // the half-live quad at the end of a row with T % 4 == 2
+                    float* yp = a.y + (int64_t)b0 * a.y_bs + (int64_t)g * a.y_gs + (int64_t)cobase * T + t + 2 * pr;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        f32x2 o;
+                        o[0] = y[q][2 * pr];
+                        o[1] = y[q][2 * pr + 1];
+                        *reinterpret_cast<f32x2*>(yp + (int64_t)NEF_ROW(q) * T) = o;
+                    }
+                }
+            }
+            {
+                const __amdgpu_buffer_rsrc_t yrs =
+                    nef_rsrc(a.y + (int64_t)b0 * a.y_bs + (int64_t)g * a.y_gs + (int64_t)(m0 + wm * (32 * TM) + i * 32) * T);
+                const unsigned yvo = live[1] ? (unsigned)((4 * hi * T + t) * 4) : NEF_OOB;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    f32x4 o;
+                    o[0] = y[q][0];
+                    o[1] = y[q][1];
+                    o[2] = y[q][2];
+                    o[3] = y[q][3];
+                    nef_buf_store_f32x4(o, yrs, yvo, (unsigned)(NEF_ROW(q) * T * 4));
+                }
+            }
+            if (a.bnb_slots && a.bnb_up) {      // see conv_wino4_kernel: BatchNorm-backward sums through the x2 upsampling's adjoint
+                const int Lh = T >> 1;
+                const float* xp = a.bnb_x + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * Lh;
+                const int j2 = live[0] ? (t >> 1) : 0;
+                const int im1 = j2 > 0 ? j2 - 1 : 0, i1 = j2 + 1 < Lh ? j2 + 1 : Lh - 1, ip2 = j2 + 2 < Lh ? j2 + 2 : Lh - 1;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int row = NEF_ROW(q);
+                    const int er = erow0 + row;
+                    const float af = El[3 * MT + er], bf = El[4 * MT + er];
+                    const float mf = El[MT + er], is = El[2 * MT + er];
+                    const float* xr = xp + (int64_t)row * Lh;
+                    const float xa = xr[im1], xb_ = xr[j2], xc = xr[i1], xd = xr[ip2];
+                    const float ma = fmaf(xa, af, bf) > 0.f ? 1.f : 0.f, mb = fmaf(xb_, af, bf) > 0.f ? 1.f : 0.f;
+                    const float mc = fmaf(xc, af, bf) > 0.f ? 1.f : 0.f, md = fmaf(xd, af, bf) > 0.f ? 1.f : 0.f;
+                    const float ha = ma * ((xa - mf) * is), hb = mb * ((xb_ - mf) * is);
+                    const float hc = mc * ((xc - mf) * is), hd = md * ((xd - mf) * is);
+                    const float g0 = live[0] ? y[q][0] : 0.f, g1 = live[0] ? y[q][1] : 0.f;
+                    const float g2 = live[1] ? y[q][2] : 0.f, g3 = live[1] ? y[q][3] : 0.f;
+                    sv[2 * (q + 8 * h)] = fmaf(g0, fmaf(0.75f, mb, 0.25f * ma), g1 * fmaf(0.75f, mb, 0.25f * mc)) +
+                                          fmaf(g2, fmaf(0.75f, mc, 0.25f * mb), g3 * fmaf(0.75f, mc, 0.25f * md));
+                    sv[2 * (q + 8 * h) + 1] = fmaf(g0, fmaf(0.75f, hb, 0.25f * ha), g1 * fmaf(0.75f, hb, 0.25f * hc)) +
+                                              fmaf(g2, fmaf(0.75f, hc, 0.25f * hb), g3 * fmaf(0.75f, hc, 0.25f * hd));
+                }
+            } else if (a.bnb_slots) {
+                const float* xp = a.bnb_x + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int row = NEF_ROW(q);
+                    const int er = erow0 + row;
+                    const float af = El[3 * MT + er], bf = El[4 * MT + er];
+                    const float mf = El[MT + er], is = El[2 * MT + er];
+                    const f32x2 x01 = *reinterpret_cast<const f32x2*>(xp + (int64_t)row * T + ts[0]);
+                    const f32x2 x23 = *reinterpret_cast<const f32x2*>(xp + (int64_t)row * T + ts[1]);
+                    const float g0 = (live[0] && fmaf(x01[0], af, bf) > 0.f) ? y[q][0] : 0.f;
+                    const float g1 = (live[0] && fmaf(x01[1], af, bf) > 0.f) ? y[q][1] : 0.f;
+                    const float g2 = (live[1] && fmaf(x23[0], af, bf) > 0.f) ? y[q][2] : 0.f;
+                    const float g3 = (live[1] && fmaf(x23[1], af, bf) > 0.f) ? y[q][3] : 0.f;
+                    sv[2 * (q + 8 * h)] = (g0 + g1) + (g2 + g3);
+                    sv[2 * (q + 8 * h) + 1] = fmaf(g0, (x01[0] - mf) * is, g1 * ((x01[1] - mf) * is)) +
+                                              fmaf(g2, (x23[0] - mf) * is, g3 * ((x23[1] - mf) * is));
+                }
+            } else if (a.stats) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float y0 = live[0] ? y[q][0] : 0.f, y1 = live[0] ? y[q][1] : 0.f;
+                    const float y2 = live[1] ? y[q][2] : 0.f, y3 = live[1] ? y[q][3] : 0.f;
+                    sv[2 * (q + 8 * h)] = (y0 + y1) + (y2 + y3);
+                    sv[2 * (q + 8 * h) + 1] = fmaf(y0, y0, y1 * y1) + fmaf(y2, y2, y3 * y3);
+                }
+            }
+#undef NEF_ROW
+        }
+        if (slot_out) {      // halving butterfly over the 32 lanes that share `hi` (conv_wino4_kernel): lane lo ends with value lo
+#pragma unroll
+            for (int step = 0; step < 5; ++step) {
+                const int off = 16 >> step;
+                const bool up = (lo & off) != 0;
+#pragma unroll
+                for (int k = 0; k < off; ++k) {
+                    const float send = up ? sv[k] : sv[k + off];
+                    const float keep = up ? sv[k + off] : sv[k];
+                    sv[k] = keep + __shfl_xor(send, off, 64);
+                }
+            }
+            const int r = lo >> 1;
+            const int ch = g * Cog + cobase + (r & 3) + 8 * (r >> 2);
+            const int64_t nslot = (int64_t)tps * 2;
+            const int64_t slot = (int64_t)b0 * nslot + (int64_t)(t0 / NTO) * 2 + wn;
+            if (inb) slot_out[((int64_t)ch * a.B * nslot + slot) * 2 + (lo & 1)] = sv[0];
+        }
+    }
+}
+
+template <int K, int PRO, int TM>
+int launch_h2(const nef_conv_args& a, hipStream_t st) {
+    constexpr int MT = 64 * TM;
+    constexpr int XROW = NTO + K - 1;
+    constexpr int P4 = (XROW + 3) / 4 + 1;
+    constexpr int PLANE = 4 * P4 * 32;
+    constexpr size_t lds = (size_t)4 * PLANE + (((PRO & 1) ? 2 * PRO_MAX_CIN : 0) + 6 * MT) * sizeof(float);
+    static unsigned long long lds_set = 0;
+    if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_h2_kernel<K, PRO, TM>), lds, &lds_set)) return e;
+    const int tps = (a.T + NTO - 1) / NTO;
+    const int n_tiles = a.B * tps;
+    const int m_tiles = a.Cout_g / MT;
+    const int64_t blocks = (int64_t)a.G * m_tiles * n_tiles;
+    if (blocks <= 0 || blocks > 0x7fffffff) return NEF_E_SHAPE;
+    hipLaunchKernelGGL((conv_h2_kernel<K, PRO, TM>), dim3((unsigned)blocks), dim3(256), lds, st, a, tps, n_tiles, m_tiles);
+    return nef_launch_status();
+}
+
+}  // namespace
+
+// ---- entry points of this file (hidden: reached through nef_conv_fwd / nef_pack_weights / nef_pack_weight_h2)
+__attribute__((visibility("hidden"))) bool nef_h2_ok(const nef_conv_args* a) {
+    return (a->K == 3 || a->K == 7) && a->Cout_g % 64 == 0 && a->Cin_g % KC == 0 && a->T % 2 == 0 && a->T >= NTO / 2 &&
+           a->pro_mode >= 0 && a->pro_mode <= 3 && (a->K == 3 || a->pro_mode == 0) && !(a->pro_mode && a->in_scale) &&
+           (!(a->pro_mode & 1) || a->Cin_g <= PRO_MAX_CIN);
+}
+
+__attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, hipStream_t st) {
+    if (!nef_h2_ok(a)) return NEF_E_SHAPE;
+    if ((a->pro_mode & 1) && !(a->pro_a && a->pro_b && a->pro_Bp > 0)) return NEF_E_NULL;
+    const bool wide = a->Cout_g % 128 == 0;
+    if (a->K == 7) return wide ? launch_h2<7, 0, 2>(*a, st) : launch_h2<7, 0, 1>(*a, st);
+    switch (a->pro_mode) {
+        case 0: return wide ? launch_h2<3, 0, 2>(*a, st) : launch_h2<3, 0, 1>(*a, st);
+        case 1: return wide ? launch_h2<3, 1, 2>(*a, st) : launch_h2<3, 1, 1>(*a, st);
+        case 2: return wide ? launch_h2<3, 2, 2>(*a, st) : launch_h2<3, 2, 1>(*a, st);
+        default: return wide ? launch_h2<3, 3, 2>(*a, st) : launch_h2<3, 3, 1>(*a, st);
+    }
+}
+
+__attribute__((visibility("hidden"))) int nef_h2_pack(const nef_pack_desc* descs, int n, hipStream_t st) {
+    for (int i0 = 0; i0 < n; i0 += H2_PACK_MAX) {
+        H2PackTable tab;
+        const int m = n - i0 < H2_PACK_MAX ? n - i0 : H2_PACK_MAX;
+        int rows_max = 1;
+        for (int i = 0; i < m; ++i) {
+            const nef_pack_desc& d = descs[i0 + i];
+            if (!d.w || !d.wp) return NEF_E_NULL;
+            const int co_n = d.transpose_flip ? d.Cig : d.Cog, ci_n = d.transpose_flip ? d.Cog : d.Cig;
+            if (d.G <= 0 || co_n % 32 != 0 || ci_n % 16 != 0 || (d.K != 3 && d.K != 7)) return NEF_E_SHAPE;
+            tab.d[i] = H2PackDesc{d.w, reinterpret_cast<_Float16*>(d.wp), d.G, d.Cog, d.Cig, d.K, d.transpose_flip};
+            if (d.G * co_n > rows_max) rows_max = d.G * co_n;
+        }
+        hipLaunchKernelGGL(pack_h2_kernel, dim3((unsigned)((rows_max + 3) / 4), (unsigned)m), dim3(256), 0, st, tab);
+    }
+    return nef_launch_status();
+}

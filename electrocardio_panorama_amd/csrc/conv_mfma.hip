@@ -2318,9 +2318,14 @@ constexpr int CHAN_SUM_SPLIT = 16;
 
 }  // namespace
 
+// conv_h2.hip: direct convolutions on exact fp16 splits of the fp32 operands (conv args wino = 3)
+__attribute__((visibility("hidden"))) bool nef_h2_ok(const nef_conv_args* a);
+__attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, hipStream_t st);
+__attribute__((visibility("hidden"))) int nef_h2_pack(const nef_pack_desc* descs, int n, hipStream_t st);
+
 extern "C" {
 
-int nef_abi_version(void) { return 12; }
+int nef_abi_version(void) { return 13; }
 
 int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                     nef_stream_t stream) {
@@ -2355,22 +2360,52 @@ int nef_pack_weight_wino4(const float* w, float* wp, int G, int Cog, int Cig, in
     return nef_launch_status();
 }
 
+int nef_pack_weight_h2(const float* w, void* wp, int G, int Cog, int Cig, int K, int transpose_flip, nef_stream_t stream) {
+    NEF_ENTER();
+    nef_pack_desc d;
+    d.w = w;
+    d.wp = (float*)wp;
+    d.G = G, d.Cog = Cog, d.Cig = Cig, d.K = K, d.transpose_flip = transpose_flip, d.wino = 3;
+    return nef_h2_pack(&d, 1, (hipStream_t)stream);
+}
+
+size_t nef_pack_weight_h2_bytes(int G, int Cog, int Cig, int K, int transpose_flip) {
+    if (G <= 0 || Cog <= 0 || Cig <= 0 || K <= 0) return 0;
+    return ((size_t)G * K * Cog * Cig + (size_t)G * (transpose_flip ? Cig : Cog)) * sizeof(float);
+}
+
 int nef_pack_weights(const nef_pack_desc* descs, int n, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(descs || n == 0, NEF_E_NULL);
     NEF_REQUIRE(n >= 0, NEF_E_SHAPE);
+    nef_pack_desc h2[PACK_MULTI_MAX];      // split-fp16 operands (wino == 3) are packed by conv_h2.hip
+    int n_h2 = 0;
     for (int i = 0; i < n; ++i) {
         const nef_pack_desc& d = descs[i];
         NEF_REQUIRE(d.w && d.wp, NEF_E_NULL);
-        NEF_REQUIRE(d.G > 0 && d.Cog > 0 && d.Cig > 0 && d.K > 0 && d.wino >= 0 && d.wino <= 2 &&
+        NEF_REQUIRE(d.G > 0 && d.Cog > 0 && d.Cig > 0 && d.K > 0 && d.wino >= 0 && d.wino <= 3 &&
                         (!d.wino || d.K == 3 || d.K == 7), NEF_E_SHAPE);
+        if (d.wino == 3) {
+            if (n_h2 == PACK_MULTI_MAX) {
+                if (int e = nef_h2_pack(h2, n_h2, (hipStream_t)stream)) return e;
+                n_h2 = 0;
+            }
+            h2[n_h2++] = d;
+        }
     }
-    for (int i0 = 0; i0 < n; i0 += PACK_MULTI_MAX) {
+    if (n_h2) {
+        if (int e = nef_h2_pack(h2, n_h2, (hipStream_t)stream)) return e;
+    }
+    for (int i0 = 0; i0 < n;) {
         PackTable t;
-        const int m = n - i0 < PACK_MULTI_MAX ? n - i0 : PACK_MULTI_MAX;
+        int m = 0;
         int64_t biggest = 1;
+        for (; i0 < n && m < PACK_MULTI_MAX; ++i0) {
+            if (descs[i0].wino == 3) continue;
+            t.d[m++] = descs[i0];
+        }
+        if (m == 0) break;
         for (int i = 0; i < m; ++i) {
-            t.d[i] = descs[i0 + i];
             const int64_t e = (int64_t)t.d[i].G * t.d[i].Cog * t.d[i].Cig * (t.d[i].wino ? 1 : t.d[i].K);
             if (e > biggest) biggest = e;
         }
@@ -2398,11 +2433,15 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
     NEF_REQUIRE(K == 1 || K == 3 || K == 7, NEF_E_SHAPE);
     NEF_REQUIRE(a->Cout_g % 64 == 0 && a->Cin_g > 0, NEF_E_SHAPE);
     hipStream_t st = (hipStream_t)stream;
-    NEF_REQUIRE((!a->stats && !a->bnb_slots) || a->wino == 2, NEF_E_UNSUPPORTED);   // only the F(4,3) epilogue leaves slot sums
+    NEF_REQUIRE((!a->stats && !a->bnb_slots) || a->wino == 2 || a->wino == 3, NEF_E_UNSUPPORTED);   // only the F(4,3) and split-fp16 epilogues leave slot sums
     NEF_REQUIRE(!(a->stats && a->bnb_slots), NEF_E_UNSUPPORTED);
     NEF_REQUIRE(!a->bnb_slots || (a->bnb_x && a->bnb_mean && a->bnb_invstd && a->bnb_a && a->bnb_b), NEF_E_NULL);
     NEF_REQUIRE(!a->bnb_slots || a->bnb_Bp > 0, NEF_E_SHAPE);
     NEF_REQUIRE(!a->bnb_slots || !a->bnb_up || a->T % 4 == 0, NEF_E_SHAPE);
+    if (a->wino == 3) {      // operand packed by nef_pack_weight_h2: direct conv on exact fp16 splits (conv_h2.hip)
+        NEF_REQUIRE(nef_h2_ok(a), NEF_E_SHAPE);
+        return nef_h2_launch(a, st);
+    }
     bool big = (a->Cout_g % 128 == 0);
     if (big) {
         // small problems (reference-native batch 32, L=512): a 128-row tile gives fewer workgroups than the chip has

@@ -235,7 +235,7 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
         T_out = x_in.shape[2] * (2 if up_after and pro[0] & 2 else 1)
         stats = None
         if li == 0 and shared_B is not None:
-            p2 = ops.conv(GV.dense(x_in, 2), ops.pack_weight(_regroup_halves(P[wname]), 2, T=T_out, f4=True), cout, 3, pro=pro)
+            p2 = ops.conv(GV.dense(x_in, 2), ops.pack_weight(_regroup_halves(P[wname]), 2, T=T_out, f4=True, site=P[wname].data_ptr()), cout, 3, pro=pro)
             if training and passes == 3:      # the BatchNorm statistics of c1 come out of the same pass
                 c, *stats = ops.pass_combine_fwd_stats(p2, P[bname], shared_B, P[pre + ".weight"], P[pre + ".bias"],
                                                        Bf[pre + ".running_mean"], Bf[pre + ".running_var"], BN_EPS, BN_MOM)
@@ -302,7 +302,7 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
             gp2 = gc if gc.shape[0] == 2 * shared_B else ops.pass_combine_bwd(gc)   # [2B, 2*128, 2T]
             gpv, xv = GV.dense(gp2, 2), GV.dense(x, 2)
             grads[wname] = side.run(lambda: _ungroup_halves(ops.conv_bwd_weight(xv, gpv, 3, pro=pro)), x, gp2)
-            g = ops.conv(gpv, ops.pack_weight(_regroup_halves(P[wname]), 2, flip=True, T=gp2.shape[2], f4=True), x.shape[1] // 2, 3,
+            g = ops.conv(gpv, ops.pack_weight(_regroup_halves(P[wname]), 2, flip=True, T=gp2.shape[2], f4=True, site=P[wname].data_ptr()), x.shape[1] // 2, 3,
                          role="conv_bwd_data")
         else:
             gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
@@ -402,6 +402,7 @@ def forward(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", t
     drop = drop or DropCfg(False)
     B, V, L = x.shape
     T = L // 4
+    ops.amax_roll()        # split-fp16 convs: last pass's operand magnitudes become this pass's input scales
     z1, z2b, sv = _latents(P, x, in_theta, rois, drop, save)
     if phase == "gen":
         return (z1, z2b), None
@@ -425,6 +426,7 @@ def forward2(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", 
     drop = drop or DropCfg(False)
     B, V, L = x.shape
     T, N = L // 4, V * B
+    ops.amax_roll()
     xf = x.transpose(0, 1).reshape(N, 1, L).contiguous()
     thf = in_theta.transpose(0, 1).reshape(N, 1, 2).contiguous()
     roisf = rois.repeat(V, 1, 1)

@@ -89,13 +89,14 @@ class GraphedTrainStep:
         m = self.model
         P = {k: v.detach() for k, v in m.named_parameters()}
         drop = engine.DropCfg(True, m.dropout_p, m.dropout_masks, seed=0, seed_dev=self.seed_dev)
-        outs, sv = engine.forward(P, dict(m.named_buffers()), self.data, self.in_theta, self.q_theta, self.rois,
-                                  phase="train", training=True, drop=drop, lead_choice=self.choice_dev, save=True,
-                                  status=self.status)
-        o, p_, l_ = (t.contiguous() for t in outs)
-        self.losses.copy_(ops.loss_fwd(o, p_, l_, self.target, self.factors, self.reg_l2, self.use_mask))
-        g3 = ops.loss_bwd(o, p_, l_, self.target, None, self.factors, self.reg_l2, self.use_mask)
-        return engine.backward(P, sv, g3)
+        with ops.amax_scope(m._nef_scope):
+            outs, sv = engine.forward(P, dict(m.named_buffers()), self.data, self.in_theta, self.q_theta, self.rois,
+                                      phase="train", training=True, drop=drop, lead_choice=self.choice_dev, save=True,
+                                      status=self.status)
+            o, p_, l_ = (t.contiguous() for t in outs)
+            self.losses.copy_(ops.loss_fwd(o, p_, l_, self.target, self.factors, self.reg_l2, self.use_mask))
+            g3 = ops.loss_bwd(o, p_, l_, self.target, None, self.factors, self.reg_l2, self.use_mask)
+            return engine.backward(P, sv, g3)
 
     def _sgd(self):
         ops.sgd_momentum(self.flat_p, self.flat_g, self.flat_buf, self.lr, self.mu, 1.0 / self.world, False)

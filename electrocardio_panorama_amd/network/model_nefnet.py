@@ -13,7 +13,7 @@ import random
 import torch
 import torch.nn as nn
 
-from .. import engine
+from .. import engine, ops
 
 
 class _Block(nn.Module):
@@ -71,11 +71,23 @@ class _NefNetFn(torch.autograd.Function):
 
 class Model_nefnet(nn.Module):
     """Nef-Net (reference codes/network/model_nefnet.py:63)."""
-    _engine_fwd = staticmethod(engine.forward)
-    _engine_bwd = staticmethod(engine.backward)
+    _ENGINE = (engine.forward, engine.backward)
+
+    def _engine_fwd(self, *args, **kw):
+        with ops.amax_scope(self._nef_scope):       # the split-fp16 convs keep their operand magnitudes per model (ops.py)
+            return self._ENGINE[0](*args, **kw)
+
+    def _engine_bwd(self, *args, **kw):
+        with ops.amax_scope(self._nef_scope):
+            return self._ENGINE[1](*args, **kw)
+
+    def load_state_dict(self, *args, **kw):
+        self._nef_scope = ops.new_amax_scope()      # other weights, other magnitudes: measure again
+        return super().load_state_dict(*args, **kw)
 
     def __init__(self, theta_encoder_len=1, lead_num=1):
         super().__init__()
+        self._nef_scope = ops.new_amax_scope()
         if theta_encoder_len != 1:
             # ThetaEncoder.forward ignores encoder_len (theta_encoder.py:13-29), so mlp1/mlp2 only fit theta_L == 1
             raise ValueError("theta_encoder_len must be 1 (the reference's angular encoding emits 12 values)")
@@ -204,8 +216,7 @@ class Model_nefnet2(Model_nefnet):
     except that phase 'gen' returns the two lead MEANS `(z1_mean, z2_mean)`, each [B, 128, T] (model_nefnet2.py:158-159).
     Not reachable from the reference's config (`build_model` only knows 'model_nefnet'); offered under the name
     'model_nefnet2'.  `dropout_masks`, when set, are per folded sample (lead-major, V*B rows)."""
-    _engine_fwd = staticmethod(engine.forward2)
-    _engine_bwd = staticmethod(engine.backward2)
+    _ENGINE = (engine.forward2, engine.backward2)
 
     @staticmethod
     def _group_leads(lead_num):

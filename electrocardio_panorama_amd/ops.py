@@ -5,6 +5,8 @@ ROIs) tensors on a HIP device, allocates the outputs, and enqueues the library c
 stream.  Nothing here computes on the host and nothing falls back to torch ops.
 """
 import ctypes as C
+import contextlib
+import itertools
 import os
 
 import torch
@@ -216,6 +218,73 @@ WINO_BW7 = os.environ.get("NEF_BW7_F42", "1") == "1" and _WV not in ("1", "2")
 _WINO_PLANES = {(1, 3): 4, (1, 7): 10, (2, 3): 6, (2, 7): 13}
 
 
+# Split-fp16 direct convolution (csrc/conv_h2.hip, conv args wino = 3): both fp32 operands split exactly into two fp16 terms,
+# three fp16 matrix instructions per 16 channels and tap, fp32 accumulation -- fp32-class results at 3/16 of the fp32 matrix
+# instructions' pipe time.  NEF_H2=0 keeps the fp32 Winograd forms; NEF_H2=1 takes it wherever the shape allows
+# (128-channel output tiles, 16-channel input chunks, T even and >= 128; K = 7 without an input prologue).
+H2 = os.environ.get("NEF_H2", "0") == "1"
+_H2_DIR = {False: os.environ.get("NEF_H2_FWD", "1") == "1", True: os.environ.get("NEF_H2_BWD", "1") == "1"}     # diagnostics
+_H2_K = os.environ.get("NEF_H2_K", "3,7").split(",")
+
+
+def h2_ok(K, Cin_g, Cout_g, T_out, pro=0):
+    return (H2 and (K == 3 or (K == 7 and not pro)) and T_out % 2 == 0 and T_out >= 128 and Cin_g % 16 == 0 and
+            Cout_g % 64 == 0)
+
+
+# Input magnitudes of the split-fp16 launches, per call site (= per weight tensor and direction): `cur` is what a launch derives
+# its power-of-two input scale from, `nxt` is what it max-accumulates its own operand's magnitude into; amax_roll() -- once per
+# forward pass -- moves nxt into cur.  A site's FIRST launch runs twice: once to measure, once with the measured scale.  Nothing is
+# read back by the host, so the launches stay capturable; a site whose operand grows more than 16x from one step to the next
+# gets its largest elements clamped at 65000 / scale for that one step (conv_h2.hip).
+AMAX_SITES = 1024
+_AMAX = {}
+# A call site = (scope, weight address, direction, role, batch, length).  The scope is the owning model's token
+# (Model_nefnet sets it around every engine call; a fresh model or a loaded checkpoint gets a fresh token, so nothing is inherited
+# from whatever lived at the same addresses before).  Without a scope (bare engine / ops calls) every launch measures first.
+AMAX_SCOPE = None
+_SCOPE_IDS = itertools.count(1)
+
+
+def new_amax_scope():
+    return next(_SCOPE_IDS)
+
+
+@contextlib.contextmanager
+def amax_scope(token):
+    global AMAX_SCOPE
+    prev, AMAX_SCOPE = AMAX_SCOPE, token
+    try:
+        yield
+    finally:
+        AMAX_SCOPE = prev
+
+
+def _amax_state(dev):
+    st = _AMAX.get(dev)
+    if st is None:
+        st = _AMAX[dev] = dict(cur=torch.zeros(AMAX_SITES, device=dev, dtype=torch.float32),
+                               nxt=torch.zeros(AMAX_SITES, device=dev, dtype=torch.float32), index={}, ready=set(), used=False)
+    return st
+
+
+def amax_roll():
+    """cur <- nxt wherever a launch left a magnitude, nxt <- 0 (stream-ordered; three tiny launches)."""
+    for st in _AMAX.values():
+        if st["used"]:
+            torch.where(st["nxt"] > 0, st["nxt"], st["cur"], out=st["cur"])
+            st["nxt"].zero_()
+            st["used"] = False
+
+
+def _packed_floats(wino, K, G, Cog, Cig, flip):
+    """fp32 words of a packed operand: plain K per (co, ci); Winograd: planes per (co, ci); split-fp16: two halves per weight
+    = K words, + one descale word per output row of the launch."""
+    if wino == 3:
+        return G * Cog * Cig * K + G * (Cig if flip else Cog)
+    return G * Cog * Cig * (_WINO_PLANES[(wino, K)] if wino else K)
+
+
 def wino_ok(K, Cin_g, Cout_g, T_out, pro=0):
     return (WINOGRAD and (K == 3 or (K == 7 and not pro)) and T_out % 2 == 0 and Cin_g % 16 == 0 and
             ((Cout_g % 128 == 0 and T_out >= 128) or (Cout_g % 128 != 0 and Cout_g % 64 == 0 and T_out >= 256)))
@@ -228,6 +297,8 @@ def _pack_shape(w, G, flip, T, f4=False):
     Cog, Cig, K = w.shape[0] // G, w.shape[1], w.shape[2]
     cin_g, cout_g = (Cog, Cig) if flip else (Cig, Cog)          # roles in the launch that consumes the operand
     wino = (WINO_FWD if f4 else 1) if (T is not None and wino_ok(K, cin_g, cout_g, T)) else 0
+    if T is not None and h2_ok(K, cin_g, cout_g, T) and _H2_DIR[bool(flip)] and str(K) in _H2_K:
+        wino = 3
     return Cog, Cig, K, wino
 
 
@@ -248,7 +319,7 @@ def pack_many(requests):
             reqs.append((key, w, G, Cog, Cig, K, bool(flip), wino))
     if not reqs:
         return
-    sizes = [G * Cog * Cig * (_WINO_PLANES[(wino, K)] if wino else K) for _, _, G, Cog, Cig, K, _, wino in reqs]
+    sizes = [(_packed_floats(wino, K, G, Cog, Cig, flip) + 3) // 4 * 4 for _, _, G, Cog, Cig, K, flip, wino in reqs]      # 16-byte aligned operands
     arena = torch.empty(sum(sizes), device=reqs[0][1].device, dtype=torch.float32)
     descs = (_lib.PackDesc * len(reqs))()
     off = 0
@@ -257,12 +328,13 @@ def pack_many(requests):
         off += n
         if wino:
             wp.nef_wino = wino
+            wp.nef_site = (w.data_ptr(), flip)
         d.w, d.wp, d.G, d.Cog, d.Cig, d.K, d.transpose_flip, d.wino = w.data_ptr(), wp.data_ptr(), G, Cog, Cig, K, int(flip), int(wino)
         _PREPACKED[key] = (wp, w)          # keep the source alive while its pointer is the key
     _lib.check(L.nef_pack_weights(descs, len(reqs), _stream()), "nef_pack_weights")
 
 
-def pack_weight(w, G, flip=False, T=None, f4=False):
+def pack_weight(w, G, flip=False, T=None, f4=False, site=None):
     """w [G*Cog, Cig, K] -> packed operand (forward: [G][K][Cig][Cog]; flip: [G][K][Cog][Cig], taps reversed).
     `T`: output length of the conv launch this operand is for; when the Winograd F(2,3) path applies to that launch
     the operand is packed for it (marked with `.nef_wino`) and `conv()` takes that path; `f4` allows the F(4,3) form."""
@@ -272,6 +344,13 @@ def pack_weight(w, G, flip=False, T=None, f4=False):
     hit = _PREPACKED.pop((w.data_ptr(), G, bool(flip), wino), None)
     if hit is not None and hit[1] is w:
         return hit[0]
+    # `site`: identity of the call site for the split-fp16 input-magnitude slots when `w` is a temporary (default: w's address)
+    if wino == 3:
+        wp = torch.empty(_packed_floats(3, K, G, Cog, Cig, flip), device=w.device, dtype=torch.float32)
+        _lib.check(L.nef_pack_weight_h2(_p(w), _p(wp), G, Cog, Cig, K, int(flip), _stream()), "nef_pack_weight_h2")
+        wp.nef_wino = 3
+        wp.nef_site = (w.data_ptr() if site is None else site, bool(flip))
+        return wp
     if wino:
         wp = torch.empty(G * _WINO_PLANES[(wino, K)] * Cog * Cig, device=w.device, dtype=torch.float32)
         fn = L.nef_pack_weight_wino if wino == 1 else L.nef_pack_weight_wino4
@@ -286,9 +365,11 @@ def pack_weight(w, G, flip=False, T=None, f4=False):
 def conv_stats_buffer(wp, B, G, Cog, T_out, device):
     """(slots tensor, slots per sample) for conv(..., stats=...) -- or None when the conv would not run on the F(4,3)
     kernel, whose epilogue is the one that leaves the BatchNorm slot sums."""
-    if int(getattr(wp, "nef_wino", 0)) != 2:
+    wino = int(getattr(wp, "nef_wino", 0))
+    if wino not in (2, 3):
         return None
-    nslot = _lib.load().nef_conv_stats_slots(T_out, Cog)
+    # a slot = one wave's 128 columns; the split-fp16 kernel tiles a sample in 256-column workgroups (2 slots each)
+    nslot = 2 * ((T_out + 255) // 256) if wino == 3 else _lib.load().nef_conv_stats_slots(T_out, Cog)
     if nslot <= 0:
         return None
     return torch.empty(G * Cog, B * nslot, 2, device=device, dtype=torch.float32), nslot
@@ -309,7 +390,8 @@ def bn_stats_from_slots(stats, gamma, beta, running_mean, running_var, P, N, Ln,
 
 
 def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None, gate_scale=1.0, relu=False,
-         mask=None, drop_p=0.0, drop_scale=1.0, seed=0, role="conv_fwd", pro=None, seed_dev=None, stats=None, bnb=None):
+         mask=None, drop_p=0.0, drop_scale=1.0, seed=0, role="conv_fwd", pro=None, seed_dev=None, stats=None, bnb=None,
+         x_scale=0.0):
     """out = epilogue(conv1d(prologue(x) * in_scale, w) + bias + res).  `xv`, `res`, `gate`, `out` are GV views;
     `in_scale` is (tensor, batch_stride, group_stride).  `pro` = (mode, a, b, Bp): input prologue applied while
     staging -- bit0 BatchNorm affine + ReLU with a/b [P, C_in], bit1 x2 linear upsampling of a half-resolution input
@@ -343,11 +425,29 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     a.gate_scale, a.drop_scale, a.drop_p, a.rng_seed = gate_scale, drop_scale, drop_p, seed
     a.rng_seed_dev = _p(seed_dev)
     a.wino = int(getattr(wp, "nef_wino", 0))
+    a.x_scale = float(x_scale)
     a.stats = _p(stats[0]) if stats is not None else None
     if bnb is not None:      # (x, mean, invstd, a, b, Bp, slots buffer): BatchNorm-backward sums of the layer below
         a.bnb_x, a.bnb_mean, a.bnb_invstd, a.bnb_a, a.bnb_b = (_p(t) for t in bnb[:5])
         a.bnb_Bp, a.bnb_slots = bnb[5], _p(bnb[6][0])
         a.bnb_up = int(bnb[7]) if len(bnb) > 7 else 0
+    if a.wino == 3 and not x_scale:
+        st = _amax_state(xv.t.device)
+        ws = getattr(wp, "nef_site", None)
+        site = (AMAX_SCOPE, ws, role, xv.B, T_out) if (AMAX_SCOPE is not None and ws is not None) else None
+        i = st["index"].get(site)
+        if i is None:
+            if len(st["index"]) >= AMAX_SITES:       # models come and go (tests): start over
+                st["index"].clear(), st["ready"].clear(), st["cur"].zero_(), st["nxt"].zero_()
+            i = st["index"][site] = len(st["index"])
+        a.x_amax_next = st["nxt"].data_ptr() + 4 * i
+        if i not in st["ready"] or site is None:      # first launch of the site (or no scope): measure, then run
+            st["nxt"][i] = 0.0
+            _lib.check(L.nef_conv_fwd(C.byref(a), _stream()), "nef_conv_fwd")
+            st["cur"][i] = st["nxt"][i]
+            st["ready"].add(i)
+        a.x_amax = st["cur"].data_ptr() + 4 * i
+        st["used"] = True
     ev = _timed((role, K, xv.G, xv.Cg, Cog, xv.B, T_out))
     if ev is not None:
         EXEC_FRAC[(role, K, xv.G, xv.Cg, Cog, xv.B, T_out)] = _exec_frac(K, a.wino)

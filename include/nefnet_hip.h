@@ -34,7 +34,7 @@ extern "C" {
 typedef void* nef_stream_t;
 
 /* ABI version of this header; bumped on any signature change. */
-int nef_abi_version(void);   /* 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
+int nef_abi_version(void);   /* 13 (round 4: + nef_pack_weight_h2 / conv args wino = 3 and x_scale: direct convolutions on exact fp16 splits of the fp32 operands); 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
 
 /* ---------------------------------------------------------------------------------------------
  * Stem: Conv1d(1->128 per lead, k15, s2, p7, no bias) + ReLU + MaxPool1d(3,2,1), fused.
@@ -75,8 +75,18 @@ int nef_pack_weight_wino(const float* w, float* wp, int G, int Cog, int Cig, int
 int nef_pack_weight_wino4(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                           nef_stream_t stream);
 
+/* The split-fp16 operand (conv args wino = 3): each weight, scaled by a power of two per output row of the launch (row
+ * maximum -> [2^14, 2^15)), is split exactly into two fp16 terms w = wh + wl (+ < 2^-22 |w|) and stored as matrix-core
+ * fragments wp[g][ci/16][k][co/32][wh | wl][lane][8] (fp16), followed by the per-row descale factors [g][co] (fp32).
+ * nef_conv_fwd then runs the DIRECT convolution as three v_mfma_f32_32x32x16_f16 per 16 channels and tap -- xh*wh + xh*wl +
+ * xl*wh, exact fp16 products, fp32 accumulation (csrc/conv_h2.hip): fp32-class results (1.1e-7 rel-L2 on a 128-channel K = 7
+ * layer against fp64; an fp32 direct conv: 1.3e-7) at 3/16 of the fp32 matrix instructions' pipe time.  K == 3 or 7, Cig % 16 == 0,
+ * Cog % 32 == 0 (both as the LAUNCH sees them: exchanged under transpose_flip).  wp: nef_pack_weight_h2_bytes(...) bytes. */
+int nef_pack_weight_h2(const float* w, void* wp, int G, int Cog, int Cig, int K, int transpose_flip, nef_stream_t stream);
+size_t nef_pack_weight_h2_bytes(int G, int Cog, int Cig, int K, int transpose_flip);
+
 /* Any number of operands in one launch (a whole forward or backward pass packs ~25): each descriptor is one
- * nef_pack_weight (wino = 0), nef_pack_weight_wino (wino = 1) or nef_pack_weight_wino4 (wino = 2) call.  `descs` is a HOST array. */
+ * nef_pack_weight (wino = 0), nef_pack_weight_wino (wino = 1), nef_pack_weight_wino4 (wino = 2) or nef_pack_weight_h2 (wino = 3) call.  `descs` is a HOST array. */
 typedef struct nef_pack_desc {
     const float* w;
     float* wp;
@@ -117,7 +127,10 @@ typedef struct nef_conv_args {
                               F(2,4) + F(2,3) (2/3 resp. 9/14 of the multiplies; still fp32 multiplies and adds on the matrix cores, results differ
                               from the direct form by the rounding of the transforms).  2: packed by
                               nef_pack_weight_wino4 -- Winograd F(4,3) resp. F(4,4) + F(4,3): 1/2 resp. 13/28 of the multiplies.  Needs T even, T >= 128
-                              (Cout_g % 128 == 0) or T >= 256 (Cout_g % 64 == 0), Cin_g % 16 == 0; K == 7: pro_mode 0. */
+                              (Cout_g % 128 == 0) or T >= 256 (Cout_g % 64 == 0), Cin_g % 16 == 0; K == 7: pro_mode 0.
+                              3: packed by nef_pack_weight_h2 -- the direct convolution on exact fp16 splits of both operands
+                              (K == 3 or 7, Cout_g % 64 == 0, Cin_g % 16 == 0, T even and >= 128; every epilogue option
+                              incl. stats / bnb_slots; K == 7: pro_mode 0). */
     float* stats;          /* NULL, or (wino == 2 only) the epilogue also leaves, per output channel and per 128-column slot
                               of a sample, the sum and the sum of squares of the final outputs of that slot:
                               stats[(ch * B * nslot + b * nslot + slot) * 2 + {0,1}], ch = g*Cout_g + co, nslot =
@@ -138,6 +151,16 @@ typedef struct nef_conv_args {
     int32_t bnb_up;        /* 1: a x2 linear upsampling (nn.Upsample, align_corners=False) sits between that BatchNorm's ReLU
                               and this launch's output: bnb_x is [B][G*Cout_g][T/2] and the sums are those of the
                               upsampling's adjoint (what nef_bn_relu_bwd_up reduces); T % 4 == 0 */
+    float x_scale;         /* wino == 3 only: 0 (= 1) or an exact power of two the input is multiplied by before it is split into
+                              fp16 terms and the accumulators are divided by again -- brings operands far from magnitude 1
+                              (gradients) into fp16's range; the result is unchanged up to the split's rounding */
+    int32_t reserved0;
+    const float* x_amax;   /* wino == 3: NULL, or a device word holding the largest |input| (after in_scale / prologue) this call
+                              site saw at its previous launch: when it is a positive finite number the input scale is derived
+                              from it (-> [2^8, 2^9)) instead of x_scale -- the operand is then in fp16's range whatever its
+                              magnitude, and the launch stays capturable (nothing is read back by the host) */
+    float* x_amax_next;    /* wino == 3: NULL, or a device word (zeroed by the caller) this launch max-accumulates the largest
+                              |input| of ITS operand into -- next launch's x_amax */
 } nef_conv_args;
 
 /* y = epilogue(conv(x * in_scale, wp) + bias + res).  Also the bwd-data pass (pack with transpose_flip=1,
