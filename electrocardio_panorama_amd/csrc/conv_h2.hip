@@ -122,8 +122,11 @@ __global__ __launch_bounds__(256) void pack_h2_kernel(H2PackTable tab) {
 // PRO as in conv_fwd_kernel (bit0: BatchNorm affine + ReLU of the producing layer, bit1: x2 linear upsampling of a
 // half-resolution input), applied to the fp32 values before the split.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef NEF_H2_OCC1
+#define NEF_H2_OCC1 3      // workgroups per CU the 64-channel tile is compiled for (168 VGPRs); the x2-upsampling prologue needs 2
+#endif
 template <int K, int PRO, int TM>
-__global__ __launch_bounds__(256, 2) void conv_h2_kernel(nef_conv_args a, int tps, int n_tiles, int m_tiles) {
+__global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2) void conv_h2_kernel(nef_conv_args a, int tps, int n_tiles, int m_tiles) {
     constexpr int MT = 64 * TM;                    // output channels per workgroup: 2 (co) x 2 (t) waves of TM x 4 tiles
     constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
     constexpr int NS = UP ? 2 : 1;
@@ -325,17 +328,24 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(nef_conv_args a, int tp
             else NEF_H2A_ISSUE(more ? st + 1 : st, 0, (kk + 1) & 1)
             if (kk + 4 < NSF) NEF_H2B_LOAD(kk + 4)
             __builtin_amdgcn_s_setprio(1);      // scheduling fence (see conv_wino_kernel)
+            // product-major order: the three MFMAs that accumulate into one tile are 4 TM instructions apart (never back to
+            // back on the same accumulator)
+            const int s_ = kk & 1;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const h16x8 bh = fb[(kk + j) % 5][0], bl = fb[(kk + j) % 5][1];
-                const int s_ = kk & 1;
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s_][2 * i], bh, acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s_][2 * i], fb[(kk + j) % 5][0], acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s_][2 * i], bl, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s_][2 * i + 1], bh, acc[i][j], 0, 0, 0);
-            }
+                for (int i = 0; i < TM; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s_][2 * i], fb[(kk + j) % 5][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s_][2 * i + 1], fb[(kk + j) % 5][0], acc[i][j], 0, 0, 0);
         }
 #undef NEF_H2B_LOAD
         // K odd: the set toggles K times per stage, so stage st + 1 finds its tap 0 in set (K & 1) ^ ... -- keep it simple:
@@ -379,8 +389,15 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(nef_conv_args a, int tp
             float y[8][4];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
+#if defined(NEF_H2_DBG) && NEF_H2_DBG == 1
+                const float ds = reinterpret_cast<const float*>(wph + (int64_t)a.G * K * Cog * Cig * 2)[g * Cog + cobase + NEF_ROW(q)] / xs_;
+                const float bv = a.bias ? a.bias[g * Cog + cobase + NEF_ROW(q)] : 0.f;
+#elif defined(NEF_H2_DBG) && NEF_H2_DBG == 2
+                const float ds = 1.f, bv = 1000.f;
+#else
                 const float ds = El[5 * MT + erow0 + NEF_ROW(q)];
                 const float bv = El[erow0 + NEF_ROW(q)];
+#endif
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[q][e] = fmaf(acc[i][e][q + 8 * h], ds, bv);
             }
@@ -583,12 +600,16 @@ __attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, 
     if (!nef_h2_ok(a)) return NEF_E_SHAPE;
     if ((a->pro_mode & 1) && !(a->pro_a && a->pro_b && a->pro_Bp > 0)) return NEF_E_NULL;
     const bool wide = a->Cout_g % 128 == 0;
+    // the x2-upsampling prologue keeps two source samples per staged position in registers: next to the 128 accumulator
+    // registers of the 128-channel tile that spills (250..330 bytes per lane), so those launches take the 64-channel tile
+    static const bool up_wide = getenv("NEF_H2_UP_TM") && atoi(getenv("NEF_H2_UP_TM")) == 2;
+    const bool wide_up = wide && up_wide;
     if (a->K == 7) return wide ? launch_h2<7, 0, 2>(*a, st) : launch_h2<7, 0, 1>(*a, st);
     switch (a->pro_mode) {
         case 0: return wide ? launch_h2<3, 0, 2>(*a, st) : launch_h2<3, 0, 1>(*a, st);
         case 1: return wide ? launch_h2<3, 1, 2>(*a, st) : launch_h2<3, 1, 1>(*a, st);
-        case 2: return wide ? launch_h2<3, 2, 2>(*a, st) : launch_h2<3, 2, 1>(*a, st);
-        default: return wide ? launch_h2<3, 3, 2>(*a, st) : launch_h2<3, 3, 1>(*a, st);
+        case 2: return wide_up ? launch_h2<3, 2, 2>(*a, st) : launch_h2<3, 2, 1>(*a, st);
+        default: return wide_up ? launch_h2<3, 3, 2>(*a, st) : launch_h2<3, 3, 1>(*a, st);
     }
 }
 

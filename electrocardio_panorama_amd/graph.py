@@ -82,7 +82,9 @@ class GraphedTrainStep:
             p = named[k]
             m = p.numel()
             self.flat_p[off:off + m].copy_(p.data.reshape(-1))
+            old_ptr = p.data.data_ptr()
             p.data = self.flat_p[off:off + m].view_as(p.data)       # parameters become views of the flat buffer
+            ops.amax_move(old_ptr, p.data.data_ptr())
             off += m
 
     def _fwd_bwd(self):

@@ -222,14 +222,20 @@ _WINO_PLANES = {(1, 3): 4, (1, 7): 10, (2, 3): 6, (2, 7): 13}
 # three fp16 matrix instructions per 16 channels and tap, fp32 accumulation -- fp32-class results at 3/16 of the fp32 matrix
 # instructions' pipe time.  NEF_H2=0 keeps the fp32 Winograd forms; NEF_H2=1 takes it wherever the shape allows
 # (128-channel output tiles, 16-channel input chunks, T even and >= 128; K = 7 without an input prologue).
-H2 = os.environ.get("NEF_H2", "0") == "1"
+H2 = os.environ.get("NEF_H2", "1") == "1"
 _H2_DIR = {False: os.environ.get("NEF_H2_FWD", "1") == "1", True: os.environ.get("NEF_H2_BWD", "1") == "1"}     # diagnostics
 _H2_K = os.environ.get("NEF_H2_K", "3,7").split(",")
+_H2_64 = os.environ.get("NEF_H2_64", "1") == "1"
+_H2_AMAX = os.environ.get("NEF_H2_AMAX", "sticky")      # diagnostics: "anon" = every launch measures first, "follow" = no stickiness
 
 
 def h2_ok(K, Cin_g, Cout_g, T_out, pro=0):
+    # 64-channel output tiles (conv_h2_kernel<., ., 1>) are not faster than the F(4,3) kernels on the two 64-channel decoder
+    # layers (HBM-bound at 2 x 983 MB), but they keep every conv of a pass on ONE arithmetic -- direct, exact zeros preserved,
+    # fp32-class rounding -- which is what the ReLU decisions of the reference's fp32 trajectory follow; NEF_H2_64=0 leaves them
+    # to F(4,3)
     return (H2 and (K == 3 or (K == 7 and not pro)) and T_out % 2 == 0 and T_out >= 128 and Cin_g % 16 == 0 and
-            Cout_g % 64 == 0)
+            Cout_g % (64 if _H2_64 else 128) == 0)
 
 
 # Input magnitudes of the split-fp16 launches, per call site (= per weight tensor and direction): `cur` is what a launch derives
@@ -237,7 +243,7 @@ def h2_ok(K, Cin_g, Cout_g, T_out, pro=0):
 # forward pass -- moves nxt into cur.  A site's FIRST launch runs twice: once to measure, once with the measured scale.  Nothing is
 # read back by the host, so the launches stay capturable; a site whose operand grows more than 16x from one step to the next
 # gets its largest elements clamped at 65000 / scale for that one step (conv_h2.hip).
-AMAX_SITES = 1024
+AMAX_SITES = 16384
 _AMAX = {}
 # A call site = (scope, weight address, direction, role, batch, length).  The scope is the owning model's token
 # (Model_nefnet sets it around every engine call; a fresh model or a loaded checkpoint gets a fresh token, so nothing is inherited
@@ -264,17 +270,33 @@ def _amax_state(dev):
     st = _AMAX.get(dev)
     if st is None:
         st = _AMAX[dev] = dict(cur=torch.zeros(AMAX_SITES, device=dev, dtype=torch.float32),
-                               nxt=torch.zeros(AMAX_SITES, device=dev, dtype=torch.float32), index={}, ready=set(), used=False)
+                               nxt=torch.zeros(AMAX_SITES, device=dev, dtype=torch.float32), index={}, ready=set(), used=False, occ={})
     return st
 
 
 def amax_roll():
-    """cur <- nxt wherever a launch left a magnitude, nxt <- 0 (stream-ordered; three tiny launches)."""
+    """Once per pass (stream-ordered, a handful of tiny launches): a site's reference magnitude `cur` follows what its last launch
+    measured (`nxt`) only when that left the window [cur / 64, 64 cur] -- the scale is STICKY, so passes over data of similar
+    magnitude (a repeated step, train after eval, eager and captured steps of one run) split their operands identically and
+    stay bit-reproducible; inside the window nothing is clamped (the scale puts `cur` at 2^8..2^9, fp16 ends at 2^16) and elements within
+    2^-9 / 64 of the largest keep full precision."""
     for st in _AMAX.values():
+        st["occ"].clear()
         if st["used"]:
-            torch.where(st["nxt"] > 0, st["nxt"], st["cur"], out=st["cur"])
-            st["nxt"].zero_()
+            cur, nxt = st["cur"], st["nxt"]
+            upd = (nxt > 0) & ((cur <= 0) | (nxt > 64.0 * cur) | (nxt * 64.0 < cur))
+            if _H2_AMAX == "follow":
+                upd = nxt > 0
+            torch.where(upd, nxt, cur, out=cur)
+            nxt.zero_()
             st["used"] = False
+
+
+def amax_move(old_ptr, new_ptr):
+    """A weight tensor moved (an optimiser re-pointed its parameters into a flat buffer): its call sites keep their history."""
+    for st in _AMAX.values():
+        for site in [k for k in st["index"] if k is not None and k[1][0] == old_ptr]:
+            st["index"][(site[0], (new_ptr, site[1][1])) + site[2:]] = st["index"].pop(site)
 
 
 def _packed_floats(wino, K, G, Cog, Cig, flip):
@@ -434,14 +456,24 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     if a.wino == 3 and not x_scale:
         st = _amax_state(xv.t.device)
         ws = getattr(wp, "nef_site", None)
-        site = (AMAX_SCOPE, ws, role, xv.B, T_out) if (AMAX_SCOPE is not None and ws is not None) else None
+        site = None
+        if AMAX_SCOPE is not None and ws is not None and _H2_AMAX != "anon":
+            # + the occurrence within the pass: the k-th launch through one weight keeps its own history, so a step repeated on
+            # the same data finds the scales it left (bit-identical results)
+            occ = st["occ"]
+            k = occ[(AMAX_SCOPE, ws, role, xv.B, T_out)] = occ.get((AMAX_SCOPE, ws, role, xv.B, T_out), 0) + 1
+            site = (AMAX_SCOPE, ws, role, xv.B, T_out, k)
         i = st["index"].get(site)
         if i is None:
             if len(st["index"]) >= AMAX_SITES:       # models come and go (tests): start over
                 st["index"].clear(), st["ready"].clear(), st["cur"].zero_(), st["nxt"].zero_()
+                assert not torch.cuda.is_current_stream_capturing()
             i = st["index"][site] = len(st["index"])
         a.x_amax_next = st["nxt"].data_ptr() + 4 * i
         if i not in st["ready"] or site is None:      # first launch of the site (or no scope): measure, then run
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("split-fp16 conv: a call site's first launch (it measures its operand) cannot be captured; "
+                                   "run the step once eagerly first (GraphedTrainStep does)")
             st["nxt"][i] = 0.0
             _lib.check(L.nef_conv_fwd(C.byref(a), _stream()), "nef_conv_fwd")
             st["cur"][i] = st["nxt"][i]

@@ -27,7 +27,9 @@ class FusedSGD(torch.optim.Optimizer):
         for p in live:
             k = p.numel()
             flat_p[off:off + k].copy_(p.data.reshape(-1))
+            old_ptr = p.data.data_ptr()
             p.data = flat_p[off:off + k].view_as(p.data)          # parameters become views of the flat buffer
+            ops.amax_move(old_ptr, p.data.data_ptr())
             st = self.state[p]
             if "momentum_buffer" in st and st["momentum_buffer"] is not None:
                 flat_b[off:off + k].copy_(st["momentum_buffer"].reshape(-1))
