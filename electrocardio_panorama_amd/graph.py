@@ -128,7 +128,9 @@ class GraphedTrainStep:
             self.status = torch.zeros(1, device=dev, dtype=torch.int32)
             self.losses = torch.zeros(4, device=dev, dtype=torch.float32)
             self._host = torch.zeros(4, dtype=torch.int64).pin_memory()
-        self._stage(data, in_theta, q_theta, rois, target, draw=False)      # probe: no `random` consumed
+        # the probe runs THIS step's inputs, Standin choices and dropout seed (drawn by __call__ before it builds): the split-fp16
+        # convs measure their operands in it, and what they measure must be what the eager path measures on the same step
+        self._stage(data, in_theta, q_theta, rois, target, draw=False)
         self.model.train()
         # eager probe (no update): which parameters are live, and every kernel variant gets its one-time setup
         saved = {k: v.clone() for k, v in self.model.named_buffers()}
@@ -160,22 +162,26 @@ class GraphedTrainStep:
         slot["workspaces"] = list(ops._WS.values())
         return slot
 
+    def _draw(self):
+        """This step's host decisions: Python `random` consumed exactly twice, z1 choice first (model_nefnet.py:154,156)."""
+        V = self.model.lead_num
+        self.calls += 1
+        self._draws = (random.randint(0, V - 1), random.randint(0, V - 1))
+
     def _stage(self, data, in_theta, q_theta, rois, target, draw=True):
         self.data.copy_(data, non_blocking=True)
         self.in_theta.copy_(in_theta, non_blocking=True)
         self.q_theta.copy_(q_theta, non_blocking=True)
         self.rois.copy_(rois, non_blocking=True)
         self.target.copy_(target.reshape(self.target.shape), non_blocking=True)
-        V = self.model.lead_num
         if draw:
-            self.calls += 1
-            # Python `random` consumed exactly twice per step, z1 choice first (model_nefnet.py:154,156)
-            self._host[0], self._host[1] = random.randint(0, V - 1), random.randint(0, V - 1)
+            self._draw()
         rank = dist.get_rank() if self.world > 1 else 0
         # same ingredients as the eager path (model_nefnet.py: initial seed + call counter + epoch + rank): a resumed run
         # (Solver sets model.dropout_epoch; `calls` travels in state_dict) does not replay the masks of step 1
         self._host[2] = (torch.initial_seed() + self.calls + int(getattr(self.model, "dropout_epoch", 0)) * 0x1000003
                          + rank * 0x9E3779B1) & 0x7FFFFFFFFFFF
+        self._host[0], self._host[1] = getattr(self, "_draws", (0, 0))
         self.choice_dev.copy_(self._host[:2].to(torch.int32), non_blocking=False)
         self.seed_dev.copy_(self._host[2:3], non_blocking=False)
 
@@ -220,13 +226,17 @@ class GraphedTrainStep:
             fl = self.optimizer._flat.get(0)
             if self.flat_p is not None and (fl is None or fl["p"] is not self.flat_p):   # e.g. optimizer.load_state_dict
                 self.slots.clear()
+        if getattr(self, "_scope", None) != self.model._nef_scope:       # the model loaded other weights: its split-fp16 call sites
+            self._scope = self.model._nef_scope                            # start over (ops.amax_scope), and the captures hold the old slots
+            self.slots.clear()
+        self._draw()
         shape = (tuple(data.shape), tuple(in_theta.shape))
         slot = self.slots.get(shape)
         if slot is None:
             slot = self.slots[shape] = self._build(data, in_theta, q_theta, rois, target)
             self._restore_momentum()
         self._use(slot)
-        self._stage(data, in_theta, q_theta, rois, target)
+        self._stage(data, in_theta, q_theta, rois, target, draw=False)
         slot["graph"].replay()
         if self.world > 1:
             dist.all_reduce(self.flat_g)

@@ -230,10 +230,7 @@ _H2_AMAX = os.environ.get("NEF_H2_AMAX", "sticky")      # diagnostics: "anon" = 
 
 
 def h2_ok(K, Cin_g, Cout_g, T_out, pro=0):
-    # 64-channel output tiles (conv_h2_kernel<., ., 1>) are not faster than the F(4,3) kernels on the two 64-channel decoder
-    # layers (HBM-bound at 2 x 983 MB), but they keep every conv of a pass on ONE arithmetic -- direct, exact zeros preserved,
-    # fp32-class rounding -- which is what the ReLU decisions of the reference's fp32 trajectory follow; NEF_H2_64=0 leaves them
-    # to F(4,3)
+    # NEF_H2_64=0 leaves the 64-channel output tiles (conv_h2_kernel<., ., 1>) to the F(4,3) kernels
     return (H2 and (K == 3 or (K == 7 and not pro)) and T_out % 2 == 0 and T_out >= 128 and Cin_g % 16 == 0 and
             Cout_g % (64 if _H2_64 else 128) == 0)
 

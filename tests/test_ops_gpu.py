@@ -21,6 +21,28 @@ def g(t):
     return t.to(DEV).contiguous()
 
 
+@pytest.fixture(autouse=True, params=["h2", "wino"])
+def conv_algo(request):
+    """Every test of this file runs twice: with the split-fp16 direct convs (the default, ops.H2) wherever their shape rules
+    apply, and with them off -- the fp32 Winograd / direct kernels that remain the path for every other shape and for NEF_H2=0."""
+    o = ops()
+    saved = o.H2
+    o.H2 = request.param == "h2"
+    yield request.param
+    o.H2 = saved
+
+
+def fwd_form(o, K, Cig, Cog, T, f4):
+    """The conv args `wino` value pack_weight picks for a forward / backward-data launch of this shape."""
+    if o.h2_ok(K, Cig, Cog, T):
+        return 3
+    return (o.WINO_FWD if f4 else 1) if o.wino_ok(K, Cig, Cog, T) else 0
+
+
+def packed_floats(o, form, K, G, Cog, Cig, flip=False):
+    return o._packed_floats(form, K, G, Cog, Cig, flip)
+
+
 @pytest.mark.parametrize("B,V,L", [(2, 3, 512), (2, 1, 1000), (3, 2, 520), (1, 8, 256)])
 def test_stem(B, V, L):
     o = ops()
@@ -528,7 +550,7 @@ def test_shared_first_conv_pieces():
 @pytest.mark.parametrize("B,Cin,Cout,T,pro", [(6, 128, 128, 300, 1), (6, 128, 64, 600, 0), (3, 64, 64, 514, 1),
                                               (6, 256, 128, 128, 2)])
 def test_conv_epilogue_bn_slot_sums(B, Cin, Cout, T, pro):
-    """The F(4,3) conv epilogue's slot sums (nef_conv_args.stats) + nef_bn_stats_from_slots against nef_bn_train_stats on
+    """The conv epilogue's slot sums (nef_conv_args.stats; the split-fp16 kernel and the F(4,3) kernel) + nef_bn_stats_from_slots against nef_bn_train_stats on
     the conv output: same mean / invstd / affine / running statistics (three passes), ragged last tile included."""
     o = ops()
     from electrocardio_panorama_amd.ops import GV
@@ -553,8 +575,10 @@ def test_conv_epilogue_bn_slot_sums(B, Cin, Cout, T, pro):
     for a_, b_ in zip(got, want):
         assert rel(a_, b_) < 1e-6
     assert rel(rm2, rm1) < 1e-6 and rel(rv2, rv1) < 1e-6
-    # the other conv kernels do not leave slot sums: the boundary says so instead of ignoring the request
+    # the other conv kernels (direct fp32, F(2,3)) do not leave slot sums: the boundary says so instead of ignoring the request
+    saved, o.H2 = o.H2, False
     assert o.conv_stats_buffer(o.pack_weight(w, 1, T=T), B, 1, Cout, T, x.device) is None
+    o.H2 = saved
 
 
 @pytest.mark.parametrize("B,Cin,Cout,T", [(6, 128, 128, 300), (6, 64, 64, 514), (3, 128, 64, 256)])
@@ -768,8 +792,8 @@ def test_conv_winograd(K, G, Cig, Cog, T, B, f4):
     ref64 = F.conv1d(x.double(), w.double(), None, 1, K // 2, 1, G)
     xd, wd = g(x), g(w)
     wpw = o.pack_weight(wd, G, T=T, f4=f4)
-    form = o.WINO_FWD if f4 else 1
-    assert wpw.nef_wino == form and wpw.numel() == o._WINO_PLANES[(form, K)] * G * Cog * Cig
+    form = fwd_form(o, K, Cig, Cog, T, f4)
+    assert form in (1, 2, 3) and wpw.nef_wino == form and wpw.numel() == packed_floats(o, form, K, G, Cog, Cig)
     y = o.conv(GV.dense(xd, G), wpw, Cog, K)
     yd = o.conv(GV.dense(xd, G), o.pack_weight(wd, G), Cog, K)
     assert rel(y, ref) < FWD_TOL, "forward"
@@ -779,7 +803,7 @@ def test_conv_winograd(K, G, Cig, Cog, T, B, f4):
     ref.backward(gy)
     if o.wino_ok(K, Cog, Cig, T):
         wf = o.pack_weight(wd, G, flip=True, T=T, f4=f4)
-        assert wf.nef_wino == form
+        assert wf.nef_wino == fwd_form(o, K, Cog, Cig, T, f4)
         gx = o.conv(GV.dense(g(gy), G), wf, Cig, K)
         assert rel(gx, xr.grad) < GRAD_TOL, "bwd-data"
 
@@ -1028,3 +1052,106 @@ def test_conv_bwd_weight_dma_upsampling_stays_inside_the_operand():
     torch.cuda.synchronize()
     want = o.conv_bwd_weight(GV.dense(x, 1), GV.dense(gy, 1), 3, pro=pro, wino=False)
     assert rel(gw, want) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ split-fp16 direct convs
+def test_conv_h2_is_fp32_class(conv_algo):
+    """csrc/conv_h2.hip against fp64: forward and backward-data of a 128-channel K = 7 and K = 3 layer land within 3x of
+    torch's own fp32 conv (measured ~1.7x; the Winograd F(4,.) forms: 4..5x) -- and the operand scale makes that hold for
+    operands of ANY magnitude: a 1e-7-sized gradient operand (explicit power-of-two x_scale, and the measured scale of a
+    scope-less launch) is as accurate as an O(1) one."""
+    if conv_algo != "h2":
+        pytest.skip("split-fp16 path")
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    for K, G, Cig, Cog, B, T in [(7, 3, 128, 128, 3, 1250), (3, 1, 256, 128, 2, 500), (3, 1, 64, 64, 3, 514)]:
+        x = F.relu(rnd(B, G * Cig, T, seed=301))
+        w = rnd(G * Cog, Cig, K, seed=302, scale=0.05)
+        ref64 = F.conv1d(x.double(), w.double(), None, 1, K // 2, 1, G)
+        e32 = rel(F.conv1d(x, w, None, 1, K // 2, 1, G), ref64)
+        wp = o.pack_weight(g(w), G, T=T, f4=True)
+        assert wp.nef_wino == 3 and wp.numel() == packed_floats(o, 3, K, G, Cog, Cig)
+        y = o.conv(GV.dense(g(x), G), wp, Cog, K)
+        assert rel(y.double().cpu(), ref64) < 3 * e32 + 1e-8, (K, rel(y.double().cpu(), ref64), e32)
+        # backward-data, operand 7 orders of magnitude below 1
+        gy = rnd(B, G * Cog, T, seed=303) * 1e-7
+        gref64 = torch.nn.grad.conv1d_input(x.shape, w.double(), gy.double(), padding=K // 2, groups=G)
+        g32 = rel(torch.nn.grad.conv1d_input(x.shape, w, gy, padding=K // 2, groups=G), gref64)
+        wf = o.pack_weight(g(w), G, flip=True, T=T, f4=True)
+        assert wf.nef_wino == 3
+        gx_meas = o.conv(GV.dense(g(gy), G), wf, Cig, K)                      # no scope: the launch measures its operand first
+        gx_expl = o.conv(GV.dense(g(gy), G), wf, Cig, K, x_scale=2.0 ** 30)    # the caller's power of two
+        for gx in (gx_meas, gx_expl):
+            assert rel(gx.double().cpu(), gref64) < 3 * g32 + 1e-8, (K, rel(gx.double().cpu(), gref64), g32)
+        # without a scale the low terms of such an operand fall below fp16's range: the reason the scale exists
+        gx_raw = o.conv(GV.dense(g(gy), G), wf, Cig, K, x_scale=1.0)
+        assert rel(gx_raw.double().cpu(), gref64) > 1e-4
+
+
+def test_conv_h2_sites_are_sticky_and_scoped(conv_algo):
+    """Inside a scope (ops.amax_scope, what Model_nefnet sets) a call site measures once, then keeps its power-of-two operand
+    scale while the operand stays within 64x of what it measured (bit-identical repeats, also after a 10x change of magnitude
+    and back), follows a larger change at the next amax_roll(), and a new scope starts from scratch."""
+    if conv_algo != "h2":
+        pytest.skip("split-fp16 path")
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    K, G, C, B, T = 3, 1, 128, 2, 384
+    x, w = g(rnd(B, C, T, seed=311)), g(rnd(C, C, K, seed=312, scale=0.05))
+    wp = o.pack_weight(w, G, T=T, f4=True)
+    ref = F.conv1d(x.double(), w.double(), None, 1, 1).float()
+
+    def slot():
+        st = o._amax_state(x.device)
+        (i,) = [v for k, v in st["index"].items() if k is not None and k[0] == tok]
+        return float(st["cur"][i])
+    tok = o.new_amax_scope()
+    with o.amax_scope(tok):
+        y1 = o.conv(GV.dense(x, G), wp, C, K)
+        m0 = slot()
+        assert abs(m0 - float(x.abs().max())) < 1e-6 * m0
+        o.amax_roll()
+        y2 = o.conv(GV.dense(x, G), wp, C, K)
+        assert torch.equal(y1, y2) and slot() == m0
+        o.amax_roll()
+        y3 = o.conv(GV.dense(x * 10, G), wp, C, K)            # inside the window: same scale, nothing re-measured
+        assert slot() == m0 and rel(y3, 10 * ref) < 1e-6
+        o.amax_roll()
+        assert slot() == m0
+        y4 = o.conv(GV.dense(x * 100, G), wp, C, K)           # outside: this launch still runs on the old scale (in range: the
+        assert rel(y4, 100 * ref) < 1e-6                      # scale leaves 128x of headroom, clamping starts beyond that) ...
+        o.amax_roll()
+        assert abs(slot() - 100 * m0) < 1e-3 * m0 * 100       # ... and the next pass follows
+        y5 = o.conv(GV.dense(x * 100, G), wp, C, K)
+        assert rel(y5, 100 * ref) < 1e-6
+    tok2 = o.new_amax_scope()
+    with o.amax_scope(tok2):
+        tok = tok2
+        y6 = o.conv(GV.dense(x, G), wp, C, K)
+        assert slot() == m0 and torch.equal(y6, y1)
+
+
+@pytest.mark.parametrize("Cig,Cog,T,mode", [(64, 64, 5000, 0), (128, 64, 5000, 3), (128, 128, 2500, 2)])
+def test_conv_h2_full_size_every_lane_arrives(conv_algo, Cig, Cog, T, mode):
+    """The decoder launches at configs[1]'s size (768 samples) against the fp32 Winograd kernels, element by element, three
+    times: the epilogue of an earlier build lost 16 lanes of one accumulator row to exact 0.0 a few hundred times per launch
+    on a loaded chip only (packed-fp32 instructions created by SLP vectorisation; conv_h2.hip is built without it)."""
+    if conv_algo != "h2":
+        pytest.skip("split-fp16 path")
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    B = 768
+    Tin = T // 2 if mode & 2 else T
+    x = torch.randn(B, Cig, Tin, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    w, bias = g(rnd(Cog, Cig, 3, seed=321, scale=0.05)), g(rnd(Cog, seed=322, scale=0.1))
+    pa, pb = g(rnd(3, Cig, seed=323).abs() + 0.5), g(rnd(3, Cig, seed=324) * 0.2)
+    pro = (mode, pa, pb, B // 3) if mode & 1 else (mode, None, None, 1)
+    o.H2 = False
+    y0 = o.conv(GV.dense(x, 1), o.pack_weight(w, 1, T=T, f4=True), Cog, 3, bias=bias, pro=pro)
+    o.H2 = True
+    wp = o.pack_weight(w, 1, T=T, f4=True)
+    assert wp.nef_wino == 3
+    for _ in range(3):
+        y1 = o.conv(GV.dense(x, 1), wp, Cog, 3, bias=bias, pro=pro)
+        assert int(((y1 - y0).abs() > 1e-3).sum()) == 0
+        del y1
