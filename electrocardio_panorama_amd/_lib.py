@@ -61,6 +61,9 @@ SIGNATURES = {
     "nef_conv_bwd_weight_pro": (i32, [p, i64, i64, p, p, i32, i32, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32, i32, p]),
     "nef_conv_bwd_weight_wino4": (i32, [p, i64, i64, p, i64, i64, p, p, i32, i32, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32,
                                         i32, p]),
+    "nef_conv_bwd_weight_h2_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "nef_conv_bwd_weight_h2": (i32, [p, i64, i64, p, i64, i64, p, p, i32, i32, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32, i32,
+                               f32, f32, p, p, p, p, p]),
     "nef_chan_sum_ws_bytes": (sz, [i32]),
     "nef_chan_sum": (i32, [p, p, p, sz, i32, i32, i32, p]),
     "nef_convt2_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, i32, p]),

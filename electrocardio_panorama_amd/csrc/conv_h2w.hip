@@ -1,0 +1,361 @@
+// conv_h2w.hip -- the weight gradient of the grouped 1-D convolutions (K = 3, K = 7) on exact fp16 splits of BOTH fp32
+// operands (see conv_h2.hip for the arithmetic: x = xh + xl, gy = gh + gl, three v_mfma_f32_32x32x16_f16 per product --
+// gh*xh + gh*xl + gl*xh -- fp32 accumulation):
+//
+//     gw[g][co][ci][k] = sum_{b, t} gy[b][g][co][t] * X[b][g][ci][t + k - PAD],      X = prologue(x) * in_scale, zero padded
+//
+// The reduction index t is the k dimension of the matrix instruction (16 columns per instruction): a lane of the A fragment
+// holds gy[co][t0 + 8 hi .. + 7], a lane of the B fragment X[ci][t0 + 8 hi + k - PAD .. + 7] -- for every tap the SAME row
+// shifted by one column.  The tiles are staged in their natural [channel][t] order (fp16 hi / lo planes, row pitch an odd
+// multiple of 8 bytes: the 8-byte fragment reads of 32 rows are conflict-free); a lane reads the 16-column window
+// X[ci][t0 + 8 hi - 4 .. + 11] once per 16 columns (four ds_read_b64 per plane) and cuts each tap's fragment out of it in
+// registers: even shifts are register renames, odd shifts four v_alignbit_b32.  K = 7: 12 LDS reads and 32 alignbits feed 21
+// matrix instructions.
+//
+// One workgroup = 64 output x 64 input channels of one group, all K taps: 4 waves as 2 (co) x 2 (ci), a wave owns K
+// accumulator tiles of 32 x 32.  The (sample, 64-column tile) sequence is split S ways; every workgroup streams its share
+// through two LDS buffers (registers carry tile i+1 while tile i is multiplied: one barrier per tile) and leaves a partial
+// sum in ws[split][g][k][co][ci], which conv_bwd_weight_reduce (conv_mfma.hip) adds up in a fixed order.  The workgroups that
+// share a (group, split) -- the co x ci tiles of the layer -- run on ONE XCD, so gy and X come from HBM once per split.
+//
+// Both operands are scaled by exact powers of two derived from the magnitudes their call site measured before (x_amax,
+// gy_amax; ops.py keeps them per site as for the forward launches); the product of the two scales is divided out of the
+// partial sums.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "nefnet_hip.h"
+#include "nef_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int TT = 64;                 // reduction columns per staged tile
+constexpr int GP = TT * 2 + 8;         // gy row pitch in bytes (136 = 8 x 17)
+constexpr int XW = TT + 8;             // staged X columns per row: t0 - 4 .. t0 + TT + 3
+constexpr int XP = XW * 2 + 8;         // X row pitch in bytes (152 = 8 x 19)
+constexpr int GY_PLANE = 64 * GP, X_PLANE = 64 * XP;
+constexpr int BUF = 2 * GY_PLANE + 2 * X_PLANE;      // one stage: gy hi | gy lo | X hi | X lo
+
+struct H2WArgs {
+    const float* x;
+    const float* gy;
+    const float* in_scale;
+    const float* pro_a;
+    const float* pro_b;
+    float* ws;
+    const float* x_amax;
+    const float* gy_amax;
+    float* x_amax_next;
+    float* gy_amax_next;
+    int64_t x_bs, x_gs, gy_bs, gy_gs, sc_bs, sc_gs;
+    int B, T, G, Cig, Cog, pro_Bp, S, tps, n_tiles, m_tiles, c_tiles, teams;
+    float x_scale, gy_scale;
+};
+
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& l) {
+    x0 = __builtin_amdgcn_fmed3f(x0, -65000.f, 65000.f);
+    x1 = __builtin_amdgcn_fmed3f(x1, -65000.f, 65000.f);
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;
+    const h16x2 hh = {h0, h1};
+    const h16x2 ll = {(_Float16)r0, (_Float16)r1};
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
+__device__ __forceinline__ float scale_from(const float* amax, float fallback) {
+    float s = fallback != 0.f ? fallback : 1.f;
+    if (amax) {
+        const float m = amax[0];
+        if (m > 0.f && m < 3e38f) {
+            int e;
+            (void)frexpf(m, &e);
+            s = ldexpf(1.f, 9 - e);       // largest magnitude -> [2^8, 2^9), as conv_h2_kernel
+        }
+    }
+    return s;
+}
+
+template <int K, int PRO>
+__global__ __launch_bounds__(256, 2) void conv_h2w_kernel(H2WArgs a) {
+    constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int NGQ = 64 * (TT / 2) / 256;              // gy column pairs per thread and tile (8)
+    constexpr int NXQ = (64 * (XW / 2) + 255) / 256;      // X column pairs per thread and tile (9)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+
+    // team = (group, split); its members = the co x ci tiles.  Block ids go round-robin over the 8 XCDs: the members of a team
+    // take ids that are congruent mod 8
+    const int members = a.m_tiles * a.c_tiles;
+    const int xcd = blockIdx.x & 7, q_ = blockIdx.x >> 3;
+    const int member = q_ % members;
+    const int team = (q_ / members) * 8 + xcd;
+    if (team >= a.teams) return;
+    const int g = team / a.S, sp = team % a.S;
+    const int mt = member / a.c_tiles, ct = member % a.c_tiles;
+    const int T = a.T, Tin = UP ? (T >> 1) : T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave_u >> 1, wn = wave_u & 1;
+
+    const int64_t per = ((int64_t)a.n_tiles + a.S - 1) / a.S;
+    const int n_lo = (int)(per * sp);
+    int n_hi = (int)(per * (sp + 1));
+    if (n_hi > a.n_tiles) n_hi = a.n_tiles;
+
+    const float sx = scale_from(a.x_amax, a.x_scale), sg = scale_from(a.gy_amax, a.gy_scale);
+    float amax_x = 0.f, amax_g = 0.f;
+
+    f32x16 acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    // ---- staging registers: this thread's column pairs of the tile in flight
+    f32x2 gq[NGQ];
+    f32x2 xq[NXQ][UP ? 2 : 1];       // UP: the two half-resolution source pairs (see stage_x)
+    // pair p of the gy tile: row p / 32, columns 2 (p % 32) ..; pair p of the X tile: row p / 36, columns 2 (p % 36) .. (t0 - 4 + ..)
+#define NEF_W_ISSUE(N)                                                                                               \
+    {                                                                                                               \
+        const int b_ = (N) / a.tps, t0_ = ((N) % a.tps) * TT;                                                       \
+        const bool on_ = (N) < n_hi;                                                                                \
+        const __amdgpu_buffer_rsrc_t grs = nef_rsrc_n(a.gy + (int64_t)b_ * a.gy_bs + (int64_t)g * a.gy_gs + (int64_t)(mt * 64) * T, \
+                                                      on_ ? 0x7FFFFFFCu : 0u);                                      \
+        _Pragma("unroll") for (int q = 0; q < NGQ; ++q) {                                                           \
+            const int p = (int)threadIdx.x + 256 * q;                                                               \
+            const int row = p >> 5, t = t0_ + 2 * (p & 31);                                                         \
+            gq[q] = nef_buf_f32x2(grs, t < T ? (unsigned)((row * T + t) * 4) : NEF_OOB, 0);                         \
+        }                                                                                                           \
+        const __amdgpu_buffer_rsrc_t xrs = nef_rsrc_n(a.x + (int64_t)b_ * a.x_bs + (int64_t)g * a.x_gs + (int64_t)(ct * 64) * Tin, \
+                                                      on_ ? 0x7FFFFFFCu : 0u);                                      \
+        _Pragma("unroll") for (int q = 0; q < NXQ; ++q) {                                                           \
+            const int p = (int)threadIdx.x + 256 * q;                                                               \
+            const int row = p / (XW / 2), t = t0_ - 4 + 2 * (p % (XW / 2));                                         \
+            const bool ok = p < 64 * (XW / 2) && t >= 0 && t < T;                                                   \
+            if constexpr (UP) {                                                                                     \
+                /* outputs t, t + 1 (t even): sources t/2 - 1, t/2 and t/2, t/2 + 1, clamped as nn.Upsample clamps */ \
+                const int h_ = t >> 1;                                                                              \
+                const int im = h_ > 0 ? h_ - 1 : 0, ip = h_ + 1 < Tin ? h_ + 1 : Tin - 1;                           \
+                const float v0 = nef_buf_f32(xrs, ok ? (unsigned)((row * Tin + im) * 4) : NEF_OOB, 0);              \
+                const float v1 = nef_buf_f32(xrs, ok ? (unsigned)((row * Tin + h_) * 4) : NEF_OOB, 0);              \
+                const float v2 = nef_buf_f32(xrs, ok ? (unsigned)((row * Tin + ip) * 4) : NEF_OOB, 0);              \
+                xq[q][0] = f32x2{v0, v1};                                                                           \
+                xq[q][UP ? 1 : 0] = f32x2{v1, v2};                                                                  \
+            } else {                                                                                                \
+                xq[q][0] = nef_buf_f32x2(xrs, ok ? (unsigned)((row * T + t) * 4) : NEF_OOB, 0);                     \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
+#define NEF_W_STORE(N, BUFP)                                                                                         \
+    {                                                                                                               \
+        const int b_ = (N) / a.tps, t0_ = ((N) % a.tps) * TT;                                                       \
+        _Pragma("unroll") for (int q = 0; q < NGQ; ++q) {                                                           \
+            const int p = (int)threadIdx.x + 256 * q;                                                               \
+            const int row = p >> 5, c2 = p & 31;                                                                    \
+            amax_g = fmaxf(amax_g, fmaxf(fabsf(gq[q][0]), fabsf(gq[q][1])));                                        \
+            unsigned h_, l_;                                                                                        \
+            split2(gq[q][0] * sg, gq[q][1] * sg, h_, l_);                                                           \
+            unsigned char* p_ = (BUFP) + row * GP + c2 * 4;                                                         \
+            *reinterpret_cast<unsigned*>(p_) = h_;                                                                  \
+            *reinterpret_cast<unsigned*>(p_ + GY_PLANE) = l_;                                                       \
+        }                                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < NXQ; ++q) {                                                           \
+            const int p = (int)threadIdx.x + 256 * q;                                                               \
+            const int row = p / (XW / 2), c2 = p % (XW / 2), t = t0_ - 4 + 2 * c2;                                  \
+            if (p < 64 * (XW / 2)) {                                                                                \
+                const int ch = g * a.Cig + ct * 64 + row;                                                           \
+                float v0, v1;                                                                                       \
+                if constexpr (UP) {                                                                                 \
+                    float s0 = xq[q][0][0], s1 = xq[q][0][1], s2 = xq[q][UP ? 1 : 0][1];                            \
+                    if constexpr (AFF) {                                                                            \
+                        const int pr = (b_ / a.pro_Bp) * a.G * a.Cig + ch;                                          \
+                        const float pa = a.pro_a[pr], pb = a.pro_b[pr];                                             \
+                        s0 = fmaxf(fmaf(s0, pa, pb), 0.f), s1 = fmaxf(fmaf(s1, pa, pb), 0.f), s2 = fmaxf(fmaf(s2, pa, pb), 0.f); \
+                    }                                                                                               \
+                    /* t even: src = t/2 - 0.25 -> 0.25 x[t/2-1] + 0.75 x[t/2] (t = 0: clamped to x[0]); t + 1: 0.75 x[t/2] + 0.25 x[t/2+1] */ \
+                    v0 = t > 0 ? (1.f - 0.75f) * s0 + 0.75f * s1 : s1;                                              \
+                    v1 = (1.f - 0.25f) * s1 + 0.25f * s2;                                                           \
+                } else {                                                                                            \
+                    v0 = xq[q][0][0], v1 = xq[q][0][1];                                                             \
+                    if constexpr (AFF) {                                                                            \
+                        const int pr = (b_ / a.pro_Bp) * a.G * a.Cig + ch;                                          \
+                        const float pa = a.pro_a[pr], pb = a.pro_b[pr];                                             \
+                        v0 = fmaxf(fmaf(v0, pa, pb), 0.f), v1 = fmaxf(fmaf(v1, pa, pb), 0.f);                       \
+                    }                                                                                               \
+                }                                                                                                   \
+                if (a.in_scale) {                                                                                   \
+                    const float sc = a.in_scale[(int64_t)b_ * a.sc_bs + (int64_t)g * a.sc_gs + ct * 64 + row];      \
+                    v0 *= sc, v1 *= sc;                                                                             \
+                }                                                                                                   \
+                if (t < 0 || t >= T) v0 = v1 = 0.f;      /* zero padding comes after the prologue */                \
+                amax_x = fmaxf(amax_x, fmaxf(fabsf(v0), fabsf(v1)));                                                \
+                unsigned h_, l_;                                                                                    \
+                split2(v0 * sx, v1 * sx, h_, l_);                                                                   \
+                unsigned char* p_ = (BUFP) + 2 * GY_PLANE + row * XP + c2 * 4;                                      \
+                *reinterpret_cast<unsigned*>(p_) = h_;                                                              \
+                *reinterpret_cast<unsigned*>(p_ + X_PLANE) = l_;                                                    \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
+
+    if (n_lo < n_hi) {
+        NEF_W_ISSUE(n_lo)
+        NEF_W_STORE(n_lo, smem_w)
+    }
+    __syncthreads();
+    for (int n = n_lo; n < n_hi; ++n) {
+        const unsigned char* const bufp = smem_w + ((n - n_lo) & 1) * BUF;
+        NEF_W_ISSUE(n + 1)
+        const unsigned char* const ga = bufp + (wm * 32 + lo) * GP + hi * 16;
+        const unsigned char* const xa = bufp + 2 * GY_PLANE + (wn * 32 + lo) * XP + hi * 16;
+#pragma unroll
+        for (int c = 0; c < TT / 16; ++c) {
+            // A: gy[co][16 c + 8 hi .. + 7], both planes
+            unsigned ah[4], al[4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u32x2 vh = *reinterpret_cast<const u32x2*>(ga + c * 32 + 8 * j);
+                const u32x2 vl = *reinterpret_cast<const u32x2*>(ga + GY_PLANE + c * 32 + 8 * j);
+                ah[2 * j] = vh[0], ah[2 * j + 1] = vh[1];
+                al[2 * j] = vl[0], al[2 * j + 1] = vl[1];
+            }
+            // B window: X columns 16 c + 8 hi .. + 15 of the staged row (= t0 + 16 c + 8 hi - 4 .. + 11)
+            unsigned wh[8], wl[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x2 vh = *reinterpret_cast<const u32x2*>(xa + c * 32 + 8 * j);
+                const u32x2 vl = *reinterpret_cast<const u32x2*>(xa + X_PLANE + c * 32 + 8 * j);
+                wh[2 * j] = vh[0], wh[2 * j + 1] = vh[1];
+                wl[2 * j] = vl[0], wl[2 * j + 1] = vl[1];
+            }
+            const h16x8 fah = __builtin_bit_cast(h16x8, u32x4{ah[0], ah[1], ah[2], ah[3]});
+            const h16x8 fal = __builtin_bit_cast(h16x8, u32x4{al[0], al[1], al[2], al[3]});
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int e0 = 4 + k - PAD;            // first window element of this tap's fragment (compile time after unrolling)
+                unsigned bh[4], bl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if ((e0 & 1) == 0) {
+                        bh[j] = wh[e0 / 2 + j];
+                        bl[j] = wl[e0 / 2 + j];
+                    } else {
+                        bh[j] = __builtin_amdgcn_alignbit(wh[(e0 + 1) / 2 + j], wh[(e0 - 1) / 2 + j], 16);
+                        bl[j] = __builtin_amdgcn_alignbit(wl[(e0 + 1) / 2 + j], wl[(e0 - 1) / 2 + j], 16);
+                    }
+                }
+                const h16x8 fbh = __builtin_bit_cast(h16x8, u32x4{bh[0], bh[1], bh[2], bh[3]});
+                const h16x8 fbl = __builtin_bit_cast(h16x8, u32x4{bl[0], bl[1], bl[2], bl[3]});
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbh, acc[k], 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbl, acc[k], 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, fbh, acc[k], 0, 0, 0);
+            }
+        }
+        if (n + 1 < n_hi) NEF_W_STORE(n + 1, smem_w + ((n + 1 - n_lo) & 1) * BUF)
+        __syncthreads();
+    }
+#undef NEF_W_ISSUE
+#undef NEF_W_STORE
+
+    // this launch's operand magnitudes, for the call site's next launch
+    if (a.x_amax_next) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            amax_x = fmaxf(amax_x, __shfl_xor(amax_x, o, 64));
+            amax_g = fmaxf(amax_g, __shfl_xor(amax_g, o, 64));
+        }
+        if (lane == 0) {
+            unsigned* const px = reinterpret_cast<unsigned*>(a.x_amax_next);
+            unsigned* const pg = reinterpret_cast<unsigned*>(a.gy_amax_next);
+            const unsigned bx = __builtin_bit_cast(unsigned, amax_x), bg = __builtin_bit_cast(unsigned, amax_g);
+            if (amax_x < 3e38f && bx > __atomic_load_n(px, __ATOMIC_RELAXED)) atomicMax(px, bx);
+            if (amax_g < 3e38f && bg > __atomic_load_n(pg, __ATOMIC_RELAXED)) atomicMax(pg, bg);
+        }
+    }
+
+    // partial sums: ws[split][g][k][co][ci]; a lane's column is ci = wn 32 + lo, its rows co = wm 32 + 4 hi + (r & 3) + 8 (r >> 2)
+    const float ds = 1.f / (sx * sg);
+    const int co0 = mt * 64 + wm * 32 + 4 * hi, ci = ct * 64 + wn * 32 + lo;
+    float* const wsp = a.ws + ((int64_t)sp * a.G + g) * K * a.Cog * a.Cig;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            wsp[((int64_t)k * a.Cog + co0 + (r & 3) + 8 * (r >> 2)) * a.Cig + ci] = acc[k][r] * ds;
+}
+
+template <int K, int PRO>
+int launch_h2w(const H2WArgs& a, hipStream_t st) {
+    constexpr size_t lds = 2 * BUF;
+    static unsigned long long lds_set = 0;
+    if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_h2w_kernel<K, PRO>), lds, &lds_set)) return e;
+    const int members = a.m_tiles * a.c_tiles;
+    const int teams8 = (a.teams + 7) / 8 * 8;
+    const int64_t blocks = (int64_t)teams8 * members;
+    if (blocks <= 0 || blocks > 0x7fffffff) return NEF_E_SHAPE;
+    hipLaunchKernelGGL((conv_h2w_kernel<K, PRO>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    return nef_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+__attribute__((visibility("hidden"))) bool nef_h2w_ok(int B, int T, int Cig, int Cog, int K, int pro_mode) {
+    return (K == 3 || K == 7) && B > 0 && T >= TT && T % 2 == 0 && Cig % 64 == 0 && Cog % 64 == 0 && pro_mode >= 0 && pro_mode <= 3 &&
+           (K == 3 || pro_mode == 0);
+}
+
+// splits for this shape (the partial-sum workspace is S * G * K * Cog * Cig floats)
+__attribute__((visibility("hidden"))) int nef_h2w_splits(int B, int T, int G, int Cig, int Cog) {
+    const int tps = (T + TT - 1) / TT;
+    const int64_t n_tiles = (int64_t)B * tps;
+    const int units = G * (Cog / 64) * (Cig / 64);
+    int S = (2 * 2 * nef_cu_count() + units - 1) / units;      // two rounds of two workgroups per CU
+    if (S > n_tiles) S = (int)n_tiles;
+    if (S < 1) S = 1;
+    return S;
+}
+
+__attribute__((visibility("hidden"))) int nef_h2w_launch(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
+                                                         int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
+                                                         const float* gy, int64_t gy_bs, int64_t gy_gs, float* ws, int B, int T, int G,
+                                                         int Cig, int Cog, int K, int S, float x_scale, float gy_scale,
+                                                         const float* x_amax, const float* gy_amax, float* x_amax_next,
+                                                         float* gy_amax_next, hipStream_t st) {
+    if (!nef_h2w_ok(B, T, Cig, Cog, K, pro_mode)) return NEF_E_SHAPE;
+    if ((pro_mode & 1) && !(pro_a && pro_b && pro_Bp > 0)) return NEF_E_NULL;
+    if ((x_amax_next == nullptr) != (gy_amax_next == nullptr)) return NEF_E_NULL;
+    H2WArgs a;
+    a.x = x, a.gy = gy, a.in_scale = in_scale, a.pro_a = pro_a, a.pro_b = pro_b, a.ws = ws;
+    a.x_amax = x_amax, a.gy_amax = gy_amax, a.x_amax_next = x_amax_next, a.gy_amax_next = gy_amax_next;
+    a.x_bs = x_bs, a.x_gs = x_gs, a.gy_bs = gy_bs, a.gy_gs = gy_gs, a.sc_bs = sc_bs, a.sc_gs = sc_gs;
+    a.B = B, a.T = T, a.G = G, a.Cig = Cig, a.Cog = Cog, a.pro_Bp = pro_Bp > 0 ? pro_Bp : 1, a.S = S;
+    a.tps = (T + TT - 1) / TT;
+    a.n_tiles = B * a.tps;
+    a.m_tiles = Cog / 64, a.c_tiles = Cig / 64;
+    a.teams = G * S;
+    a.x_scale = x_scale, a.gy_scale = gy_scale;
+    if (K == 7) return launch_h2w<7, 0>(a, st);
+    switch (pro_mode) {
+        case 0: return launch_h2w<3, 0>(a, st);
+        case 1: return launch_h2w<3, 1>(a, st);
+        case 2: return launch_h2w<3, 2>(a, st);
+        default: return launch_h2w<3, 3>(a, st);
+    }
+}
+
+}  // extern "C"

@@ -139,12 +139,12 @@ def block_bwd(saved, gy, P, grads, out=None, side=None, pre_gated=False, gate_in
     G, Cig = xv.G, xv.Cg
     g2 = gy if pre_gated else ops.gate(gy, y)                # through the final ReLU
     g2v, hv = GV.dense(g2, G), GV.dense(h, G)
-    grads[prefix + ".conv2.weight"] = side.run(lambda: ops.conv_bwd_weight(hv, g2v, K), h, g2)
+    grads[prefix + ".conv2.weight"] = side.run(lambda: ops.conv_bwd_weight(hv, g2v, K, site=P[prefix + ".conv2.weight"].data_ptr()), h, g2)
     # through conv2, then dropout and the inner ReLU: h > 0 <=> ReLU active and kept
     gc1 = ops.conv(g2v, ops.pack_weight(P[prefix + ".conv2.weight"], G, flip=True, T=xv.T, f4=_bwd_f4(K)), Cog, K, gate=hv,
                    gate_scale=dscale, role="conv_bwd_data")
     gc1v = GV.dense(gc1, G)
-    grads[prefix + ".conv1.weight"] = side.run(lambda: ops.conv_bwd_weight(xv, gc1v, K), xv.t, gc1)
+    grads[prefix + ".conv1.weight"] = side.run(lambda: ops.conv_bwd_weight(xv, gc1v, K, site=P[prefix + ".conv1.weight"].data_ptr()), xv.t, gc1)
     if res_conv:
         grads[prefix + ".residual_conv.weight"] = side.run(lambda: ops.conv_bwd_weight(xv, g2v, 1), xv.t, g2)
         grads[prefix + ".residual_conv.bias"] = side.run(lambda: ops.chan_sum(g2), g2)
@@ -301,12 +301,12 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
         if li == 0 and shared_B is not None:
             gp2 = gc if gc.shape[0] == 2 * shared_B else ops.pass_combine_bwd(gc)   # [2B, 2*128, 2T]
             gpv, xv = GV.dense(gp2, 2), GV.dense(x, 2)
-            grads[wname] = side.run(lambda: _ungroup_halves(ops.conv_bwd_weight(xv, gpv, 3, pro=pro)), x, gp2)
+            grads[wname] = side.run(lambda: _ungroup_halves(ops.conv_bwd_weight(xv, gpv, 3, pro=pro, site=P[wname].data_ptr())), x, gp2)
             g = ops.conv(gpv, ops.pack_weight(_regroup_halves(P[wname]), 2, flip=True, T=gp2.shape[2], f4=True, site=P[wname].data_ptr()), x.shape[1] // 2, 3,
                          role="conv_bwd_data")
         else:
             gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
-            grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro), x, gc)
+            grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro, site=P[wname].data_ptr()), x, gc)
             wpf = ops.pack_weight(P[wname], 1, flip=True, T=gc.shape[2], f4=True)
             # g is the gradient wrt relu(bn(c_below)) when no upsampling sits in between: the epilogue then leaves the
             # reduction sums of that BatchNorm's backward (it reads c_below's tile for the ReLU decision and xhat)

@@ -226,6 +226,8 @@ H2 = os.environ.get("NEF_H2", "1") == "1"
 _H2_DIR = {False: os.environ.get("NEF_H2_FWD", "1") == "1", True: os.environ.get("NEF_H2_BWD", "1") == "1"}     # diagnostics
 _H2_K = os.environ.get("NEF_H2_K", "3,7").split(",")
 _H2_64 = os.environ.get("NEF_H2_64", "1") == "1"
+_H2_W = os.environ.get("NEF_H2_W", "1") == "1"          # weight gradients on the split-fp16 kernel too (csrc/conv_h2w.hip)
+_H2_WK = os.environ.get("NEF_H2_WK", "3,7").split(",")
 _H2_AMAX = os.environ.get("NEF_H2_AMAX", "sticky")      # diagnostics: "anon" = every launch measures first, "follow" = no stickiness
 
 
@@ -267,8 +269,21 @@ def _amax_state(dev):
     st = _AMAX.get(dev)
     if st is None:
         st = _AMAX[dev] = dict(cur=torch.zeros(AMAX_SITES, device=dev, dtype=torch.float32),
-                               nxt=torch.zeros(AMAX_SITES, device=dev, dtype=torch.float32), index={}, ready=set(), used=False, occ={})
+                               nxt=torch.zeros(AMAX_SITES, device=dev, dtype=torch.float32), index={}, ready=set(), used=False, occ={}, n=0)
     return st
+
+
+def _amax_index(st, site, n):
+    """First of the `n` consecutive magnitude slots of a call site (allocated on first use)."""
+    i = st["index"].get(site)
+    if i is None:
+        if st["n"] + n > AMAX_SITES:       # models come and go (tests): start over
+            assert not torch.cuda.is_current_stream_capturing()
+            st["index"].clear(), st["ready"].clear(), st["cur"].zero_(), st["nxt"].zero_()
+            st["n"] = 0
+        i = st["index"][site] = st["n"]
+        st["n"] += n
+    return i
 
 
 def amax_roll():
@@ -460,12 +475,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
             occ = st["occ"]
             k = occ[(AMAX_SCOPE, ws, role, xv.B, T_out)] = occ.get((AMAX_SCOPE, ws, role, xv.B, T_out), 0) + 1
             site = (AMAX_SCOPE, ws, role, xv.B, T_out, k)
-        i = st["index"].get(site)
-        if i is None:
-            if len(st["index"]) >= AMAX_SITES:       # models come and go (tests): start over
-                st["index"].clear(), st["ready"].clear(), st["cur"].zero_(), st["nxt"].zero_()
-                assert not torch.cuda.is_current_stream_capturing()
-            i = st["index"][site] = len(st["index"])
+        i = _amax_index(st, site, 1)
         a.x_amax_next = st["nxt"].data_ptr() + 4 * i
         if i not in st["ready"] or site is None:      # first launch of the site (or no scope): measure, then run
             if torch.cuda.is_current_stream_capturing():
@@ -486,13 +496,64 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     return out.t
 
 
-def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None):
-    """gw [G*Cog, Cig, K] for y = conv(prologue(x) * in_scale, w); `pro` as in conv().  `wino`: force (True / 4) or forbid
+def h2w_ok(K, Cig, Cog, T, pro_mode=0, in_scale=False):
+    return (H2 and _H2_W and str(K) in _H2_WK and T % 2 == 0 and T >= 64 and Cig % 64 == 0 and Cog % 64 == 0 and
+            (K == 3 or not pro_mode) and not (pro_mode and in_scale))
+
+
+def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None, site=None, h2=None, x_scale=0.0, gy_scale=0.0):
+    """gw [G*Cog, Cig, K] for y = conv(prologue(x) * in_scale, w); `pro` as in conv().  Default path: the split-fp16 kernel
+    (csrc/conv_h2w.hip) wherever its shape rules hold (h2w_ok; `h2=False` forbids it, giving `wino` forbids it too); `site`: the
+    identity of the call site for its operand-magnitude slots (the engine passes the weight's address; None = measure at every
+    call), `x_scale` / `gy_scale`: explicit powers of two instead.  `wino`: force (True / 4) or forbid
     (False) the transposed-Winograd form -- F(3,4) for K == 3, the 4 + 3 split through F(4,4) + F(3,4) for K == 7; default:
     wherever it applies (see WINOGRAD, WINO_BW4, WINO_BW7)."""
     L = _lib.load()
     B, T, G, Cig, Cog = xv.B, gyv.T, xv.G, xv.Cg, gyv.Cg
     gw = torch.empty(G * Cog, Cig, K, device=xv.t.device, dtype=torch.float32)
+    pm0 = pro[0] if pro is not None else 0
+    if h2 is None:
+        h2 = wino is None and h2w_ok(K, Cig, Cog, T, pm0, in_scale is not None)
+    if h2:
+        n = L.nef_conv_bwd_weight_h2_ws_bytes(B, T, G, Cig, Cog, K)
+        if n == 0:
+            raise _lib.NefLibraryError(f"conv_bwd_weight (split-fp16): unsupported shape Cig={Cig} Cog={Cog} K={K} T={T}")
+        ws = workspace(n, xv.t.device)
+        sc, sc_bs, sc_gs = (None, 0, 0) if in_scale is None else (_p(in_scale[0]), in_scale[1], in_scale[2])
+        pm, pa, pb, pbp = (pro[0], _p(pro[1]), _p(pro[2]), pro[3]) if pm0 else (0, None, None, 1)
+
+        def launch(amax, nxt):
+            _lib.check(L.nef_conv_bwd_weight_h2(xv.ptr, xv.bs, xv.gs, sc, sc_bs, sc_gs, pa, pb, pm, pbp, gyv.ptr, gyv.bs, gyv.gs,
+                                                _p(gw), _p(ws), n, B, T, G, Cig, Cog, K, float(x_scale), float(gy_scale),
+                                                amax, None if amax is None else amax + 4, nxt, None if nxt is None else nxt + 4,
+                                                _stream()), "nef_conv_bwd_weight_h2")
+        ev = _timed(("conv_bwd_weight", K, G, Cig, Cog, B, T))
+        if ev is not None:
+            EXEC_FRAC[("conv_bwd_weight", K, G, Cig, Cog, B, T)] = 0.0
+        if x_scale and gy_scale:
+            launch(None, None)
+        else:
+            st = _amax_state(xv.t.device)
+            key = None
+            if AMAX_SCOPE is not None and site is not None and _H2_AMAX != "anon":
+                occ = st["occ"]
+                base = (AMAX_SCOPE, (site, "w"), "conv_bwd_weight", B, T)
+                k = occ[base] = occ.get(base, 0) + 1
+                key = base + (k,)
+            i = _amax_index(st, key, 2)          # slots i (x) and i + 1 (gy)
+            nxt = st["nxt"].data_ptr() + 4 * i
+            if i not in st["ready"] or key is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("split-fp16 weight gradient: a call site's first launch cannot be captured")
+                st["nxt"][i:i + 2] = 0.0
+                launch(None, nxt)
+                st["cur"][i:i + 2] = st["nxt"][i:i + 2]
+                st["ready"].add(i)
+            st["used"] = True
+            launch(st["cur"].data_ptr() + 4 * i, nxt)
+        if ev is not None:
+            ev.record()
+        return gw
     n = L.nef_conv_bwd_weight_ws_bytes(B, T, G, Cig, Cog, K)
     if n == 0:
         raise _lib.NefLibraryError(f"conv_bwd_weight: unsupported shape Cig={Cig} Cog={Cog} K={K}")
