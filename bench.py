@@ -303,7 +303,8 @@ def main():
     # step (measured: 57.8 vs 57.1 ms), so the per-kernel breakdown and the HBM-bound set are taken from two extra,
     # untimed steps right after the timed region.
     T_lat = L // 4
-    dom = {("conv_fwd", 7, V, 128, 128, B, T_lat), ("conv_bwd_data", 7, V, 128, 128, B, T_lat)}
+    dom = {("conv_fwd", 7, V, 128, 128, B, T_lat), ("conv_bwd_data", 7, V, 128, 128, B, T_lat),
+           ("conv_bwd_weight", 7, V, 128, 128, B, T_lat)}
     timing = rank == 0 and not args.no_kernel_events and not args.graph
     ops.PROFILE, ops.PROFILE_ONLY = ([] if timing else None), (lambda tag: tag in dom)
     parallel.TIMING = [] if (world > 1 and rank == 0) else None      # events around the exposed part of the gradient all-reduce
@@ -344,88 +345,97 @@ def main():
         dt = float(t.item())
     final_loss = float(final_loss_t.item())
 
+    # the arithmetic of the step: fp32 data, parameters, accumulators and elementwise work; the conv products run on the fp16 matrix
+    # cores on EXACT two-term fp16 splits of the fp32 operands (ops.H2; results at fp32 rounding) -- or on the fp32
+    # matrix cores throughout with NEF_H2=0
+    DTYPE = ("f32 (conv products: fp32 operands split exactly into fp16 hi+lo, 3 fp16 matrix products each, fp32 accumulate)"
+             if ops.H2 else "f32")
     if rank == 0:
-        # Dominant kernel: the K=7 grouped conv over the encoder's [B,128V,T] activations, 18 launches per step: 6 forward
-        # (conv_wino_kernel<7,2,0>: Winograd F(2,4)+F(2,3) on the taps split 4+3 -- the one `roofline` prices, from the launches of
-        # the TIMED region), 6 backward-data (conv_wino4_kernel<7,4,0>: F(4,4) + F(4,3) on the taps split 4+3) and 6 weight gradients
-        # (conv_bww_glds_kernel<7,.,4> + <7,.,5>: taps split 4+3 over two launches, transposed F(4,4) + F(3,4), tiles by LDS-DMA).
-        # roofline.achieved / frac = EXECUTED matrix-core flops (what the MFMA pipes really did) over the kernel's time,
-        # against the dense fp32 MFMA peak.  The algorithmic (direct-convolution) rate 2*B*Cout*T*Cin_g*K / time is
-        # reported beside it as `algorithmic_TFLOPs`: it exceeds the executed rate by the Winograd saving and is NOT a
-        # roofline fraction.
+        # Every tagged conv launch is priced against BOTH roofs and bound by the larger floor:
+        #   matrix floor = executed fp32 flops / 157.3 TF + executed fp16 flops / 2500 TF  (ops.EXEC_FRAC / ops.EXEC_FP16: what the
+        #                  matrix cores really do per algorithmic multiply -- 3 fp16 instructions-worth in the split-fp16 kernels,
+        #                  9/14 .. 1/2 fp32 in the Winograd forms, 1 in the direct fp32 kernels),
+        #   HBM floor    = algorithmic bytes (input + output rows once, + residual / gate operands where the block has them) / 8 TB/s.
+        # `roofline` carries the kernel with the largest share of the step (by its launches in the single-stream breakdown
+        # steps), timed over the launches of the TIMED region; `k7_kernels_one_at_a_time` the three K = 7 kernels;
+        # `whole_step` the sum of the binding floors of all tagged conv launches + the algorithmic bytes of the HBM-bound
+        # passes over the timed step.
         T = L // 4
-        key = ("conv_fwd", 7, V, 128, 128, B, T)
-        times = [s.elapsed_time(e) for tag, s, e in prof if tag == key]
-        times_bd = [s.elapsed_time(e) for tag, s, e in prof if tag == ("conv_bwd_data",) + key[1:]]
-        flops = 2.0 * B * (128 * V) * T * 128 * 7
-        # multiplies executed on the matrix cores per algorithmic multiply
-        from electrocardio_panorama_amd import engine as _eng
-        ex_fwd = 9.0 / 14.0 if ops.WINOGRAD else 1.0
-        ex_bd = (13.0 / 28.0 if _eng._bwd_f4(7) else 10.0 / 14.0) if ops.WINOGRAD else 1.0
-        ex_bw = 13.0 / 28.0 if (ops.WINOGRAD and ops.WINO_BW7) else 1.0
+        KNAME = {3: "conv_h2_kernel (direct conv on exact fp16 splits of both fp32 operands, fp32 accumulate)",
+                 2: "conv_wino4_kernel (Winograd F(4,3) / F(4,4)+F(4,3), fp32)", 1: "conv_wino_kernel (Winograd F(2,3) / F(2,4)+F(2,3), fp32)",
+                 0: "conv_fwd_kernel (direct, fp32)"}
+
+        def price(tag, ms):
+            role, k_, g_, cig_, cog_, b_, t_ = tag
+            f_ = 2.0 * b_ * g_ * cog_ * t_ * cig_ * k_
+            ex32, ex16 = f_ * ops.EXEC_FRAC.get(tag, 1.0), f_ * ops.EXEC_FP16.get(tag, 0.0)
+            byts = 4.0 * b_ * g_ * (cig_ + cog_) * t_ + 4.0 * g_ * cig_ * cog_ * k_
+            if role != "conv_bwd_weight" and cig_ == cog_ and k_ == 7:
+                byts += 0.5 * 4.0 * b_ * g_ * cog_ * t_        # every second launch of an encoder block reads a residual / gate row
+            fl_m = (ex32 / FP32_MFMA_PEAK_TFLOPS + ex16 / FP16_MFMA_PEAK_TFLOPS) / 1e9      # ms
+            fl_h = byts / HBM_PEAK_GBS / 1e6                                              # ms
+            bound = "mfma" if fl_m >= fl_h else "hbm"
+            d = {"avg_ms": round(ms, 4), "bound": bound, "floor_ms": round(max(fl_m, fl_h), 4),
+                 "frac": round(max(fl_m, fl_h) / ms, 4), "mfma_floor_ms": round(fl_m, 4), "hbm_floor_ms": round(fl_h, 4),
+                 "algorithmic_flops_per_launch": f_, "executed_fp32_mfma_flops": ex32, "executed_fp16_mfma_flops": ex16,
+                 "algorithmic_bytes_per_launch": byts}
+            if bound == "mfma":
+                peak = FP16_MFMA_PEAK_TFLOPS if ex16 > 0 else FP32_MFMA_PEAK_TFLOPS
+                d.update(achieved=round((ex16 if ex16 > 0 else ex32) / ms / 1e9, 2), peak=peak, unit="TFLOP/s",
+                         matrix_dtype="f16 (exact splits of f32 operands), f32 accumulate" if ex16 > 0 else "f32")
+            else:
+                d.update(achieved=round(byts / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s")
+            return d
+
+        serial = {}
+        for tag, s_, e_ in prof_all:
+            if tag[0] in ("conv_fwd", "conv_bwd_data", "conv_bwd_weight"):
+                serial.setdefault(tag, []).append(s_.elapsed_time(e_))
+        timed = {}
+        for tag, s_, e_ in prof:
+            timed.setdefault(tag, []).append(s_.elapsed_time(e_))
         roof = None
-        if times:
-            avg_ms = sum(times) / len(times)
-            alg = flops / (avg_ms * 1e-3) / 1e12
-            ach = alg * ex_fwd
+        if serial:
+            dom_tag = max(serial, key=lambda t_: sum(serial[t_]))
+            # weight gradients run on the side stream, next to chain kernels: their event time in the timed region contains that
+            # sharing, so they are priced by their launches of the single-stream breakdown steps
+            use = (timed.get(dom_tag) if dom_tag[0] != "conv_bwd_weight" else None) or serial[dom_tag]
+            roof = price(dom_tag, sum(use) / len(use))
             traffic = traffic_source = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath) and (V, B, L) == (3, 256, 5000):     # PMC pass was taken at configs[1] only
                 tj = json.load(open(tpath))
-                traffic = tj.get("conv_fwd_k7_bytes_per_launch")
+                kn = ("conv_h2w_kernel<%d, 0>" % dom_tag[1]) if dom_tag[0] == "conv_bwd_weight" else ("conv_h2_kernel<%d, 0, 2>" % dom_tag[1])
+                traffic = tj.get("by_kernel", {}).get(kn) if ops.H2 else None
                 # NOT measured by this run: replayed from the committed rocprofv3 --pmc pass (separate run, as the
                 # counters cannot be collected together with timing)
-                traffic_source = "replayed from " + tj.get("source", "profiles/traffic.json")
-            # forward launches: conv1 of a block reads x and writes h; conv2 reads h AND the residual x, writes y
-            act = 4.0 * B * 128 * V * T
-            alg_bytes = ((2 * act) + (3 * act)) / 2 + 4.0 * 128 * V * 128 * 7
-            # the same kernel family one launch at a time (single-stream breakdown steps): its own duration per kernel
-            def _serial(role, ex):
-                ts = [s.elapsed_time(e) for tag, s, e in prof_all if tag == (role,) + key[1:]]
-                if not ts:
-                    return None
-                ms = sum(ts) / len(ts)
-                return {"avg_ms": round(ms, 4), "launches": len(ts), "executed_over_algorithmic": round(ex, 4),
-                        "executed_TFLOPs": round(flops * ex / ms / 1e9, 2),
-                        "frac": round(flops * ex / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                    "kernel": ("conv_wino_kernel<7,2,0> (k7 grouped conv, Winograd F(2,4)+F(2,3) on taps 4+3)" if ops.WINOGRAD
-                               else "conv_fwd_kernel<7,2,0> (k7 grouped conv, direct)") + ", forward launches of the timed region",
-                    "launches": len(times), "avg_ms": round(avg_ms, 4),
-                    "executed_mfma_flops_per_launch": flops * ex_fwd,
-                    "algorithmic_flops_per_launch": flops, "algorithmic_TFLOPs": round(alg, 2),
-                    "algorithmic_over_peak": round(alg / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "algorithmic_bytes_per_launch": alg_bytes,
-                    "hbm_GBps": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1),
-                    "avg_ms_bwd_data_launches_overlapped": round(sum(times_bd) / max(len(times_bd), 1), 4),
-                    "k7_kernels_one_at_a_time": {
-                        "conv_wino_kernel<7,2,0> fwd F(2,4)+F(2,3) on taps 4+3": _serial("conv_fwd", ex_fwd),
-                        "conv_wino4_kernel<7,4,0> bwd-data F(4,4)+F(4,3) on taps 4+3": _serial("conv_bwd_data", ex_bd),
-                        "conv_bww_glds_kernel<7,.,4> + <7,.,5>: taps 4+3 as two launches, transposed F(4,4) + F(3,4), tiles by LDS-DMA (+ the split-K reduce)": _serial("conv_bwd_weight", ex_bw)},
-                    "side_stream": os.environ.get("NEF_SIDE_STREAM", "auto") != "0"}
-        # Whole step against the same roof: EXECUTED matrix-core flops of every tagged conv launch of one (single-stream,
-        # untimed) breakdown step -- algorithmic 2*B*Cout*T*Cin_g*K times the executed fraction ops.EXEC_FRAC recorded for
-        # the form that ran -- over the TIMED ms_per_step.  The stem, the transposed conv and the theta MLPs are not in the sum
-        # (< 1 % of the step's matrix work), so the figure is a slight under-count.
-        ex_flops = alg_flops = 0.0
-        for tag, s_, e_ in prof_all:
-            if tag[0] in ("conv_fwd", "conv_bwd_data", "conv_bwd_weight"):
-                _, k_, g_, cig_, cog_, b_, t_ = tag
-                f_ = 2.0 * b_ * g_ * cog_ * t_ * cig_ * k_
-                alg_flops += f_
-                ex_flops += f_ * ops.EXEC_FRAC.get(tag, 1.0)
-        ex_flops /= max(extra_steps, 1)
-        alg_flops /= max(extra_steps, 1)
-        if roof is not None and ex_flops > 0:
+                traffic_source = ("replayed from " + tj.get("source", "profiles/traffic.json")) if traffic else None
+            roof.update(traffic=traffic, traffic_source=traffic_source, kernel_tag="/".join(str(x) for x in dom_tag),
+                        kernel=("conv_h2w_kernel (weight gradient on exact fp16 splits of both operands)" if dom_tag[0] == "conv_bwd_weight" and roof["executed_fp16_mfma_flops"] > 0
+                                else KNAME[3] if roof["executed_fp16_mfma_flops"] > 0 else "fp32 conv kernel") +
+                               (", launches of the timed region" if use is not serial[dom_tag] else ", launches of the single-stream breakdown steps"),
+                        launches=len(use), ms_per_step_serialized=round(sum(serial[dom_tag]) / max(extra_steps, 1), 3),
+                        side_stream=os.environ.get("NEF_SIDE_STREAM", "auto") != "0")
+            k7 = {}
+            for role in ("conv_fwd", "conv_bwd_data", "conv_bwd_weight"):
+                tg = (role, 7, V, 128, 128, B, T)
+                if tg in serial:
+                    k7[role] = price(tg, sum(serial[tg]) / len(serial[tg]))
+            roof["k7_kernels_one_at_a_time"] = k7
+            # whole step: binding floors of the conv launches + the HBM-bound passes at the HBM peak, over the timed step
+            fl_conv = sum(price(tg, 1.0)["floor_ms"] * len(v) for tg, v in serial.items()) / max(extra_steps, 1)
+            fl_hbm = sum(tag[2] for tag, s_, e_ in prof_all if tag[0] == "hbm") / max(extra_steps, 1) / HBM_PEAK_GBS / 1e6
             ms_step = 1e3 * dt / args.steps
+            ex32 = sum(price(tg, 1.0)["executed_fp32_mfma_flops"] * len(v) for tg, v in serial.items()) / max(extra_steps, 1)
+            ex16 = sum(price(tg, 1.0)["executed_fp16_mfma_flops"] * len(v) for tg, v in serial.items()) / max(extra_steps, 1)
+            alg = sum(price(tg, 1.0)["algorithmic_flops_per_launch"] * len(v) for tg, v in serial.items()) / max(extra_steps, 1)
             roof["whole_step"] = {
-                "executed_mfma_TFLOP_per_step": round(ex_flops / 1e12, 4),
-                "algorithmic_TFLOP_per_step": round(alg_flops / 1e12, 4),
-                "executed_TFLOPs": round(ex_flops / ms_step / 1e9, 2),
-                "frac": round(ex_flops / ms_step / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
-                "floor_ms_at_peak": round(ex_flops / FP32_MFMA_PEAK_TFLOPS / 1e9, 3),
-                "basis": "executed matrix-core flops of the tagged conv launches of one step / timed ms_per_step / fp32 MFMA peak"}
+                "floor_ms": round(fl_conv + fl_hbm, 3), "conv_floor_ms": round(fl_conv, 3), "hbm_pass_floor_ms": round(fl_hbm, 3),
+                "frac": round((fl_conv + fl_hbm) / ms_step, 4),
+                "algorithmic_TFLOP_per_step": round(alg / 1e12, 4), "executed_fp32_mfma_TFLOP_per_step": round(ex32 / 1e12, 4),
+                "executed_fp16_mfma_TFLOP_per_step": round(ex16 / 1e12, 4),
+                "basis": "sum over the tagged conv launches of one step of max(matrix floor, HBM floor) + algorithmic bytes of the "
+                         "HBM-bound passes / 8 TB/s, over the timed ms_per_step"}
         by_kernel = {}
         hbm = {}
         for tag, s, e in prof_all:
@@ -461,7 +471,7 @@ def main():
             "metric": "ECG-samples/sec (train step)", "value": round(world * B * args.steps / dt, 2),
             "unit": "ECG-samples/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": f"{_config_name(V, B, L)}: Nef-Net train step, {V}-lead len={L}, batch={B}/GPU, "
                                    f"3-view-in -> 1-view-out, Standin losses on, dropout "
                                    f"{'off' if args.no_dropout else 'on'}",

@@ -39,6 +39,8 @@ PROFILE_ONLY = None     # optional predicate(tag): bracket only these launches (
 # is on: 1 direct; K=3: 2/3 through F(2,3), 1/2 through F(4,3) / the transposed F(3,4); K=7: 9/14 forward (F(2,4)+F(2,3)),
 # 13/28 backward-data (F(4,4)+F(4,3)) and weight gradient (transposed F(4,4)+F(3,4)), 10/14 for the 3+3+1 forms
 EXEC_FRAC = {}
+# ... and fp16 matrix-core multiplies executed per algorithmic multiply (the split-fp16 kernels: 3; every other form: 0)
+EXEC_FP16 = {}
 
 
 def _exec_frac(K, form):
@@ -489,7 +491,8 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
         st["used"] = True
     ev = _timed((role, K, xv.G, xv.Cg, Cog, xv.B, T_out))
     if ev is not None:
-        EXEC_FRAC[(role, K, xv.G, xv.Cg, Cog, xv.B, T_out)] = _exec_frac(K, a.wino)
+        EXEC_FRAC[(role, K, xv.G, xv.Cg, Cog, xv.B, T_out)] = 0.0 if a.wino == 3 else _exec_frac(K, a.wino)
+        EXEC_FP16[(role, K, xv.G, xv.Cg, Cog, xv.B, T_out)] = 3.0 if a.wino == 3 else 0.0
     _lib.check(L.nef_conv_fwd(C.byref(a), _stream()), "nef_conv_fwd")
     if ev is not None:
         ev.record()
@@ -530,6 +533,7 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None, site=None, h
         ev = _timed(("conv_bwd_weight", K, G, Cig, Cog, B, T))
         if ev is not None:
             EXEC_FRAC[("conv_bwd_weight", K, G, Cig, Cog, B, T)] = 0.0
+            EXEC_FP16[("conv_bwd_weight", K, G, Cig, Cog, B, T)] = 3.0
         if x_scale and gy_scale:
             launch(None, None)
         else:
@@ -566,6 +570,7 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None, site=None, h
     wino = 4 if wino else False
     if ev is not None:
         EXEC_FRAC[("conv_bwd_weight", K, G, Cig, Cog, B, T)] = _exec_frac(K, 2) if wino else 1.0
+        EXEC_FP16[("conv_bwd_weight", K, G, Cig, Cog, B, T)] = 0.0
     if wino:
         pm, pa, pb, pbp = (pro[0], _p(pro[1]), _p(pro[2]), pro[3]) if (pro is not None and pro[0]) else (0, None, None, 1)
         _lib.check(L.nef_conv_bwd_weight_wino4(xv.ptr, xv.bs, xv.gs, sc, sc_bs, sc_gs, pa, pb, pm, pbp, gyv.ptr, gyv.bs,

@@ -19,7 +19,7 @@ SHAPES = [  # (name, K, G, Cig, Cog, B, T)
 ]
 only = sys.argv[1] if len(sys.argv) > 1 else None
 iters = int(os.environ.get("ITERS", 10))
-whats = os.environ.get("ONLY_WHAT", "fwd,wino,bwd_w,bwd_ww").split(",")
+whats = os.environ.get("ONLY_WHAT", "fwd,wino,bwd_w,bwd_ww,bwd_h2").split(",")
 for name, K, G, Cig, Cog, B, T in SHAPES:
     if only and only not in name:
         continue
@@ -29,7 +29,7 @@ for name, K, G, Cig, Cog, B, T in SHAPES:
     wp = ops.pack_weight(w, G)
     wpw = ops.pack_weight(w, G, T=T, f4=os.environ.get("F4", "1") == "1")      # F4=0: the F(2,3) form
     flops = 2.0 * B * G * Cog * T * Cig * K
-    for what in ("fwd", "wino", "bwd_w", "bwd_ww"):
+    for what in ("fwd", "wino", "bwd_w", "bwd_ww", "bwd_h2"):
         if what not in whats:
             continue
         if what == "wino" and not getattr(wpw, "nef_wino", False):
@@ -37,7 +37,10 @@ for name, K, G, Cig, Cog, B, T in SHAPES:
         fn = (lambda: ops.conv(GV.dense(x, G), wp, Cog, K, relu=True)) if what == "fwd" else \
              (lambda: ops.conv(GV.dense(x, G), wpw, Cog, K, relu=True)) if what == "wino" else \
              (lambda: ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, wino=False)) if what == "bwd_w" else \
-             (lambda: ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, wino=4))
+             (lambda: ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, wino=4)) if what == "bwd_ww" else \
+             (lambda: ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, h2=True, x_scale=64.0, gy_scale=64.0))
+        if what == "bwd_h2" and not ops.h2w_ok(K, Cig, Cog, T):
+            continue
         if what == "bwd_ww" and (K not in (3, 7) or T < 64 or T % 2):
             continue
         for _ in range(int(os.environ.get("WARM", 30))):      # the first kernel timed in a process runs ~10 % slow for a few dozen launches

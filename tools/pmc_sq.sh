@@ -1,14 +1,14 @@
 #!/bin/bash
 # SQ / GRBM counters of the conv micro-benchmark (one shape): where the waves' cycles go.   usage: tools/pmc_sq.sh "enc k7" out
-# Two passes: F4=1 (direct forward, F(4,.) forward / backward-data form, both weight-gradient forms) and F4=0 ONLY_WHAT=wino
-# (the F(2,.) forward kernel -- conv_wino_kernel<7,2,0> for "enc k7", the kernel bench.py's roofline prices).
+# Two passes: NEF_H2=0 F4=1 (the fp32 kernels: direct forward, F(4,.) forward / backward-data form, both fp32 weight-gradient forms)
+# and the default path ONLY_WHAT=wino,bwd_h2 (the split-fp16 kernels conv_h2_kernel / conv_h2w_kernel bench.py's roofline prices).
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${2:-sq}
 rm -rf $O && mkdir -p $O
 CNT="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
-ITERS=3 F4=1 timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d $O/p1 -o t -- python tools/bench_conv.py "$1" > $O/run1.log 2>&1
-ITERS=3 F4=0 ONLY_WHAT=wino timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d $O/p2 -o t -- python tools/bench_conv.py "$1" > $O/run2.log 2>&1
+WARM=3 NEF_H2=0 ITERS=3 F4=1 timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d $O/p1 -o t -- python tools/bench_conv.py "$1" > $O/run1.log 2>&1
+WARM=3 ITERS=3 ONLY_WHAT=wino,bwd_h2 timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d $O/p2 -o t -- python tools/bench_conv.py "$1" > $O/run2.log 2>&1
 python - <<PY
 import sqlite3, glob
 out = {}
@@ -36,7 +36,7 @@ with open("$O/sq.md", "w") as f:
         for c, v in sorted(d.items()):
             f.write(f"    {c:28s} {v:.4g}\n")
         if direct and "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["SQ_VALU_MFMA_BUSY_CYCLES"] > 0:
-            f.write(f"    MFMA_BUSY / direct forward's   {d['SQ_VALU_MFMA_BUSY_CYCLES'] / direct:.4f}   (9/14 = 0.6429 F(2,4)+F(2,3); 13/28 = 0.4643 F(4,4)+F(4,3); 1/2 F(4,3); 2/3 F(2,3))\n")
+            f.write(f"    MFMA_BUSY / direct forward's   {d['SQ_VALU_MFMA_BUSY_CYCLES'] / direct:.4f}   (split-fp16: 3 x 32 / (8 x 64) = 0.1875; 13/28 = 0.4643 F(4,4)+F(4,3); 1/2 F(4,3))\n")
         if "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["GRBM_GUI_ACTIVE"] > 0:
             f.write(f"    matrix-pipe occupancy          {d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}   (busy cycles / (cycles per XCD x 1024 SIMDs))\n")
 print(open("$O/sq.md").read())

@@ -13,7 +13,7 @@ import sqlite3
 import sys
 
 fetch_db, write_db, out_md, out_json = sys.argv[1:5]
-DOM = sys.argv[5] if len(sys.argv) > 5 else "conv_wino_kernel<7"
+DOM = sys.argv[5] if len(sys.argv) > 5 else "conv_h2w_kernel<7"
 
 
 def short(name):
@@ -42,11 +42,11 @@ cal_w = (sum(w for _, w in cal) / len(cal)) * 1024 / CAL_BYTES
 if not (0.40 < cal_ratio < 0.62) or not (0.85 < cal_w < 1.15):
     sys.exit(f"pmc_table: calibration off: FETCH_SIZE x 1024 = {cal_ratio:.3f} of the known read bytes (expected 0.5), "
              f"WRITE_SIZE x 1024 = {cal_w:.3f} of the known write bytes (expected 1.0)")
-# dominant kernel, forward launches only: the first 6 launches of each step are the encoder's forward convs
+# dominant kernel (bench.py's `roofline`): the kernel with the largest summed duration in the step -- since round 4 the K = 7
+# weight gradient conv_h2w_kernel<7, 0>; every launch of a kernel name is averaged
 k7 = [(f, w) for (n, g, f), (_, _, w) in zip(F, W) if n.startswith(DOM)]
-per_step = len(k7) // 2
-fwd = k7[0:6] + k7[per_step:per_step + 6]
-fwd_bytes = sum((2 * f + w) * 1024 for f, w in fwd) / len(fwd)
+if not k7:
+    sys.exit(f"pmc_table: no launch of {DOM} in the trace")
 all_bytes = sum((2 * f + w) * 1024 for f, w in k7) / len(k7)
 with open(out_md, "w") as fh:
     fh.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1, config 2 "
@@ -56,9 +56,9 @@ with open(out_md, "w") as fh:
              f"{CAL_BYTES:,.0f} bytes per launch; FETCH_SIZE x 1024 = {cal_ratio:.3f} of the read, WRITE_SIZE x 1024 = {cal_w:.3f} of "
              "the write.  Fabric-side counters: hits in the memory-side\n"
              "cache (MALL) are counted like HBM reads, so these are upper bounds on DRAM traffic.\n\n")
-    fh.write(f"Dominant kernel `{DOM}...>`: forward launches (6 per step: 3 read x, 3 read x + residual; "
-             f"algorithmic 0.984 / 1.476 GB) move {fwd_bytes/1e9:.3f} GB per launch on average; all 12 launches per step "
-             f"(forward + backward-data, which also read a gate or residual operand) {all_bytes/1e9:.3f} GB.\n\n")
+    fh.write(f"Dominant kernel `{DOM}...>`: {len(k7)} launches, {all_bytes/1e9:.3f} GB per launch on average "
+             "(algorithmic: one read of each operand row, 0.984 GB for the K = 7 weight gradient -- each of the 2 x 2 channel "
+             "tiles of a (group, split) re-reads its operand rows through the L2 of one XCD).\n\n")
     fh.write("| kernel | launches | FETCH_SIZE avg (min..max) KB | WRITE_SIZE avg (min..max) KB | corrected bytes/launch (GB) |\n"
              "|---|---:|---:|---:|---:|\n")
     order = sorted(stats.items(), key=lambda kv: -sum((2 * f + w) for f, w in kv[1]))
@@ -67,10 +67,9 @@ with open(out_md, "w") as fh:
         gb = sum((2 * f + w) * 1024 for f, w in v) / len(v) / 1e9
         fh.write(f"| `{n}` | {len(v)} | {sum(fs)/len(fs):.0f} ({min(fs):.0f}..{max(fs):.0f}) | "
                  f"{sum(ws)/len(ws):.0f} ({min(ws):.0f}..{max(ws):.0f}) | {gb:.3f} |\n")
-json.dump({"conv_fwd_k7_bytes_per_launch": int(fwd_bytes), "conv_fwd_k7_bytes_per_launch_all": int(all_bytes),
-           "algorithmic_bytes_per_forward_launch": int((3 * 984416256 + 3 * 1475936256) / 6),
+json.dump({"by_kernel": {n: int(sum((2 * f + w) * 1024 for f, w in v) / len(v)) for n, v in stats.items()},
+           "dominant": DOM, "dominant_bytes_per_launch": int(all_bytes),
            "source": out_md + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-           "note": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024, mean over the forward launches of the dominant k7 conv kernel "
-                   "(the launches bench.py times for roofline.achieved)"},
+           "note": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024, mean over the launches of a kernel name"},
           open(out_json, "w"), indent=1)
 print(open(out_md).read()[:1800])

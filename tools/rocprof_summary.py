@@ -3,10 +3,10 @@
     python tools/rocprof_summary.py <results.db> <out.md> [steps] [warm]
 
 `steps` = train steps the profiled command ran in all, `warm` (default 1) = how many of them, from the start, are warm-up and
-are DROPPED: per kernel name the launches are ordered by start time and the first calls*warm/steps of them are left out (the
-first step's launches read 3-10 % long: cold instruction caches, first-touch page faults, the clocks ramping), so averages and
-the per-step total are over steady-state steps only.  Kernels whose launch count is not a multiple of `steps` (one-off setup
-work) are kept whole and divided by the profiled steps like the rest.
+are DROPPED: every launch that started before the (warm + 1)-th `stem_fwd_kernel` launch (the first kernel of a train step) is
+left out (the first step's launches read 3-10 % long -- cold instruction caches, first-touch page faults, the clocks ramping --
+and it carries the one-off operand-measuring launches of the split-fp16 call sites), so averages and the per-step total are
+over steady-state steps only.
 """
 import sqlite3
 import sys
@@ -19,14 +19,19 @@ try:
     raw = list(cur.execute("select name, start, duration from kernels order by start"))
 except sqlite3.OperationalError:
     raw = [(n, i, d) for i, (n, d) in enumerate(cur.execute("select name, duration from kernels"))]
+# step boundaries: `stem_fwd_kernel` is launched exactly once per train step and is the step's first conv -- everything that
+# started before its (warm + 1)-th launch is warm-up (the first step also carries the one-off operand-measuring launches of the
+# split-fp16 call sites, so dropping a fixed share of each kernel's launches would miscount)
+marks = [st for name, st, _ in raw if "stem_fwd_kernel" in name]
+cut = marks[warm] if (warm and len(marks) > warm) else None
 by = {}
-for name, _, dur in raw:
+for name, st, dur in raw:
+    if cut is not None and st < cut:
+        continue
     by.setdefault(name, []).append(dur)
-kept_steps = steps - warm
+kept_steps = steps - warm if cut is not None or not warm else steps
 rows = []
 for name, durs in by.items():
-    if warm and len(durs) % steps == 0:
-        durs = durs[len(durs) * warm // steps:]
     rows.append((name, len(durs), sum(durs), sum(durs) / len(durs), min(durs), max(durs)))
 rows.sort(key=lambda r: -r[2])
 total = sum(r[2] for r in rows)

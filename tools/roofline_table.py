@@ -28,14 +28,16 @@ def pmc(path, counter):
 f, w = pmc(fetch, "FETCH_SIZE"), pmc(write, "WRITE_SIZE")
 cur = sqlite3.connect(trace).cursor()
 rows = {}
-for name, gx, gy, gz, dur in cur.execute("select name, grid_x, grid_y, grid_z, duration from kernels order by start"):
-    rows.setdefault((short(name), gx * gy * gz), []).append(dur)
-# the first profiled step is warm-up (3-10 % long): per launch shape, drop its share of the launches when the count allows
+# the first profiled step is warm-up (3-10 % long, and it carries the one-off measuring launches of the split-fp16 call sites):
+# everything that started before the second `stem_fwd_kernel` launch (first kernel of a train step) is dropped
 STEPS = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-WARM = 1 if STEPS > 1 else 0
-for k in list(rows):
-    if WARM and len(rows[k]) % STEPS == 0:
-        rows[k] = rows[k][len(rows[k]) * WARM // STEPS:]
+allk = list(cur.execute("select name, grid_x, grid_y, grid_z, duration, start from kernels order by start"))
+marks = [st for name, _, _, _, _, st in allk if "stem_fwd_kernel" in name]
+cut = marks[1] if (STEPS > 1 and len(marks) > 1) else None
+for name, gx, gy, gz, dur, st in allk:
+    if cut is not None and st < cut:
+        continue
+    rows.setdefault((short(name), gx * gy * gz), []).append(dur)
 total = sum(sum(v) for v in rows.values())
 lines = []
 for key, durs in rows.items():
