@@ -32,7 +32,7 @@ class ConvArgs(C.Structure):
         ("pro_a", p), ("pro_b", p), ("pro_mode", i32), ("pro_Bp", i32), ("rng_seed_dev", p), ("wino", i32),
         ("stats", p),
         ("bnb_x", p), ("bnb_mean", p), ("bnb_invstd", p), ("bnb_a", p), ("bnb_b", p), ("bnb_slots", p), ("bnb_Bp", i32),
-        ("bnb_up", i32), ("x_scale", f32), ("reserved0", i32), ("x_amax", p), ("x_amax_next", p),
+        ("bnb_up", i32), ("x_scale", f32), ("reserved0", i32), ("x_amax", p), ("x_amax_next", p), ("x_clamped", p),
     ]
 
 
@@ -63,7 +63,7 @@ SIGNATURES = {
                                         i32, p]),
     "nef_conv_bwd_weight_h2_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "nef_conv_bwd_weight_h2": (i32, [p, i64, i64, p, i64, i64, p, p, i32, i32, p, i64, i64, p, p, sz, i32, i32, i32, i32, i32, i32,
-                               f32, f32, p, p, p, p, p]),
+                               f32, f32, p, p, p, p, p, p]),
     "nef_chan_sum_ws_bytes": (sz, [i32]),
     "nef_chan_sum": (i32, [p, p, p, sz, i32, i32, i32, p]),
     "nef_convt2_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, i32, p]),

@@ -361,9 +361,12 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
 #undef NEF_H2X_STORE
 #undef NEF_H2A_ISSUE
 
-    if (a.x_amax_next) {      // this launch's own input magnitude, for the call site's next launch
+    if (a.x_amax_next || a.x_clamped) {      // this launch's own input magnitude, for the call site's next launch
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax_ = fmaxf(amax_, __shfl_xor(amax_, o, 64));
+        if (a.x_clamped && lane == 0 && !(amax_ * xs_ < 65000.f)) atomicAdd(a.x_clamped, 1);      // an element was clamped (or is not finite)
+    }
+    if (a.x_amax_next) {
         if (lane == 0 && amax_ < 3e38f) {
             unsigned* const p_ = reinterpret_cast<unsigned*>(a.x_amax_next);
             const unsigned b_ = __builtin_bit_cast(unsigned, amax_);       // non-negative floats order like their bit patterns
@@ -599,7 +602,8 @@ __attribute__((visibility("hidden"))) bool nef_h2_ok(const nef_conv_args* a) {
 __attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, hipStream_t st) {
     if (!nef_h2_ok(a)) return NEF_E_SHAPE;
     if ((a->pro_mode & 1) && !(a->pro_a && a->pro_b && a->pro_Bp > 0)) return NEF_E_NULL;
-    const bool wide = a->Cout_g % 128 == 0;
+    static const bool force_tm1 = getenv("NEF_H2_TM1") && atoi(getenv("NEF_H2_TM1")) == 1;      // A/B: 64-channel tile everywhere
+    const bool wide = a->Cout_g % 128 == 0 && !force_tm1;
     // the x2-upsampling prologue keeps two source samples per staged position in registers: next to the 128 accumulator
     // registers of the 128-channel tile that spills (250..330 bytes per lane), so those launches take the 64-channel tile
     static const bool up_wide = getenv("NEF_H2_UP_TM") && atoi(getenv("NEF_H2_UP_TM")) == 2;

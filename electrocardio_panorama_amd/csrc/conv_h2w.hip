@@ -55,6 +55,7 @@ struct H2WArgs {
     const float* gy_amax;
     float* x_amax_next;
     float* gy_amax_next;
+    int* clamped;
     int64_t x_bs, x_gs, gy_bs, gy_gs, sc_bs, sc_gs;
     int B, T, G, Cig, Cog, pro_Bp, S, tps, n_tiles, m_tiles, c_tiles, teams;
     float x_scale, gy_scale;
@@ -271,13 +272,14 @@ __global__ __launch_bounds__(256, 2) void conv_h2w_kernel(H2WArgs a) {
 #undef NEF_W_STORE
 
     // this launch's operand magnitudes, for the call site's next launch
-    if (a.x_amax_next) {
+    if (a.x_amax_next || a.clamped) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             amax_x = fmaxf(amax_x, __shfl_xor(amax_x, o, 64));
             amax_g = fmaxf(amax_g, __shfl_xor(amax_g, o, 64));
         }
-        if (lane == 0) {
+        if (a.clamped && lane == 0 && !(amax_x * sx < 65000.f && amax_g * sg < 65000.f)) atomicAdd(a.clamped, 1);
+        if (a.x_amax_next && lane == 0) {
             unsigned* const px = reinterpret_cast<unsigned*>(a.x_amax_next);
             unsigned* const pg = reinterpret_cast<unsigned*>(a.gy_amax_next);
             const unsigned bx = __builtin_bit_cast(unsigned, amax_x), bg = __builtin_bit_cast(unsigned, amax_g);
@@ -335,13 +337,13 @@ __attribute__((visibility("hidden"))) int nef_h2w_launch(const float* x, int64_t
                                                          const float* gy, int64_t gy_bs, int64_t gy_gs, float* ws, int B, int T, int G,
                                                          int Cig, int Cog, int K, int S, float x_scale, float gy_scale,
                                                          const float* x_amax, const float* gy_amax, float* x_amax_next,
-                                                         float* gy_amax_next, hipStream_t st) {
+                                                         float* gy_amax_next, int* clamped, hipStream_t st) {
     if (!nef_h2w_ok(B, T, Cig, Cog, K, pro_mode)) return NEF_E_SHAPE;
     if ((pro_mode & 1) && !(pro_a && pro_b && pro_Bp > 0)) return NEF_E_NULL;
     if ((x_amax_next == nullptr) != (gy_amax_next == nullptr)) return NEF_E_NULL;
     H2WArgs a;
     a.x = x, a.gy = gy, a.in_scale = in_scale, a.pro_a = pro_a, a.pro_b = pro_b, a.ws = ws;
-    a.x_amax = x_amax, a.gy_amax = gy_amax, a.x_amax_next = x_amax_next, a.gy_amax_next = gy_amax_next;
+    a.x_amax = x_amax, a.gy_amax = gy_amax, a.x_amax_next = x_amax_next, a.gy_amax_next = gy_amax_next, a.clamped = clamped;
     a.x_bs = x_bs, a.x_gs = x_gs, a.gy_bs = gy_bs, a.gy_gs = gy_gs, a.sc_bs = sc_bs, a.sc_gs = sc_gs;
     a.B = B, a.T = T, a.G = G, a.Cig = Cig, a.Cog = Cog, a.pro_Bp = pro_Bp > 0 ? pro_Bp : 1, a.S = S;
     a.tps = (T + TT - 1) / TT;

@@ -2325,7 +2325,7 @@ __attribute__((visibility("hidden"))) int nef_h2_pack(const nef_pack_desc* descs
 
 extern "C" {
 
-int nef_abi_version(void) { return 14; }
+int nef_abi_version(void) { return 15; }
 
 int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                     nef_stream_t stream) {
@@ -2600,7 +2600,7 @@ __attribute__((visibility("hidden"))) int nef_h2w_launch(const float* x, int64_t
                                                          const float* gy, int64_t gy_bs, int64_t gy_gs, float* ws, int B, int T, int G,
                                                          int Cig, int Cog, int K, int S, float x_scale, float gy_scale,
                                                          const float* x_amax, const float* gy_amax, float* x_amax_next,
-                                                         float* gy_amax_next, hipStream_t st);
+                                                         float* gy_amax_next, int* clamped, hipStream_t st);
 
 size_t nef_conv_bwd_weight_h2_ws_bytes(int B, int T, int G, int Cin_g, int Cout_g, int K) {
     if (G <= 0 || !nef_h2w_ok(B, T, Cin_g, Cout_g, K, 0)) return 0;
@@ -2611,7 +2611,7 @@ int nef_conv_bwd_weight_h2(const float* x, int64_t x_bs, int64_t x_gs, const flo
                            const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp, const float* gy, int64_t gy_bs,
                            int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B, int T, int G, int Cin_g, int Cout_g, int K,
                            float x_scale, float gy_scale, const float* x_amax, const float* gy_amax, float* x_amax_next,
-                           float* gy_amax_next, nef_stream_t stream) {
+                           float* gy_amax_next, int32_t* clamped, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(x && gy && gw && ws, NEF_E_NULL);
     NEF_REQUIRE(G > 0 && nef_h2w_ok(B, T, Cin_g, Cout_g, K, pro_mode), NEF_E_SHAPE);
@@ -2620,7 +2620,7 @@ int nef_conv_bwd_weight_h2(const float* x, int64_t x_bs, int64_t x_gs, const flo
     NEF_REQUIRE(ws_bytes >= (size_t)S * G * K * Cout_g * Cin_g * sizeof(float), NEF_E_WORKSPACE);
     hipStream_t st = (hipStream_t)stream;
     if (int rc = nef_h2w_launch(x, x_bs, x_gs, in_scale, sc_bs, sc_gs, pro_a, pro_b, pro_mode, pro_Bp, gy, gy_bs, gy_gs, (float*)ws, B,
-                                T, G, Cin_g, Cout_g, K, S, x_scale, gy_scale, x_amax, gy_amax, x_amax_next, gy_amax_next, st))
+                                T, G, Cin_g, Cout_g, K, S, x_scale, gy_scale, x_amax, gy_amax, x_amax_next, gy_amax_next, clamped, st))
         return rc;
     const int64_t n = (int64_t)G * K * Cout_g * Cin_g;
     hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3(nef_stream_grid(n, 256)), dim3(256), 0, st, (const float*)ws, gw, G, Cout_g,

@@ -271,8 +271,21 @@ def _amax_state(dev):
     st = _AMAX.get(dev)
     if st is None:
         st = _AMAX[dev] = dict(cur=torch.zeros(AMAX_SITES, device=dev, dtype=torch.float32),
-                               nxt=torch.zeros(AMAX_SITES, device=dev, dtype=torch.float32), index={}, ready=set(), used=False, occ={}, n=0)
+                               nxt=torch.zeros(AMAX_SITES, device=dev, dtype=torch.float32), index={}, ready=set(), used=False, occ={}, n=0,
+                               clamped=torch.zeros(1, device=dev, dtype=torch.int32))
     return st
+
+
+def h2_clamped(reset=True):
+    """Waves of split-fp16 launches (sited ones: measuring launches are not counted) that had to clamp an operand element at
+    fp16's range since the last call -- an operand grew by more than ~128x from one pass to the next, so those launches' results
+    are off (the next pass has followed).  Reading synchronises: call it at a logging interval, not per step."""
+    n = 0
+    for st in _AMAX.values():
+        n += int(st["clamped"].item())
+        if reset:
+            st["clamped"].zero_()
+    return n
 
 
 def _amax_index(st, site, n):
@@ -488,6 +501,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
             st["cur"][i] = st["nxt"][i]
             st["ready"].add(i)
         a.x_amax = st["cur"].data_ptr() + 4 * i
+        a.x_clamped = st["clamped"].data_ptr()
         st["used"] = True
     ev = _timed((role, K, xv.G, xv.Cg, Cog, xv.B, T_out))
     if ev is not None:
@@ -525,11 +539,11 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None, site=None, h
         sc, sc_bs, sc_gs = (None, 0, 0) if in_scale is None else (_p(in_scale[0]), in_scale[1], in_scale[2])
         pm, pa, pb, pbp = (pro[0], _p(pro[1]), _p(pro[2]), pro[3]) if pm0 else (0, None, None, 1)
 
-        def launch(amax, nxt):
+        def launch(amax, nxt, clamped=None):
             _lib.check(L.nef_conv_bwd_weight_h2(xv.ptr, xv.bs, xv.gs, sc, sc_bs, sc_gs, pa, pb, pm, pbp, gyv.ptr, gyv.bs, gyv.gs,
                                                 _p(gw), _p(ws), n, B, T, G, Cig, Cog, K, float(x_scale), float(gy_scale),
                                                 amax, None if amax is None else amax + 4, nxt, None if nxt is None else nxt + 4,
-                                                _stream()), "nef_conv_bwd_weight_h2")
+                                                clamped, _stream()), "nef_conv_bwd_weight_h2")
         ev = _timed(("conv_bwd_weight", K, G, Cig, Cog, B, T))
         if ev is not None:
             EXEC_FRAC[("conv_bwd_weight", K, G, Cig, Cog, B, T)] = 0.0
@@ -554,7 +568,7 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None, site=None, h
                 st["cur"][i:i + 2] = st["nxt"][i:i + 2]
                 st["ready"].add(i)
             st["used"] = True
-            launch(st["cur"].data_ptr() + 4 * i, nxt)
+            launch(st["cur"].data_ptr() + 4 * i, nxt, st["clamped"].data_ptr())
         if ev is not None:
             ev.record()
         return gw

@@ -171,6 +171,10 @@ class Solver:
                 msg += '\npsnr_gen: {}, psnr_reg: {}, ssim_gen:{}, ssim_reg:{}'.format(psnr_gen, psnr_reg, ssim_gen, ssim_reg)
             if self.summary_writer is not None:
                 self.write_tensorboardx(scalars, names, epoch)
+            clamped = ops.h2_clamped()        # once per epoch (it synchronises): split-fp16 launches that ran out of fp16 range
+            if clamped:
+                msg += ('\nWARNING: {} waves of split-fp16 conv launches clamped an operand this epoch (a tensor grew more '
+                        'than ~128x between two consecutive steps); NEF_H2=0 runs the fp32 kernels'.format(clamped))
             print(msg)
             save_arguments['psnr_gen'] = psnr_gen
             save_arguments['psnr_reg'] = psnr_reg

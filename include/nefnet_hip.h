@@ -34,7 +34,7 @@ extern "C" {
 typedef void* nef_stream_t;
 
 /* ABI version of this header; bumped on any signature change. */
-int nef_abi_version(void);   /* 14 (round 4: + nef_conv_bwd_weight_h2); 13 (round 4: + nef_pack_weight_h2 / conv args wino = 3 and x_scale: direct convolutions on exact fp16 splits of the fp32 operands); 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
+int nef_abi_version(void);   /* 15 (round 4: + x_clamped / clamped counters); 14 (round 4: + nef_conv_bwd_weight_h2); 13 (round 4: + nef_pack_weight_h2 / conv args wino = 3 and x_scale: direct convolutions on exact fp16 splits of the fp32 operands); 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
 
 /* ---------------------------------------------------------------------------------------------
  * Stem: Conv1d(1->128 per lead, k15, s2, p7, no bias) + ReLU + MaxPool1d(3,2,1), fused.
@@ -161,6 +161,9 @@ typedef struct nef_conv_args {
                               magnitude, and the launch stays capturable (nothing is read back by the host) */
     float* x_amax_next;    /* wino == 3: NULL, or a device word (zeroed by the caller) this launch max-accumulates the largest
                               |input| of ITS operand into -- next launch's x_amax */
+    int32_t* x_clamped;    /* wino == 3: NULL, or a device counter the launch adds 1 to (per wave) when an element of its scaled
+                              operand reached fp16's range and was clamped at 65000 / scale: the operand grew more than ~128x
+                              since its scale was measured -- results of THIS launch are off, the caller should know */
 } nef_conv_args;
 
 /* y = epilogue(conv(x * in_scale, wp) + bias + res).  Also the bwd-data pass (pack with transpose_flip=1,
@@ -205,14 +208,15 @@ int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const 
  * x_scale / gy_scale: 0 (= 1) or the exact powers of two the operands are multiplied by before they are split (their product is
  * divided out); x_amax / gy_amax: NULL, or device words with the largest |operand| the call site saw before -- when positive and
  * finite the scales are derived from them instead; x_amax_next / gy_amax_next: both NULL, or device words this launch
- * max-accumulates its operands' magnitudes into.  ws: nef_conv_bwd_weight_h2_ws_bytes(...) bytes (split partial sums, added up in a
+ * max-accumulates its operands' magnitudes into; clamped: NULL, or a device counter incremented when a scaled operand element
+ * had to be clamped at fp16's range (see nef_conv_args.x_clamped).  ws: nef_conv_bwd_weight_h2_ws_bytes(...) bytes (split partial sums, added up in a
  * fixed order). */
 size_t nef_conv_bwd_weight_h2_ws_bytes(int B, int T, int G, int Cin_g, int Cout_g, int K);
 int nef_conv_bwd_weight_h2(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs, int64_t sc_gs,
                            const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp, const float* gy, int64_t gy_bs,
                            int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B, int T, int G, int Cin_g, int Cout_g, int K,
                            float x_scale, float gy_scale, const float* x_amax, const float* gy_amax, float* x_amax_next,
-                           float* gy_amax_next, nef_stream_t stream);
+                           float* gy_amax_next, int32_t* clamped, nef_stream_t stream);
 
 /* out[c] = sum_{b,t} x[b][c][t] (bias gradients).  ws: nef_chan_sum_ws_bytes(C). */
 size_t nef_chan_sum_ws_bytes(int C);

@@ -23,8 +23,8 @@ def test_header_symbols_exported():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().nef_abi_version() == 14
-    assert ctypes.sizeof(_lib.ConvArgs) == 320 == _lib.load().nef_conv_args_bytes()
+    assert _lib.load().nef_abi_version() == 15
+    assert ctypes.sizeof(_lib.ConvArgs) == 328 == _lib.load().nef_conv_args_bytes()
 
 
 def test_rejects_bad_calls_without_touching_the_gpu():

@@ -735,7 +735,7 @@ def test_graphed_step_keeps_momentum_across_shapes_and_checkpoints():
     else:
         assert torch.equal(l_a, l_b)
     p2 = dict(m2.named_parameters())
-    assert max(rel(p2[k], pg[k]) for k in pg) < (1e-6 if _ops.H2 else 1e-7)
+    assert max(rel(p2[k], pg[k]) for k in pg) < (1e-5 if _ops.H2 else 1e-7)
     # a new learning rate re-captures but keeps the momentum
     before = step.flat_buf.clone()
     step.set_lr(0.01)

@@ -1118,12 +1118,21 @@ def test_conv_h2_sites_are_sticky_and_scoped(conv_algo):
         assert slot() == m0 and rel(y3, 10 * ref) < 1e-6
         o.amax_roll()
         assert slot() == m0
+        assert o.h2_clamped() == 0
         y4 = o.conv(GV.dense(x * 100, G), wp, C, K)           # outside: this launch still runs on the old scale (in range: the
         assert rel(y4, 100 * ref) < 1e-6                      # scale leaves 128x of headroom, clamping starts beyond that) ...
         o.amax_roll()
         assert abs(slot() - 100 * m0) < 1e-3 * m0 * 100       # ... and the next pass follows
         y5 = o.conv(GV.dense(x * 100, G), wp, C, K)
-        assert rel(y5, 100 * ref) < 1e-6
+        assert rel(y5, 100 * ref) < 1e-6 and o.h2_clamped() == 0
+        # a jump past fp16's range from one pass to the next: the launch clamps -- and says so
+        o.amax_roll()
+        y7 = o.conv(GV.dense(x * 1e6, G), wp, C, K)
+        assert torch.isfinite(y7).all() and rel(y7, 1e6 * ref) > 1e-2 and o.h2_clamped() > 0 and o.h2_clamped() == 0
+        o.amax_roll()
+        y8 = o.conv(GV.dense(x * 1e6, G), wp, C, K)           # the next pass has followed
+        assert rel(y8, 1e6 * ref) < 1e-6 and o.h2_clamped() == 0
+        o.amax_roll()
     tok2 = o.new_amax_scope()
     with o.amax_scope(tok2):
         tok = tok2

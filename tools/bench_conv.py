@@ -35,7 +35,7 @@ for name, K, G, Cig, Cog, B, T in SHAPES:
         if what == "wino" and not getattr(wpw, "nef_wino", False):
             continue
         fn = (lambda: ops.conv(GV.dense(x, G), wp, Cog, K, relu=True)) if what == "fwd" else \
-             (lambda: ops.conv(GV.dense(x, G), wpw, Cog, K, relu=True)) if what == "wino" else \
+             (lambda: ops.conv(GV.dense(x, G), wpw, Cog, K, relu=True, x_scale=(1.0 if getattr(wpw, "nef_wino", 0) == 3 else 0.0))) if what == "wino" else \
              (lambda: ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, wino=False)) if what == "bwd_w" else \
              (lambda: ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, wino=4)) if what == "bwd_ww" else \
              (lambda: ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, h2=True, x_scale=64.0, gy_scale=64.0))
