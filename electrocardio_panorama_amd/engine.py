@@ -402,6 +402,7 @@ def forward(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", t
     drop = drop or DropCfg(False)
     B, V, L = x.shape
     T = L // 4
+    ops.BATCH_HINT = B     # small batches stay on the fp32 kernels (ops._h2_fills)
     ops.amax_roll()        # split-fp16 convs: last pass's operand magnitudes become this pass's input scales
     z1, z2b, sv = _latents(P, x, in_theta, rois, drop, save)
     if phase == "gen":
@@ -426,6 +427,7 @@ def forward2(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", 
     drop = drop or DropCfg(False)
     B, V, L = x.shape
     T, N = L // 4, V * B
+    ops.BATCH_HINT = N
     ops.amax_roll()
     xf = x.transpose(0, 1).reshape(N, 1, L).contiguous()
     thf = in_theta.transpose(0, 1).reshape(N, 1, 2).contiguous()

@@ -228,14 +228,29 @@ H2 = os.environ.get("NEF_H2", "1") == "1"
 _H2_DIR = {False: os.environ.get("NEF_H2_FWD", "1") == "1", True: os.environ.get("NEF_H2_BWD", "1") == "1"}     # diagnostics
 _H2_K = os.environ.get("NEF_H2_K", "3,7").split(",")
 _H2_64 = os.environ.get("NEF_H2_64", "1") == "1"
+_H2_MIN_T = int(os.environ.get("NEF_H2_MIN_T", "128"))      # shortest sequence the split-fp16 kernels take (256-column tiles)
 _H2_W = os.environ.get("NEF_H2_W", "1") == "1"          # weight gradients on the split-fp16 kernel too (csrc/conv_h2w.hip)
 _H2_WK = os.environ.get("NEF_H2_WK", "3,7").split(",")
 _H2_AMAX = os.environ.get("NEF_H2_AMAX", "sticky")      # diagnostics: "anon" = every launch measures first, "follow" = no stickiness
 
 
+# Small problems stay on the fp32 kernels: the split-fp16 kernels tile a sample in 256 outputs x 128 (64) channels, and below
+# ~one workgroup per CU the half-empty tiles and the per-launch setup cost more than the matrix time they save (reference-native
+# batch 32 x L 512: 3.11 ms per captured step with them, 2.72 without).  The engine announces the batch of the pass it is about
+# to run (BATCH_HINT); without a hint (bare ops calls) the shape rules alone decide.
+BATCH_HINT = None
+_H2_MIN_WGS = int(os.environ.get("NEF_H2_MIN_WGS", "256"))
+
+
+def _h2_fills(G, Cout_g, T_out, tile_t, tile_c):
+    if BATCH_HINT is None:
+        return True
+    return G * ((Cout_g + tile_c - 1) // tile_c) * BATCH_HINT * ((T_out + tile_t - 1) // tile_t) >= _H2_MIN_WGS
+
+
 def h2_ok(K, Cin_g, Cout_g, T_out, pro=0):
     # NEF_H2_64=0 leaves the 64-channel output tiles (conv_h2_kernel<., ., 1>) to the F(4,3) kernels
-    return (H2 and (K == 3 or (K == 7 and not pro)) and T_out % 2 == 0 and T_out >= 128 and Cin_g % 16 == 0 and
+    return (H2 and (K == 3 or (K == 7 and not pro)) and T_out % 2 == 0 and T_out >= max(128, _H2_MIN_T) and Cin_g % 16 == 0 and
             Cout_g % (64 if _H2_64 else 128) == 0)
 
 
@@ -346,7 +361,8 @@ def _pack_shape(w, G, flip, T, f4=False):
     Cog, Cig, K = w.shape[0] // G, w.shape[1], w.shape[2]
     cin_g, cout_g = (Cog, Cig) if flip else (Cig, Cog)          # roles in the launch that consumes the operand
     wino = (WINO_FWD if f4 else 1) if (T is not None and wino_ok(K, cin_g, cout_g, T)) else 0
-    if T is not None and h2_ok(K, cin_g, cout_g, T) and _H2_DIR[bool(flip)] and str(K) in _H2_K:
+    if (T is not None and h2_ok(K, cin_g, cout_g, T) and _H2_DIR[bool(flip)] and str(K) in _H2_K and
+            _h2_fills(G, cout_g, T, 256, 128 if cout_g % 128 == 0 else 64)):
         wino = 3
     return Cog, Cig, K, wino
 
@@ -514,7 +530,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
 
 
 def h2w_ok(K, Cig, Cog, T, pro_mode=0, in_scale=False):
-    return (H2 and _H2_W and str(K) in _H2_WK and T % 2 == 0 and T >= 64 and Cig % 64 == 0 and Cog % 64 == 0 and
+    return (H2 and _H2_W and str(K) in _H2_WK and T % 2 == 0 and T >= max(64, _H2_MIN_T) and Cig % 64 == 0 and Cog % 64 == 0 and
             (K == 3 or not pro_mode) and not (pro_mode and in_scale))
 
 
@@ -530,7 +546,8 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None, site=None, h
     gw = torch.empty(G * Cog, Cig, K, device=xv.t.device, dtype=torch.float32)
     pm0 = pro[0] if pro is not None else 0
     if h2 is None:
-        h2 = wino is None and h2w_ok(K, Cig, Cog, T, pm0, in_scale is not None)
+        h2 = (wino is None and h2w_ok(K, Cig, Cog, T, pm0, in_scale is not None) and
+              (BATCH_HINT is None or B * ((T + 63) // 64) >= 8 * _H2_MIN_WGS))      # enough (sample, tile) steps to split
     if h2:
         n = L.nef_conv_bwd_weight_h2_ws_bytes(B, T, G, Cig, Cog, K)
         if n == 0:
