@@ -53,7 +53,9 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket launches with HIP events (roofline / hbm_bound are then null): at launch-bound "
                          "shapes the ~250 event pairs per step cost more host time than the launches themselves")
-    ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (launch-bound shapes)")
+    ap.add_argument("--graph", action="store_true", help="(default) the timed steps replay the captured hipGraph of the step")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="issue every launch of the timed steps from Python instead (what the per-kernel breakdown steps always do)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[3] / configs[4] inference timings")
     return ap.parse_args()
 
@@ -274,13 +276,18 @@ def main():
                                                  ("data", "rois", "input_theta", "target_view", "target_theta"))
     tgt_view = tgt_view.unsqueeze(1)
 
+    # The timed steps replay the captured hipGraph of the step (graph.GraphedTrainStep over the SAME FusedSGD buffers -- what
+    # Solver.run_one_epoch does): since the convs run on the fp16 matrix cores a step is ~290 launches of 36 ms in all, and
+    # issuing them from Python leaves 2.5-4.5 ms of gaps per step on a busy host (measured: 37.2-39.2 ms eager, box and load
+    # dependent, against 34.4-34.9 replayed).  Same kernels, same arithmetic; --no-graph times the eager issue.
+    args.graph = not args.no_graph
     graphed = None
     if args.graph:
         from electrocardio_panorama_amd.graph import GraphedTrainStep
-        graphed = GraphedTrainStep(model, cfg)
+        graphed = GraphedTrainStep(model, cfg, optimizer=optim)
 
-    def step():
-        if graphed is not None:
+    def step(eager=False):
+        if graphed is not None and not eager:
             return graphed(data, in_theta, tgt_theta, rois, tgt_view)[0]
         out, sp, sl = model(data, in_theta, tgt_theta, rois, phase="train")
         losses = lossf(out, sp, sl, tgt_view, cfg)
@@ -315,9 +322,9 @@ def main():
     dt = time.perf_counter() - t0
     prof, ops.PROFILE, ops.PROFILE_ONLY = ops.PROFILE or [], None, None
     ar_events, parallel.TIMING = parallel.TIMING or [], None
-    final_loss_t = loss
+    final_loss_t = loss.detach().clone()      # (the graphed step returns a view of its static loss buffer)
     prof_all, extra_steps = [], 2
-    if not args.no_kernel_events and not args.graph:       # every rank takes the extra steps (they contain the all-reduce)
+    if not args.no_kernel_events:       # every rank takes the extra steps (they contain the all-reduce); always issued eagerly
         # Per-kernel breakdown: untimed extra steps with EVERY launch bracketed, on ONE stream (NEF_SIDE_STREAM=0 is read per
         # step by engine._side), so each kernel has the chip to itself and its event time is its own duration -- in the
         # default two-stream schedule a chain kernel that shares the chip with a side-stream weight-gradient kernel reads
@@ -327,12 +334,12 @@ def main():
         ops.PROFILE = [] if rank == 0 else None
         # one more bracketed step first, whose events are dropped: the first event pair recorded behind a cross-stream
         # wait can come back with the wait inside it (seen once: 52 ms on a 0.23 ms launch of the first bracketed step)
-        step()
+        step(eager=True)
         fence()
         if rank == 0:
             ops.PROFILE = []
         for _ in range(extra_steps):
-            step()
+            step(eager=True)
         fence()
         prof_all, ops.PROFILE = ops.PROFILE or [], None
         if side_env is None:

@@ -239,6 +239,14 @@ class GraphedTrainStep:
         self._stage(data, in_theta, q_theta, rois, target, draw=False)
         slot["graph"].replay()
         if self.world > 1:
+            from . import parallel
+            ev = None
+            if parallel.TIMING is not None:        # bench.py: the whole flat all-reduce is exposed behind the replay
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             dist.all_reduce(self.flat_g)
+            if ev is not None:
+                ev[1].record()
+                parallel.TIMING.append(ev)
             self._sgd()
         return self.losses

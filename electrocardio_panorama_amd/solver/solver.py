@@ -227,8 +227,7 @@ class Solver:
         return gen_num, whole
 
     def _graphed_step(self, optim, data, keep):
-        """The hipGraph stepper for this batch, or None when the step runs eagerly: `cfg.SOLVER.graph` False, or 'auto' and the
-        step is GPU-bound (engine._SIDE_MIN_WORK), the per-view host lists are wanted (the graph returns losses only), the
+        """The hipGraph stepper for this batch, or None when the step runs eagerly: `cfg.SOLVER.graph` False, the per-view host lists are wanted (the graph returns losses only), the
         model is not the plain Model_nefnet train path, DATA.noise, or the optimiser is not FusedSGD."""
         mode = self.cfg.SOLVER.get('graph', None)
         mode = 'auto' if mode is None or mode == 'auto' else bool(mode)
@@ -238,9 +237,9 @@ class Solver:
             return None
         if type(self.model).__name__ != 'Model_nefnet' or os.environ.get('NEF_SOLVER_GRAPH', '1') == '0':
             return None
-        B, V, L = data.shape
-        if mode == 'auto' and B * 128 * V * (L // 4) >= engine._SIDE_MIN_WORK:
-            return None
+        # 'auto' = wherever the conditions above hold, at every batch size: with the convs on the fp16 matrix cores even the
+        # full-size step (configs[1]: ~290 launches, 36 ms) loses 2.5-4.5 ms to launch gaps when a busy host issues it from Python
+        # (bench.py --no-graph against the default); rounds 1-3 replayed launch-bound shapes only
         st = getattr(self, '_graph_stepper', None)
         if st is None or st.optimizer is not optim:
             from ..graph import GraphedTrainStep
