@@ -487,7 +487,8 @@ def sweep_eval(P, Bf, latent, query_thetas, chunk=8):
         a, b = ops.bn_eval_affine(P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
                                   Bf[pre + ".running_var"], BN_EPS)
         wf, bf_ = ops.fold_bn(P[f"{blk}.double_conv.{cv}.weight"], P[f"{blk}.double_conv.{cv}.bias"], a, b)
-        wp.append(ops.pack_weight(wf, 1, T=(2 * T if li < 2 else 4 * T), f4=True))
+        # the folded weights are temporaries and every chunk of angles runs through them: one named call site per layer
+        wp.append(ops.pack_weight(wf, 1, T=(2 * T if li < 2 else 4 * T), f4=True, site=("sweep", li), shared=True))
         bias.append(bf_)
     uv = GV.dense(u, 1)
     rest = torch.empty(B, Q, 4 * T, device=dev, dtype=torch.float32)

@@ -399,7 +399,7 @@ def pack_many(requests):
     _lib.check(L.nef_pack_weights(descs, len(reqs), _stream()), "nef_pack_weights")
 
 
-def pack_weight(w, G, flip=False, T=None, f4=False, site=None):
+def pack_weight(w, G, flip=False, T=None, f4=False, site=None, shared=False):
     """w [G*Cog, Cig, K] -> packed operand (forward: [G][K][Cig][Cog]; flip: [G][K][Cog][Cig], taps reversed).
     `T`: output length of the conv launch this operand is for; when the Winograd F(2,3) path applies to that launch
     the operand is packed for it (marked with `.nef_wino`) and `conv()` takes that path; `f4` allows the F(4,3) form."""
@@ -415,6 +415,9 @@ def pack_weight(w, G, flip=False, T=None, f4=False, site=None):
         _lib.check(L.nef_pack_weight_h2(_p(w), _p(wp), G, Cog, Cig, K, int(flip), _stream()), "nef_pack_weight_h2")
         wp.nef_wino = 3
         wp.nef_site = (w.data_ptr() if site is None else site, bool(flip))
+        # shared: every launch of a pass through this operand is ONE call site (a loop over chunks of one tensor family, e.g.
+        # the panorama sweep's angle chunks) instead of one site per occurrence
+        wp.nef_shared = bool(shared)
         return wp
     if wino:
         wp = torch.empty(G * _WINO_PLANES[(wino, K)] * Cog * Cig, device=w.device, dtype=torch.float32)
@@ -505,7 +508,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
             # the same data finds the scales it left (bit-identical results)
             occ = st["occ"]
             k = occ[(AMAX_SCOPE, ws, role, xv.B, T_out)] = occ.get((AMAX_SCOPE, ws, role, xv.B, T_out), 0) + 1
-            site = (AMAX_SCOPE, ws, role, xv.B, T_out, k)
+            site = (AMAX_SCOPE, ws, role, xv.B, T_out, 0 if getattr(wp, "nef_shared", False) else k)
         i = _amax_index(st, site, 1)
         a.x_amax_next = st["nxt"].data_ptr() + 4 * i
         if i not in st["ready"] or site is None:      # first launch of the site (or no scope): measure, then run
