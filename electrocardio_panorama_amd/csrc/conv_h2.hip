@@ -594,7 +594,7 @@ int launch_h2(const nef_conv_args& a, hipStream_t st) {
 
 // ---- entry points of this file (hidden: reached through nef_conv_fwd / nef_pack_weights / nef_pack_weight_h2)
 __attribute__((visibility("hidden"))) bool nef_h2_ok(const nef_conv_args* a) {
-    return (a->K == 3 || a->K == 7) && a->Cout_g % 64 == 0 && a->Cin_g % KC == 0 && a->T % 2 == 0 && a->T >= NTO / 2 &&
+    return (a->K == 1 || a->K == 3 || a->K == 7) && a->Cout_g % 64 == 0 && a->Cin_g % KC == 0 && a->T % 2 == 0 && a->T >= NTO / 2 &&
            a->pro_mode >= 0 && a->pro_mode <= 3 && (a->K == 3 || a->pro_mode == 0) && !(a->pro_mode && a->in_scale) &&
            (!(a->pro_mode & 1) || a->Cin_g <= PRO_MAX_CIN);
 }
@@ -609,6 +609,7 @@ __attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, 
     static const bool up_wide = getenv("NEF_H2_UP_TM") && atoi(getenv("NEF_H2_UP_TM")) == 2;
     const bool wide_up = wide && up_wide;
     if (a->K == 7) return wide ? launch_h2<7, 0, 2>(*a, st) : launch_h2<7, 0, 1>(*a, st);
+    if (a->K == 1) return wide ? launch_h2<1, 0, 2>(*a, st) : launch_h2<1, 0, 1>(*a, st);
     switch (a->pro_mode) {
         case 0: return wide ? launch_h2<3, 0, 2>(*a, st) : launch_h2<3, 0, 1>(*a, st);
         case 1: return wide ? launch_h2<3, 1, 2>(*a, st) : launch_h2<3, 1, 1>(*a, st);
@@ -626,7 +627,7 @@ __attribute__((visibility("hidden"))) int nef_h2_pack(const nef_pack_desc* descs
             const nef_pack_desc& d = descs[i0 + i];
             if (!d.w || !d.wp) return NEF_E_NULL;
             const int co_n = d.transpose_flip ? d.Cig : d.Cog, ci_n = d.transpose_flip ? d.Cog : d.Cig;
-            if (d.G <= 0 || co_n % 32 != 0 || ci_n % 16 != 0 || (d.K != 3 && d.K != 7)) return NEF_E_SHAPE;
+            if (d.G <= 0 || co_n % 32 != 0 || ci_n % 16 != 0 || (d.K != 1 && d.K != 3 && d.K != 7)) return NEF_E_SHAPE;
             tab.d[i] = H2PackDesc{d.w, reinterpret_cast<_Float16*>(d.wp), d.G, d.Cog, d.Cig, d.K, d.transpose_flip};
             if (d.G * co_n > rows_max) rows_max = d.G * co_n;
         }

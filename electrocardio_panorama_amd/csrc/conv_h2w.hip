@@ -317,7 +317,7 @@ int launch_h2w(const H2WArgs& a, hipStream_t st) {
 extern "C" {
 
 __attribute__((visibility("hidden"))) bool nef_h2w_ok(int B, int T, int Cig, int Cog, int K, int pro_mode) {
-    return (K == 3 || K == 7) && B > 0 && T >= TT && T % 2 == 0 && Cig % 64 == 0 && Cog % 64 == 0 && pro_mode >= 0 && pro_mode <= 3 &&
+    return (K == 1 || K == 3 || K == 7) && B > 0 && T >= TT && T % 2 == 0 && Cig % 64 == 0 && Cog % 64 == 0 && pro_mode >= 0 && pro_mode <= 3 &&
            (K == 3 || pro_mode == 0);
 }
 
@@ -352,6 +352,7 @@ __attribute__((visibility("hidden"))) int nef_h2w_launch(const float* x, int64_t
     a.teams = G * S;
     a.x_scale = x_scale, a.gy_scale = gy_scale;
     if (K == 7) return launch_h2w<7, 0>(a, st);
+    if (K == 1) return launch_h2w<1, 0>(a, st);
     switch (pro_mode) {
         case 0: return launch_h2w<3, 0>(a, st);
         case 1: return launch_h2w<3, 1>(a, st);

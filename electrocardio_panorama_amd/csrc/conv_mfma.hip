@@ -2384,7 +2384,7 @@ int nef_pack_weights(const nef_pack_desc* descs, int n, nef_stream_t stream) {
         const nef_pack_desc& d = descs[i];
         NEF_REQUIRE(d.w && d.wp, NEF_E_NULL);
         NEF_REQUIRE(d.G > 0 && d.Cog > 0 && d.Cig > 0 && d.K > 0 && d.wino >= 0 && d.wino <= 3 &&
-                        (!d.wino || d.K == 3 || d.K == 7), NEF_E_SHAPE);
+                        (!d.wino || d.K == 3 || d.K == 7 || (d.wino == 3 && d.K == 1)), NEF_E_SHAPE);
         if (d.wino == 3) {
             if (n_h2 == PACK_MULTI_MAX) {
                 if (int e = nef_h2_pack(h2, n_h2, (hipStream_t)stream)) return e;

@@ -68,7 +68,7 @@ def block_fwd(xv, P, prefix, K, Cog, drop):
     h = ops.conv(xv, ops.pack_weight(P[prefix + ".conv1.weight"], G, T=xv.T), Cog, K, relu=True, **drop.args(prefix))
     res_conv = (K == 3 and Cog != xv.Cg)                     # model_nefnet.py:54
     if res_conv:
-        r = ops.conv(xv, ops.pack_weight(P[prefix + ".residual_conv.weight"], G), Cog, 1,
+        r = ops.conv(xv, ops.pack_weight(P[prefix + ".residual_conv.weight"], G, T=xv.T), Cog, 1,
                      bias=P[prefix + ".residual_conv.bias"])
         resv = GV.dense(r, G)
     else:
@@ -91,7 +91,7 @@ def _block_pack_requests(P, prefix, G, T, flip):
     f4 = bool(flip) and _bwd_f4(w1.shape[2])
     reqs = [(P[prefix + ".conv1.weight"], G, flip, T, f4), (P[prefix + ".conv2.weight"], G, flip, T, f4)]
     if w1.shape[2] == 3 and w1.shape[0] // G != w1.shape[1]:          # block_fwd's res_conv condition
-        reqs.append((P[prefix + ".residual_conv.weight"], G, flip, None))
+        reqs.append((P[prefix + ".residual_conv.weight"], G, flip, T))
     return reqs
 
 
@@ -146,9 +146,9 @@ def block_bwd(saved, gy, P, grads, out=None, side=None, pre_gated=False, gate_in
     gc1v = GV.dense(gc1, G)
     grads[prefix + ".conv1.weight"] = side.run(lambda: ops.conv_bwd_weight(xv, gc1v, K, site=P[prefix + ".conv1.weight"].data_ptr()), xv.t, gc1)
     if res_conv:
-        grads[prefix + ".residual_conv.weight"] = side.run(lambda: ops.conv_bwd_weight(xv, g2v, 1), xv.t, g2)
+        grads[prefix + ".residual_conv.weight"] = side.run(lambda: ops.conv_bwd_weight(xv, g2v, 1, site=P[prefix + ".residual_conv.weight"].data_ptr()), xv.t, g2)
         grads[prefix + ".residual_conv.bias"] = side.run(lambda: ops.chan_sum(g2), g2)
-        gres = ops.conv(g2v, ops.pack_weight(P[prefix + ".residual_conv.weight"], G, flip=True), Cig, 1,
+        gres = ops.conv(g2v, ops.pack_weight(P[prefix + ".residual_conv.weight"], G, flip=True, T=xv.T), Cig, 1,
                         role="conv_bwd_data")
         resv = GV.dense(gres, G)
     else:

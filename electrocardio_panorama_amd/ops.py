@@ -226,11 +226,11 @@ _WINO_PLANES = {(1, 3): 4, (1, 7): 10, (2, 3): 6, (2, 7): 13}
 # (128-channel output tiles, 16-channel input chunks, T even and >= 128; K = 7 without an input prologue).
 H2 = os.environ.get("NEF_H2", "1") == "1"
 _H2_DIR = {False: os.environ.get("NEF_H2_FWD", "1") == "1", True: os.environ.get("NEF_H2_BWD", "1") == "1"}     # diagnostics
-_H2_K = os.environ.get("NEF_H2_K", "3,7").split(",")
+_H2_K = os.environ.get("NEF_H2_K", "1,3,7").split(",")
 _H2_64 = os.environ.get("NEF_H2_64", "1") == "1"
-_H2_MIN_T = int(os.environ.get("NEF_H2_MIN_T", "128"))      # shortest sequence the split-fp16 kernels take (256-column tiles)
+_H2_MIN_T = int(os.environ.get("NEF_H2_MIN_T", "0"))      # shortest sequence the split-fp16 kernels take (256-column tiles)
 _H2_W = os.environ.get("NEF_H2_W", "1") == "1"          # weight gradients on the split-fp16 kernel too (csrc/conv_h2w.hip)
-_H2_WK = os.environ.get("NEF_H2_WK", "3,7").split(",")
+_H2_WK = os.environ.get("NEF_H2_WK", "1,3,7").split(",")
 _H2_AMAX = os.environ.get("NEF_H2_AMAX", "sticky")      # diagnostics: "anon" = every launch measures first, "follow" = no stickiness
 
 
@@ -250,7 +250,7 @@ def _h2_fills(G, Cout_g, T_out, tile_t, tile_c):
 
 def h2_ok(K, Cin_g, Cout_g, T_out, pro=0):
     # NEF_H2_64=0 leaves the 64-channel output tiles (conv_h2_kernel<., ., 1>) to the F(4,3) kernels
-    return (H2 and (K == 3 or (K == 7 and not pro)) and T_out % 2 == 0 and T_out >= max(128, _H2_MIN_T) and Cin_g % 16 == 0 and
+    return (H2 and (K == 3 or (K in (1, 7) and not pro)) and T_out % 2 == 0 and T_out >= max(128, _H2_MIN_T) and Cin_g % 16 == 0 and
             Cout_g % (64 if _H2_64 else 128) == 0)
 
 

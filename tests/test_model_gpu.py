@@ -30,17 +30,20 @@ def conv_path(request):
     o._H2_MIN_WGS = 0 if request.param == "h2" else saved
     yield request.param
     o._H2_MIN_WGS = saved
-# Caps on the measured allowance of the fixture-gradient checks (test_train_golden, test_nefnet2_golden).  A step in which the
-# GPU took every ReLU / L1 decision the way the fp64 oracle does (no replayed flip) gets the fixtures' own distance from exact
-# arithmetic only: up to 2e-4 on the flat statistic.  A step WITH replayed flips -- each one asserted to be a tie within fp32
-# round-off and rare by assert_flips_are_ties -- may differ from the fixture by what those ties move when the reference
-# resolved them the other way: up to ~1.3e-3 on the flat gradient of these tiny shapes (tools/debug_tie.py).
-SLACK_CAPS_NO_FLIP = (3e-4, 3e-3)       # (flat, per tensor)
-SLACK_CAPS_TIES = (3e-3, 1e-2)      # largest seen: 1.87e-3 flat (nefnet2_B3_V1_L1000_Q3, 3 ties)
+# Caps on the measured allowance of the fixture-gradient checks (test_train_golden, test_nefnet2_golden).  The allowance is the
+# distance between the decision-replaying fp64 oracle and the fixture (the reference's own fp32 run); it is large (up to ~1.9e-3 on
+# the flat gradient of these tiny shapes, tools/debug_tie.py) exactly when a ReLU / L1 argument sits within fp32 round-off of its
+# switching point and the REFERENCE resolved it differently from exact arithmetic.  Two ways to get there: the HIP path resolved
+# it like the reference (then the oracle replays a flip, which assert_flips_are_ties certifies as a tie), or the HIP path resolved
+# it like exact arithmetic (no flip to replay: the split-fp16 convs land there on nefnet2_B3_V1_L1000_Q3 -- HIP equals the fp64
+# oracle to the fixed bars of oracle_replaying() and the fixture is the one that is 1.7e-3 away).  Either way the HIP path is held to
+# the fixed bars against the oracle FIRST; the fixture comparison then gets the measured distance, capped so that nothing can
+# widen its own bar beyond what a tie moves.
+SLACK_CAPS = (3e-3, 1e-2)       # (flat, per tensor); largest seen: 1.87e-3 flat (nefnet2_B3_V1_L1000_Q3, 3 ties)
 
 
 def slack_caps(dec):
-    return SLACK_CAPS_TIES if dec.total_flips() > 0 else SLACK_CAPS_NO_FLIP
+    return SLACK_CAPS
 
 
 class Cfg(dict):
@@ -235,7 +238,7 @@ def test_train_golden(golden_dir):
             fslack = min(rel(np.concatenate(x64_all), ref_cat), SLACK_CAP_FLAT)
             assert rel(np.concatenate(got_all), ref_cat) < FLAT_TOL + fslack, (
                 name, f"bar {FLAT_TOL} + measured oracle-to-fixture distance {fslack:.2e} (capped at {SLACK_CAP_FLAT})")
-            if dec.total_flips() > 0:
+            if dec.total_flips() > 0 or fslack > 3e-4:
                 import conftest
                 conftest.report(f"{name}: {dec.total_flips()} replayed tie(s); replaying fp64 oracle to fixture {fslack:.2e}, "
                                 f"HIP to fixture {rel(np.concatenate(got_all), ref_cat):.2e} on the flat statistic")
@@ -944,7 +947,7 @@ def test_nefnet2_golden(golden_dir):
             fslack = min(rel(np.concatenate(x64_all), ref_cat), SLACK_CAP_FLAT)
             assert rel(np.concatenate(got_all), ref_cat) < FLAT_TOL + fslack, (
                 name, f"bar {FLAT_TOL} + measured oracle-to-fixture distance {fslack:.2e} (capped at {SLACK_CAP_FLAT})")
-            if dec.total_flips() > 0:
+            if dec.total_flips() > 0 or fslack > 3e-4:
                 import conftest
                 conftest.report(f"{name}: {dec.total_flips()} replayed tie(s); replaying fp64 oracle to fixture {fslack:.2e}, "
                                 f"HIP to fixture {rel(np.concatenate(got_all), ref_cat):.2e} on the flat statistic")

@@ -1065,7 +1065,7 @@ def test_conv_h2_is_fp32_class(conv_algo):
         pytest.skip("split-fp16 path")
     o = ops()
     from electrocardio_panorama_amd.ops import GV
-    for K, G, Cig, Cog, B, T in [(7, 3, 128, 128, 3, 1250), (3, 1, 256, 128, 2, 500), (3, 1, 64, 64, 3, 514)]:
+    for K, G, Cig, Cog, B, T in [(7, 3, 128, 128, 3, 1250), (3, 1, 256, 128, 2, 500), (3, 1, 64, 64, 3, 514), (1, 3, 64, 128, 3, 1250)]:
         x = F.relu(rnd(B, G * Cig, T, seed=301))
         w = rnd(G * Cog, Cig, K, seed=302, scale=0.05)
         ref64 = F.conv1d(x.double(), w.double(), None, 1, K // 2, 1, G)
@@ -1165,3 +1165,47 @@ def test_conv_h2_full_size_every_lane_arrives(conv_algo, Cig, Cog, T, mode):
         y1 = o.conv(GV.dense(x, 1), wp, Cog, 3, bias=bias, pro=pro)
         assert int(((y1 - y0).abs() > 1e-3).sum()) == 0
         del y1
+
+
+@pytest.mark.parametrize("K,G,Cig,Cog,B,T,mode,insc", [
+    (7, 3, 128, 128, 2, 300, 0, False), (3, 1, 64, 128, 3, 130, 0, True), (3, 1, 128, 64, 6, 500, 1, False),
+    (3, 2, 128, 128, 6, 256, 2, False), (3, 1, 128, 64, 6, 504, 3, False), (7, 1, 64, 64, 2, 1250, 0, False),
+    (1, 3, 64, 128, 3, 1250, 0, False), (3, 1, 64, 64, 3, 66, 0, False)])
+def test_conv_bwd_weight_h2(conv_algo, K, G, Cig, Cog, B, T, mode, insc):
+    """csrc/conv_h2w.hip -- the weight gradient on exact fp16 splits of both operands -- against fp64 autograd, with a gradient
+    operand of magnitude 1e-4, every input prologue (BatchNorm affine + ReLU, x2 upsampling, both) and the channel scale: within
+    3x of torch's own fp32 result (measured: below it), and closer to fp64 than the fp32 transposed-Winograd path; deterministic."""
+    if conv_algo != "h2":
+        pytest.skip("split-fp16 path")
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    Tin = T // 2 if mode & 2 else T
+    x, gy = rnd(B, G * Cig, Tin, seed=331), rnd(B, G * Cog, T, seed=332) * 1e-4
+    pa, pb, sc = rnd(3, G * Cig, seed=333).abs() + 0.5, rnd(3, G * Cig, seed=334) * 0.2, rnd(B, G * Cig, seed=335)
+    def inputs(dt):
+        xin = x.to(dt)
+        if mode & 1:
+            Bp = B // 3
+            xin = F.relu(xin * pa.to(dt).repeat_interleave(Bp, 0)[:, :, None] + pb.to(dt).repeat_interleave(Bp, 0)[:, :, None])
+        if mode & 2:
+            xin = F.interpolate(xin, scale_factor=2, mode="linear", align_corners=False)
+        if insc:
+            xin = xin * sc.to(dt)[:, :, None]
+        return xin
+    refs = {}
+    for dt in (torch.float64, torch.float32):
+        w = torch.zeros(G * Cog, Cig, K, dtype=dt, requires_grad=True)
+        F.conv1d(inputs(dt), w, None, 1, K // 2, 1, G).backward(gy.to(dt))
+        refs[dt] = w.grad
+    pro = (mode, g(pa), g(pb), B // 3) if mode & 1 else ((mode, None, None, 1) if mode else None)
+    kw = dict(in_scale=(g(sc), G * Cig, Cig) if insc else None, pro=pro)
+    assert o.h2w_ok(K, Cig, Cog, T, mode, insc)
+    xv, gv = GV.dense(g(x), G), GV.dense(g(gy), G)
+    got = o.conv_bwd_weight(xv, gv, K, **kw)                      # default path = the split-fp16 kernel; no scope: it measures first
+    e32 = rel(refs[torch.float32], refs[torch.float64])
+    e = rel(got.double().cpu(), refs[torch.float64])
+    assert e < 3 * e32 + 1e-8, (e, e32)
+    assert torch.equal(got, o.conv_bwd_weight(xv, gv, K, **kw))
+    if K != 1:
+        e_w = rel(o.conv_bwd_weight(xv, gv, K, h2=False, **kw).double().cpu(), refs[torch.float64])
+        assert e < e_w * 1.2 + 1e-8, (e, e_w)
