@@ -12,11 +12,17 @@
 // registers: even shifts are register renames, odd shifts four v_alignbit_b32.  K = 7: 12 LDS reads and 32 alignbits feed 21
 // matrix instructions.
 //
-// One workgroup = 64 output x 64 input channels of one group, all K taps: 4 waves as 2 (co) x 2 (ci), a wave owns K
-// accumulator tiles of 32 x 32.  The (sample, 64-column tile) sequence is split S ways; every workgroup streams its share
-// through two LDS buffers (registers carry tile i+1 while tile i is multiplied: one barrier per tile) and leaves a partial
-// sum in ws[split][g][k][co][ci], which conv_bwd_weight_reduce (conv_mfma.hip) adds up in a fixed order.  The workgroups that
-// share a (group, split) -- the co x ci tiles of the layer -- run on ONE XCD, so gy and X come from HBM once per split.
+// Tiles.  The kernel is vector-issue-bound, not matrix-bound (every workgroup splits the fp32 rows it stages into fp16 pairs
+// itself, and cuts K tap fragments out of every window).  Two tile forms are built; the smaller one is the default (h2w_form):
+//   MCO = 2 (Cout_g % 128 == 0, NEF_H2W_MCO=2 only): 128 output x 64 input channels, 512 threads = 8 waves, one workgroup per CU.  A wave owns
+//           64 x 32 channels (two row tiles share every B fragment it builds).  K = 7: the two wave groups take taps 0..3 and
+//           4..6 (SPLIT 1: 8 accumulator tiles per wave); K = 3 / 1: they take the even and the odd 16-column chunks of a tile
+//           and leave TWO partial sums (SPLIT 2: the reduce kernel adds 2 S of them).
+//   MCO = 1 (Cout_g % 64 == 0): 64 x 64 channels, 256 threads, all taps in every wave, two workgroups per CU (round-4 first form).
+// The (sample, 64-column tile) sequence is split S ways; every workgroup streams its share through two LDS buffers (registers
+// carry tile i+1 while tile i is multiplied: one barrier per tile) and leaves its partial sums in ws[split][g][k][co][ci],
+// which conv_bwd_weight_reduce (conv_mfma.hip) adds up in a fixed order.  The workgroups that share a (group, split) -- the
+// co x ci tiles of the layer -- run on ONE XCD, so gy and X come from HBM once per split.
 //
 // Both operands are scaled by exact powers of two derived from the magnitudes their call site measured before (x_amax,
 // gy_amax; ops.py keeps them per site as for the forward launches); the product of the two scales is divided out of the
@@ -41,8 +47,9 @@ constexpr int TT = 64;                 // reduction columns per staged tile
 constexpr int GP = TT * 2 + 8;         // gy row pitch in bytes (136 = 8 x 17)
 constexpr int XW = TT + 8;             // staged X columns per row: t0 - 4 .. t0 + TT + 3
 constexpr int XP = XW * 2 + 8;         // X row pitch in bytes (152 = 8 x 19)
-constexpr int GY_PLANE = 64 * GP, X_PLANE = 64 * XP;
-constexpr int BUF = 2 * GY_PLANE + 2 * X_PLANE;      // one stage: gy hi | gy lo | X hi | X lo
+constexpr int X_PLANE = 64 * XP;
+constexpr int gy_plane(int MCO) { return 64 * MCO * GP; }
+constexpr int buf_bytes(int MCO) { return 2 * gy_plane(MCO) + 2 * X_PLANE; }      // one stage: gy hi | gy lo | X hi | X lo
 
 struct H2WArgs {
     const float* x;
@@ -85,12 +92,73 @@ __device__ __forceinline__ float scale_from(const float* amax, float fallback) {
     return s;
 }
 
-template <int K, int PRO>
-__global__ __launch_bounds__(256, 2) void conv_h2w_kernel(H2WArgs a) {
-    constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
+// 16 reduction columns of one tile: taps [K0, K1) of this wave's MCO x (K1 - K0) accumulator tiles
+template <int K, int K0, int K1, int MCO, int KA>
+__device__ __forceinline__ void h2w_chunk(const unsigned char* ga, const unsigned char* xa, int c, f32x16 (&acc)[MCO][KA]) {
     constexpr int PAD = (K - 1) / 2;
-    constexpr int NGQ = 64 * (TT / 2) / 256;              // gy column pairs per thread and tile (8)
-    constexpr int NXQ = (64 * (XW / 2) + 255) / 256;      // X column pairs per thread and tile (9)
+    constexpr int GY_PLANE = gy_plane(MCO);
+    // A: gy[co][16 c + 8 hi .. + 7] of the wave's MCO row tiles, both planes
+    h16x8 fah[MCO], fal[MCO];
+#pragma unroll
+    for (int i = 0; i < MCO; ++i) {
+        unsigned ah[4], al[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const u32x2 vh = *reinterpret_cast<const u32x2*>(ga + i * 32 * GP + c * 32 + 8 * j);
+            const u32x2 vl = *reinterpret_cast<const u32x2*>(ga + i * 32 * GP + GY_PLANE + c * 32 + 8 * j);
+            ah[2 * j] = vh[0], ah[2 * j + 1] = vh[1];
+            al[2 * j] = vl[0], al[2 * j + 1] = vl[1];
+        }
+        fah[i] = __builtin_bit_cast(h16x8, u32x4{ah[0], ah[1], ah[2], ah[3]});
+        fal[i] = __builtin_bit_cast(h16x8, u32x4{al[0], al[1], al[2], al[3]});
+    }
+    // B window: X columns 16 c + 8 hi .. + 15 of the staged row (= t0 + 16 c + 8 hi - 4 .. + 11)
+    unsigned wh[8], wl[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32x2 vh = *reinterpret_cast<const u32x2*>(xa + c * 32 + 8 * j);
+        const u32x2 vl = *reinterpret_cast<const u32x2*>(xa + X_PLANE + c * 32 + 8 * j);
+        wh[2 * j] = vh[0], wh[2 * j + 1] = vh[1];
+        wl[2 * j] = vl[0], wl[2 * j + 1] = vl[1];
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+        const int e0 = 4 + k - PAD;            // first window element of this tap's fragment (compile time after unrolling)
+        unsigned bh[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if ((e0 & 1) == 0) {
+                bh[j] = wh[e0 / 2 + j];
+                bl[j] = wl[e0 / 2 + j];
+            } else {
+                bh[j] = __builtin_amdgcn_alignbit(wh[(e0 + 1) / 2 + j], wh[(e0 - 1) / 2 + j], 16);
+                bl[j] = __builtin_amdgcn_alignbit(wl[(e0 + 1) / 2 + j], wl[(e0 - 1) / 2 + j], 16);
+            }
+        }
+        const h16x8 fbh = __builtin_bit_cast(h16x8, u32x4{bh[0], bh[1], bh[2], bh[3]});
+        const h16x8 fbl = __builtin_bit_cast(h16x8, u32x4{bl[0], bl[1], bl[2], bl[3]});
+#pragma unroll
+        for (int i = 0; i < MCO; ++i) acc[i][k - K0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh, acc[i][k - K0], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MCO; ++i) acc[i][k - K0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbl, acc[i][k - K0], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MCO; ++i) acc[i][k - K0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i], fbh, acc[i][k - K0], 0, 0, 0);
+    }
+}
+
+// SPLIT: 0 = 256 threads, every wave all taps and chunks; 1 = 512 threads, the two wave groups split the taps (K = 7: 4 + 3);
+// 2 = 512 threads, the two wave groups take alternate 16-column chunks and leave two partial sums (split index 2 sp + group)
+template <int K, int PRO, int MCO, int SPLIT>
+__global__ __launch_bounds__(SPLIT ? 512 : 256, SPLIT ? 1 : 2) void conv_h2w_kernel(H2WArgs a) {
+    constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
+    constexpr int NT = SPLIT ? 512 : 256;
+    constexpr int ROWS_G = 64 * MCO;
+    constexpr int GY_PLANE = gy_plane(MCO), BUF = buf_bytes(MCO);
+    constexpr int KA = SPLIT == 1 ? (K + 1) / 2 : K;      // accumulator tiles per row tile and wave
+    constexpr int NGQ = ROWS_G * (TT / 2) / NT;           // gy column pairs per thread and tile
+    constexpr int NXQ = (64 * (XW / 2) + NT - 1) / NT;    // X column pairs per thread and tile
+    static_assert(SPLIT == 0 || MCO == 2, "the 512-thread forms are the 128-channel tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
 
     // team = (group, split); its members = the co x ci tiles.  Block ids go round-robin over the 8 XCDs: the members of a team
@@ -106,7 +174,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2w_kernel(H2WArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lo = lane & 31, hi = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int wm = wave_u >> 1, wn = wave_u & 1;
+    const int wt = wave_u >> 2;                        // wave group (0 with 256 threads)
+    const int wm = (wave_u >> 1) & 1, wn = wave_u & 1;
 
     const int64_t per = ((int64_t)a.n_tiles + a.S - 1) / a.S;
     const int n_lo = (int)(per * sp);
@@ -116,11 +185,13 @@ __global__ __launch_bounds__(256, 2) void conv_h2w_kernel(H2WArgs a) {
     const float sx = scale_from(a.x_amax, a.x_scale), sg = scale_from(a.gy_amax, a.gy_scale);
     float amax_x = 0.f, amax_g = 0.f;
 
-    f32x16 acc[K];
+    f32x16 acc[MCO][KA];
 #pragma unroll
-    for (int k = 0; k < K; ++k)
+    for (int i = 0; i < MCO; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+        for (int k = 0; k < KA; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
 
     // ---- staging registers: this thread's column pairs of the tile in flight
     f32x2 gq[NGQ];
@@ -130,17 +201,17 @@ __global__ __launch_bounds__(256, 2) void conv_h2w_kernel(H2WArgs a) {
     {                                                                                                               \
         const int b_ = (N) / a.tps, t0_ = ((N) % a.tps) * TT;                                                       \
         const bool on_ = (N) < n_hi;                                                                                \
-        const __amdgpu_buffer_rsrc_t grs = nef_rsrc_n(a.gy + (int64_t)b_ * a.gy_bs + (int64_t)g * a.gy_gs + (int64_t)(mt * 64) * T, \
+        const __amdgpu_buffer_rsrc_t grs = nef_rsrc_n(a.gy + (int64_t)b_ * a.gy_bs + (int64_t)g * a.gy_gs + (int64_t)(mt * ROWS_G) * T, \
                                                       on_ ? 0x7FFFFFFCu : 0u);                                      \
         _Pragma("unroll") for (int q = 0; q < NGQ; ++q) {                                                           \
-            const int p = (int)threadIdx.x + 256 * q;                                                               \
+            const int p = (int)threadIdx.x + NT * q;                                                                \
             const int row = p >> 5, t = t0_ + 2 * (p & 31);                                                         \
             gq[q] = nef_buf_f32x2(grs, t < T ? (unsigned)((row * T + t) * 4) : NEF_OOB, 0);                         \
         }                                                                                                           \
         const __amdgpu_buffer_rsrc_t xrs = nef_rsrc_n(a.x + (int64_t)b_ * a.x_bs + (int64_t)g * a.x_gs + (int64_t)(ct * 64) * Tin, \
                                                       on_ ? 0x7FFFFFFCu : 0u);                                      \
         _Pragma("unroll") for (int q = 0; q < NXQ; ++q) {                                                           \
-            const int p = (int)threadIdx.x + 256 * q;                                                               \
+            const int p = (int)threadIdx.x + NT * q;                                                                \
             const int row = p / (XW / 2), t = t0_ - 4 + 2 * (p % (XW / 2));                                         \
             const bool ok = p < 64 * (XW / 2) && t >= 0 && t < T;                                                   \
             if constexpr (UP) {                                                                                     \
@@ -161,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2w_kernel(H2WArgs a) {
     {                                                                                                               \
         const int b_ = (N) / a.tps, t0_ = ((N) % a.tps) * TT;                                                       \
         _Pragma("unroll") for (int q = 0; q < NGQ; ++q) {                                                           \
-            const int p = (int)threadIdx.x + 256 * q;                                                               \
+            const int p = (int)threadIdx.x + NT * q;                                                                \
             const int row = p >> 5, c2 = p & 31;                                                                    \
             amax_g = fmaxf(amax_g, fmaxf(fabsf(gq[q][0]), fabsf(gq[q][1])));                                        \
             unsigned h_, l_;                                                                                        \
@@ -171,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2w_kernel(H2WArgs a) {
             *reinterpret_cast<unsigned*>(p_ + GY_PLANE) = l_;                                                       \
         }                                                                                                           \
         _Pragma("unroll") for (int q = 0; q < NXQ; ++q) {                                                           \
-            const int p = (int)threadIdx.x + 256 * q;                                                               \
+            const int p = (int)threadIdx.x + NT * q;                                                                \
             const int row = p / (XW / 2), c2 = p % (XW / 2), t = t0_ - 4 + 2 * c2;                                  \
             if (p < 64 * (XW / 2)) {                                                                                \
                 const int ch = g * a.Cig + ct * 64 + row;                                                           \
@@ -217,53 +288,23 @@ __global__ __launch_bounds__(256, 2) void conv_h2w_kernel(H2WArgs a) {
     for (int n = n_lo; n < n_hi; ++n) {
         const unsigned char* const bufp = smem_w + ((n - n_lo) & 1) * BUF;
         NEF_W_ISSUE(n + 1)
-        const unsigned char* const ga = bufp + (wm * 32 + lo) * GP + hi * 16;
+        const unsigned char* const ga = bufp + (wm * MCO * 32 + lo) * GP + hi * 16;
         const unsigned char* const xa = bufp + 2 * GY_PLANE + (wn * 32 + lo) * XP + hi * 16;
-#pragma unroll
-        for (int c = 0; c < TT / 16; ++c) {
-            // A: gy[co][16 c + 8 hi .. + 7], both planes
-            unsigned ah[4], al[4];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const u32x2 vh = *reinterpret_cast<const u32x2*>(ga + c * 32 + 8 * j);
-                const u32x2 vl = *reinterpret_cast<const u32x2*>(ga + GY_PLANE + c * 32 + 8 * j);
-                ah[2 * j] = vh[0], ah[2 * j + 1] = vh[1];
-                al[2 * j] = vl[0], al[2 * j + 1] = vl[1];
+        if constexpr (SPLIT == 1) {
+            // (chunk loops NOT unrolled: with both tap groups' code in one kernel the unrolled form spilled 90 registers)
+            if (wt == 0) {
+#pragma unroll 1
+                for (int c = 0; c < TT / 16; ++c) h2w_chunk<K, 0, KA, MCO, KA>(ga, xa, c, acc);
+            } else {
+#pragma unroll 1
+                for (int c = 0; c < TT / 16; ++c) h2w_chunk<K, KA, K, MCO, KA>(ga, xa, c, acc);
             }
-            // B window: X columns 16 c + 8 hi .. + 15 of the staged row (= t0 + 16 c + 8 hi - 4 .. + 11)
-            unsigned wh[8], wl[8];
+        } else if constexpr (SPLIT == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const u32x2 vh = *reinterpret_cast<const u32x2*>(xa + c * 32 + 8 * j);
-                const u32x2 vl = *reinterpret_cast<const u32x2*>(xa + X_PLANE + c * 32 + 8 * j);
-                wh[2 * j] = vh[0], wh[2 * j + 1] = vh[1];
-                wl[2 * j] = vl[0], wl[2 * j + 1] = vl[1];
-            }
-            const h16x8 fah = __builtin_bit_cast(h16x8, u32x4{ah[0], ah[1], ah[2], ah[3]});
-            const h16x8 fal = __builtin_bit_cast(h16x8, u32x4{al[0], al[1], al[2], al[3]});
-            __builtin_amdgcn_s_setprio(1);
+            for (int cc = 0; cc < TT / 32; ++cc) h2w_chunk<K, 0, K, MCO, KA>(ga, xa, 2 * cc + wt, acc);
+        } else {
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int e0 = 4 + k - PAD;            // first window element of this tap's fragment (compile time after unrolling)
-                unsigned bh[4], bl[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if ((e0 & 1) == 0) {
-                        bh[j] = wh[e0 / 2 + j];
-                        bl[j] = wl[e0 / 2 + j];
-                    } else {
-                        bh[j] = __builtin_amdgcn_alignbit(wh[(e0 + 1) / 2 + j], wh[(e0 - 1) / 2 + j], 16);
-                        bl[j] = __builtin_amdgcn_alignbit(wl[(e0 + 1) / 2 + j], wl[(e0 - 1) / 2 + j], 16);
-                    }
-                }
-                const h16x8 fbh = __builtin_bit_cast(h16x8, u32x4{bh[0], bh[1], bh[2], bh[3]});
-                const h16x8 fbl = __builtin_bit_cast(h16x8, u32x4{bl[0], bl[1], bl[2], bl[3]});
-                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbh, acc[k], 0, 0, 0);
-                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbl, acc[k], 0, 0, 0);
-                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, fbh, acc[k], 0, 0, 0);
-            }
+            for (int c = 0; c < TT / 16; ++c) h2w_chunk<K, 0, K, MCO, KA>(ga, xa, c, acc);
         }
         if (n + 1 < n_hi) NEF_W_STORE(n + 1, smem_w + ((n + 1 - n_lo) & 1) * BUF)
         __syncthreads();
@@ -288,28 +329,48 @@ __global__ __launch_bounds__(256, 2) void conv_h2w_kernel(H2WArgs a) {
         }
     }
 
-    // partial sums: ws[split][g][k][co][ci]; a lane's column is ci = wn 32 + lo, its rows co = wm 32 + 4 hi + (r & 3) + 8 (r >> 2)
+    // partial sums: ws[split][g][k][co][ci]; a lane's column is ci = wn 32 + lo, its rows co = (wm MCO + i) 32 + 4 hi + (r & 3) + 8 (r >> 2)
     const float ds = 1.f / (sx * sg);
-    const int co0 = mt * 64 + wm * 32 + 4 * hi, ci = ct * 64 + wn * 32 + lo;
-    float* const wsp = a.ws + ((int64_t)sp * a.G + g) * K * a.Cog * a.Cig;
+    const int ci = ct * 64 + wn * 32 + lo;
+    const int spw = SPLIT == 2 ? 2 * sp + wt : sp;
+    const int k0 = SPLIT == 1 ? wt * KA : 0;
+    float* const wsp = a.ws + ((int64_t)spw * a.G + g) * K * a.Cog * a.Cig;
 #pragma unroll
-    for (int k = 0; k < K; ++k)
+    for (int i = 0; i < MCO; ++i) {
+        const int co0 = mt * ROWS_G + (wm * MCO + i) * 32 + 4 * hi;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            wsp[((int64_t)k * a.Cog + co0 + (r & 3) + 8 * (r >> 2)) * a.Cig + ci] = acc[k][r] * ds;
+        for (int k = 0; k < KA; ++k) {
+            if (k0 + k < K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    wsp[((int64_t)(k0 + k) * a.Cog + co0 + (r & 3) + 8 * (r >> 2)) * a.Cig + ci] = acc[i][k][r] * ds;
+            }
+        }
+    }
 }
 
-template <int K, int PRO>
+template <int K, int PRO, int MCO, int SPLIT>
 int launch_h2w(const H2WArgs& a, hipStream_t st) {
-    constexpr size_t lds = 2 * BUF;
+    constexpr size_t lds = 2 * buf_bytes(MCO);
     static unsigned long long lds_set = 0;
-    if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_h2w_kernel<K, PRO>), lds, &lds_set)) return e;
+    if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_h2w_kernel<K, PRO, MCO, SPLIT>), lds, &lds_set)) return e;
     const int members = a.m_tiles * a.c_tiles;
     const int teams8 = (a.teams + 7) / 8 * 8;
     const int64_t blocks = (int64_t)teams8 * members;
     if (blocks <= 0 || blocks > 0x7fffffff) return NEF_E_SHAPE;
-    hipLaunchKernelGGL((conv_h2w_kernel<K, PRO>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_h2w_kernel<K, PRO, MCO, SPLIT>), dim3((unsigned)blocks), dim3(SPLIT ? 512 : 256), lds, st, a);
     return nef_launch_status();
+}
+
+// tile form for a shape: MCO (row tiles of 64 channels per workgroup) and SPLIT (see the kernel)
+struct H2WForm { int mco, split; };
+H2WForm h2w_form(int Cog, int K) {
+    // Measured (tools/_h2w_check.py, ms, 64 x 64 tile -> 128 x 64 tile): decoder 128->128 T=2500 0.93 -> 0.85, first decoder layer
+    // 1.21 -> 1.11, but encoder-side K = 3 (384 channels, T = 1250) 0.54 -> 0.60 and K = 7 0.87 -> 3.3 (the two tap groups' code in
+    // one kernel spills 90 registers): a wash over the step, so the 64 x 64 tile stays the default; NEF_H2W_MCO=2 takes the large one
+    static const bool large = getenv("NEF_H2W_MCO") && atoi(getenv("NEF_H2W_MCO")) == 2;
+    if (Cog % 128 != 0 || !large) return {1, 0};
+    return {2, K == 7 ? 1 : 2};
 }
 
 }  // namespace
@@ -321,14 +382,18 @@ __attribute__((visibility("hidden"))) bool nef_h2w_ok(int B, int T, int Cig, int
            (K == 3 || pro_mode == 0);
 }
 
-// splits for this shape (the partial-sum workspace is S * G * K * Cog * Cig floats)
-__attribute__((visibility("hidden"))) int nef_h2w_splits(int B, int T, int G, int Cig, int Cog) {
+// team splits of the (sample, tile) sequence, and partial sums per (g, k, co, ci) the launch leaves (= splits, or twice that
+// when the wave groups keep separate sums)
+__attribute__((visibility("hidden"))) int nef_h2w_splits(int B, int T, int G, int Cig, int Cog, int K, int* partials) {
+    const H2WForm f = h2w_form(Cog, K);
     const int tps = (T + TT - 1) / TT;
     const int64_t n_tiles = (int64_t)B * tps;
-    const int units = G * (Cog / 64) * (Cig / 64);
-    int S = (2 * 2 * nef_cu_count() + units - 1) / units;      // two rounds of two workgroups per CU
+    const int units = G * (Cog / (64 * f.mco)) * (Cig / 64);
+    const int resident = f.split ? 1 : 2;                              // workgroups per CU
+    int S = (2 * resident * nef_cu_count() + units - 1) / units;       // two rounds of resident workgroups
     if (S > n_tiles) S = (int)n_tiles;
     if (S < 1) S = 1;
+    if (partials) *partials = S * (f.split == 2 ? 2 : 1);
     return S;
 }
 
@@ -341,6 +406,7 @@ __attribute__((visibility("hidden"))) int nef_h2w_launch(const float* x, int64_t
     if (!nef_h2w_ok(B, T, Cig, Cog, K, pro_mode)) return NEF_E_SHAPE;
     if ((pro_mode & 1) && !(pro_a && pro_b && pro_Bp > 0)) return NEF_E_NULL;
     if ((x_amax_next == nullptr) != (gy_amax_next == nullptr)) return NEF_E_NULL;
+    const H2WForm f = h2w_form(Cog, K);
     H2WArgs a;
     a.x = x, a.gy = gy, a.in_scale = in_scale, a.pro_a = pro_a, a.pro_b = pro_b, a.ws = ws;
     a.x_amax = x_amax, a.gy_amax = gy_amax, a.x_amax_next = x_amax_next, a.gy_amax_next = gy_amax_next, a.clamped = clamped;
@@ -348,16 +414,26 @@ __attribute__((visibility("hidden"))) int nef_h2w_launch(const float* x, int64_t
     a.B = B, a.T = T, a.G = G, a.Cig = Cig, a.Cog = Cog, a.pro_Bp = pro_Bp > 0 ? pro_Bp : 1, a.S = S;
     a.tps = (T + TT - 1) / TT;
     a.n_tiles = B * a.tps;
-    a.m_tiles = Cog / 64, a.c_tiles = Cig / 64;
+    a.m_tiles = Cog / (64 * f.mco), a.c_tiles = Cig / 64;
     a.teams = G * S;
     a.x_scale = x_scale, a.gy_scale = gy_scale;
-    if (K == 7) return launch_h2w<7, 0>(a, st);
-    if (K == 1) return launch_h2w<1, 0>(a, st);
+    if (f.mco == 2) {
+        if (K == 7) return launch_h2w<7, 0, 2, 1>(a, st);
+        if (K == 1) return launch_h2w<1, 0, 2, 2>(a, st);
+        switch (pro_mode) {
+            case 0: return launch_h2w<3, 0, 2, 2>(a, st);
+            case 1: return launch_h2w<3, 1, 2, 2>(a, st);
+            case 2: return launch_h2w<3, 2, 2, 2>(a, st);
+            default: return launch_h2w<3, 3, 2, 2>(a, st);
+        }
+    }
+    if (K == 7) return launch_h2w<7, 0, 1, 0>(a, st);
+    if (K == 1) return launch_h2w<1, 0, 1, 0>(a, st);
     switch (pro_mode) {
-        case 0: return launch_h2w<3, 0>(a, st);
-        case 1: return launch_h2w<3, 1>(a, st);
-        case 2: return launch_h2w<3, 2>(a, st);
-        default: return launch_h2w<3, 3>(a, st);
+        case 0: return launch_h2w<3, 0, 1, 0>(a, st);
+        case 1: return launch_h2w<3, 1, 1, 0>(a, st);
+        case 2: return launch_h2w<3, 2, 1, 0>(a, st);
+        default: return launch_h2w<3, 3, 1, 0>(a, st);
     }
 }
 
