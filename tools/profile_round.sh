@@ -11,10 +11,10 @@ O=gpurun_out/$R
 # the summarisers divide by THIS number (round 2 passed 6 while the run did 7 steps: its per-step totals were 7/6 too high)
 STEPS=4
 rm -rf $O && mkdir -p $O
-NEF_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $O/one -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary > $O/one.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/two -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary > $O/two.log 2>&1
-NEF_SIDE_STREAM=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o t -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary > $O/fetch.log 2>&1
-NEF_SIDE_STREAM=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o t -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary > $O/write.log 2>&1
+NEF_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $O/one -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --no-graph > $O/one.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/two -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --no-graph > $O/two.log 2>&1
+NEF_SIDE_STREAM=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o t -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --no-graph > $O/fetch.log 2>&1
+NEF_SIDE_STREAM=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o t -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --no-graph > $O/write.log 2>&1
 python tools/rocprof_summary.py $(find $O/one -name "*results.db" | head -1) $O/${R}_kernel_stats_serialized.md $STEPS 1 > /dev/null
 python tools/rocprof_summary.py $(find $O/two -name "*results.db" | head -1) $O/${R}_kernel_stats.md $STEPS 1 > /dev/null
 python tools/pmc_table.py $(find $O/fetch -name "*results.db" | head -1) $(find $O/write -name "*results.db" | head -1) $O/${R}_pmc_traffic.md $O/traffic.json > /dev/null 2> $O/pmc.err
