@@ -1170,7 +1170,11 @@ def test_conv_h2_full_size_every_lane_arrives(conv_algo, Cig, Cog, T, mode):
 @pytest.mark.parametrize("K,G,Cig,Cog,B,T,mode,insc", [
     (7, 3, 128, 128, 2, 300, 0, False), (3, 1, 64, 128, 3, 130, 0, True), (3, 1, 128, 64, 6, 500, 1, False),
     (3, 2, 128, 128, 6, 256, 2, False), (3, 1, 128, 64, 6, 504, 3, False), (7, 1, 64, 64, 2, 1250, 0, False),
-    (1, 3, 64, 128, 3, 1250, 0, False), (3, 1, 64, 64, 3, 66, 0, False)])
+    (1, 3, 64, 128, 3, 1250, 0, False), (3, 1, 64, 64, 3, 66, 0, False),
+    # the producer / consumer form (Cout_g % 128 == 0): every prologue, T % 4 == 2, one-tile rows, shares of zero and one tile
+    (3, 1, 128, 128, 6, 500, 1, False), (3, 1, 128, 128, 6, 1004, 3, False), (3, 1, 128, 128, 3, 190, 2, False),
+    (7, 1, 128, 128, 3, 1250, 0, False), (3, 1, 64, 256, 1, 64, 0, False), (3, 2, 128, 128, 3, 1250, 0, True),
+    (7, 2, 64, 128, 1, 66, 0, False)])
 def test_conv_bwd_weight_h2(conv_algo, K, G, Cig, Cog, B, T, mode, insc):
     """csrc/conv_h2w.hip -- the weight gradient on exact fp16 splits of both operands -- against fp64 autograd, with a gradient
     operand of magnitude 1e-4, every input prologue (BatchNorm affine + ReLU, x2 upsampling, both) and the channel scale: within
