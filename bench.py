@@ -412,13 +412,17 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath) and (V, B, L) == (3, 256, 5000):     # PMC pass was taken at configs[1] only
                 tj = json.load(open(tpath))
-                kn = ("conv_h2w_kernel<%d, 0>" % dom_tag[1]) if dom_tag[0] == "conv_bwd_weight" else ("conv_h2_kernel<%d, 0, 2>" % dom_tag[1])
-                traffic = tj.get("by_kernel", {}).get(kn) if ops.H2 else None
+                # kernel names of the trace: conv_h2w2_kernel<K, PRO, ...> (producer / consumer weight gradient; conv_h2w_kernel = its
+                # first form) and conv_h2_kernel<K, PRO, TM>
+                pre = (("conv_h2w2_kernel<%d, 0" % dom_tag[1], "conv_h2w_kernel<%d, 0" % dom_tag[1]) if dom_tag[0] == "conv_bwd_weight"
+                       else ("conv_h2_kernel<%d, 0, 2>" % dom_tag[1],))
+                hits = [v for pfx in pre for k_, v in tj.get("by_kernel", {}).items() if k_.startswith(pfx)]
+                traffic = hits[0] if (hits and ops.H2) else None
                 # NOT measured by this run: replayed from the committed rocprofv3 --pmc pass (separate run, as the
                 # counters cannot be collected together with timing)
                 traffic_source = ("replayed from " + tj.get("source", "profiles/traffic.json")) if traffic else None
             roof.update(traffic=traffic, traffic_source=traffic_source, kernel_tag="/".join(str(x) for x in dom_tag),
-                        kernel=("conv_h2w_kernel (weight gradient on exact fp16 splits of both operands)" if dom_tag[0] == "conv_bwd_weight" and roof["executed_fp16_mfma_flops"] > 0
+                        kernel=("conv_h2w2_kernel (weight gradient on exact fp16 splits of both operands, producer / consumer waves)" if dom_tag[0] == "conv_bwd_weight" and roof["executed_fp16_mfma_flops"] > 0
                                 else KNAME[3] if roof["executed_fp16_mfma_flops"] > 0 else "fp32 conv kernel") +
                                (", launches of the timed region" if use is not serial[dom_tag] else ", launches of the single-stream breakdown steps"),
                         launches=len(use), ms_per_step_serialized=round(sum(serial[dom_tag]) / max(extra_steps, 1), 3),

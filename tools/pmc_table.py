@@ -13,7 +13,7 @@ import sqlite3
 import sys
 
 fetch_db, write_db, out_md, out_json = sys.argv[1:5]
-DOM = sys.argv[5] if len(sys.argv) > 5 else "conv_h2w_kernel<7"
+DOM = sys.argv[5] if len(sys.argv) > 5 else "conv_h2w2_kernel<7"
 
 
 def short(name):
@@ -43,7 +43,7 @@ if not (0.40 < cal_ratio < 0.62) or not (0.85 < cal_w < 1.15):
     sys.exit(f"pmc_table: calibration off: FETCH_SIZE x 1024 = {cal_ratio:.3f} of the known read bytes (expected 0.5), "
              f"WRITE_SIZE x 1024 = {cal_w:.3f} of the known write bytes (expected 1.0)")
 # dominant kernel (bench.py's `roofline`): the kernel with the largest summed duration in the step -- since round 4 the K = 7
-# weight gradient conv_h2w_kernel<7, 0>; every launch of a kernel name is averaged
+# weight gradient conv_h2w2_kernel<7, 0, ...>; every launch of a kernel name is averaged
 k7 = [(f, w) for (n, g, f), (_, _, w) in zip(F, W) if n.startswith(DOM)]
 if not k7:
     sys.exit(f"pmc_table: no launch of {DOM} in the trace")
@@ -57,8 +57,8 @@ with open(out_md, "w") as fh:
              "the write.  Fabric-side counters: hits in the memory-side\n"
              "cache (MALL) are counted like HBM reads, so these are upper bounds on DRAM traffic.\n\n")
     fh.write(f"Dominant kernel `{DOM}...>`: {len(k7)} launches, {all_bytes/1e9:.3f} GB per launch on average "
-             "(algorithmic: one read of each operand row, 0.984 GB for the K = 7 weight gradient -- each of the 2 x 2 channel "
-             "tiles of a (group, split) re-reads its operand rows through the L2 of one XCD).\n\n")
+             "(algorithmic: one read of each operand row, 0.984 GB for the K = 7 weight gradient -- the two 64-channel "
+             "column tiles of a (group, split) both read the 128 gradient rows, through the L2 of one XCD).\n\n")
     fh.write("| kernel | launches | FETCH_SIZE avg (min..max) KB | WRITE_SIZE avg (min..max) KB | corrected bytes/launch (GB) |\n"
              "|---|---:|---:|---:|---:|\n")
     order = sorted(stats.items(), key=lambda kv: -sum((2 * f + w) for f, w in kv[1]))
