@@ -61,6 +61,18 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));
 }
 
+// the same split with the power-of-two scale s folded into the conversions: hi = fp16(x s), lo = fp16(x s - hi), each ONE
+// mixed-precision FMA per element (x s is exact, x s - hi is exact in fp32: bit-identical to split2(x0 * s, x1 * s));
+// |x| is clamped at lim = 65000 / s first
+__device__ __forceinline__ void split2s(float x0, float x1, float s, float lim, unsigned& h, unsigned& l) {
+    x0 = __builtin_amdgcn_fmed3f(x0, -lim, lim);
+    x1 = __builtin_amdgcn_fmed3f(x1, -lim, lim);
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Weight operand.  Logical operand of the launch: W[co][ci][kk] (forward: w[g*Cog+co][ci][kk]; transpose_flip: the
 // backward-data operand, W[co' = ci][ci' = co][kk] = w[g*Cog+ci'][co'][K-1-kk]).  Packed as fp16 fragments
@@ -210,6 +222,7 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
             xs_ = ldexpf(1.f, 9 - e_);
         }
     }
+    const float xlim_ = 65000.f / xs_;
     float amax_ = 0.f;
     const int pro_row0 = AFF ? (b0 / a.pro_Bp) * a.G * Cig + g * Cig : 0;
 
@@ -256,12 +269,12 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
                 if constexpr (PRO != 0) v = xok[it] ? v : 0.f;                                                      \
                 v *= sa_[rr];                                                                                       \
                 amax_ = fmaxf(amax_, fabsf(v));                                                                     \
-                v_[rr] = v * xs_;                                                                                   \
+                v_[rr] = v;                                                                                         \
             }                                                                                                       \
             const int r = lane + 64 * it;                                                                           \
             unsigned h0_, l0_, h1_, l1_;                                                                            \
-            split2(v_[0], v_[1], h0_, l0_);                                                                         \
-            split2(v_[2], v_[3], h1_, l1_);                                                                         \
+            split2s(v_[0], v_[1], xs_, xlim_, h0_, l0_);                                                            \
+            split2s(v_[2], v_[3], xs_, xlim_, h1_, l1_);                                                            \
             const u32x2 hv = {h0_, h1_}, lv = {l0_, l1_};                                                           \
             if (r < XROW) {                                                                                         \
                 unsigned char* p_ = (BUFP) + (((r & 3) * P4 + (r >> 2)) * 32 + 8 * wave);                           \

@@ -71,16 +71,21 @@ struct H2WArgs {
     float x_scale, gy_scale;
 };
 
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& l) {
-    x0 = __builtin_amdgcn_fmed3f(x0, -65000.f, 65000.f);
-    x1 = __builtin_amdgcn_fmed3f(x1, -65000.f, 65000.f);
-    // h = (fp16(x0), fp16(x1));  r = x - h in ONE mixed-precision FMA per element (h * -1 + x, the fp16 source read in place:
-    // bit-identical to x - float(h), two instructions fewer per element than convert-back + subtract);  l = (fp16(r0), fp16(r1))
-    float r0, r1;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x1));
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));
+
+// (x0, x1) * s -> fp16 pair h, residual pair l; |x| is clamped at lim = 65000 / s first
+__device__ __forceinline__ void split_pair_s(float x0, float x1, float s, float lim, unsigned& h, unsigned& l) {
+    x0 = __builtin_amdgcn_fmed3f(x0, -lim, lim);
+    x1 = __builtin_amdgcn_fmed3f(x1, -lim, lim);
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
+}
+// one value: the low halves of h and l (the high halves are not defined)
+__device__ __forceinline__ void split_one_s(float x0, float s, float lim, unsigned& h, unsigned& l) {
+    x0 = __builtin_amdgcn_fmed3f(x0, -lim, lim);
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x0), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
 }
 
 __device__ __forceinline__ float scale_from(const float* amax, float fallback) {
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, SPLIT ? 1 : 2) void conv_h2w_ker
     if (n_hi > a.n_tiles) n_hi = a.n_tiles;
 
     const float sx = scale_from(a.x_amax, a.x_scale), sg = scale_from(a.gy_amax, a.gy_scale);
+    const float limx = 65000.f / sx, limg = 65000.f / sg;
     float amax_x = 0.f, amax_g = 0.f;
 
     f32x16 acc[MCO][KA];
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, SPLIT ? 1 : 2) void conv_h2w_ker
             const int row = p >> 5, c2 = p & 31;                                                                    \
             amax_g = fmaxf(amax_g, fmaxf(fabsf(gq[q][0]), fabsf(gq[q][1])));                                        \
             unsigned h_, l_;                                                                                        \
-            split2(gq[q][0] * sg, gq[q][1] * sg, h_, l_);                                                           \
+            split_pair_s(gq[q][0], gq[q][1], sg, limg, h_, l_);                                                           \
             unsigned char* p_ = (BUFP) + row * GP + c2 * 4;                                                         \
             *reinterpret_cast<unsigned*>(p_) = h_;                                                                  \
             *reinterpret_cast<unsigned*>(p_ + GY_PLANE) = l_;                                                       \
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, SPLIT ? 1 : 2) void conv_h2w_ker
                 if (t < 0 || t >= T) v0 = v1 = 0.f;      /* zero padding comes after the prologue */                \
                 amax_x = fmaxf(amax_x, fmaxf(fabsf(v0), fabsf(v1)));                                                \
                 unsigned h_, l_;                                                                                    \
-                split2(v0 * sx, v1 * sx, h_, l_);                                                                   \
+                split_pair_s(v0, v1, sx, limx, h_, l_);                                                                   \
                 unsigned char* p_ = (BUFP) + 2 * GY_PLANE + row * XP + c2 * 4;                                      \
                 *reinterpret_cast<unsigned*>(p_) = h_;                                                              \
                 *reinterpret_cast<unsigned*>(p_ + X_PLANE) = l_;                                                    \
@@ -406,22 +412,6 @@ H2WForm h2w_form(int Cog, int K) {
 #endif
 typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// (x0, x1) * s -> fp16 pair h, residual pair l; |x| is clamped at lim = 65000 / s first
-__device__ __forceinline__ void split_pair_s(float x0, float x1, float s, float lim, unsigned& h, unsigned& l) {
-    x0 = __builtin_amdgcn_fmed3f(x0, -lim, lim);
-    x1 = __builtin_amdgcn_fmed3f(x1, -lim, lim);
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x0), "v"(s));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x1), "v"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
-}
-// one value: the low halves of h and l (the high halves are not defined)
-__device__ __forceinline__ void split_one_s(float x0, float s, float lim, unsigned& h, unsigned& l) {
-    x0 = __builtin_amdgcn_fmed3f(x0, -lim, lim);
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x0), "v"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
-}
 
 __device__ __forceinline__ unsigned extent_from(int64_t end_bytes, int64_t off_elems, bool on) {
     int64_t r = end_bytes - off_elems * 4;
