@@ -20,11 +20,16 @@ BN_EPS, BN_MOM = 1e-5, 0.1
 # NEF_FUSE_L2=0: third decoder conv on a materialised u2 = up2(relu(bn(c2))) instead of the (affine + ReLU, x2) prologue on c2.
 # Round 2 measured the prologue form slower (60.2 against 58.8 ms/step: the register-staged weight gradient paid for the
 # prologue per staged element); since the LDS-DMA weight gradient interpolates while it forms its fragments it is the
-# faster one: 47.85 -> 47.36 ms/step, and the 1.97 GB tensor is never written.
+# faster one: 47.85 -> 47.36 ms/step, and the 1.97 GB tensor is never written.  On the split-fp16 kernels of round 4 the two
+# forms are equal within the run-to-run noise (three alternating runs on one box: 31.2 - 31.7 against 31.5 - 31.9 ms/step,
+# bit-identical loss): the prologue stays.
 _FUSE_L2 = os.environ.get("NEF_FUSE_L2", "1") == "1"
 
 # NEF_FUSE_STATS=0: BatchNorm statistics by a pass over the conv output (nef_bn_train_stats) instead of the conv epilogue
 _FUSE_STATS = os.environ.get("NEF_FUSE_STATS", "1") == "1"
+# NEF_BNB_UP=0: the BatchNorm-backward sums behind a x2 upsampling by the pass (bn_relu_bwd_up reduces them itself) instead of the
+# backward-data conv's epilogue
+_BNB_UP = os.environ.get("NEF_BNB_UP", "1") == "1"
 
 _BWD_F4 = os.environ.get("NEF_BWD_F4", "1")
 
@@ -316,7 +321,7 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
                 cb, mb, ib, ab, bb = saved[li - 1][1:6]
                 Tg = gc.shape[2]
                 plain = not up_after and cb.shape[2] == Tg
-                upv = bool(up_after) and 2 * cb.shape[2] == Tg and Tg % 8 == 0 and Tg >= 16     # the g_is_up case below
+                upv = _BNB_UP and bool(up_after) and 2 * cb.shape[2] == Tg and Tg % 8 == 0 and Tg >= 16     # the g_is_up case below
                 if (plain or upv) and mb is not None:
                     g_slots = ops.conv_stats_buffer(wpf, cb.shape[0], 1, x.shape[1], Tg, gc.device)
                     if g_slots is not None:
