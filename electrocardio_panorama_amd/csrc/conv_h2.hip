@@ -38,6 +38,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));      // a 16-byte global load at dword alignment
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -517,14 +518,13 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
                 const float* xp = a.bnb_x + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * Lh;
                 const int j2 = live[0] ? (t >> 1) : 0;
                 const int im1 = j2 > 0 ? j2 - 1 : 0, i1 = j2 + 1 < Lh ? j2 + 1 : Lh - 1, ip2 = j2 + 2 < Lh ? j2 + 2 : Lh - 1;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int row = NEF_ROW(q);
-                    const int er = erow0 + row;
+                // the four half-resolution samples j2 - 1 .. j2 + 2 of a row: one 16-byte load away from the row ends (every lane
+                // but the first and the last of a row), four clamped scalar loads there
+                const bool interior = j2 >= 1 && j2 + 2 < Lh;
+                auto sums = [&](int q, float xa, float xb_, float xc, float xd) __attribute__((always_inline)) {
+                    const int er = erow0 + NEF_ROW(q);
                     const float af = El[3 * MT + er], bf = El[4 * MT + er];
                     const float mf = El[MT + er], is = El[2 * MT + er];
-                    const float* xr = xp + (int64_t)row * Lh;
-                    const float xa = xr[im1], xb_ = xr[j2], xc = xr[i1], xd = xr[ip2];
                     const float ma = fmaf(xa, af, bf) > 0.f ? 1.f : 0.f, mb = fmaf(xb_, af, bf) > 0.f ? 1.f : 0.f;
                     const float mc = fmaf(xc, af, bf) > 0.f ? 1.f : 0.f, md = fmaf(xd, af, bf) > 0.f ? 1.f : 0.f;
                     const float ha = ma * ((xa - mf) * is), hb = mb * ((xb_ - mf) * is);
@@ -535,6 +535,19 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
                                           fmaf(g2, fmaf(0.75f, mc, 0.25f * mb), g3 * fmaf(0.75f, mc, 0.25f * md));
                     sv[2 * (q + 8 * h) + 1] = fmaf(g0, fmaf(0.75f, hb, 0.25f * ha), g1 * fmaf(0.75f, hb, 0.25f * hc)) +
                                               fmaf(g2, fmaf(0.75f, hc, 0.25f * hb), g3 * fmaf(0.75f, hc, 0.25f * hd));
+                };
+                if (interior) {
+                    f32x4_a4 xv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) xv[q] = *reinterpret_cast<const f32x4_a4*>(xp + (int64_t)NEF_ROW(q) * Lh + (j2 - 1));
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sums(q, xv[q][0], xv[q][1], xv[q][2], xv[q][3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float* xr = xp + (int64_t)NEF_ROW(q) * Lh;
+                        sums(q, xr[im1], xr[j2], xr[i1], xr[ip2]);
+                    }
                 }
             } else if (a.bnb_slots) {
                 const float* xp = a.bnb_x + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T;
