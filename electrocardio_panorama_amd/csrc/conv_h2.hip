@@ -136,6 +136,9 @@ __global__ __launch_bounds__(256) void pack_h2_kernel(H2PackTable tab) {
 // PRO as in conv_fwd_kernel (bit0: BatchNorm affine + ReLU of the producing layer, bit1: x2 linear upsampling of a
 // half-resolution input), applied to the fp32 values before the split.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef NEF_H2_T
+#define NEF_H2_T 0      // timing-only builds: 1 = no activation loads in the loop, 2 = no matrix instructions, 4 = no epilogue
+#endif
 #ifndef NEF_H2_OCC1
 #define NEF_H2_OCC1 3      // workgroups per CU the 64-channel tile is compiled for (168 VGPRs); the x2-upsampling prologue needs 2
 #endif
@@ -324,7 +327,9 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
         const unsigned char* const xb = Xl + (st & 1) * (2 * PLANE) + fb_lane;
         const bool more = st + 1 < nst;
         const __amdgpu_buffer_rsrc_t xrs_n = nef_rsrc_n(xbase, more ? 0x7FFFFFFCu : 0u);      // branch-free: see conv_wino4_kernel
+#if !(NEF_H2_T & 1)
         NEF_H2X_ISSUE((st + 1) * KC, xrs_n)
+#endif
         h16x8 fb[5][2];              // ring over s: [slot][plane]
 #define NEF_H2B_LOAD(S)                                                                                              \
     {                                                                                                               \
@@ -345,6 +350,7 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
             __builtin_amdgcn_s_setprio(1);      // scheduling fence (see conv_wino_kernel)
             // product-major order: the three MFMAs that accumulate into one tile are 4 TM instructions apart (never back to
             // back on the same accumulator)
+#if !(NEF_H2_T & 2)
             const int s_ = kk & 1;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -361,6 +367,7 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s_][2 * i + 1], fb[(kk + j) % 5][0], acc[i][j], 0, 0, 0);
+#endif
         }
 #undef NEF_H2B_LOAD
         // K odd: the set toggles K times per stage, so stage st + 1 finds its tap 0 in set (K & 1) ^ ... -- keep it simple:
@@ -388,6 +395,14 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
             if (b_ > __atomic_load_n(p_, __ATOMIC_RELAXED)) atomicMax(p_, b_);
         }
     }
+#if NEF_H2_T & 4
+    {
+        float z_ = 0.f;
+        for (int i = 0; i < TM; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) z_ += acc[i][j][r];
+        if (z_ == 12345.678f) a.y[0] = z_;
+        return;
+    }
+#endif
     // ---- epilogue: descale, then bias / residual / ReLU / dropout / gate on the four adjacent outputs a lane owns per row
     const int64_t ctot = (int64_t)a.G * Cog;
     const int t = t0 + wn * 128 + 4 * lo;
