@@ -142,7 +142,10 @@ __global__ __launch_bounds__(256) void pack_h2_kernel(H2PackTable tab) {
 #ifndef NEF_H2_OCC1
 #define NEF_H2_OCC1 3      // workgroups per CU the 64-channel tile is compiled for (168 VGPRs); the x2-upsampling prologue needs 2
 #endif
-template <int K, int PRO, int TM>
+// PACK (short rows, 8 <= T <= 64, T % 4 == 0): a tile is `tps` SAMPLES laid end to end at a pitch of T + 4 positions -- the four
+// positions between two samples are staged as zeros (the zero padding of both neighbours) and their outputs are dropped; a lane's
+// four adjacent outputs lie inside one sample or inside one gap.  No prologue, channel scale or statistics in this mode.
+template <int K, int PRO, int TM, bool PACK = false>
 __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2) void conv_h2_kernel(nef_conv_args a, int tps, int n_tiles, int m_tiles) {
     constexpr int MT = 64 * TM;                    // output channels per workgroup: 2 (co) x 2 (t) waves of TM x 4 tiles
     constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
@@ -163,7 +166,10 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
     const int mt = gm % m_tiles;
     const int g = gm / m_tiles;
     int b0, t0;
-    {      // tiles of one sample 8 workgroup ids apart: same XCD, back to back (see conv_fwd_kernel)
+    if constexpr (PACK) {
+        b0 = tile * tps;
+        t0 = 0;
+    } else {      // tiles of one sample 8 workgroup ids apart: same XCD, back to back (see conv_fwd_kernel)
         const int full = (n_tiles / (8 * tps)) * (8 * tps);
         if (tile < full) {
             const int grp = tile / (8 * tps), r = tile % (8 * tps);
@@ -200,7 +206,11 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
         const int t = t0 + r - PAD;
         xok[it] = (r < XROW) && (t >= 0) && (t < T);
         lam[it] = 0.f;
-        if constexpr (UP) {
+        if constexpr (PACK) {
+            const int v = r - PAD, vb = v >= 0 ? v / (T + 4) : 0, tl = v - vb * (T + 4);
+            xok[it] = (r < XROW) && v >= 0 && tl < T && vb < tps && b0 + vb < a.B;
+            xvo[it][0] = xok[it] ? (unsigned)((vb * (int)a.x_bs + tl) * 4) : NEF_OOB;
+        } else if constexpr (UP) {
             float src = 0.5f * ((float)t + 0.5f) - 0.5f;
             if (src < 0.f) src = 0.f;
             int i0 = (int)src;
@@ -405,11 +415,21 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
 #endif
     // ---- epilogue: descale, then bias / residual / ReLU / dropout / gate on the four adjacent outputs a lane owns per row
     const int64_t ctot = (int64_t)a.G * Cog;
-    const int t = t0 + wn * 128 + 4 * lo;
-    const bool inb = b0 < a.B;
+    int t = t0 + wn * 128 + 4 * lo;
+    int bq = b0;                                         // the sample of this lane's outputs
+    bool inb = b0 < a.B;
+    if constexpr (PACK) {
+        const int vp = wn * 128 + 4 * lo, vb = vp / (T + 4);
+        t = vp - vb * (T + 4);
+        bq = b0 + vb;
+        inb = vb < tps && bq < a.B && t < T;
+    }
+    const int vbq = bq - b0;
+    // this lane's sample offset in dense [b][c][t] tensors (elements); lanes without an output stay on the tile's first sample
+    const int vb_ct = (PACK && inb) ? vbq * (int)(ctot * T) : 0;
     const bool live[2] = {inb && t < T, inb && t + 2 < T};
     const int ts[2] = {live[0] ? t : 0, live[1] ? t + 2 : 0};
-    const bool ragged = t0 + NTO > T;                    // workgroup-uniform
+    const bool ragged = PACK ? false : t0 + NTO > T;     // workgroup-uniform
     float* const slot_out = a.bnb_slots ? a.bnb_slots : a.stats;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -438,7 +458,7 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
     if (!ragged) {                                                                                                  \
         const __amdgpu_buffer_rsrc_t rs_ =                                                                          \
             nef_rsrc((PTR) + (int64_t)b0 * (BS) + (int64_t)g * (GS) + (int64_t)(m0 + wm * (32 * TM) + i * 32) * T);        \
-        const unsigned vo_ = inb ? (unsigned)((4 * hi * T + t) * 4) : NEF_OOB;                                      \
+        const unsigned vo_ = inb ? (unsigned)((4 * hi * T + t) * 4) + (PACK ? (unsigned)(vbq * (int)(BS) * 4) : 0u) : NEF_OOB; \
         _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                             \
             const f32x4 t4 = nef_buf_f32x4(rs_, vo_, (unsigned)(NEF_ROW(q) * T * 4));                               \
             DST[q][0] = t4[0]; DST[q][1] = t4[1]; DST[q][2] = t4[2]; DST[q][3] = t4[3];                             \
@@ -470,7 +490,7 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {        // dropout works on the two output pairs (t, t+1), (t+2, t+3)
                 if (a.mask) {
-                    const uint8_t* mp = a.mask + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T + ts[pr];
+                    const uint8_t* mp = a.mask + ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T + ts[pr] + vb_ct;
                     unsigned short t8[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) t8[q] = *reinterpret_cast<const unsigned short*>(mp + (int64_t)NEF_ROW(q) * T);
@@ -480,7 +500,7 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
                         y[q][2 * pr + 1] *= (float)(t8[q] >> 8) * a.drop_scale;
                     }
                 } else if (a.drop_p > 0.f) {
-                    const int64_t d0 = ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T + ts[pr];
+                    const int64_t d0 = ((int64_t)b0 * ctot + (int64_t)g * Cog + cobase) * T + ts[pr] + vb_ct;
                     const uint64_t seed = a.rng_seed + (a.rng_seed_dev ? a.rng_seed_dev[0] : 0ull);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -517,7 +537,7 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
             {
                 const __amdgpu_buffer_rsrc_t yrs =
                     nef_rsrc(a.y + (int64_t)b0 * a.y_bs + (int64_t)g * a.y_gs + (int64_t)(m0 + wm * (32 * TM) + i * 32) * T);
-                const unsigned yvo = live[1] ? (unsigned)((4 * hi * T + t) * 4) : NEF_OOB;
+                const unsigned yvo = live[1] ? (unsigned)((4 * hi * T + t) * 4) + (PACK ? (unsigned)(vbq * (int)a.y_bs * 4) : 0u) : NEF_OOB;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     f32x4 o;
@@ -614,7 +634,7 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
     }
 }
 
-template <int K, int PRO, int TM>
+template <int K, int PRO, int TM, bool PACK = false>
 int launch_h2(const nef_conv_args& a, hipStream_t st) {
     constexpr int MT = 64 * TM;
     constexpr int XROW = NTO + K - 1;
@@ -622,21 +642,32 @@ int launch_h2(const nef_conv_args& a, hipStream_t st) {
     constexpr int PLANE = 4 * P4 * 32;
     constexpr size_t lds = (size_t)4 * PLANE + (((PRO & 1) ? 2 * PRO_MAX_CIN : 0) + 6 * MT) * sizeof(float);
     static unsigned long long lds_set = 0;
-    if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_h2_kernel<K, PRO, TM>), lds, &lds_set)) return e;
-    const int tps = (a.T + NTO - 1) / NTO;
-    const int n_tiles = a.B * tps;
+    if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_h2_kernel<K, PRO, TM, PACK>), lds, &lds_set)) return e;
+    // PACK: `tps` = samples per tile (pitch T + 4; the last sample needs no gap behind it)
+    const int tps = PACK ? (NTO + 4) / (a.T + 4) : (a.T + NTO - 1) / NTO;
+    const int n_tiles = PACK ? (a.B + tps - 1) / tps : a.B * tps;
     const int m_tiles = a.Cout_g / MT;
     const int64_t blocks = (int64_t)a.G * m_tiles * n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffff) return NEF_E_SHAPE;
-    hipLaunchKernelGGL((conv_h2_kernel<K, PRO, TM>), dim3((unsigned)blocks), dim3(256), lds, st, a, tps, n_tiles, m_tiles);
+    hipLaunchKernelGGL((conv_h2_kernel<K, PRO, TM, PACK>), dim3((unsigned)blocks), dim3(256), lds, st, a, tps, n_tiles, m_tiles);
     return nef_launch_status();
 }
 
 }  // namespace
 
 // ---- entry points of this file (hidden: reached through nef_conv_fwd / nef_pack_weights / nef_pack_weight_h2)
+// short rows (PACK): several samples per tile; plain launches only (no prologue, channel scale, statistics or BatchNorm-backward sums)
+static bool h2_pack_shape(const nef_conv_args* a) {
+    if (!(a->T >= 8 && a->T <= 64 && a->T % 4 == 0 && (a->K == 1 || a->K == 3))) return false;
+    const int64_t spt = (NTO + 4) / (a->T + 4);
+    const int64_t lim = 0x7fffffff / 4;
+    return a->pro_mode == 0 && !a->in_scale && !a->stats && !a->bnb_slots && spt * a->x_bs < lim && spt * a->y_bs < lim &&
+           (!a->res || spt * a->res_bs < lim) && (!a->gate || spt * a->gate_bs < lim);
+}
+
 __attribute__((visibility("hidden"))) bool nef_h2_ok(const nef_conv_args* a) {
-    return (a->K == 1 || a->K == 3 || a->K == 7) && a->Cout_g % 64 == 0 && a->Cin_g % KC == 0 && a->T % 2 == 0 && a->T >= NTO / 2 &&
+    return (a->K == 1 || a->K == 3 || a->K == 7) && a->Cout_g % 64 == 0 && a->Cin_g % KC == 0 && a->T % 2 == 0 &&
+           (a->T >= NTO / 2 || h2_pack_shape(a)) &&
            a->pro_mode >= 0 && a->pro_mode <= 3 && (a->K == 3 || a->pro_mode == 0) && !(a->pro_mode && a->in_scale) &&
            (!(a->pro_mode & 1) || a->Cin_g <= PRO_MAX_CIN);
 }
@@ -650,6 +681,8 @@ __attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, 
     // registers of the 128-channel tile that spills (250..330 bytes per lane), so those launches take the 64-channel tile
     static const bool up_wide = getenv("NEF_H2_UP_TM") && atoi(getenv("NEF_H2_UP_TM")) == 2;
     const bool wide_up = wide && up_wide;
+    if (a->T < NTO / 2)      // short rows: the 64-channel tile (the 128-channel form spills 185 registers with the per-lane sample offsets)
+        return a->K == 1 ? launch_h2<1, 0, 1, true>(*a, st) : launch_h2<3, 0, 1, true>(*a, st);
     if (a->K == 7) return wide ? launch_h2<7, 0, 2>(*a, st) : launch_h2<7, 0, 1>(*a, st);
     if (a->K == 1) return wide ? launch_h2<1, 0, 2>(*a, st) : launch_h2<1, 0, 1>(*a, st);
     switch (a->pro_mode) {

@@ -239,18 +239,29 @@ _H2_AMAX = os.environ.get("NEF_H2_AMAX", "sticky")      # diagnostics: "anon" = 
 # batch 32 x L 512: 3.11 ms per captured step with them, 2.72 without).  The engine announces the batch of the pass it is about
 # to run (BATCH_HINT); without a hint (bare ops calls) the shape rules alone decide.
 BATCH_HINT = None
+_H2_PACK = os.environ.get("NEF_H2_PACK", "1") == "1"
 _H2_MIN_WGS = int(os.environ.get("NEF_H2_MIN_WGS", "256"))
+
+
+def _h2_packed(K, T_out, pro=0):
+    """Short rows (8 <= T <= 64, T % 4 == 0) of plain K = 1 / K = 3 launches: several samples per tile of conv_h2_kernel
+    (csrc/conv_h2.hip, PACK).  NEF_H2_PACK=0: they stay on the fp32 kernels."""
+    return _H2_PACK and K in (1, 3) and not pro and 8 <= T_out <= 64 and T_out % 4 == 0
 
 
 def _h2_fills(G, Cout_g, T_out, tile_t, tile_c):
     if BATCH_HINT is None:
         return True
+    if T_out < 128:       # packed short rows: (256 + 4) // (T + 4) samples per tile, 64-channel tiles
+        spt = (256 + 4) // (T_out + 4)
+        return G * ((Cout_g + 63) // 64) * ((BATCH_HINT + spt - 1) // spt) >= _H2_MIN_WGS
     return G * ((Cout_g + tile_c - 1) // tile_c) * BATCH_HINT * ((T_out + tile_t - 1) // tile_t) >= _H2_MIN_WGS
 
 
 def h2_ok(K, Cin_g, Cout_g, T_out, pro=0):
     # NEF_H2_64=0 leaves the 64-channel output tiles (conv_h2_kernel<., ., 1>) to the F(4,3) kernels
-    return (H2 and (K == 3 or (K in (1, 7) and not pro)) and T_out % 2 == 0 and T_out >= max(128, _H2_MIN_T) and Cin_g % 16 == 0 and
+    return (H2 and (K == 3 or (K in (1, 7) and not pro)) and T_out % 2 == 0 and
+            (T_out >= max(128, _H2_MIN_T) or (_h2_packed(K, T_out, pro) and _H2_64)) and Cin_g % 16 == 0 and
             Cout_g % (64 if _H2_64 else 128) == 0)
 
 
@@ -434,7 +445,7 @@ def conv_stats_buffer(wp, B, G, Cog, T_out, device):
     """(slots tensor, slots per sample) for conv(..., stats=...) -- or None when the conv would not run on the F(4,3)
     kernel, whose epilogue is the one that leaves the BatchNorm slot sums."""
     wino = int(getattr(wp, "nef_wino", 0))
-    if wino not in (2, 3):
+    if wino not in (2, 3) or (wino == 3 and T_out < 128):      # (packed short rows leave no statistics)
         return None
     # a slot = one wave's 128 columns; the split-fp16 kernel tiles a sample in 256-column workgroups (2 slots each)
     nslot = 2 * ((T_out + 255) // 256) if wino == 3 else _lib.load().nef_conv_stats_slots(T_out, Cog)

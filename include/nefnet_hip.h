@@ -129,8 +129,9 @@ typedef struct nef_conv_args {
                               nef_pack_weight_wino4 -- Winograd F(4,3) resp. F(4,4) + F(4,3): 1/2 resp. 13/28 of the multiplies.  Needs T even, T >= 128
                               (Cout_g % 128 == 0) or T >= 256 (Cout_g % 64 == 0), Cin_g % 16 == 0; K == 7: pro_mode 0.
                               3: packed by nef_pack_weight_h2 -- the direct convolution on exact fp16 splits of both operands
-                              (K == 3 or 7, Cout_g % 64 == 0, Cin_g % 16 == 0, T even and >= 128; every epilogue option
-                              incl. stats / bnb_slots; K == 7: pro_mode 0). */
+                              (K == 1, 3 or 7, Cout_g % 64 == 0, Cin_g % 16 == 0, T even and >= 128; every epilogue option
+                              incl. stats / bnb_slots; K == 7: pro_mode 0).  Short rows, 8 <= T <= 64 with T % 4 == 0
+                              (K == 1 or 3): several samples per tile; then no prologue, in_scale, stats or bnb_slots. */
     float* stats;          /* NULL, or (wino == 2 only) the epilogue also leaves, per output channel and per 128-column slot
                               of a sample, the sum and the sum of squares of the final outputs of that slot:
                               stats[(ch * B * nslot + b * nslot + slot) * 2 + {0,1}], ch = g*Cout_g + co, nslot =

@@ -1089,6 +1089,51 @@ def test_conv_h2_is_fp32_class(conv_algo):
         assert rel(gx_raw.double().cpu(), gref64) > 1e-4
 
 
+@pytest.mark.parametrize("K,G,Cig,Cog,B,T", [(3, 21, 128, 128, 30, 16), (3, 3, 64, 128, 5, 32), (1, 21, 64, 128, 27, 16), (3, 2, 128, 64, 14, 8),
+                                             (3, 1, 128, 128, 3, 64), (3, 7, 128, 128, 13, 20)])
+def test_conv_h2_packed_short_rows(conv_algo, K, G, Cig, Cog, B, T):
+    """Short rows (8 <= T <= 64, T % 4 == 0) on the split-fp16 kernel: several samples per 256-position tile at a pitch of T + 4,
+    zeros staged between them (conv_h2_kernel, PACK).  Forward with bias + residual + ReLU + a dropout mask, and backward-data with
+    a ReLU gate, against fp64 -- including a last tile that is not full (B not a multiple of the samples per tile) and exact
+    zeros wherever the reference has them; the measured-scale launch and fp32-class accuracy as for the long rows."""
+    if conv_algo != "h2":
+        pytest.skip("split-fp16 path")
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    x = F.relu(rnd(B, G * Cig, T, seed=341))
+    w = rnd(G * Cog, Cig, K, seed=342, scale=0.05)
+    bias, res = rnd(G * Cog, seed=343), rnd(B, G * Cog, T, seed=344)
+    mask = (torch.rand(B, G * Cog, T, generator=torch.Generator().manual_seed(345)) > 0.2).to(torch.uint8)
+    wp = o.pack_weight(g(w), G, T=T, f4=True)
+    assert wp.nef_wino == 3
+    def ref(dt):
+        y = F.relu(F.conv1d(x.to(dt), w.to(dt), bias.to(dt), 1, K // 2, 1, G) + res.to(dt))
+        return y * mask.to(dt) * 1.25
+    r64 = ref(torch.float64)
+    e32 = rel(ref(torch.float32), r64)
+    y = o.conv(GV.dense(g(x), G), wp, Cog, K, bias=g(bias), res=GV.dense(g(res), G), relu=True, mask=g(mask), drop_scale=1.25)
+    e = rel(y.double().cpu(), r64)
+    assert e < 3 * e32 + 1e-8, (e, e32)
+    assert torch.equal((y.cpu() == 0), (r64 == 0))                       # the reference's exact zeros (ReLU, dropped elements)
+    assert torch.equal(y, o.conv(GV.dense(g(x), G), wp, Cog, K, bias=g(bias), res=GV.dense(g(res), G), relu=True, mask=g(mask), drop_scale=1.25))
+    # backward-data through the same layer, gated by the ReLU of its input
+    gy = rnd(B, G * Cog, T, seed=346) * 1e-5
+    gref = torch.nn.grad.conv1d_input(x.shape, w.double(), gy.double(), padding=K // 2, groups=G) * (x.double() > 0)
+    g32 = rel(torch.nn.grad.conv1d_input(x.shape, w, gy, padding=K // 2, groups=G) * (x > 0), gref)
+    wf = o.pack_weight(g(w), G, flip=True, T=T, f4=True)
+    assert wf.nef_wino == 3
+    gx = o.conv(GV.dense(g(gy), G), wf, Cig, K, gate=GV.dense(g(x), G), gate_scale=1.0, role="conv_bwd_data")
+    assert rel(gx.double().cpu(), gref) < 3 * g32 + 1e-8
+    # against the fp32 kernels the step used before, element by element
+    o.H2 = False
+    try:
+        y0 = o.conv(GV.dense(g(x), G), o.pack_weight(g(w), G, T=T, f4=True), Cog, K, bias=g(bias), res=GV.dense(g(res), G), relu=True,
+                    mask=g(mask), drop_scale=1.25)
+    finally:
+        o.H2 = True
+    assert float((y - y0).abs().max()) < 1e-4 * float(y0.abs().max())
+
+
 def test_conv_h2_sites_are_sticky_and_scoped(conv_algo):
     """Inside a scope (ops.amax_scope, what Model_nefnet sets) a call site measures once, then keeps its power-of-two operand
     scale while the operand stays within 64x of what it measured (bit-identical repeats, also after a 10x change of magnitude
