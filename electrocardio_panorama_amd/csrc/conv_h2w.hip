@@ -6,23 +6,20 @@
 //
 // The reduction index t is the k dimension of the matrix instruction (16 columns per instruction): a lane of the A fragment
 // holds gy[co][t0 + 8 hi .. + 7], a lane of the B fragment X[ci][t0 + 8 hi + k - PAD .. + 7] -- for every tap the SAME row
-// shifted by one column.  The tiles are staged in their natural [channel][t] order (fp16 hi / lo planes, row pitch an odd
-// multiple of 8 bytes: the 8-byte fragment reads of 32 rows are conflict-free); a lane reads the 16-column window
-// X[ci][t0 + 8 hi - 4 .. + 11] once per 16 columns (four ds_read_b64 per plane) and cuts each tap's fragment out of it in
-// registers: even shifts are register renames, odd shifts four v_alignbit_b32.  K = 7: 12 LDS reads and 32 alignbits feed 21
-// matrix instructions.
+// shifted by one column.  The tiles are staged in their natural [channel][t] order as fp16 hi / lo planes.  The (sample,
+// 64-column tile) sequence is split S ways (nef_h2w_splits: as many workgroups as are resident at once, never one more); every
+// workgroup streams its share through two LDS stages and leaves its partial sums in ws[split][g][k][co][ci], which
+// conv_bwd_weight_reduce (conv_mfma.hip) adds up in a fixed order.  The workgroups that share a (group, split) -- the co x ci
+// tiles of the layer -- run on ONE XCD, so gy and X come from HBM once per split.
 //
-// Tiles.  The kernel is vector-issue-bound, not matrix-bound (every workgroup splits the fp32 rows it stages into fp16 pairs
-// itself, and cuts K tap fragments out of every window).  Two tile forms are built; the smaller one is the default (h2w_form):
-//   MCO = 2 (Cout_g % 128 == 0, NEF_H2W_MCO=2 only): 128 output x 64 input channels, 512 threads = 8 waves, one workgroup per CU.  A wave owns
-//           64 x 32 channels (two row tiles share every B fragment it builds).  K = 7: the two wave groups take taps 0..3 and
-//           4..6 (SPLIT 1: 8 accumulator tiles per wave); K = 3 / 1: they take the even and the odd 16-column chunks of a tile
-//           and leave TWO partial sums (SPLIT 2: the reduce kernel adds 2 S of them).
-//   MCO = 1 (Cout_g % 64 == 0): 64 x 64 channels, 256 threads, all taps in every wave, two workgroups per CU (round-4 first form).
-// The (sample, 64-column tile) sequence is split S ways; every workgroup streams its share through two LDS buffers (registers
-// carry tile i+1 while tile i is multiplied: one barrier per tile) and leaves its partial sums in ws[split][g][k][co][ci],
-// which conv_bwd_weight_reduce (conv_mfma.hip) adds up in a fixed order.  The workgroups that share a (group, split) -- the
-// co x ci tiles of the layer -- run on ONE XCD, so gy and X come from HBM once per split.
+// Two kernels:
+//   conv_h2w2_kernel (below, "second form"; Cout_g % 128 == 0): 128 x 64 channels per workgroup, producer waves stage and split
+//           the tiles, consumer waves only issue matrix instructions -- see the comment in front of it;
+//   conv_h2w_kernel ("first form"; the 64-output-channel layers): 64 x 64 channels, 256 threads, every wave stages, splits and
+//           multiplies in turn, two workgroups per CU.  A lane reads the 16-column window X[ci][t0 + 8 hi - 4 .. + 11] once per 16
+//           columns and cuts each tap's fragment out of it in registers (even shifts: register renames, odd shifts: four
+//           v_alignbit_b32).  (NEF_H2W_MCO=2 builds its 128 x 64 variant with the taps / chunks divided between two wave groups:
+//           measured a wash, kept for A/B.)
 //
 // Both operands are scaled by exact powers of two derived from the magnitudes their call site measured before (x_amax,
 // gy_amax; ops.py keeps them per site as for the forward launches); the product of the two scales is divided out of the
