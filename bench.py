@@ -415,7 +415,7 @@ def main():
                 # kernel names of the trace: conv_h2w2_kernel<K, PRO, ...> (producer / consumer weight gradient; conv_h2w_kernel = its
                 # first form) and conv_h2_kernel<K, PRO, TM>
                 pre = (("conv_h2w2_kernel<%d, 0" % dom_tag[1], "conv_h2w_kernel<%d, 0" % dom_tag[1]) if dom_tag[0] == "conv_bwd_weight"
-                       else ("conv_h2_kernel<%d, 0, 2>" % dom_tag[1],))
+                       else ("conv_h2_kernel<%d, 0, 2" % dom_tag[1],))
                 hits = [v for pfx in pre for k_, v in tj.get("by_kernel", {}).items() if k_.startswith(pfx)]
                 traffic = hits[0] if (hits and ops.H2) else None
                 # NOT measured by this run: replayed from the committed rocprofv3 --pmc pass (separate run, as the
