@@ -223,6 +223,37 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
             xvo[it][0] = xok[it] ? (unsigned)(t * 4) : NEF_OOB;
         }
     }
+    // x2-upsampling prologue: a lane stages INTERVALS of the half-resolution row instead of positions -- interval m = t0/2 - 1 + u
+    // (u = lane + 64 it, it = 0, 1) holds the sources x[m], x[m + 1] of the two outputs t = 2m + 1 (position r = 2u: 0.75 / 0.25) and
+    // t = 2m + 2 (r = 2u + 1: 0.25 / 0.75; output 0 is x[0] itself: weights 0 / 1 on the pair (x[-1] -> 0, x[0])), exactly
+    // nn.Upsample's values (and the (1 - lam) a + lam b expression of the position form): two loads per two outputs instead of
+    // four, the affine + ReLU once per source.  The right halo interval u = 128 (r = 256, 257) is staged by lanes 0..3 of each
+    // wave, one of the wave's four channels each.
+    unsigned uvo[2][2], mvo[2];
+    bool uok[2][2], mok[2];
+    float ulam[2];
+    if constexpr (UP) {
+        static_assert(!UP || (K == 3 && NTO == 256), "interval staging: K = 3, 256-column tiles");
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int u = it < 2 ? lane + 64 * it : 128;
+            const int m = (t0 >> 1) - 1 + u;
+            const bool ok0 = 2 * m + 1 >= 0 && 2 * m + 1 < T, ok1 = 2 * m + 2 >= 0 && 2 * m + 2 < T;
+            const bool any = ok0 || ok1;
+            const int mb = m + 1 < Tin ? m + 1 : Tin - 1;
+            const unsigned oa = (any && m >= 0 && m < Tin) ? (unsigned)(m * 4) : NEF_OOB;
+            const unsigned ob = (any && m < Tin) ? (unsigned)(mb * 4) : NEF_OOB;
+            if (it < 2) {
+                uok[it][0] = ok0, uok[it][1] = ok1;
+                uvo[it][0] = oa, uvo[it][1] = ob;
+                ulam[it] = m == -1 ? 1.f : 0.75f;
+            } else {      // lane l < 4: channel 4 wave + l (its row starts l Tin floats behind the wave's first)
+                mok[0] = ok0 && lane < 4, mok[1] = ok1 && lane < 4;
+                mvo[0] = (lane < 4 && oa != NEF_OOB) ? oa + (unsigned)(lane * Tin * 4) : NEF_OOB;
+                mvo[1] = (lane < 4 && ob != NEF_OOB) ? ob + (unsigned)(lane * Tin * 4) : NEF_OOB;
+            }
+        }
+    }
     const int64_t soff = (int64_t)b0 * a.sc_bs + (int64_t)g * a.sc_gs;
     // input scale (an exact power of two, undone in the epilogue): from the magnitude this operand had at the call site's previous
     // launch (*x_amax -> [2^8, 2^9): room for a 128x jump before anything is clamped, full precision for elements within 2^-9 of the
@@ -249,13 +280,23 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // ---- operand streams
-    float xreg[4][NIT][NS];          // this wave's 4 channels (4 wave + 0..3) of the stage in flight
+    float xreg[4][UP ? 2 : NIT][NS];          // this wave's 4 channels (4 wave + 0..3) of the stage in flight
+    float xm[2];                              // UP: the right halo interval, channel 4 wave + lane (lanes 0..3)
 #define NEF_H2X_ISSUE(C0, RS)                                                                                        \
     {                                                                                                               \
         _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                          \
             const unsigned so = (unsigned)(((C0) + 4 * wave_u + rr) * Tin * 4);                                     \
-            _Pragma("unroll") for (int it = 0; it < NIT; ++it)                                                      \
-                _Pragma("unroll") for (int ns = 0; ns < NS; ++ns) xreg[rr][it][ns] = nef_buf_f32(RS, xvo[it][ns], so); \
+            if constexpr (UP) {                                                                                     \
+                _Pragma("unroll") for (int it = 0; it < 2; ++it)                                                    \
+                    _Pragma("unroll") for (int ns = 0; ns < 2; ++ns) xreg[rr][it][ns] = nef_buf_f32(RS, uvo[it][ns], so); \
+            } else {                                                                                                \
+                _Pragma("unroll") for (int it = 0; it < NIT; ++it) xreg[rr][it][0] = nef_buf_f32(RS, xvo[it][0], so); \
+            }                                                                                                       \
+        }                                                                                                           \
+        if constexpr (UP) {                                                                                         \
+            const unsigned so = (unsigned)(((C0) + 4 * wave_u) * Tin * 4);                                          \
+            xm[0] = nef_buf_f32(RS, mvo[0], so);                                                                    \
+            xm[1] = nef_buf_f32(RS, mvo[1], so);                                                                    \
         }                                                                                                           \
     }
     // split the stage in registers and store it: position r of channel c -> plane[(r & 3) * P4 + (r >> 2)][c]
@@ -270,16 +311,60 @@ __global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2)
                 pb_[rr] = Pl[Cig + (C0) + 4 * wave_u + rr];                                                         \
             }                                                                                                       \
         }                                                                                                           \
+        if constexpr (UP) {                                                                                         \
+            _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                      \
+                float v0_[4], v1_[4];                                                                               \
+                _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                  \
+                    float sa = xreg[rr][it][0], sb = xreg[rr][it][1];                                               \
+                    if constexpr (AFF) sa = fmaxf(fmaf(sa, pa_[rr], pb_[rr]), 0.f), sb = fmaxf(fmaf(sb, pa_[rr], pb_[rr]), 0.f); \
+                    float o0 = (1.f - 0.25f) * sa + 0.25f * sb;                                                     \
+                    float o1 = (1.f - ulam[it]) * sa + ulam[it] * sb;                                               \
+                    o0 = uok[it][0] ? o0 : 0.f;                                                                     \
+                    o1 = uok[it][1] ? o1 : 0.f;                                                                     \
+                    o0 *= sa_[rr], o1 *= sa_[rr];                                                                   \
+                    amax_ = fmaxf(amax_, fmaxf(fabsf(o0), fabsf(o1)));                                              \
+                    v0_[rr] = o0, v1_[rr] = o1;                                                                     \
+                }                                                                                                   \
+                const int r = 2 * (lane + 64 * it);                                                                 \
+                unsigned h0_, l0_, h1_, l1_, h2_, l2_, h3_, l3_;                                                    \
+                split2s(v0_[0], v0_[1], xs_, xlim_, h0_, l0_);                                                      \
+                split2s(v0_[2], v0_[3], xs_, xlim_, h1_, l1_);                                                      \
+                split2s(v1_[0], v1_[1], xs_, xlim_, h2_, l2_);                                                      \
+                split2s(v1_[2], v1_[3], xs_, xlim_, h3_, l3_);                                                      \
+                unsigned char* p0_ = (BUFP) + (((r & 3) * P4 + (r >> 2)) * 32 + 8 * wave);                          \
+                unsigned char* p1_ = (BUFP) + ((((r + 1) & 3) * P4 + ((r + 1) >> 2)) * 32 + 8 * wave);              \
+                *reinterpret_cast<u32x2*>(p0_) = u32x2{h0_, h1_};                                                   \
+                *reinterpret_cast<u32x2*>(p0_ + PLANE) = u32x2{l0_, l1_};                                           \
+                *reinterpret_cast<u32x2*>(p1_) = u32x2{h2_, h3_};                                                   \
+                *reinterpret_cast<u32x2*>(p1_ + PLANE) = u32x2{l2_, l3_};                                           \
+            }                                                                                                       \
+            if (lane < 4) {      /* the right halo interval: positions 256, 257 of channel 4 wave + lane */          \
+                float sa = xm[0], sb = xm[1];                                                                       \
+                if constexpr (AFF) {                                                                                \
+                    const float pa = Pl[(C0) + 4 * wave_u + lane], pb = Pl[Cig + (C0) + 4 * wave_u + lane];         \
+                    sa = fmaxf(fmaf(sa, pa, pb), 0.f), sb = fmaxf(fmaf(sb, pa, pb), 0.f);                           \
+                }                                                                                                   \
+                const float sc = a.in_scale ? a.in_scale[soff + (C0) + 4 * wave + lane] : 1.f;                      \
+                float o0 = (1.f - 0.25f) * sa + 0.25f * sb;                                                         \
+                float o1 = (1.f - 0.75f) * sa + 0.75f * sb;                                                         \
+                o0 = mok[0] ? o0 * sc : 0.f;                                                                        \
+                o1 = mok[1] ? o1 * sc : 0.f;                                                                        \
+                amax_ = fmaxf(amax_, fmaxf(fabsf(o0), fabsf(o1)));                                                  \
+                unsigned h_, l_;                                                                                    \
+                split2s(o0, o1, xs_, xlim_, h_, l_);                                                                \
+                unsigned char* p0_ = (BUFP) + (((256 & 3) * P4 + (256 >> 2)) * 32 + 8 * wave + 2 * lane);           \
+                unsigned char* p1_ = (BUFP) + (((257 & 3) * P4 + (257 >> 2)) * 32 + 8 * wave + 2 * lane);           \
+                *reinterpret_cast<unsigned short*>(p0_) = (unsigned short)(h_ & 0xffffu);                           \
+                *reinterpret_cast<unsigned short*>(p0_ + PLANE) = (unsigned short)(l_ & 0xffffu);                   \
+                *reinterpret_cast<unsigned short*>(p1_) = (unsigned short)(h_ >> 16);                               \
+                *reinterpret_cast<unsigned short*>(p1_ + PLANE) = (unsigned short)(l_ >> 16);                       \
+            }                                                                                                       \
+        } else                                                                                                      \
         _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                        \
             float v_[4];                                                                                            \
             _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                      \
                 float v = xreg[rr][it][0];                                                                          \
                 if constexpr (AFF) v = fmaxf(fmaf(v, pa_[rr], pb_[rr]), 0.f);                                       \
-                if constexpr (UP) {                                                                                 \
-                    float v1 = xreg[rr][it][NS - 1];                                                                \
-                    if constexpr (AFF) v1 = fmaxf(fmaf(v1, pa_[rr], pb_[rr]), 0.f);                                 \
-                    v = (1.f - lam[it]) * v + lam[it] * v1;                                                         \
-                }                                                                                                   \
                 if constexpr (PRO != 0) v = xok[it] ? v : 0.f;                                                      \
                 v *= sa_[rr];                                                                                       \
                 amax_ = fmaxf(amax_, fabsf(v));                                                                     \
