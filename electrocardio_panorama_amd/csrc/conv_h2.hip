@@ -139,6 +139,9 @@ __global__ __launch_bounds__(256) void pack_h2_kernel(H2PackTable tab) {
 #ifndef NEF_H2_T
 #define NEF_H2_T 0      // timing-only builds: 1 = no activation loads in the loop, 2 = no matrix instructions, 4 = no epilogue
 #endif
+#ifndef NEF_H2_UP_OCC3
+#define NEF_H2_UP_OCC3 0      // 1: the x2-upsampling forms of the 64-channel tile at three workgroups per CU too
+#endif
 #ifndef NEF_H2_OCC1
 #define NEF_H2_OCC1 3      // workgroups per CU the 64-channel tile is compiled for (168 VGPRs); the x2-upsampling prologue needs 2
 #endif
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void pack_h2_kernel(H2PackTable tab) {
 // positions between two samples are staged as zeros (the zero padding of both neighbours) and their outputs are dropped; a lane's
 // four adjacent outputs lie inside one sample or inside one gap.  No prologue, channel scale or statistics in this mode.
 template <int K, int PRO, int TM, bool PACK = false>
-__global__ __launch_bounds__(256, (TM == 1 && (PRO & 2) == 0) ? NEF_H2_OCC1 : 2) void conv_h2_kernel(nef_conv_args a, int tps, int n_tiles, int m_tiles) {
+__global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)) ? NEF_H2_OCC1 : 2) void conv_h2_kernel(nef_conv_args a, int tps, int n_tiles, int m_tiles) {
     constexpr int MT = 64 * TM;                    // output channels per workgroup: 2 (co) x 2 (t) waves of TM x 4 tiles
     constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
     constexpr int NS = UP ? 2 : 1;
