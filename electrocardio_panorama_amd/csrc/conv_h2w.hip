@@ -407,6 +407,9 @@ H2WForm h2w_form(int Cog, int K) {
 #ifndef NEF_W2_DBG
 #define NEF_W2_DBG 0      // timing-only builds: 1 = no split / LDS stores, 2 = no global loads, 4 = no matrix work
 #endif
+#ifndef NEF_H2W_64_DEFAULT
+#define NEF_H2W_64_DEFAULT 12     // the x2-upsampling prologues (modes 2, 3): 1.12 -> 0.92 ms for the 128 -> 64 decoder layer; plain and affine-only 64-channel layers are at the load rate with either form
+#endif
 typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -796,10 +799,15 @@ int launch_h2w2(const H2WArgs& a, hipStream_t st) {
     return nef_launch_status();
 }
 
-// the second kernel takes the shapes with Cout_g % 128 == 0 (NEF_H2W_V=1: the first kernel everywhere)
-int h2w2_form(int Cog) {
+// the second kernel takes the shapes with Cout_g % 128 == 0 (form 1: 128 x 64 channels per workgroup); NEF_H2W_V=1: the first kernel
+// everywhere; NEF_H2W_64=<mask of prologue modes + 1>: form 2 (64 x 64 channels, 4 consumer + 8 producer waves) for the 64-channel
+// layers with those prologues (bit p + 1 set: pro_mode p)
+int h2w2_form(int Cog, int pro_mode) {
     static const bool v1 = getenv("NEF_H2W_V") && atoi(getenv("NEF_H2W_V")) == 1;
-    return (!v1 && Cog % 128 == 0) ? 1 : 0;
+    static const int m64 = getenv("NEF_H2W_64") ? atoi(getenv("NEF_H2W_64")) : NEF_H2W_64_DEFAULT;
+    if (v1) return 0;
+    if (Cog % 128 == 0) return 1;
+    return ((m64 >> pro_mode) & 1) ? 2 : 0;
 }
 
 }  // namespace
@@ -813,12 +821,12 @@ __attribute__((visibility("hidden"))) bool nef_h2w_ok(int B, int T, int Cig, int
 
 // team splits of the (sample, tile) sequence, and partial sums per (g, k, co, ci) the launch leaves (= splits, or twice that
 // when the wave groups keep separate sums)
-__attribute__((visibility("hidden"))) int nef_h2w_splits(int B, int T, int G, int Cig, int Cog, int K, int* partials) {
-    const int v2 = h2w2_form(Cog);
+__attribute__((visibility("hidden"))) int nef_h2w_splits(int B, int T, int G, int Cig, int Cog, int K, int pro_mode, int* partials) {
+    const int v2 = h2w2_form(Cog, pro_mode);
     const H2WForm f = h2w_form(Cog, K);
     const int tps = (T + TT - 1) / TT;
     const int64_t n_tiles = (int64_t)B * tps;
-    const int units = v2 ? G * (Cog / 128) * (Cig / 64) : G * (Cog / (64 * f.mco)) * (Cig / 64);
+    const int units = v2 ? G * (Cog / (v2 == 1 ? 128 : 64)) * (Cig / 64) : G * (Cog / (64 * f.mco)) * (Cig / 64);
     const int resident = v2 ? 1 : (f.split ? 1 : 2);      // workgroups per CU
     static const int rounds = getenv("NEF_H2W_ROUNDS") ? atoi(getenv("NEF_H2W_ROUNDS")) : 1;
     const int slots = rounds * resident * nef_cu_count();
@@ -852,11 +860,13 @@ __attribute__((visibility("hidden"))) int nef_h2w_launch(const float* x, int64_t
     const int Tin = (pro_mode & 2) ? T / 2 : T;
     a.x_end = ((int64_t)(B - 1) * x_bs + (int64_t)(G - 1) * x_gs + (int64_t)Cig * Tin) * 4;
     a.gy_end = ((int64_t)(B - 1) * gy_bs + (int64_t)(G - 1) * gy_gs + (int64_t)Cog * T) * 4;
-    if (h2w2_form(Cog)) {
-        a.m_tiles = Cog / 128, a.c_tiles = Cig / 64;
+    if (const int v2 = h2w2_form(Cog, pro_mode)) {
+        a.m_tiles = Cog / (v2 == 1 ? 128 : 64), a.c_tiles = Cig / 64;
         // 12 waves = 168 registers each.  K = 7: 8 consumer waves of one row tile (7 x 16 accumulator registers) + 4 producer waves
         // with one staging set;  K = 3, 1: 4 consumer waves of two row tiles + 8 producer waves with two tiles in flight
-#define NEF_H2W2(KK, PP) launch_h2w2<KK, PP, 4, 2, (KK == 7 ? 1 : 2), 64, (KK == 7 ? 4 : 8), (KK == 7 ? 1 : 2)>(a, st)
+#define NEF_H2W2(KK, PP)                                                                                             \
+    (v2 == 1 ? launch_h2w2<KK, PP, 4, 2, (KK == 7 ? 1 : 2), 64, (KK == 7 ? 4 : 8), (KK == 7 ? 1 : 2)>(a, st)               \
+             : launch_h2w2<KK, PP, 2, 2, 1, 64, 8, (KK == 7 ? 1 : 2)>(a, st))
         if (K == 7) return NEF_H2W2(7, 0);
         if (K == 1) return NEF_H2W2(1, 0);
         switch (pro_mode) {

@@ -2594,7 +2594,7 @@ int nef_conv_bwd_weight_pro(const float* x, int64_t x_bs, int64_t x_gs, const fl
 
 // conv_h2w.hip: the weight gradient on exact fp16 splits of both operands
 __attribute__((visibility("hidden"))) bool nef_h2w_ok(int B, int T, int Cig, int Cog, int K, int pro_mode);
-__attribute__((visibility("hidden"))) int nef_h2w_splits(int B, int T, int G, int Cig, int Cog, int K, int* partials);
+__attribute__((visibility("hidden"))) int nef_h2w_splits(int B, int T, int G, int Cig, int Cog, int K, int pro_mode, int* partials);
 __attribute__((visibility("hidden"))) int nef_h2w_launch(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
                                                          int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
                                                          const float* gy, int64_t gy_bs, int64_t gy_gs, float* ws, int B, int T, int G,
@@ -2604,8 +2604,12 @@ __attribute__((visibility("hidden"))) int nef_h2w_launch(const float* x, int64_t
 
 size_t nef_conv_bwd_weight_h2_ws_bytes(int B, int T, int G, int Cin_g, int Cout_g, int K) {
     if (G <= 0 || !nef_h2w_ok(B, T, Cin_g, Cout_g, K, 0)) return 0;
-    int partials = 0;
-    (void)nef_h2w_splits(B, T, G, Cin_g, Cout_g, K, &partials);
+    int partials = 0;      // the tile form (and with it the split count) may depend on the prologue: size for the largest
+    for (int pm = 0; pm < (K == 3 ? 4 : 1); ++pm) {
+        int p_ = 0;
+        (void)nef_h2w_splits(B, T, G, Cin_g, Cout_g, K, pm, &p_);
+        if (p_ > partials) partials = p_;
+    }
     return (size_t)partials * G * K * Cout_g * Cin_g * sizeof(float);
 }
 
@@ -2619,7 +2623,7 @@ int nef_conv_bwd_weight_h2(const float* x, int64_t x_bs, int64_t x_gs, const flo
     NEF_REQUIRE(G > 0 && nef_h2w_ok(B, T, Cin_g, Cout_g, K, pro_mode), NEF_E_SHAPE);
     NEF_REQUIRE(!(pro_mode && in_scale), NEF_E_UNSUPPORTED);
     int partials = 0;
-    const int S = nef_h2w_splits(B, T, G, Cin_g, Cout_g, K, &partials);
+    const int S = nef_h2w_splits(B, T, G, Cin_g, Cout_g, K, pro_mode, &partials);
     NEF_REQUIRE(ws_bytes >= (size_t)partials * G * K * Cout_g * Cin_g * sizeof(float), NEF_E_WORKSPACE);
     hipStream_t st = (hipStream_t)stream;
     if (int rc = nef_h2w_launch(x, x_bs, x_gs, in_scale, sc_bs, sc_gs, pro_a, pro_b, pro_mode, pro_Bp, gy, gy_bs, gy_gs, (float*)ws, B,
