@@ -495,6 +495,9 @@ def main():
                                 "roi_unpool_bwd": "adjoint of a variable-length linear resampling: gather arithmetic, latency-bound"},
             "secondary": sec,
             "hip_graph": bool(args.graph),
+            # split-fp16 launches (waves) of the whole run whose scaled operand left fp16 range and was clamped: 0 unless an operand
+            # grew more than 64x between two consecutive steps (ops.h2_clamped; the Solver warns once per epoch)
+            "h2_clamped_waves": int(ops.h2_clamped(reset=False)) if ops.H2 else None,
             # N > 1: time the launching stream spends waiting for gradient collectives per step (the encoder bucket's
             # all-reduce + whatever is left of the early bucket's, which runs under the encoder's backward pass)
             "allreduce_ms_exposed": (round(sum(a.elapsed_time(b) for a, b in ar_events) / max(args.steps, 1), 4)
