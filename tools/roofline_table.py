@@ -50,7 +50,7 @@ lines.sort(reverse=True)
 with open(out, "w") as fh:
     fh.write("# Measured HBM traffic and achieved bandwidth per launch shape (config 2, one-stream run: launches alone; warm-up step dropped)\n\n")
     fh.write("bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from the PMC passes; time from the kernel trace; peak 8 TB/s.\n"
-             "MFMA-bound kernels (conv_*) are listed for their traffic only -- their roof is the fp32 matrix peak.\n\n")
+             "MFMA-bound kernels (conv_*) are listed for their traffic only -- their roof is the matrix peak (fp16 for the split-fp16 kernels conv_h2*, fp32 for the others).\n\n")
     fh.write("| kernel | workitems | launches | avg us | HBM MB / launch | TB/s | % of 8 TB/s | % of kernel time |\n"
              "|---|---:|---:|---:|---:|---:|---:|---:|\n")
     for tot, (name, grid), n, avg, by in lines:
