@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NEF_LIB") or os.path.join(_HERE, "csrc", "libnefnet_hip.so")   # NEF_LIB: A/B builds
 
 NEF_OK = 0
+OPT_H2_FORM, OPT_H2P_WGS = 1, 2      # nef_set_option keys (include/nefnet_hip.h)
 _ERR = {-1: "NEF_E_SHAPE", -2: "NEF_E_NULL", -3: "NEF_E_WORKSPACE", -4: "NEF_E_UNSUPPORTED"}
 
 p = C.c_void_p
@@ -45,6 +46,8 @@ class PackDesc(C.Structure):
 # name -> (restype, argtypes); every symbol include/nefnet_hip.h declares
 SIGNATURES = {
     "nef_abi_version": (i32, []),
+    "nef_set_option": (i32, [i32, i32]),
+    "nef_get_option": (i32, [i32]),
     "nef_stem_fwd": (i32, [p, p, p, i32, i32, i32, p]),
     "nef_stem_bwd_ws_bytes": (sz, [i32]),
     "nef_stem_bwd_weight": (i32, [p, p, p, p, p, sz, i32, i32, i32, p]),

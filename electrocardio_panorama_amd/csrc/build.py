@@ -6,12 +6,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["conv_mfma.hip", "conv_h2.hip", "conv_h2w.hip", "conv_bww_glds.hip", "stem.hip", "elementwise.hip", "roi.hip", "convt_theta.hip", "pano_h.hip", "metrics.hip"]
+SOURCES = ["conv_mfma.hip", "conv_h2.hip", "conv_h2p.hip", "conv_h2w.hip", "conv_bww_glds.hip", "stem.hip", "elementwise.hip", "roi.hip", "convt_theta.hip", "pano_h.hip", "metrics.hip"]
 LIB = os.path.join(HERE, "libnefnet_hip.so")
 # per-source extra flags.  conv_h2.hip: no SLP vectorisation -- the packed-fp32 instructions it creates in the epilogue
 # (v_pk_fma_f32 with op_sel on registers a ds_read_b128 has just returned) intermittently produced 0.0 in lanes 48..63 on a loaded
 # chip ("split-fp16 convolution"); scalar fp32 is also what the matrix-core guide recommends beside MFMAs
-EXTRA_FLAGS = {"conv_h2.hip": ["-fno-slp-vectorize"], "conv_h2w.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"conv_h2.hip": ["-fno-slp-vectorize"], "conv_h2p.hip": ["-fno-slp-vectorize"], "conv_h2w.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include"), "-I", HERE]
 
@@ -40,7 +40,7 @@ def build_variant(name, defines, sources=("conv_mfma.hip",)):
         o = os.path.join(HERE, s.replace(".hip", ".o"))
         if s in sources:
             o = os.path.join(vdir, f"{name}_{s.replace('.hip', '.o')}")
-            subprocess.check_call([hipcc()] + FLAGS + EXTRA_FLAGS.get(s, []) + [f"-D{d}" for d in defines] + ["-c", os.path.join(HERE, s), "-o", o])
+            subprocess.check_call([hipcc()] + FLAGS + ["-w"] + EXTRA_FLAGS.get(s, []) + [f"-D{d}" for d in defines] + ["-c", os.path.join(HERE, s), "-o", o])
         objs.append(o)
     lib = os.path.join(vdir, f"lib{name}.so")
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)

@@ -760,9 +760,15 @@ __attribute__((visibility("hidden"))) bool nef_h2_ok(const nef_conv_args* a) {
            (!(a->pro_mode & 1) || a->Cin_g <= PRO_MAX_CIN);
 }
 
+// the producer / consumer form (conv_h2p.hip)
+__attribute__((visibility("hidden"))) int nef_opt_h2_form();
+__attribute__((visibility("hidden"))) bool nef_h2p_ok(const nef_conv_args* a);
+__attribute__((visibility("hidden"))) int nef_h2p_launch(const nef_conv_args* a, hipStream_t st);
+
 __attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, hipStream_t st) {
     if (!nef_h2_ok(a)) return NEF_E_SHAPE;
     if ((a->pro_mode & 1) && !(a->pro_a && a->pro_b && a->pro_Bp > 0)) return NEF_E_NULL;
+    if (nef_opt_h2_form() && nef_h2p_ok(a)) return nef_h2p_launch(a, st);
     static const bool force_tm1 = getenv("NEF_H2_TM1") && atoi(getenv("NEF_H2_TM1")) == 1;      // A/B: 64-channel tile everywhere
     const bool wide = a->Cout_g % 128 == 0 && !force_tm1;
     // the x2-upsampling prologue keeps two source samples per staged position in registers: next to the 128 accumulator

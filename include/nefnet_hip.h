@@ -34,7 +34,18 @@ extern "C" {
 typedef void* nef_stream_t;
 
 /* ABI version of this header; bumped on any signature change. */
-int nef_abi_version(void);   /* 15 (round 4: + x_clamped / clamped counters); 14 (round 4: + nef_conv_bwd_weight_h2); 13 (round 4: + nef_pack_weight_h2 / conv args wino = 3 and x_scale: direct convolutions on exact fp16 splits of the fp32 operands); 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
+int nef_abi_version(void);   /* 16 (round 5: + nef_set_option / nef_get_option); 15 (round 4: + x_clamped / clamped counters); 14 (round 4: + nef_conv_bwd_weight_h2); 13 (round 4: + nef_pack_weight_h2 / conv args wino = 3 and x_scale: direct convolutions on exact fp16 splits of the fp32 operands); 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
+
+/* Kernel-form options of the process (tuning / A-B hooks; every value computes the same results).  Not part of any reference
+ * interface: the reference's nn.Conv1d has one form (codes/network/model_nefnet.py:18-21).  Returns the previous value, or
+ * NEF_E_SHAPE for an unknown key.  Read by the launches that follow; not meant to be flipped while a hipGraph capture is open. */
+#define NEF_OPT_H2_FORM 1       /* split-fp16 forward / backward-data convolutions (conv args wino = 3): 0 (default) = every wave
+                                   stages, multiplies and stores in turn (csrc/conv_h2.hip); 1 = producer and consumer waves in a
+                                   persistent twelve-wave workgroup (csrc/conv_h2p.hip) wherever its shape rules hold -- bit-identical
+                                   results, measured slower in round 5, kept as the A/B reference */
+#define NEF_OPT_H2P_WGS 2       /* persistent workgroups per CU of that form (default 1: twelve waves fill a CU at 168 registers) */
+int nef_set_option(int key, int value);
+int nef_get_option(int key);
 
 /* ---------------------------------------------------------------------------------------------
  * Stem: Conv1d(1->128 per lead, k15, s2, p7, no bias) + ReLU + MaxPool1d(3,2,1), fused.

@@ -1089,6 +1089,77 @@ def test_conv_h2_is_fp32_class(conv_algo):
         assert rel(gx_raw.double().cpu(), gref64) > 1e-4
 
 
+H2P_CASES = [  # K, G, Cig, Cog, B, T_out, pro_mode, extras
+    (7, 2, 48, 64, 9, 386, 0, "relu,drop"), (7, 1, 64, 128, 3, 1250, 0, "gate"), (3, 3, 64, 64, 13, 1250, 0, "relu,res,sc"),
+    (1, 2, 64, 128, 5, 700, 0, "bias"), (3, 1, 64, 64, 5, 512, 3, "bias,stats"), (3, 2, 64, 128, 6, 2500, 2, "bias"),
+    (3, 1, 128, 64, 6, 1000, 1, "bias,stats"), (3, 1, 64, 64, 6, 1000, 0, "bnb"), (3, 1, 64, 128, 6, 1000, 0, "bnbup"),
+    (3, 1, 64, 64, 17, 256, 0, "relu"), (3, 1, 48, 64, 2, 130, 1, "bias"),
+]
+
+
+@pytest.mark.parametrize("K,G,Cig,Cog,B,T,pm,extra", H2P_CASES)
+def test_conv_h2_producer_consumer_form_is_bit_identical(conv_algo, K, G, Cig, Cog, B, T, pm, extra):
+    """csrc/conv_h2p.hip (producer / consumer waves, persistent twelve-wave workgroup; nef_set_option(NEF_OPT_H2_FORM, 1)) does
+    conv_h2_kernel's arithmetic in the same order: outputs, BatchNorm slot sums and BatchNorm-backward sums must be bit-identical
+    -- every prologue mode, every epilogue option, first / interior / last tiles of a row (quad loads vs checked loads), batches
+    that are not a multiple of 8 (empty tiles of the walk), 3 and 8 stages."""
+    if conv_algo != "h2":
+        pytest.skip("split-fp16 path")
+    o = ops()
+    from electrocardio_panorama_amd import _lib
+    from electrocardio_panorama_amd.ops import GV
+    L = _lib.load()
+    ex = set(extra.split(","))
+    Tin = T // 2 if pm & 2 else T
+    x = g(rnd(B, G * Cig, Tin, seed=901))
+    w = g(rnd(G * Cog, Cig, K, seed=902, scale=0.05))
+    wp = o.pack_weight(w, G, T=T)
+    assert wp.nef_wino == 3
+    kw = dict(x_scale=16.0, relu="relu" in ex)
+    if "bias" in ex:
+        kw["bias"] = g(rnd(G * Cog, seed=903))
+    if "drop" in ex:
+        kw.update(drop_p=0.2, drop_scale=1.25, seed=77)
+    if "sc" in ex:
+        kw["in_scale"] = (g(rnd(B, G * Cig, seed=904) + 1.5), G * Cig, Cig)
+    if "res" in ex:
+        kw["res"] = GV.dense(g(rnd(B, G * Cog, T, seed=905)), G)
+    if "gate" in ex:
+        kw.update(gate=GV.dense(g(rnd(B, G * Cog, T, seed=906)), G), gate_scale=1.25, role="conv_bwd_data")
+    P = 3 if B % 3 == 0 else 1
+    if pm:
+        kw["pro"] = (pm, g(rnd(P, G * Cig, seed=907) + 0.5), g(rnd(P, G * Cig, seed=908) * 0.3), B // P)
+    bn = None
+    if "bnb" in ex or "bnbup" in ex:
+        up = "bnbup" in ex
+        bn = [g(rnd(B, G * Cog, T // 2 if up else T, seed=909)), g(rnd(P, G * Cog, seed=910)), g(rnd(P, G * Cog, seed=911) + 1.5),
+              g(rnd(P, G * Cog, seed=912) + 0.5), g(rnd(P, G * Cog, seed=913) * 0.3)]
+        kw["role"] = "conv_bwd_data"
+
+    def run():
+        k2, slots = dict(kw), None
+        if "stats" in ex:
+            slots = k2["stats"] = o.conv_stats_buffer(wp, B, G, Cog, T, DEV)
+        if bn is not None:
+            slots = o.conv_stats_buffer(wp, B, G, Cog, T, DEV)
+            k2["bnb"] = (*bn, B // P, slots, int("bnbup" in ex))
+        if slots is not None:
+            slots[0].fill_(-7.0)
+        return o.conv(GV.dense(x, G), wp, Cog, K, **k2), (None if slots is None else slots[0])
+
+    assert L.nef_get_option(_lib.OPT_H2_FORM) == 0
+    y0, s0 = run()
+    L.nef_set_option(_lib.OPT_H2_FORM, 1)
+    try:
+        y1, s1 = run()
+        y2, _ = run()
+    finally:
+        L.nef_set_option(_lib.OPT_H2_FORM, 0)
+    assert torch.equal(y0, y1) and torch.equal(y1, y2)
+    assert s0 is None or torch.equal(s0, s1)
+    assert float(y0.abs().max()) > 0
+
+
 @pytest.mark.parametrize("K,G,Cig,Cog,B,T", [(3, 21, 128, 128, 30, 16), (3, 3, 64, 128, 5, 32), (1, 21, 64, 128, 27, 16), (3, 2, 128, 64, 14, 8),
                                              (3, 1, 128, 128, 3, 64), (3, 7, 128, 128, 13, 20)])
 def test_conv_h2_packed_short_rows(conv_algo, K, G, Cig, Cog, B, T):
