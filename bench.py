@@ -353,9 +353,9 @@ def main():
     final_loss = float(final_loss_t.item())
 
     # the arithmetic of the step: fp32 data, parameters, accumulators and elementwise work; the conv products run on the fp16 matrix
-    # cores on EXACT two-term fp16 splits of the fp32 operands (ops.H2; results at fp32 rounding) -- or on the fp32
+    # cores on two-term fp16 splits of the fp32 operands (ops.H2; fp32-class: 22-23 bits per operand, block-scaled) -- or on the fp32
     # matrix cores throughout with NEF_H2=0
-    DTYPE = ("f32 (conv products: fp32 operands split exactly into fp16 hi+lo, 3 fp16 matrix products each, fp32 accumulate)"
+    DTYPE = ("f32 (conv products: fp32 operands split into fp16 hi+lo = 22-23 bits, block-scaled, 3 fp16 matrix products each, fp32 accumulate; fp32-class, not IEEE fp32)"
              if ops.H2 else "f32")
     if rank == 0:
         # Every tagged conv launch is priced against BOTH roofs and bound by the larger floor:
@@ -368,7 +368,7 @@ def main():
         # `whole_step` the sum of the binding floors of all tagged conv launches + the algorithmic bytes of the HBM-bound
         # passes over the timed step.
         T = L // 4
-        KNAME = {3: "conv_h2_kernel (direct conv on exact fp16 splits of both fp32 operands, fp32 accumulate)",
+        KNAME = {3: "conv_h2_kernel (direct conv on two-term fp16 splits of both fp32 operands, fp32 accumulate)",
                  2: "conv_wino4_kernel (Winograd F(4,3) / F(4,4)+F(4,3), fp32)", 1: "conv_wino_kernel (Winograd F(2,3) / F(2,4)+F(2,3), fp32)",
                  0: "conv_fwd_kernel (direct, fp32)"}
 
@@ -389,7 +389,7 @@ def main():
             if bound == "mfma":
                 peak = FP16_MFMA_PEAK_TFLOPS if ex16 > 0 else FP32_MFMA_PEAK_TFLOPS
                 d.update(achieved=round((ex16 if ex16 > 0 else ex32) / ms / 1e9, 2), peak=peak, unit="TFLOP/s",
-                         matrix_dtype="f16 (exact splits of f32 operands), f32 accumulate" if ex16 > 0 else "f32")
+                         matrix_dtype="f16 (two-term splits of f32 operands, 22-23 bits), f32 accumulate" if ex16 > 0 else "f32")
             else:
                 d.update(achieved=round(byts / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s")
             return d
@@ -422,7 +422,7 @@ def main():
                 # counters cannot be collected together with timing)
                 traffic_source = ("replayed from " + tj.get("source", "profiles/traffic.json")) if traffic else None
             roof.update(traffic=traffic, traffic_source=traffic_source, kernel_tag="/".join(str(x) for x in dom_tag),
-                        kernel=("conv_h2w2_kernel (weight gradient on exact fp16 splits of both operands, producer / consumer waves)" if dom_tag[0] == "conv_bwd_weight" and roof["executed_fp16_mfma_flops"] > 0
+                        kernel=("conv_h2w2_kernel (weight gradient on two-term fp16 splits of both operands, producer / consumer waves)" if dom_tag[0] == "conv_bwd_weight" and roof["executed_fp16_mfma_flops"] > 0
                                 else KNAME[3] if roof["executed_fp16_mfma_flops"] > 0 else "fp32 conv kernel") +
                                (", launches of the timed region" if use is not serial[dom_tag] else ", launches of the single-stream breakdown steps"),
                         launches=len(use), ms_per_step_serialized=round(sum(serial[dom_tag]) / max(extra_steps, 1), 3),
@@ -496,8 +496,11 @@ def main():
             "secondary": sec,
             "hip_graph": bool(args.graph),
             # split-fp16 launches (waves) of the whole run whose scaled operand left fp16 range and was clamped: 0 unless an operand
-            # grew more than 64x between two consecutive steps (ops.h2_clamped; the Solver warns once per epoch)
+            # grew more than ops.H2_HEADROOM (64) x between two consecutive steps (ops.h2_clamped); a step that contains such a launch
+            # is skipped on the device (ops.h2_taint -> sgd_momentum) and counted in h2_skipped_steps; Solver checks both per epoch
             "h2_clamped_waves": int(ops.h2_clamped(reset=False)) if ops.H2 else None,
+            "h2_skipped_steps": int(ops.h2_skipped(reset=False)) if ops.H2 else None,
+            "h2_headroom": f"{ops.H2_HEADROOM}x growth of an operand between two consecutive steps",
             # N > 1: time the launching stream spends waiting for gradient collectives per step (the encoder bucket's
             # all-reduce + whatever is left of the early bucket's, which runs under the encoder's backward pass)
             "allreduce_ms_exposed": (round(sum(a.elapsed_time(b) for a, b in ar_events) / max(args.steps, 1), 4)

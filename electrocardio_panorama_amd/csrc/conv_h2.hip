@@ -1,8 +1,9 @@
 // conv_h2.hip -- the grouped 1-D convolutions (K = 3, K = 7; forward and backward-data) as DIRECT convolutions whose fp32
-// operands are split EXACTLY into two fp16 terms each and multiplied on the fp16 matrix cores with fp32 accumulation:
+// operands are each split into two fp16 terms and multiplied on the fp16 matrix cores with fp32 accumulation.  fp32-CLASS
+// arithmetic (22..23 significant bits per operand, block-scaled by one power of two per tensor and per weight row), not IEEE fp32:
 //
 //     x = xh + xl + ex,  xh = fp16(x),  xl = fp16(x - xh)            |ex| <= 2^-23 |x|   (22..23 significant bits kept)
-//     w = wh + wl + ew   (after an exact power-of-two scaling of each output row, undone in the epilogue)
+//     w = wh + wl + ew   (after a power-of-two scaling of each output row, undone in the epilogue)
 //     x * w  ~  xh*wh + xh*wl + xl*wh                                (the dropped xl*wl is 2^-22 of the product)
 //
 // Every fp16 x fp16 product is exact in fp32 and the sums run in fp32 accumulators, so the result carries the rounding of an
@@ -12,12 +13,14 @@
 // cycles instead of 8 x 64 on a SIMD's matrix pipe (5.3x fewer; against the Winograd forms 2.5..3.4x fewer), which turns every
 // conv of the train step from matrix-bound into HBM-bound.
 //
-// Range: fp16 holds |v| < 65504 and loses relative precision below 6.1e-5.  Weights are scaled per output row at pack time
-// (row maximum -> [2^14, 2^15)), so their split is always at full precision.  Activations are taken as they are: tiles are
-// clamped to +-65000 before the split (no infinities), and an element below 2^-3 keeps an ABSOLUTE error of <= 2^-25 in its
-// low term -- relative to tensors of magnitude O(1), which is what reaches these launches (post-ReLU activations, BatchNorm
-// outputs), that is below fp32's own rounding.  Gradient operands (backward-data) span any range: the engine passes their
-// power-of-two pre-scale in `x_scale` (see nef_conv_args) -- exact, undone in the epilogue.
+// Range: fp16 holds |v| < 65504 and loses relative precision below 6.1e-5 (absolute 2^-25 below it).  Weights are scaled per
+// output row at pack time (row maximum -> [2^14, 2^15)), so their split is always at full precision.  Activations and gradients
+// are scaled by ONE power of two per launch, derived from the magnitude the call site's previous launch measured (x_amax ->
+// [2^8, 2^9); ops.py: amax_roll, H2_HEADROOM = 64 x of growth per pass before anything is clamped); tiles are clamped to
+// +-65000 / scale before the split (no infinities) and a launch that had to clamp counts itself in x_clamped -- the host side
+// skips the train step that contains it (nef_h2_taint).  Elements more than 2^11 below the tensor's largest keep an ABSOLUTE
+// error of <= 2^-25 / scale instead of a relative one: 2^-34 of the largest element at worst, below fp32's own rounding of a
+// dot product that contains that element, but NOT a per-element relative bound (tests: test_conv_h2_operand_distributions).
 //
 // Tiling: one workgroup = 128 (TM = 2; 64 with TM = 1) output channels x 256 outputs of one sample and group, 4 waves as
 // 2 (co) x 2 (t), a wave owns 32 TM x 128 = TM x 4 accumulator tiles of 32 x 32.  MFMA column n of t-tile j is output t = 4 n + j, so a lane ends up with FOUR
@@ -259,8 +262,8 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
     }
     const int64_t soff = (int64_t)b0 * a.sc_bs + (int64_t)g * a.sc_gs;
     // input scale (an exact power of two, undone in the epilogue): from the magnitude this operand had at the call site's previous
-    // launch (*x_amax -> [2^8, 2^9): room for a 128x jump before anything is clamped, full precision for elements within 2^-9 of the
-    // largest), else the caller's x_scale, else 1
+    // launch (*x_amax -> [2^8, 2^9): with ops.amax_roll's follow-up rule, room for 64 x of growth since that launch before anything
+    // is clamped; full precision for elements within 2^-9 of the largest), else the caller's x_scale, else 1
     float xs_ = a.x_scale != 0.f ? a.x_scale : 1.f;
     if (a.x_amax) {
         const float m_ = a.x_amax[0];

@@ -1,4 +1,4 @@
-// conv_h2w.hip -- the weight gradient of the grouped 1-D convolutions (K = 3, K = 7) on exact fp16 splits of BOTH fp32
+// conv_h2w.hip -- the weight gradient of the grouped 1-D convolutions (K = 3, K = 7) on two-term fp16 splits (fp32-class: 22..23 bits, block-scaled) of BOTH fp32
 // operands (see conv_h2.hip for the arithmetic: x = xh + xl, gy = gh + gl, three v_mfma_f32_32x32x16_f16 per product --
 // gh*xh + gh*xl + gl*xh -- fp32 accumulation):
 //

@@ -1166,13 +1166,23 @@ __global__ void loss_bwd_kernel(const float* __restrict__ pred, const float* __r
 // torch.optim.SGD(momentum)                                 (codes/solver/optim_scheduler.py:10)
 // ------------------------------------------------------------------------------------------------
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, int64_t n,
-                           float lr, float mu, float gscale, int first) {
+                           float lr, float mu, float gscale, int first, const float* __restrict__ skip, int32_t* skipped) {
+    if (skip && skip[0] > 0.f) {      // a tainted step (nef_h2_taint): parameters and momentum stay as they are
+        if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gv = g[i] * gscale;
         const float bv = first ? gv : fmaf(mu, buf[i], gv);
         buf[i] = bv;
         p[i] = p[i] - lr * bv;
     }
+}
+
+__global__ void h2_taint_kernel(const int32_t* __restrict__ total, int32_t* __restrict__ mark, float* __restrict__ out) {
+    const int32_t t = total[0];
+    out[0] = (float)(t - mark[0]);
+    mark[0] = t;
 }
 
 }  // namespace
@@ -1792,12 +1802,19 @@ int nef_loss_bwd(const float* pred, const float* pred_p, const float* pred_l, co
 }
 
 int nef_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float gscale, int first_step,
-                     nef_stream_t stream) {
+                     const float* skip_if_positive, int32_t* skipped, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(p && g && buf, NEF_E_NULL);
     NEF_REQUIRE(n > 0, NEF_E_SHAPE);
     hipLaunchKernelGGL(sgd_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, p, g, buf, n, lr, mu, gscale,
-                       first_step);
+                       first_step, skip_if_positive, skipped);
+    return nef_launch_status();
+}
+
+int nef_h2_taint(const int32_t* clamped_total, int32_t* mark, float* out, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(clamped_total && mark && out, NEF_E_NULL);
+    hipLaunchKernelGGL(h2_taint_kernel, dim3(1), dim3(1), 0, NEF_ST, clamped_total, mark, out);
     return nef_launch_status();
 }
 

@@ -558,6 +558,8 @@ def sweep_eval_h(P, Bf, latent, query_thetas, pair_budget=16384):
 def gen_ecg(P, Bf, z1, z2b, query_thetas, rois, chunk=8, half=False):
     """model_nefnet.py:196-218 (always eval-mode BatchNorm)."""
     V = z1.shape[1] // 128
+    ops.BATCH_HINT = z1.shape[0]      # as forward(): the kernel choice follows THIS call's batch, not whichever pass ran last
+    ops.amax_roll()                   # ... and the split-fp16 convs of the sweep start from the scales their last sweep left
     z2r = ops.roi_unpool_fwd(z2b.contiguous(), rois, z1.shape[2])
     latent = ops.lead_mean(z1, z2r, V)
     if half:

@@ -62,7 +62,7 @@ class GraphedTrainStep:
                 opt._build(0, params)
                 fl = opt._flat[0]
             self.live = live
-            self.flat_p, self.flat_g, self.flat_buf = fl["p"], fl["g"], fl["buf"]
+            self.flat_p, self.flat_g, self.flat_buf, self.flat_g_all = fl["p"], fl["g"], fl["buf"], fl["g_all"]
             return
         if self.live == live and self.flat_p is not None and all(
                 named[k].data.data_ptr() >= self.flat_p.data_ptr() and
@@ -73,7 +73,8 @@ class GraphedTrainStep:
         n = sum(named[k].numel() for k in live)
         dev = self.data.device
         self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)
-        self.flat_g = torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat_g_all = torch.zeros(n + 1, device=dev, dtype=torch.float32)      # [taint word | gradients] (FusedSGD._build)
+        self.flat_g = self.flat_g_all[1:]
         self.flat_buf = torch.zeros(n, device=dev, dtype=torch.float32)
         if old_buf is not None and old_live == live:       # parameters were re-pointed from outside: keep the momentum
             self.flat_buf.copy_(old_buf)
@@ -91,7 +92,7 @@ class GraphedTrainStep:
         m = self.model
         P = {k: v.detach() for k, v in m.named_parameters()}
         drop = engine.DropCfg(True, m.dropout_p, m.dropout_masks, seed=0, seed_dev=self.seed_dev)
-        with ops.amax_scope(m._nef_scope):
+        with ops.amax_scope((m._nef_scope, True)):        # the train-mode call sites of the model (Model_nefnet._engine_fwd)
             outs, sv = engine.forward(P, dict(m.named_buffers()), self.data, self.in_theta, self.q_theta, self.rois,
                                       phase="train", training=True, drop=drop, lead_choice=self.choice_dev, save=True,
                                       status=self.status)
@@ -101,11 +102,13 @@ class GraphedTrainStep:
             return engine.backward(P, sv, g3)
 
     def _sgd(self):
-        ops.sgd_momentum(self.flat_p, self.flat_g, self.flat_buf, self.lr, self.mu, 1.0 / self.world, False)
+        ops.sgd_momentum(self.flat_p, self.flat_g, self.flat_buf, self.lr, self.mu, 1.0 / self.world, False,
+                         skip=self.flat_g_all[:1])
 
     def _body(self):
         grads = self._fwd_bwd()
         torch.cat([grads[k].reshape(-1) for k in self.live], out=self.flat_g)
+        ops.h2_taint(self.flat_g_all[:1])      # this step's clamped split-fp16 launches: the update is skipped (on every rank)
         if self.world == 1:
             self._sgd()
 
@@ -218,6 +221,7 @@ class GraphedTrainStep:
 
     def __call__(self, data, in_theta, q_theta, rois, target):
         """One train step; returns the device tensor [loss, f0*l1, f1*l2, f2*l3] (valid in stream order)."""
+        self.model._check_inputs(data, rois)       # what Model_nefnet.forward rejects (float rois, L % 4, CPU tensors) is rejected here too
         if self.optimizer is not None:
             g = self.optimizer.param_groups[0]
             if float(g["lr"]) != self.lr or float(g["momentum"]) != self.mu:      # a scheduler stepped: re-capture
@@ -226,6 +230,10 @@ class GraphedTrainStep:
             fl = self.optimizer._flat.get(0)
             if self.flat_p is not None and (fl is None or fl["p"] is not self.flat_p):   # e.g. optimizer.load_state_dict
                 self.slots.clear()
+        gen = ops.amax_generation(data.device)
+        if getattr(self, "_amax_gen", gen) != gen:        # the split-fp16 site table started over: captured launches hold stale slots
+            self.slots.clear()
+        self._amax_gen = gen
         if getattr(self, "_scope", None) != self.model._nef_scope:       # the model loaded other weights: its split-fp16 call sites
             self._scope = self.model._nef_scope                            # start over (ops.amax_scope), and the captures hold the old slots
             self.slots.clear()
@@ -244,7 +252,7 @@ class GraphedTrainStep:
             if parallel.TIMING is not None:        # bench.py: the whole flat all-reduce is exposed behind the replay
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            dist.all_reduce(self.flat_g)
+            dist.all_reduce(self.flat_g_all)
             if ev is not None:
                 ev[1].record()
                 parallel.TIMING.append(ev)

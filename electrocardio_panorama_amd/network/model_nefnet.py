@@ -74,11 +74,14 @@ class Model_nefnet(nn.Module):
     _ENGINE = (engine.forward, engine.backward)
 
     def _engine_fwd(self, *args, **kw):
-        with ops.amax_scope(self._nef_scope):       # the split-fp16 convs keep their operand magnitudes per model (ops.py)
+        # the split-fp16 convs keep their operand magnitudes per model AND per mode (ops.py): train-mode and eval-mode passes see
+        # different activations (batch vs running BatchNorm statistics, dropout), and a scale that follows every 2 x change
+        # (ops.H2_FOLLOW_UP) would otherwise flip between them -- a repeated train step would not find the scales it left
+        with ops.amax_scope((self._nef_scope, bool(kw.get("training", False)))):
             return self._ENGINE[0](*args, **kw)
 
     def _engine_bwd(self, *args, **kw):
-        with ops.amax_scope(self._nef_scope):
+        with ops.amax_scope((self._nef_scope, True)):
             return self._ENGINE[1](*args, **kw)
 
     def load_state_dict(self, *args, **kw):
@@ -204,7 +207,7 @@ class Model_nefnet(nn.Module):
 
     def gen_ecg(self, z1, z2, query_theta, rois):
         self.eval()
-        with torch.no_grad():
+        with torch.no_grad(), ops.amax_scope((self._nef_scope, False)):      # the sweep's split-fp16 convs keep their call sites (no measuring launch per call)
             return engine.gen_ecg(self._params_by_name(), self._buffers_by_name(), self._f32(z1), self._f32(z2),
                                   self._f32(query_theta), rois.detach().to(torch.int64).contiguous(),
                                   half=self._half_sweep())

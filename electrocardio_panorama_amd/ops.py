@@ -220,7 +220,7 @@ WINO_BW7 = os.environ.get("NEF_BW7_F42", "1") == "1" and _WV not in ("1", "2")
 _WINO_PLANES = {(1, 3): 4, (1, 7): 10, (2, 3): 6, (2, 7): 13}
 
 
-# Split-fp16 direct convolution (csrc/conv_h2.hip, conv args wino = 3): both fp32 operands split exactly into two fp16 terms,
+# Split-fp16 direct convolution (csrc/conv_h2.hip, conv args wino = 3): both fp32 operands split into two fp16 terms each (22-23 bits kept),
 # three fp16 matrix instructions per 16 channels and tap, fp32 accumulation -- fp32-class results at 3/16 of the fp32 matrix
 # instructions' pipe time.  NEF_H2=0 keeps the fp32 Winograd forms; NEF_H2=1 takes it wherever the shape allows
 # (128-channel output tiles, 16-channel input chunks, T even and >= 128; K = 7 without an input prologue).
@@ -268,8 +268,15 @@ def h2_ok(K, Cin_g, Cout_g, T_out, pro=0):
 # Input magnitudes of the split-fp16 launches, per call site (= per weight tensor and direction): `cur` is what a launch derives
 # its power-of-two input scale from, `nxt` is what it max-accumulates its own operand's magnitude into; amax_roll() -- once per
 # forward pass -- moves nxt into cur.  A site's FIRST launch runs twice: once to measure, once with the measured scale.  Nothing is
-# read back by the host, so the launches stay capturable; a site whose operand grows more than 16x from one step to the next
-# gets its largest elements clamped at 65000 / scale for that one step (conv_h2.hip).
+# read back by the host, so the launches stay capturable.
+# Range, in ONE place (bench.py and Solver quote these): the scale puts `cur` at [2^8, 2^9); amax_roll follows a
+# measurement UP as soon as it exceeds H2_FOLLOW_UP x cur and DOWN only once it is H2_FOLLOW_DOWN x smaller (sticky: repeated
+# passes split their operands identically), so the operand a launch meets is below 2^10 as long as it grew less than
+# H2_HEADROOM = 2^16 / 2^10 = 64 x since the previous pass.  Beyond that the largest elements are clamped at 65000 / scale, the
+# launch counts itself in `clamped`, and the train step that contains it is SKIPPED on the device (h2_taint / sgd_momentum).
+H2_FOLLOW_UP = 2.0
+H2_FOLLOW_DOWN = 64.0
+H2_HEADROOM = 64
 AMAX_SITES = 16384
 _AMAX = {}
 # A call site = (scope, weight address, direction, role, batch, length).  The scope is the owning model's token
@@ -298,20 +305,44 @@ def _amax_state(dev):
     if st is None:
         st = _AMAX[dev] = dict(cur=torch.zeros(AMAX_SITES, device=dev, dtype=torch.float32),
                                nxt=torch.zeros(AMAX_SITES, device=dev, dtype=torch.float32), index={}, ready=set(), used=False, occ={}, n=0,
-                               clamped=torch.zeros(1, device=dev, dtype=torch.int32))
+                               clamped=torch.zeros(1, device=dev, dtype=torch.int32),       # waves that clamped (device total, never reset)
+                               mark=torch.zeros(1, device=dev, dtype=torch.int32),          # ... at the last step boundary (h2_taint)
+                               skipped=torch.zeros(1, device=dev, dtype=torch.int32),       # train steps skipped because of a clamp
+                               seen=0, seen_skipped=0)                                       # ... as of the host's last h2_clamped() / h2_skipped()
     return st
 
 
 def h2_clamped(reset=True):
     """Waves of split-fp16 launches (sited ones: measuring launches are not counted) that had to clamp an operand element at
-    fp16's range since the last call -- an operand grew by more than ~128x from one pass to the next, so those launches' results
-    are off (the next pass has followed).  Reading synchronises: call it at a logging interval, not per step."""
+    fp16's range since the last call -- an operand grew by more than H2_HEADROOM x from one pass to the next, so those launches'
+    results are off (the next pass has followed; a train step that contains one is skipped, see h2_taint).  Reading
+    synchronises: call it at a logging interval, not per step."""
     n = 0
     for st in _AMAX.values():
-        n += int(st["clamped"].item())
+        tot = int(st["clamped"].item())
+        n += tot - st["seen"]
         if reset:
-            st["clamped"].zero_()
+            st["seen"] = tot
     return n
+
+
+def h2_skipped(reset=True):
+    """Train steps whose parameter update was skipped on the device because a split-fp16 launch of the step clamped (on this or,
+    data parallel, on any rank) since the last call.  Synchronises like h2_clamped()."""
+    n = 0
+    for st in _AMAX.values():
+        tot = int(st["skipped"].item())
+        n += tot - st["seen_skipped"]
+        if reset:
+            st["seen_skipped"] = tot
+    return n
+
+
+def h2_taint(out):
+    """out[0] (a one-element fp32 device view, e.g. the word in front of the flat gradient buffer) = the number of waves that clamped
+    since the previous call; stream-ordered, capturable.  The optimiser passes the word to sgd_momentum(skip=...)."""
+    st = _amax_state(out.device)
+    _lib.check(_lib.load().nef_h2_taint(_p(st["clamped"]), _p(st["mark"]), _p(out), _stream()), "nef_h2_taint")
 
 
 def _amax_index(st, site, n):
@@ -322,6 +353,7 @@ def _amax_index(st, site, n):
             assert not torch.cuda.is_current_stream_capturing()
             st["index"].clear(), st["ready"].clear(), st["cur"].zero_(), st["nxt"].zero_()
             st["n"] = 0
+            st["gen"] = st.get("gen", 0) + 1       # captured graphs hold the old slots: GraphedTrainStep re-captures (amax_generation)
         i = st["index"][site] = st["n"]
         st["n"] += n
     return i
@@ -329,15 +361,16 @@ def _amax_index(st, site, n):
 
 def amax_roll():
     """Once per pass (stream-ordered, a handful of tiny launches): a site's reference magnitude `cur` follows what its last launch
-    measured (`nxt`) only when that left the window [cur / 64, 64 cur] -- the scale is STICKY, so passes over data of similar
-    magnitude (a repeated step, train after eval, eager and captured steps of one run) split their operands identically and
-    stay bit-reproducible; inside the window nothing is clamped (the scale puts `cur` at 2^8..2^9, fp16 ends at 2^16) and elements within
-    2^-9 / 64 of the largest keep full precision."""
+    measured (`nxt`) UP as soon as that exceeds H2_FOLLOW_UP x cur and DOWN once it fell below cur / H2_FOLLOW_DOWN -- the scale is
+    STICKY inside that window, so passes over data of similar magnitude (a repeated step, train after eval, eager and captured
+    steps of one run) split their operands identically and stay bit-reproducible, and never lags a growing operand by more than
+    H2_FOLLOW_UP: H2_HEADROOM x of growth per pass is absorbed whatever the history (round 4 followed up only at 64 x, which left
+    2 x in the worst case).  Elements within 2^-9 / H2_FOLLOW_DOWN of the largest keep full precision."""
     for st in _AMAX.values():
         st["occ"].clear()
         if st["used"]:
             cur, nxt = st["cur"], st["nxt"]
-            upd = (nxt > 0) & ((cur <= 0) | (nxt > 64.0 * cur) | (nxt * 64.0 < cur))
+            upd = (nxt > 0) & ((cur <= 0) | (nxt > H2_FOLLOW_UP * cur) | (nxt * H2_FOLLOW_DOWN < cur))
             if _H2_AMAX == "follow":
                 upd = nxt > 0
             torch.where(upd, nxt, cur, out=cur)
@@ -345,10 +378,15 @@ def amax_roll():
             st["used"] = False
 
 
+def amax_generation(dev):
+    """Bumped whenever the site table of `dev` started over: pointers a captured launch baked in may now belong to other sites."""
+    return _amax_state(dev).get("gen", 0)
+
+
 def amax_move(old_ptr, new_ptr):
     """A weight tensor moved (an optimiser re-pointed its parameters into a flat buffer): its call sites keep their history."""
     for st in _AMAX.values():
-        for site in [k for k in st["index"] if k is not None and k[1][0] == old_ptr]:
+        for site in [k for k in st["index"] if k[0] is not None and k[1][0] == old_ptr]:
             st["index"][(site[0], (new_ptr, site[1][1])) + site[2:]] = st["index"].pop(site)
 
 
@@ -520,7 +558,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
             occ = st["occ"]
             k = occ[(AMAX_SCOPE, ws, role, xv.B, T_out)] = occ.get((AMAX_SCOPE, ws, role, xv.B, T_out), 0) + 1
             site = (AMAX_SCOPE, ws, role, xv.B, T_out, 0 if getattr(wp, "nef_shared", False) else k)
-        i = _amax_index(st, site, 1)
+        i = _amax_index(st, site if site is not None else (None, "conv"), 1)      # (unscoped launches: a slot of their own, never a site's)
         a.x_amax_next = st["nxt"].data_ptr() + 4 * i
         if i not in st["ready"] or site is None:      # first launch of the site (or no scope): measure, then run
             if torch.cuda.is_current_stream_capturing():
@@ -589,7 +627,7 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None, site=None, h
                 base = (AMAX_SCOPE, (site, "w"), "conv_bwd_weight", B, T)
                 k = occ[base] = occ.get(base, 0) + 1
                 key = base + (k,)
-            i = _amax_index(st, key, 2)          # slots i (x) and i + 1 (gy)
+            i = _amax_index(st, key if key is not None else (None, "bww"), 2)          # slots i (x) and i + 1 (gy); unscoped launches: a pair of their own
             nxt = st["nxt"].data_ptr() + 4 * i
             if i not in st["ready"] or key is None:
                 if torch.cuda.is_current_stream_capturing():
@@ -1245,11 +1283,15 @@ def view_metrics(pred, gt, rois=None):
     return psnr, ssim
 
 
-def sgd_momentum(p, g, buf, lr, mu, gscale, first_step):
+def sgd_momentum(p, g, buf, lr, mu, gscale, first_step, skip=None):
+    """`skip`: a one-element fp32 device view (h2_taint's output, summed over the ranks): > 0 leaves p and buf untouched and counts
+    the step in h2_skipped()."""
     L = _lib.load()
-    _chk(p), _chk(g), _chk(buf)
+    _chk(p), _chk(buf)
+    assert g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()
     ev = _hbm("sgd_momentum", p, p, g, buf, buf)
-    _lib.check(L.nef_sgd_momentum(_p(p), _p(g), _p(buf), p.numel(), lr, mu, gscale, int(first_step), _stream()),
+    sk = _p(_amax_state(p.device)["skipped"]) if skip is not None else None
+    _lib.check(L.nef_sgd_momentum(_p(p), _p(g), _p(buf), p.numel(), lr, mu, gscale, int(first_step), _p(skip), sk, _stream()),
                "nef_sgd_momentum")
     _done(ev)
 

@@ -35,8 +35,10 @@ class FusedSGD(torch.optim.Optimizer):
                 flat_b[off:off + k].copy_(st["momentum_buffer"].reshape(-1))
             st["momentum_buffer"] = flat_b[off:off + k].view_as(p.data)
             off += k
-        self._flat[gi] = dict(ids=[id(p) for p in live], params=live, p=flat_p, buf=flat_b,
-                              g=torch.empty(n, device=dev, dtype=torch.float32))
+        # gradients: [taint word | n gradients] -- the word in front (ops.h2_taint: clamps of this step's split-fp16 launches) is
+        # summed by the same all-reduce as the gradients, so a clamp on any rank makes every rank skip the update
+        g_all = torch.zeros(n + 1, device=dev, dtype=torch.float32)
+        self._flat[gi] = dict(ids=[id(p) for p in live], params=live, p=flat_p, buf=flat_b, g_all=g_all, g=g_all[1:])
 
     def load_state_dict(self, state_dict):
         """The loaded momentum buffers replace the flat one: drop the flat views so the next step() re-imports them."""
@@ -44,7 +46,7 @@ class FusedSGD(torch.optim.Optimizer):
         self._flat = {}
 
     @staticmethod
-    def _reduce(live, flat, world):
+    def _reduce(live, flat, world, flat_all=None):
         """Sum of the flat gradient buffer across ranks (RCCL over xGMI).  When engine.backward already started the
         all-reduce of the gradients that were final early (parallel.early_reduce: a SUFFIX of the parameter order --
         everything behind the per-lead encoder), only the encoder bucket is reduced here and the early bucket's result
@@ -68,7 +70,9 @@ class FusedSGD(torch.optim.Optimizer):
             if parallel.TIMING is not None and world > 1:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            reduce_flat_grads([p.grad for p in live], flat)             # one RCCL sum all-reduce over xGMI
+            torch.cat([p.grad.reshape(-1) for p in live], out=flat)
+            if world > 1:
+                dist.all_reduce(flat if flat_all is None else flat_all)      # one RCCL sum all-reduce over xGMI (+ the taint word)
             if ev is not None:
                 ev[1].record()
                 parallel.TIMING.append(ev)
@@ -80,7 +84,9 @@ class FusedSGD(torch.optim.Optimizer):
         if parallel.TIMING is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        if k:
+        if flat_all is not None:
+            dist.all_reduce(flat_all[:1 + split])       # the encoder bucket, with the taint word in front of it
+        elif k:
             dist.all_reduce(flat[:split])
         early["work"].wait()                  # the launching stream now waits for the early bucket's collective
         if ev is not None:
@@ -101,10 +107,11 @@ class FusedSGD(torch.optim.Optimizer):
                     p.data.data_ptr() >= fl["p"].data_ptr() + fl["p"].numel() * 4 for p in live):
                 self._build(gi, live)
                 fl = self._flat[gi]
-            self._reduce(live, fl["g"], world)
-            # buf starts at zero, so mu*buf + g reproduces torch's first-step "buf = g" exactly
+            ops.h2_taint(fl["g_all"][:1])          # clamps of this step's split-fp16 launches -> the word in front of the gradients
+            self._reduce(live, fl["g"], world, fl["g_all"])
+            # buf starts at zero, so mu*buf + g reproduces torch's first-step "buf = g" exactly; a tainted step is skipped
             ops.sgd_momentum(fl["p"], fl["g"], fl["buf"], float(group["lr"]), float(group["momentum"]), 1.0 / world,
-                             False)
+                             False, skip=fl["g_all"][:1])
         return None
 
 

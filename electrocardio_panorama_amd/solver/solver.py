@@ -171,10 +171,6 @@ class Solver:
                 msg += '\npsnr_gen: {}, psnr_reg: {}, ssim_gen:{}, ssim_reg:{}'.format(psnr_gen, psnr_reg, ssim_gen, ssim_reg)
             if self.summary_writer is not None:
                 self.write_tensorboardx(scalars, names, epoch)
-            clamped = ops.h2_clamped()        # once per epoch (it synchronises): split-fp16 launches that ran out of fp16 range
-            if clamped:
-                msg += ('\nWARNING: {} waves of split-fp16 conv launches clamped an operand this epoch (a tensor grew more '
-                        'than ~128x between two consecutive steps); NEF_H2=0 runs the fp32 kernels'.format(clamped))
             print(msg)
             save_arguments['psnr_gen'] = psnr_gen
             save_arguments['psnr_reg'] = psnr_reg
@@ -246,6 +242,25 @@ class Solver:
             st = self._graph_stepper = GraphedTrainStep(self.model, self.cfg, optimizer=optim)
         return st
 
+    @staticmethod
+    def _check_h2_range(phase, optim):
+        """The split-fp16 convs clamp an operand that grew more than ops.H2_HEADROOM x between two consecutive passes (fp16 ends
+        at 65504; the reference's fp32 nn.Conv1d, model_nefnet.py:18-21, has no such limit).  A train step that contained such a
+        launch was SKIPPED on the device when the optimiser is FusedSGD (ops.h2_taint): that is reported; clamps nothing
+        protected against -- a test-phase forward, another optimiser -- mean wrong results were used: raise, unless
+        NEF_H2_ALLOW_CLAMP=1 (then warn).  NEF_H2=0 runs the fp32 kernels instead."""
+        clamped, skipped = ops.h2_clamped(), ops.h2_skipped()
+        if not clamped and not skipped:
+            return
+        msg = ('{} waves of split-fp16 conv launches clamped an operand in this {} phase (a tensor grew more than {}x between two '
+               'consecutive passes); {} train step(s) were skipped on the device'.format(clamped, phase, ops.H2_HEADROOM, skipped))
+        protected = phase == 'train' and hasattr(optim, '_flat') and skipped > 0
+        if protected or os.environ.get('NEF_H2_ALLOW_CLAMP') == '1':
+            print('WARNING: ' + msg + ('' if protected else ' -- results of those launches are wrong (NEF_H2_ALLOW_CLAMP=1)'))
+            return
+        raise RuntimeError(msg + '; their results are wrong.  Set NEF_H2=0 (fp32 kernels) for data of this dynamic range, or '
+                                 'NEF_H2_ALLOW_CLAMP=1 to continue')
+
     def run_one_epoch(self, dl, phase, optim=None, collect_views=None):
         """solver.py:139-246.  `collect_views` (default: the Solver's setting) = also return the per-view host lists the
         reference returns (inputs, ground truth, predictions, rois); train() / val() only consume losses and metrics and
@@ -298,6 +313,7 @@ class Solver:
                 in_s.add(source_data)
                 rois_s.add(rois)
         losses = [a.tolist() for a in losses_s.arrays()]
+        self._check_h2_range(phase, optim)       # same cadence as the loss read-back above: the device has been waited for anyway
         if phase == 'train':
             return losses, gt_s.rows(), pred_s.rows(), in_s.rows(), [], rois_s.rows()
         mertics_all, mertics_gen_singlelead = [], []

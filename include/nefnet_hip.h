@@ -444,7 +444,16 @@ int nef_loss_bwd(const float* pred, const float* pred_p, const float* pred_l, co
  * first step buf = g, afterwards buf = mu*buf + g; p -= lr*buf).  g is multiplied by gscale first
  * (1/world_size after an all-reduce sum). */
 int nef_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float gscale,
-                     int first_step, nef_stream_t stream);
+                     int first_step, const float* skip_if_positive /* NULL, or a device word: > 0 = leave p and buf as they are
+                     (a step whose gradients are tainted, see nef_h2_taint) */, int32_t* skipped /* NULL, or a device counter of
+                     skipped steps */, nef_stream_t stream);
+/* The split-fp16 convolutions (conv args wino = 3, nef_conv_bwd_weight_h2) count the waves that had to clamp an operand at fp16's
+ * range in a device counter (x_clamped); such a launch's results are wrong.  nef_h2_taint writes out[0] = (float)(*clamped_total -
+ * *mark) -- the clamps since the previous call -- and sets *mark = *clamped_total: called once per train step behind the backward
+ * pass, its output word travels with the gradients (summed by the data-parallel all-reduce, so every rank sees a clamp on any rank)
+ * and makes nef_sgd_momentum skip the update.  No counterpart in the reference (its fp32 nn.Conv1d cannot overflow at 65504,
+ * codes/network/model_nefnet.py:18-21); capturable, nothing is read by the host. */
+int nef_h2_taint(const int32_t* clamped_total, int32_t* mark, float* out, nef_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Test-phase metrics on the device.  Replaces PSNR / SSIM of codes/utils/mertic.py:7-32 as called from

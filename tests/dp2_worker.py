@@ -159,5 +159,32 @@ assert sol_g._graph_stepper is not None and sol_g._graph_stepper.calls == 3
 np.savez(os.path.join(out_dir, f"graph_rank{rank}.npz"), params_3=flat_params(sol_g.model),
          losses=np.array(res_g[0] + res_g2[0]))
 dist.barrier()
+
+# ---------------------------------------------------------------- part 4: a split-fp16 launch clamps on ONE rank
+# (simulated: rank 1 bumps its device clamp counter -- exactly what conv_h2_kernel's x_clamped does).  The taint word travels in
+# front of the flat gradient buffer through the same all-reduce, so BOTH ranks skip the update: parameters and momentum stay as
+# they were, bit-identical across ranks, and every rank's h2_skipped() says 1 -- eager step, then a replayed (graphed) step
+from electrocardio_panorama_amd import ops                                   # noqa: E402
+ops.h2_clamped(), ops.h2_skipped()
+taint = {}
+for label, solver, opt in (("eager", sol, optim), ("graph", sol_g, optim_g)):
+    before = flat_params(solver.model)
+    mom_before = opt._flat[0]["buf"].clone()
+    if rank == 1:
+        ops._amax_state(dev)["clamped"] += 3
+    try:
+        solver.run_one_epoch(parallel.ShardedLoader([full]), "train", opt, collect_views=False)
+        warned = True                       # FusedSGD skipped the step: Solver only warns
+    except RuntimeError:
+        warned = False
+    taint[label + "_unchanged"] = bool(np.array_equal(before, flat_params(solver.model)) and torch.equal(mom_before, opt._flat[0]["buf"]))
+    taint[label + "_warned"] = warned
+    taint[label + "_skipped"] = int(ops._amax_state(dev)["skipped"].item())
+    # the step after it is a normal step again
+    solver.run_one_epoch(parallel.ShardedLoader([full]), "train", opt, collect_views=False)
+    taint[label + "_resumed"] = bool(not np.array_equal(before, flat_params(solver.model)))
+    taint[label + "_params"] = flat_params(solver.model)
+np.savez(os.path.join(out_dir, f"taint_rank{rank}.npz"), **{k: np.array(v) for k, v in taint.items()})
+dist.barrier()
 dist.destroy_process_group()
 print("DP2_OK", rank)

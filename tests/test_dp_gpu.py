@@ -175,6 +175,17 @@ def test_world2_graphed_solver_is_bit_identical_to_eager(dp_run):
     assert np.array_equal(a["params_3"], b["params_3"])
 
 
+def test_world2_clamp_on_one_rank_skips_the_step_on_both(dp_run):
+    """A split-fp16 launch that clamps on ONE rank taints the step on EVERY rank (the taint word is all-reduced in front of the
+    gradients): nobody applies the update, parameters stay bit-identical, the next step runs normally -- eager and graphed."""
+    a, b = (np.load(os.path.join(dp_run, f"taint_rank{r}.npz")) for r in range(2))
+    for z in (a, b):
+        for label in ("eager", "graph"):
+            assert bool(z[label + "_unchanged"]) and bool(z[label + "_warned"]) and bool(z[label + "_resumed"]), label
+        assert int(z["eager_skipped"]) == 1 and int(z["graph_skipped"]) == 2
+    assert np.array_equal(a["eager_params"], b["eager_params"]) and np.array_equal(a["graph_params"], b["graph_params"])
+
+
 def test_bench_two_ranks_prints_one_json_line():
     """bench.py's torchrun branch (barrier, max-over-ranks timing, whole-job value) with world_size 2."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
