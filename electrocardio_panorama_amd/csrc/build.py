@@ -8,10 +8,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SOURCES = ["conv_mfma.hip", "conv_h2.hip", "conv_h2p.hip", "conv_h2w.hip", "conv_bww_glds.hip", "stem.hip", "elementwise.hip", "roi.hip", "convt_theta.hip", "pano_h.hip", "metrics.hip"]
 LIB = os.path.join(HERE, "libnefnet_hip.so")
-# per-source extra flags.  conv_h2.hip: no SLP vectorisation -- the packed-fp32 instructions it creates in the epilogue
-# (v_pk_fma_f32 with op_sel on registers a ds_read_b128 has just returned) intermittently produced 0.0 in lanes 48..63 on a loaded
-# chip ("split-fp16 convolution"); scalar fp32 is also what the matrix-core guide recommends beside MFMAs
-EXTRA_FLAGS = {"conv_h2.hip": ["-fno-slp-vectorize"], "conv_h2p.hip": ["-fno-slp-vectorize"], "conv_h2w.hip": ["-fno-slp-vectorize"]}
+# per-source extra flags.  Every source that issues matrix instructions is built WITHOUT SLP vectorisation: the packed-fp32
+# instructions it creates (v_pk_fma_f32 with op_sel on registers a ds_read_b128 has just returned, in conv_h2.hip's epilogue)
+# intermittently produced 0.0 in lanes 48..63 on a loaded chip (profiles/r05_pk_fp32_hazard.md: not reproduced
+# in isolation, no root cause) -- and the matrix-core guide lists packed fp32 beside MFMAs as an anti-lever anyway.  Round 5
+# extended the flag from the two split-fp16 files to all of them (conv_mfma.hip alone had 10 k such instructions).
+_NO_SLP = ["-fno-slp-vectorize"]
+EXTRA_FLAGS = {s: _NO_SLP for s in ("conv_mfma.hip", "conv_h2.hip", "conv_h2p.hip", "conv_h2w.hip", "conv_bww_glds.hip", "stem.hip",
+                                    "pano_h.hip")}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include"), "-I", HERE]
 
