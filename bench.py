@@ -373,10 +373,17 @@ def main():
                  0: "conv_fwd_kernel (direct, fp32)"}
 
         def price(tag, ms):
-            role, k_, g_, cig_, cog_, b_, t_ = tag
+            role, k_, g_, cig_, cog_, b_, t_ = tag[:7]
+            extra = tag[7] if len(tag) > 7 else ""
             f_ = 2.0 * b_ * g_ * cog_ * t_ * cig_ * k_
             ex32, ex16 = f_ * ops.EXEC_FRAC.get(tag, 1.0), f_ * ops.EXEC_FP16.get(tag, 0.0)
-            byts = 4.0 * b_ * g_ * (cig_ + cog_) * t_ + 4.0 * g_ * cig_ * cog_ * k_
+            # external operands at the resolution they are actually read at: behind the x2-upsampling prologue the input
+            # is the half-resolution tensor (round 4 priced it at full resolution); the BatchNorm-backward epilogue also reads the
+            # layer's BatchNorm input (half resolution where the upsampling sits in between)
+            t_in = t_ / 2 if extra.startswith("up") else t_
+            byts = 4.0 * b_ * g_ * (cig_ * t_in + cog_ * t_) + 4.0 * g_ * cig_ * cog_ * k_
+            if "bnb" in extra:
+                byts += 4.0 * b_ * g_ * cog_ * (t_ / 2 if extra.endswith("bnbup") else t_)
             if role != "conv_bwd_weight" and cig_ == cog_ and k_ == 7:
                 byts += 0.5 * 4.0 * b_ * g_ * cog_ * t_        # every second launch of an encoder block reads a residual / gate row
             fl_m = (ex32 / FP32_MFMA_PEAK_TFLOPS + ex16 / FP16_MFMA_PEAK_TFLOPS) / 1e9      # ms

@@ -586,6 +586,9 @@ def _head_bwd(P, sv, g_outs, grads, side, relu_z1=False):
     return gz1, gz2r
 
 
+EARLY_HOOK = None      # callable(P, grads, side) invoked instead of parallel.early_reduce at the early-bucket point of backward()
+
+
 def _latents_bwd(P, sv, gz1, gz2r, grads, side, z1_pre_gated=False, early=False):
     """Back through `_latents` (+ the segment un-pooling that follows it): encoder-side parameter gradients."""
     B, V, T = sv["B"], sv["V"], sv["T"]
@@ -614,8 +617,11 @@ def _latents_bwd(P, sv, gz1, gz2r, grads, side, z1_pre_gated=False, early=False)
     gW1, gb1 = side.run(lambda: ops.theta_mlp_bwd(sv["in_theta"], ge, 128), ge)
     grads["mlp1.weight"], grads["mlp1.bias"] = gW1, gb1
     if early:      # data parallel: everything but the encoder blocks' gradients is final -- start summing it across ranks now
-        from . import parallel
-        parallel.early_reduce(P, grads, getattr(side, "stream", None))
+        if EARLY_HOOK is not None:      # graph.GraphedTrainStep: the capture is cut in two here, the collective runs between the replays
+            EARLY_HOOK(P, grads, side)
+        else:
+            from . import parallel
+            parallel.early_reduce(P, grads, getattr(side, "stream", None))
     for i in (2, 1, 0):
         g = block_bwd(sv["blk_enc"][i], g, P, grads, side=side, pre_gated=True, gate_input=(i > 0))
     grads["W_encoder.conv1.weight"] = ops.stem_bwd_weight(sv["x"], P["W_encoder.conv1.weight"], g)

@@ -11,6 +11,10 @@ One graph (with its own static input buffers) is kept per input shape, so a fina
 replay instead of re-capturing; the flat parameter / gradient / momentum buffers are shared by all of them and survive
 every re-capture (shape change, learning-rate change).  `state_dict()` / `load_state_dict()` carry the momentum buffer
 for checkpoints.
+
+Data parallel (world > 1): the step is captured as TWO graphs cut at the early-bucket point of the backward pass; the all-reduce
+of the bucket that is final there runs between the replays, under the second graph (`_capture_split`; NEF_GRAPH_SPLIT=0 keeps one
+graph and one exposed all-reduce).
 """
 import random
 
@@ -45,6 +49,9 @@ class GraphedTrainStep:
         self.choice_dev = None
         self.calls = 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # data parallel: capture the step as two graphs with the early gradient bucket's all-reduce between them (_capture_split)
+        import os
+        self.split_capture = os.environ.get("NEF_GRAPH_SPLIT", "1") != "0"
 
     # -------------------------------------------------------------------------------------------------
     def _flatten(self, live):
@@ -112,6 +119,50 @@ class GraphedTrainStep:
         if self.world == 1:
             self._sgd()
 
+    def _capture_split(self):
+        """Data parallel: the step as TWO graphs, cut where engine.backward would start the early gradient bucket (everything
+        behind the per-lead encoder: a suffix of the parameter order, 71 % of the bytes at 3 leads).  Between the two replays the
+        suffix bucket's all-reduce is started on a side stream and runs under the second graph -- the encoder blocks' backward
+        pass, ~10 ms at configs[1] -- so that only the encoder bucket (+ the taint word in front of it) is summed behind the
+        replay: the overlap the eager path has had since round 3 (parallel.early_reduce), bit for bit the same buffer."""
+        import gc
+        gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        info = {}
+
+        def hook(P, grads, side):
+            side.join()                                      # nothing forked may be open when a capture ends
+            early = [k for k in self.live if grads.get(k) is not None]
+            k0 = len(self.live) - len(early)
+            if self.live[k0:] != early:
+                raise RuntimeError("early gradient bucket is not a suffix of the live parameters")
+            named = dict(self.model.named_parameters())
+            info["k0"], info["split"] = k0, sum(named[k].numel() for k in self.live[:k0])
+            torch.cat([grads[k].reshape(-1) for k in early], out=self.flat_g[info["split"]:])
+            gA.capture_end()
+            gB.capture_begin(pool=gA.pool())
+
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            gA.capture_begin()
+            engine.EARLY_HOOK = hook
+            try:
+                grads = self._fwd_bwd()
+            finally:
+                engine.EARLY_HOOK = None
+            if "split" not in info:
+                raise RuntimeError("engine.backward never reached its early-bucket point")
+            if info["k0"]:
+                torch.cat([grads[k].reshape(-1) for k in self.live[:info["k0"]]], out=self.flat_g[:info["split"]])
+            ops.h2_taint(self.flat_g_all[:1])
+            gB.capture_end()
+        torch.cuda.current_stream().wait_stream(cap)
+        self._comm = getattr(self, "_comm", None) or torch.cuda.Stream()
+        return (gA, gB, info["split"])
+
     def _use(self, slot):
         self.data, self.in_theta, self.q_theta, self.rois, self.target = (slot[k] for k in
                                                                           ("data", "in_theta", "q_theta", "rois", "target"))
@@ -150,8 +201,11 @@ class GraphedTrainStep:
         graph = torch.cuda.CUDAGraph()
         saved = {k: v.clone() for k, v in self.model.named_buffers()}
         p0, b0 = self.flat_p.clone(), self.flat_buf.clone()
-        with torch.cuda.graph(graph):
-            self._body()
+        if self.world > 1 and self.split_capture:
+            graph = self._capture_split()
+        else:
+            with torch.cuda.graph(graph):
+                self._body()
         # capture does not execute, but keep state exactly as before the capture regardless
         for k, v in self.model.named_buffers():
             v.copy_(saved[k])
@@ -245,16 +299,32 @@ class GraphedTrainStep:
             self._restore_momentum()
         self._use(slot)
         self._stage(data, in_theta, q_theta, rois, target, draw=False)
-        slot["graph"].replay()
-        if self.world > 1:
-            from . import parallel
-            ev = None
-            if parallel.TIMING is not None:        # bench.py: the whole flat all-reduce is exposed behind the replay
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-            dist.all_reduce(self.flat_g_all)
+        if self.world == 1:
+            slot["graph"].replay()
+            return self.losses
+        from . import parallel
+        timing = parallel.TIMING is not None       # bench.py: HIP events around what the launching stream waits for
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timing else None
+        if isinstance(slot["graph"], tuple):
+            gA, gB, split = slot["graph"]
+            gA.replay()
+            cur = torch.cuda.current_stream()
+            self._comm.wait_stream(cur)
+            with torch.cuda.stream(self._comm):        # the suffix bucket travels while graph B (the encoder's backward pass) runs
+                work = dist.all_reduce(self.flat_g[split:], async_op=True)
+            gB.replay()
             if ev is not None:
-                ev[1].record()
-                parallel.TIMING.append(ev)
-            self._sgd()
+                ev[0].record()
+            dist.all_reduce(self.flat_g_all[:1 + split])       # the encoder bucket, the taint word in front of it
+            work.wait()
+            cur.wait_stream(self._comm)
+        else:
+            slot["graph"].replay()
+            if ev is not None:
+                ev[0].record()
+            dist.all_reduce(self.flat_g_all)                   # one fully exposed all-reduce (NEF_GRAPH_SPLIT=0)
+        if ev is not None:
+            ev[1].record()
+            parallel.TIMING.append(ev)
+        self._sgd()
         return self.losses

@@ -571,10 +571,15 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
         a.x_amax = st["cur"].data_ptr() + 4 * i
         a.x_clamped = st["clamped"].data_ptr()
         st["used"] = True
-    ev = _timed((role, K, xv.G, xv.Cg, Cog, xv.B, T_out))
+    # bench.py prices a launch by its tag; the optional 8th element says which operands are NOT at the output's resolution / are extra:
+    # "up" = the input is the half-resolution tensor (x2-upsampling prologue), "bnb" / "bnbup" = the epilogue also reads the
+    # BatchNorm input of the layer below (full / half resolution) for the backward sums
+    extra = ("up" if (pro is not None and pro[0] & 2) else "") + ("bnb" + ("up" if len(bnb) > 7 and bnb[7] else "") if bnb is not None else "")
+    tag = (role, K, xv.G, xv.Cg, Cog, xv.B, T_out) + ((extra,) if extra else ())
+    ev = _timed(tag)
     if ev is not None:
-        EXEC_FRAC[(role, K, xv.G, xv.Cg, Cog, xv.B, T_out)] = 0.0 if a.wino == 3 else _exec_frac(K, a.wino)
-        EXEC_FP16[(role, K, xv.G, xv.Cg, Cog, xv.B, T_out)] = 3.0 if a.wino == 3 else 0.0
+        EXEC_FRAC[tag] = 0.0 if a.wino == 3 else _exec_frac(K, a.wino)
+        EXEC_FP16[tag] = 3.0 if a.wino == 3 else 0.0
     _lib.check(L.nef_conv_fwd(C.byref(a), _stream()), "nef_conv_fwd")
     if ev is not None:
         ev.record()
@@ -613,10 +618,11 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None, site=None, h
                                                 _p(gw), _p(ws), n, B, T, G, Cig, Cog, K, float(x_scale), float(gy_scale),
                                                 amax, None if amax is None else amax + 4, nxt, None if nxt is None else nxt + 4,
                                                 clamped, _stream()), "nef_conv_bwd_weight_h2")
-        ev = _timed(("conv_bwd_weight", K, G, Cig, Cog, B, T))
+        tag = ("conv_bwd_weight", K, G, Cig, Cog, B, T) + (("up",) if pm0 & 2 else ())
+        ev = _timed(tag)
         if ev is not None:
-            EXEC_FRAC[("conv_bwd_weight", K, G, Cig, Cog, B, T)] = 0.0
-            EXEC_FP16[("conv_bwd_weight", K, G, Cig, Cog, B, T)] = 3.0
+            EXEC_FRAC[tag] = 0.0
+            EXEC_FP16[tag] = 3.0
         if x_scale and gy_scale:
             launch(None, None)
         else:
@@ -646,14 +652,15 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None, site=None, h
         raise _lib.NefLibraryError(f"conv_bwd_weight: unsupported shape Cig={Cig} Cog={Cog} K={K}")
     ws = workspace(n, xv.t.device)
     sc, sc_bs, sc_gs = (None, 0, 0) if in_scale is None else (_p(in_scale[0]), in_scale[1], in_scale[2])
-    ev = _timed(("conv_bwd_weight", K, G, Cig, Cog, B, T))
+    tag = ("conv_bwd_weight", K, G, Cig, Cog, B, T) + (("up",) if pm0 & 2 else ())
+    ev = _timed(tag)
     if wino is None:
         wino = (WINOGRAD and ((K == 3 and WINO_BW4) or (K == 7 and WINO_BW7)) and T % 2 == 0 and T >= 64
                 and not (K == 7 and pro is not None and pro[0]))
     wino = 4 if wino else False
     if ev is not None:
-        EXEC_FRAC[("conv_bwd_weight", K, G, Cig, Cog, B, T)] = _exec_frac(K, 2) if wino else 1.0
-        EXEC_FP16[("conv_bwd_weight", K, G, Cig, Cog, B, T)] = 0.0
+        EXEC_FRAC[tag] = _exec_frac(K, 2) if wino else 1.0
+        EXEC_FP16[tag] = 0.0
     if wino:
         pm, pa, pb, pbp = (pro[0], _p(pro[1]), _p(pro[2]), pro[3]) if (pro is not None and pro[0]) else (0, None, None, 1)
         _lib.check(L.nef_conv_bwd_weight_wino4(xv.ptr, xv.bs, xv.gs, sc, sc_bs, sc_gs, pa, pb, pm, pbp, gyv.ptr, gyv.bs,

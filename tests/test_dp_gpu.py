@@ -219,3 +219,23 @@ def test_bench_self_launches_two_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
     assert line["value"] > 0 and line["allreduce_ms_exposed"] is not None and np.isfinite(line["final_loss"])
+
+
+def test_bench_self_launches_eight_ranks():
+    """`python bench.py --gpus 8` end to end on a one-GPU box: eight ranks share cuda:0 and sum their gradients over gloo (the
+    NEF_SHARE_GPU / NEF_DIST_BACKEND test hooks) -- the launcher, the rendezvous, the 8-way shard arithmetic, the two-graph split
+    capture with the early bucket between the replays, max-over-ranks timing and the single JSON line are the production path;
+    only the transport differs from RCCL over xGMI.  Tiny shape (batch 2 per rank, L = 512)."""
+    env = _env(0)
+    for k in ("WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--len", "512", "--leads", "3", "--no-secondary"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp8"
+    assert line["scaling"] == "weak" and line["hip_graph"] is True
+    assert line["value"] > 0 and line["allreduce_ms_exposed"] is not None and np.isfinite(line["final_loss"])

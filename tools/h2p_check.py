@@ -43,6 +43,8 @@ CASES = [
     ("small up B=5 T=512", 3, 1, 64, 64, 5, 512, 3, "bias,stats"),
 ]
 only = sys.argv[1] if len(sys.argv) > 1 else None
+forms = tuple(int(f) for f in os.environ.get("FORMS", "0,1").split(","))      # FORMS=0: the default form only (profiling runs)
+with_wgrad = os.environ.get("WG", "0") == "1"      # WG=1: also launch the weight gradient of the case (same prologue) once per iteration
 iters, warm = int(os.environ.get("ITERS", 10)), int(os.environ.get("WARM", 20))
 check = os.environ.get("CHECK", "1") == "1"
 bad = 0
@@ -91,7 +93,16 @@ for name, K, G, Cig, Cog, B, T, pm, extra in CASES:
     if "bnb" in ex or "bnbup" in ex:
         mean, invstd, ba, bb = rnd(P, G * Cog), rnd(P, G * Cog) + 1.5, rnd(P, G * Cog) + 0.5, rnd(P, G * Cog) * 0.3
     res = {}
-    for form in (0, 1):
+    if with_wgrad and K in (3, 7) and not (ex & {"bnb", "bnbup", "gate"}):
+        gyw = rnd(B, G * Cog, T)
+        run_conv = run
+
+        def run():
+            out = run_conv()
+            ops.conv_bwd_weight(GV.dense(x, G), GV.dense(gyw, G), K, pro=kw.get("pro"), in_scale=kw.get("in_scale"), h2=True,
+                                x_scale=16.0, gy_scale=16.0)
+            return out
+    for form in forms:
         L.nef_set_option(_lib.OPT_H2_FORM, form)
         y, st = run()
         torch.cuda.synchronize()
@@ -105,6 +116,9 @@ for name, K, G, Cig, Cog, B, T, pm, extra in CASES:
         torch.cuda.synchronize()
         res[form] = (y, st, s.elapsed_time(e) / iters)
     msg = ""
+    if len(forms) < 2:
+        print(f"{name:28s} form {forms[0]} {res[forms[0]][2]:7.3f} ms", flush=True)
+        continue
     if check:
         same = torch.equal(res[0][0], res[1][0])
         sst = res[0][1] is None or torch.equal(res[0][1], res[1][1])
