@@ -7,9 +7,10 @@ import ctypes as C
 import os
 
 import torch  # noqa: F401  (first: the library must bind to the HIP runtime PyTorch-ROCm has already loaded)
+from . import _env
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("NEF_LIB") or os.path.join(_HERE, "csrc", "libnefnet_hip.so")   # NEF_LIB: A/B builds
+LIB_PATH = _env.get("NEF_LIB") or os.path.join(_HERE, "csrc", "libnefnet_hip.so")   # NEF_LIB: A/B builds
 
 NEF_OK = 0
 OPT_H2_FORM, OPT_H2P_WGS = 1, 2      # nef_set_option keys (include/nefnet_hip.h)

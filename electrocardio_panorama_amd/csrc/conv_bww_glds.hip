@@ -494,7 +494,7 @@ int launch(const float* x, int64_t x_bs, int64_t x_gs, const float* gy, int64_t 
 extern "C" __attribute__((visibility("hidden"))) bool nef_bww_glds_ok(int B, int T, int Cig, int Cog, int K, int pro_mode, int pro_Bp,
                                                                       bool in_scale) {
     static const int on = [] {
-        const char* e = getenv("NEF_BWW_GLDS");
+        const char* e = nef_diag_env("NEF_BWW_GLDS");
         return (e && e[0] == '0') ? 0 : 1;
     }();
     if (!on || in_scale || (K != 3 && K != 7) || (K == 7 && pro_mode != 0)) return false;

@@ -139,6 +139,9 @@ __global__ __launch_bounds__(256) void pack_h2_kernel(H2PackTable tab) {
 // PRO as in conv_fwd_kernel (bit0: BatchNorm affine + ReLU of the producing layer, bit1: x2 linear upsampling of a
 // half-resolution input), applied to the fp32 values before the split.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef NEF_H2_LAYOUT
+#define NEF_H2_LAYOUT 1
+#endif
 #ifndef NEF_H2_T
 #define NEF_H2_T 0      // timing-only builds: 1 = no activation loads in the loop, 2 = no matrix instructions, 4 = no epilogue
 #endif
@@ -159,7 +162,19 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
     constexpr int PAD = (K - 1) / 2;
     constexpr int XROW = NTO + K - 1;              // staged positions per channel: t0 - PAD .. t0 + NTO + PAD - 1
     constexpr int P4 = (XROW + 3) / 4 + 1;         // positions per (t mod 4) class
-    constexpr int PLANE = 4 * P4 * 32;             // bytes of one fp16 plane of a stage: [4][P4][16 channels]
+    constexpr int PLANE = 4 * P4 * 32;             // bytes of one fp16 plane of a stage
+    // LDS image of a plane.  NEF_H2_LAYOUT 1 (round 5): [channel half][t mod 4][P4][8 channels] -- a 16-byte chunk per (position, half)
+    // at a pitch of 16 bytes, so a fragment read (lane = position, ds_read_b128) covers 256 contiguous bytes per 16-lane group:
+    // conflict-free.  0 (round 4): [t mod 4][P4][16 channels] -- 32 bytes per position, of which a lane reads one half: every
+    // 16-lane group of a fragment read spans 512 bytes for 256 of data (2-way bank conflict), stores 4-way.
+    constexpr int HALF = 4 * P4 * 16;
+#if NEF_H2_LAYOUT
+#define NEF_H2_WADDR(R, W) (((W) >> 1) * HALF + (((R) & 3) * P4 + ((R) >> 2)) * 16 + ((W) & 1) * 8)
+#define NEF_H2_RPOS(S) ((((S) & 3) * P4 + ((S) >> 2)) * 16)
+#else
+#define NEF_H2_WADDR(R, W) ((((R) & 3) * P4 + ((R) >> 2)) * 32 + 8 * (W))
+#define NEF_H2_RPOS(S) ((((S) & 3) * P4 + ((S) >> 2)) * 32)
+#endif
     constexpr int NIT = (XROW + 63) / 64;
     constexpr int NSF = K + 3;                     // distinct B fragments per stage (s = tap + t-tile)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
@@ -337,8 +352,8 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
                 split2s(v0_[2], v0_[3], xs_, xlim_, h1_, l1_);                                                      \
                 split2s(v1_[0], v1_[1], xs_, xlim_, h2_, l2_);                                                      \
                 split2s(v1_[2], v1_[3], xs_, xlim_, h3_, l3_);                                                      \
-                unsigned char* p0_ = (BUFP) + (((r & 3) * P4 + (r >> 2)) * 32 + 8 * wave);                          \
-                unsigned char* p1_ = (BUFP) + ((((r + 1) & 3) * P4 + ((r + 1) >> 2)) * 32 + 8 * wave);              \
+                unsigned char* p0_ = (BUFP) + NEF_H2_WADDR(r, wave);                                                \
+                unsigned char* p1_ = (BUFP) + NEF_H2_WADDR(r + 1, wave);                                            \
                 *reinterpret_cast<u32x2*>(p0_) = u32x2{h0_, h1_};                                                   \
                 *reinterpret_cast<u32x2*>(p0_ + PLANE) = u32x2{l0_, l1_};                                           \
                 *reinterpret_cast<u32x2*>(p1_) = u32x2{h2_, h3_};                                                   \
@@ -358,8 +373,8 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
                 amax_ = fmaxf(amax_, fmaxf(fabsf(o0), fabsf(o1)));                                                  \
                 unsigned h_, l_;                                                                                    \
                 split2s(o0, o1, xs_, xlim_, h_, l_);                                                                \
-                unsigned char* p0_ = (BUFP) + (((256 & 3) * P4 + (256 >> 2)) * 32 + 8 * wave + 2 * lane);           \
-                unsigned char* p1_ = (BUFP) + (((257 & 3) * P4 + (257 >> 2)) * 32 + 8 * wave + 2 * lane);           \
+                unsigned char* p0_ = (BUFP) + NEF_H2_WADDR(256, wave) + 2 * lane;                                   \
+                unsigned char* p1_ = (BUFP) + NEF_H2_WADDR(257, wave) + 2 * lane;                                   \
                 *reinterpret_cast<unsigned short*>(p0_) = (unsigned short)(h_ & 0xffffu);                           \
                 *reinterpret_cast<unsigned short*>(p0_ + PLANE) = (unsigned short)(l_ & 0xffffu);                   \
                 *reinterpret_cast<unsigned short*>(p1_) = (unsigned short)(h_ >> 16);                               \
@@ -382,7 +397,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
             split2s(v_[2], v_[3], xs_, xlim_, h1_, l1_);                                                            \
             const u32x2 hv = {h0_, h1_}, lv = {l0_, l1_};                                                           \
             if (r < XROW) {                                                                                         \
-                unsigned char* p_ = (BUFP) + (((r & 3) * P4 + (r >> 2)) * 32 + 8 * wave);                           \
+                unsigned char* p_ = (BUFP) + NEF_H2_WADDR(r, wave);                                                 \
                 *reinterpret_cast<u32x2*>(p_) = hv;                                                                 \
                 *reinterpret_cast<u32x2*>(p_ + PLANE) = lv;                                                         \
             }                                                                                                       \
@@ -423,7 +438,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
 
     const int nst = Cig / KC;
     // this lane's fragment address inside a plane: position wn * 32 + lo (+ the s-dependent constant), channels 8 hi ..
-    const unsigned fb_lane = (unsigned)((wn * 32 + lo) * 32 + hi * 16);
+    const unsigned fb_lane = NEF_H2_LAYOUT ? (unsigned)(hi * HALF + (wn * 32 + lo) * 16) : (unsigned)((wn * 32 + lo) * 32 + hi * 16);
     for (int st = 0; st < nst; ++st) {
         const unsigned char* const xb = Xl + (st & 1) * (2 * PLANE) + fb_lane;
         const bool more = st + 1 < nst;
@@ -434,7 +449,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
         h16x8 fb[5][2];              // ring over s: [slot][plane]
 #define NEF_H2B_LOAD(S)                                                                                              \
     {                                                                                                               \
-        const unsigned char* p_ = xb + ((((S) & 3) * P4 + ((S) >> 2)) * 32);                                        \
+        const unsigned char* p_ = xb + NEF_H2_RPOS(S);                                                              \
         fb[(S) % 5][0] = *reinterpret_cast<const h16x8*>(p_);                                                       \
         fb[(S) % 5][1] = *reinterpret_cast<const h16x8*>(p_ + PLANE);                                               \
     }
@@ -483,6 +498,8 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
 #undef NEF_H2X_ISSUE
 #undef NEF_H2X_STORE
 #undef NEF_H2A_ISSUE
+#undef NEF_H2_WADDR
+#undef NEF_H2_RPOS
 
     if (a.x_amax_next || a.x_clamped) {      // this launch's own input magnitude, for the call site's next launch
 #pragma unroll
@@ -772,12 +789,11 @@ __attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, 
     if (!nef_h2_ok(a)) return NEF_E_SHAPE;
     if ((a->pro_mode & 1) && !(a->pro_a && a->pro_b && a->pro_Bp > 0)) return NEF_E_NULL;
     if (nef_opt_h2_form() && nef_h2p_ok(a)) return nef_h2p_launch(a, st);
-    static const bool force_tm1 = getenv("NEF_H2_TM1") && atoi(getenv("NEF_H2_TM1")) == 1;      // A/B: 64-channel tile everywhere
+    static const bool force_tm1 = nef_diag_env("NEF_H2_TM1") && atoi(nef_diag_env("NEF_H2_TM1")) == 1;      // A/B: 64-channel tile everywhere
     const bool wide = a->Cout_g % 128 == 0 && !force_tm1;
     // the x2-upsampling prologue keeps two source samples per staged position in registers: next to the 128 accumulator
-    // registers of the 128-channel tile that spills (250..330 bytes per lane), so those launches take the 64-channel tile
-    static const bool up_wide = getenv("NEF_H2_UP_TM") && atoi(getenv("NEF_H2_UP_TM")) == 2;
-    const bool wide_up = wide && up_wide;
+    // registers of the 128-channel tile that spills (250..330 bytes per lane; 34.1 vs 31.1 ms/step in round 4), so those launches
+    // always take the 64-channel tile (the 128-channel instantiations <3, 2, 2> / <3, 3, 2> are no longer built)
     if (a->T < NTO / 2)      // short rows: the 64-channel tile (the 128-channel form spills 185 registers with the per-lane sample offsets)
         return a->K == 1 ? launch_h2<1, 0, 1, true>(*a, st) : launch_h2<3, 0, 1, true>(*a, st);
     if (a->K == 7) return wide ? launch_h2<7, 0, 2>(*a, st) : launch_h2<7, 0, 1>(*a, st);
@@ -785,8 +801,8 @@ __attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, 
     switch (a->pro_mode) {
         case 0: return wide ? launch_h2<3, 0, 2>(*a, st) : launch_h2<3, 0, 1>(*a, st);
         case 1: return wide ? launch_h2<3, 1, 2>(*a, st) : launch_h2<3, 1, 1>(*a, st);
-        case 2: return wide_up ? launch_h2<3, 2, 2>(*a, st) : launch_h2<3, 2, 1>(*a, st);
-        default: return wide_up ? launch_h2<3, 3, 2>(*a, st) : launch_h2<3, 3, 1>(*a, st);
+        case 2: return launch_h2<3, 2, 1>(*a, st);
+        default: return launch_h2<3, 3, 1>(*a, st);
     }
 }
 

@@ -46,12 +46,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-// process-wide kernel-form options (nef_set_option); the environment gives the initial values: NEF_H2P, NEF_H2P_WGS
+// process-wide kernel-form options (nef_set_option); under NEF_DIAG=1 the environment gives the initial values: NEF_H2P, NEF_H2P_WGS
 int g_opt[4] = {0, -1, -1, 0};
 void opt_init() {
     if (__atomic_load_n(&g_opt[0], __ATOMIC_ACQUIRE)) return;
-    const char* e1 = getenv("NEF_H2P");
-    const char* e2 = getenv("NEF_H2P_WGS");
+    const char* e1 = nef_diag_env("NEF_H2P");
+    const char* e2 = nef_diag_env("NEF_H2P_WGS");
     int v1 = e1 ? atoi(e1) : 0, v2 = e2 ? atoi(e2) : 1;
     int neg = -1;
     __atomic_compare_exchange_n(&g_opt[NEF_OPT_H2_FORM], &neg, v1, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);

@@ -372,12 +372,11 @@ int launch_h2w(const H2WArgs& a, hipStream_t st) {
 // tile form for a shape: MCO (row tiles of 64 channels per workgroup) and SPLIT (see the kernel)
 struct H2WForm { int mco, split; };
 H2WForm h2w_form(int Cog, int K) {
-    // Measured (tools/_h2w_check.py, ms, 64 x 64 tile -> 128 x 64 tile): decoder 128->128 T=2500 0.93 -> 0.85, first decoder layer
-    // 1.21 -> 1.11, but encoder-side K = 3 (384 channels, T = 1250) 0.54 -> 0.60 and K = 7 0.87 -> 3.3 (the two tap groups' code in
-    // one kernel spills 90 registers): a wash over the step, so the 64 x 64 tile stays the default; NEF_H2W_MCO=2 takes the large one
-    static const bool large = getenv("NEF_H2W_MCO") && atoi(getenv("NEF_H2W_MCO")) == 2;
-    if (Cog % 128 != 0 || !large) return {1, 0};
-    return {2, K == 7 ? 1 : 2};
+    // Measured in round 4 (ms, 64 x 64 tile -> 128 x 64 tile): decoder 128->128 T=2500 0.93 -> 0.85, first decoder layer 1.21 -> 1.11,
+    // but encoder-side K = 3 0.54 -> 0.60 and K = 7 0.87 -> 3.3 (spills): a wash; the 128 x 64 instantiations (MCO = 2) are no longer
+    // built -- the layers with 128 output channels take the producer / consumer form below
+    (void)Cog, (void)K;
+    return {1, 0};
 }
 
 
@@ -803,8 +802,8 @@ int launch_h2w2(const H2WArgs& a, hipStream_t st) {
 // everywhere; NEF_H2W_64=<mask of prologue modes + 1>: form 2 (64 x 64 channels, 4 consumer + 8 producer waves) for the 64-channel
 // layers with those prologues (bit p + 1 set: pro_mode p)
 int h2w2_form(int Cog, int pro_mode) {
-    static const bool v1 = getenv("NEF_H2W_V") && atoi(getenv("NEF_H2W_V")) == 1;
-    static const int m64 = getenv("NEF_H2W_64") ? atoi(getenv("NEF_H2W_64")) : NEF_H2W_64_DEFAULT;
+    static const bool v1 = nef_diag_env("NEF_H2W_V") && atoi(nef_diag_env("NEF_H2W_V")) == 1;
+    static const int m64 = nef_diag_env("NEF_H2W_64") ? atoi(nef_diag_env("NEF_H2W_64")) : NEF_H2W_64_DEFAULT;
     if (v1) return 0;
     if (Cog % 128 == 0) return 1;
     return ((m64 >> pro_mode) & 1) ? 2 : 0;
@@ -828,7 +827,7 @@ __attribute__((visibility("hidden"))) int nef_h2w_splits(int B, int T, int G, in
     const int64_t n_tiles = (int64_t)B * tps;
     const int units = v2 ? G * (Cog / (v2 == 1 ? 128 : 64)) * (Cig / 64) : G * (Cog / (64 * f.mco)) * (Cig / 64);
     const int resident = v2 ? 1 : (f.split ? 1 : 2);      // workgroups per CU
-    static const int rounds = getenv("NEF_H2W_ROUNDS") ? atoi(getenv("NEF_H2W_ROUNDS")) : 1;
+    static const int rounds = nef_diag_env("NEF_H2W_ROUNDS") ? atoi(nef_diag_env("NEF_H2W_ROUNDS")) : 1;
     const int slots = rounds * resident * nef_cu_count();
     int S = slots / units;                 // `rounds` rounds of resident workgroups and never a workgroup more: one extra costs a whole round
     if (S > n_tiles) S = (int)n_tiles;
@@ -876,16 +875,6 @@ __attribute__((visibility("hidden"))) int nef_h2w_launch(const float* x, int64_t
             default: return NEF_H2W2(3, 3);
         }
 #undef NEF_H2W2
-    }
-    if (f.mco == 2) {
-        if (K == 7) return launch_h2w<7, 0, 2, 1>(a, st);
-        if (K == 1) return launch_h2w<1, 0, 2, 2>(a, st);
-        switch (pro_mode) {
-            case 0: return launch_h2w<3, 0, 2, 2>(a, st);
-            case 1: return launch_h2w<3, 1, 2, 2>(a, st);
-            case 2: return launch_h2w<3, 2, 2, 2>(a, st);
-            default: return launch_h2w<3, 3, 2, 2>(a, st);
-        }
     }
     if (K == 7) return launch_h2w<7, 0, 1, 0>(a, st);
     if (K == 1) return launch_h2w<1, 0, 1, 0>(a, st);

@@ -1360,7 +1360,7 @@ static int launch_conv_wino4(const nef_conv_args& a, hipStream_t st) {
     static unsigned long long lds_set = 0;      // per-device bits, see nef_ensure_dyn_lds
 #ifdef NEF_TRACE
     size_t lds_launch = lds;       // NEF_DEBUG_LDS=<bytes>: inflate the LDS request to force fewer workgroups per CU
-    if (const char* e_ = getenv("NEF_DEBUG_LDS")) lds_launch = (size_t)atol(e_);
+    if (const char* e_ = nef_diag_env("NEF_DEBUG_LDS")) lds_launch = (size_t)atol(e_);
     if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_wino4_kernel<K, WMC, PRO>), 160 * 1024, &lds_set)) return e;
 #else
     constexpr size_t lds_launch = lds;

@@ -23,6 +23,14 @@ static inline int nef_launch_status() {
 
 static inline int64_t nef_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Diagnostics switches (A/B kernel forms, timing experiments) are read from the environment ONLY under NEF_DIAG=1: a stray variable
+// cannot change which kernel a production run takes.  Product switches (NEF_H2, NEF_LIB, ...) are documented in README.md.
+#include <stdlib.h>
+static inline const char* nef_diag_env(const char* name) {
+    const char* d = getenv("NEF_DIAG");
+    return (d && d[0] == '1') ? getenv(name) : nullptr;
+}
+
 // Compute units of the CURRENT device (256 on MI355X); queried once per device, idempotent -> thread-safe.
 static inline int nef_cu_count() {
     static int cached[64] = {0};

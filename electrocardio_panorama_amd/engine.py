@@ -9,6 +9,7 @@ All arithmetic happens in libnefnet_hip.so; this file only sequences launches.
 import os
 
 import torch
+from . import _env
 
 from . import ops
 from .ops import GV
@@ -23,15 +24,15 @@ BN_EPS, BN_MOM = 1e-5, 0.1
 # faster one: 47.85 -> 47.36 ms/step, and the 1.97 GB tensor is never written.  On the split-fp16 kernels of round 4 the two
 # forms are equal within the run-to-run noise (three alternating runs on one box: 31.2 - 31.7 against 31.5 - 31.9 ms/step,
 # bit-identical loss): the prologue stays.
-_FUSE_L2 = os.environ.get("NEF_FUSE_L2", "1") == "1"
+_FUSE_L2 = _env.get("NEF_FUSE_L2", "1") == "1"
 
 # NEF_FUSE_STATS=0: BatchNorm statistics by a pass over the conv output (nef_bn_train_stats) instead of the conv epilogue
-_FUSE_STATS = os.environ.get("NEF_FUSE_STATS", "1") == "1"
+_FUSE_STATS = _env.get("NEF_FUSE_STATS", "1") == "1"
 # NEF_BNB_UP=0: the BatchNorm-backward sums behind a x2 upsampling by the pass (bn_relu_bwd_up reduces them itself) instead of the
 # backward-data conv's epilogue
-_BNB_UP = os.environ.get("NEF_BNB_UP", "1") == "1"
+_BNB_UP = _env.get("NEF_BNB_UP", "1") == "1"
 
-_BWD_F4 = os.environ.get("NEF_BWD_F4", "1")
+_BWD_F4 = _env.get("NEF_BWD_F4", "1")
 
 DROPOUT_SITES = ("W_encoder.layer1.0", "W_encoder.layer1.1", "W_encoder.layer1.2", "w_conv.0", "z1_conv.0",
                  "z2_conv1.0", "z2_conv2.0", "z2_conv2.2")
@@ -124,11 +125,11 @@ _SIDE_MIN_WORK = 1 << 24
 
 
 def _side(device, work=None):
-    mode = os.environ.get("NEF_SIDE_STREAM", "auto")
+    mode = _env.get("NEF_SIDE_STREAM", "auto")
     if mode == "0" or (mode == "auto" and work is not None and work < _SIDE_MIN_WORK
                        and not torch.cuda.is_current_stream_capturing()):
         return ops._Inline()
-    if torch.cuda.is_current_stream_capturing() and os.environ.get("NEF_GRAPH_SIDE", "1") == "0":
+    if torch.cuda.is_current_stream_capturing() and _env.get("NEF_GRAPH_SIDE", "1") == "0":
         return ops._Inline()          # NEF_GRAPH_SIDE=0: a captured step stays on the capturing stream
     return ops.SideStream.get(device)
 
@@ -512,7 +513,7 @@ def sweep_eval(P, Bf, latent, query_thetas, chunk=8):
     return rest
 
 
-PANO_FUSE_PAIR = os.environ.get("NEF_PANO_FUSE_PAIR", "1") != "0"   # measurement switch: 0 = two launches
+PANO_FUSE_PAIR = _env.get("NEF_PANO_FUSE_PAIR", "1") != "0"   # measurement switch: 0 = two launches
 
 
 def sweep_eval_h(P, Bf, latent, query_thetas, pair_budget=16384):

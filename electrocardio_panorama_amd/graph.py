@@ -19,6 +19,7 @@ graph and one exposed all-reduce).
 import random
 
 import torch
+from . import _env
 import torch.distributed as dist
 
 from . import engine, ops
@@ -51,7 +52,7 @@ class GraphedTrainStep:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # data parallel: capture the step as two graphs with the early gradient bucket's all-reduce between them (_capture_split)
         import os
-        self.split_capture = os.environ.get("NEF_GRAPH_SPLIT", "1") != "0"
+        self.split_capture = _env.get("NEF_GRAPH_SPLIT", "1") != "0"
 
     # -------------------------------------------------------------------------------------------------
     def _flatten(self, live):

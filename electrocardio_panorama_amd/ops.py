@@ -10,6 +10,7 @@ import itertools
 import os
 
 import torch
+from . import _env
 
 from . import _lib
 
@@ -202,7 +203,7 @@ def stem_bwd_weight(x, w, gy):
 # K = 3 convs through Winograd F(2,3), K = 7 convs through F(2,4) + F(2,3) on the taps split 4 + 3 (conv_mfma.hip:
 # conv_wino_kernel; "F(2,3)" below stands for this F(2,.) family) wherever a whole output tile of one
 # sample exists; NEF_WINOGRAD=0 keeps every conv on the direct kernel.
-_WV = os.environ.get("NEF_WINOGRAD", "4")
+_WV = _env.get("NEF_WINOGRAD", "4")
 WINOGRAD = _WV != "0"
 # Forward / backward-data form where the caller allows the larger tile (`f4=True`: the decoder convs): 2 = F(4,3)
 # (default), 1 = F(2,3) everywhere (NEF_WINOGRAD=2).  The encoder-side convs always take F(2,3), for two measured reasons:
@@ -215,8 +216,8 @@ WINOGRAD = _WV != "0"
 WINO_FWD = 1 if _WV in ("1", "2") else 2
 # Winograd weight gradients (nef_conv_bwd_weight_wino4): K=3 through the transposed F(3,4), K=7 with the taps split 4 + 3 over
 # two launches (transposed F(4,4) + F(3,4)).  NEF_BW_WINO4=0 / NEF_BW7_F42=0 put K=3 / K=7 back on the direct kernel.
-WINO_BW4 = os.environ.get("NEF_BW_WINO4", "1") == "1" and _WV not in ("1", "2")
-WINO_BW7 = os.environ.get("NEF_BW7_F42", "1") == "1" and _WV not in ("1", "2")
+WINO_BW4 = _env.get("NEF_BW_WINO4", "1") == "1" and _WV not in ("1", "2")
+WINO_BW7 = _env.get("NEF_BW7_F42", "1") == "1" and _WV not in ("1", "2")
 _WINO_PLANES = {(1, 3): 4, (1, 7): 10, (2, 3): 6, (2, 7): 13}
 
 
@@ -224,14 +225,14 @@ _WINO_PLANES = {(1, 3): 4, (1, 7): 10, (2, 3): 6, (2, 7): 13}
 # three fp16 matrix instructions per 16 channels and tap, fp32 accumulation -- fp32-class results at 3/16 of the fp32 matrix
 # instructions' pipe time.  NEF_H2=0 keeps the fp32 Winograd forms; NEF_H2=1 takes it wherever the shape allows
 # (128-channel output tiles, 16-channel input chunks, T even and >= 128; K = 7 without an input prologue).
-H2 = os.environ.get("NEF_H2", "1") == "1"
-_H2_DIR = {False: os.environ.get("NEF_H2_FWD", "1") == "1", True: os.environ.get("NEF_H2_BWD", "1") == "1"}     # diagnostics
-_H2_K = os.environ.get("NEF_H2_K", "1,3,7").split(",")
-_H2_64 = os.environ.get("NEF_H2_64", "1") == "1"
-_H2_MIN_T = int(os.environ.get("NEF_H2_MIN_T", "0"))      # shortest sequence the split-fp16 kernels take (256-column tiles)
-_H2_W = os.environ.get("NEF_H2_W", "1") == "1"          # weight gradients on the split-fp16 kernel too (csrc/conv_h2w.hip)
-_H2_WK = os.environ.get("NEF_H2_WK", "1,3,7").split(",")
-_H2_AMAX = os.environ.get("NEF_H2_AMAX", "sticky")      # diagnostics: "anon" = every launch measures first, "follow" = no stickiness
+H2 = _env.get("NEF_H2", "1") == "1"
+_H2_DIR = {False: _env.get("NEF_H2_FWD", "1") == "1", True: _env.get("NEF_H2_BWD", "1") == "1"}     # diagnostics
+_H2_K = _env.get("NEF_H2_K", "1,3,7").split(",")
+_H2_64 = _env.get("NEF_H2_64", "1") == "1"
+_H2_MIN_T = int(_env.get("NEF_H2_MIN_T", "0"))      # shortest sequence the split-fp16 kernels take (256-column tiles)
+_H2_W = _env.get("NEF_H2_W", "1") == "1"          # weight gradients on the split-fp16 kernel too (csrc/conv_h2w.hip)
+_H2_WK = _env.get("NEF_H2_WK", "1,3,7").split(",")
+_H2_AMAX = _env.get("NEF_H2_AMAX", "sticky")      # diagnostics: "anon" = every launch measures first, "follow" = no stickiness
 
 
 # Small problems stay on the fp32 kernels: the split-fp16 kernels tile a sample in 256 outputs x 128 (64) channels, and below
@@ -239,8 +240,8 @@ _H2_AMAX = os.environ.get("NEF_H2_AMAX", "sticky")      # diagnostics: "anon" = 
 # batch 32 x L 512: 3.11 ms per captured step with them, 2.72 without).  The engine announces the batch of the pass it is about
 # to run (BATCH_HINT); without a hint (bare ops calls) the shape rules alone decide.
 BATCH_HINT = None
-_H2_PACK = os.environ.get("NEF_H2_PACK", "1") == "1"
-_H2_MIN_WGS = int(os.environ.get("NEF_H2_MIN_WGS", "256"))
+_H2_PACK = _env.get("NEF_H2_PACK", "1") == "1"
+_H2_MIN_WGS = int(_env.get("NEF_H2_MIN_WGS", "256"))
 
 
 def _h2_packed(K, T_out, pro=0):

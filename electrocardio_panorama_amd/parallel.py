@@ -5,6 +5,7 @@ statistics stay per shard, as under DataParallel; rank 0's running statistics ar
 import os
 
 import torch
+from . import _env
 import torch.distributed as dist
 
 
@@ -123,7 +124,7 @@ EARLY_ENABLED = False
 
 def enable_early_reduce():
     global EARLY_ENABLED
-    EARLY_ENABLED = os.environ.get("NEF_EARLY_REDUCE", "1") != "0"
+    EARLY_ENABLED = _env.get("NEF_EARLY_REDUCE", "1") != "0"
 
 
 def early_reduce(P, grads, side_stream=None):

@@ -18,6 +18,7 @@ import os
 
 import numpy as np
 import torch
+from .. import _env
 import torch.distributed as dist
 
 from .. import engine, ops, parallel
@@ -231,7 +232,7 @@ class Solver:
             return None
         if not hasattr(optim, '_flat') or len(optim.param_groups) != 1:
             return None
-        if type(self.model).__name__ != 'Model_nefnet' or os.environ.get('NEF_SOLVER_GRAPH', '1') == '0':
+        if type(self.model).__name__ != 'Model_nefnet' or _env.get('NEF_SOLVER_GRAPH', '1') == '0':
             return None
         # 'auto' = wherever the conditions above hold, at every batch size: with the convs on the fp16 matrix cores even the
         # full-size step (configs[1]: ~290 launches, 36 ms) loses 2.5-4.5 ms to launch gaps when a busy host issues it from Python
@@ -255,7 +256,7 @@ class Solver:
         msg = ('{} waves of split-fp16 conv launches clamped an operand in this {} phase (a tensor grew more than {}x between two '
                'consecutive passes); {} train step(s) were skipped on the device'.format(clamped, phase, ops.H2_HEADROOM, skipped))
         protected = phase == 'train' and hasattr(optim, '_flat') and skipped > 0
-        if protected or os.environ.get('NEF_H2_ALLOW_CLAMP') == '1':
+        if protected or _env.get('NEF_H2_ALLOW_CLAMP') == '1':
             print('WARNING: ' + msg + ('' if protected else ' -- results of those launches are wrong (NEF_H2_ALLOW_CLAMP=1)'))
             return
         raise RuntimeError(msg + '; their results are wrong.  Set NEF_H2=0 (fp32 kernels) for data of this dynamic range, or '

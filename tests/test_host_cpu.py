@@ -355,3 +355,32 @@ def test_dropin_shim_resolves_reference_import_lines():
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "electrocardio_panorama_amd", "dropin"), ROOT]))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd="/tmp")
     assert r.returncode == 0 and "DROPIN_OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_env_switch_groups(monkeypatch, capsys):
+    """Product switches are always honoured; diagnostics switches only under NEF_DIAG=1 (ignored with one warning otherwise);
+    anything else is a programming error.  The C side gates its own diagnostics reads the same way (nef_common.h: nef_diag_env)."""
+    from electrocardio_panorama_amd import _env
+    monkeypatch.delenv("NEF_DIAG", raising=False)
+    monkeypatch.setenv("NEF_H2", "0")
+    assert _env.get("NEF_H2", "1") == "0"
+    monkeypatch.setenv("NEF_FUSE_STATS", "0")
+    _env._warned.discard("NEF_FUSE_STATS")
+    assert _env.get("NEF_FUSE_STATS", "1") == "1" and _env.get("NEF_FUSE_STATS", "1") == "1"
+    assert capsys.readouterr().err.count("NEF_FUSE_STATS=0 ignored") == 1
+    monkeypatch.setenv("NEF_DIAG", "1")
+    assert _env.get("NEF_FUSE_STATS", "1") == "0"
+    monkeypatch.setenv("NEF_NOT_A_SWITCH", "1")
+    with pytest.raises(KeyError):
+        _env.get("NEF_NOT_A_SWITCH")
+    # every switch the sources read is registered in one of the groups
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = set()
+    for dirpath, _, files in os.walk(os.path.join(root, "electrocardio_panorama_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                seen |= set(re.findall(r'(?:_env\.get|nef_diag_env|getenv)\(["\'](NEF_[A-Z0-9_]+)', txt))
+    hooks = {"NEF_SHARE_GPU", "NEF_DIST_BACKEND", "NEF_DIST_FORCE"}
+    assert seen - set(_env.PRODUCT) - _env.DIAGNOSTICS - hooks == set(), seen - set(_env.PRODUCT) - _env.DIAGNOSTICS - hooks
