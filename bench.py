@@ -428,6 +428,19 @@ def main():
                 # NOT measured by this run: replayed from the committed rocprofv3 --pmc pass (separate run, as the
                 # counters cannot be collected together with timing)
                 traffic_source = ("replayed from " + tj.get("source", "profiles/traffic.json")) if traffic else None
+            # effective clock and matrix-pipe occupancy of the dominant kernel: from the committed SQ / GRBM counter pass (a separate
+            # rocprofv3 --pmc run, profiles/sq_k7.json) -- tells a pipe that idles from a chip that clocks down under the load:
+            # `peak` assumes 2.4 GHz and a pipe that never waits
+            sq = None
+            spath = os.path.join(ROOT, "profiles", "sq_k7.json")
+            if os.path.exists(spath) and ops.H2 and (V, B, L) == (3, 256, 5000):
+                sj = json.load(open(spath))
+                want = "conv_h2w2_kernel<%d" % dom_tag[1] if dom_tag[0] == "conv_bwd_weight" else "conv_h2_kernel<%d, 0, 2" % dom_tag[1]
+                hit = [v for k_, v in sj.get("by_kernel", {}).items() if k_.startswith(want)]
+                if hit:
+                    sq = dict(hit[0], source="replayed from " + sj.get("source", "profiles/sq_k7.json"))
+            roof.update(effective_clock_GHz=sq["effective_clock_GHz"] if sq else None, pipe_busy=sq["pipe_busy"] if sq else None,
+                        clock_source=sq["source"] if sq else None)
             roof.update(traffic=traffic, traffic_source=traffic_source, kernel_tag="/".join(str(x) for x in dom_tag),
                         kernel=("conv_h2w2_kernel (weight gradient on two-term fp16 splits of both operands, producer / consumer waves)" if dom_tag[0] == "conv_bwd_weight" and roof["executed_fp16_mfma_flops"] > 0
                                 else KNAME[3] if roof["executed_fp16_mfma_flops"] > 0 else "fp32 conv kernel") +
