@@ -16,11 +16,13 @@
 // Range: fp16 holds |v| < 65504 and loses relative precision below 6.1e-5 (absolute 2^-25 below it).  Weights are scaled per
 // output row at pack time (row maximum -> [2^14, 2^15)), so their split is always at full precision.  Activations and gradients
 // are scaled by ONE power of two per launch, derived from the magnitude the call site's previous launch measured (x_amax ->
-// [2^8, 2^9); ops.py: amax_roll, H2_HEADROOM = 64 x of growth per pass before anything is clamped); tiles are clamped to
-// +-65000 / scale before the split (no infinities) and a launch that had to clamp counts itself in x_clamped -- the host side
-// skips the train step that contains it (nef_h2_taint).  Elements more than 2^11 below the tensor's largest keep an ABSOLUTE
-// error of <= 2^-25 / scale instead of a relative one: 2^-34 of the largest element at worst, below fp32's own rounding of a
-// dot product that contains that element, but NOT a per-element relative bound (tests: test_conv_h2_operand_distributions).
+// [2^8, 2^9); ops.py: amax_roll, H2_HEADROOM = 64 x of growth per pass fit under it).  RANGE RESCUE (round 5): a workgroup whose
+// tile nevertheless holds an element that does not fit redoes the tile with the scale its own data asks for -- the scale is divided
+// out in the epilogue, so tiles of one launch may use different ones -- and no finite operand is ever clamped; what is still out of
+// range afterwards is not finite and counts itself in x_clamped (the host side then skips the train step: nef_h2_taint).
+// Elements more than 2^11 below the tensor's largest keep an ABSOLUTE error of <= 2^-25 / scale instead of a relative one: 2^-34 of
+// the largest element at worst, below fp32's own rounding of a dot product that contains that element, but NOT a per-element
+// relative bound (tests: test_conv_h2_operand_distributions).
 //
 // Tiling: one workgroup = 128 (TM = 2; 64 with TM = 1) output channels x 256 outputs of one sample and group, 4 waves as
 // 2 (co) x 2 (t), a wave owns 32 TM x 128 = TM x 4 accumulator tiles of 32 x 32.  MFMA column n of t-tile j is output t = 4 n + j, so a lane ends up with FOUR
@@ -37,6 +39,10 @@
 
 #include "nefnet_hip.h"
 #include "nef_common.h"
+
+#ifndef NEF_H2_CLAMP
+#define NEF_H2_CLAMP 0      // 1: clamp operands at fp16's range before the split (round 4; the range rescue makes it unnecessary)
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -69,8 +75,12 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned
 // mixed-precision FMA per element (x s is exact, x s - hi is exact in fp32: bit-identical to split2(x0 * s, x1 * s));
 // |x| is clamped at lim = 65000 / s first
 __device__ __forceinline__ void split2s(float x0, float x1, float s, float lim, unsigned& h, unsigned& l) {
+#if NEF_H2_CLAMP
     x0 = __builtin_amdgcn_fmed3f(x0, -lim, lim);
     x1 = __builtin_amdgcn_fmed3f(x1, -lim, lim);
+#else
+    (void)lim;      // no clamp: a tile whose data does not fit is redone with its own scale (range rescue), its first pass is discarded
+#endif
     asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x0), "v"(s));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x1), "v"(s));
     asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
@@ -181,6 +191,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
     unsigned char* const Xl = smem_h2;             // [2 buffers][2 planes][PLANE]
     float* const Pl = reinterpret_cast<float*>(smem_h2 + 4 * PLANE);      // [2][Cin_g] prologue affine (AFF)
     float* const El = Pl + (AFF ? 2 * PRO_MAX_CIN : 0);                    // [6][MT] epilogue tables
+    float* const Al = El + 6 * MT;                                         // [4] the waves' operand magnitudes of this tile (range rescue)
 
     const int tile = blockIdx.x % n_tiles;
     const int gm = blockIdx.x / n_tiles;
@@ -288,10 +299,17 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
             xs_ = ldexpf(1.f, 9 - e_);
         }
     }
+    const int pro_row0 = AFF ? (b0 / a.pro_Bp) * a.G * Cig + g * Cig : 0;
+    // Range rescue (round 5): if an element of THIS tile turns out to exceed fp16's range under the launch's scale (the operand grew
+    // more than ops.H2_HEADROOM x since the call site measured it), the workgroup does its tile again with the scale its own data
+    // asks for -- the scale is a power of two that the epilogue divides out again, so tiles of one launch may use different ones.
+    // Costs a wave reduction and four LDS words per tile when nothing happens; a launch no longer clamps finite data at all.
+    // The tile's work is a lambda inlined TWICE (a backward branch around it made the register allocator demote the staging and
+    // accumulator arrays to scratch: 1.3 .. 4.3 KB per lane): returns the tile's largest |operand| if that did not fit and the
+    // epilogue was therefore skipped (`last` = false), else a negative number.
+    auto tile_pass = [&](const float xs_, const bool last) __attribute__((always_inline)) -> float {
     const float xlim_ = 65000.f / xs_;
     float amax_ = 0.f;
-    const int pro_row0 = AFF ? (b0 / a.pro_Bp) * a.G * Cig + g * Cig : 0;
-
     f32x16 acc[TM][4];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -493,7 +511,19 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
             for (int q = 0; q < 2 * TM; ++q) fa[0][q] = fa[1][q];
         }
         if (more) NEF_H2X_STORE((st + 1) * KC, Xl + ((st + 1) & 1) * (2 * PLANE))
+        else {      // every element of the tile has been staged: publish this wave's magnitude with the loop's last barrier
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) amax_ = fmaxf(amax_, __shfl_xor(amax_, o, 64));
+            if (lane == 0) Al[wave_u] = amax_;
+        }
         __syncthreads();
+    }
+    {
+        const float wg_ = fmaxf(fmaxf(Al[0], Al[1]), fmaxf(Al[2], Al[3]));      // workgroup-uniform
+        if (!last && !(wg_ * xs_ < 65000.f) && wg_ < 3e38f) {
+            __syncthreads();      // (Al is rewritten by the second pass)
+            return wg_;
+        }
     }
 #undef NEF_H2X_ISSUE
 #undef NEF_H2X_STORE
@@ -501,11 +531,8 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
 #undef NEF_H2_WADDR
 #undef NEF_H2_RPOS
 
-    if (a.x_amax_next || a.x_clamped) {      // this launch's own input magnitude, for the call site's next launch
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amax_ = fmaxf(amax_, __shfl_xor(amax_, o, 64));
-        if (a.x_clamped && lane == 0 && !(amax_ * xs_ < 65000.f)) atomicAdd(a.x_clamped, 1);      // an element was clamped (or is not finite)
-    }
+    // (amax_ is wave-uniform here: reduced in the last stage)  what is still out of range after the rescue is not finite
+    if (a.x_clamped && lane == 0 && !(amax_ * xs_ < 65000.f)) atomicAdd(a.x_clamped, 1);
     if (a.x_amax_next) {
         if (lane == 0 && amax_ < 3e38f) {
             unsigned* const p_ = reinterpret_cast<unsigned*>(a.x_amax_next);
@@ -518,7 +545,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
         float z_ = 0.f;
         for (int i = 0; i < TM; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) z_ += acc[i][j][r];
         if (z_ == 12345.678f) a.y[0] = z_;
-        return;
+        return -1.f;
     }
 #endif
     // ---- epilogue: descale, then bias / residual / ReLU / dropout / gate on the four adjacent outputs a lane owns per row
@@ -740,6 +767,14 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
             if (inb) slot_out[((int64_t)ch * a.B * nslot + slot) * 2 + (lo & 1)] = sv[0];
         }
     }
+    return -1.f;
+    };      // tile_pass
+    const float over_ = tile_pass(xs_, false);
+    if (over_ > 0.f) {
+        int e_;
+        (void)frexpf(over_, &e_);
+        (void)tile_pass(ldexpf(1.f, 9 - e_), true);
+    }
 }
 
 template <int K, int PRO, int TM, bool PACK = false>
@@ -748,7 +783,7 @@ int launch_h2(const nef_conv_args& a, hipStream_t st) {
     constexpr int XROW = NTO + K - 1;
     constexpr int P4 = (XROW + 3) / 4 + 1;
     constexpr int PLANE = 4 * P4 * 32;
-    constexpr size_t lds = (size_t)4 * PLANE + (((PRO & 1) ? 2 * PRO_MAX_CIN : 0) + 6 * MT) * sizeof(float);
+    constexpr size_t lds = (size_t)4 * PLANE + (((PRO & 1) ? 2 * PRO_MAX_CIN : 0) + 6 * MT + 4) * sizeof(float);
     static unsigned long long lds_set = 0;
     if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_h2_kernel<K, PRO, TM, PACK>), lds, &lds_set)) return e;
     // PACK: `tps` = samples per tile (pitch T + 4; the last sample needs no gap behind it)

@@ -33,6 +33,10 @@
 #include "nefnet_hip.h"
 #include "nef_common.h"
 
+#ifndef NEF_H2_CLAMP
+#define NEF_H2_CLAMP 0      // 1: clamp operands at fp16's range before the split (round 4; the range rescue makes it unnecessary)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -71,8 +75,12 @@ struct H2WArgs {
 
 // (x0, x1) * s -> fp16 pair h, residual pair l; |x| is clamped at lim = 65000 / s first
 __device__ __forceinline__ void split_pair_s(float x0, float x1, float s, float lim, unsigned& h, unsigned& l) {
+#if NEF_H2_CLAMP
     x0 = __builtin_amdgcn_fmed3f(x0, -lim, lim);
     x1 = __builtin_amdgcn_fmed3f(x1, -lim, lim);
+#else
+    (void)lim;      // no clamp: a tile whose data does not fit is redone with its own scale (range rescue), its first pass is discarded
+#endif
     asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x0), "v"(s));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x1), "v"(s));
     asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
@@ -80,9 +88,20 @@ __device__ __forceinline__ void split_pair_s(float x0, float x1, float s, float 
 }
 // one value: the low halves of h and l (the high halves are not defined)
 __device__ __forceinline__ void split_one_s(float x0, float s, float lim, unsigned& h, unsigned& l) {
+#if NEF_H2_CLAMP
     x0 = __builtin_amdgcn_fmed3f(x0, -lim, lim);
+#else
+    (void)lim;
+#endif
     asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x0), "v"(s));
     asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+}
+
+// scale that puts a measured magnitude at [2^8, 2^9)
+__device__ __forceinline__ float scale_for(float m) {
+    int e;
+    (void)frexpf(m, &e);
+    return ldexpf(1.f, 9 - e);
 }
 
 __device__ __forceinline__ float scale_from(const float* amax, float fallback) {
@@ -188,7 +207,12 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, SPLIT ? 1 : 2) void conv_h2w_ker
     int n_hi = (int)(per * (sp + 1));
     if (n_hi > a.n_tiles) n_hi = a.n_tiles;
 
-    const float sx = scale_from(a.x_amax, a.x_scale), sg = scale_from(a.gy_amax, a.gy_scale);
+    // Range rescue (round 5, as conv_h2_kernel): the workgroup's whole share is redone with scales from its OWN operands if an element
+    // left fp16's range under the launch's scales; the pass is a lambda inlined twice (a backward branch demotes the arrays to
+    // scratch).  Returns true when the partial sums were written.
+    float* const Wl = reinterpret_cast<float*>(smem_w);      // [2][8] wave magnitudes, written behind the last tile (the stages are free then)
+    float rx_ = 0.f, rg_ = 0.f;                              // the share's magnitudes, left by a pass that did not fit
+    auto share_pass = [&](const float sx, const float sg, const bool last) __attribute__((always_inline)) -> bool {
     const float limx = 65000.f / sx, limg = 65000.f / sg;
     float amax_x = 0.f, amax_g = 0.f;
 
@@ -319,21 +343,31 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, SPLIT ? 1 : 2) void conv_h2w_ker
 #undef NEF_W_ISSUE
 #undef NEF_W_STORE
 
-    // this launch's operand magnitudes, for the call site's next launch
-    if (a.x_amax_next || a.clamped) {
+    // this share's operand magnitudes: for the rescue, and for the call site's next launch
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            amax_x = fmaxf(amax_x, __shfl_xor(amax_x, o, 64));
-            amax_g = fmaxf(amax_g, __shfl_xor(amax_g, o, 64));
+    for (int o = 32; o > 0; o >>= 1) {
+        amax_x = fmaxf(amax_x, __shfl_xor(amax_x, o, 64));
+        amax_g = fmaxf(amax_g, __shfl_xor(amax_g, o, 64));
+    }
+    if (lane == 0) Wl[wave_u] = amax_x, Wl[8 + wave_u] = amax_g;
+    __syncthreads();
+    {
+        float wx = 0.f, wg_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) wx = fmaxf(wx, Wl[i]), wg_ = fmaxf(wg_, Wl[8 + i]);
+        __syncthreads();      // (the next pass stages over Wl)
+        if (!last && !(wx * sx < 65000.f && wg_ * sg < 65000.f) && wx < 3e38f && wg_ < 3e38f) {
+            rx_ = wx, rg_ = wg_;
+            return false;
         }
-        if (a.clamped && lane == 0 && !(amax_x * sx < 65000.f && amax_g * sg < 65000.f)) atomicAdd(a.clamped, 1);
-        if (a.x_amax_next && lane == 0) {
-            unsigned* const px = reinterpret_cast<unsigned*>(a.x_amax_next);
-            unsigned* const pg = reinterpret_cast<unsigned*>(a.gy_amax_next);
-            const unsigned bx = __builtin_bit_cast(unsigned, amax_x), bg = __builtin_bit_cast(unsigned, amax_g);
-            if (amax_x < 3e38f && bx > __atomic_load_n(px, __ATOMIC_RELAXED)) atomicMax(px, bx);
-            if (amax_g < 3e38f && bg > __atomic_load_n(pg, __ATOMIC_RELAXED)) atomicMax(pg, bg);
-        }
+    }
+    if (a.clamped && lane == 0 && !(amax_x * sx < 65000.f && amax_g * sg < 65000.f)) atomicAdd(a.clamped, 1);      // not finite
+    if (a.x_amax_next && lane == 0) {
+        unsigned* const px = reinterpret_cast<unsigned*>(a.x_amax_next);
+        unsigned* const pg = reinterpret_cast<unsigned*>(a.gy_amax_next);
+        const unsigned bx = __builtin_bit_cast(unsigned, amax_x), bg = __builtin_bit_cast(unsigned, amax_g);
+        if (amax_x < 3e38f && bx > __atomic_load_n(px, __ATOMIC_RELAXED)) atomicMax(px, bx);
+        if (amax_g < 3e38f && bg > __atomic_load_n(pg, __ATOMIC_RELAXED)) atomicMax(pg, bg);
     }
 
     // partial sums: ws[split][g][k][co][ci]; a lane's column is ci = wn 32 + lo, its rows co = (wm MCO + i) 32 + 4 hi + (r & 3) + 8 (r >> 2)
@@ -354,6 +388,11 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, SPLIT ? 1 : 2) void conv_h2w_ker
             }
         }
     }
+    return true;
+    };      // share_pass
+    const float sx0 = scale_from(a.x_amax, a.x_scale), sg0 = scale_from(a.gy_amax, a.gy_scale);
+    if (!share_pass(sx0, sg0, false))
+        (void)share_pass(rx_ * sx0 < 65000.f ? sx0 : scale_for(rx_), rg_ * sg0 < 65000.f ? sg0 : scale_for(rg_), true);
 }
 
 template <int K, int PRO, int MCO, int SPLIT>
@@ -509,7 +548,12 @@ __global__ __launch_bounds__(64 * (WM / WR * WN + NP), 1) void conv_h2w2_kernel(
     int n_hi = (int)(per * (sp + 1));
     if (n_hi > a.n_tiles) n_hi = a.n_tiles;
 
-    const float sx = scale_from(a.x_amax, a.x_scale), sg = scale_from(a.gy_amax, a.gy_scale);
+    // Range rescue (round 5, as conv_h2w_kernel): the whole share again with scales from its own operands if an element left fp16's
+    // range; the pass -- both roles -- is a lambda inlined twice.  The producers know the magnitudes; they publish them through the
+    // first words of the (then idle) stages behind the last tile.
+    float* const Wl = reinterpret_cast<float*>(smem_w);      // [2][16] wave magnitudes
+    float rx_ = 0.f, rg_ = 0.f;
+    auto share_pass = [&](const float sx, const float sg, const bool last) __attribute__((always_inline)) -> bool {
     const float limx = 65000.f / sx, limg = 65000.f / sg;
     float amax_x = 0.f, amax_g = 0.f;
 
@@ -751,24 +795,34 @@ __global__ __launch_bounds__(64 * (WM / WR * WN + NP), 1) void conv_h2w2_kernel(
         }
     }
 
-    // this launch's operand magnitudes, for the call site's next launch
-    if (producer) {
-        if (a.x_amax_next || a.clamped) {
+    // this share's operand magnitudes: for the rescue, and for the call site's next launch
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                amax_x = fmaxf(amax_x, __shfl_xor(amax_x, o, 64));
-                amax_g = fmaxf(amax_g, __shfl_xor(amax_g, o, 64));
-            }
-            if (a.clamped && lane == 0 && !(amax_x * sx < 65000.f && amax_g * sg < 65000.f)) atomicAdd(a.clamped, 1);
-            if (a.x_amax_next && lane == 0) {
-                unsigned* const px = reinterpret_cast<unsigned*>(a.x_amax_next);
-                unsigned* const pg = reinterpret_cast<unsigned*>(a.gy_amax_next);
-                const unsigned bx = __builtin_bit_cast(unsigned, amax_x), bg = __builtin_bit_cast(unsigned, amax_g);
-                if (amax_x < 3e38f && bx > __atomic_load_n(px, __ATOMIC_RELAXED)) atomicMax(px, bx);
-                if (amax_g < 3e38f && bg > __atomic_load_n(pg, __ATOMIC_RELAXED)) atomicMax(pg, bg);
-            }
+    for (int o = 32; o > 0; o >>= 1) {
+        amax_x = fmaxf(amax_x, __shfl_xor(amax_x, o, 64));
+        amax_g = fmaxf(amax_g, __shfl_xor(amax_g, o, 64));
+    }
+    if (lane == 0) Wl[wave_u] = amax_x, Wl[16 + wave_u] = amax_g;      // (consumer waves: 0)
+    __syncthreads();
+    {
+        float wx = 0.f, wg_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC + NP; ++i) wx = fmaxf(wx, Wl[i]), wg_ = fmaxf(wg_, Wl[16 + i]);
+        __syncthreads();      // (the next pass stages over Wl)
+        if (!last && !(wx * sx < 65000.f && wg_ * sg < 65000.f) && wx < 3e38f && wg_ < 3e38f) {
+            rx_ = wx, rg_ = wg_;
+            return false;
         }
-        return;
+    }
+    if (producer) {
+        if (a.clamped && lane == 0 && !(amax_x * sx < 65000.f && amax_g * sg < 65000.f)) atomicAdd(a.clamped, 1);      // not finite
+        if (a.x_amax_next && lane == 0) {
+            unsigned* const px = reinterpret_cast<unsigned*>(a.x_amax_next);
+            unsigned* const pg = reinterpret_cast<unsigned*>(a.gy_amax_next);
+            const unsigned bx = __builtin_bit_cast(unsigned, amax_x), bg = __builtin_bit_cast(unsigned, amax_g);
+            if (amax_x < 3e38f && bx > __atomic_load_n(px, __ATOMIC_RELAXED)) atomicMax(px, bx);
+            if (amax_g < 3e38f && bg > __atomic_load_n(pg, __ATOMIC_RELAXED)) atomicMax(pg, bg);
+        }
+        return true;
     }
 
     // partial sums: ws[split][g][k][co][ci]; a lane's column is ci = wn 32 + lo, its rows co = wm 32 + 4 hi + (r & 3) + 8 (r >> 2)
@@ -783,6 +837,11 @@ __global__ __launch_bounds__(64 * (WM / WR * WN + NP), 1) void conv_h2w2_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) wsp[((int64_t)k * a.Cog + co0 + (r & 3) + 8 * (r >> 2)) * a.Cig + ci] = acc[i][k][r] * ds;
     }
+    return true;
+    };      // share_pass
+    const float sx0 = scale_from(a.x_amax, a.x_scale), sg0 = scale_from(a.gy_amax, a.gy_scale);
+    if (!share_pass(sx0, sg0, false))
+        (void)share_pass(rx_ * sx0 < 65000.f ? sx0 : scale_for(rx_), rg_ * sg0 < 65000.f ? sg0 : scale_for(rg_), true);
 }
 
 template <int K, int PRO, int WM, int WN, int WR, int TTv, int NP, int DEPTH>

@@ -273,8 +273,10 @@ def h2_ok(K, Cin_g, Cout_g, T_out, pro=0):
 # Range, in ONE place (bench.py and Solver quote these): the scale puts `cur` at [2^8, 2^9); amax_roll follows a
 # measurement UP as soon as it exceeds H2_FOLLOW_UP x cur and DOWN only once it is H2_FOLLOW_DOWN x smaller (sticky: repeated
 # passes split their operands identically), so the operand a launch meets is below 2^10 as long as it grew less than
-# H2_HEADROOM = 2^16 / 2^10 = 64 x since the previous pass.  Beyond that the largest elements are clamped at 65000 / scale, the
-# launch counts itself in `clamped`, and the train step that contains it is SKIPPED on the device (h2_taint / sgd_momentum).
+# H2_HEADROOM = 2^16 / 2^10 = 64 x since the previous pass.  Beyond that the kernels RESCUE the launch: a workgroup whose tile (weight
+# gradient: share) does not fit redoes it with the scale its own data asks for (conv_h2.hip / conv_h2w.hip), so finite operands are
+# never clamped; a launch that meets non-finite data (or the opt-in producer / consumer form, which still clamps) counts itself in
+# `clamped`, and the train step that contains it is SKIPPED on the device (h2_taint / sgd_momentum).
 H2_FOLLOW_UP = 2.0
 H2_FOLLOW_DOWN = 64.0
 H2_HEADROOM = 64
@@ -315,9 +317,9 @@ def _amax_state(dev):
 
 def h2_clamped(reset=True):
     """Waves of split-fp16 launches (sited ones: measuring launches are not counted) that had to clamp an operand element at
-    fp16's range since the last call -- an operand grew by more than H2_HEADROOM x from one pass to the next, so those launches'
-    results are off (the next pass has followed; a train step that contains one is skipped, see h2_taint).  Reading
-    synchronises: call it at a logging interval, not per step."""
+    fp16's range since the last call: since round 5 that means NON-FINITE data (finite operands beyond the headroom are rescued
+    inside the launch), or the opt-in producer / consumer form, which has no rescue.  Those launches' results are off; a train step
+    that contains one is skipped (h2_taint).  Reading synchronises: call it at a logging interval, not per step."""
     n = 0
     for st in _AMAX.values():
         tot = int(st["clamped"].item())

@@ -245,22 +245,23 @@ class Solver:
 
     @staticmethod
     def _check_h2_range(phase, optim):
-        """The split-fp16 convs clamp an operand that grew more than ops.H2_HEADROOM x between two consecutive passes (fp16 ends
-        at 65504; the reference's fp32 nn.Conv1d, model_nefnet.py:18-21, has no such limit).  A train step that contained such a
-        launch was SKIPPED on the device when the optimiser is FusedSGD (ops.h2_taint): that is reported; clamps nothing
-        protected against -- a test-phase forward, another optimiser -- mean wrong results were used: raise, unless
-        NEF_H2_ALLOW_CLAMP=1 (then warn).  NEF_H2=0 runs the fp32 kernels instead."""
+        """The split-fp16 convs count a launch whose operand is out of fp16's range even after the in-launch range rescue: non-finite
+        data (finite operands beyond ops.H2_HEADROOM x of growth are redone with their own scale inside the launch), or any
+        clamp of the opt-in producer / consumer kernel form (fp16 ends at 65504; the reference's fp32 nn.Conv1d,
+        model_nefnet.py:18-21, has no such limit).  A train step that contained such a launch was SKIPPED on the device when the
+        optimiser is FusedSGD (ops.h2_taint): that is reported; counts nothing protected against -- a test-phase forward,
+        another optimiser -- mean wrong results were used: raise, unless NEF_H2_ALLOW_CLAMP=1 (then warn).  NEF_H2=0 runs the
+        fp32 kernels instead."""
         clamped, skipped = ops.h2_clamped(), ops.h2_skipped()
         if not clamped and not skipped:
             return
-        msg = ('{} waves of split-fp16 conv launches clamped an operand in this {} phase (a tensor grew more than {}x between two '
-               'consecutive passes); {} train step(s) were skipped on the device'.format(clamped, phase, ops.H2_HEADROOM, skipped))
+        msg = ('{} waves of split-fp16 conv launches met an operand outside fp16\'s range in this {} phase (non-finite data; finite '
+               'operands are rescaled inside the launch); {} train step(s) were skipped on the device'.format(clamped, phase, skipped))
         protected = phase == 'train' and hasattr(optim, '_flat') and skipped > 0
         if protected or _env.get('NEF_H2_ALLOW_CLAMP') == '1':
             print('WARNING: ' + msg + ('' if protected else ' -- results of those launches are wrong (NEF_H2_ALLOW_CLAMP=1)'))
             return
-        raise RuntimeError(msg + '; their results are wrong.  Set NEF_H2=0 (fp32 kernels) for data of this dynamic range, or '
-                                 'NEF_H2_ALLOW_CLAMP=1 to continue')
+        raise RuntimeError(msg + '; their results are wrong.  Set NEF_H2=0 (fp32 kernels), or NEF_H2_ALLOW_CLAMP=1 to continue')
 
     def run_one_epoch(self, dl, phase, optim=None, collect_views=None):
         """solver.py:139-246.  `collect_views` (default: the Solver's setting) = also return the per-view host lists the

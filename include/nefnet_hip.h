@@ -173,9 +173,12 @@ typedef struct nef_conv_args {
                               magnitude, and the launch stays capturable (nothing is read back by the host) */
     float* x_amax_next;    /* wino == 3: NULL, or a device word (zeroed by the caller) this launch max-accumulates the largest
                               |input| of ITS operand into -- next launch's x_amax */
-    int32_t* x_clamped;    /* wino == 3: NULL, or a device counter the launch adds 1 to (per wave) when an element of its scaled
-                              operand reached fp16's range and was clamped at 65000 / scale: the operand grew more than ~128x
-                              since its scale was measured -- results of THIS launch are off, the caller should know */
+    int32_t* x_clamped;    /* wino == 3: NULL, or a device counter the launch adds 1 to (per wave) when an element of its operand is
+                              still out of fp16's range AFTER the range rescue -- i.e. is not finite.  (A tile whose finite data does
+                              not fit under the launch's scale -- the operand grew more than ~64x since x_amax was measured -- is
+                              redone inside the launch with the scale its own data asks for; round 4 clamped it and counted it.)
+                              The producer / consumer form (nef_set_option(NEF_OPT_H2_FORM, 1)) has no rescue: it clamps at
+                              65000 / scale and counts */
 } nef_conv_args;
 
 /* y = epilogue(conv(x * in_scale, wp) + bias + res).  Also the bwd-data pass (pack with transpose_flip=1,

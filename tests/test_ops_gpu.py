@@ -1165,11 +1165,48 @@ def test_conv_h2_operand_distributions(conv_algo, kind, K):
     assert e[1] < small[0] and ed[1] < small[1] and ew[1] < small[2], (kind, e, ed, ew)
 
 
+@pytest.mark.parametrize("K", [3, 7])
+def test_conv_h2_range_rescue(conv_algo, K):
+    """A launch whose scale is wrong by far more than the headroom (explicit x_scale 2^14 on data of magnitude 10^3 .. 10^5: scaled
+    operands of 10^7 .. 10^9 against fp16's 65504) still returns the fp32-class result: every workgroup whose tile does not fit redoes
+    it with the scale its own data asks for -- forward with mixed tiles (one sample 100 x larger than the rest, one all-zero),
+    backward-data, and the weight gradient with either operand or both out of range (both kernel forms).  Nothing clamps."""
+    if conv_algo != "h2":
+        pytest.skip("split-fp16 path")
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    o.h2_clamped()
+    B, G, C, T = 6, 2, 128, 700
+    x = rnd(B, G * C, T, seed=740) * 1e3
+    x[2] *= 100.0
+    x[4] = 0.0
+    w = rnd(G * C, C, K, seed=741, scale=0.05)
+    r64 = F.conv1d(x.double(), w.double(), None, 1, K // 2, 1, G)
+    y = o.conv(GV.dense(g(x), G), o.pack_weight(g(w), G, T=T), C, K, x_scale=2.0 ** 14)
+    assert rel(y, r64) < 5e-7 and float(y[4].abs().max()) == 0.0
+    for b in (0, 2):      # per sample: the small samples are not drowned by the large one (tiles rescale independently)
+        assert rel(y[b], r64[b]) < 5e-7, b
+    gy = rnd(B, G * C, T, seed=742) * 1e4
+    d64 = torch.nn.grad.conv1d_input(x.shape, w.double(), gy.double(), padding=K // 2, groups=G)
+    gx = o.conv(GV.dense(g(gy), G), o.pack_weight(g(w), G, flip=True, T=T), C, K, role="conv_bwd_data", x_scale=2.0 ** 14)
+    assert rel(gx, d64) < 5e-7
+    w64 = torch.nn.grad.conv1d_weight(x.double(), w.shape, gy.double(), padding=K // 2, groups=G)
+    for sx, sg in ((2.0 ** 14, 2.0 ** -4), (2.0 ** -6, 2.0 ** 14), (2.0 ** 14, 2.0 ** 14)):
+        gw = o.conv_bwd_weight(GV.dense(g(x), G), GV.dense(g(gy), G), K, h2=True, x_scale=sx, gy_scale=sg)
+        assert rel(gw, w64) < 1e-6, (sx, sg)
+    # the first-form kernel (64-channel layers)
+    x6, g6 = x[:, :64].contiguous(), gy[:, :64].contiguous()
+    w6 = torch.nn.grad.conv1d_weight(x6.double(), (64, 64, K), g6.double(), padding=K // 2)
+    gw6 = o.conv_bwd_weight(GV.dense(g(x6), 1), GV.dense(g(g6), 1), K, h2=True, x_scale=2.0 ** 14, gy_scale=2.0 ** 14)
+    assert rel(gw6, w6) < 1e-6
+    assert o.h2_clamped() == 0
+
+
 def test_conv_h2_scale_follows_a_drifting_operand(conv_algo):
     """ops.amax_roll: an operand that grows x1.5 per pass for ten passes and then jumps x3 never clamps (the scale follows up as
     soon as the operand doubled: H2_HEADROOM = 64 x per pass whatever the history; round 4 followed at 64 x only, so this
-    sequence -- x57 of drift, then x3 -- ran into the clamp); a x200 jump does clamp, is counted, and the pass after it has
-    followed; shrinking operands keep their scale (sticky) and their precision."""
+    sequence -- x57 of drift, then x3 -- ran into the clamp); a x200 jump is beyond the headroom and is RESCUED inside the launch
+    (no clamp, fp32-class result); shrinking operands keep their scale (sticky) and their precision."""
     if conv_algo != "h2":
         pytest.skip("split-fp16 path")
     o = ops()
@@ -1196,8 +1233,10 @@ def test_conv_h2_scale_follows_a_drifting_operand(conv_algo):
         s *= 3.0
         assert one_pass(s)[0] < 5e-7
         assert o.h2_clamped() == 0
-        assert one_pass(s * 200.0)[0] > 1e-3 and o.h2_clamped() > 0        # beyond the headroom: clamped, counted
-        assert one_pass(s * 200.0)[0] < 5e-7 and o.h2_clamped() == 0       # ... and followed
+        # beyond the headroom: the tiles whose data does not fit are redone with their own scale inside the launch (range rescue,
+        # conv_h2.hip / conv_h2w.hip) -- nothing clamps, nothing is wrong; the pass after it has followed
+        assert one_pass(s * 200.0)[0] < 5e-7 and o.h2_clamped() == 0
+        assert one_pass(s * 200.0)[0] < 5e-7 and o.h2_clamped() == 0
         assert one_pass(s * 200.0 / 50.0)[0] < 5e-7                         # 50 x smaller: the scale stays (sticky), precision holds
         # 5000 x below the reference (100 x below the last pass): this pass still runs on the old scale -- 13 binades down the
         # absolute floor of the low term starts to show -- and the next one has followed down
@@ -1387,10 +1426,15 @@ def test_conv_h2_sites_are_sticky_and_scoped(conv_algo):
         assert abs(slot() - 50 * m0) < 1e-3 * m0 * 50         # ... and the next pass follows
         y5 = o.conv(GV.dense(x * 100, G), wp, C, K)           # x 2 on top of it: still inside the window of the NEW reference
         assert rel(y5, 100 * ref) < 1e-6 and o.h2_clamped() == 0
-        # a jump past fp16's range from one pass to the next: the launch clamps -- and says so
+        # a jump past fp16's range from one pass to the next: every tile is redone with its own scale inside the launch -- right
+        # result, no clamp; only data that is not finite still counts itself
         o.amax_roll()
         y7 = o.conv(GV.dense(x * 1e6, G), wp, C, K)
-        assert torch.isfinite(y7).all() and rel(y7, 1e6 * ref) > 1e-2 and o.h2_clamped() > 0 and o.h2_clamped() == 0
+        assert torch.isfinite(y7).all() and rel(y7, 1e6 * ref) < 1e-6 and o.h2_clamped() == 0
+        xb = (x * 1e6).clone()
+        xb[0, 0, 0] = float("inf")
+        o.conv(GV.dense(xb, G), wp, C, K)
+        assert o.h2_clamped() > 0 and o.h2_clamped() == 0
         o.amax_roll()
         y8 = o.conv(GV.dense(x * 1e6, G), wp, C, K)           # the next pass has followed
         assert rel(y8, 1e6 * ref) < 1e-6 and o.h2_clamped() == 0
