@@ -127,7 +127,7 @@ SIGNATURES = {
     "nef_loss_ws_bytes": (sz, []),
     "nef_loss_fwd": (i32, [p, p, p, p, p, p, sz, i64, f32, f32, f32, i32, i32, p]),
     "nef_loss_bwd": (i32, [p, p, p, p, p, p, p, p, i64, f32, f32, f32, i32, i32, p]),
-    "nef_sgd_momentum": (i32, [p, p, p, i64, f32, f32, f32, i32, p, p, p]),
+    "nef_sgd_momentum": (i32, [p, p, p, i64, f32, f32, f32, i32, p, p, p, p]),
     "nef_h2_taint": (i32, [p, p, p, p]),
     "nef_view_metrics": (i32, [p, p, p, p, p, i32, i32, i32, p]),
     "nef_pano_h_from_f32": (i32, [p, p, i32, i32, i32, p]),

@@ -1166,7 +1166,9 @@ __global__ void loss_bwd_kernel(const float* __restrict__ pred, const float* __r
 // torch.optim.SGD(momentum)                                 (codes/solver/optim_scheduler.py:10)
 // ------------------------------------------------------------------------------------------------
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, int64_t n,
-                           float lr, float mu, float gscale, int first, const float* __restrict__ skip, int32_t* skipped) {
+                           float lr, float mu, float gscale, int first, const float* __restrict__ skip, int32_t* skipped,
+                           const float* __restrict__ lr_dev) {
+    if (lr_dev) lr = lr_dev[0];      // a captured launch freezes its scalar arguments: the learning rate of a replayed step lives in memory
     if (skip && skip[0] > 0.f) {      // a tainted step (nef_h2_taint): parameters and momentum stay as they are
         if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
         return;
@@ -1802,12 +1804,12 @@ int nef_loss_bwd(const float* pred, const float* pred_p, const float* pred_l, co
 }
 
 int nef_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float gscale, int first_step,
-                     const float* skip_if_positive, int32_t* skipped, nef_stream_t stream) {
+                     const float* skip_if_positive, int32_t* skipped, const float* lr_dev, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(p && g && buf, NEF_E_NULL);
     NEF_REQUIRE(n > 0, NEF_E_SHAPE);
     hipLaunchKernelGGL(sgd_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, p, g, buf, n, lr, mu, gscale,
-                       first_step, skip_if_positive, skipped);
+                       first_step, skip_if_positive, skipped, lr_dev);
     return nef_launch_status();
 }
 

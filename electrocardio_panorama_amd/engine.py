@@ -494,7 +494,8 @@ def sweep_eval(P, Bf, latent, query_thetas, chunk=8):
                                   Bf[pre + ".running_var"], BN_EPS)
         wf, bf_ = ops.fold_bn(P[f"{blk}.double_conv.{cv}.weight"], P[f"{blk}.double_conv.{cv}.bias"], a, b)
         # the folded weights are temporaries and every chunk of angles runs through them: one named call site per layer
-        wp.append(ops.pack_weight(wf, 1, T=(2 * T if li < 2 else 4 * T), f4=True, site=("sweep", li), shared=True))
+        # (layer 0 runs with the per-angle channel scale: not a plain launch -- at 2T <= 64 it must not take the packed short-row form)
+        wp.append(ops.pack_weight(wf, 1, T=(2 * T if li < 2 else 4 * T), f4=True, site=("sweep", li), shared=True, plain=li > 0))
         bias.append(bf_)
     uv = GV.dense(u, 1)
     rest = torch.empty(B, Q, 4 * T, device=dev, dtype=torch.float32)

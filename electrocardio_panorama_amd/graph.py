@@ -9,7 +9,8 @@ travel through device words that the kernels read at run time.  Same arithmetic 
 
 One graph (with its own static input buffers) is kept per input shape, so a final partial batch or alternating shapes
 replay instead of re-capturing; the flat parameter / gradient / momentum buffers are shared by all of them and survive
-every re-capture (shape change, learning-rate change).  `state_dict()` / `load_state_dict()` carry the momentum buffer
+every re-capture (shape change); the learning rate lives in a device word the captured SGD launch reads, so a scheduler step costs
+one small copy and no re-capture.  `state_dict()` / `load_state_dict()` carry the momentum buffer
 for checkpoints.
 
 Data parallel (world > 1): the step is captured as TWO graphs cut at the early-bucket point of the backward pass; the all-reduce
@@ -48,6 +49,7 @@ class GraphedTrainStep:
         self.flat_p = self.flat_g = self.flat_buf = None
         self.live = None
         self.choice_dev = None
+        self.lr_dev = None
         self.calls = 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # data parallel: capture the step as two graphs with the early gradient bucket's all-reduce between them (_capture_split)
@@ -110,8 +112,10 @@ class GraphedTrainStep:
             return engine.backward(P, sv, g3)
 
     def _sgd(self):
+        # the learning rate travels through a device word (a captured launch freezes its scalars): a scheduler step updates the word,
+        # nothing is re-captured
         ops.sgd_momentum(self.flat_p, self.flat_g, self.flat_buf, self.lr, self.mu, 1.0 / self.world, False,
-                         skip=self.flat_g_all[:1])
+                         skip=self.flat_g_all[:1], lr_dev=self.lr_dev)
 
     def _body(self):
         grads = self._fwd_bwd()
@@ -182,6 +186,7 @@ class GraphedTrainStep:
             self.seed_dev = torch.zeros(1, device=dev, dtype=torch.int64)
             self.status = torch.zeros(1, device=dev, dtype=torch.int32)
             self.losses = torch.zeros(4, device=dev, dtype=torch.float32)
+            self.lr_dev = torch.full((1,), self.lr, device=dev, dtype=torch.float32)
             self._host = torch.zeros(4, dtype=torch.int64).pin_memory()
         # the probe runs THIS step's inputs, Standin choices and dropout seed (drawn by __call__ before it builds): the split-fp16
         # convs measure their operands in it, and what they measure must be what the eager path measures on the same step
@@ -245,11 +250,11 @@ class GraphedTrainStep:
 
     # -------------------------------------------------------------------------------------------------
     def set_lr(self, lr):
-        """A captured launch freezes its scalar arguments: a new learning rate re-captures the graphs (parameters and
-        momentum live in the shared flat buffers and are untouched)."""
+        """The captured SGD launch reads its learning rate from a device word: a new value is one small copy, no re-capture."""
         if float(lr) != self.lr:
             self.lr = float(lr)
-            self.slots.clear()
+            if getattr(self, "lr_dev", None) is not None:
+                self.lr_dev.fill_(self.lr)
 
     def state_dict(self):
         """The optimiser state of the graphed path: the flat momentum buffer and the parameter order it refers to."""
@@ -279,9 +284,10 @@ class GraphedTrainStep:
         self.model._check_inputs(data, rois)       # what Model_nefnet.forward rejects (float rois, L % 4, CPU tensors) is rejected here too
         if self.optimizer is not None:
             g = self.optimizer.param_groups[0]
-            if float(g["lr"]) != self.lr or float(g["momentum"]) != self.mu:      # a scheduler stepped: re-capture
-                self.lr, self.mu = float(g["lr"]), float(g["momentum"])
+            if float(g["momentum"]) != self.mu:                # (momentum is a captured scalar: re-capture)
+                self.mu = float(g["momentum"])
                 self.slots.clear()
+            self.set_lr(g["lr"])                               # a scheduler stepped: the device word follows, nothing is re-captured
             fl = self.optimizer._flat.get(0)
             if self.flat_p is not None and (fl is None or fl["p"] is not self.flat_p):   # e.g. optimizer.load_state_dict
                 self.slots.clear()

@@ -409,11 +409,13 @@ def wino_ok(K, Cin_g, Cout_g, T_out, pro=0):
 _PREPACKED = {}     # (weight data_ptr, G, flip, wino) -> operand packed by pack_many(), consumed by the next pack_weight()
 
 
-def _pack_shape(w, G, flip, T, f4=False):
+def _pack_shape(w, G, flip, T, f4=False, plain=True):
+    """`plain`: the launch has no prologue, channel scale, statistics or BatchNorm-backward sums -- the only launches the packed
+    short-row form of the split-fp16 kernel (8 <= T <= 64) takes; pass False for the others so that they fall back to the fp32 kernels."""
     Cog, Cig, K = w.shape[0] // G, w.shape[1], w.shape[2]
     cin_g, cout_g = (Cog, Cig) if flip else (Cig, Cog)          # roles in the launch that consumes the operand
     wino = (WINO_FWD if f4 else 1) if (T is not None and wino_ok(K, cin_g, cout_g, T)) else 0
-    if (T is not None and h2_ok(K, cin_g, cout_g, T) and _H2_DIR[bool(flip)] and str(K) in _H2_K and
+    if (T is not None and (T >= 128 or plain) and h2_ok(K, cin_g, cout_g, T) and _H2_DIR[bool(flip)] and str(K) in _H2_K and
             _h2_fills(G, cout_g, T, 256, 128 if cout_g % 128 == 0 else 64)):
         wino = 3
     return Cog, Cig, K, wino
@@ -451,13 +453,13 @@ def pack_many(requests):
     _lib.check(L.nef_pack_weights(descs, len(reqs), _stream()), "nef_pack_weights")
 
 
-def pack_weight(w, G, flip=False, T=None, f4=False, site=None, shared=False):
+def pack_weight(w, G, flip=False, T=None, f4=False, site=None, shared=False, plain=True):
     """w [G*Cog, Cig, K] -> packed operand (forward: [G][K][Cig][Cog]; flip: [G][K][Cog][Cig], taps reversed).
     `T`: output length of the conv launch this operand is for; when the Winograd F(2,3) path applies to that launch
     the operand is packed for it (marked with `.nef_wino`) and `conv()` takes that path; `f4` allows the F(4,3) form."""
     L = _lib.load()
     _chk(w)
-    Cog, Cig, K, wino = _pack_shape(w, G, flip, T, f4)
+    Cog, Cig, K, wino = _pack_shape(w, G, flip, T, f4, plain)
     hit = _PREPACKED.pop((w.data_ptr(), G, bool(flip), wino), None)
     if hit is not None and hit[1] is w:
         return hit[0]
@@ -1293,16 +1295,16 @@ def view_metrics(pred, gt, rois=None):
     return psnr, ssim
 
 
-def sgd_momentum(p, g, buf, lr, mu, gscale, first_step, skip=None):
+def sgd_momentum(p, g, buf, lr, mu, gscale, first_step, skip=None, lr_dev=None):
     """`skip`: a one-element fp32 device view (h2_taint's output, summed over the ranks): > 0 leaves p and buf untouched and counts
-    the step in h2_skipped()."""
+    the step in h2_skipped().  `lr_dev`: a one-element fp32 device tensor that replaces `lr` at run time (captured steps)."""
     L = _lib.load()
     _chk(p), _chk(buf)
     assert g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()
     ev = _hbm("sgd_momentum", p, p, g, buf, buf)
     sk = _p(_amax_state(p.device)["skipped"]) if skip is not None else None
-    _lib.check(L.nef_sgd_momentum(_p(p), _p(g), _p(buf), p.numel(), lr, mu, gscale, int(first_step), _p(skip), sk, _stream()),
-               "nef_sgd_momentum")
+    _lib.check(L.nef_sgd_momentum(_p(p), _p(g), _p(buf), p.numel(), lr, mu, gscale, int(first_step), _p(skip), sk, _p(lr_dev),
+                                  _stream()), "nef_sgd_momentum")
     _done(ev)
 
 

@@ -449,7 +449,8 @@ int nef_loss_bwd(const float* pred, const float* pred_p, const float* pred_l, co
 int nef_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float gscale,
                      int first_step, const float* skip_if_positive /* NULL, or a device word: > 0 = leave p and buf as they are
                      (a step whose gradients are tainted, see nef_h2_taint) */, int32_t* skipped /* NULL, or a device counter of
-                     skipped steps */, nef_stream_t stream);
+                     skipped steps */, const float* lr_dev /* NULL, or a device word that replaces `lr` at run time (hipGraph replay: a scheduler's
+                     new learning rate without a re-capture) */, nef_stream_t stream);
 /* The split-fp16 convolutions (conv args wino = 3, nef_conv_bwd_weight_h2) count the waves that had to clamp an operand at fp16's
  * range in a device counter (x_clamped); such a launch's results are wrong.  nef_h2_taint writes out[0] = (float)(*clamped_total -
  * *mark) -- the clamps since the previous call -- and sets *mark = *clamped_total: called once per train step behind the backward

@@ -755,10 +755,22 @@ def test_graphed_step_keeps_momentum_across_shapes_and_checkpoints():
         assert torch.equal(l_a, l_b)
     p2 = dict(m2.named_parameters())
     assert max(rel(p2[k], pg[k]) for k in pg) < (1e-5 if _ops.H2 else 1e-7)
-    # a new learning rate re-captures but keeps the momentum
-    before = step.flat_buf.clone()
+    # a new learning rate does NOT re-capture (the captured SGD launch reads it from a device word) and keeps the momentum; the
+    # replayed step applies it: the update of the next step is lr_new / lr_old times what the old rate would have given
+    before, graphs = step.flat_buf.clone(), dict(step.slots)
+    p_before = step.flat_p.clone()
+    st = random.getstate()
+    step(b["data"], b["input_theta"], b["target_theta"], b["rois"], b["target_view"])
+    d_old = (step.flat_p - p_before).clone()
+    step.flat_p.copy_(p_before), step.flat_buf.copy_(before)
+    lr_old = step.lr
     step.set_lr(0.01)
-    assert not step.slots and torch.equal(step.flat_buf, before)
+    assert step.slots == graphs and torch.equal(step.flat_buf, before)
+    random.setstate(st)
+    step.calls -= 1
+    step(b["data"], b["input_theta"], b["target_theta"], b["rois"], b["target_view"])
+    d_new = step.flat_p - p_before
+    assert rel(d_new, d_old * (0.01 / lr_old)) < 1e-3      # (differences of fp32 parameters: each update is rounded at the parameter's ulp)
 
 
 def test_adversarial_rois_full_step_vs_oracle():
