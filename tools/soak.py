@@ -29,3 +29,10 @@ for i in range(N):
               f"reserved {torch.cuda.memory_reserved()/2**30:.2f} GiB  peak {torch.cuda.max_memory_allocated()/2**30:.2f} GiB", flush=True)
 h = torch.stack(hist).cpu().numpy()
 print("loss first/last:", h[0], h[-1], "finite:", bool(np.isfinite(h).all()), "status:", model.segment_status())
+from electrocardio_panorama_amd import ops
+print("split-fp16: clamped waves", ops.h2_clamped(reset=False), "skipped steps", ops.h2_skipped(reset=False))
+st = next(iter(ops._AMAX.values())) if ops._AMAX else None
+if st is not None:
+    cur = st["cur"][:st["n"]].cpu().numpy()
+    if (cur > 0).any():
+        print(f"sites {st['n']}, reference magnitudes min {cur[cur > 0].min():.3e} max {cur.max():.3e}")
