@@ -52,6 +52,10 @@ class GraphedTrainStep:
         self.lr_dev = None
         self.calls = 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # dp: the step sums its gradients through torch.distributed.  True for more than one rank -- and for a ONE-rank group under the
+        # NEF_DIST_FORCE test hook, so that the collectives between the two graph replays run on the real backend (RCCL) of a one-GPU box
+        from . import parallel as _par
+        self.dp = self.world > 1 or (dist.is_available() and dist.is_initialized() and _par._hook("NEF_DIST_FORCE") == "1")
         # data parallel: capture the step as two graphs with the early gradient bucket's all-reduce between them (_capture_split)
         import os
         self.split_capture = _env.get("NEF_GRAPH_SPLIT", "1") != "0"
@@ -121,7 +125,7 @@ class GraphedTrainStep:
         grads = self._fwd_bwd()
         torch.cat([grads[k].reshape(-1) for k in self.live], out=self.flat_g)
         ops.h2_taint(self.flat_g_all[:1])      # this step's clamped split-fp16 launches: the update is skipped (on every rank)
-        if self.world == 1:
+        if not self.dp:
             self._sgd()
 
     def _capture_split(self):
@@ -195,7 +199,7 @@ class GraphedTrainStep:
         # eager probe (no update): which parameters are live, and every kernel variant gets its one-time setup
         saved = {k: v.clone() for k, v in self.model.named_buffers()}
         grads = self._fwd_bwd()
-        if self.world > 1:                   # the eager probe may have started an early gradient bucket: retire it
+        if self.dp:                          # the eager probe may have started an early gradient bucket: retire it
             from . import parallel
             pend = parallel.take_early()
             if pend is not None:
@@ -207,7 +211,7 @@ class GraphedTrainStep:
         graph = torch.cuda.CUDAGraph()
         saved = {k: v.clone() for k, v in self.model.named_buffers()}
         p0, b0 = self.flat_p.clone(), self.flat_buf.clone()
-        if self.world > 1 and self.split_capture:
+        if self.dp and self.split_capture:
             graph = self._capture_split()
         else:
             with torch.cuda.graph(graph):
@@ -306,7 +310,7 @@ class GraphedTrainStep:
             self._restore_momentum()
         self._use(slot)
         self._stage(data, in_theta, q_theta, rois, target, draw=False)
-        if self.world == 1:
+        if not self.dp:
             slot["graph"].replay()
             return self.losses
         from . import parallel

@@ -44,5 +44,31 @@ for bf in model.buffers():
 torch.cuda.synchronize()
 after = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
 assert not torch.equal(before, after) and bool(torch.isfinite(after).all())
+# the GRAPHED data-parallel step on the real backend: two captured graphs, the early gradient bucket's RCCL all-reduce started on the
+# communication stream between the replays, the encoder bucket (+ taint word) reduced behind the second replay -- against eager
+# FusedSGD steps on a copy of the model (bit-identical parameters, as in the gloo world-2 test)
+import copy                                                                   # noqa: E402
+from electrocardio_panorama_amd.graph import GraphedTrainStep                 # noqa: E402
+m_e = build_model(cfg).float().to(dev).train()
+m_e.load_state_dict(copy.deepcopy(model.state_dict()))
+m_g = build_model(cfg).float().to(dev).train()
+m_g.load_state_dict(copy.deepcopy(model.state_dict()))
+m_e.dropout_p = m_g.dropout_p = 0.0
+o_e, o_g = get_optimizer(cfg, m_e.parameters()), get_optimizer(cfg, m_g.parameters())
+stepper = GraphedTrainStep(m_g, cfg, optimizer=o_g)
+assert stepper.dp and stepper.split_capture
+for it in range(3):
+    random.seed(10 + it)
+    out = m_e(b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train")
+    lossf(*out, b["target_view"].unsqueeze(1), cfg)[0].backward()
+    o_e.step()
+    o_e.zero_grad()
+    random.seed(10 + it)
+    stepper(b["data"], b["input_theta"], b["target_theta"], b["rois"], b["target_view"])
+torch.cuda.synchronize()
+assert isinstance(next(iter(stepper.slots.values()))["graph"], tuple)          # the split capture was taken
+pe = torch.cat([p.detach().reshape(-1) for p in m_e.parameters()])
+pg = torch.cat([p.detach().reshape(-1) for p in m_g.parameters()])
+assert torch.equal(pe, pg), float((pe - pg).abs().max())
 dist.destroy_process_group()
 print("RCCL_OK")
