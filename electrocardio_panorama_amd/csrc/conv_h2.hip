@@ -149,6 +149,25 @@ __global__ __launch_bounds__(256) void pack_h2_kernel(H2PackTable tab) {
 // PRO as in conv_fwd_kernel (bit0: BatchNorm affine + ReLU of the producing layer, bit1: x2 linear upsampling of a
 // half-resolution input), applied to the fp32 values before the split.
 // ------------------------------------------------------------------------------------------------------------------
+// A/B switches of the range rescue (tools/h2_rescue_ab.sh): RESCUE 0 = one pass, no second copy of the tile's work; AMAX 0 = the
+// staging does not track the operand magnitude either (x_amax_next is then not written: timing only); EPI_ALWAYS 1 = the first
+// pass runs its epilogue even when the tile has to be redone (the second pass overwrites it).
+#ifndef NEF_H2_RESCUE
+#define NEF_H2_RESCUE 1
+#endif
+#ifndef NEF_H2_AMAX
+#define NEF_H2_AMAX 1
+#endif
+#ifndef NEF_H2_EPI_ALWAYS
+#define NEF_H2_EPI_ALWAYS 0
+#endif
+#if NEF_H2_AMAX
+#define NEF_H2_TRACK1(V) amax_ = fmaxf(amax_, fabsf(V));
+#define NEF_H2_TRACK2(V, W) amax_ = fmaxf(amax_, fmaxf(fabsf(V), fabsf(W)));
+#else
+#define NEF_H2_TRACK1(V)
+#define NEF_H2_TRACK2(V, W)
+#endif
 #ifndef NEF_H2_LAYOUT
 #define NEF_H2_LAYOUT 1
 #endif
@@ -165,7 +184,7 @@ __global__ __launch_bounds__(256) void pack_h2_kernel(H2PackTable tab) {
 // positions between two samples are staged as zeros (the zero padding of both neighbours) and their outputs are dropped; a lane's
 // four adjacent outputs lie inside one sample or inside one gap.  No prologue, channel scale or statistics in this mode.
 template <int K, int PRO, int TM, bool PACK = false>
-__global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)) ? NEF_H2_OCC1 : 2) void conv_h2_kernel(nef_conv_args a, int tps, int n_tiles, int m_tiles) {
+__global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)) ? NEF_H2_OCC1 : 2) void conv_h2_kernel(nef_conv_args a_, int tps_, int n_tiles_, int m_tiles_) {
     constexpr int MT = 64 * TM;                    // output channels per workgroup: 2 (co) x 2 (t) waves of TM x 4 tiles
     constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
     constexpr int NS = UP ? 2 : 1;
@@ -193,8 +212,23 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
     float* const El = Pl + (AFF ? 2 * PRO_MAX_CIN : 0);                    // [6][MT] epilogue tables
     float* const Al = El + 6 * MT;                                         // [4] the waves' operand magnitudes of this tile (range rescue)
 
-    const int tile = blockIdx.x % n_tiles;
-    const int gm = blockIdx.x / n_tiles;
+    // Range rescue (round 5): if an element of THIS tile turns out to exceed fp16's range under the launch's scale (the operand grew
+    // more than ops.H2_HEADROOM x since the call site measured it), the workgroup does its tile again with the scale its own data
+    // asks for -- the scale is a power of two that the epilogue divides out again, so tiles of one launch may use different ones.
+    // Costs a wave reduction and four LDS words per tile when nothing happens; a launch no longer clamps finite data at all.
+    // The tile's work is a lambda inlined TWICE (a backward branch around it made the register allocator demote the staging and
+    // accumulator arrays to scratch: 1.3 .. 4.3 KB per lane): returns the tile's largest |operand| if that did not fit and the
+    // epilogue was therefore skipped (`last` = false), else a negative number.
+    // The two copies share NOTHING but their roots: the second one starts from opaque copies of the workgroup id, the thread id and
+    // the kernel-argument pointer and derives everything again (tile, arguments, per-lane offsets).  Sharing them -- value
+    // numbering finds the second copy's scalars and offsets in the first -- kept ~40 scalar and ~20 vector registers live across
+    // the first copy for the sake of the second and cost the K = 3 launches 2 .. 15 % (tools/h2_rescue_ab.sh).
+    typedef const nef_conv_args __attribute__((address_space(4))) kargs_t;
+    auto tile_pass = [&](kargs_t* const ap, const int bid, const int tid, const int tps, const int n_tiles, const int m_tiles,
+                         const float xs_force, const bool last) __attribute__((always_inline)) -> float {
+#define a (*ap)
+    const int tile = bid % n_tiles;
+    const int gm = bid / n_tiles;
     const int mt = gm % m_tiles;
     const int g = gm / m_tiles;
     int b0, t0;
@@ -214,7 +248,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
     }
     const int m0 = mt * MT;
     const int T = a.T, Cig = a.Cin_g, Cog = a.Cout_g;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     const int lo = lane & 31, hi = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave_u >> 1, wn = wave_u & 1;
@@ -227,8 +261,25 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
     // this wave's 2 TM A fragments of (chunk c, tap kk): contiguous at ((g*nc16 + c)*K + kk)*ncot*2 KB + (m0/32 + TM wm)*2 KB
     const __amdgpu_buffer_rsrc_t wrs = nef_rsrc(wph + ((int64_t)g * nc16 * K * ncot * 2 + (int64_t)(m0 / 32 + TM * wm) * 2) * 512);
     const unsigned a_tap = (unsigned)(ncot * 2 * 1024);      // bytes between taps of one chunk
-    const unsigned avo = (unsigned)(lane * 16);
 
+    const int64_t soff = (int64_t)b0 * a.sc_bs + (int64_t)g * a.sc_gs;
+    // input scale (an exact power of two, undone in the epilogue): from the magnitude this operand had at the call site's previous
+    // launch (*x_amax -> [2^8, 2^9): with ops.amax_roll's follow-up rule, room for 64 x of growth since that launch before anything
+    // is clamped; full precision for elements within 2^-9 of the largest), else the caller's x_scale, else 1
+    float xs_ = xs_force;      // (second pass: the scale this tile's own data asks for)
+    if (!last) {
+        xs_ = a.x_scale != 0.f ? a.x_scale : 1.f;
+        if (a.x_amax) {
+            const float m_ = a.x_amax[0];
+            if (m_ > 0.f && m_ < 3e38f) {
+                int e_;
+                (void)frexpf(m_, &e_);
+                xs_ = ldexpf(1.f, 9 - e_);
+            }
+        }
+    }
+    const int pro_row0 = AFF ? (b0 / a.pro_Bp) * a.G * Cig + g * Cig : 0;
+    const unsigned avo = (unsigned)(lane * 16);
     unsigned xvo[NIT][NS];
     float lam[NIT];
     bool xok[NIT];
@@ -286,30 +337,10 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
             }
         }
     }
-    const int64_t soff = (int64_t)b0 * a.sc_bs + (int64_t)g * a.sc_gs;
-    // input scale (an exact power of two, undone in the epilogue): from the magnitude this operand had at the call site's previous
-    // launch (*x_amax -> [2^8, 2^9): with ops.amax_roll's follow-up rule, room for 64 x of growth since that launch before anything
-    // is clamped; full precision for elements within 2^-9 of the largest), else the caller's x_scale, else 1
-    float xs_ = a.x_scale != 0.f ? a.x_scale : 1.f;
-    if (a.x_amax) {
-        const float m_ = a.x_amax[0];
-        if (m_ > 0.f && m_ < 3e38f) {
-            int e_;
-            (void)frexpf(m_, &e_);
-            xs_ = ldexpf(1.f, 9 - e_);
-        }
-    }
-    const int pro_row0 = AFF ? (b0 / a.pro_Bp) * a.G * Cig + g * Cig : 0;
-    // Range rescue (round 5): if an element of THIS tile turns out to exceed fp16's range under the launch's scale (the operand grew
-    // more than ops.H2_HEADROOM x since the call site measured it), the workgroup does its tile again with the scale its own data
-    // asks for -- the scale is a power of two that the epilogue divides out again, so tiles of one launch may use different ones.
-    // Costs a wave reduction and four LDS words per tile when nothing happens; a launch no longer clamps finite data at all.
-    // The tile's work is a lambda inlined TWICE (a backward branch around it made the register allocator demote the staging and
-    // accumulator arrays to scratch: 1.3 .. 4.3 KB per lane): returns the tile's largest |operand| if that did not fit and the
-    // epilogue was therefore skipped (`last` = false), else a negative number.
-    auto tile_pass = [&](const float xs_, const bool last) __attribute__((always_inline)) -> float {
     const float xlim_ = 65000.f / xs_;
     float amax_ = 0.f;
+    float over_ret = -1.f;
+    (void)over_ret;
     f32x16 acc[TM][4];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -361,7 +392,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
                     o0 = uok[it][0] ? o0 : 0.f;                                                                     \
                     o1 = uok[it][1] ? o1 : 0.f;                                                                     \
                     o0 *= sa_[rr], o1 *= sa_[rr];                                                                   \
-                    amax_ = fmaxf(amax_, fmaxf(fabsf(o0), fabsf(o1)));                                              \
+                    NEF_H2_TRACK2(o0, o1)                                              \
                     v0_[rr] = o0, v1_[rr] = o1;                                                                     \
                 }                                                                                                   \
                 const int r = 2 * (lane + 64 * it);                                                                 \
@@ -388,7 +419,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
                 float o1 = (1.f - 0.75f) * sa + 0.75f * sb;                                                         \
                 o0 = mok[0] ? o0 * sc : 0.f;                                                                        \
                 o1 = mok[1] ? o1 * sc : 0.f;                                                                        \
-                amax_ = fmaxf(amax_, fmaxf(fabsf(o0), fabsf(o1)));                                                  \
+                NEF_H2_TRACK2(o0, o1)                                                  \
                 unsigned h_, l_;                                                                                    \
                 split2s(o0, o1, xs_, xlim_, h_, l_);                                                                \
                 unsigned char* p0_ = (BUFP) + NEF_H2_WADDR(256, wave) + 2 * lane;                                   \
@@ -406,7 +437,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
                 if constexpr (AFF) v = fmaxf(fmaf(v, pa_[rr], pb_[rr]), 0.f);                                       \
                 if constexpr (PRO != 0) v = xok[it] ? v : 0.f;                                                      \
                 v *= sa_[rr];                                                                                       \
-                amax_ = fmaxf(amax_, fabsf(v));                                                                     \
+                NEF_H2_TRACK1(v)                                                                                    \
                 v_[rr] = v;                                                                                         \
             }                                                                                                       \
             const int r = lane + 64 * it;                                                                           \
@@ -431,21 +462,21 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
 
     NEF_H2X_ISSUE(0, xrs)
     NEF_H2A_ISSUE(0, 0, 0)
-    if (threadIdx.x < MT) {     // epilogue tables, published by the barrier behind the first stage's LDS stores
-        const int ch_ = g * Cog + m0 + (int)threadIdx.x;
+    if (tid < MT) {     // epilogue tables, published by the barrier behind the first stage's LDS stores
+        const int ch_ = g * Cog + m0 + (int)tid;
         const float* const dsc = reinterpret_cast<const float*>(wph + (int64_t)a.G * K * Cog * Cig * 2);
-        El[threadIdx.x] = a.bias ? a.bias[ch_] : 0.f;
-        El[5 * MT + threadIdx.x] = dsc[ch_] / xs_;
+        El[tid] = a.bias ? a.bias[ch_] : 0.f;
+        El[5 * MT + tid] = dsc[ch_] / xs_;
         if (a.bnb_slots) {
             const int pr_ = (b0 / a.bnb_Bp) * a.G * Cog + ch_;
-            El[MT + threadIdx.x] = a.bnb_mean[pr_];
-            El[2 * MT + threadIdx.x] = a.bnb_invstd[pr_];
-            El[3 * MT + threadIdx.x] = a.bnb_a[pr_];
-            El[4 * MT + threadIdx.x] = a.bnb_b[pr_];
+            El[MT + tid] = a.bnb_mean[pr_];
+            El[2 * MT + tid] = a.bnb_invstd[pr_];
+            El[3 * MT + tid] = a.bnb_a[pr_];
+            El[4 * MT + tid] = a.bnb_b[pr_];
         }
     }
     if constexpr (AFF) {
-        for (int i = threadIdx.x; i < Cig; i += 256) {
+        for (int i = tid; i < Cig; i += 256) {
             Pl[i] = a.pro_a[pro_row0 + i];
             Pl[Cig + i] = a.pro_b[pro_row0 + i];
         }
@@ -520,9 +551,13 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
     }
     {
         const float wg_ = fmaxf(fmaxf(Al[0], Al[1]), fmaxf(Al[2], Al[3]));      // workgroup-uniform
-        if (!last && !(wg_ * xs_ < 65000.f) && wg_ < 3e38f) {
+        if (NEF_H2_RESCUE && !last && !(wg_ * xs_ < 65000.f) && wg_ < 3e38f) {
+#if NEF_H2_EPI_ALWAYS
+            over_ret = wg_;
+#else
             __syncthreads();      // (Al is rewritten by the second pass)
             return wg_;
+#endif
         }
     }
 #undef NEF_H2X_ISSUE
@@ -767,14 +802,27 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
             if (inb) slot_out[((int64_t)ch * a.B * nslot + slot) * 2 + (lo & 1)] = sv[0];
         }
     }
+#if NEF_H2_EPI_ALWAYS
+    __syncthreads();
+    return over_ret;
+#else
     return -1.f;
+#endif
+#undef a
     };      // tile_pass
-    const float over_ = tile_pass(xs_, false);
+    kargs_t* ap_ = (kargs_t*)__builtin_amdgcn_kernarg_segment_ptr();      // (a_ is the segment's first member)
+    (void)a_;
+    const float over_ = tile_pass(ap_, (int)blockIdx.x, (int)threadIdx.x, tps_, n_tiles_, m_tiles_, 0.f, false);
+#if NEF_H2_RESCUE
     if (over_ > 0.f) {
         int e_;
         (void)frexpf(over_, &e_);
-        (void)tile_pass(ldexpf(1.f, 9 - e_), true);
+        int bid_ = (int)blockIdx.x, tid_ = (int)threadIdx.x, tps2_ = tps_, nt2_ = n_tiles_, mt2_ = m_tiles_;
+        asm volatile("" : "+s"(ap_), "+s"(bid_), "+s"(tps2_), "+s"(nt2_), "+s"(mt2_));
+        asm volatile("" : "+v"(tid_));
+        (void)tile_pass(ap_, bid_, tid_, tps2_, nt2_, mt2_, ldexpf(1.f, 9 - e_), true);
     }
+#endif
 }
 
 template <int K, int PRO, int TM, bool PACK = false>
