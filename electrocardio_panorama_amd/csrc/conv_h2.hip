@@ -71,6 +71,19 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));
 }
 
+#ifndef NEF_H2_SPLIT
+#define NEF_H2_SPLIT 1      // 1 (round 5): the scale rides on the staging's channel-scale multiply, split by full-rate instructions
+#endif
+// split of an already scaled pair, no clamp (range rescue): h = (fp16(x0), fp16(x1)), l = (fp16(x0 - h0), fp16(x1 - h1)).  Four
+// full-rate instructions (2.2 ns of SIMD time each, profiles/r05_valu_rates.md) where split2s spends four half-rate ones (3.75 ns).
+__device__ __forceinline__ void split2n(float x0, float x1, unsigned& h, unsigned& l) {
+    float r0, r1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));
+}
+
 // the same split with the power-of-two scale s folded into the conversions: hi = fp16(x s), lo = fp16(x s - hi), each ONE
 // mixed-precision FMA per element (x s is exact, x s - hi is exact in fp32: bit-identical to split2(x0 * s, x1 * s));
 // |x| is clamped at lim = 65000 / s first
@@ -160,6 +173,16 @@ __global__ __launch_bounds__(256) void pack_h2_kernel(H2PackTable tab) {
 #endif
 #ifndef NEF_H2_EPI_ALWAYS
 #define NEF_H2_EPI_ALWAYS 0
+#endif
+// NEF_H2_SPLIT 1: the staging multiplies by (channel scale x launch scale) -- one product it does anyway, exact because the launch
+// scale is a power of two -- and splits the scaled value; the magnitude it tracks is the scaled one (divided out once per tile).
+// Bit-identical to the 0 form (scale folded into v_fma_mixlo/hi_f16).
+#if NEF_H2_SPLIT
+#define NEF_H2_SPLIT2(V0, V1, H, L) split2n(V0, V1, H, L)
+#define NEF_H2_STAGE_SCALE xs_
+#else
+#define NEF_H2_SPLIT2(V0, V1, H, L) split2s(V0, V1, xs_, xlim_, H, L)
+#define NEF_H2_STAGE_SCALE 1.f
 #endif
 #if NEF_H2_AMAX
 #define NEF_H2_TRACK1(V) amax_ = fmaxf(amax_, fabsf(V));
@@ -274,7 +297,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
             if (m_ > 0.f && m_ < 3e38f) {
                 int e_;
                 (void)frexpf(m_, &e_);
-                xs_ = ldexpf(1.f, 9 - e_);
+                xs_ = ldexpf(1.f, 9 - e_ < 100 ? 9 - e_ : 100);
             }
         }
     }
@@ -374,7 +397,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
     {                                                                                                               \
         float sa_[4], pa_[4], pb_[4];                                                                               \
         _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                          \
-            sa_[rr] = a.in_scale ? a.in_scale[soff + (C0) + 4 * wave + rr] : 1.f;                                   \
+            sa_[rr] = (a.in_scale ? a.in_scale[soff + (C0) + 4 * wave + rr] : 1.f) * NEF_H2_STAGE_SCALE;            \
             pa_[rr] = 1.f, pb_[rr] = 0.f;                                                                           \
             if constexpr (AFF) {                                                                                    \
                 pa_[rr] = Pl[(C0) + 4 * wave_u + rr];                                                               \
@@ -397,10 +420,10 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
                 }                                                                                                   \
                 const int r = 2 * (lane + 64 * it);                                                                 \
                 unsigned h0_, l0_, h1_, l1_, h2_, l2_, h3_, l3_;                                                    \
-                split2s(v0_[0], v0_[1], xs_, xlim_, h0_, l0_);                                                      \
-                split2s(v0_[2], v0_[3], xs_, xlim_, h1_, l1_);                                                      \
-                split2s(v1_[0], v1_[1], xs_, xlim_, h2_, l2_);                                                      \
-                split2s(v1_[2], v1_[3], xs_, xlim_, h3_, l3_);                                                      \
+                NEF_H2_SPLIT2(v0_[0], v0_[1], h0_, l0_);                                                      \
+                NEF_H2_SPLIT2(v0_[2], v0_[3], h1_, l1_);                                                      \
+                NEF_H2_SPLIT2(v1_[0], v1_[1], h2_, l2_);                                                      \
+                NEF_H2_SPLIT2(v1_[2], v1_[3], h3_, l3_);                                                      \
                 unsigned char* p0_ = (BUFP) + NEF_H2_WADDR(r, wave);                                                \
                 unsigned char* p1_ = (BUFP) + NEF_H2_WADDR(r + 1, wave);                                            \
                 *reinterpret_cast<u32x2*>(p0_) = u32x2{h0_, h1_};                                                   \
@@ -414,14 +437,14 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
                     const float pa = Pl[(C0) + 4 * wave_u + lane], pb = Pl[Cig + (C0) + 4 * wave_u + lane];         \
                     sa = fmaxf(fmaf(sa, pa, pb), 0.f), sb = fmaxf(fmaf(sb, pa, pb), 0.f);                           \
                 }                                                                                                   \
-                const float sc = a.in_scale ? a.in_scale[soff + (C0) + 4 * wave + lane] : 1.f;                      \
+                const float sc = (a.in_scale ? a.in_scale[soff + (C0) + 4 * wave + lane] : 1.f) * NEF_H2_STAGE_SCALE; \
                 float o0 = (1.f - 0.25f) * sa + 0.25f * sb;                                                         \
                 float o1 = (1.f - 0.75f) * sa + 0.75f * sb;                                                         \
                 o0 = mok[0] ? o0 * sc : 0.f;                                                                        \
                 o1 = mok[1] ? o1 * sc : 0.f;                                                                        \
                 NEF_H2_TRACK2(o0, o1)                                                  \
                 unsigned h_, l_;                                                                                    \
-                split2s(o0, o1, xs_, xlim_, h_, l_);                                                                \
+                NEF_H2_SPLIT2(o0, o1, h_, l_);                                                                \
                 unsigned char* p0_ = (BUFP) + NEF_H2_WADDR(256, wave) + 2 * lane;                                   \
                 unsigned char* p1_ = (BUFP) + NEF_H2_WADDR(257, wave) + 2 * lane;                                   \
                 *reinterpret_cast<unsigned short*>(p0_) = (unsigned short)(h_ & 0xffffu);                           \
@@ -442,8 +465,8 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
             }                                                                                                       \
             const int r = lane + 64 * it;                                                                           \
             unsigned h0_, l0_, h1_, l1_;                                                                            \
-            split2s(v_[0], v_[1], xs_, xlim_, h0_, l0_);                                                            \
-            split2s(v_[2], v_[3], xs_, xlim_, h1_, l1_);                                                            \
+            NEF_H2_SPLIT2(v_[0], v_[1], h0_, l0_);                                                            \
+            NEF_H2_SPLIT2(v_[2], v_[3], h1_, l1_);                                                            \
             const u32x2 hv = {h0_, h1_}, lv = {l0_, l1_};                                                           \
             if (r < XROW) {                                                                                         \
                 unsigned char* p_ = (BUFP) + NEF_H2_WADDR(r, wave);                                                 \
@@ -545,6 +568,9 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
         else {      // every element of the tile has been staged: publish this wave's magnitude with the loop's last barrier
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) amax_ = fmaxf(amax_, __shfl_xor(amax_, o, 64));
+#if NEF_H2_SPLIT
+            amax_ *= 1.f / xs_;      // tracked on the scaled values (exact: a power of two)
+#endif
             if (lane == 0) Al[wave_u] = amax_;
         }
         __syncthreads();
@@ -820,7 +846,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
         int bid_ = (int)blockIdx.x, tid_ = (int)threadIdx.x, tps2_ = tps_, nt2_ = n_tiles_, mt2_ = m_tiles_;
         asm volatile("" : "+s"(ap_), "+s"(bid_), "+s"(tps2_), "+s"(nt2_), "+s"(mt2_));
         asm volatile("" : "+v"(tid_));
-        (void)tile_pass(ap_, bid_, tid_, tps2_, nt2_, mt2_, ldexpf(1.f, 9 - e_), true);
+        (void)tile_pass(ap_, bid_, tid_, tps2_, nt2_, mt2_, ldexpf(1.f, 9 - e_ < 100 ? 9 - e_ : 100), true);
     }
 #endif
 }

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv_h2p_kernel(nef_conv_args a_,
         if (m_ > 0.f && m_ < 3e38f) {
             int e_;
             (void)frexpf(m_, &e_);
-            xs_ = ldexpf(1.f, 9 - e_);
+            xs_ = ldexpf(1.f, 9 - e_ < 100 ? 9 - e_ : 100);
         }
     }
     const float xlim_ = 65000.f / xs_;
