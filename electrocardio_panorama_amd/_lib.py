@@ -97,6 +97,7 @@ SIGNATURES = {
     "nef_mix_fwd_shared": (i32, [p, p, p, p, p, i32, i32, i32, i32, i32, p, p]),
     "nef_lead_mean_mix_shared": (i32, [p, p, p, p, p, i32, i32, i32, i32, i32, p, p]),
     "nef_mix_bwd_shared_up": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, i32, p]),
+    "nef_mix_bwd_shared": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, i32, p]),
     "nef_pass_combine_fwd": (i32, [p, p, p, i32, i32, i32, p]),
     "nef_pass_combine_bwd": (i32, [p, p, i32, i32, i32, p]),
     "nef_pass_combine_stats_ws_bytes": (sz, [i32, i32]),
@@ -129,6 +130,8 @@ SIGNATURES = {
     "nef_loss_bwd": (i32, [p, p, p, p, p, p, p, p, i64, f32, f32, f32, i32, i32, p]),
     "nef_sgd_momentum": (i32, [p, p, p, i64, f32, f32, f32, i32, p, p, p, p]),
     "nef_h2_taint": (i32, [p, p, p, p]),
+    "nef_poly_weights": (i32, [p, p, i32, i32, p]),
+    "nef_poly_bwd_edge": (i32, [p, p, p, i32, i32, i32, i32, i32, p, p, p, p, p, i32, p, i32, p]),
     "nef_view_metrics": (i32, [p, p, p, p, p, i32, i32, i32, p]),
     "nef_pano_h_from_f32": (i32, [p, p, i32, i32, i32, p]),
     "nef_pano_h_pack_weight": (i32, [p, p, i32, i32, p]),

@@ -210,6 +210,10 @@ template <int K, int PRO, int TM, bool PACK = false>
 __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)) ? NEF_H2_OCC1 : 2) void conv_h2_kernel(nef_conv_args a_, int tps_, int n_tiles_, int m_tiles_) {
     constexpr int MT = 64 * TM;                    // output channels per workgroup: 2 (co) x 2 (t) waves of TM x 4 tiles
     constexpr bool UP = (PRO & 2) != 0, AFF = (PRO & 1) != 0;
+    // PH (pro_mode 4, polyphase backward-data through a x2 upsampling): the input is a FULL-resolution tensor [Cin_g / 2][2 T] read as
+    // Cin_g phase channels of length T -- reduction channel 2 c + p at position m is x[c][2 m + p], one 8-byte load per two channels
+    constexpr bool PH = (PRO & 4) != 0;
+    static_assert(!PH || (!UP && K == 3), "phase-stacked input: K = 3, no upsampling prologue");
     constexpr int NS = UP ? 2 : 1;
     constexpr int PAD = (K - 1) / 2;
     constexpr int XROW = NTO + K - 1;              // staged positions per channel: t0 - PAD .. t0 + NTO + PAD - 1
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
     const int lo = lane & 31, hi = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave_u >> 1, wn = wave_u & 1;
-    const int Tin = UP ? (T >> 1) : T;
+    const int Tin = UP ? (T >> 1) : (PH ? 2 * T : T);      // row pitch of the input tensor
 
     const float* const xbase = a.x + (int64_t)b0 * a.x_bs + (int64_t)g * a.x_gs;
     const __amdgpu_buffer_rsrc_t xrs = nef_rsrc(xbase);
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
             xvo[it][0] = xok[it] ? (unsigned)(i0 * 4) : NEF_OOB;
             xvo[it][NS - 1] = xok[it] ? (unsigned)(i1 * 4) : NEF_OOB;
         } else {
-            xvo[it][0] = xok[it] ? (unsigned)(t * 4) : NEF_OOB;
+            xvo[it][0] = xok[it] ? (unsigned)(t * (PH ? 8 : 4)) : NEF_OOB;
         }
     }
     // x2-upsampling prologue: a lane stages INTERVALS of the half-resolution row instead of positions -- interval m = t0/2 - 1 + u
@@ -382,6 +386,9 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
             if constexpr (UP) {                                                                                     \
                 _Pragma("unroll") for (int it = 0; it < 2; ++it)                                                    \
                     _Pragma("unroll") for (int ns = 0; ns < 2; ++ns) xreg[rr][it][ns] = nef_buf_f32(RS, uvo[it][ns], so); \
+            } else if constexpr (PH) {                                                                              \
+                const unsigned so2 = (unsigned)((((C0) >> 1) + 2 * wave_u + (rr >> 1)) * Tin * 4 + (rr & 1) * 4);   \
+                _Pragma("unroll") for (int it = 0; it < NIT; ++it) xreg[rr][it][0] = nef_buf_f32(RS, xvo[it][0], so2); \
             } else {                                                                                                \
                 _Pragma("unroll") for (int it = 0; it < NIT; ++it) xreg[rr][it][0] = nef_buf_f32(RS, xvo[it][0], so); \
             }                                                                                                       \
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
             _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                      \
                 float v = xreg[rr][it][0];                                                                          \
                 if constexpr (AFF) v = fmaxf(fmaf(v, pa_[rr], pb_[rr]), 0.f);                                       \
-                if constexpr (PRO != 0) v = xok[it] ? v : 0.f;                                                      \
+                if constexpr (AFF) v = xok[it] ? v : 0.f;                                                           \
                 v *= sa_[rr];                                                                                       \
                 NEF_H2_TRACK1(v)                                                                                    \
                 v_[rr] = v;                                                                                         \
@@ -885,7 +892,8 @@ static bool h2_pack_shape(const nef_conv_args* a) {
 __attribute__((visibility("hidden"))) bool nef_h2_ok(const nef_conv_args* a) {
     return (a->K == 1 || a->K == 3 || a->K == 7) && a->Cout_g % 64 == 0 && a->Cin_g % KC == 0 && a->T % 2 == 0 &&
            (a->T >= NTO / 2 || h2_pack_shape(a)) &&
-           a->pro_mode >= 0 && a->pro_mode <= 3 && (a->K == 3 || a->pro_mode == 0) && !(a->pro_mode && a->in_scale) &&
+           a->pro_mode >= 0 && a->pro_mode <= 4 && (a->K == 3 || a->pro_mode == 0) && !(a->pro_mode && a->in_scale) &&
+           (a->pro_mode != 4 || (a->T >= NTO / 2 && (int64_t)a->Cin_g * a->T * 4 < 0x7fffffff)) &&
            (!(a->pro_mode & 1) || a->Cin_g <= PRO_MAX_CIN);
 }
 
@@ -897,7 +905,7 @@ __attribute__((visibility("hidden"))) int nef_h2p_launch(const nef_conv_args* a,
 __attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, hipStream_t st) {
     if (!nef_h2_ok(a)) return NEF_E_SHAPE;
     if ((a->pro_mode & 1) && !(a->pro_a && a->pro_b && a->pro_Bp > 0)) return NEF_E_NULL;
-    if (nef_opt_h2_form() && nef_h2p_ok(a)) return nef_h2p_launch(a, st);
+    if (nef_opt_h2_form() && a->pro_mode <= 3 && nef_h2p_ok(a)) return nef_h2p_launch(a, st);
     static const bool force_tm1 = nef_diag_env("NEF_H2_TM1") && atoi(nef_diag_env("NEF_H2_TM1")) == 1;      // A/B: 64-channel tile everywhere
     const bool wide = a->Cout_g % 128 == 0 && !force_tm1;
     // the x2-upsampling prologue keeps two source samples per staged position in registers: next to the 128 accumulator
@@ -911,6 +919,7 @@ __attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, 
         case 0: return wide ? launch_h2<3, 0, 2>(*a, st) : launch_h2<3, 0, 1>(*a, st);
         case 1: return wide ? launch_h2<3, 1, 2>(*a, st) : launch_h2<3, 1, 1>(*a, st);
         case 2: return launch_h2<3, 2, 1>(*a, st);
+        case 4: return wide ? launch_h2<3, 4, 2>(*a, st) : launch_h2<3, 4, 1>(*a, st);
         default: return launch_h2<3, 3, 1>(*a, st);
     }
 }

@@ -2325,7 +2325,7 @@ __attribute__((visibility("hidden"))) int nef_h2_pack(const nef_pack_desc* descs
 
 extern "C" {
 
-int nef_abi_version(void) { return 16; }
+int nef_abi_version(void) { return 17; }
 
 int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                     nef_stream_t stream) {

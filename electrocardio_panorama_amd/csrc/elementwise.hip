@@ -266,7 +266,7 @@ __global__ void mix_bwd_kernel(const float* __restrict__ gD, const float* __rest
         const float* g0 = gD + row * (UP ? 2 * T : T);
         const int64_t gpass = UP ? 2 * pass : pass;
         float acc = 0.f;
-        if (UP && SHARED && (T & 1) == 0 && T >= 8) {
+        if (SHARED && (T & 1) == 0 && T >= 8) {
             // Vector path of the train step's launch (two passes, x2 adjoint, T even): a lane owns two consecutive
             // positions (t, t+1), t even: the 2T-long gradient rows are read as one 16-byte word g[2t..2t+3] plus the two
             // neighbours, everything else as 8-byte words.  Same expressions as the scalar path below (gz1 / gz2r are
@@ -276,7 +276,11 @@ __global__ void mix_bwd_kernel(const float* __restrict__ gD, const float* __rest
             for (int p = lane; p < T / 2; p += 64) {
                 const int t = 2 * p;
                 float ga[2], gb[2];
-                if (p == 0 || p == T / 2 - 1) {
+                if constexpr (!UP) {      // the gradient is already at the latent's resolution (polyphase backward-data)
+                    typedef float f2g __attribute__((ext_vector_type(2)));
+                    const f2g a2 = *(const f2g*)(g0 + t), b2 = *(const f2g*)(g1r + t);
+                    ga[0] = a2[0], ga[1] = a2[1], gb[0] = b2[0], gb[1] = b2[1];
+                } else if (p == 0 || p == T / 2 - 1) {
                     ga[0] = up2_adjoint(g0, T, t); ga[1] = up2_adjoint(g0, T, t + 1);
                     gb[0] = up2_adjoint(g1r, T, t); gb[1] = up2_adjoint(g1r, T, t + 1);
                 } else {
@@ -1181,6 +1185,75 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Polyphase form of conv1d(upsample2(x), w), K = 3.  Output 2 m + p of that conv is a K = 3 conv of the
+// HALF-resolution x with the phase weights W'_p (taps on x[m - 1], x[m], x[m + 1]):
+//     W'_0 = (0.75 w0 + 0.25 w1,  0.25 w0 + 0.75 w1 + 0.75 w2,  0.25 w2)
+//     W'_1 = (0.25 w0,  0.75 w0 + 0.75 w1 + 0.25 w2,  0.25 w1 + 0.75 w2)
+// (nn.Upsample(scale_factor=2, mode='linear'): u[2j] = 0.25 x[j-1] + 0.75 x[j], u[2j+1] = 0.75 x[j] + 0.25 x[j+1]).
+// wsyn [R * 2][Cig][3], row 2 r + p for row r of w [R][Cig][3].  One thread per (r, ci).
+__global__ __launch_bounds__(256) void poly_weights_kernel(const float* __restrict__ w, float* __restrict__ ws, int R, int Cig) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)R * Cig) return;
+    const int r = (int)(i / Cig), ci = (int)(i - (int64_t)r * Cig);
+    const float w0 = w[3 * i], w1 = w[3 * i + 1], w2 = w[3 * i + 2];
+    float* const o0 = ws + ((int64_t)(2 * r) * Cig + ci) * 3;
+    float* const o1 = ws + ((int64_t)(2 * r + 1) * Cig + ci) * 3;
+    o0[0] = fmaf(0.75f, w0, 0.25f * w1);
+    o0[1] = fmaf(0.25f, w0, 0.75f * (w1 + w2));
+    o0[2] = 0.25f * w2;
+    o1[0] = 0.25f * w0;
+    o1[1] = fmaf(0.25f, w2, 0.75f * (w0 + w1));
+    o1[2] = fmaf(0.75f, w2, 0.25f * w1);
+}
+
+// Row ends of the polyphase backward-data pass.  The phase convs treat both ends of x as if the interpolation formula continued
+// (x[-1] = x[0], x[Tin] = x[Tin-1]: nn.Upsample's clamped sources) and as if u[-1], u[T] existed; the conv's zero padding of u
+// says they do not.  Written out (gu = the gradient wrt u the full-resolution pass would have produced):
+//     gx[0]      += 0.25 (w1 - w0)^T gy[:, 0]   + 0.25 w0^T gy[:, 1]
+//     gx[Tin-1]  += 0.25 (w1 - w2)^T gy[:, T-1] + 0.25 w2^T gy[:, T-2]
+// One workgroup per (sample, group); also adds the two columns' share of the BatchNorm-backward sums to the sample's first slot.
+__global__ __launch_bounds__(256) void poly_bwd_edge_kernel(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx,
+                                                            int B, int G, int Cog, int Cig, int T, const float* __restrict__ bx,
+                                                            const float* __restrict__ bmean, const float* __restrict__ binv,
+                                                            const float* __restrict__ ba, const float* __restrict__ bb, int Bp,
+                                                            float* __restrict__ slots, int nslot) {
+    extern __shared__ float gl[];      // [4][Cog]: columns 0, 1, T-2, T-1 of this (sample, group)'s gradient rows
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int Tin = T >> 1;
+    const float* const gyb = gy + ((int64_t)b * G + g) * Cog * T;
+    for (int i = threadIdx.x; i < 4 * Cog; i += 256) {
+        const int c = i >> 2, k = i & 3;
+        gl[k * Cog + c] = gyb[(int64_t)c * T + (k < 2 ? k : T - 4 + k)];
+    }
+    __syncthreads();
+    const int64_t ctot = (int64_t)G * Cig;
+    for (int ci = threadIdx.x; ci < Cig; ci += 256) {
+        float d0 = 0.f, dl = 0.f;
+        const float* wp = w + ((int64_t)g * Cog * Cig + ci) * 3;
+        for (int co = 0; co < Cog; ++co, wp += (int64_t)Cig * 3) {
+            const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
+            d0 = fmaf(w1 - w0, gl[co], fmaf(w0, gl[Cog + co], d0));
+            dl = fmaf(w1 - w2, gl[3 * Cog + co], fmaf(w2, gl[2 * Cog + co], dl));
+        }
+        d0 *= 0.25f, dl *= 0.25f;
+        const int64_t ch = (int64_t)g * Cig + ci;
+        float* const row = gx + ((int64_t)b * ctot + ch) * Tin;
+        row[0] += d0;
+        row[Tin - 1] += dl;
+        if (slots) {
+            const int64_t pr = (int64_t)(b / Bp) * ctot + ch;
+            const float* const xr = bx + ((int64_t)b * ctot + ch) * Tin;
+            const float af = ba[pr], bf = bb[pr], mf = bmean[pr], is = binv[pr];
+            const float x0 = xr[0], xl = xr[Tin - 1];
+            const float g0 = fmaf(x0, af, bf) > 0.f ? d0 : 0.f, g1 = fmaf(xl, af, bf) > 0.f ? dl : 0.f;
+            float* const sl = slots + ((ch * B + b) * nslot) * 2;
+            sl[0] += g0 + g1;
+            sl[1] += fmaf(g0, (x0 - mf) * is, g1 * ((xl - mf) * is));
+        }
+    }
+}
+
 __global__ void h2_taint_kernel(const int32_t* __restrict__ total, int32_t* __restrict__ mark, float* __restrict__ out) {
     const int32_t t = total[0];
     out[0] = (float)(t - mark[0]);
@@ -1192,6 +1265,17 @@ __global__ void h2_taint_kernel(const int32_t* __restrict__ total, int32_t* __re
 #define NEF_ST ((hipStream_t)stream)
 
 extern "C" {
+
+int nef_mix_bwd_shared(const float* gD2, const float* latent, const float* z1, const float* z2r, const float* q,
+                       float* gz1, float* gz2r, float* gq, int B, int V, int T, int c1, int c2,
+                       const int32_t* choice_dev, int relu_z1, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gD2 && latent && z1 && z2r && q && gz1 && gz2r && gq, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && V > 0 && T > 1 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
+    hipLaunchKernelGGL((mix_bwd_kernel<false, true>), dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gD2,
+                       latent, z1, z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev, relu_z1);
+    return nef_launch_status();
+}
 
 int nef_mix_bwd_shared_up(const float* gU2, const float* latent, const float* z1, const float* z2r, const float* q,
                           float* gz1, float* gz2r, float* gq, int B, int V, int T, int c1, int c2,
@@ -1810,6 +1894,27 @@ int nef_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, 
     NEF_REQUIRE(n > 0, NEF_E_SHAPE);
     hipLaunchKernelGGL(sgd_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, p, g, buf, n, lr, mu, gscale,
                        first_step, skip_if_positive, skipped, lr_dev);
+    return nef_launch_status();
+}
+
+int nef_poly_weights(const float* w, float* wsyn, int rows, int Cig, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(w && wsyn, NEF_E_NULL);
+    NEF_REQUIRE(rows > 0 && Cig > 0, NEF_E_SHAPE);
+    const int64_t n = (int64_t)rows * Cig;
+    hipLaunchKernelGGL(poly_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, NEF_ST, w, wsyn, rows, Cig);
+    return nef_launch_status();
+}
+
+int nef_poly_bwd_edge(const float* gy, const float* w, float* gx, int B, int G, int Cog, int Cig, int T, const float* bnb_x,
+                      const float* bnb_mean, const float* bnb_invstd, const float* bnb_a, const float* bnb_b, int bnb_Bp,
+                      float* bnb_slots, int nslot, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gy && w && gx, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && G > 0 && Cog > 0 && Cig > 0 && T >= 4 && T % 2 == 0 && Cog <= 4096, NEF_E_SHAPE);
+    NEF_REQUIRE(!bnb_slots || (bnb_x && bnb_mean && bnb_invstd && bnb_a && bnb_b && bnb_Bp > 0 && nslot > 0), NEF_E_NULL);
+    hipLaunchKernelGGL(poly_bwd_edge_kernel, dim3((unsigned)(B * G)), dim3(256), (size_t)4 * Cog * sizeof(float), NEF_ST, gy, w, gx, B, G,
+                       Cog, Cig, T, bnb_x, bnb_mean, bnb_invstd, bnb_a, bnb_b, bnb_Bp, bnb_slots, nslot);
     return nef_launch_status();
 }
 

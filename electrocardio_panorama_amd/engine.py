@@ -289,6 +289,7 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
     g_is_up = False
     g = None if fuse_last else ops.outconv_bwd_data(g_out, out, P["decoder.4.weight"], c4.shape[1])
     g_slots = None            # BatchNorm-backward sums the conv that produced g left in its epilogue
+    poly_first = False        # the first layer's backward-data pass already went through its upsampling
     for li in (3, 2, 1, 0):
         blk, cv, bn, cout = _DEC[li]
         x, c, mean, invstd, a, b, pro, up_after = saved[li]
@@ -308,11 +309,29 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
             gp2 = gc if gc.shape[0] == 2 * shared_B else ops.pass_combine_bwd(gc)   # [2B, 2*128, 2T]
             gpv, xv = GV.dense(gp2, 2), GV.dense(x, 2)
             grads[wname] = side.run(lambda: _ungroup_halves(ops.conv_bwd_weight(xv, gpv, 3, pro=pro, site=P[wname].data_ptr())), x, gp2)
-            g = ops.conv(gpv, ops.pack_weight(_regroup_halves(P[wname]), 2, flip=True, T=gp2.shape[2], f4=True, site=P[wname].data_ptr()), x.shape[1] // 2, 3,
-                         role="conv_bwd_data")
+            poly = bool(up_after and pro[0] == 2 and ops.poly_bwd_ok(2, gp2.shape[1] // 2, x.shape[1] // 2, gp2.shape[2]))
+            if poly:      # straight to the gradient wrt the half-resolution D (polyphase pass): nothing left for the consumer to fold
+                g = ops.conv_bwd_data_poly(gpv, _regroup_halves(P[wname]), x.shape[1] // 2, site=P[wname].data_ptr())
+                poly_first = True
+            else:
+                g = ops.conv(gpv, ops.pack_weight(_regroup_halves(P[wname]), 2, flip=True, T=gp2.shape[2], f4=True, site=P[wname].data_ptr()), x.shape[1] // 2, 3,
+                             role="conv_bwd_data")
         else:
             gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
             grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro, site=P[wname].data_ptr()), x, gc)
+            if up_after and pro[0] & 2 and ops.poly_bwd_ok(1, gc.shape[1], x.shape[1], gc.shape[2]):
+                # x2 upsampling in front of this conv: the polyphase pass leaves the gradient wrt the half-resolution input (= what the
+                # BatchNorm below produced) directly, with that BatchNorm's backward sums in its epilogue
+                bnb = None
+                if li > 0 and _FUSE_STATS and saved[li - 1][2] is not None:
+                    cb, mb, ib, ab, bb = saved[li - 1][1:6]
+                    bnb = (cb, mb, ib, ab, bb, cb.shape[0] // passes)
+                g = ops.conv_bwd_data_poly(gcv, P[wname], x.shape[1], bnb=bnb)
+                g_slots = g.nef_slots
+                g_is_up = False
+                if li == 0:
+                    poly_first = True
+                continue
             wpf = ops.pack_weight(P[wname], 1, flip=True, T=gc.shape[2], f4=True)
             # g is the gradient wrt relu(bn(c_below)) when no upsampling sits in between: the epilogue then leaves the
             # reduction sums of that BatchNorm's backward (it reads c_below's tile for the ReLU decision and xhat)
@@ -334,7 +353,7 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
         if up_after and li > 0 and not g_is_up:
             g = ops.upsample2_bwd(g)
     # the adjoint of the FIRST upsampling is left to the consumer (mix_bwd takes it while reading)
-    return g, bool(saved[0][7]), shared_B is not None
+    return g, bool(saved[0][7]) and not poly_first, shared_B is not None
 
 
 # ----------------------------------------------------------------------------------------------

@@ -579,7 +579,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     # bench.py prices a launch by its tag; the optional 8th element says which operands are NOT at the output's resolution / are extra:
     # "up" = the input is the half-resolution tensor (x2-upsampling prologue), "bnb" / "bnbup" = the epilogue also reads the
     # BatchNorm input of the layer below (full / half resolution) for the backward sums
-    extra = ("up" if (pro is not None and pro[0] & 2) else "") + ("bnb" + ("up" if len(bnb) > 7 and bnb[7] else "") if bnb is not None else "")
+    extra = ("up" if (pro is not None and pro[0] & 2) else "") + ("ph" if (pro is not None and pro[0] == 4) else "") + ("bnb" + ("up" if len(bnb) > 7 and bnb[7] else "") if bnb is not None else "")
     tag = (role, K, xv.G, xv.Cg, Cog, xv.B, T_out) + ((extra,) if extra else ())
     ev = _timed(tag)
     if ev is not None:
@@ -589,6 +589,54 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     if ev is not None:
         ev.record()
     return out.t
+
+
+# ------------------------------------------------------------------ polyphase form of conv1d(upsample2(x)), K = 3
+POLY = _env.get("NEF_POLY", "1") == "1"
+
+
+def poly_weights(w):
+    """w [R, Cig, 3] -> [2R, Cig, 3]: row 2r + p = the phase-p weights of row r (csrc/elementwise.hip poly_weights_kernel): output
+    2m + p of conv1d(upsample2(x), w) is the K = 3 conv of the half-resolution x with them."""
+    _chk(w)
+    ws = torch.empty(2 * w.shape[0], w.shape[1], 3, device=w.device, dtype=torch.float32)
+    _lib.check(_lib.load().nef_poly_weights(_p(w), _p(ws), w.shape[0], w.shape[1], _stream()), "nef_poly_weights")
+    return ws
+
+
+def poly_bwd_ok(G, Cog, Cig, T):
+    """Can the backward-data pass of conv1d(upsample2(x) [.., G*Cig, T], w [G*Cog, Cig, 3]) run in polyphase form?  (the launch is a
+    split-fp16 conv with 2 Cog reduction channels, Cig outputs, T / 2 columns)"""
+    Th = T // 2
+    return (POLY and H2 and T % 2 == 0 and Th >= 128 and Cig % 64 == 0 and (2 * Cog) % 16 == 0 and h2_ok(3, 2 * Cog, Cig, Th) and
+            _H2_DIR[True] and "3" in _H2_K and _h2_fills(G, Cig, Th, 256, 128 if Cig % 128 == 0 else 64))
+
+
+def conv_bwd_data_poly(gyv, w, Cig, bnb=None, site=None):
+    """Gradient wrt the HALF-resolution input x of y = conv1d(upsample2(x), w) (K = 3, zero padding 1), from gy [B, G*Cog, T]
+    (`gyv`, a GV): one split-fp16 conv at half resolution over the 2 Cog phase channels of gy (conv args pro_mode 4) + the row-end
+    terms (nef_poly_bwd_edge) -- the full-resolution gradient wrt upsample2(x) is never formed.  `w` [G*Cog, Cig, 3] is the conv's
+    own weight; `bnb` as in conv() (plain form: its x at the half resolution).  Reference semantics: autograd through
+    codes/network/model_nefnet.py:102-105.  Summation order differs from conv + upsample2_bwd (fp32-class either way)."""
+    L = _lib.load()
+    G, Cog, T = gyv.G, gyv.Cg, gyv.T
+    Th = T // 2
+    assert w.shape == (G * Cog, Cig, 3) and gyv.gs == Cog * T, "conv_bwd_data_poly: dense gradient rows"
+    ws = poly_weights(w)
+    wp = pack_weight(ws, G, flip=True, T=Th, site=w.data_ptr() if site is None else site)
+    if int(getattr(wp, "nef_wino", 0)) != 3:
+        raise _lib.NefLibraryError("conv_bwd_data_poly: shape outside the split-fp16 kernel (ask poly_bwd_ok first)")
+    xv = GV(gyv.t, gyv.B, G, 2 * Cog, Th, gyv.bs, gyv.gs, gyv.off)
+    if bnb is not None and len(bnb) == 6:      # (x, mean, invstd, a, b, Bp): the slot buffer is made here (returned as g.nef_slots)
+        slots = conv_stats_buffer(wp, gyv.B, G, Cig, Th, gyv.t.device)
+        bnb = None if slots is None else (*bnb, slots)
+    g = conv(xv, wp, Cig, 3, role="conv_bwd_data", bnb=bnb, pro=(4, None, None, 1))
+    g.nef_slots = bnb[6] if bnb is not None else None
+    ba = [None] * 5 + [1, None, 0]
+    if bnb is not None:
+        ba = [_p(t) for t in bnb[:5]] + [bnb[5], _p(bnb[6][0]), bnb[6][1]]
+    _lib.check(L.nef_poly_bwd_edge(gyv.ptr, _p(w), _p(g), gyv.B, G, Cog, Cig, T, *ba, _stream()), "nef_poly_bwd_edge")
+    return g
 
 
 def h2w_ok(K, Cig, Cog, T, pro_mode=0, in_scale=False):
@@ -991,17 +1039,21 @@ def lead_mean_mix_shared(z1, z2r, q, V, c1, c2=None):
 
 
 def mix_bwd_shared_up(gU2, latent, z1, z2r, q, V, c1, c2=None, relu_z1=False):
-    """mix_bwd for the two-pass gradient wrt the x2-upsampled shared input, gU2 [2B,256,2T]."""
+    """mix_bwd for the two-pass gradient wrt the shared input: gU2 [2B,256,2T] wrt its x2-upsampled form (the adjoint is taken on
+    the fly), or [2B,256,T] wrt the input itself (what the polyphase backward-data pass leaves)."""
     L = _lib.load()
     c1, c2, cdev = _choice(c1 if c2 is None else (c1, c2))
     _chk(gU2)
     B, _, T = latent.shape
-    assert gU2.shape == (2 * B, 256, 2 * T)
+    up = gU2.shape[2] == 2 * T
+    assert gU2.shape == (2 * B, 256, 2 * T if up else T)
     gz1, gz2r = torch.empty_like(z1), torch.empty_like(z2r)
     gq = torch.empty(B, 256, device=latent.device, dtype=torch.float32)
-    ev = _hbm("mix_bwd_shared_up", gU2, z1, z2r, gz1, gz2r)
-    _lib.check(L.nef_mix_bwd_shared_up(_p(gU2), _p(latent), _p(z1), _p(z2r), _p(q), _p(gz1), _p(gz2r), _p(gq), B, V, T, c1,
-                                       c2, cdev, int(relu_z1), _stream()), "nef_mix_bwd_shared_up")
+    name = "mix_bwd_shared_up" if up else "mix_bwd_shared"
+    ev = _hbm(name, gU2, z1, z2r, gz1, gz2r)
+    fn = L.nef_mix_bwd_shared_up if up else L.nef_mix_bwd_shared
+    _lib.check(fn(_p(gU2), _p(latent), _p(z1), _p(z2r), _p(q), _p(gz1), _p(gz2r), _p(gq), B, V, T, c1, c2, cdev, int(relu_z1),
+                  _stream()), "nef_" + name)
     _done(ev)
     return gz1, gz2r, gq
 

@@ -34,7 +34,7 @@ extern "C" {
 typedef void* nef_stream_t;
 
 /* ABI version of this header; bumped on any signature change. */
-int nef_abi_version(void);   /* 16 (round 5: + nef_set_option / nef_get_option); 15 (round 4: + x_clamped / clamped counters); 14 (round 4: + nef_conv_bwd_weight_h2); 13 (round 4: + nef_pack_weight_h2 / conv args wino = 3 and x_scale: direct convolutions on exact fp16 splits of the fp32 operands); 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
+int nef_abi_version(void);   /* 17 (round 5: + pro_mode 4, nef_poly_weights, nef_poly_bwd_edge: polyphase backward-data through the x2 upsampling); 16 (round 5: + nef_set_option / nef_get_option); 15 (round 4: + x_clamped / clamped counters); 14 (round 4: + nef_conv_bwd_weight_h2); 13 (round 4: + nef_pack_weight_h2 / conv args wino = 3 and x_scale: direct convolutions on exact fp16 splits of the fp32 operands); 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
 
 /* Kernel-form options of the process (tuning / A-B hooks; every value computes the same results).  Not part of any reference
  * interface: the reference's nn.Conv1d has one form (codes/network/model_nefnet.py:18-21).  Returns the previous value, or
@@ -127,6 +127,8 @@ typedef struct nef_conv_args {
      *   pro_mode bit1: the input is stored at half resolution [..][T/2] and is x2-upsampled on the fly exactly as
      *                  nn.Upsample(scale_factor=2, mode='linear', align_corners=False) (model_nefnet.py:102,104);
      *                  x_bs / x_gs and the channel pitch then refer to the half-resolution tensor.
+     *   pro_mode 4 (alone, wino == 3 only): phase-stacked input for the polyphase backward-data pass -- x is a full-resolution
+     *                  tensor [..][Cin_g / 2][2 T]; reduction channel 2 c + p at position m is x[c][2 m + p] (see nef_poly_weights).
      * Zero padding is applied after the prologue.  in_scale must be NULL when pro_mode != 0. */
     const float* pro_a;
     const float* pro_b;
@@ -328,13 +330,17 @@ int nef_mix_bwd_up(const float* gU, const float* latent, const float* z1, const 
  *   (grouped conv, G = 2, on D2 with the weight regrouped to [2*Cout][Cin/2][3] -> P2 [2B][2C][L])
  *   nef_pass_combine_fwd : c1[p][b][c] = P2 A-half[ia(p)] + P2 B-half[ib(p)] + bias[c],  (ia,ib) = (m,m),(pick,m),(m,pick)
  *   nef_pass_combine_bwd : its adjoint, gc1 [3B][C][L] -> gP2 [2B][2C][L]
- *   nef_mix_bwd_shared_up: nef_mix_bwd_up for the two-pass gradient gU2 [2B][256][2T] (wrt the upsampled D2). */
+ *   nef_mix_bwd_shared_up: nef_mix_bwd_up for the two-pass gradient gU2 [2B][256][2T] (wrt the upsampled D2);
+ *   nef_mix_bwd_shared: the same for the gradient wrt D2 itself, gD2 [2B][256][T] (what the polyphase backward-data pass leaves). */
 int nef_mix_fwd_shared(const float* latent, const float* z1, const float* z2r, const float* q, float* D2, int B, int V,
                        int T, int c1, int c2, const int32_t* choice_dev, nef_stream_t stream);
 /* nef_lead_mean + nef_mix_fwd_shared in one pass over z1 / z2r (the picked lead is one of the rows being averaged):
  * bit-identical latent and D2, 0.65 GB less traffic per step at config 2. */
 int nef_lead_mean_mix_shared(const float* z1, const float* z2r, const float* q, float* latent, float* D2, int B, int V,
                              int T, int c1, int c2, const int32_t* choice_dev, nef_stream_t stream);
+int nef_mix_bwd_shared(const float* gD2, const float* latent, const float* z1, const float* z2r, const float* q,
+                       float* gz1, float* gz2r, float* gq, int B, int V, int T, int c1, int c2,
+                       const int32_t* choice_dev, int relu_z1, nef_stream_t stream);
 int nef_mix_bwd_shared_up(const float* gU2, const float* latent, const float* z1, const float* z2r, const float* q,
                           float* gz1, float* gz2r, float* gq, int B, int V, int T, int c1, int c2,
                           const int32_t* choice_dev, int relu_z1, nef_stream_t stream);
@@ -458,6 +464,20 @@ int nef_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, 
  * and makes nef_sgd_momentum skip the update.  No counterpart in the reference (its fp32 nn.Conv1d cannot overflow at 65504,
  * codes/network/model_nefnet.py:18-21); capturable, nothing is read by the host. */
 int nef_h2_taint(const int32_t* clamped_total, int32_t* mark, float* out, nef_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Polyphase form of a K = 3 conv behind the x2 linear upsampling (codes/network/model_nefnet.py:101-105, nn.Upsample + DoubleConv's
+ * first conv): output 2m + p is a K = 3 conv of the HALF-resolution input with phase weights W'_p.
+ * nef_poly_weights: w [rows][Cig][3] -> wsyn [2 rows][Cig][3], row 2 r + p = W'_p of row r.
+ * Backward-data through conv + upsampling in one pass at half resolution: nef_conv_fwd with pro_mode 4 (input = the
+ * full-resolution gradient [B][G Cog][T] read as 2 Cog phase channels of length T / 2), weights = wsyn packed transposed / flipped,
+ * output = the gradient wrt the half-resolution input; then nef_poly_bwd_edge adds the two row-end terms the phase form leaves out
+ * (and their share of the BatchNorm-backward sums, into slot 0 of the sample: bnb_* as in nef_conv_args, NULL slots = none). */
+int nef_poly_weights(const float* w, float* wsyn, int rows, int Cig, nef_stream_t stream);
+int nef_poly_bwd_edge(const float* gy, const float* w /* [G Cog][Cig][3], the conv's own weight */, float* gx, int B, int G, int Cog,
+                      int Cig, int T /* length of gy = 2 x length of gx */, const float* bnb_x, const float* bnb_mean,
+                      const float* bnb_invstd, const float* bnb_a, const float* bnb_b, int bnb_Bp, float* bnb_slots, int nslot,
+                      nef_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Test-phase metrics on the device.  Replaces PSNR / SSIM of codes/utils/mertic.py:7-32 as called from

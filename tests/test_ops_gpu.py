@@ -640,6 +640,45 @@ def test_conv_epilogue_bn_backward_slot_sums_through_upsampling(B, Cin, Cout, T)
     assert maxabs(got[3], want[3]) < 1e-4 * float(want[0].abs().sum() / Cout) + 1e-6
 
 
+@pytest.mark.parametrize("B,G,Cog,Cig,T", [(6, 1, 64, 128, 1000), (3, 1, 64, 128, 520), (6, 2, 128, 128, 512), (3, 1, 128, 64, 776)])
+def test_conv_bwd_data_polyphase_through_upsampling(B, G, Cog, Cig, T):
+    """Backward-data through conv1d(upsample2(x), w) at HALF resolution (ops.conv_bwd_data_poly: phase-stacked input, pro_mode 4,
+    + the row-end terms) against fp64 autograd through the reference's own ops (codes/network/model_nefnet.py:102-105), against the
+    two-pass form (full-resolution backward-data, then the upsampling's adjoint), and its BatchNorm-backward slot sums against
+    bn_relu_bwd's own reduction.  fp32-class: the bar is the two-pass form's own distance from fp64."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    if not o.poly_bwd_ok(G, Cog, Cig, T):
+        pytest.skip("polyphase form switched off / shape outside the split-fp16 kernel")
+    gy = g(rnd(B, G * Cog, T, seed=1200))
+    w = g(rnd(G * Cog, Cig, 3, seed=1201, scale=0.05))
+    x64 = torch.zeros(B, G * Cig, T // 2, dtype=torch.float64, device=DEV, requires_grad=True)
+    u = torch.nn.functional.interpolate(x64, scale_factor=2, mode="linear", align_corners=False)
+    y = torch.nn.functional.conv1d(u, w.double(), padding=1, groups=G)
+    y.backward(gy.double())
+    want = x64.grad
+    two = o.upsample2_bwd(o.conv(GV.dense(gy, G), o.pack_weight(w, G, flip=True, T=T, f4=True), Cig, 3, role="conv_bwd_data"))
+    got = o.conv_bwd_data_poly(GV.dense(gy, G), w, Cig)
+    e_two, e_got = rel(two.double(), want), rel(got.double(), want)
+    print(f"polyphase backward-data B={B} G={G} {Cog}->{Cig} T={T}: rel-L2 vs fp64 {e_got:.2e} (two-pass form {e_two:.2e})")
+    assert e_got < max(2.0 * e_two, 1e-6)
+    for col in (0, 1, T // 2 - 2, T // 2 - 1):      # the row ends, where the phase form needs its correction
+        assert rel(got[:, :, col].double(), want[:, :, col]) < 2e-6
+    if G == 1:
+        c_below = g(rnd(B, Cig, T // 2, seed=1202))
+        gamma, beta = g(rnd(Cig, seed=1203) + 1.2), g(rnd(Cig, seed=1204, scale=0.3))
+        mean, invstd, a_, b_ = o.bn_train_stats(c_below, gamma, beta, torch.zeros(Cig, device=DEV), torch.ones(Cig, device=DEV), 3)
+        wsyn = o.pack_weight(o.poly_weights(w), 1, flip=True, T=T // 2)
+        slots = o.conv_stats_buffer(wsyn, B, 1, Cig, T // 2, gy.device)
+        slots[0].fill_(float("nan"))
+        gv = o.conv_bwd_data_poly(GV.dense(gy, 1), w, Cig, bnb=(c_below, mean, invstd, a_, b_, B // 3, slots))
+        assert torch.equal(gv, got)
+        want_b = o.bn_relu_bwd(gv, c_below, gamma, mean, invstd, a_, b_, 3, with_chan_sum=True)
+        got_b = o.bn_relu_bwd(gv, c_below, gamma, mean, invstd, a_, b_, 3, with_chan_sum=True, slots=slots)
+        for x_, y_ in zip(got_b[:3], want_b[:3]):
+            assert rel(x_, y_) < 2e-6
+
+
 def test_bn_relu_bwd_combine3_equals_two_calls():
     o = ops()
     Bp, C, L = 2, 16, 301
