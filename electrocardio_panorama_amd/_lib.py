@@ -130,7 +130,8 @@ SIGNATURES = {
     "nef_loss_bwd": (i32, [p, p, p, p, p, p, p, p, i64, f32, f32, f32, i32, i32, p]),
     "nef_sgd_momentum": (i32, [p, p, p, i64, f32, f32, f32, i32, p, p, p, p]),
     "nef_h2_taint": (i32, [p, p, p, p]),
-    "nef_poly_weights": (i32, [p, p, i32, i32, p]),
+    "nef_poly_weights": (i32, [p, p, i32, i32, i32, p]),
+    "nef_poly_fwd_edge": (i32, [p, p, p, i32, i32, i32, i32, i32, p, p, i32, p, i32, p]),
     "nef_poly_bwd_edge": (i32, [p, p, p, i32, i32, i32, i32, i32, p, p, p, p, p, i32, p, i32, p]),
     "nef_view_metrics": (i32, [p, p, p, p, p, i32, i32, i32, p]),
     "nef_pano_h_from_f32": (i32, [p, p, i32, i32, i32, p]),

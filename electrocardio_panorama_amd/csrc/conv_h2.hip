@@ -214,6 +214,13 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
     // Cin_g phase channels of length T -- reduction channel 2 c + p at position m is x[c][2 m + p], one 8-byte load per two channels
     constexpr bool PH = (PRO & 4) != 0;
     static_assert(!PH || (!UP && K == 3), "phase-stacked input: K = 3, no upsampling prologue");
+    // PF (pro_mode 8 | affine bit, polyphase FORWARD of conv1d(upsample2(x))): x is the half-resolution tensor, staged with
+    // nn.Upsample's clamped ends (position -1 = x[0], position T = x[T-1]); the launch's Cout_g rows are (channel, phase) pairs in
+    // tile order -- row wm 64 + p 32 + r of a 128-row tile = phase p of channel m0 / 2 + wm 32 + r, i.e. a lane's two accumulator
+    // sets are the two phases of the same channels -- and the epilogue writes y[c][2 m + p] (y: [Cout_g / 2][2 T]), eight
+    // consecutive outputs per lane and row; bias and BatchNorm statistics only.
+    constexpr bool PF = (PRO & 8) != 0;
+    static_assert(!PF || (!UP && !PH && K == 3 && TM == 2 && !PACK), "polyphase forward: K = 3, 128-row tile");
     constexpr int NS = UP ? 2 : 1;
     constexpr int PAD = (K - 1) / 2;
     constexpr int XROW = NTO + K - 1;              // staged positions per channel: t0 - PAD .. t0 + NTO + PAD - 1
@@ -329,6 +336,10 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
             lam[it] = src - (float)i0;
             xvo[it][0] = xok[it] ? (unsigned)(i0 * 4) : NEF_OOB;
             xvo[it][NS - 1] = xok[it] ? (unsigned)(i1 * 4) : NEF_OOB;
+        } else if constexpr (PF) {
+            xok[it] = (r < XROW) && (t >= -1) && (t <= T);
+            const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+            xvo[it][0] = xok[it] ? (unsigned)(tc * 4) : NEF_OOB;
         } else {
             xvo[it][0] = xok[it] ? (unsigned)(t * (PH ? 8 : 4)) : NEF_OOB;
         }
@@ -495,6 +506,8 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
     if (tid < MT) {     // epilogue tables, published by the barrier behind the first stage's LDS stores
         const int ch_ = g * Cog + m0 + (int)tid;
         const float* const dsc = reinterpret_cast<const float*>(wph + (int64_t)a.G * K * Cog * Cig * 2);
+        if constexpr (PF) El[tid] = a.bias ? a.bias[g * (Cog >> 1) + (m0 >> 1) + ((int)tid >> 6) * 32 + ((int)tid & 31)] : 0.f;
+        else
         El[tid] = a.bias ? a.bias[ch_] : 0.f;
         El[5 * MT + tid] = dsc[ch_] / xs_;
         if (a.bnb_slots) {
@@ -616,6 +629,68 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
         return -1.f;
     }
 #endif
+    if constexpr (PF) {
+        // ---- polyphase epilogue: the lane's four adjacent half-resolution columns m .. m + 3 of both phases = outputs 2 m .. 2 m + 7
+        const int t = t0 + wn * 128 + 4 * lo;
+        const bool inb = b0 < a.B;
+        const bool live0 = inb && t < T, live1 = inb && t + 2 < T;
+        const int Cr = Cog >> 1;
+        const int cw = (m0 >> 1) + wm * 32;             // first channel of this wave's rows
+        const int erow = wm * 64 + 4 * hi;
+        const __amdgpu_buffer_rsrc_t yrs = nef_rsrc(a.y + (int64_t)b0 * a.y_bs + (int64_t)g * a.y_gs + (int64_t)cw * (2 * T));
+        const unsigned yv0 = live0 ? (unsigned)((4 * hi * 2 * T + 2 * t) * 4) : NEF_OOB;
+        const unsigned yv1 = live1 ? (unsigned)((4 * hi * 2 * T + 2 * t + 4) * 4) : NEF_OOB;
+        float* const slot_out = a.stats;
+        float sv[32];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = ((q + 8 * h) & 3) + 8 * ((q + 8 * h) >> 2);
+                const float ds0 = El[5 * MT + erow + row], ds1 = El[5 * MT + erow + 32 + row], bv = El[erow + row];
+                float y0[4], y1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y0[e] = fmaf(acc[0][e][q + 8 * h], ds0, bv);
+                    y1[e] = fmaf(acc[TM - 1][e][q + 8 * h], ds1, bv);
+                }
+                const f32x4 o0 = {y0[0], y1[0], y0[1], y1[1]}, o1 = {y0[2], y1[2], y0[3], y1[3]};
+                nef_buf_store_f32x4(o0, yrs, yv0, (unsigned)(row * 2 * T * 4));
+                nef_buf_store_f32x4(o1, yrs, yv1, (unsigned)(row * 2 * T * 4));
+                if (slot_out) {
+                    const float s0 = live0 ? (y0[0] + y1[0]) + (y0[1] + y1[1]) : 0.f, s1 = live1 ? (y0[2] + y1[2]) + (y0[3] + y1[3]) : 0.f;
+                    const float q0 = live0 ? fmaf(y0[0], y0[0], y1[0] * y1[0]) + fmaf(y0[1], y0[1], y1[1] * y1[1]) : 0.f;
+                    const float q1 = live1 ? fmaf(y0[2], y0[2], y1[2] * y1[2]) + fmaf(y0[3], y0[3], y1[3] * y1[3]) : 0.f;
+                    sv[2 * (q + 8 * h)] = s0 + s1;
+                    sv[2 * (q + 8 * h) + 1] = q0 + q1;
+                }
+            }
+        }
+        if (slot_out) {      // (the butterfly of the other forms)
+#pragma unroll
+            for (int step = 0; step < 5; ++step) {
+                const int off = 16 >> step;
+                const bool up = (lo & off) != 0;
+#pragma unroll
+                for (int k = 0; k < off; ++k) {
+                    const float send = up ? sv[k] : sv[k + off];
+                    const float keep = up ? sv[k + off] : sv[k];
+                    sv[k] = keep + __shfl_xor(send, off, 64);
+                }
+            }
+            const int r = lo >> 1;
+            const int ch = g * Cr + cw + 4 * hi + (r & 3) + 8 * (r >> 2);
+            const int64_t nslot = (int64_t)tps * 2;
+            const int64_t slot = (int64_t)b0 * nslot + (int64_t)(t0 / NTO) * 2 + wn;
+            if (inb) slot_out[((int64_t)ch * a.B * nslot + slot) * 2 + (lo & 1)] = sv[0];
+        }
+#if NEF_H2_EPI_ALWAYS
+        __syncthreads();
+        return over_ret;
+#else
+        return -1.f;
+#endif
+    }
     // ---- epilogue: descale, then bias / residual / ReLU / dropout / gate on the four adjacent outputs a lane owns per row
     const int64_t ctot = (int64_t)a.G * Cog;
     int t = t0 + wn * 128 + 4 * lo;
@@ -892,7 +967,10 @@ static bool h2_pack_shape(const nef_conv_args* a) {
 __attribute__((visibility("hidden"))) bool nef_h2_ok(const nef_conv_args* a) {
     return (a->K == 1 || a->K == 3 || a->K == 7) && a->Cout_g % 64 == 0 && a->Cin_g % KC == 0 && a->T % 2 == 0 &&
            (a->T >= NTO / 2 || h2_pack_shape(a)) &&
-           a->pro_mode >= 0 && a->pro_mode <= 4 && (a->K == 3 || a->pro_mode == 0) && !(a->pro_mode && a->in_scale) &&
+           ((a->pro_mode >= 0 && a->pro_mode <= 4) || a->pro_mode == 8 || a->pro_mode == 9) && (a->K == 3 || a->pro_mode == 0) &&
+           !(a->pro_mode && a->in_scale) &&
+           (!(a->pro_mode & 8) || (a->Cout_g % 128 == 0 && a->T >= NTO / 2 && !a->res && !a->gate && !a->mask && !a->relu && a->drop_p <= 0.f &&
+                                   !a->bnb_slots && (int64_t)a->Cout_g * a->T * 4 < 0x7fffffff)) &&
            (a->pro_mode != 4 || (a->T >= NTO / 2 && (int64_t)a->Cin_g * a->T * 4 < 0x7fffffff)) &&
            (!(a->pro_mode & 1) || a->Cin_g <= PRO_MAX_CIN);
 }
@@ -920,6 +998,8 @@ __attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, 
         case 1: return wide ? launch_h2<3, 1, 2>(*a, st) : launch_h2<3, 1, 1>(*a, st);
         case 2: return launch_h2<3, 2, 1>(*a, st);
         case 4: return wide ? launch_h2<3, 4, 2>(*a, st) : launch_h2<3, 4, 1>(*a, st);
+        case 8: return launch_h2<3, 8, 2>(*a, st);
+        case 9: return launch_h2<3, 9, 2>(*a, st);
         default: return launch_h2<3, 3, 1>(*a, st);
     }
 }

@@ -1192,19 +1192,73 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
 //     W'_1 = (0.25 w0,  0.75 w0 + 0.75 w1 + 0.25 w2,  0.25 w1 + 0.75 w2)
 // (nn.Upsample(scale_factor=2, mode='linear'): u[2j] = 0.25 x[j-1] + 0.75 x[j], u[2j+1] = 0.75 x[j] + 0.25 x[j+1]).
 // wsyn [R * 2][Cig][3], row 2 r + p for row r of w [R][Cig][3].  One thread per (r, ci).
-__global__ __launch_bounds__(256) void poly_weights_kernel(const float* __restrict__ w, float* __restrict__ ws, int R, int Cig) {
+// `Cr` > 0: TILE order for the polyphase forward launch (conv_h2_kernel PF) -- w has Cr rows per group, phase p of channel co of
+// group g is row g 2 Cr + (co / 64) 128 + ((co / 32) & 1) 64 + p 32 + co % 32.
+__global__ __launch_bounds__(256) void poly_weights_kernel(const float* __restrict__ w, float* __restrict__ ws, int R, int Cig, int Cr) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)R * Cig) return;
     const int r = (int)(i / Cig), ci = (int)(i - (int64_t)r * Cig);
     const float w0 = w[3 * i], w1 = w[3 * i + 1], w2 = w[3 * i + 2];
-    float* const o0 = ws + ((int64_t)(2 * r) * Cig + ci) * 3;
-    float* const o1 = ws + ((int64_t)(2 * r + 1) * Cig + ci) * 3;
+    int r0 = 2 * r, r1 = 2 * r + 1;
+    if (Cr > 0) {
+        const int g = r / Cr, co = r - g * Cr;
+        r0 = g * 2 * Cr + (co >> 6) * 128 + ((co >> 5) & 1) * 64 + (co & 31);
+        r1 = r0 + 32;
+    }
+    float* const o0 = ws + ((int64_t)r0 * Cig + ci) * 3;
+    float* const o1 = ws + ((int64_t)r1 * Cig + ci) * 3;
     o0[0] = fmaf(0.75f, w0, 0.25f * w1);
     o0[1] = fmaf(0.25f, w0, 0.75f * (w1 + w2));
     o0[2] = 0.25f * w2;
     o1[0] = 0.25f * w0;
     o1[1] = fmaf(0.25f, w2, 0.75f * (w0 + w1));
     o1[2] = fmaf(0.75f, w2, 0.25f * w1);
+}
+
+// Row ends of the polyphase forward pass: the phase convs see x[-1] = x[0] and x[Tin] = x[Tin-1] (nn.Upsample's clamped sources)
+// and therefore u[-1] = x[0], u[T] = x[Tin-1] where the conv's zero padding has 0:
+//     y[c][0] -= sum_ci w[c][ci][0] x'[ci][0]        y[c][T-1] -= sum_ci w[c][ci][2] x'[ci][Tin-1]        (x' = the prologue's output)
+// and the two columns' change in the BatchNorm statistics (sum, sum of squares) goes into slot 0 of the sample.  One workgroup per
+// (sample, group), one wave per output channel at a time.
+__global__ __launch_bounds__(256) void poly_fwd_edge_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                            int B, int G, int Cr, int Cig, int T, const float* __restrict__ pa,
+                                                            const float* __restrict__ pb, int Bp, float* __restrict__ slots, int nslot) {
+    extern __shared__ float xl[];      // [2][Cig]: x'[:, 0], x'[:, Tin - 1]
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int Tin = T >> 1;
+    const float* const xb = x + ((int64_t)b * G + g) * Cig * Tin;
+    for (int i = threadIdx.x; i < 2 * Cig; i += 256) {
+        const int ci = i >> 1, k = i & 1;
+        float v = xb[(int64_t)ci * Tin + (k ? Tin - 1 : 0)];
+        if (pa) {
+            const int64_t pr = (int64_t)(b / Bp) * G * Cig + (int64_t)g * Cig + ci;
+            v = fmaxf(fmaf(v, pa[pr], pb[pr]), 0.f);
+        }
+        xl[k * Cig + ci] = v;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = wave; c < Cr; c += 4) {
+        const float* const wr = w + ((int64_t)g * Cr + c) * Cig * 3;
+        float c0 = 0.f, cl = 0.f;
+        for (int ci = lane; ci < Cig; ci += 64) {
+            c0 = fmaf(wr[3 * ci], xl[ci], c0);
+            cl = fmaf(wr[3 * ci + 2], xl[Cig + ci], cl);
+        }
+        c0 = nef_wave_sum(c0), cl = nef_wave_sum(cl);
+        if (lane == 0) {
+            const int64_t ch = (int64_t)g * Cr + c;
+            float* const row = y + ((int64_t)b * G * Cr + ch) * T;
+            const float y0 = row[0], yl = row[T - 1];
+            row[0] = y0 - c0;
+            row[T - 1] = yl - cl;
+            if (slots) {
+                float* const sl = slots + ((ch * B + b) * nslot) * 2;
+                sl[0] -= c0 + cl;
+                sl[1] += fmaf(c0, c0 - 2.f * y0, cl * (cl - 2.f * yl));
+            }
+        }
+    }
 }
 
 // Row ends of the polyphase backward-data pass.  The phase convs treat both ends of x as if the interpolation formula continued
@@ -1897,12 +1951,24 @@ int nef_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, 
     return nef_launch_status();
 }
 
-int nef_poly_weights(const float* w, float* wsyn, int rows, int Cig, nef_stream_t stream) {
+int nef_poly_weights(const float* w, float* wsyn, int rows, int Cig, int tile_Cr, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(w && wsyn, NEF_E_NULL);
-    NEF_REQUIRE(rows > 0 && Cig > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(rows > 0 && Cig > 0 && (tile_Cr == 0 || (tile_Cr > 0 && tile_Cr % 64 == 0 && rows % tile_Cr == 0)), NEF_E_SHAPE);
     const int64_t n = (int64_t)rows * Cig;
-    hipLaunchKernelGGL(poly_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, NEF_ST, w, wsyn, rows, Cig);
+    hipLaunchKernelGGL(poly_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, NEF_ST, w, wsyn, rows, Cig, tile_Cr);
+    return nef_launch_status();
+}
+
+int nef_poly_fwd_edge(const float* x, const float* w, float* y, int B, int G, int Cr, int Cig, int T, const float* pro_a,
+                      const float* pro_b, int pro_Bp, float* stats, int nslot, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && w && y, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && G > 0 && Cr > 0 && Cig > 0 && Cig <= 4096 && T >= 4 && T % 2 == 0, NEF_E_SHAPE);
+    NEF_REQUIRE((!pro_a && !pro_b) || (pro_a && pro_b && pro_Bp > 0), NEF_E_NULL);
+    NEF_REQUIRE(!stats || nslot > 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(poly_fwd_edge_kernel, dim3((unsigned)(B * G)), dim3(256), (size_t)2 * Cig * sizeof(float), NEF_ST, x, w, y, B, G, Cr,
+                       Cig, T, pro_a, pro_b, pro_Bp, stats, nslot);
     return nef_launch_status();
 }
 

@@ -114,9 +114,12 @@ def _latent_pack_requests(P, V, T, win, flip):
 
 
 def _decoder_pack_requests(P, T_lat, flip):
-    """Decoder convs whose weight is used as stored (the first one is regrouped per call): output lengths 2T, 4T, 4T."""
-    return [(P["decoder.1.double_conv.3.weight"], 1, flip, 2 * T_lat, True), (P["decoder.3.double_conv.0.weight"], 1, flip, 4 * T_lat, True),
-            (P["decoder.3.double_conv.3.weight"], 1, flip, 4 * T_lat, True)]
+    """Decoder convs whose weight is used as stored (the first one is regrouped per call): output lengths 2T, 4T, 4T.  The conv
+    behind the second upsampling packs its own (phase) weights when it runs in polyphase form."""
+    w3 = P["decoder.3.double_conv.0.weight"]
+    poly = (ops.poly_bwd_ok if flip else ops.poly_fwd_ok)(1, w3.shape[0], w3.shape[1], 4 * T_lat)
+    return ([(P["decoder.1.double_conv.3.weight"], 1, flip, 2 * T_lat, True)] +
+            ([] if poly else [(w3, 1, flip, 4 * T_lat, True)]) + [(P["decoder.3.double_conv.3.weight"], 1, flip, 4 * T_lat, True)])
 
 
 # Below this many latent elements per step (B * 128V * T) the step is bound by the host issuing launches, and the second
@@ -240,13 +243,29 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
             up_after = bool(mode & 2)
         T_out = x_in.shape[2] * (2 if up_after and pro[0] & 2 else 1)
         stats = None
+        # the two convs behind a x2 upsampling run in polyphase form where the shape allows: a conv over the half-resolution input
+        # whose rows are the two output phases (ops.conv_poly_fwd) -- half the staged elements, no interpolation arithmetic
+        poly = bool(pro[0] & 2) and ops.poly_fwd_ok(2 if (li == 0 and shared_B is not None) else 1, cout,
+                                                     x_in.shape[1] // (2 if (li == 0 and shared_B is not None) else 1), T_out)
         if li == 0 and shared_B is not None:
-            p2 = ops.conv(GV.dense(x_in, 2), ops.pack_weight(_regroup_halves(P[wname]), 2, T=T_out, f4=True, site=P[wname].data_ptr()), cout, 3, pro=pro)
+            if poly:
+                p2 = ops.conv_poly_fwd(GV.dense(x_in, 2), _regroup_halves(P[wname]), cout, pro=pro, site=P[wname].data_ptr())
+            else:
+                p2 = ops.conv(GV.dense(x_in, 2), ops.pack_weight(_regroup_halves(P[wname]), 2, T=T_out, f4=True, site=P[wname].data_ptr()), cout, 3, pro=pro)
             if training and passes == 3:      # the BatchNorm statistics of c1 come out of the same pass
                 c, *stats = ops.pass_combine_fwd_stats(p2, P[bname], shared_B, P[pre + ".weight"], P[pre + ".bias"],
                                                        Bf[pre + ".running_mean"], Bf[pre + ".running_var"], BN_EPS, BN_MOM)
             else:
                 c = ops.pass_combine_fwd(p2, P[bname], shared_B)
+        elif poly:
+            slots = None
+            if training and _FUSE_STATS:
+                c, slots = ops.conv_poly_fwd(GV.dense(x_in, 1), P[wname], cout, bias=P[bname], pro=pro, stats=True)
+            else:
+                c = ops.conv_poly_fwd(GV.dense(x_in, 1), P[wname], cout, bias=P[bname], pro=pro)
+            if slots is not None:
+                stats = ops.bn_stats_from_slots(slots, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
+                                                Bf[pre + ".running_var"], passes, N, T_out, BN_EPS, BN_MOM)
         else:
             wp = ops.pack_weight(P[wname], 1, T=T_out, f4=True)
             # train mode: the F(4,3) epilogue leaves the BatchNorm slot sums of c -- no statistics pass over c

@@ -579,7 +579,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     # bench.py prices a launch by its tag; the optional 8th element says which operands are NOT at the output's resolution / are extra:
     # "up" = the input is the half-resolution tensor (x2-upsampling prologue), "bnb" / "bnbup" = the epilogue also reads the
     # BatchNorm input of the layer below (full / half resolution) for the backward sums
-    extra = ("up" if (pro is not None and pro[0] & 2) else "") + ("ph" if (pro is not None and pro[0] == 4) else "") + ("bnb" + ("up" if len(bnb) > 7 and bnb[7] else "") if bnb is not None else "")
+    extra = ("up" if (pro is not None and pro[0] & 2) else "") + ("ph" if (pro is not None and pro[0] == 4) else "") + ("pf" if (pro is not None and pro[0] & 8) else "") + ("bnb" + ("up" if len(bnb) > 7 and bnb[7] else "") if bnb is not None else "")
     tag = (role, K, xv.G, xv.Cg, Cog, xv.B, T_out) + ((extra,) if extra else ())
     ev = _timed(tag)
     if ev is not None:
@@ -593,15 +593,52 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
 
 # ------------------------------------------------------------------ polyphase form of conv1d(upsample2(x)), K = 3
 POLY = _env.get("NEF_POLY", "1") == "1"
+_POLY_FWD = _env.get("NEF_POLY_FWD", "1") == "1"
 
 
-def poly_weights(w):
+def poly_weights(w, tile_Cr=0):
     """w [R, Cig, 3] -> [2R, Cig, 3]: row 2r + p = the phase-p weights of row r (csrc/elementwise.hip poly_weights_kernel): output
-    2m + p of conv1d(upsample2(x), w) is the K = 3 conv of the half-resolution x with them."""
+    2m + p of conv1d(upsample2(x), w) is the K = 3 conv of the half-resolution x with them.  `tile_Cr` (channels per group): rows in
+    the tile order the polyphase FORWARD launch wants instead."""
     _chk(w)
     ws = torch.empty(2 * w.shape[0], w.shape[1], 3, device=w.device, dtype=torch.float32)
-    _lib.check(_lib.load().nef_poly_weights(_p(w), _p(ws), w.shape[0], w.shape[1], _stream()), "nef_poly_weights")
+    _lib.check(_lib.load().nef_poly_weights(_p(w), _p(ws), w.shape[0], w.shape[1], int(tile_Cr), _stream()), "nef_poly_weights")
     return ws
+
+
+def poly_fwd_ok(G, Cog, Cig, T):
+    """Can y = conv1d(upsample2(x [.., G*Cig, T/2]), w [G*Cog, Cig, 3]) run in polyphase form?  (a split-fp16 conv with Cig reduction
+    channels, 2 Cog output rows in 128-row tiles, T / 2 columns)"""
+    Th = T // 2
+    return (POLY and _POLY_FWD and H2 and T % 2 == 0 and Th >= 128 and Cog % 64 == 0 and Cig % 16 == 0 and h2_ok(3, Cig, 2 * Cog, Th, 1) and
+            _H2_DIR[False] and "3" in _H2_K and _h2_fills(G, 2 * Cog, Th, 256, 128))
+
+
+def conv_poly_fwd(xv, w, Cog, bias=None, pro=None, stats=False, site=None):
+    """y [B, G*Cog, 2T] = conv1d(upsample2(prologue(x)), w) + bias in polyphase form: one split-fp16 conv over the half-resolution
+    x (`xv`, a GV) whose rows are the two phases of each channel (conv args pro_mode 8 | affine bit), written interleaved, + the two
+    row-end columns (nef_poly_fwd_edge).  `pro` = (mode, a, b, Bp) as conv() gets it for this layer (bit1 = the upsampling itself,
+    bit0 the BatchNorm affine + ReLU of the layer below); `stats`: also leave the BatchNorm slot sums -> (y, (slots, nslot)).
+    Reference: codes/network/model_nefnet.py:102-105 (nn.Upsample + the DoubleConv's first conv).  Summation order differs from
+    the upsampling-prologue form (fp32-class either way)."""
+    L = _lib.load()
+    G, Cig, Th = xv.G, xv.Cg, xv.T
+    assert w.shape == (G * Cog, Cig, 3)
+    aff = pro is not None and bool(pro[0] & 1)
+    ws = poly_weights(w, Cog)
+    wp = pack_weight(ws, G, T=Th, site=w.data_ptr() if site is None else site, plain=False)
+    if int(getattr(wp, "nef_wino", 0)) != 3:
+        raise _lib.NefLibraryError("conv_poly_fwd: shape outside the split-fp16 kernel (ask poly_fwd_ok first)")
+    y = torch.empty(xv.B, G * Cog, 2 * Th, device=xv.t.device, dtype=torch.float32)
+    slots = conv_stats_buffer(wp, xv.B, G, Cog, Th, xv.t.device) if stats else None
+    out = GV(y, xv.B, G, 2 * Cog, Th, G * Cog * 2 * Th, Cog * 2 * Th, 0)      # (strides of the real tensor; Cg / T as the launch counts them)
+    conv(xv, wp, 2 * Cog, 3, out=out, bias=bias, pro=(8 | int(aff), pro[1] if aff else None, pro[2] if aff else None, pro[3] if aff else 1),
+         stats=slots)
+    pa, pb, pbp = (_p(pro[1]), _p(pro[2]), pro[3]) if aff else (None, None, 1)
+    _lib.check(L.nef_poly_fwd_edge(xv.ptr, _p(w), _p(y), xv.B, G, Cog, Cig, 2 * Th, pa, pb, pbp,
+                                   _p(slots[0]) if slots is not None else None, slots[1] if slots is not None else 0, _stream()),
+               "nef_poly_fwd_edge")
+    return (y, slots) if stats else y
 
 
 def poly_bwd_ok(G, Cog, Cig, T):

@@ -34,7 +34,7 @@ extern "C" {
 typedef void* nef_stream_t;
 
 /* ABI version of this header; bumped on any signature change. */
-int nef_abi_version(void);   /* 17 (round 5: + pro_mode 4, nef_poly_weights, nef_poly_bwd_edge: polyphase backward-data through the x2 upsampling); 16 (round 5: + nef_set_option / nef_get_option); 15 (round 4: + x_clamped / clamped counters); 14 (round 4: + nef_conv_bwd_weight_h2); 13 (round 4: + nef_pack_weight_h2 / conv args wino = 3 and x_scale: direct convolutions on exact fp16 splits of the fp32 operands); 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
+int nef_abi_version(void);   /* 17 (round 5: + pro_mode 4 / 8 / 9, nef_poly_weights, nef_poly_fwd_edge, nef_poly_bwd_edge, nef_mix_bwd_shared: polyphase forward / backward-data through the x2 upsampling); 16 (round 5: + nef_set_option / nef_get_option); 15 (round 4: + x_clamped / clamped counters); 14 (round 4: + nef_conv_bwd_weight_h2); 13 (round 4: + nef_pack_weight_h2 / conv args wino = 3 and x_scale: direct convolutions on exact fp16 splits of the fp32 operands); 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
 
 /* Kernel-form options of the process (tuning / A-B hooks; every value computes the same results).  Not part of any reference
  * interface: the reference's nn.Conv1d has one form (codes/network/model_nefnet.py:18-21).  Returns the previous value, or
@@ -127,6 +127,9 @@ typedef struct nef_conv_args {
      *   pro_mode bit1: the input is stored at half resolution [..][T/2] and is x2-upsampled on the fly exactly as
      *                  nn.Upsample(scale_factor=2, mode='linear', align_corners=False) (model_nefnet.py:102,104);
      *                  x_bs / x_gs and the channel pitch then refer to the half-resolution tensor.
+     *   pro_mode 8 / 9 (wino == 3 only): polyphase forward of conv1d(upsample2(x)) -- x at half resolution [..][T], Cout_g = 2 x the
+     *                  conv's channels (tile-ordered phase weights, nef_poly_weights), y [..][Cout_g / 2][2 T]; bit0 as above;
+     *                  bias and stats only; followed by nef_poly_fwd_edge.
      *   pro_mode 4 (alone, wino == 3 only): phase-stacked input for the polyphase backward-data pass -- x is a full-resolution
      *                  tensor [..][Cin_g / 2][2 T]; reduction channel 2 c + p at position m is x[c][2 m + p] (see nef_poly_weights).
      * Zero padding is applied after the prologue.  in_scale must be NULL when pro_mode != 0. */
@@ -473,7 +476,15 @@ int nef_h2_taint(const int32_t* clamped_total, int32_t* mark, float* out, nef_st
  * full-resolution gradient [B][G Cog][T] read as 2 Cog phase channels of length T / 2), weights = wsyn packed transposed / flipped,
  * output = the gradient wrt the half-resolution input; then nef_poly_bwd_edge adds the two row-end terms the phase form leaves out
  * (and their share of the BatchNorm-backward sums, into slot 0 of the sample: bnb_* as in nef_conv_args, NULL slots = none). */
-int nef_poly_weights(const float* w, float* wsyn, int rows, int Cig, nef_stream_t stream);
+int nef_poly_weights(const float* w, float* wsyn, int rows, int Cig, int tile_Cr /* 0, or the channels per group (a multiple of 64):
+                     rows in the TILE order of the polyphase forward launch, phase p of channel co of group g = row
+                     g 2 Cr + (co / 64) 128 + ((co / 32) & 1) 64 + p 32 + co % 32 */, nef_stream_t stream);
+/* Forward in polyphase form: nef_conv_fwd with pro_mode 8 (| 1: the BatchNorm affine + ReLU prologue) -- x the half-resolution input
+ * [B][G Cin_g][T], weights = tile-ordered wsyn (Cout_g = 2 x channels), y [B][G Cout_g / 2][2 T], bias / stats only; then
+ * nef_poly_fwd_edge corrects the first and the last output column (and slot 0 of the statistics) for the conv's zero padding. */
+int nef_poly_fwd_edge(const float* x, const float* w, float* y, int B, int G, int Cr /* output channels per group */, int Cig,
+                      int T /* length of y = 2 x length of x */, const float* pro_a, const float* pro_b, int pro_Bp, float* stats,
+                      int nslot, nef_stream_t stream);
 int nef_poly_bwd_edge(const float* gy, const float* w /* [G Cog][Cig][3], the conv's own weight */, float* gx, int B, int G, int Cog,
                       int Cig, int T /* length of gy = 2 x length of gx */, const float* bnb_x, const float* bnb_mean,
                       const float* bnb_invstd, const float* bnb_a, const float* bnb_b, int bnb_Bp, float* bnb_slots, int nslot,

@@ -640,6 +640,41 @@ def test_conv_epilogue_bn_backward_slot_sums_through_upsampling(B, Cin, Cout, T)
     assert maxabs(got[3], want[3]) < 1e-4 * float(want[0].abs().sum() / Cout) + 1e-6
 
 
+@pytest.mark.parametrize("B,G,Cog,Cig,T,aff", [(6, 1, 64, 128, 1000, True), (3, 1, 64, 128, 520, False), (6, 2, 128, 128, 512, False),
+                                                (3, 1, 128, 64, 776, True), (3, 1, 64, 64, 256, True)])
+def test_conv_fwd_polyphase_behind_upsampling(B, G, Cog, Cig, T, aff):
+    """conv1d(upsample2(relu(bn(x))), w) + bias in polyphase form (ops.conv_poly_fwd: conv args pro_mode 8 / 9 + the row-end
+    columns) against fp64 through the reference's own ops (codes/network/model_nefnet.py:102-105), against the upsampling-prologue
+    form, and its BatchNorm slot sums against the statistics pass.  fp32-class: the bar is the other form's own distance from fp64."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    if not o.poly_fwd_ok(G, Cog, Cig, T):
+        pytest.skip("polyphase form switched off / shape outside the split-fp16 kernel")
+    x = g(rnd(B, G * Cig, T // 2, seed=1210))
+    w = g(rnd(G * Cog, Cig, 3, seed=1211, scale=0.05))
+    bias = g(rnd(G * Cog, seed=1212, scale=0.2))
+    pa, pb = g(rnd(3, G * Cig, seed=1213) + 1.0), g(rnd(3, G * Cig, seed=1214, scale=0.3))
+    pro = (3, pa, pb, B // 3) if aff else (2, None, None, 1)
+    x64 = x.double()
+    if aff:
+        x64 = torch.relu(x64 * pa.double().repeat_interleave(B // 3, 0)[:, :, None] + pb.double().repeat_interleave(B // 3, 0)[:, :, None])
+    u = torch.nn.functional.interpolate(x64, scale_factor=2, mode="linear", align_corners=False)
+    want = torch.nn.functional.conv1d(u, w.double(), bias.double(), padding=1, groups=G)
+    other = o.conv(GV.dense(x, G), o.pack_weight(w, G, T=T, f4=True), Cog, 3, bias=bias, pro=pro)
+    got, slots = o.conv_poly_fwd(GV.dense(x, G), w, Cog, bias=bias, pro=pro, stats=True)
+    e_o, e_g = rel(other.double(), want), rel(got.double(), want)
+    print(f"polyphase forward B={B} G={G} {Cig}->{Cog} T={T} aff={aff}: rel-L2 vs fp64 {e_g:.2e} (upsampling-prologue form {e_o:.2e})")
+    assert e_g < max(2.0 * e_o, 1e-6)
+    for col in (0, 1, 2, T - 3, T - 2, T - 1):
+        assert rel(got[:, :, col].double(), want[:, :, col]) < 2e-6
+    assert torch.equal(o.conv_poly_fwd(GV.dense(x, G), w, Cog, bias=bias, pro=pro), got)
+    if slots is not None:
+        sl, nslot = slots
+        ssum = sl.view(G * Cog, B * nslot, 2).double().sum(1)
+        assert rel(ssum[:, 0], got.double().sum((0, 2))) < 1e-6
+        assert rel(ssum[:, 1], (got.double() ** 2).sum((0, 2))) < 1e-6
+
+
 @pytest.mark.parametrize("B,G,Cog,Cig,T", [(6, 1, 64, 128, 1000), (3, 1, 64, 128, 520), (6, 2, 128, 128, 512), (3, 1, 128, 64, 776)])
 def test_conv_bwd_data_polyphase_through_upsampling(B, G, Cog, Cig, T):
     """Backward-data through conv1d(upsample2(x), w) at HALF resolution (ops.conv_bwd_data_poly: phase-stacked input, pro_mode 4,
