@@ -115,8 +115,10 @@ SIGNATURES = {
     "nef_affine_relu_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, p]),
     "nef_bn_bwd_ws_bytes": (sz, [i32, i32, i32]),
     "nef_bn_relu_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p, i32, p]),
+    "nef_bn_relu_bwd_phase_major": (i32, [p, p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p, i32, p]),
     "nef_bn_relu_bwd_up": (i32, [p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p, i32, p]),
     "nef_bn_relu_bwd_combine3": (i32, [p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, p, i32, p]),
+    "nef_bn_relu_bwd_combine3_phase_major": (i32, [p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, p, i32, p]),
     "nef_bn_bwd_outconv_ws_bytes": (sz, [i32, i32, i32, i32]),
     "nef_bn_relu_bwd_outconv": (i32, [p, p, p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, p]),
     "nef_outconv_fwd": (i32, [p, p, p, p, i32, i32, i32, p]),
@@ -131,8 +133,9 @@ SIGNATURES = {
     "nef_sgd_momentum": (i32, [p, p, p, i64, f32, f32, f32, i32, p, p, p, p]),
     "nef_h2_taint": (i32, [p, p, p, p]),
     "nef_poly_weights": (i32, [p, p, i32, i32, i32, p]),
-    "nef_poly_fwd_edge": (i32, [p, p, p, i32, i32, i32, i32, i32, p, p, i32, p, i32, p]),
-    "nef_poly_bwd_edge": (i32, [p, p, p, i32, i32, i32, i32, i32, p, p, p, p, p, i32, p, i32, p]),
+    "nef_poly_fwd_edge": (i32, [p, p, p, i32, i32, i32, i32, i32, p, p, i32, p, i32, p, p]),
+    "nef_poly_wgrad_fold": (i32, [p, p, p, p, i32, i32, i32, i32, i32, p]),
+    "nef_poly_bwd_edge": (i32, [p, p, p, i32, i32, i32, i32, i32, p, p, p, p, p, i32, p, i32, i32, p]),
     "nef_view_metrics": (i32, [p, p, p, p, p, i32, i32, i32, p]),
     "nef_pano_h_from_f32": (i32, [p, p, i32, i32, i32, p]),
     "nef_pano_h_pack_weight": (i32, [p, p, i32, i32, p]),

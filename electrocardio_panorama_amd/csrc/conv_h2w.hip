@@ -70,6 +70,7 @@ struct H2WArgs {
     int64_t x_end, gy_end;            // bytes from x / gy to the end of the last row the launch may touch
     int B, T, G, Cig, Cog, pro_Bp, S, tps, n_tiles, m_tiles, c_tiles, teams;
     float x_scale, gy_scale;
+    int xclamp;      // pro_mode bit 2 (polyphase weight gradient): the window's columns -1 and T hold x[0] and x[T-1] instead of zeros
 };
 
 
@@ -637,7 +638,8 @@ __global__ __launch_bounds__(64 * (WM / WR * WN + NP), 1) void conv_h2w2_kernel(
                 } else {
 #pragma unroll
                     for (int i = 0; i < 5; ++i) {
-                        const int ti = t + i;
+                        int ti = t + i;
+                        if (a.xclamp) ti = ti == -1 ? 0 : (ti == T ? T - 1 : ti);      // nn.Upsample's clamped sources (polyphase form)
                         const float v = nef_buf_f32(xrs, live && ti >= 0 && ti < T ? rowoff + (unsigned)(ti * 4) : NEF_OOB, 0);
                         if (i < 4) z.xq[q][i] = v; else z.x5[q] = v;
                     }
@@ -700,9 +702,10 @@ __global__ __launch_bounds__(64 * (WM / WR * WN + NP), 1) void conv_h2w2_kernel(
                 }
                 if constexpr (EDGE) {      // zero padding comes after the prologue
                     const int t = t0_ - 4 + 4 * (int)x_qd[q];
+                    const int lo_ = a.xclamp ? -1 : 0, hi_ = a.xclamp ? T + 1 : T;
 #pragma unroll
                     for (int i = 0; i < 5; ++i)
-                        if (t + i < 0 || t + i >= T) v[i] = 0.f;
+                        if (t + i < lo_ || t + i >= hi_) v[i] = 0.f;
                 }
                 amax_x = fmaxf(amax_x, fmaxf(fabsf(v[0]), fabsf(v[1])));
                 amax_x = fmaxf(amax_x, fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -873,14 +876,15 @@ int h2w2_form(int Cog, int pro_mode) {
 extern "C" {
 
 __attribute__((visibility("hidden"))) bool nef_h2w_ok(int B, int T, int Cig, int Cog, int K, int pro_mode) {
-    return (K == 1 || K == 3 || K == 7) && B > 0 && T >= TT && T % 2 == 0 && Cig % 64 == 0 && Cog % 64 == 0 && pro_mode >= 0 && pro_mode <= 3 &&
-           (K == 3 || pro_mode == 0);
+    // pro_mode 4 / 5: bit 2 = clamped window ends (polyphase weight gradient), producer / consumer form only, no upsampling bit
+    return (K == 1 || K == 3 || K == 7) && B > 0 && T >= TT && T % 2 == 0 && Cig % 64 == 0 && Cog % 64 == 0 && pro_mode >= 0 &&
+           (pro_mode <= 3 || (pro_mode <= 5 && Cog % 128 == 0)) && (K == 3 || pro_mode == 0);
 }
 
 // team splits of the (sample, tile) sequence, and partial sums per (g, k, co, ci) the launch leaves (= splits, or twice that
 // when the wave groups keep separate sums)
 __attribute__((visibility("hidden"))) int nef_h2w_splits(int B, int T, int G, int Cig, int Cog, int K, int pro_mode, int* partials) {
-    const int v2 = h2w2_form(Cog, pro_mode);
+    const int v2 = h2w2_form(Cog, pro_mode & 3);
     const H2WForm f = h2w_form(Cog, K);
     const int tps = (T + TT - 1) / TT;
     const int64_t n_tiles = (int64_t)B * tps;
@@ -915,9 +919,12 @@ __attribute__((visibility("hidden"))) int nef_h2w_launch(const float* x, int64_t
     a.m_tiles = Cog / (64 * f.mco), a.c_tiles = Cig / 64;
     a.teams = G * S;
     a.x_scale = x_scale, a.gy_scale = gy_scale;
+    a.xclamp = (pro_mode >> 2) & 1;
+    pro_mode &= 3;
     const int Tin = (pro_mode & 2) ? T / 2 : T;
     a.x_end = ((int64_t)(B - 1) * x_bs + (int64_t)(G - 1) * x_gs + (int64_t)Cig * Tin) * 4;
     a.gy_end = ((int64_t)(B - 1) * gy_bs + (int64_t)(G - 1) * gy_gs + (int64_t)Cog * T) * 4;
+    if (a.xclamp && !h2w2_form(Cog, pro_mode)) return NEF_E_UNSUPPORTED;      // (only the producer / consumer form continues the window)
     if (const int v2 = h2w2_form(Cog, pro_mode)) {
         a.m_tiles = Cog / (v2 == 1 ? 128 : 64), a.c_tiles = Cig / 64;
         // 12 waves = 168 registers each.  K = 7: 8 consumer waves of one row tile (7 x 16 accumulator registers) + 4 producer waves

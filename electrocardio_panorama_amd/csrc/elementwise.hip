@@ -769,7 +769,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict
                                                          const float* __restrict__ a, const float* __restrict__ b,
                                                          const float* __restrict__ coef, float* __restrict__ gx,
                                                          double* __restrict__ rowsum, int Bp, int C, int L4,
-                                                         const float* __restrict__ ocw) {
+                                                         const float* __restrict__ ocw, int deint = 0) {
+    // deint: the row is written PHASE-MAJOR -- gx[row][t & 1][t >> 1], i.e. as the two half-length rows 2 row, 2 row + 1 of a
+    // [.., 2 C, L / 2] tensor: the operand layout of the polyphase backward passes through a x2 upsampling
     __shared__ double sm[4];
     const int64_t row = blockIdx.x;
     const int c = (int)(row % C);
@@ -806,6 +808,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict
                     o[e] = af * (g - k1 - (xv[u][e] - mf) * is * k2);
                     rs += (double)o[e];
                 }
+                if (deint) {
+                    float* const gb_ = gx + row * 4 * L4;
+                    ((nef_f32x2*)gb_)[t] = nef_f32x2{o[0], o[2]};
+                    ((nef_f32x2*)(gb_ + 2 * L4))[t] = nef_f32x2{o[1], o[3]};
+                } else
                 gxr[t] = o;
             }
         }
@@ -824,7 +831,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_combine3(const float* __rest
                                                              const float* __restrict__ invstd, const float* __restrict__ a,
                                                              const float* __restrict__ b, const float* __restrict__ coef,
                                                              float* __restrict__ gP2, double* __restrict__ rowsum, int Bp,
-                                                             int C, int L) {
+                                                             int C, int L, int deint = 0) {
     __shared__ double sm[4];
     const int bb = blockIdx.x / C, c = blockIdx.x % C;
     float mf[3], is[3], af[3], bf[3], k1[3], k2[3];
@@ -853,10 +860,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_combine3(const float* __rest
             o[p] = af[p] * (g - k1[p] - (xv - mf[p]) * is[p] * k2[p]);
             rs[p] += (double)o[p];
         }
-        am[t] = o[0] + o[2];
-        ap[t] = o[1];
-        bm[t] = o[0] + o[1];
-        bp[t] = o[2];
+        const int tq = deint ? (t & 1) * (L >> 1) + (t >> 1) : t;      // (phase-major rows, see bn_bwd_apply_rows)
+        am[tq] = o[0] + o[2];
+        ap[tq] = o[1];
+        bm[tq] = o[0] + o[1];
+        bp[tq] = o[2];
     }
     if (rowsum) {
 #pragma unroll
@@ -1222,7 +1230,8 @@ __global__ __launch_bounds__(256) void poly_weights_kernel(const float* __restri
 // (sample, group), one wave per output channel at a time.
 __global__ __launch_bounds__(256) void poly_fwd_edge_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
                                                             int B, int G, int Cr, int Cig, int T, const float* __restrict__ pa,
-                                                            const float* __restrict__ pb, int Bp, float* __restrict__ slots, int nslot) {
+                                                            const float* __restrict__ pb, int Bp, float* __restrict__ slots, int nslot,
+                                                            float* __restrict__ xedge) {
     extern __shared__ float xl[];      // [2][Cig]: x'[:, 0], x'[:, Tin - 1]
     const int b = blockIdx.x / G, g = blockIdx.x % G;
     const int Tin = T >> 1;
@@ -1235,6 +1244,7 @@ __global__ __launch_bounds__(256) void poly_fwd_edge_kernel(const float* __restr
             v = fmaxf(fmaf(v, pa[pr], pb[pr]), 0.f);
         }
         xl[k * Cig + ci] = v;
+        if (xedge) xedge[(((int64_t)b * G + g) * Cig + ci) * 2 + k] = v;      // kept for the weight gradient's row-end terms
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1261,6 +1271,55 @@ __global__ __launch_bounds__(256) void poly_fwd_edge_kernel(const float* __restr
     }
 }
 
+// Weight gradient of the polyphase form: gw2 [R 2][Cig][3] = the gradients of the phase weights (row 2 r + p), folded back through
+// W'_p(w) -- the transpose of poly_weights_kernel's 6 x 3 map -- minus the two row-end terms of the forward correction:
+//     gw[r][ci][0] -= sum_b gy[b][r][0] x'[b][ci][0]        gw[r][ci][2] -= sum_b gy[b][r][T-1] x'[b][ci][Tin-1]
+// gy phase-major [B][G 2 Cog][Tin], xedge [B][G Cig][2] (nef_poly_fwd_edge).  One workgroup per output row r = g Cog + co.
+__global__ __launch_bounds__(256) void poly_wgrad_fold_kernel(const float* __restrict__ gw2, const float* __restrict__ gy,
+                                                              const float* __restrict__ xedge, float* __restrict__ gw, int B, int G,
+                                                              int Cog, int Cig, int Tin) {
+    constexpr int BC = 2048;
+    __shared__ float ge[2][BC];
+    const int r = blockIdx.x, g = r / Cog, co = r - g * Cog;
+    float e0[2] = {0.f, 0.f}, el[2] = {0.f, 0.f};      // up to 512 input channels per group: two per thread
+    for (int b0 = 0; b0 < B; b0 += BC) {
+        const int nb = B - b0 < BC ? B - b0 : BC;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * nb; i += 256) {
+            const int b = b0 + (i >> 1), p = i & 1;
+            ge[p][i >> 1] = gy[(((int64_t)b * G + g) * 2 * Cog + 2 * co + p) * Tin + (p ? Tin - 1 : 0)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ci = threadIdx.x + 256 * u;
+            if (ci < Cig) {
+                const float* xe = xedge + (((int64_t)b0 * G + g) * Cig + ci) * 2;
+                float s0 = 0.f, s1 = 0.f;
+                for (int b = 0; b < nb; ++b, xe += (int64_t)G * Cig * 2) {
+                    const nef_f32x2 xv = *(const nef_f32x2*)xe;
+                    s0 = fmaf(ge[0][b], xv[0], s0);
+                    s1 = fmaf(ge[1][b], xv[1], s1);
+                }
+                e0[u] += s0, el[u] += s1;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int ci = threadIdx.x + 256 * u;
+        if (ci < Cig) {
+            const float* A = gw2 + ((int64_t)(2 * r) * Cig + ci) * 3;
+            const float* Bq = gw2 + ((int64_t)(2 * r + 1) * Cig + ci) * 3;
+            const float a0 = A[0], a1 = A[1], a2 = A[2], b0_ = Bq[0], b1 = Bq[1], b2 = Bq[2];
+            float* o = gw + ((int64_t)r * Cig + ci) * 3;
+            o[0] = fmaf(0.75f, a0 + b1, 0.25f * (a1 + b0_)) - e0[u];
+            o[1] = fmaf(0.75f, a1 + b1, 0.25f * (a0 + b2));
+            o[2] = fmaf(0.75f, a1 + b2, 0.25f * (a2 + b1)) - el[u];
+        }
+    }
+}
+
 // Row ends of the polyphase backward-data pass.  The phase convs treat both ends of x as if the interpolation formula continued
 // (x[-1] = x[0], x[Tin] = x[Tin-1]: nn.Upsample's clamped sources) and as if u[-1], u[T] existed; the conv's zero padding of u
 // says they do not.  Written out (gu = the gradient wrt u the full-resolution pass would have produced):
@@ -1271,14 +1330,16 @@ __global__ __launch_bounds__(256) void poly_bwd_edge_kernel(const float* __restr
                                                             int B, int G, int Cog, int Cig, int T, const float* __restrict__ bx,
                                                             const float* __restrict__ bmean, const float* __restrict__ binv,
                                                             const float* __restrict__ ba, const float* __restrict__ bb, int Bp,
-                                                            float* __restrict__ slots, int nslot) {
+                                                            float* __restrict__ slots, int nslot, int pm) {
     extern __shared__ float gl[];      // [4][Cog]: columns 0, 1, T-2, T-1 of this (sample, group)'s gradient rows
     const int b = blockIdx.x / G, g = blockIdx.x % G;
     const int Tin = T >> 1;
     const float* const gyb = gy + ((int64_t)b * G + g) * Cog * T;
     for (int i = threadIdx.x; i < 4 * Cog; i += 256) {
         const int c = i >> 2, k = i & 3;
-        gl[k * Cog + c] = gyb[(int64_t)c * T + (k < 2 ? k : T - 4 + k)];
+        const int t = k < 2 ? k : T - 4 + k;
+        // pm: gy is stored phase-major, [2 Cog][T / 2] -- column t of channel c is element t >> 1 of row 2 c + (t & 1)
+        gl[k * Cog + c] = pm ? gyb[(int64_t)(2 * c + (t & 1)) * Tin + (t >> 1)] : gyb[(int64_t)c * T + t];
     }
     __syncthreads();
     const int64_t ctot = (int64_t)G * Cig;
@@ -1728,13 +1789,15 @@ int nef_affine_relu_fwd(const float* x, const float* a, const float* b, float* y
 
 size_t nef_bn_bwd_ws_bytes(int P, int Bp, int C) { return nef_bn_ws_bytes(P, C) + (size_t)P * Bp * C * sizeof(double); }
 
-int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* invstd,
-                    const float* a, const float* b, float* gx, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
-                    size_t ws_bytes, int P, int Bp, int C, int L, const float* slots, int nslot, nef_stream_t stream) {
+static int bn_relu_bwd_impl(const float* gy, const float* x, const float* gamma, const float* mean, const float* invstd,
+                            const float* a, const float* b, float* gx, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
+                            size_t ws_bytes, int P, int Bp, int C, int L, const float* slots, int nslot, int deint,
+                            nef_stream_t stream) {
     NEF_ENTER();
     (void)gamma;
     NEF_REQUIRE(gy && x && mean && invstd && a && b && gx && ggamma && gbeta && ws, NEF_E_NULL);
     NEF_REQUIRE(P > 0 && Bp > 0 && C > 0 && L > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(!deint || ((L & 3) == 0 && (int64_t)P * Bp * C <= 0x7FFFFFFF), NEF_E_SHAPE);
     NEF_REQUIRE(!slots || (nslot > 0 && (int64_t)Bp * nslot <= 0x7FFFFFFF), NEF_E_SHAPE);
     NEF_REQUIRE(ws_bytes >= nef_bn_bwd_ws_bytes(P, Bp, C), NEF_E_WORKSPACE);
     double* part = (double*)ws;
@@ -1753,7 +1816,7 @@ int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const f
     const int64_t rows = (int64_t)P * Bp * C;
     if ((L & 3) == 0 && rows <= 0x7FFFFFFF)
         hipLaunchKernelGGL(bn_bwd_apply_rows<0>, dim3((unsigned)rows), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b,
-                           (const float*)coef, gx, rowsum, Bp, C, L >> 2, (const float*)nullptr);
+                           (const float*)coef, gx, rowsum, Bp, C, L >> 2, (const float*)nullptr, deint);
     else
         hipLaunchKernelGGL(bn_bwd_apply, dim3(nef_stream_grid(rows, 4)), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b,
                            (const float*)coef, gx, rowsum, P, Bp, C, L);
@@ -1761,6 +1824,21 @@ int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const f
         hipLaunchKernelGGL(rowsum_to_channel, dim3(C), dim3(256), 0, NEF_ST, (const double*)rowsum, gx_chan_sum,
                            P * Bp, C);
     return nef_launch_status();
+}
+
+int nef_bn_relu_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* invstd,
+                    const float* a, const float* b, float* gx, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
+                    size_t ws_bytes, int P, int Bp, int C, int L, const float* slots, int nslot, nef_stream_t stream) {
+    return bn_relu_bwd_impl(gy, x, gamma, mean, invstd, a, b, gx, ggamma, gbeta, gx_chan_sum, ws, ws_bytes, P, Bp, C, L, slots, nslot, 0,
+                            stream);
+}
+
+int nef_bn_relu_bwd_phase_major(const float* gy, const float* x, const float* gamma, const float* mean, const float* invstd,
+                                const float* a, const float* b, float* gx, float* ggamma, float* gbeta, float* gx_chan_sum,
+                                void* ws, size_t ws_bytes, int P, int Bp, int C, int L, const float* slots, int nslot,
+                                nef_stream_t stream) {
+    return bn_relu_bwd_impl(gy, x, gamma, mean, invstd, a, b, gx, ggamma, gbeta, gx_chan_sum, ws, ws_bytes, P, Bp, C, L, slots, nslot, 1,
+                            stream);
 }
 
 int nef_bn_relu_bwd_up(const float* gu, const float* x, const float* mean, const float* invstd, const float* a,
@@ -1794,11 +1872,12 @@ int nef_bn_relu_bwd_up(const float* gu, const float* x, const float* mean, const
     return nef_launch_status();
 }
 
-int nef_bn_relu_bwd_combine3(const float* gy, const float* x, const float* mean, const float* invstd, const float* a,
-                             const float* b, float* gP2, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
-                             size_t ws_bytes, int Bp, int C, int L, const float* slots, int nslot,
-                             nef_stream_t stream) {
+static int bn_relu_bwd_combine3_impl(const float* gy, const float* x, const float* mean, const float* invstd, const float* a,
+                                     const float* b, float* gP2, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
+                                     size_t ws_bytes, int Bp, int C, int L, const float* slots, int nslot, int deint,
+                                     nef_stream_t stream) {
     NEF_ENTER();
+    NEF_REQUIRE(!deint || (L & 1) == 0, NEF_E_SHAPE);
     NEF_REQUIRE(gy && x && mean && invstd && a && b && gP2 && ggamma && gbeta && ws, NEF_E_NULL);
     NEF_REQUIRE(Bp > 0 && C > 0 && L > 0 && (int64_t)Bp * C <= 0x7FFFFFFF, NEF_E_SHAPE);
     NEF_REQUIRE(!slots || (nslot > 0 && (int64_t)Bp * nslot <= 0x7FFFFFFF), NEF_E_SHAPE);
@@ -1817,11 +1896,26 @@ int nef_bn_relu_bwd_combine3(const float* gy, const float* x, const float* mean,
                            gbeta, 3, Bp, C, L, BN_SPLIT);
     }
     hipLaunchKernelGGL(bn_bwd_apply_combine3, dim3((unsigned)(Bp * C)), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b,
-                       (const float*)coef, gP2, rowsum, Bp, C, L);
+                       (const float*)coef, gP2, rowsum, Bp, C, L, deint);
     if (gx_chan_sum)
         hipLaunchKernelGGL(rowsum_to_channel, dim3(C), dim3(256), 0, NEF_ST, (const double*)rowsum, gx_chan_sum, 3 * Bp,
                            C);
     return nef_launch_status();
+}
+
+int nef_bn_relu_bwd_combine3(const float* gy, const float* x, const float* mean, const float* invstd, const float* a,
+                             const float* b, float* gP2, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
+                             size_t ws_bytes, int Bp, int C, int L, const float* slots, int nslot, nef_stream_t stream) {
+    return bn_relu_bwd_combine3_impl(gy, x, mean, invstd, a, b, gP2, ggamma, gbeta, gx_chan_sum, ws, ws_bytes, Bp, C, L, slots, nslot, 0,
+                                     stream);
+}
+
+int nef_bn_relu_bwd_combine3_phase_major(const float* gy, const float* x, const float* mean, const float* invstd, const float* a,
+                                         const float* b, float* gP2, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
+                                         size_t ws_bytes, int Bp, int C, int L, const float* slots, int nslot,
+                                         nef_stream_t stream) {
+    return bn_relu_bwd_combine3_impl(gy, x, mean, invstd, a, b, gP2, ggamma, gbeta, gx_chan_sum, ws, ws_bytes, Bp, C, L, slots, nslot, 1,
+                                     stream);
 }
 
 size_t nef_bn_bwd_outconv_ws_bytes(int P, int Bp, int C, int L) {
@@ -1960,27 +2054,37 @@ int nef_poly_weights(const float* w, float* wsyn, int rows, int Cig, int tile_Cr
     return nef_launch_status();
 }
 
+int nef_poly_wgrad_fold(const float* gw2, const float* gy_pm, const float* xedge, float* gw, int B, int G, int Cog, int Cig, int T,
+                        nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(gw2 && gy_pm && xedge && gw, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && G > 0 && Cog > 0 && Cig > 0 && Cig <= 512 && T >= 4 && T % 2 == 0, NEF_E_SHAPE);
+    hipLaunchKernelGGL(poly_wgrad_fold_kernel, dim3((unsigned)(G * Cog)), dim3(256), 0, NEF_ST, gw2, gy_pm, xedge, gw, B, G, Cog, Cig,
+                       T / 2);
+    return nef_launch_status();
+}
+
 int nef_poly_fwd_edge(const float* x, const float* w, float* y, int B, int G, int Cr, int Cig, int T, const float* pro_a,
-                      const float* pro_b, int pro_Bp, float* stats, int nslot, nef_stream_t stream) {
+                      const float* pro_b, int pro_Bp, float* stats, int nslot, float* xedge, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(x && w && y, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && G > 0 && Cr > 0 && Cig > 0 && Cig <= 4096 && T >= 4 && T % 2 == 0, NEF_E_SHAPE);
     NEF_REQUIRE((!pro_a && !pro_b) || (pro_a && pro_b && pro_Bp > 0), NEF_E_NULL);
     NEF_REQUIRE(!stats || nslot > 0, NEF_E_SHAPE);
     hipLaunchKernelGGL(poly_fwd_edge_kernel, dim3((unsigned)(B * G)), dim3(256), (size_t)2 * Cig * sizeof(float), NEF_ST, x, w, y, B, G, Cr,
-                       Cig, T, pro_a, pro_b, pro_Bp, stats, nslot);
+                       Cig, T, pro_a, pro_b, pro_Bp, stats, nslot, xedge);
     return nef_launch_status();
 }
 
 int nef_poly_bwd_edge(const float* gy, const float* w, float* gx, int B, int G, int Cog, int Cig, int T, const float* bnb_x,
                       const float* bnb_mean, const float* bnb_invstd, const float* bnb_a, const float* bnb_b, int bnb_Bp,
-                      float* bnb_slots, int nslot, nef_stream_t stream) {
+                      float* bnb_slots, int nslot, int gy_phase_major, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(gy && w && gx, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && G > 0 && Cog > 0 && Cig > 0 && T >= 4 && T % 2 == 0 && Cog <= 4096, NEF_E_SHAPE);
     NEF_REQUIRE(!bnb_slots || (bnb_x && bnb_mean && bnb_invstd && bnb_a && bnb_b && bnb_Bp > 0 && nslot > 0), NEF_E_NULL);
     hipLaunchKernelGGL(poly_bwd_edge_kernel, dim3((unsigned)(B * G)), dim3(256), (size_t)4 * Cog * sizeof(float), NEF_ST, gy, w, gx, B, G,
-                       Cog, Cig, T, bnb_x, bnb_mean, bnb_invstd, bnb_a, bnb_b, bnb_Bp, bnb_slots, nslot);
+                       Cog, Cig, T, bnb_x, bnb_mean, bnb_invstd, bnb_a, bnb_b, bnb_Bp, bnb_slots, nslot, gy_phase_major);
     return nef_launch_status();
 }
 

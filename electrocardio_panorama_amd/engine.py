@@ -242,14 +242,15 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
             pro = (mode, pro_in[0], pro_in[1], pro_in[2]) if pro_in is not None else (mode, None, None, 1)
             up_after = bool(mode & 2)
         T_out = x_in.shape[2] * (2 if up_after and pro[0] & 2 else 1)
-        stats = None
+        stats = xedge = None
         # the two convs behind a x2 upsampling run in polyphase form where the shape allows: a conv over the half-resolution input
         # whose rows are the two output phases (ops.conv_poly_fwd) -- half the staged elements, no interpolation arithmetic
         poly = bool(pro[0] & 2) and ops.poly_fwd_ok(2 if (li == 0 and shared_B is not None) else 1, cout,
                                                      x_in.shape[1] // (2 if (li == 0 and shared_B is not None) else 1), T_out)
         if li == 0 and shared_B is not None:
             if poly:
-                p2 = ops.conv_poly_fwd(GV.dense(x_in, 2), _regroup_halves(P[wname]), cout, pro=pro, site=P[wname].data_ptr())
+                p2 = ops.conv_poly_fwd(GV.dense(x_in, 2), _regroup_halves(P[wname]), cout, pro=pro, site=P[wname].data_ptr(), save_edge=save)
+                xedge = p2.nef_xedge
             else:
                 p2 = ops.conv(GV.dense(x_in, 2), ops.pack_weight(_regroup_halves(P[wname]), 2, T=T_out, f4=True, site=P[wname].data_ptr()), cout, 3, pro=pro)
             if training and passes == 3:      # the BatchNorm statistics of c1 come out of the same pass
@@ -260,9 +261,10 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
         elif poly:
             slots = None
             if training and _FUSE_STATS:
-                c, slots = ops.conv_poly_fwd(GV.dense(x_in, 1), P[wname], cout, bias=P[bname], pro=pro, stats=True)
+                c, slots = ops.conv_poly_fwd(GV.dense(x_in, 1), P[wname], cout, bias=P[bname], pro=pro, stats=True, save_edge=save)
             else:
-                c = ops.conv_poly_fwd(GV.dense(x_in, 1), P[wname], cout, bias=P[bname], pro=pro)
+                c = ops.conv_poly_fwd(GV.dense(x_in, 1), P[wname], cout, bias=P[bname], pro=pro, save_edge=save)
+            xedge = c.nef_xedge
             if slots is not None:
                 stats = ops.bn_stats_from_slots(slots, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
                                                 Bf[pre + ".running_var"], passes, N, T_out, BN_EPS, BN_MOM)
@@ -289,7 +291,7 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
             mean = invstd = None
             Bp = N
         if save:
-            saved.append((x_in, c, mean, invstd, a, b, pro, up_after))
+            saved.append((x_in, c, mean, invstd, a, b, pro, up_after, xedge))
         x, pro_in = c, (a, b, Bp)
     out = ops.outconv_fwd(x, P["decoder.4.weight"], P["decoder.4.bias"], pro=pro_in)
     return out, (saved, x, out, passes, pro_in, shared_B)
@@ -311,41 +313,58 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
     poly_first = False        # the first layer's backward-data pass already went through its upsampling
     for li in (3, 2, 1, 0):
         blk, cv, bn, cout = _DEC[li]
-        x, c, mean, invstd, a, b, pro, up_after = saved[li]
+        x, c, mean, invstd, a, b, pro, up_after = saved[li][:8]
+        xedge = saved[li][8] if len(saved[li]) > 8 else None
+        # polyphase backward of a conv behind the x2 upsampling (ops.conv_bwd_data_poly / conv_bwd_weight_poly): with the forward's
+        # row-end values at hand the BatchNorm-backward pass writes this conv's output gradient PHASE-MAJOR ([.., 2C, T/2]) and both
+        # backward convs run on that at half resolution; without them (forward not in polyphase form) only the backward-data pass does
+        sh0 = li == 0 and shared_B is not None
+        Cog_, Cig_ = c.shape[1], x.shape[1] // (2 if sh0 else 1)
+        poly_b = bool(up_after and pro[0] & 2 and (not sh0 or pro[0] == 2) and ops.poly_bwd_ok(2 if sh0 else 1, Cog_, Cig_, c.shape[2]))
+        pm = bool(poly_b and xedge is not None and ops.poly_w_ok((2 if sh0 else 1) * (shared_B if sh0 else c.shape[0]), 2 if sh0 else 1, Cog_, Cig_, c.shape[2]))
         wname, bname, pre = f"{blk}.double_conv.{cv}.weight", f"{blk}.double_conv.{cv}.bias", f"{blk}.double_conv.{bn}"
+        pm0_done = False
         if li == 3 and fuse_last:
             gc, gg, gbeta, gbias = ops.bn_relu_bwd_outconv(g_out, out, P["decoder.4.weight"], c, mean, invstd, a, b, passes)
         elif li == 0 and shared_B is not None and not g_is_up:
             # gc is the per-half gradient [2B, 2*128, 2T] straight away (pass_combine_bwd fused into the apply pass)
-            gc, gg, gbeta, gbias = ops.bn_relu_bwd_combine3(g, c, mean, invstd, a, b, slots=g_slots)
+            gc, gg, gbeta, gbias = ops.bn_relu_bwd_combine3(g, c, mean, invstd, a, b, slots=g_slots, phase_major=pm)
+            pm0_done = pm
         elif g_is_up:
             gc, gg, gbeta, gbias = ops.bn_relu_bwd_up(g, c, mean, invstd, a, b, passes, slots=g_slots)
         else:
             gc, gg, gbeta, gbias = ops.bn_relu_bwd(g, c, P[pre + ".weight"], mean, invstd, a, b, passes,
-                                                   with_chan_sum=True, slots=g_slots)
+                                                   with_chan_sum=True, slots=g_slots, phase_major=pm and not sh0)
+            pm0_done = pm and not sh0
         grads[pre + ".weight"], grads[pre + ".bias"], grads[bname] = gg, gbeta, gbias
+        pm = pm and pm0_done      # (the branches that did not write phase-major keep the interleaved forms)
         if li == 0 and shared_B is not None:
-            gp2 = gc if gc.shape[0] == 2 * shared_B else ops.pass_combine_bwd(gc)   # [2B, 2*128, 2T]
+            gp2 = gc if gc.shape[0] == 2 * shared_B else ops.pass_combine_bwd(gc)   # [2B, 2*128, 2T] (pm: [2B, 4*128, T])
             gpv, xv = GV.dense(gp2, 2), GV.dense(x, 2)
-            grads[wname] = side.run(lambda: _ungroup_halves(ops.conv_bwd_weight(xv, gpv, 3, pro=pro, site=P[wname].data_ptr())), x, gp2)
-            poly = bool(up_after and pro[0] == 2 and ops.poly_bwd_ok(2, gp2.shape[1] // 2, x.shape[1] // 2, gp2.shape[2]))
-            if poly:      # straight to the gradient wrt the half-resolution D (polyphase pass): nothing left for the consumer to fold
-                g = ops.conv_bwd_data_poly(gpv, _regroup_halves(P[wname]), x.shape[1] // 2, site=P[wname].data_ptr())
+            if pm:
+                grads[wname] = side.run(lambda: _ungroup_halves(ops.conv_bwd_weight_poly(xv, gp2, Cog_, pro, xedge, site=P[wname].data_ptr())), x, gp2, xedge)
+            else:
+                grads[wname] = side.run(lambda: _ungroup_halves(ops.conv_bwd_weight(xv, gpv, 3, pro=pro, site=P[wname].data_ptr())), x, gp2)
+            if poly_b:      # straight to the gradient wrt the half-resolution D (polyphase pass): nothing left for the consumer to fold
+                g = ops.conv_bwd_data_poly(gpv, _regroup_halves(P[wname]), x.shape[1] // 2, site=P[wname].data_ptr(), phase_major=pm)
                 poly_first = True
             else:
                 g = ops.conv(gpv, ops.pack_weight(_regroup_halves(P[wname]), 2, flip=True, T=gp2.shape[2], f4=True, site=P[wname].data_ptr()), x.shape[1] // 2, 3,
                              role="conv_bwd_data")
         else:
             gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
-            grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro, site=P[wname].data_ptr()), x, gc)
-            if up_after and pro[0] & 2 and ops.poly_bwd_ok(1, gc.shape[1], x.shape[1], gc.shape[2]):
+            if pm:
+                grads[wname] = side.run(lambda: ops.conv_bwd_weight_poly(xv, gc, Cog_, pro, xedge, site=P[wname].data_ptr()), x, gc, xedge)
+            else:
+                grads[wname] = side.run(lambda: ops.conv_bwd_weight(xv, gcv, 3, pro=pro, site=P[wname].data_ptr()), x, gc)
+            if poly_b:
                 # x2 upsampling in front of this conv: the polyphase pass leaves the gradient wrt the half-resolution input (= what the
                 # BatchNorm below produced) directly, with that BatchNorm's backward sums in its epilogue
                 bnb = None
                 if li > 0 and _FUSE_STATS and saved[li - 1][2] is not None:
                     cb, mb, ib, ab, bb = saved[li - 1][1:6]
                     bnb = (cb, mb, ib, ab, bb, cb.shape[0] // passes)
-                g = ops.conv_bwd_data_poly(gcv, P[wname], x.shape[1], bnb=bnb)
+                g = ops.conv_bwd_data_poly(gcv, P[wname], x.shape[1], bnb=bnb, phase_major=pm)
                 g_slots = g.nef_slots
                 g_is_up = False
                 if li == 0:

@@ -513,7 +513,7 @@ def bn_stats_from_slots(stats, gamma, beta, running_mean, running_var, P, N, Ln,
 
 def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None, gate_scale=1.0, relu=False,
          mask=None, drop_p=0.0, drop_scale=1.0, seed=0, role="conv_fwd", pro=None, seed_dev=None, stats=None, bnb=None,
-         x_scale=0.0):
+         x_scale=0.0, tag_extra=""):
     """out = epilogue(conv1d(prologue(x) * in_scale, w) + bias + res).  `xv`, `res`, `gate`, `out` are GV views;
     `in_scale` is (tensor, batch_stride, group_stride).  `pro` = (mode, a, b, Bp): input prologue applied while
     staging -- bit0 BatchNorm affine + ReLU with a/b [P, C_in], bit1 x2 linear upsampling of a half-resolution input
@@ -579,7 +579,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     # bench.py prices a launch by its tag; the optional 8th element says which operands are NOT at the output's resolution / are extra:
     # "up" = the input is the half-resolution tensor (x2-upsampling prologue), "bnb" / "bnbup" = the epilogue also reads the
     # BatchNorm input of the layer below (full / half resolution) for the backward sums
-    extra = ("up" if (pro is not None and pro[0] & 2) else "") + ("ph" if (pro is not None and pro[0] == 4) else "") + ("pf" if (pro is not None and pro[0] & 8) else "") + ("bnb" + ("up" if len(bnb) > 7 and bnb[7] else "") if bnb is not None else "")
+    extra = ("up" if (pro is not None and pro[0] & 2) else "") + ("ph" if (pro is not None and pro[0] == 4) else "") + ("pf" if (pro is not None and pro[0] & 8) else "") + tag_extra + ("bnb" + ("up" if len(bnb) > 7 and bnb[7] else "") if bnb is not None else "")
     tag = (role, K, xv.G, xv.Cg, Cog, xv.B, T_out) + ((extra,) if extra else ())
     ev = _timed(tag)
     if ev is not None:
@@ -594,6 +594,7 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
 # ------------------------------------------------------------------ polyphase form of conv1d(upsample2(x)), K = 3
 POLY = _env.get("NEF_POLY", "1") == "1"
 _POLY_FWD = _env.get("NEF_POLY_FWD", "1") == "1"
+_POLY_W = _env.get("NEF_POLY_W", "1") == "1"
 
 
 def poly_weights(w, tile_Cr=0):
@@ -614,7 +615,7 @@ def poly_fwd_ok(G, Cog, Cig, T):
             _H2_DIR[False] and "3" in _H2_K and _h2_fills(G, 2 * Cog, Th, 256, 128))
 
 
-def conv_poly_fwd(xv, w, Cog, bias=None, pro=None, stats=False, site=None):
+def conv_poly_fwd(xv, w, Cog, bias=None, pro=None, stats=False, site=None, save_edge=False):
     """y [B, G*Cog, 2T] = conv1d(upsample2(prologue(x)), w) + bias in polyphase form: one split-fp16 conv over the half-resolution
     x (`xv`, a GV) whose rows are the two phases of each channel (conv args pro_mode 8 | affine bit), written interleaved, + the two
     row-end columns (nef_poly_fwd_edge).  `pro` = (mode, a, b, Bp) as conv() gets it for this layer (bit1 = the upsampling itself,
@@ -635,9 +636,11 @@ def conv_poly_fwd(xv, w, Cog, bias=None, pro=None, stats=False, site=None):
     conv(xv, wp, 2 * Cog, 3, out=out, bias=bias, pro=(8 | int(aff), pro[1] if aff else None, pro[2] if aff else None, pro[3] if aff else 1),
          stats=slots)
     pa, pb, pbp = (_p(pro[1]), _p(pro[2]), pro[3]) if aff else (None, None, 1)
+    xedge = torch.empty(xv.B, G * Cig, 2, device=xv.t.device, dtype=torch.float32) if save_edge else None
     _lib.check(L.nef_poly_fwd_edge(xv.ptr, _p(w), _p(y), xv.B, G, Cog, Cig, 2 * Th, pa, pb, pbp,
-                                   _p(slots[0]) if slots is not None else None, slots[1] if slots is not None else 0, _stream()),
-               "nef_poly_fwd_edge")
+                                   _p(slots[0]) if slots is not None else None, slots[1] if slots is not None else 0, _p(xedge),
+                                   _stream()), "nef_poly_fwd_edge")
+    y.nef_xedge = xedge      # (the prologue's output at both row ends: what the polyphase weight gradient's row-end terms need)
     return (y, slots) if stats else y
 
 
@@ -649,14 +652,17 @@ def poly_bwd_ok(G, Cog, Cig, T):
             _H2_DIR[True] and "3" in _H2_K and _h2_fills(G, Cig, Th, 256, 128 if Cig % 128 == 0 else 64))
 
 
-def conv_bwd_data_poly(gyv, w, Cig, bnb=None, site=None):
+def conv_bwd_data_poly(gyv, w, Cig, bnb=None, site=None, phase_major=False):
     """Gradient wrt the HALF-resolution input x of y = conv1d(upsample2(x), w) (K = 3, zero padding 1), from gy [B, G*Cog, T]
     (`gyv`, a GV): one split-fp16 conv at half resolution over the 2 Cog phase channels of gy (conv args pro_mode 4) + the row-end
     terms (nef_poly_bwd_edge) -- the full-resolution gradient wrt upsample2(x) is never formed.  `w` [G*Cog, Cig, 3] is the conv's
     own weight; `bnb` as in conv() (plain form: its x at the half resolution).  Reference semantics: autograd through
     codes/network/model_nefnet.py:102-105.  Summation order differs from conv + upsample2_bwd (fp32-class either way)."""
     L = _lib.load()
-    G, Cog, T = gyv.G, gyv.Cg, gyv.T
+    if phase_major:      # `gyv`: the gradient as [B, G * 2 Cog, T/2] (bn_relu_bwd(..., phase_major=True)): a plain conv over it
+        G, Cog, T = gyv.G, gyv.Cg // 2, 2 * gyv.T
+    else:
+        G, Cog, T = gyv.G, gyv.Cg, gyv.T
     Th = T // 2
     assert w.shape == (G * Cog, Cig, 3) and gyv.gs == Cog * T, "conv_bwd_data_poly: dense gradient rows"
     ws = poly_weights(w)
@@ -667,13 +673,37 @@ def conv_bwd_data_poly(gyv, w, Cig, bnb=None, site=None):
     if bnb is not None and len(bnb) == 6:      # (x, mean, invstd, a, b, Bp): the slot buffer is made here (returned as g.nef_slots)
         slots = conv_stats_buffer(wp, gyv.B, G, Cig, Th, gyv.t.device)
         bnb = None if slots is None else (*bnb, slots)
-    g = conv(xv, wp, Cig, 3, role="conv_bwd_data", bnb=bnb, pro=(4, None, None, 1))
+    g = conv(xv, wp, Cig, 3, role="conv_bwd_data", bnb=bnb, pro=None if phase_major else (4, None, None, 1),
+             tag_extra="pm" if phase_major else "")      # (bench.py: "pm" = plain conv over the phase-major gradient)
     g.nef_slots = bnb[6] if bnb is not None else None
     ba = [None] * 5 + [1, None, 0]
     if bnb is not None:
         ba = [_p(t) for t in bnb[:5]] + [bnb[5], _p(bnb[6][0]), bnb[6][1]]
-    _lib.check(L.nef_poly_bwd_edge(gyv.ptr, _p(w), _p(g), gyv.B, G, Cog, Cig, T, *ba, _stream()), "nef_poly_bwd_edge")
+    _lib.check(L.nef_poly_bwd_edge(gyv.ptr, _p(w), _p(g), gyv.B, G, Cog, Cig, T, *ba, int(phase_major), _stream()), "nef_poly_bwd_edge")
     return g
+
+
+def poly_w_ok(B, G, Cog, Cig, T):
+    """Weight gradient of conv1d(upsample2(x), w) in polyphase form: a split-fp16 weight gradient over the half-resolution x and
+    the phase-major gradient (2 Cog rows), producer / consumer form (2 Cog % 128 == 0), then nef_poly_wgrad_fold."""
+    Th = T // 2
+    return (POLY and _POLY_W and T % 4 == 0 and Cog % 64 == 0 and Cig <= 512 and h2w_ok(3, Cig, 2 * Cog, Th, 1) and
+            (BATCH_HINT is None or B * ((Th + 63) // 64) >= 8 * _H2_MIN_WGS))
+
+
+def conv_bwd_weight_poly(xv, gy_pm, Cog, pro, xedge, site=None):
+    """gw [G*Cog, Cig, 3] of y = conv1d(upsample2(prologue(x)), w) from the half-resolution x (`xv`), the PHASE-MAJOR gradient
+    gy_pm [B, G*2Cog, T/2] and `xedge` [B, G*Cig, 2] (the prologue's output at both row ends, conv_poly_fwd(..., save_edge=True)).
+    `pro` as the forward got it (bit0 = affine + ReLU prologue; the upsampling bit is what the polyphase form replaces)."""
+    L = _lib.load()
+    G, Cig = xv.G, xv.Cg
+    aff = pro is not None and bool(pro[0] & 1)
+    gyv = GV.dense(gy_pm, G)
+    gw2 = conv_bwd_weight(xv, gyv, 3, pro=(4 | int(aff), pro[1] if aff else None, pro[2] if aff else None, pro[3] if aff else 1),
+                          site=site, h2=True)
+    gw = torch.empty(G * Cog, Cig, 3, device=gy_pm.device, dtype=torch.float32)
+    _lib.check(L.nef_poly_wgrad_fold(_p(gw2), _p(gy_pm), _p(xedge), _p(gw), xv.B, G, Cog, Cig, 2 * xv.T, _stream()), "nef_poly_wgrad_fold")
+    return gw
 
 
 def h2w_ok(K, Cig, Cog, T, pro_mode=0, in_scale=False):
@@ -708,7 +738,7 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None, site=None, h
                                                 _p(gw), _p(ws), n, B, T, G, Cig, Cog, K, float(x_scale), float(gy_scale),
                                                 amax, None if amax is None else amax + 4, nxt, None if nxt is None else nxt + 4,
                                                 clamped, _stream()), "nef_conv_bwd_weight_h2")
-        tag = ("conv_bwd_weight", K, G, Cig, Cog, B, T) + (("up",) if pm0 & 2 else ())
+        tag = ("conv_bwd_weight", K, G, Cig, Cog, B, T) + (("up",) if pm0 & 2 else (("pw",) if pm0 & 4 else ()))
         ev = _timed(tag)
         if ev is not None:
             EXEC_FRAC[tag] = 0.0
@@ -1227,42 +1257,46 @@ def affine_relu_fwd(x, a, b, P):
     return y
 
 
-def bn_relu_bwd(gy, x, gamma, mean, invstd, a, b, P, with_chan_sum=False, slots=None):
+def bn_relu_bwd(gy, x, gamma, mean, invstd, a, b, P, with_chan_sum=False, slots=None, phase_major=False):
     """Returns (gx, ggamma, gbeta[, sum_{b,t} gx per channel]).  `slots`: the conv_stats_buffer() the conv that produced
-    `gy` filled (conv(..., bnb=...)) -- the reduction pass over (gy, x) is then skipped."""
+    `gy` filled (conv(..., bnb=...)) -- the reduction pass over (gy, x) is then skipped.  `phase_major`: gx comes back as
+    [N, 2C, L/2], row 2c + p = positions p, p + 2, ... of channel c (the operand of the polyphase backward passes)."""
     L = _lib.load()
     _chk(gy), _chk(x)
     N, Ct, Ln = x.shape
-    gx = torch.empty_like(x)
+    gx = torch.empty(N, 2 * Ct, Ln // 2, device=x.device, dtype=torch.float32) if phase_major else torch.empty_like(x)
     gg = torch.empty(Ct, device=x.device, dtype=torch.float32)
     gb = torch.empty(Ct, device=x.device, dtype=torch.float32)
     gs = torch.empty(Ct, device=x.device, dtype=torch.float32) if with_chan_sum else None
     n = L.nef_bn_bwd_ws_bytes(P, N // P, Ct)
     ws = workspace(n, x.device)
     ev = _hbm("bn_relu_bwd", gy, x, gx)
-    _lib.check(L.nef_bn_relu_bwd(_p(gy), _p(x), _p(gamma), _p(mean), _p(invstd), _p(a), _p(b), _p(gx), _p(gg), _p(gb),
-                                 _p(gs), _p(ws), n, P, N // P, Ct, Ln, _p(slots[0]) if slots else None,
-                                 slots[1] if slots else 0, _stream()), "nef_bn_relu_bwd")
+    fn = L.nef_bn_relu_bwd_phase_major if phase_major else L.nef_bn_relu_bwd
+    _lib.check(fn(_p(gy), _p(x), _p(gamma), _p(mean), _p(invstd), _p(a), _p(b), _p(gx), _p(gg), _p(gb),
+                  _p(gs), _p(ws), n, P, N // P, Ct, Ln, _p(slots[0]) if slots else None,
+                  slots[1] if slots else 0, _stream()), "nef_bn_relu_bwd")
     _done(ev)
     return (gx, gg, gb, gs) if with_chan_sum else (gx, gg, gb)
 
 
-def bn_relu_bwd_combine3(gy, x, mean, invstd, a, b, slots=None):
-    """pass_combine_bwd(bn_relu_bwd(gy, x, ..., P=3)) in one pass: returns (gP2 [2B,2C,L], ggamma, gbeta, chan sum of gx)."""
+def bn_relu_bwd_combine3(gy, x, mean, invstd, a, b, slots=None, phase_major=False):
+    """pass_combine_bwd(bn_relu_bwd(gy, x, ..., P=3)) in one pass: returns (gP2 [2B,2C,L], ggamma, gbeta, chan sum of gx);
+    `phase_major`: gP2 as [2B, 4C, L/2] (see bn_relu_bwd)."""
     L = _lib.load()
     _chk(gy), _chk(x)
     N, Ct, Ln = x.shape
     Bp = N // 3
-    gP2 = torch.empty(2 * Bp, 2 * Ct, Ln, device=x.device, dtype=torch.float32)
+    gP2 = torch.empty((2 * Bp, 4 * Ct, Ln // 2) if phase_major else (2 * Bp, 2 * Ct, Ln), device=x.device, dtype=torch.float32)
     gg = torch.empty(Ct, device=x.device, dtype=torch.float32)
     gb = torch.empty(Ct, device=x.device, dtype=torch.float32)
     gs = torch.empty(Ct, device=x.device, dtype=torch.float32)
     n = L.nef_bn_bwd_ws_bytes(3, Bp, Ct)
     ws = workspace(n, x.device)
     ev = _hbm("bn_relu_bwd_combine3", gy, x, gP2)
-    _lib.check(L.nef_bn_relu_bwd_combine3(_p(gy), _p(x), _p(mean), _p(invstd), _p(a), _p(b), _p(gP2), _p(gg), _p(gb),
-                                          _p(gs), _p(ws), n, Bp, Ct, Ln, _p(slots[0]) if slots else None,
-                                          slots[1] if slots else 0, _stream()), "nef_bn_relu_bwd_combine3")
+    fn = L.nef_bn_relu_bwd_combine3_phase_major if phase_major else L.nef_bn_relu_bwd_combine3
+    _lib.check(fn(_p(gy), _p(x), _p(mean), _p(invstd), _p(a), _p(b), _p(gP2), _p(gg), _p(gb),
+                  _p(gs), _p(ws), n, Bp, Ct, Ln, _p(slots[0]) if slots else None,
+                  slots[1] if slots else 0, _stream()), "nef_bn_relu_bwd_combine3")
     _done(ev)
     return gP2, gg, gb, gs
 

@@ -484,11 +484,30 @@ int nef_poly_weights(const float* w, float* wsyn, int rows, int Cig, int tile_Cr
  * nef_poly_fwd_edge corrects the first and the last output column (and slot 0 of the statistics) for the conv's zero padding. */
 int nef_poly_fwd_edge(const float* x, const float* w, float* y, int B, int G, int Cr /* output channels per group */, int Cig,
                       int T /* length of y = 2 x length of x */, const float* pro_a, const float* pro_b, int pro_Bp, float* stats,
-                      int nslot, nef_stream_t stream);
+                      int nslot, float* xedge /* NULL, or [B][G Cig][2]: the prologue's output at positions 0 and T/2 - 1 */,
+                      nef_stream_t stream);
 int nef_poly_bwd_edge(const float* gy, const float* w /* [G Cog][Cig][3], the conv's own weight */, float* gx, int B, int G, int Cog,
                       int Cig, int T /* length of gy = 2 x length of gx */, const float* bnb_x, const float* bnb_mean,
                       const float* bnb_invstd, const float* bnb_a, const float* bnb_b, int bnb_Bp, float* bnb_slots, int nslot,
-                      nef_stream_t stream);
+                      int gy_phase_major /* gy stored [B][G 2 Cog][T / 2] (nef_bn_relu_bwd_phase_major) */, nef_stream_t stream);
+/* PHASE-MAJOR gradients: nef_bn_relu_bwd_phase_major / nef_bn_relu_bwd_combine3_phase_major are nef_bn_relu_bwd /
+ * nef_bn_relu_bwd_combine3 writing row r of their output as the two half-length rows 2 r (even positions) and 2 r + 1 (odd
+ * positions) of a [.., 2 C, L / 2] tensor (L % 4 == 0 resp. L % 2 == 0).  That is the operand the polyphase backward passes of the
+ * conv behind the upsampling want: backward-data = a PLAIN nef_conv_fwd over it (weights nef_poly_weights, transposed / flipped)
+ * + nef_poly_bwd_edge(gy_phase_major = 1); weight gradient = nef_conv_bwd_weight_h2 with pro_mode 4 (| 1: affine prologue; bit 2 =
+ * the half-resolution x window is continued with x[0] / x[T-1] at the row ends) giving gw2 [G 2 Cog][Cig][3], then
+ * nef_poly_wgrad_fold: gw2 folded back onto the conv's own taps minus the row-end terms (xedge [B][G Cig][2] = the prologue's
+ * output at the first / last position, written by nef_poly_fwd_edge). */
+int nef_bn_relu_bwd_phase_major(const float* gy, const float* x, const float* gamma, const float* mean, const float* invstd,
+                                const float* a, const float* b, float* gx, float* ggamma, float* gbeta, float* gx_chan_sum,
+                                void* ws, size_t ws_bytes, int P, int Bp, int C, int L, const float* slots, int nslot,
+                                nef_stream_t stream);
+int nef_bn_relu_bwd_combine3_phase_major(const float* gy, const float* x, const float* mean, const float* invstd, const float* a,
+                                         const float* b, float* gP2, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
+                                         size_t ws_bytes, int Bp, int C, int L, const float* slots, int nslot,
+                                         nef_stream_t stream);
+int nef_poly_wgrad_fold(const float* gw2, const float* gy_pm, const float* xedge, float* gw, int B, int G, int Cog, int Cig,
+                        int T /* full-resolution length = 2 x the rows of gy_pm */, nef_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Test-phase metrics on the device.  Replaces PSNR / SSIM of codes/utils/mertic.py:7-32 as called from

@@ -675,6 +675,53 @@ def test_conv_fwd_polyphase_behind_upsampling(B, G, Cog, Cig, T, aff):
         assert rel(ssum[:, 1], (got.double() ** 2).sum((0, 2))) < 1e-6
 
 
+@pytest.mark.parametrize("B,G,Cog,Cig,T,aff", [(6, 1, 64, 128, 1000, True), (6, 2, 128, 128, 512, False), (3, 1, 128, 64, 776, True),
+                                                (3, 1, 64, 64, 520, False)])
+def test_polyphase_backward_on_phase_major_gradients(B, G, Cog, Cig, T, aff):
+    """The whole backward of y = conv1d(upsample2(relu(bn(x))), w) at half resolution: the BatchNorm-backward pass above writes
+    the gradient phase-major (ops.bn_relu_bwd(phase_major=True): [.., 2C, T/2]), the backward-data pass is a plain conv over it +
+    row-end terms, the weight gradient a split-fp16 weight gradient over (half-resolution x with clamped ends, phase rows) folded
+    back onto the three taps (nef_poly_wgrad_fold) -- against fp64 autograd through the reference's ops
+    (codes/network/model_nefnet.py:102-105) and against the interleaved forms."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    if not (o.poly_fwd_ok(G, Cog, Cig, T) and o.poly_bwd_ok(G, Cog, Cig, T) and o.poly_w_ok(B, G, Cog, Cig, T)):
+        pytest.skip("polyphase forms switched off / shape outside the split-fp16 kernels")
+    x = g(rnd(B, G * Cig, T // 2, seed=1220))
+    w = g(rnd(G * Cog, Cig, 3, seed=1221, scale=0.05))
+    pa, pb = g(rnd(3, G * Cig, seed=1222) + 1.0), g(rnd(3, G * Cig, seed=1223, scale=0.3))
+    pro = (3, pa, pb, B // 3) if aff else (2, None, None, 1)
+    # the gradient at the conv output comes out of a BatchNorm-backward pass: run it in both layouts
+    gy_in, cc = g(rnd(B, G * Cog, T, seed=1224)), g(rnd(B, G * Cog, T, seed=1225))
+    gamma, beta = g(rnd(G * Cog, seed=1226) + 1.2), g(rnd(G * Cog, seed=1227, scale=0.3))
+    mean, invstd, a_, b_ = o.bn_train_stats(cc, gamma, beta, torch.zeros(G * Cog, device=DEV), torch.ones(G * Cog, device=DEV), 3)
+    gy = o.bn_relu_bwd(gy_in, cc, gamma, mean, invstd, a_, b_, 3)[0]
+    gy_pm = o.bn_relu_bwd(gy_in, cc, gamma, mean, invstd, a_, b_, 3, phase_major=True)[0]
+    assert gy_pm.shape == (B, 2 * G * Cog, T // 2)
+    assert torch.equal(gy_pm.view(B, G * Cog, 2, T // 2).permute(0, 1, 3, 2).reshape(B, G * Cog, T), gy)
+    # fp64 truth
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    xp = x64
+    if aff:
+        xp = torch.relu(x64 * pa.double().repeat_interleave(B // 3, 0)[:, :, None] + pb.double().repeat_interleave(B // 3, 0)[:, :, None])
+    xp.retain_grad()
+    u = torch.nn.functional.interpolate(xp, scale_factor=2, mode="linear", align_corners=False)
+    torch.nn.functional.conv1d(u, w64, padding=1, groups=G).backward(gy.double())
+    y = o.conv_poly_fwd(GV.dense(x, G), w, Cog, pro=pro, save_edge=True)
+    gx = o.conv_bwd_data_poly(GV.dense(gy_pm, G), w, Cig, phase_major=True)
+    gx_il = o.conv_bwd_data_poly(GV.dense(gy, G), w, Cig)
+    gw = o.conv_bwd_weight_poly(GV.dense(x, G), gy_pm, Cog, pro, y.nef_xedge)
+    gw_up = o.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), 3, pro=pro)
+    e_gx, e_il = rel(gx.double(), xp.grad), rel(gx_il.double(), xp.grad)
+    e_gw, e_up = rel(gw.double(), w64.grad), rel(gw_up.double(), w64.grad)
+    print(f"polyphase backward B={B} G={G} {Cig}->{Cog} T={T} aff={aff}: vs fp64 gx {e_gx:.2e} (interleaved input {e_il:.2e}), "
+          f"gw {e_gw:.2e} (upsampling-prologue form {e_up:.2e})")
+    assert e_gx < max(2.0 * e_il, 1e-6) and e_gw < max(2.0 * e_up, 1e-6)
+    for k in range(3):
+        assert rel(gw[:, :, k].double(), w64.grad[:, :, k]) < max(2.0 * rel(gw_up[:, :, k].double(), w64.grad[:, :, k]), 1e-6)
+
+
 @pytest.mark.parametrize("B,G,Cog,Cig,T", [(6, 1, 64, 128, 1000), (3, 1, 64, 128, 520), (6, 2, 128, 128, 512), (3, 1, 128, 64, 776)])
 def test_conv_bwd_data_polyphase_through_upsampling(B, G, Cog, Cig, T):
     """Backward-data through conv1d(upsample2(x), w) at HALF resolution (ops.conv_bwd_data_poly: phase-stacked input, pro_mode 4,
