@@ -134,7 +134,8 @@ SIGNATURES = {
     "nef_h2_taint": (i32, [p, p, p, p]),
     "nef_poly_weights": (i32, [p, p, i32, i32, i32, p]),
     "nef_poly_fwd_edge": (i32, [p, p, p, i32, i32, i32, i32, i32, p, p, i32, p, i32, p, p]),
-    "nef_poly_wgrad_fold": (i32, [p, p, p, p, i32, i32, i32, i32, i32, p]),
+    "nef_poly_wgrad_fold_ws_bytes": (sz, [i32, i32, i32, i32]),
+    "nef_poly_wgrad_fold": (i32, [p, p, p, p, p, sz, i32, i32, i32, i32, i32, p]),
     "nef_poly_bwd_edge": (i32, [p, p, p, i32, i32, i32, i32, i32, p, p, p, p, p, i32, p, i32, i32, p]),
     "nef_view_metrics": (i32, [p, p, p, p, p, i32, i32, i32, p]),
     "nef_pano_h_from_f32": (i32, [p, p, i32, i32, i32, p]),

@@ -1274,49 +1274,49 @@ __global__ __launch_bounds__(256) void poly_fwd_edge_kernel(const float* __restr
 // Weight gradient of the polyphase form: gw2 [R 2][Cig][3] = the gradients of the phase weights (row 2 r + p), folded back through
 // W'_p(w) -- the transpose of poly_weights_kernel's 6 x 3 map -- minus the two row-end terms of the forward correction:
 //     gw[r][ci][0] -= sum_b gy[b][r][0] x'[b][ci][0]        gw[r][ci][2] -= sum_b gy[b][r][T-1] x'[b][ci][Tin-1]
-// gy phase-major [B][G 2 Cog][Tin], xedge [B][G Cig][2] (nef_poly_fwd_edge).  One workgroup per output row r = g Cog + co.
-__global__ __launch_bounds__(256) void poly_wgrad_fold_kernel(const float* __restrict__ gw2, const float* __restrict__ gy,
-                                                              const float* __restrict__ xedge, float* __restrict__ gw, int B, int G,
-                                                              int Cog, int Cig, int Tin) {
-    constexpr int BC = 2048;
-    __shared__ float ge[2][BC];
+// gy phase-major [B][G 2 Cog][Tin], xedge [B][G Cig][2] (nef_poly_fwd_edge).  Two launches: the row-end sums per (row r = g Cog + co,
+// chunk of POLY_BC samples) -> part [chunks][R][Cig][2] (fixed order, no atomics), then the fold, one workgroup per row.
+constexpr int POLY_BC = 64;
+__global__ __launch_bounds__(256) void poly_wgrad_edge_partial(const float* __restrict__ gy, const float* __restrict__ xedge,
+                                                               float* __restrict__ part, int B, int G, int Cog, int Cig, int Tin) {
+    __shared__ float ge[2][POLY_BC];
     const int r = blockIdx.x, g = r / Cog, co = r - g * Cog;
-    float e0[2] = {0.f, 0.f}, el[2] = {0.f, 0.f};      // up to 512 input channels per group: two per thread
-    for (int b0 = 0; b0 < B; b0 += BC) {
-        const int nb = B - b0 < BC ? B - b0 : BC;
-        __syncthreads();
-        for (int i = threadIdx.x; i < 2 * nb; i += 256) {
-            const int b = b0 + (i >> 1), p = i & 1;
-            ge[p][i >> 1] = gy[(((int64_t)b * G + g) * 2 * Cog + 2 * co + p) * Tin + (p ? Tin - 1 : 0)];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int ci = threadIdx.x + 256 * u;
-            if (ci < Cig) {
-                const float* xe = xedge + (((int64_t)b0 * G + g) * Cig + ci) * 2;
-                float s0 = 0.f, s1 = 0.f;
-                for (int b = 0; b < nb; ++b, xe += (int64_t)G * Cig * 2) {
-                    const nef_f32x2 xv = *(const nef_f32x2*)xe;
-                    s0 = fmaf(ge[0][b], xv[0], s0);
-                    s1 = fmaf(ge[1][b], xv[1], s1);
-                }
-                e0[u] += s0, el[u] += s1;
-            }
-        }
+    const int b0 = blockIdx.y * POLY_BC;
+    const int nb = B - b0 < POLY_BC ? B - b0 : POLY_BC;
+    if (threadIdx.x < 2 * POLY_BC) {
+        const int i = threadIdx.x >> 1, p = threadIdx.x & 1;
+        ge[p][i] = i < nb ? gy[(((int64_t)(b0 + i) * G + g) * 2 * Cog + 2 * co + p) * Tin + (p ? Tin - 1 : 0)] : 0.f;
     }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int ci = threadIdx.x + 256 * u;
-        if (ci < Cig) {
-            const float* A = gw2 + ((int64_t)(2 * r) * Cig + ci) * 3;
-            const float* Bq = gw2 + ((int64_t)(2 * r + 1) * Cig + ci) * 3;
-            const float a0 = A[0], a1 = A[1], a2 = A[2], b0_ = Bq[0], b1 = Bq[1], b2 = Bq[2];
-            float* o = gw + ((int64_t)r * Cig + ci) * 3;
-            o[0] = fmaf(0.75f, a0 + b1, 0.25f * (a1 + b0_)) - e0[u];
-            o[1] = fmaf(0.75f, a1 + b1, 0.25f * (a0 + b2));
-            o[2] = fmaf(0.75f, a1 + b2, 0.25f * (a2 + b1)) - el[u];
+    __syncthreads();
+    for (int ci = threadIdx.x; ci < Cig; ci += 256) {
+        const float* xe = xedge + (((int64_t)b0 * G + g) * Cig + ci) * 2;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+        for (int b = 0; b < nb; ++b) {
+            const nef_f32x2 xv = *(const nef_f32x2*)(xe + (int64_t)b * G * Cig * 2);
+            s0 = fmaf(ge[0][b], xv[0], s0);
+            s1 = fmaf(ge[1][b], xv[1], s1);
         }
+        *(nef_f32x2*)(part + (((int64_t)blockIdx.y * gridDim.x + r) * Cig + ci) * 2) = nef_f32x2{s0, s1};
+    }
+}
+
+__global__ __launch_bounds__(256) void poly_wgrad_fold_kernel(const float* __restrict__ gw2, const float* __restrict__ part,
+                                                              float* __restrict__ gw, int R, int Cig, int chunks) {
+    const int r = blockIdx.x;
+    for (int ci = threadIdx.x; ci < Cig; ci += 256) {
+        float e0 = 0.f, el = 0.f;
+        for (int c = 0; c < chunks; ++c) {
+            const nef_f32x2 v = *(const nef_f32x2*)(part + (((int64_t)c * R + r) * Cig + ci) * 2);
+            e0 += v[0], el += v[1];
+        }
+        const float* A = gw2 + ((int64_t)(2 * r) * Cig + ci) * 3;
+        const float* Bq = gw2 + ((int64_t)(2 * r + 1) * Cig + ci) * 3;
+        const float a0 = A[0], a1 = A[1], a2 = A[2], b0_ = Bq[0], b1 = Bq[1], b2 = Bq[2];
+        float* o = gw + ((int64_t)r * Cig + ci) * 3;
+        o[0] = fmaf(0.75f, a0 + b1, 0.25f * (a1 + b0_)) - e0;
+        o[1] = fmaf(0.75f, a1 + b1, 0.25f * (a0 + b2));
+        o[2] = fmaf(0.75f, a1 + b2, 0.25f * (a2 + b1)) - el;
     }
 }
 
@@ -2054,13 +2054,22 @@ int nef_poly_weights(const float* w, float* wsyn, int rows, int Cig, int tile_Cr
     return nef_launch_status();
 }
 
-int nef_poly_wgrad_fold(const float* gw2, const float* gy_pm, const float* xedge, float* gw, int B, int G, int Cog, int Cig, int T,
-                        nef_stream_t stream) {
+size_t nef_poly_wgrad_fold_ws_bytes(int B, int G, int Cog, int Cig) {
+    return (size_t)((B + POLY_BC - 1) / POLY_BC) * G * Cog * Cig * 2 * sizeof(float);
+}
+
+int nef_poly_wgrad_fold(const float* gw2, const float* gy_pm, const float* xedge, float* gw, void* ws, size_t ws_bytes, int B, int G,
+                        int Cog, int Cig, int T, nef_stream_t stream) {
     NEF_ENTER();
-    NEF_REQUIRE(gw2 && gy_pm && xedge && gw, NEF_E_NULL);
-    NEF_REQUIRE(B > 0 && G > 0 && Cog > 0 && Cig > 0 && Cig <= 512 && T >= 4 && T % 2 == 0, NEF_E_SHAPE);
-    hipLaunchKernelGGL(poly_wgrad_fold_kernel, dim3((unsigned)(G * Cog)), dim3(256), 0, NEF_ST, gw2, gy_pm, xedge, gw, B, G, Cog, Cig,
-                       T / 2);
+    NEF_REQUIRE(gw2 && gy_pm && xedge && gw && ws, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && G > 0 && Cog > 0 && Cig > 0 && T >= 4 && T % 2 == 0, NEF_E_SHAPE);
+    const int chunks = (B + POLY_BC - 1) / POLY_BC;
+    NEF_REQUIRE(chunks <= 65535, NEF_E_SHAPE);
+    NEF_REQUIRE(ws_bytes >= nef_poly_wgrad_fold_ws_bytes(B, G, Cog, Cig), NEF_E_WORKSPACE);
+    hipLaunchKernelGGL(poly_wgrad_edge_partial, dim3((unsigned)(G * Cog), (unsigned)chunks), dim3(256), 0, NEF_ST, gy_pm, xedge,
+                       (float*)ws, B, G, Cog, Cig, T / 2);
+    hipLaunchKernelGGL(poly_wgrad_fold_kernel, dim3((unsigned)(G * Cog)), dim3(256), 0, NEF_ST, gw2, (const float*)ws, gw, G * Cog, Cig,
+                       chunks);
     return nef_launch_status();
 }
 

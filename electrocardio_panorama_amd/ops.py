@@ -687,7 +687,7 @@ def poly_w_ok(B, G, Cog, Cig, T):
     """Weight gradient of conv1d(upsample2(x), w) in polyphase form: a split-fp16 weight gradient over the half-resolution x and
     the phase-major gradient (2 Cog rows), producer / consumer form (2 Cog % 128 == 0), then nef_poly_wgrad_fold."""
     Th = T // 2
-    return (POLY and _POLY_W and T % 4 == 0 and Cog % 64 == 0 and Cig <= 512 and h2w_ok(3, Cig, 2 * Cog, Th, 1) and
+    return (POLY and _POLY_W and T % 4 == 0 and Cog % 64 == 0 and h2w_ok(3, Cig, 2 * Cog, Th, 1) and
             (BATCH_HINT is None or B * ((Th + 63) // 64) >= 8 * _H2_MIN_WGS))
 
 
@@ -702,7 +702,10 @@ def conv_bwd_weight_poly(xv, gy_pm, Cog, pro, xedge, site=None):
     gw2 = conv_bwd_weight(xv, gyv, 3, pro=(4 | int(aff), pro[1] if aff else None, pro[2] if aff else None, pro[3] if aff else 1),
                           site=site, h2=True)
     gw = torch.empty(G * Cog, Cig, 3, device=gy_pm.device, dtype=torch.float32)
-    _lib.check(L.nef_poly_wgrad_fold(_p(gw2), _p(gy_pm), _p(xedge), _p(gw), xv.B, G, Cog, Cig, 2 * xv.T, _stream()), "nef_poly_wgrad_fold")
+    n = L.nef_poly_wgrad_fold_ws_bytes(xv.B, G, Cog, Cig)
+    ws = torch.empty(n // 4, device=gy_pm.device, dtype=torch.float32)
+    _lib.check(L.nef_poly_wgrad_fold(_p(gw2), _p(gy_pm), _p(xedge), _p(gw), _p(ws), n, xv.B, G, Cog, Cig, 2 * xv.T, _stream()),
+               "nef_poly_wgrad_fold")
     return gw
 
 

@@ -506,8 +506,9 @@ int nef_bn_relu_bwd_combine3_phase_major(const float* gy, const float* x, const 
                                          const float* b, float* gP2, float* ggamma, float* gbeta, float* gx_chan_sum, void* ws,
                                          size_t ws_bytes, int Bp, int C, int L, const float* slots, int nslot,
                                          nef_stream_t stream);
-int nef_poly_wgrad_fold(const float* gw2, const float* gy_pm, const float* xedge, float* gw, int B, int G, int Cog, int Cig,
-                        int T /* full-resolution length = 2 x the rows of gy_pm */, nef_stream_t stream);
+size_t nef_poly_wgrad_fold_ws_bytes(int B, int G, int Cog, int Cig);
+int nef_poly_wgrad_fold(const float* gw2, const float* gy_pm, const float* xedge, float* gw, void* ws, size_t ws_bytes, int B, int G,
+                        int Cog, int Cig, int T /* full-resolution length = 2 x the rows of gy_pm */, nef_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Test-phase metrics on the device.  Replaces PSNR / SSIM of codes/utils/mertic.py:7-32 as called from
