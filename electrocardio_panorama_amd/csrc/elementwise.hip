@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(256) void poly_weights_kernel(const float* __restri
 // and therefore u[-1] = x[0], u[T] = x[Tin-1] where the conv's zero padding has 0:
 //     y[c][0] -= sum_ci w[c][ci][0] x'[ci][0]        y[c][T-1] -= sum_ci w[c][ci][2] x'[ci][Tin-1]        (x' = the prologue's output)
 // and the two columns' change in the BatchNorm statistics (sum, sum of squares) goes into slot 0 of the sample.  One workgroup per
-// (sample, group), one wave per output channel at a time.
+// (sample, group).
 __global__ __launch_bounds__(256) void poly_fwd_edge_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
                                                             int B, int G, int Cr, int Cig, int T, const float* __restrict__ pa,
                                                             const float* __restrict__ pb, int Bp, float* __restrict__ slots, int nslot,
@@ -1247,25 +1247,36 @@ __global__ __launch_bounds__(256) void poly_fwd_edge_kernel(const float* __restr
         if (xedge) xedge[(((int64_t)b * G + g) * Cig + ci) * 2 + k] = v;      // kept for the weight gradient's row-end terms
     }
     __syncthreads();
+    // a wave takes FOUR channels at a time (lanes over the input channels, coalesced weight rows): their 16 loads are in flight
+    // together, then the eight wave sums -- one channel at a time made the kernel a chain of dependent latencies (48 us)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int c = wave; c < Cr; c += 4) {
-        const float* const wr = w + ((int64_t)g * Cr + c) * Cig * 3;
-        float c0 = 0.f, cl = 0.f;
+    for (int c4 = 4 * wave; c4 < Cr; c4 += 16) {
+        float c0[4] = {0.f, 0.f, 0.f, 0.f}, cl[4] = {0.f, 0.f, 0.f, 0.f};
         for (int ci = lane; ci < Cig; ci += 64) {
-            c0 = fmaf(wr[3 * ci], xl[ci], c0);
-            cl = fmaf(wr[3 * ci + 2], xl[Cig + ci], cl);
+            const float x0 = xl[ci], xe = xl[Cig + ci];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (c4 + u < Cr) {
+                    const float* const wr = w + (((int64_t)g * Cr + c4 + u) * Cig + ci) * 3;
+                    c0[u] = fmaf(wr[0], x0, c0[u]);
+                    cl[u] = fmaf(wr[2], xe, cl[u]);
+                }
+            }
         }
-        c0 = nef_wave_sum(c0), cl = nef_wave_sum(cl);
-        if (lane == 0) {
-            const int64_t ch = (int64_t)g * Cr + c;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c0[u] = nef_wave_sum(c0[u]), cl[u] = nef_wave_sum(cl[u]);
+        if (lane < 4 && c4 + lane < Cr) {
+            const float c0v = lane == 0 ? c0[0] : (lane == 1 ? c0[1] : (lane == 2 ? c0[2] : c0[3]));
+            const float clv = lane == 0 ? cl[0] : (lane == 1 ? cl[1] : (lane == 2 ? cl[2] : cl[3]));
+            const int64_t ch = (int64_t)g * Cr + c4 + lane;
             float* const row = y + ((int64_t)b * G * Cr + ch) * T;
             const float y0 = row[0], yl = row[T - 1];
-            row[0] = y0 - c0;
-            row[T - 1] = yl - cl;
+            row[0] = y0 - c0v;
+            row[T - 1] = yl - clv;
             if (slots) {
-                float* const sl = slots + ((ch * B + b) * nslot) * 2;
-                sl[0] -= c0 + cl;
-                sl[1] += fmaf(c0, c0 - 2.f * y0, cl * (cl - 2.f * yl));
+                float* const sp = slots + ((ch * B + b) * nslot) * 2;
+                sp[0] -= c0v + clv;
+                sp[1] += fmaf(c0v, c0v - 2.f * y0, clv * (clv - 2.f * yl));
             }
         }
     }
