@@ -624,7 +624,7 @@ def conv_poly_fwd(xv, w, Cog, bias=None, pro=None, stats=False, site=None, save_
     the upsampling-prologue form (fp32-class either way)."""
     L = _lib.load()
     G, Cig, Th = xv.G, xv.Cg, xv.T
-    assert w.shape == (G * Cog, Cig, 3)
+    assert w.shape == (G * Cog, Cig, 3) and xv.bs == G * Cig * Th and xv.gs == Cig * Th, "conv_poly_fwd: dense input rows"
     aff = pro is not None and bool(pro[0] & 1)
     ws = poly_weights(w, Cog)
     wp = pack_weight(ws, G, T=Th, site=w.data_ptr() if site is None else site, plain=False)
