@@ -384,3 +384,45 @@ def test_env_switch_groups(monkeypatch, capsys):
                 seen |= set(re.findall(r'(?:_env\.get|nef_diag_env|getenv)\(["\'](NEF_[A-Z0-9_]+)', txt))
     hooks = {"NEF_SHARE_GPU", "NEF_DIST_BACKEND", "NEF_DIST_FORCE"}
     assert seen - set(_env.PRODUCT) - _env.DIAGNOSTICS - hooks == set(), seen - set(_env.PRODUCT) - _env.DIAGNOSTICS - hooks
+
+
+def test_polyphase_form_of_conv_behind_upsampling_is_exact_algebra():
+    """The identities csrc/elementwise.hip (poly_weights_kernel, poly_fwd_edge_kernel, poly_bwd_edge_kernel, poly_wgrad_fold_kernel)
+    and DESIGN 3.0b rest on, in fp64 on the CPU against torch's own ops (codes/network/model_nefnet.py:102-105): forward = two K = 3
+    convs of the half-resolution input with the phase weights (clamped ends) minus the two row-end columns; backward-data = conv of
+    the phase-major gradient with the transposed / flipped phase weights plus its row-end terms; weight gradient = phase weight
+    gradients folded back minus theirs."""
+    import torch
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    B, Ci, Co, Th = 3, 5, 4, 9
+    x = torch.randn(B, Ci, Th, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Co, Ci, 3, dtype=torch.float64, requires_grad=True)
+    gy = torch.randn(B, Co, 2 * Th, dtype=torch.float64)
+    y = F.conv1d(F.interpolate(x, scale_factor=2, mode="linear", align_corners=False), w, padding=1)
+    y.backward(gy)
+    w0, w1, w2 = w.detach().unbind(2)
+    W = [torch.stack([.75 * w0 + .25 * w1, .25 * w0 + .75 * w1 + .75 * w2, .25 * w2], 2),
+         torch.stack([.25 * w0, .75 * w0 + .75 * w1 + .25 * w2, .25 * w1 + .75 * w2], 2)]
+    xd = x.detach()
+    xe = torch.cat([xd[:, :, :1], xd, xd[:, :, -1:]], 2)                       # nn.Upsample's clamped sources
+    yp = torch.stack([F.conv1d(xe, W[p]) for p in (0, 1)], 3).reshape(B, Co, 2 * Th)
+    yp[:, :, 0] -= torch.einsum("oc,bc->bo", w0, xd[:, :, 0])
+    yp[:, :, -1] -= torch.einsum("oc,bc->bo", w2, xd[:, :, -1])
+    assert torch.allclose(yp, y.detach(), atol=1e-12)
+    # backward-data on the phase-major gradient [B, 2 Co, Th] (row 2 co + p), zero padding
+    gpm = gy.view(B, Co, Th, 2).permute(0, 1, 3, 2).reshape(B, 2 * Co, Th)
+    Wsyn = torch.stack(W, 1).reshape(2 * Co, Ci, 3)                             # row 2 co + p
+    gx = F.conv1d(gpm, Wsyn.permute(1, 0, 2).flip(2), padding=1)
+    gx[:, :, 0] += .25 * (torch.einsum("oc,bo->bc", w1 - w0, gy[:, :, 0]) + torch.einsum("oc,bo->bc", w0, gy[:, :, 1]))
+    gx[:, :, -1] += .25 * (torch.einsum("oc,bo->bc", w1 - w2, gy[:, :, -1]) + torch.einsum("oc,bo->bc", w2, gy[:, :, -2]))
+    assert torch.allclose(gx, x.grad, atol=1e-12)
+    # weight gradient: phase weight gradients over the clamped-end input, folded back, minus the row-end terms
+    gW = torch.stack([torch.einsum("bot,bct->oc", gpm, xe[:, :, j:j + Th]) for j in range(3)], 2).view(Co, 2, Ci, 3)
+    A, Bq = gW[:, 0], gW[:, 1]
+    gw = torch.stack([.75 * (A[..., 0] + Bq[..., 1]) + .25 * (A[..., 1] + Bq[..., 0]),
+                      .75 * (A[..., 1] + Bq[..., 1]) + .25 * (A[..., 0] + Bq[..., 2]),
+                      .75 * (A[..., 1] + Bq[..., 2]) + .25 * (A[..., 2] + Bq[..., 1])], 2)
+    gw[:, :, 0] -= torch.einsum("bo,bc->oc", gy[:, :, 0], xd[:, :, 0])
+    gw[:, :, 2] -= torch.einsum("bo,bc->oc", gy[:, :, -1], xd[:, :, -1])
+    assert torch.allclose(gw, w.grad, atol=1e-12)
