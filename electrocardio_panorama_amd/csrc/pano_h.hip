@@ -357,11 +357,16 @@ __global__ __launch_bounds__(256, MINB) void hconv_kernel(const _Float16* __rest
 // ------------------------------------------------------------------------------------------------------------
 #define PHW_ORS 272   // bytes per staged output row: 128 halfs + 16 B pad
 
-template <int CIN, int COUT, int PRO>
+//   OUT = 1 (64 -> 64, round 5): the last conv (64 -> 1) evaluated on the staged output tile as in hconv_kernel -- the 64-channel
+//             tile never reaches memory; tile-edge columns are completed by the neighbouring tile (two-addend atomic add)
+template <int CIN, int COUT, int PRO, int OUT = 0>
 __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __restrict__ x, const nef_h8* __restrict__ wp,
                                                          const float* __restrict__ bias, const float* __restrict__ scale,
                                                          _Float16* __restrict__ y, int T, int tiles_per_n, int total_tiles,
-                                                         int x_div, int nq, long sc_bs, long sc_is) {
+                                                         int x_div, int nq, long sc_bs, long sc_is,
+                                                         const float* __restrict__ wout, float* __restrict__ logit,
+                                                         long out_bs, long out_is) {
+    static_assert(!OUT || (COUT == 64 && PRO == 0), "the fused last conv rides on the 64-channel layer");
     constexpr int WM = COUT / 64, WN = 4 / WM;   // waves along the output channels / along time
     constexpr int NT = 256, NI = NT / (32 * WN); // wave = 64 co x 128 t (COUT = 128) or 64 co x 64 t (COUT = 64)
     constexpr int MT = COUT / 32;                // A fragments per k-step in the packed weights
@@ -382,6 +387,8 @@ __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __re
     const int seg = tid & 7, rg = tid >> 3;
     const int Tin = UP ? T / 2 : T;
     char* const dump = smem + 2 * XBYTES + tid * 16;
+    float* const Of = (float*)(smem + 2 * XBYTES + 256 * 16);      // OUT: wout[192], d0[NT], d2[NT]
+    if (OUT && tid < 192) Of[tid] = wout[tid];                     // [ci][tap]; visible after the first barrier
 
     nef_f16acc acc[2][NI];
 #pragma unroll
@@ -574,12 +581,43 @@ __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __re
             __syncthreads();
             constexpr int VPR = COUT / 8;        // 16-byte vectors per output row
             constexpr int ROWS = NT / NPS;
+            if constexpr (OUT) {
+                // last conv on the staged tile: row r = this thread; d_k = sum_c wout[c][k] * tile[r][c]
+                const int r = tid, t = t0 + r;
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+                if (t < T) {
+#pragma unroll
+                    for (int sg = 0; sg < 8; ++sg) {
+                        const nef_h8 v = *(const nef_h8*)(Ol + r * ORS + sg * 16);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = (float)v[e];
+                            const float* wc = Of + (sg * 8 + e) * 3;
+                            d0 = fmaf(wc[0], f, d0);
+                            d1 = fmaf(wc[1], f, d1);
+                            d2 = fmaf(wc[2], f, d2);
+                        }
+                    }
+                }
+                Of[192 + r] = d0;        // tap 0 weights this row into column t + 1
+                Of[192 + NT + r] = d2;   // tap 2 into column t - 1
+                __syncthreads();
+                float* lg = logit + (size_t)(n / nq) * out_bs + (size_t)(n % nq) * out_is;
+                if (t < T) {
+                    const float s_ = d1 + (r > 0 ? Of[192 + r - 1] : 0.f) + (r < NT - 1 ? Of[192 + NT + r + 1] : 0.f);
+                    if (r == 0 || r == NT - 1) atomicAdd(lg + t, s_);
+                    else lg[t] = s_;
+                    if (r == NT - 1 && t + 1 < T) atomicAdd(lg + t + 1, d0);
+                    if (r == 0 && t > 0) atomicAdd(lg + t - 1, d2);
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < ROWS * VPR / 256; ++k) {
                 const int idx = tid + k * 256, r = idx / VPR, v = idx % VPR;
                 const int t = t0 + ps * ROWS + r;
                 if (t < T)
                     *(nef_h8*)(yb + (size_t)t * COUT + v * 8) = *(const nef_h8*)(Ol + r * ORS + v * 16);
+            }
             }
             __syncthreads();                 // staging read: the next pass / the next chunk's X may overwrite it
         }
@@ -885,15 +923,16 @@ static int launch_hconv(const void* x, const void* wp, const float* bias, const 
     return nef_launch_status();
 }
 
-template <int CIN, int COUT, int PRO>
+template <int CIN, int COUT, int PRO, int OUT = 0>
 static int launch_hconv_wide(const void* x, const void* wp, const float* bias, const float* scale, void* y, int N, int T,
-                             int x_div, int nq, long sc_bs, long sc_is, hipStream_t st) {
+                             int x_div, int nq, long sc_bs, long sc_is, hipStream_t st, const float* wout = nullptr,
+                             float* logit = nullptr, long out_bs = 0, long out_is = 0) {
     constexpr int NT = 256;
-    constexpr int LDS = 2 * (NT + 2) * PH_XRS + 256 * 16;
+    constexpr int LDS = 2 * (NT + 2) * PH_XRS + 256 * 16 + (OUT ? (192 + 2 * NT) * 4 : 0);
     const int tiles = (T + NT - 1) / NT;
     const int64_t total = (int64_t)N * tiles;
     if (total > 0x7FFFFFFF) return NEF_E_SHAPE;
-    auto k = hconv_wide_kernel<CIN, COUT, PRO>;
+    auto k = hconv_wide_kernel<CIN, COUT, PRO, OUT>;
     static int resident_dev[64] = {0};       // per device, idempotent -> thread-safe without a lock
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -910,7 +949,7 @@ static int launch_hconv_wide(const void* x, const void* wp, const float* bias, c
     }
     const int grid = (int)(total < resident ? total : resident);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), LDS, st, (const _Float16*)x, (const nef_h8*)wp, bias, scale,
-                       (_Float16*)y, T, tiles, (int)total, x_div, nq, sc_bs, sc_is);
+                       (_Float16*)y, T, tiles, (int)total, x_div, nq, sc_bs, sc_is, wout, logit, out_bs, out_is);
     return nef_launch_status();
 }
 
@@ -931,6 +970,13 @@ static int launch_hconv_pair(const void* x, const void* wp1, const float* b1, co
     hipLaunchKernelGGL(hconv_pair_kernel, dim3(N < cus ? N : cus), dim3(512), LDS, st, (const _Float16*)x,
                        (const nef_h8*)wp1, b1, scale, (const nef_h8*)wp2, b2, (_Float16*)y, T, N, x_div, nq, sc_bs, sc_is);
     return nef_launch_status();
+}
+
+static bool ph_l4_old() {
+    // the 64 -> 64 layer (+ fused last conv) on hconv_wide_kernel<64, 64, 0, OUT> measured SLOWER than the round-1 kernel (sweep 52.1 vs
+    // 50.7 ms, gen_ecg share 9.98 vs 9.68: one 64-channel chunk per tile leaves the double buffer nothing to hide): opt-in, A/B only
+    static const bool v = !(nef_diag_env("NEF_PANO_L4_WIDE") && atoi(nef_diag_env("NEF_PANO_L4_WIDE")) == 1);
+    return v;
 }
 
 extern "C" {
@@ -973,6 +1019,7 @@ int nef_pano_h_conv(const void* x, const void* wp, const float* bias, const floa
     PHW_CASE(128, 128, 0);
     PHW_CASE(128, 64, 2);
     PHW_CASE(128, 64, 0);
+    if (!ph_l4_old()) PHW_CASE(64, 64, 0);      // round 5, opt-in (NEF_DIAG=1 NEF_PANO_L4_WIDE=1): measured slower, see ph_l4_old()
 #undef PHW_CASE
     PH_CASE(64, 64, 0);
 #undef PH_CASE
@@ -1001,8 +1048,10 @@ int nef_pano_h_conv_outconv(const void* x, const void* wp, const float* bias, co
                        T, NT, tiles, nq, (long)out_bs, (long)out_is);
     int rc = nef_launch_status();
     if (rc != NEF_OK) return rc;
-    rc = launch_hconv<64, 64, 0, 1>(x, wp, bias, nullptr, nullptr, N, T, 1, nq, 0, 0, st, wout, out, (long)out_bs,
-                                    (long)out_is);
+    rc = ph_l4_old() ? launch_hconv<64, 64, 0, 1>(x, wp, bias, nullptr, nullptr, N, T, 1, nq, 0, 0, st, wout, out, (long)out_bs,
+                                                  (long)out_is)
+                     : launch_hconv_wide<64, 64, 0, 1>(x, wp, bias, nullptr, nullptr, N, T, 1, nq, 0, 0, st, wout, out,
+                                                       (long)out_bs, (long)out_is);
     if (rc != NEF_OK) return rc;
     hipLaunchKernelGGL(ph_sigmoid3_kernel, dim3(nef_stream_grid((int64_t)N * T, 256)), dim3(256), 0, st, out, bout, N, T,
                        nq, (long)out_bs, (long)out_is);
