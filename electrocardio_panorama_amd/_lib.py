@@ -35,6 +35,7 @@ class ConvArgs(C.Structure):
         ("stats", p),
         ("bnb_x", p), ("bnb_mean", p), ("bnb_invstd", p), ("bnb_a", p), ("bnb_b", p), ("bnb_slots", p), ("bnb_Bp", i32),
         ("bnb_up", i32), ("x_scale", f32), ("reserved0", i32), ("x_amax", p), ("x_amax_next", p), ("x_clamped", p),
+        ("res_scale", p), ("rs_bs", i64), ("rs_gs", i64),
     ]
 
 

@@ -31,6 +31,8 @@ _FUSE_STATS = _env.get("NEF_FUSE_STATS", "1") == "1"
 # NEF_BNB_UP=0: the BatchNorm-backward sums behind a x2 upsampling by the pass (bn_relu_bwd_up reduces them itself) instead of the
 # backward-data conv's epilogue
 _BNB_UP = _env.get("NEF_BNB_UP", "1") == "1"
+# NEF_FOLD_CHSCALE=0: the theta scaling in front of w_conv as a pass of its own (chscale_fwd) instead of in_scale / res_scale on the block's convs
+_FOLD_CHSCALE = _env.get("NEF_FOLD_CHSCALE", "1") == "1"
 
 _BWD_F4 = _env.get("NEF_BWD_F4", "1")
 
@@ -69,18 +71,28 @@ class DropCfg:
 # ----------------------------------------------------------------------------------------------
 # BasicBlock (resnet_1d.py:42-53 with k=7; model_nefnet.py:48-60 with k=3)
 # ----------------------------------------------------------------------------------------------
-def block_fwd(xv, P, prefix, K, Cog, drop):
+def block_fwd(xv, P, prefix, K, Cog, drop, in_scale=None):
+    """`in_scale` (tensor [B, G, Cin], batch stride, group stride): the block's input is xv * in_scale per (sample, channel) -- applied
+    by the first conv while it stages and by the last one to its residual, so the scaled tensor is never written (split-fp16
+    launches, identity residual only: the caller checks block_scale_ok)."""
     G = xv.G
-    h = ops.conv(xv, ops.pack_weight(P[prefix + ".conv1.weight"], G, T=xv.T), Cog, K, relu=True, **drop.args(prefix))
+    h = ops.conv(xv, ops.pack_weight(P[prefix + ".conv1.weight"], G, T=xv.T), Cog, K, relu=True, in_scale=in_scale, **drop.args(prefix))
     res_conv = (K == 3 and Cog != xv.Cg)                     # model_nefnet.py:54
+    assert in_scale is None or not res_conv
     if res_conv:
         r = ops.conv(xv, ops.pack_weight(P[prefix + ".residual_conv.weight"], G, T=xv.T), Cog, 1,
                      bias=P[prefix + ".residual_conv.bias"])
         resv = GV.dense(r, G)
     else:
         resv = xv
-    y = ops.conv(GV.dense(h, G), ops.pack_weight(P[prefix + ".conv2.weight"], G, T=xv.T), Cog, K, res=resv, relu=True)
-    return y, (xv, h, y, prefix, K, Cog, res_conv, drop.scale)
+    y = ops.conv(GV.dense(h, G), ops.pack_weight(P[prefix + ".conv2.weight"], G, T=xv.T), Cog, K, res=resv, relu=True,
+                 res_scale=in_scale)
+    return y, (xv, h, y, prefix, K, Cog, res_conv, drop.scale, in_scale)
+
+
+def block_scale_ok(P, prefix, G, T):
+    """Both convs of the block on the split-fp16 kernel at full-size tiles (what in_scale / res_scale need)?"""
+    return all(ops._pack_shape(P[prefix + n], G, False, T, plain=False)[3] == 3 for n in (".conv1.weight", ".conv2.weight")) and T >= 128
 
 
 def _bwd_f4(K):
@@ -143,7 +155,8 @@ def block_bwd(saved, gy, P, grads, out=None, side=None, pre_gated=False, gate_in
     the side stream: they are off the dependency chain and overlap with the chain's HBM-bound kernels.
     `gate_input`: the block input is itself a ReLU output whose producer would mask this gradient first thing in its own
     backward -- apply that mask in the epilogue of the last conv here; the producer is then called with `pre_gated`."""
-    xv, h, y, prefix, K, Cog, res_conv, dscale = saved
+    xv, h, y, prefix, K, Cog, res_conv, dscale = saved[:8]
+    in_scale = saved[8] if len(saved) > 8 else None      # the block input is xv * in_scale: the returned gradient is wrt THAT product
     side = side or ops._Inline()
     G, Cig = xv.G, xv.Cg
     g2 = gy if pre_gated else ops.gate(gy, y)                # through the final ReLU
@@ -153,7 +166,7 @@ def block_bwd(saved, gy, P, grads, out=None, side=None, pre_gated=False, gate_in
     gc1 = ops.conv(g2v, ops.pack_weight(P[prefix + ".conv2.weight"], G, flip=True, T=xv.T, f4=_bwd_f4(K)), Cog, K, gate=hv,
                    gate_scale=dscale, role="conv_bwd_data")
     gc1v = GV.dense(gc1, G)
-    grads[prefix + ".conv1.weight"] = side.run(lambda: ops.conv_bwd_weight(xv, gc1v, K, site=P[prefix + ".conv1.weight"].data_ptr()), xv.t, gc1)
+    grads[prefix + ".conv1.weight"] = side.run(lambda: ops.conv_bwd_weight(xv, gc1v, K, in_scale=in_scale, site=P[prefix + ".conv1.weight"].data_ptr()), xv.t, gc1)
     if res_conv:
         grads[prefix + ".residual_conv.weight"] = side.run(lambda: ops.conv_bwd_weight(xv, g2v, 1, site=P[prefix + ".residual_conv.weight"].data_ptr()), xv.t, g2)
         grads[prefix + ".residual_conv.bias"] = side.run(lambda: ops.chan_sum(g2), g2)
@@ -411,8 +424,12 @@ def _latents(P, x, in_theta, rois, drop, save):
         a, s = block_fwd(GV.dense(a, V), P, f"W_encoder.layer1.{i}", 7, 128, drop)
         sv["blk_enc"].append(s)
     e = ops.theta_mlp_fwd(in_theta, P["mlp1.weight"], P["mlp1.bias"])           # [B, V, 128]
-    ew = ops.chscale_fwd(a, e)
-    enc, sv["blk_w_conv"] = block_fwd(GV.dense(ew, V), P, "w_conv.0", 3, 128, drop)
+    if _FOLD_CHSCALE and block_scale_ok(P, "w_conv.0", V, T):
+        # a * e is never written: w_conv's first conv scales while it stages, its last conv scales the residual (round 5)
+        enc, sv["blk_w_conv"] = block_fwd(GV.dense(a, V), P, "w_conv.0", 3, 128, drop, in_scale=(e, V * 128, 128))
+    else:
+        ew = ops.chscale_fwd(a, e)
+        enc, sv["blk_w_conv"] = block_fwd(GV.dense(ew, V), P, "w_conv.0", 3, 128, drop)
     z1, sv["blk_z1"] = block_fwd(GV.half(enc, V, 0), P, "z1_conv.0", 3, 128, drop)
     # z2_conv1 feeds only roi_algin, which reads exactly two time rows: run the block on the window of
     # six samples whose centre two are exact (k=3 twice -> 2 samples of context per side) instead of all T.

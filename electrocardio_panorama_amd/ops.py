@@ -513,9 +513,9 @@ def bn_stats_from_slots(stats, gamma, beta, running_mean, running_var, P, N, Ln,
 
 def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None, gate_scale=1.0, relu=False,
          mask=None, drop_p=0.0, drop_scale=1.0, seed=0, role="conv_fwd", pro=None, seed_dev=None, stats=None, bnb=None,
-         x_scale=0.0, tag_extra=""):
-    """out = epilogue(conv1d(prologue(x) * in_scale, w) + bias + res).  `xv`, `res`, `gate`, `out` are GV views;
-    `in_scale` is (tensor, batch_stride, group_stride).  `pro` = (mode, a, b, Bp): input prologue applied while
+         x_scale=0.0, tag_extra="", res_scale=None):
+    """out = epilogue(conv1d(prologue(x) * in_scale, w) + bias + res * res_scale).  `xv`, `res`, `gate`, `out` are GV views;
+    `in_scale` / `res_scale` are (tensor, batch_stride, group_stride).  `pro` = (mode, a, b, Bp): input prologue applied while
     staging -- bit0 BatchNorm affine + ReLU with a/b [P, C_in], bit1 x2 linear upsampling of a half-resolution input
     (the output is then 2*xv.T long).  `stats`: a conv_stats_buffer() the epilogue fills with the per-slot sum and sum
     of squares of the outputs; `bnb` = (x, mean, invstd, a, b, Bp, conv_stats_buffer()[, up]): the epilogue leaves the
@@ -538,6 +538,9 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     a.x_bs, a.x_gs, a.y_bs, a.y_gs = xv.bs, xv.gs, out.bs, out.gs
     if res is not None:
         a.res_bs, a.res_gs = res.bs, res.gs
+    if res_scale is not None:      # (tensor, batch stride, group stride) like in_scale: y += res * res_scale[b, g, c]; split-fp16 launches only
+        assert res is not None
+        a.res_scale, a.rs_bs, a.rs_gs = _p(res_scale[0]), res_scale[1], res_scale[2]
     if gate is not None:
         a.gate_bs, a.gate_gs = gate.bs, gate.gs
     a.B, a.T, a.G, a.Cin_g, a.Cout_g, a.K = xv.B, T_out, xv.G, xv.Cg, Cog, K

@@ -184,6 +184,11 @@ typedef struct nef_conv_args {
                               redone inside the launch with the scale its own data asks for; round 4 clamped it and counted it.)
                               The producer / consumer form (nef_set_option(NEF_OPT_H2_FORM, 1)) has no rescue: it clamps at
                               65000 / scale and counts */
+    const float* res_scale;   /* wino == 3, res != NULL: NULL, or a per-(sample, channel) factor on the residual,
+                              y = conv + bias + res * res_scale[b*rs_bs + g*rs_gs + c] -- the residual of a block whose input is a
+                              channel-scaled tensor (w_conv behind the theta scaling, codes/network/model_nefnet.py:122-124) read
+                              from the UNSCALED tensor, with in_scale on the block's first conv: the scaled tensor is never written */
+    int64_t rs_bs, rs_gs;
 } nef_conv_args;
 
 /* y = epilogue(conv(x * in_scale, wp) + bias + res).  Also the bwd-data pass (pack with transpose_flip=1,

@@ -640,6 +640,37 @@ def test_conv_epilogue_bn_backward_slot_sums_through_upsampling(B, Cin, Cout, T)
     assert maxabs(got[3], want[3]) < 1e-4 * float(want[0].abs().sum() / Cout) + 1e-6
 
 
+@pytest.mark.parametrize("B,G,C,T", [(6, 3, 128, 1250), (3, 1, 64, 300), (5, 2, 128, 130)])
+def test_conv_h2_channel_scaled_block_input(B, G, C, T):
+    """A residual block on a per-(sample, channel) scaled input without writing the scaled tensor (the theta scaling in front of
+    w_conv, codes/network/model_nefnet.py:122-124): in_scale on the first conv, res_scale on the residual of the last one -- against
+    the same two launches on the materialised product, and against fp64."""
+    o = ops()
+    from electrocardio_panorama_amd.ops import GV
+    if not o.h2_ok(3, C, C, T):
+        pytest.skip("split-fp16 convs switched off")
+    x = g(rnd(B, G * C, T, seed=1230))
+    e = g(rnd(B, G, C, seed=1231) + 0.3)
+    w1, w2 = g(rnd(G * C, C, 3, seed=1232, scale=0.05)), g(rnd(G * C, C, 3, seed=1233, scale=0.05))
+    xs = x * e.reshape(B, G * C, 1)
+    wp1, wp2 = o.pack_weight(w1, G, T=T, plain=False), o.pack_weight(w2, G, T=T, plain=False)
+    if getattr(wp1, "nef_wino", 0) != 3:
+        pytest.skip("shape not on the split-fp16 kernel")
+    sc = (e, G * C, C)
+    h_a = o.conv(GV.dense(xs, G), wp1, C, 3, relu=True, x_scale=2.0 ** 6)
+    h_b = o.conv(GV.dense(x, G), wp1, C, 3, relu=True, in_scale=sc, x_scale=2.0 ** 6)
+    assert torch.equal(h_a, h_b)                      # x * e is formed identically while staging
+    y_a = o.conv(GV.dense(h_a, G), wp2, C, 3, res=GV.dense(xs, G), relu=True, x_scale=2.0 ** 6)
+    y_b = o.conv(GV.dense(h_a, G), wp2, C, 3, res=GV.dense(x, G), relu=True, res_scale=sc, x_scale=2.0 ** 6)
+    want = torch.relu(F.conv1d(h_a.double(), w2.double(), padding=1, groups=G) + xs.double())
+    e_a, e_b = rel(y_a.double(), want), rel(y_b.double(), want)
+    assert e_b < max(1.5 * e_a, 5e-7), (e_a, e_b)     # one fused multiply-add instead of a rounded product + an add
+    assert maxabs(y_a, y_b) < 1e-5 * float(want.abs().max())
+    gw_a = o.conv_bwd_weight(GV.dense(xs, G), GV.dense(h_a, G), 3)
+    gw_b = o.conv_bwd_weight(GV.dense(x, G), GV.dense(h_a, G), 3, in_scale=sc)
+    assert rel(gw_b, gw_a) < 1e-6
+
+
 @pytest.mark.parametrize("B,G,Cog,Cig,T,aff", [(6, 1, 64, 128, 1000, True), (3, 1, 64, 128, 520, False), (6, 2, 128, 128, 512, False),
                                                 (3, 1, 128, 64, 776, True), (3, 1, 64, 64, 256, True)])
 def test_conv_fwd_polyphase_behind_upsampling(B, G, Cog, Cig, T, aff):
