@@ -4,8 +4,9 @@
     python tools/pmc_table.py <fetch.db> <write.db> <out.md> <traffic.json> [dominant-kernel-prefix]
 
 HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: on gfx950 FETCH_SIZE counts half of the bytes read (MI355X guide);
-re-checked in every run on `chscale_fwd_kernel`, a pure streaming pass whose traffic is known: it reads the encoder output
-[B, 128V, L/4] once (+ a [B, V, 128] scale table) and writes a tensor of the same size.  The script FAILS when the calibration
+re-checked in every run on `chscale_bwd_kernel`, a pure streaming pass whose traffic is known: it reads two tensors of the encoder
+output's size [B, 128V, L/4] (+ a [B, V, 128] scale table) and writes one (round 5: `chscale_fwd_kernel`, the calibration kernel
+of rounds 1-4, is folded into w_conv and no longer in the trace).  The script FAILS when the calibration
 kernel is missing or the corrected read figure is off by more than 10 %.
 """
 import json
@@ -32,12 +33,12 @@ assert [x[:2] for x in F] == [x[:2] for x in W], "the two passes must launch the
 stats = {}
 for (n, g, f), (_, _, w) in zip(F, W):
     stats.setdefault(n, []).append((f, w))
-# calibration: chscale_fwd_kernel over the [256, 384, 1250] encoder output (config 2) reads 491,520,000 bytes and writes as many
-CAL, CAL_BYTES = "chscale_fwd_kernel", float(sys.argv[6]) if len(sys.argv) > 6 else 256 * 384 * 1250 * 4.0
+# calibration: chscale_bwd_kernel over the [256, 384, 1250] encoder output (config 2) reads 2 x 491,520,000 bytes and writes 491,520,000
+CAL, CAL_BYTES = "chscale_bwd_kernel", float(sys.argv[6]) if len(sys.argv) > 6 else 256 * 384 * 1250 * 4.0
 cal = [(f, w) for (n, g, f), (_, _, w) in zip(F, W) if n == CAL]
 if not cal:
     sys.exit(f"pmc_table: calibration kernel {CAL} not in the trace -- refusing to emit an uncalibrated table")
-cal_ratio = (sum(f for f, _ in cal) / len(cal)) * 1024 / CAL_BYTES
+cal_ratio = (sum(f for f, _ in cal) / len(cal)) * 1024 / (2 * CAL_BYTES)
 cal_w = (sum(w for _, w in cal) / len(cal)) * 1024 / CAL_BYTES
 if not (0.40 < cal_ratio < 0.62) or not (0.85 < cal_w < 1.15):
     sys.exit(f"pmc_table: calibration off: FETCH_SIZE x 1024 = {cal_ratio:.3f} of the known read bytes (expected 0.5), "
@@ -52,7 +53,7 @@ with open(out_md, "w") as fh:
     fh.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1, config 2 "
              "(B=256,V=3,L=5000)\n\n")
     fh.write("Counter unit: KB per dispatch.  HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- gfx950's FETCH_SIZE counts\n"
-             "half of the bytes read (MI355X guide).  Calibration in this run: `chscale_fwd_kernel` reads and writes\n"
+             "half of the bytes read (MI355X guide).  Calibration in this run: `chscale_bwd_kernel` reads 2 x and writes\n"
              f"{CAL_BYTES:,.0f} bytes per launch; FETCH_SIZE x 1024 = {cal_ratio:.3f} of the read, WRITE_SIZE x 1024 = {cal_w:.3f} of "
              "the write.  Fabric-side counters: hits in the memory-side\n"
              "cache (MALL) are counted like HBM reads, so these are upper bounds on DRAM traffic.\n\n")

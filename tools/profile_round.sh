@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU call: serialized + two-stream rocprofv3 kernel stats (warm-up step dropped from the averages), the two PMC traffic
-# passes of bench.py (calibrated on chscale_fwd_kernel; the script fails on a missing / off calibration) and the SQ counters of
+# passes of bench.py (calibrated on chscale_bwd_kernel; the script fails on a missing / off calibration) and the SQ counters of
 # the K=7 conv family: the fp32 kernels (NEF_H2=0) and the split-fp16 kernels of the default path, reduced to the
 # markdown summaries under gpurun_out/ (copy the ones to keep into profiles/).   usage: tools/profile_round.sh r02
 R=${1:-r02}
