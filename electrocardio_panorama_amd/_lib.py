@@ -35,7 +35,8 @@ class ConvArgs(C.Structure):
         ("stats", p),
         ("bnb_x", p), ("bnb_mean", p), ("bnb_invstd", p), ("bnb_a", p), ("bnb_b", p), ("bnb_slots", p), ("bnb_Bp", i32),
         ("bnb_up", i32), ("x_scale", f32), ("reserved0", i32), ("x_amax", p), ("x_amax_next", p), ("x_clamped", p),
-        ("res_scale", p), ("rs_bs", i64), ("rs_gs", i64),
+        ("res_scale", p), ("rs_bs", i64), ("rs_gs", i64), ("gate_rowscale", p), ("gr_bs", i64), ("gr_gs", i64),
+        ("stats_mode", i32), ("reserved1", i32),
     ]
 
 
@@ -133,6 +134,7 @@ SIGNATURES = {
     "nef_loss_bwd": (i32, [p, p, p, p, p, p, p, p, i64, f32, f32, f32, i32, i32, p]),
     "nef_sgd_momentum": (i32, [p, p, p, i64, f32, f32, f32, i32, p, p, p, p]),
     "nef_h2_taint": (i32, [p, p, p, p]),
+    "nef_slots_to_rows": (i32, [p, i32, p, i32, i32, p]),
     "nef_poly_weights": (i32, [p, p, i32, i32, i32, p]),
     "nef_poly_fwd_edge": (i32, [p, p, p, i32, i32, i32, i32, i32, p, p, i32, p, i32, p, p]),
     "nef_poly_wgrad_fold_ws_bytes": (sz, [i32, i32, i32, i32]),

@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
     unsigned char* const Xl = smem_h2;             // [2 buffers][2 planes][PLANE]
     float* const Pl = reinterpret_cast<float*>(smem_h2 + 4 * PLANE);      // [2][Cin_g] prologue affine (AFF)
-    float* const El = Pl + (AFF ? 2 * PRO_MAX_CIN : 0);                    // [7][MT] epilogue tables (bias, 4 x BatchNorm-backward, descale, residual scale)
-    float* const Al = El + 7 * MT;                                         // [4] the waves' operand magnitudes of this tile (range rescue)
+    float* const El = Pl + (AFF ? 2 * PRO_MAX_CIN : 0);                    // [8][MT] epilogue tables (bias, 4 x BatchNorm-backward, descale, residual scale, gate row scale)
+    float* const Al = El + 8 * MT;                                         // [4] the waves' operand magnitudes of this tile (range rescue)
 
     // Range rescue (round 5): if an element of THIS tile turns out to exceed fp16's range under the launch's scale (the operand grew
     // more than ops.H2_HEADROOM x since the call site measured it), the workgroup does its tile again with the scale its own data
@@ -511,6 +511,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
         El[tid] = a.bias ? a.bias[ch_] : 0.f;
         El[5 * MT + tid] = dsc[ch_] / xs_;
         El[6 * MT + tid] = (a.res_scale && b0 < a.B) ? a.res_scale[(int64_t)b0 * a.rs_bs + (int64_t)g * a.rs_gs + m0 + (int)tid] : 1.f;
+        El[7 * MT + tid] = (a.gate_rowscale && b0 < a.B) ? a.gate_rowscale[(int64_t)b0 * a.gr_bs + (int64_t)g * a.gr_gs + m0 + (int)tid] : 1.f;
         if (a.bnb_slots) {
             const int pr_ = (b0 / a.bnb_Bp) * a.G * Cog + ch_;
             El[MT + tid] = a.bnb_mean[pr_];
@@ -797,9 +798,17 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
                 float gv[8][4];
                 NEF_EPI_FETCH4(a.gate, a.gate_bs, a.gate_gs, gv)
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
+                for (int q = 0; q < 8; ++q) {
+                    if (a.stats_mode == 1) {      // sum_t (ungated output) x gate: the channel scaling's own gradient (nef_chscale_bwd's gs)
+                        const float d0 = live[0] ? fmaf(y[q][0], gv[q][0], y[q][1] * gv[q][1]) : 0.f;
+                        const float d1 = live[1] ? fmaf(y[q][2], gv[q][2], y[q][3] * gv[q][3]) : 0.f;
+                        sv[2 * (q + 8 * h)] = d0 + d1;
+                        sv[2 * (q + 8 * h) + 1] = 0.f;
+                    }
+                    const float gs_ = a.gate_scale * El[7 * MT + erow0 + NEF_ROW(q)];      // (row scale 1 without gate_rowscale)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y[q][e] = gv[q][e] > 0.f ? y[q][e] * a.gate_scale : 0.f;
+                    for (int e = 0; e < 4; ++e) y[q][e] = gv[q][e] > 0.f ? y[q][e] * gs_ : 0.f;
+                }
             }
 #undef NEF_EPI_FETCH4
 #pragma unroll
@@ -883,7 +892,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
                     sv[2 * (q + 8 * h) + 1] = fmaf(g0, (x01[0] - mf) * is, g1 * ((x01[1] - mf) * is)) +
                                               fmaf(g2, (x23[0] - mf) * is, g3 * ((x23[1] - mf) * is));
                 }
-            } else if (a.stats) {
+            } else if (a.stats && a.stats_mode == 0) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const float y0 = live[0] ? y[q][0] : 0.f, y1 = live[0] ? y[q][1] : 0.f;
@@ -942,7 +951,7 @@ int launch_h2(const nef_conv_args& a, hipStream_t st) {
     constexpr int XROW = NTO + K - 1;
     constexpr int P4 = (XROW + 3) / 4 + 1;
     constexpr int PLANE = 4 * P4 * 32;
-    constexpr size_t lds = (size_t)4 * PLANE + (((PRO & 1) ? 2 * PRO_MAX_CIN : 0) + 7 * MT + 4) * sizeof(float);
+    constexpr size_t lds = (size_t)4 * PLANE + (((PRO & 1) ? 2 * PRO_MAX_CIN : 0) + 8 * MT + 4) * sizeof(float);
     static unsigned long long lds_set = 0;
     if (int e = nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_h2_kernel<K, PRO, TM, PACK>), lds, &lds_set)) return e;
     // PACK: `tps` = samples per tile (pitch T + 4; the last sample needs no gap behind it)
@@ -963,7 +972,7 @@ static bool h2_pack_shape(const nef_conv_args* a) {
     if (!(a->T >= 8 && a->T <= 64 && a->T % 4 == 0 && (a->K == 1 || a->K == 3))) return false;
     const int64_t spt = (NTO + 4) / (a->T + 4);
     const int64_t lim = 0x7fffffff / 4;
-    return a->pro_mode == 0 && !a->in_scale && !a->res_scale && !a->stats && !a->bnb_slots && spt * a->x_bs < lim && spt * a->y_bs < lim &&
+    return a->pro_mode == 0 && !a->in_scale && !a->res_scale && !a->gate_rowscale && !a->stats && !a->bnb_slots && spt * a->x_bs < lim && spt * a->y_bs < lim &&
            (!a->res || spt * a->res_bs < lim) && (!a->gate || spt * a->gate_bs < lim);
 }
 
@@ -973,6 +982,7 @@ __attribute__((visibility("hidden"))) bool nef_h2_ok(const nef_conv_args* a) {
            ((a->pro_mode >= 0 && a->pro_mode <= 4) || a->pro_mode == 8 || a->pro_mode == 9) && (a->K == 3 || a->pro_mode == 0) &&
            !(a->pro_mode && a->in_scale) &&
            (!a->res_scale || (a->res && !(a->pro_mode & 8))) &&
+           ((!a->gate_rowscale && a->stats_mode == 0) || (a->gate && !(a->pro_mode & 8) && (a->stats_mode == 0 || (a->stats_mode == 1 && a->stats && !a->bnb_slots)))) &&
            (!(a->pro_mode & 8) || (a->Cout_g % 128 == 0 && a->T >= NTO / 2 && !a->res && !a->gate && !a->mask && !a->relu && a->drop_p <= 0.f &&
                                    !a->bnb_slots && (int64_t)a->Cout_g * a->T * 4 < 0x7fffffff)) &&
            (a->pro_mode != 4 || (a->T >= NTO / 2 && (int64_t)a->Cin_g * a->T * 4 < 0x7fffffff)) &&
@@ -987,7 +997,7 @@ __attribute__((visibility("hidden"))) int nef_h2p_launch(const nef_conv_args* a,
 __attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, hipStream_t st) {
     if (!nef_h2_ok(a)) return NEF_E_SHAPE;
     if ((a->pro_mode & 1) && !(a->pro_a && a->pro_b && a->pro_Bp > 0)) return NEF_E_NULL;
-    if (nef_opt_h2_form() && a->pro_mode <= 3 && !a->res_scale && nef_h2p_ok(a)) return nef_h2p_launch(a, st);
+    if (nef_opt_h2_form() && a->pro_mode <= 3 && !a->res_scale && !a->gate_rowscale && a->stats_mode == 0 && nef_h2p_ok(a)) return nef_h2p_launch(a, st);
     static const bool force_tm1 = nef_diag_env("NEF_H2_TM1") && atoi(nef_diag_env("NEF_H2_TM1")) == 1;      // A/B: 64-channel tile everywhere
     const bool wide = a->Cout_g % 128 == 0 && !force_tm1;
     // the x2-upsampling prologue keeps two source samples per staged position in registers: next to the 128 accumulator

@@ -2438,7 +2438,7 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
     NEF_REQUIRE(!a->bnb_slots || (a->bnb_x && a->bnb_mean && a->bnb_invstd && a->bnb_a && a->bnb_b), NEF_E_NULL);
     NEF_REQUIRE(!a->bnb_slots || a->bnb_Bp > 0, NEF_E_SHAPE);
     NEF_REQUIRE(!a->bnb_slots || !a->bnb_up || a->T % 4 == 0, NEF_E_SHAPE);
-    NEF_REQUIRE(!a->res_scale || a->wino == 3, NEF_E_UNSUPPORTED);
+    NEF_REQUIRE((!a->res_scale && !a->gate_rowscale && a->stats_mode == 0) || a->wino == 3, NEF_E_UNSUPPORTED);
     if (a->wino == 3) {      // operand packed by nef_pack_weight_h2: direct conv on exact fp16 splits (conv_h2.hip)
         NEF_REQUIRE(nef_h2_ok(a), NEF_E_SHAPE);
         return nef_h2_launch(a, st);

@@ -1380,6 +1380,17 @@ __global__ __launch_bounds__(256) void poly_bwd_edge_kernel(const float* __restr
     }
 }
 
+// out[b][c] = sum_s slots[c][b * nslot + s][0]: the per-(sample, channel) sums a conv epilogue left in stats_mode 1
+__global__ __launch_bounds__(256) void slots_to_rows_kernel(const float* __restrict__ slots, int nslot, float* __restrict__ out, int B, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * C) return;
+    const int b = (int)(i / C), c = (int)(i - (int64_t)b * C);
+    const float* p = slots + (((int64_t)c * B + b) * nslot) * 2;
+    float s = 0.f;
+    for (int k = 0; k < nslot; ++k) s += p[2 * k];      // fixed order
+    out[i] = s;
+}
+
 __global__ void h2_taint_kernel(const int32_t* __restrict__ total, int32_t* __restrict__ mark, float* __restrict__ out) {
     const int32_t t = total[0];
     out[0] = (float)(t - mark[0]);
@@ -2053,6 +2064,15 @@ int nef_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, 
     NEF_REQUIRE(n > 0, NEF_E_SHAPE);
     hipLaunchKernelGGL(sgd_kernel, dim3(nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, p, g, buf, n, lr, mu, gscale,
                        first_step, skip_if_positive, skipped, lr_dev);
+    return nef_launch_status();
+}
+
+int nef_slots_to_rows(const float* slots, int nslot, float* out, int B, int C, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(slots && out, NEF_E_NULL);
+    NEF_REQUIRE(nslot > 0 && B > 0 && C > 0, NEF_E_SHAPE);
+    const int64_t n = (int64_t)B * C;
+    hipLaunchKernelGGL(slots_to_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, NEF_ST, slots, nslot, out, B, C);
     return nef_launch_status();
 }
 

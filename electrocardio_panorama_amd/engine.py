@@ -33,6 +33,7 @@ _FUSE_STATS = _env.get("NEF_FUSE_STATS", "1") == "1"
 _BNB_UP = _env.get("NEF_BNB_UP", "1") == "1"
 # NEF_FOLD_CHSCALE=0: the theta scaling in front of w_conv as a pass of its own (chscale_fwd) instead of in_scale / res_scale on the block's convs
 _FOLD_CHSCALE = _env.get("NEF_FOLD_CHSCALE", "1") == "1"
+_FOLD_CHSCALE_BWD = _env.get("NEF_FOLD_CHSCALE_BWD", "1") == "1"      # ... and its backward in the epilogue of the block's last backward-data launch
 
 _BWD_F4 = _env.get("NEF_BWD_F4", "1")
 
@@ -149,7 +150,7 @@ def _side(device, work=None):
     return ops.SideStream.get(device)
 
 
-def block_bwd(saved, gy, P, grads, out=None, side=None, pre_gated=False, gate_input=False):
+def block_bwd(saved, gy, P, grads, out=None, side=None, pre_gated=False, gate_input=False, scale_bwd=False):
     """Accumulates the block's parameter gradients into `grads`; returns the gradient wrt the block input
     (written into the GV `out` when given, e.g. one half of the z1/z2 split).  Weight / bias gradients are issued on
     the side stream: they are off the dependency chain and overlap with the chain's HBM-bound kernels.
@@ -175,7 +176,16 @@ def block_bwd(saved, gy, P, grads, out=None, side=None, pre_gated=False, gate_in
         resv = GV.dense(gres, G)
     else:
         resv = g2v
-    return ops.conv(gc1v, ops.pack_weight(P[prefix + ".conv1.weight"], G, flip=True, T=xv.T, f4=_bwd_f4(K)), Cig, K, res=resv,
+    wp1f = ops.pack_weight(P[prefix + ".conv1.weight"], G, flip=True, T=xv.T, f4=_bwd_f4(K))
+    if in_scale is not None and scale_bwd and int(getattr(wp1f, "nef_wino", 0)) == 3 and out is None:
+        # the channel scaling's own backward in this launch's epilogue (ops.chscale_bwd with relu_x): the gradient wrt the UNSCALED
+        # input, masked where that input (a ReLU output) is zero, and the per-(sample, channel) sums of (gradient x input)
+        slots = ops.conv_stats_buffer(wp1f, xv.B, G, Cig, xv.T, xv.t.device)
+        if slots is not None:
+            gx = ops.conv(gc1v, wp1f, Cig, K, res=resv, gate=xv, gate_scale=1.0, gate_rowscale=in_scale, stats=slots, stats_mode=1,
+                          role="conv_bwd_data")
+            return gx, ops.slots_to_rows(slots, xv.B)
+    return ops.conv(gc1v, wp1f, Cig, K, res=resv,
                     out=out, gate=xv if gate_input else None, gate_scale=1.0, role="conv_bwd_data")
 
 
@@ -688,8 +698,11 @@ def _latents_bwd(P, sv, gz1, gz2r, grads, side, z1_pre_gated=False, early=False)
     else:
         gz2c = ops.roi_align_bwd(gh0.view(B, 128 * V, N_SEG, ROI_BINS), sv["rois"], T)
         block_bwd(sv["blk_z2c"], gz2c, P, grads, out=GV.half(genc, V, 1), side=side, gate_input=True)
-    gew = block_bwd(sv["blk_w_conv"], genc, P, grads, side=side, pre_gated=True)
-    g, ge = ops.chscale_bwd(gew, sv["w"], sv["e"], relu_x=True)      # sv["w"]: ReLU output of the last encoder block
+    gew = block_bwd(sv["blk_w_conv"], genc, P, grads, side=side, pre_gated=True, scale_bwd=_FOLD_CHSCALE_BWD)
+    if isinstance(gew, tuple):      # the scaling's backward came out of the block's last launch (block_fwd(..., in_scale=...) + scale_bwd)
+        g, ge = gew
+    else:
+        g, ge = ops.chscale_bwd(gew, sv["w"], sv["e"], relu_x=True)      # sv["w"]: ReLU output of the last encoder block
     gW1, gb1 = side.run(lambda: ops.theta_mlp_bwd(sv["in_theta"], ge, 128), ge)
     grads["mlp1.weight"], grads["mlp1.bias"] = gW1, gb1
     if early:      # data parallel: everything but the encoder blocks' gradients is final -- start summing it across ranks now

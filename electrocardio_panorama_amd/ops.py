@@ -513,7 +513,7 @@ def bn_stats_from_slots(stats, gamma, beta, running_mean, running_var, P, N, Ln,
 
 def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None, gate_scale=1.0, relu=False,
          mask=None, drop_p=0.0, drop_scale=1.0, seed=0, role="conv_fwd", pro=None, seed_dev=None, stats=None, bnb=None,
-         x_scale=0.0, tag_extra="", res_scale=None):
+         x_scale=0.0, tag_extra="", res_scale=None, gate_rowscale=None, stats_mode=0):
     """out = epilogue(conv1d(prologue(x) * in_scale, w) + bias + res * res_scale).  `xv`, `res`, `gate`, `out` are GV views;
     `in_scale` / `res_scale` are (tensor, batch_stride, group_stride).  `pro` = (mode, a, b, Bp): input prologue applied while
     staging -- bit0 BatchNorm affine + ReLU with a/b [P, C_in], bit1 x2 linear upsampling of a half-resolution input
@@ -538,6 +538,10 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
     a.x_bs, a.x_gs, a.y_bs, a.y_gs = xv.bs, xv.gs, out.bs, out.gs
     if res is not None:
         a.res_bs, a.res_gs = res.bs, res.gs
+    if gate_rowscale is not None:      # y = gate > 0 ? y * gate_scale * gate_rowscale[b, g, c] : 0 (split-fp16 launches only)
+        assert gate is not None
+        a.gate_rowscale, a.gr_bs, a.gr_gs = _p(gate_rowscale[0]), gate_rowscale[1], gate_rowscale[2]
+    a.stats_mode = int(stats_mode)      # 1: `stats` receives sum_t (ungated output) x gate per slot (chscale_bwd's per-channel sums)
     if res_scale is not None:      # (tensor, batch stride, group stride) like in_scale: y += res * res_scale[b, g, c]; split-fp16 launches only
         assert res is not None
         a.res_scale, a.rs_bs, a.rs_gs = _p(res_scale[0]), res_scale[1], res_scale[2]
@@ -948,6 +952,14 @@ def chscale_fwd(x, s, s_bs=None):
     _lib.check(L.nef_chscale_fwd(_p(x), _p(s), Ct if s_bs is None else s_bs, _p(y), B, Ct, T, _stream()), "nef_chscale_fwd")
     _done(ev)
     return y
+
+
+def slots_to_rows(slots, B):
+    """[B, C] per-(sample, channel) sums of the word-0 slot values a conv epilogue left (conv(..., stats=..., stats_mode=1))."""
+    sl, nslot = slots
+    out = torch.empty(B, sl.shape[0], device=sl.device, dtype=torch.float32)
+    _lib.check(_lib.load().nef_slots_to_rows(_p(sl), nslot, _p(out), B, sl.shape[0], _stream()), "nef_slots_to_rows")
+    return out
 
 
 def chscale_bwd(gy, x, s, s_bs=None, relu_x=False):

@@ -189,6 +189,14 @@ typedef struct nef_conv_args {
                               channel-scaled tensor (w_conv behind the theta scaling, codes/network/model_nefnet.py:122-124) read
                               from the UNSCALED tensor, with in_scale on the block's first conv: the scaled tensor is never written */
     int64_t rs_bs, rs_gs;
+    const float* gate_rowscale;   /* wino == 3, gate != NULL: NULL, or a per-(sample, channel) factor on the gated output,
+                              y = gate > 0 ? y * gate_scale * gate_rowscale[b*gr_bs + g*gr_gs + c] : 0 -- the backward of the same
+                              channel scaling (nef_chscale_bwd's gx) taken in the epilogue of the block's last backward-data launch */
+    int64_t gr_bs, gr_gs;
+    int32_t stats_mode;    /* what `stats` receives: 0 = per-slot sum and sum of squares of the outputs; 1 (wino == 3, gate != NULL) =
+                              per-slot sum of (ungated, unscaled output) x gate in word 0, 0 in word 1 -- nef_chscale_bwd's gs[b][c]
+                              = sum_t gy x, finished by nef_slots_to_rows */
+    int32_t reserved1;
 } nef_conv_args;
 
 /* y = epilogue(conv(x * in_scale, wp) + bias + res).  Also the bwd-data pass (pack with transpose_flip=1,
@@ -481,6 +489,8 @@ int nef_h2_taint(const int32_t* clamped_total, int32_t* mark, float* out, nef_st
  * full-resolution gradient [B][G Cog][T] read as 2 Cog phase channels of length T / 2), weights = wsyn packed transposed / flipped,
  * output = the gradient wrt the half-resolution input; then nef_poly_bwd_edge adds the two row-end terms the phase form leaves out
  * (and their share of the BatchNorm-backward sums, into slot 0 of the sample: bnb_* as in nef_conv_args, NULL slots = none). */
+/* out[b][c] = sum over the nslot slots of sample b of slots[c][b*nslot + s][0] (the word-0 sums a conv epilogue left, stats_mode 1). */
+int nef_slots_to_rows(const float* slots, int nslot, float* out, int B, int C, nef_stream_t stream);
 int nef_poly_weights(const float* w, float* wsyn, int rows, int Cig, int tile_Cr /* 0, or the channels per group (a multiple of 64):
                      rows in the TILE order of the polyphase forward launch, phase p of channel co of group g = row
                      g 2 Cr + (co / 64) 128 + ((co / 32) & 1) 64 + p 32 + co % 32 */, nef_stream_t stream);

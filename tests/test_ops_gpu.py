@@ -669,6 +669,21 @@ def test_conv_h2_channel_scaled_block_input(B, G, C, T):
     gw_a = o.conv_bwd_weight(GV.dense(xs, G), GV.dense(h_a, G), 3)
     gw_b = o.conv_bwd_weight(GV.dense(x, G), GV.dense(h_a, G), 3, in_scale=sc)
     assert rel(gw_b, gw_a) < 1e-6
+    # ... and the scaling's backward in the epilogue of the block's last backward-data launch: gate by the (ReLU-output) input,
+    # row scale e, per-(sample, channel) sums of (gradient x input) through the slots -- against ops.chscale_bwd on the materialised
+    # gradient
+    xr = torch.relu(x)
+    gc, g2 = g(rnd(B, G * C, T, seed=1234, scale=1e-3)), g(rnd(B, G * C, T, seed=1235, scale=1e-3))
+    wpf = o.pack_weight(w1, G, flip=True, T=T, plain=False)
+    gew = o.conv(GV.dense(gc, G), wpf, C, 3, res=GV.dense(g2, G), role="conv_bwd_data", x_scale=2.0 ** 16)
+    want_g, want_s = o.chscale_bwd(gew, xr, e.reshape(B, G * C), relu_x=True)
+    slots = o.conv_stats_buffer(wpf, B, G, C, T, x.device)
+    slots[0].fill_(float("nan"))
+    got_g = o.conv(GV.dense(gc, G), wpf, C, 3, res=GV.dense(g2, G), role="conv_bwd_data", x_scale=2.0 ** 16, gate=GV.dense(xr, G),
+                   gate_rowscale=sc, stats=slots, stats_mode=1)
+    got_s = o.slots_to_rows(slots, B)
+    assert torch.equal(got_g, want_g)
+    assert rel(got_s, want_s) < 2e-6
 
 
 @pytest.mark.parametrize("B,G,Cog,Cig,T,aff", [(6, 1, 64, 128, 1000, True), (3, 1, 64, 128, 520, False), (6, 2, 128, 128, 512, False),
