@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true",
                     help="issue every launch of the timed steps from Python instead (what the per-kernel breakdown steps always do)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[3] / configs[4] inference timings")
+    ap.add_argument("--dry-collective", type=int, default=0, metavar="N",
+                    help="ONE-GPU run of the N-rank data-parallel graphed step with the gradient all-reduces replaced by device-side "
+                         "stand-ins of their modelled xGMI duration (parallel.DryCollective): reports allreduce_ms_exposed for the "
+                         "two-graph and the one-graph schedule next to the collective-free step; prints its own JSON line")
     return ap.parse_args()
 
 
@@ -107,8 +111,8 @@ def cpu_baseline(V, L, B, steps, pools):
             "one_thread_samples_per_s": one[0]["samples_per_s"] if one else None}
 
 
-def secondary(dev):
-    """BASELINE configs[3] and configs[4] on one GPU, through the fp16 panorama decoder (Model_nefnet.panorama_dtype =
+def secondary(dev, headline=None):
+    """`headline` = (V, B, L, dropout) of the timed workload: its strict-fp32 leg (strict_fp32) runs first.  BASELINE configs[3] and configs[4] on one GPU, through the fp16 panorama decoder (Model_nefnet.panorama_dtype =
     'fp16'; encoder, ROI path and angular encoding stay fp32).  configs[3]: eval-mode sweep, 1 view in -> 360 queried
     angles, batch 1024, L=512 (reference model_nefnet.py:181-192); configs[4]: gen_ecg on one GPU's share of the global
     batch 4096 = 512 samples x 3 leads x 12 angles, L=5000 (model_nefnet.py:196-218).  Inputs resident in HBM, random-init
@@ -125,6 +129,11 @@ def secondary(dev):
                 "hbm_frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 4), "mfma_frac": round(flops / dt / 1e12 / FP16_MFMA_PEAK_TFLOPS, 4)}
 
     out = {}
+    if headline is not None:
+        try:
+            out["strict_fp32"] = strict_fp32(dev, *headline)
+        except Exception as exc:
+            out["strict_fp32"] = {"error": f"{type(exc).__name__}: {exc}"}
     out["reference-native 32x3x512"] = native_shape(dev)
     # configs[3]
     B, V, L, Q = 1024, 1, 512, 360
@@ -175,6 +184,47 @@ def secondary(dev):
     return out
 
 
+def strict_fp32(dev, V, B, L, steps=5, warmup=2, dropout=True):
+    """The headline workload once more with EVERY conv on the fp32 matrix-core kernels (what NEF_H2=0 selects: Winograd / direct
+    forms of conv_mfma.hip, IEEE fp32 products and accumulation -- the reference's own arithmetic, model_nefnet.py:18-21), same
+    process, after the headline: the strict-fp32 figure is driver-timed every round next to the fp32-class one."""
+    from electrocardio_panorama_amd import ops, synth
+    from electrocardio_panorama_amd.graph import GraphedTrainStep
+    from electrocardio_panorama_amd.network import build_model
+    from electrocardio_panorama_amd.solver.optim_scheduler import get_optimizer
+    from electrocardio_panorama_amd.utils import seed_torch
+    cfg = make_cfg(V)
+    saved, ops.H2 = ops.H2, False
+    try:
+        seed_torch(cfg.seed)
+        model = build_model(cfg).float().to(dev).train()
+        if not dropout:
+            model.dropout_p = 0.0
+        optim = get_optimizer(cfg, model.parameters())
+        meta = synth.make_batch(B, V, L, seed=123)
+        data, rois, in_theta, tgt_view, tgt_theta = (torch.from_numpy(np.ascontiguousarray(meta[k])).to(dev) for k in
+                                                     ("data", "rois", "input_theta", "target_view", "target_theta"))
+        tgt_view = tgt_view.unsqueeze(1)
+        g = GraphedTrainStep(model, cfg, optimizer=optim)
+        for _ in range(warmup):
+            loss = g(data, in_theta, tgt_theta, rois, tgt_view)[0]
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = g(data, in_theta, tgt_theta, rois, tgt_view)[0]
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        res = {"workload": f"{_config_name(V, B, L)} with every conv on the fp32 matrix-core kernels (NEF_H2=0), graph-replayed",
+               "dtype": "f32 (IEEE fp32 products and accumulation, v_mfma_f32_32x32x2_f32; Winograd F(2,.)/F(4,.) forms where the "
+                        "shape allows)", "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 3),
+               "samples_per_s": round(B / dt, 1), "final_loss": float(loss)}
+        del model, optim, g
+    finally:
+        ops.H2 = saved
+    torch.cuda.empty_cache()
+    return res
+
+
 def native_shape(dev, steps=40, warmup=10):
     """The only shape the reference itself trains (codes/config/nef_net.yml:8-13, codes/train_net.py:27-28: batch 32, 3 leads,
     beats of 512 samples): the train step eager and replayed as one captured hipGraph (graph.GraphedTrainStep -- what
@@ -223,6 +273,66 @@ def native_shape(dev, steps=40, warmup=10):
     return res
 
 
+def dry_collective(args, dev):
+    """bench.py --dry-collective N [--leads 8]: what the overlap logic of the data-parallel graphed step does at the real step
+    length, on one GPU.  Three schedules of the same shard, each captured and timed on its own: no collective at all; the
+    two-graph schedule (graph A | early bucket's all-reduce under graph B | encoder bucket exposed); the one-graph schedule (one
+    fully exposed all-reduce behind the replay).  The collectives are parallel.DryCollective stand-ins: a few workgroups kept busy
+    on the communication stream for 2 (N-1)/N S / 153 GB/s + 20 us -- the MODELLED ring all-reduce over xGMI (SURVEY.md section 5);
+    no multi-GPU node was available to the build, so this is the overlap exercised, not a scaling measurement."""
+    from electrocardio_panorama_amd import parallel, synth
+    from electrocardio_panorama_amd.graph import GraphedTrainStep
+    from electrocardio_panorama_amd.network import build_model
+    from electrocardio_panorama_amd.solver.optim_scheduler import get_optimizer
+    from electrocardio_panorama_amd.utils import seed_torch
+    V, L, B, N = args.leads, args.length, args.batch, args.dry_collective
+    cfg = make_cfg(V)
+    meta = synth.make_batch(B, V, L, seed=123)
+    data, rois, in_theta, tgt_view, tgt_theta = (torch.from_numpy(np.ascontiguousarray(meta[k])).to(dev) for k in
+                                                 ("data", "rois", "input_theta", "target_view", "target_theta"))
+    tgt_view = tgt_view.unsqueeze(1)
+    res = {}
+    for name in ("no_collective", "two_graph", "one_graph"):
+        seed_torch(cfg.seed)
+        model = build_model(cfg).float().to(dev).train()
+        optim = get_optimizer(cfg, model.parameters())
+        g = GraphedTrainStep(model, cfg, optimizer=optim)
+        dry = None
+        if name != "no_collective":
+            dry = g.dry = parallel.DryCollective(N)
+            g.dp, g.split_capture = True, name == "two_graph"
+        for _ in range(args.warmup):
+            g(data, in_theta, tgt_theta, rois, tgt_view)
+        torch.cuda.synchronize(dev)
+        parallel.TIMING = [] if dry is not None else None
+        if dry is not None:
+            dry.calls.clear()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = g(data, in_theta, tgt_theta, rois, tgt_view)[0]
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / args.steps
+        ev, parallel.TIMING = parallel.TIMING or [], None
+        res[name] = {"ms_per_step": round(dt * 1e3, 3), "samples_per_s_per_gpu": round(B / dt, 1), "final_loss": float(loss)}
+        if dry is not None:
+            per_step = dry.calls[:len(dry.calls) // max(args.steps, 1)]
+            res[name].update(allreduce_ms_exposed=round(sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1), 4),
+                             collectives_per_step=[{"bytes": b_, "modelled_ms": round(m_, 4)} for b_, m_ in per_step])
+        del model, optim, g
+        torch.cuda.empty_cache()
+    base = res["no_collective"]["ms_per_step"]
+    for name in ("two_graph", "one_graph"):
+        res[name]["step_overhead_ms_vs_no_collective"] = round(res[name]["ms_per_step"] - base, 3)
+    print(json.dumps({
+        "mode": "dry-collective (ONE GPU; modelled all-reduce durations, not a multi-GPU measurement)", "modelled_ranks": N,
+        "model": f"ring all-reduce over xGMI, per-link bound: 2 (N-1)/N S / {parallel.DryCollective.LINK_GBPS} GB/s + "
+                 f"{parallel.DryCollective.LATENCY_US} us per collective (SURVEY.md section 5)",
+        "config": {"workload": f"{_config_name(V, B, L)}: Nef-Net train step, {V}-lead len={L}, batch={B}/GPU, graph-replayed"},
+        "steps": args.steps, "warmup": args.warmup, "schedules": res,
+        "exposed_basis": "HIP events on the launching stream around everything it waits for behind the last graph replay (the "
+                         "encoder bucket's collective + what is left of the early bucket's)"}), flush=True)
+
+
 def _config_name(V, B, L):
     """Which BASELINE.json config the per-GPU shape is."""
     return {(3, 256, 5000): "configs[1]", (8, 256, 5000): "configs[2] (per-GPU shard)", (1, 4, 2048): "configs[0]"}.get(
@@ -263,6 +373,10 @@ def main():
         raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} HIP device(s) are visible")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if args.dry_collective > 1:
+        if world != 1:
+            raise SystemExit("--dry-collective models the collectives of an N-rank job on ONE GPU: run it with --gpus 1")
+        return dry_collective(args, dev)
     V, L, B = args.leads, args.length, args.batch
     cfg = make_cfg(V)
     seed_torch(cfg.seed)                       # identical init and Standin lead choices on every rank
@@ -428,6 +542,20 @@ def main():
                 # NOT measured by this run: replayed from the committed rocprofv3 --pmc pass (separate run, as the
                 # counters cannot be collected together with timing)
                 traffic_source = ("replayed from " + tj.get("source", "profiles/traffic.json")) if traffic else None
+                # counter bytes / algorithmic bytes: the dominant kernel, and the most-launched K = 3 form (conv_h2_kernel<3, 0, 2>:
+                # its launches differ in shape, so the ratio uses the launch-weighted mean of their algorithmic bytes)
+                if traffic:
+                    roof["traffic_ratio"] = round(traffic / roof["algorithmic_bytes_per_launch"], 3)
+                k3 = [v for k_, v in tj.get("by_kernel", {}).items() if k_.startswith("conv_h2_kernel<3, 0, 2")]
+                # launches of that kernel form: K = 3, 128-row tile, no input prologue (plain, phase-major gradient, BatchNorm-backward
+                # epilogue, and the affine-less polyphase backward over the phase-stacked input is <3, 4, 2>: not this form)
+                tags3 = [(tg, len(v)) for tg, v in serial.items() if tg[0] in ("conv_fwd", "conv_bwd_data") and tg[1] == 3 and
+                         tg[4] % 128 == 0 and tg[6] >= 128 and (tg[7] if len(tg) > 7 else "") in ("", "pm", "bnb", "pmbnb")]
+                if k3 and tags3 and ops.H2:
+                    alg3 = sum(price(tg, 1.0)["algorithmic_bytes_per_launch"] * n_ for tg, n_ in tags3) / sum(n_ for _, n_ in tags3)
+                    roof["traffic_ratio_k3"] = {"kernel": "conv_h2_kernel<3, 0, 2>", "counter_bytes_per_launch": k3[0],
+                                                "algorithmic_bytes_per_launch_mean": round(alg3), "ratio": round(k3[0] / alg3, 3),
+                                                "source": traffic_source or ("replayed from " + tj.get("source", "profiles/traffic.json"))}
             # effective clock and matrix-pipe occupancy of the dominant kernel: from the committed SQ / GRBM counter pass (a separate
             # rocprofv3 --pmc run, profiles/sq_k7.json) -- tells a pipe that idles from a chip that clocks down under the load:
             # `peak` assumes 2.4 GHz and a pipe that never waits
@@ -487,12 +615,20 @@ def main():
                      for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1]) if v[1] > 0}
         breakdown = {"/".join(str(x) for x in k): round(sum(v) / extra_steps, 3) for k, v in sorted(
             by_kernel.items(), key=lambda kv: -sum(kv[1]))[:12]}
+        # every tagged conv launch of a step (single-stream breakdown steps): launches, time per launch, binding floor and fraction
+        conv_table = {}
+        for tg, v in sorted(serial.items(), key=lambda kv: -sum(kv[1])):
+            pr = price(tg, sum(v) / len(v))
+            conv_table["/".join(str(x) for x in tg)] = {
+                "launches": len(v) // max(extra_steps, 1), "ms_per_launch": round(sum(v) / len(v), 4),
+                "ms_per_step": round(sum(v) / max(extra_steps, 1), 3), "floor_ms": pr["floor_ms"], "bound": pr["bound"],
+                "mfma_floor_ms": pr["mfma_floor_ms"], "hbm_floor_ms": pr["hbm_floor_ms"], "frac": pr["frac"]}
         sec = None
         if world == 1 and not args.no_secondary:
             del model, optim, data, loss, final_loss_t
             torch.cuda.empty_cache()
             try:
-                sec = secondary(dev)
+                sec = secondary(dev, (V, B, L, not args.no_dropout) if ops.H2 else None)
             except Exception as exc:  # the headline stays valid; the failure is visible in the line
                 sec = {"error": f"{type(exc).__name__}: {exc}"}
         cpu = None
@@ -507,7 +643,10 @@ def main():
                                    f"3-view-in -> 1-view-out, Standin losses on, dropout "
                                    f"{'off' if args.no_dropout else 'on'}",
                        "global_batch": world * B, "seq_len": L, "leads": V, "parallelism": f"dp{world}"},
-            "roofline": roof, "cpu_baseline": cpu, "final_loss": final_loss, "conv_ms_per_step": breakdown,
+            "roofline": roof, "cpu_baseline": cpu, "final_loss": final_loss, "conv_ms_per_step": breakdown, "conv_launches": conv_table,
+            "conv_launches_note": "every tagged conv launch of one step, each timed alone (single-stream breakdown steps): launches per "
+                                  "step, ms per launch, max(matrix floor, HBM floor) and floor / time; tag = role/K/groups/Cin_g/Cout_g/"
+                                  "batch/T[/prologue]",
             "hbm_bound": hbm_bound, "hbm_bound_schedule": "single stream, every launch alone (untimed breakdown steps)",
             "hbm_bound_notes": {"stem_bwd_weight": "listed for its traffic only: 2 x 28.8 MFLOP over 1.98 MB per sample = 29 FLOP/B, "
                                                    "above the 19.7 FLOP/B ridge -- fp32-compute-bound, runs its two GEMMs on the "

@@ -170,6 +170,7 @@ def load():
         fn = getattr(lib, name)        # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    lib.nef_debug_spin_us.restype, lib.nef_debug_spin_us.argtypes = i32, [f32, i32, p]      # diagnostics, not in the header
     if lib.nef_conv_args_bytes() != C.sizeof(ConvArgs):      # a stale .so next to a newer binding (or the reverse)
         raise NefLibraryError(f"{LIB_PATH}: nef_conv_args is {lib.nef_conv_args_bytes()} bytes, the binding mirrors "
                               f"{C.sizeof(ConvArgs)}; rebuild with `python -m electrocardio_panorama_amd.csrc.build`")

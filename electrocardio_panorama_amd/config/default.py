@@ -42,8 +42,9 @@ _DEFAULTS = {
         "loss_using": [1, 2, 3],
         "part_loss_no_grad": False,
         "loss_factor": [1, 1, 1],
-        # train step as one captured hipGraph (graph.GraphedTrainStep): None = automatic, i.e. when the step is bound by launch
-        # issue (fewer than 2^24 latent elements B*128V*L/4 -- the reference's own batch 32 x 512 samples is); True / False force it
+        # train step as one captured hipGraph (graph.GraphedTrainStep): None / 'auto' = replay at EVERY batch size wherever the step
+        # qualifies (plain Model_nefnet train path, FusedSGD with one parameter group, no DATA.noise, per-view host lists not
+        # wanted: Solver._graphed_step; rounds 1-3 replayed launch-bound shapes only); False = always issue eagerly; True = as auto
         "graph": None,
     },
 }

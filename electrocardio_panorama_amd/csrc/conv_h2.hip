@@ -989,15 +989,45 @@ __attribute__((visibility("hidden"))) bool nef_h2_ok(const nef_conv_args* a) {
            (!(a->pro_mode & 1) || a->Cin_g <= PRO_MAX_CIN);
 }
 
-// the producer / consumer form (conv_h2p.hip)
-__attribute__((visibility("hidden"))) int nef_opt_h2_form();
-__attribute__((visibility("hidden"))) bool nef_h2p_ok(const nef_conv_args* a);
-__attribute__((visibility("hidden"))) int nef_h2p_launch(const nef_conv_args* a, hipStream_t st);
+// Kernel-form options of the process (nef_set_option / nef_get_option; under NEF_DIAG=1 the environment gives the initial values:
+// NEF_H2P, NEF_H2P_WGS).  The producer / consumer form they select (tools/experiments/conv_h2p.hip: bit-identical, measured slower,
+// DESIGN.md 3.0a) is only linked into builds made with `csrc/build.py --with-experiments`: the two hooks below are weak, and a
+// library without them keeps every launch on conv_h2_kernel whatever the option says.
+static int g_opt[4] = {0, -1, -1, 0};
+static void opt_init() {
+    if (__atomic_load_n(&g_opt[0], __ATOMIC_ACQUIRE)) return;
+    const char* e1 = nef_diag_env("NEF_H2P");
+    const char* e2 = nef_diag_env("NEF_H2P_WGS");
+    int v1 = e1 ? atoi(e1) : 0, v2 = e2 ? atoi(e2) : 1;
+    int neg = -1;
+    __atomic_compare_exchange_n(&g_opt[NEF_OPT_H2_FORM], &neg, v1, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+    neg = -1;
+    __atomic_compare_exchange_n(&g_opt[NEF_OPT_H2P_WGS], &neg, v2, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+    __atomic_store_n(&g_opt[0], 1, __ATOMIC_RELEASE);
+}
+__attribute__((visibility("hidden"))) int nef_opt_get(int key) {
+    opt_init();
+    return __atomic_load_n(&g_opt[key], __ATOMIC_RELAXED);
+}
+extern "C" {
+int nef_set_option(int key, int value) {
+    if (key != NEF_OPT_H2_FORM && key != NEF_OPT_H2P_WGS) return NEF_E_SHAPE;
+    opt_init();
+    return __atomic_exchange_n(&g_opt[key], value, __ATOMIC_RELAXED);
+}
+int nef_get_option(int key) {
+    if (key != NEF_OPT_H2_FORM && key != NEF_OPT_H2P_WGS) return NEF_E_SHAPE;
+    return nef_opt_get(key);
+}
+}
+__attribute__((weak, visibility("hidden"))) bool nef_h2p_ok(const nef_conv_args* a);
+__attribute__((weak, visibility("hidden"))) int nef_h2p_launch(const nef_conv_args* a, hipStream_t st);
 
 __attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, hipStream_t st) {
     if (!nef_h2_ok(a)) return NEF_E_SHAPE;
     if ((a->pro_mode & 1) && !(a->pro_a && a->pro_b && a->pro_Bp > 0)) return NEF_E_NULL;
-    if (nef_opt_h2_form() && a->pro_mode <= 3 && !a->res_scale && !a->gate_rowscale && a->stats_mode == 0 && nef_h2p_ok(a)) return nef_h2p_launch(a, st);
+    if (&nef_h2p_launch && &nef_h2p_ok && nef_opt_get(NEF_OPT_H2_FORM) && a->pro_mode <= 3 && !a->res_scale && !a->gate_rowscale && a->stats_mode == 0 && nef_h2p_ok(a))
+        return nef_h2p_launch(a, st);
     static const bool force_tm1 = nef_diag_env("NEF_H2_TM1") && atoi(nef_diag_env("NEF_H2_TM1")) == 1;      // A/B: 64-channel tile everywhere
     const bool wide = a->Cout_g % 128 == 0 && !force_tm1;
     // the x2-upsampling prologue keeps two source samples per staged position in registers: next to the 128 accumulator

@@ -1193,6 +1193,14 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     }
 }
 
+// Diagnostics (bench.py --dry-collective): occupy `wgs` workgroups for `ticks` of the constant-rate wall clock -- a stand-in for a
+// collective of modelled duration on the communication stream of a ONE-GPU run (the all-reduce it replaces would hold a few CUs
+// of channel kernels for that long).  Bounded: the host side caps the duration at 50 ms.
+__global__ __launch_bounds__(64) void debug_spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Polyphase form of conv1d(upsample2(x), w), K = 3.  Output 2 m + p of that conv is a K = 3 conv of the
 // HALF-resolution x with the phase weights W'_p (taps on x[m - 1], x[m], x[m + 1]):
@@ -2125,6 +2133,18 @@ int nef_poly_bwd_edge(const float* gy, const float* w, float* gx, int B, int G, 
     NEF_REQUIRE(!bnb_slots || (bnb_x && bnb_mean && bnb_invstd && bnb_a && bnb_b && bnb_Bp > 0 && nslot > 0), NEF_E_NULL);
     hipLaunchKernelGGL(poly_bwd_edge_kernel, dim3((unsigned)(B * G)), dim3(256), (size_t)4 * Cog * sizeof(float), NEF_ST, gy, w, gx, B, G,
                        Cog, Cig, T, bnb_x, bnb_mean, bnb_invstd, bnb_a, bnb_b, bnb_Bp, bnb_slots, nslot, gy_phase_major);
+    return nef_launch_status();
+}
+
+// diagnostics (not in the header): `wgs` workgroups busy for `us` microseconds on `stream` (bench.py --dry-collective)
+int nef_debug_spin_us(float us, int wgs, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(us >= 0.f && us <= 50000.f && wgs >= 1 && wgs <= 64, NEF_E_SHAPE);
+    int dev = 0, khz = 100000;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    const unsigned long long ticks = (unsigned long long)((double)us * 1e-3 * (double)khz);
+    hipLaunchKernelGGL(debug_spin_kernel, dim3((unsigned)wgs), dim3(64), 0, NEF_ST, ticks);
     return nef_launch_status();
 }
 

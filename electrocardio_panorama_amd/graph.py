@@ -57,8 +57,14 @@ class GraphedTrainStep:
         from . import parallel as _par
         self.dp = self.world > 1 or (dist.is_available() and dist.is_initialized() and _par._hook("NEF_DIST_FORCE") == "1")
         # data parallel: capture the step as two graphs with the early gradient bucket's all-reduce between them (_capture_split)
-        import os
         self.split_capture = _env.get("NEF_GRAPH_SPLIT", "1") != "0"
+        # bench.py --dry-collective: a parallel.DryCollective standing in for dist.all_reduce on a one-GPU box (set `dp` with it)
+        self.dry = None
+
+    def _all_reduce(self, t, async_op=False):
+        if self.dry is not None:
+            return self.dry(t, async_op)
+        return dist.all_reduce(t, async_op=async_op)
 
     # -------------------------------------------------------------------------------------------------
     def _flatten(self, live):
@@ -87,8 +93,9 @@ class GraphedTrainStep:
         n = sum(named[k].numel() for k in live)
         dev = self.data.device
         self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)
-        self.flat_g_all = torch.zeros(n + 1, device=dev, dtype=torch.float32)      # [taint word | gradients] (FusedSGD._build)
-        self.flat_g = self.flat_g_all[1:]
+        from .solver.optim_scheduler import GRAD_HDR
+        self.flat_g_all = torch.zeros(n + GRAD_HDR, device=dev, dtype=torch.float32)      # [header: taint word + 3 zeros | gradients] (FusedSGD._build)
+        self.flat_g = self.flat_g_all[GRAD_HDR:]
         self.flat_buf = torch.zeros(n, device=dev, dtype=torch.float32)
         if old_buf is not None and old_live == live:       # parameters were re-pointed from outside: keep the momentum
             self.flat_buf.copy_(old_buf)
@@ -322,18 +329,18 @@ class GraphedTrainStep:
             cur = torch.cuda.current_stream()
             self._comm.wait_stream(cur)
             with torch.cuda.stream(self._comm):        # the suffix bucket travels while graph B (the encoder's backward pass) runs
-                work = dist.all_reduce(self.flat_g[split:], async_op=True)
+                work = self._all_reduce(self.flat_g[split:], async_op=True)
             gB.replay()
             if ev is not None:
                 ev[0].record()
-            dist.all_reduce(self.flat_g_all[:1 + split])       # the encoder bucket, the taint word in front of it
+            self._all_reduce(self.flat_g_all[:self.flat_g_all.numel() - self.flat_g.numel() + split])       # the encoder bucket, the header (taint word) in front of it
             work.wait()
             cur.wait_stream(self._comm)
         else:
             slot["graph"].replay()
             if ev is not None:
                 ev[0].record()
-            dist.all_reduce(self.flat_g_all)                   # one fully exposed all-reduce (NEF_GRAPH_SPLIT=0)
+            self._all_reduce(self.flat_g_all)                  # one fully exposed all-reduce (NEF_GRAPH_SPLIT=0)
         if ev is not None:
             ev[1].record()
             parallel.TIMING.append(ev)

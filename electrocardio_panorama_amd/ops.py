@@ -343,9 +343,18 @@ def h2_skipped(reset=True):
 
 def h2_taint(out):
     """out[0] (a one-element fp32 device view, e.g. the word in front of the flat gradient buffer) = the number of waves that clamped
-    since the previous call; stream-ordered, capturable.  The optimiser passes the word to sgd_momentum(skip=...)."""
+    since the previous call (or h2_rebase); stream-ordered, capturable.  The optimiser passes the word to sgd_momentum(skip=...).
+    ONE call per optimiser step: the call advances the mark, so a second parameter group must reuse the first one's word."""
     st = _amax_state(out.device)
     _lib.check(_lib.load().nef_h2_taint(_p(st["clamped"]), _p(st["mark"]), _p(out), _stream()), "nef_h2_taint")
+
+
+def h2_rebase(device=None):
+    """The taint mark := the clamp counter (stream-ordered): clamps counted so far -- a test-phase forward, gen_ecg between train
+    steps -- are not charged to the next train step.  Solver calls it where it has just read (and judged) the counters."""
+    for dev, st in _AMAX.items():
+        if device is None or torch.device(device) == dev:
+            st["mark"].copy_(st["clamped"])
 
 
 def _amax_index(st, site, n):

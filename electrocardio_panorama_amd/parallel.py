@@ -174,6 +174,48 @@ class _Null:
         return False
 
 
+class DryCollective:
+    """bench.py --dry-collective N: stands in for the gradient all-reduce of an N-rank job on a ONE-GPU box (no multi-GPU node was
+    available to the build).  Called like dist.all_reduce(tensor, async_op=...): instead of communicating it keeps a few workgroups
+    busy on the current stream for the MODELLED duration of a ring all-reduce over xGMI (per-link bound,
+    2 (N-1)/N S / 153 GB/s, + a fixed launch latency), so the overlap logic of the graphed data-parallel step -- graph A, the early
+    bucket under graph B, the exposed encoder bucket -- is exercised at the real step length.  The gradients are left as they are
+    (a one-rank sum)."""
+    LINK_GBPS = 153.0       # one xGMI link, SURVEY.md section 5
+    LATENCY_US = 20.0       # fixed cost of one collective launch (kernel launch + ring set-up), assumed
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def __init__(self, ranks, wgs=8):
+        self.ranks, self.wgs, self.calls = int(ranks), int(wgs), []
+
+    def ms(self, nbytes):
+        n = self.ranks
+        return (2.0 * (n - 1) / n * nbytes / (self.LINK_GBPS * 1e9)) * 1e3 + self.LATENCY_US * 1e-3
+
+    def __call__(self, t, async_op=False):
+        from . import _lib
+        ms = self.ms(t.numel() * t.element_size())
+        self.calls.append((t.numel() * t.element_size(), ms))
+        L = _lib.load()
+        _lib.check(L.nef_debug_spin_us(float(ms * 1e3), self.wgs, torch.cuda.current_stream().cuda_stream), "nef_debug_spin_us")
+        return self._Done() if async_op else None
+
+
+def sum_counts(counts, device):
+    """Sum of a short list of host integers over the ranks (e.g. the split-fp16 clamp / skipped-step counters): every rank
+    gets the same totals, so a decision taken on them -- raise, warn, carry on -- is taken by ALL ranks together and none is left
+    blocking in the next collective.  World size 1: the list itself."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return [int(c) for c in counts]
+    on_dev = dist.get_backend() == "nccl"
+    t = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=device if on_dev else "cpu")
+    dist.all_reduce(t)
+    return [int(v) for v in t.tolist()]
+
+
 def broadcast_buffers(model, src=0):
     """Make rank `src`'s BatchNorm running statistics authoritative (e.g. before a checkpoint)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

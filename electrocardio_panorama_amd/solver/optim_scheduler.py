@@ -12,7 +12,15 @@ from .. import ops, parallel
 from ..parallel import reduce_flat_grads
 
 
+# The flat gradient buffer starts with a 4-word header (16 bytes: word 0 = the taint word of ops.h2_taint, words 1..3 zero) so that
+# the gradients behind it, the encoder bucket's all-reduce (header + bucket) and the SGD kernel's reads stay 16-byte aligned.
+GRAD_HDR = 4
+
+
 class FusedSGD(torch.optim.Optimizer):
+    """A tainted step (a split-fp16 launch met non-finite data, on any rank) leaves parameters and momentum untouched; the
+    BatchNorm running statistics its forward pass already updated are NOT rolled back (DESIGN.md 3.0 "Range")."""
+
     def __init__(self, params, lr, momentum=0.9):
         super().__init__(params, dict(lr=lr, momentum=momentum))
         self._flat = {}      # group index -> dict(params, p, g, buf)
@@ -35,10 +43,10 @@ class FusedSGD(torch.optim.Optimizer):
                 flat_b[off:off + k].copy_(st["momentum_buffer"].reshape(-1))
             st["momentum_buffer"] = flat_b[off:off + k].view_as(p.data)
             off += k
-        # gradients: [taint word | n gradients] -- the word in front (ops.h2_taint: clamps of this step's split-fp16 launches) is
-        # summed by the same all-reduce as the gradients, so a clamp on any rank makes every rank skip the update
-        g_all = torch.zeros(n + 1, device=dev, dtype=torch.float32)
-        self._flat[gi] = dict(ids=[id(p) for p in live], params=live, p=flat_p, buf=flat_b, g_all=g_all, g=g_all[1:])
+        # gradients: [header (taint word, 3 zero words) | n gradients] -- the word in front (ops.h2_taint: clamps of this step's
+        # split-fp16 launches) is summed by the same all-reduce as the gradients, so a clamp on any rank makes every rank skip the update
+        g_all = torch.zeros(n + GRAD_HDR, device=dev, dtype=torch.float32)
+        self._flat[gi] = dict(ids=[id(p) for p in live], params=live, p=flat_p, buf=flat_b, g_all=g_all, g=g_all[GRAD_HDR:])
 
     def load_state_dict(self, state_dict):
         """The loaded momentum buffers replace the flat one: drop the flat views so the next step() re-imports them."""
@@ -85,7 +93,7 @@ class FusedSGD(torch.optim.Optimizer):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         if flat_all is not None:
-            dist.all_reduce(flat_all[:1 + split])       # the encoder bucket, with the taint word in front of it
+            dist.all_reduce(flat_all[:GRAD_HDR + split])       # the encoder bucket, with the header (taint word) in front of it
         elif k:
             dist.all_reduce(flat[:split])
         early["work"].wait()                  # the launching stream now waits for the early bucket's collective
@@ -97,6 +105,7 @@ class FusedSGD(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        taint = None           # ONE taint word per step: h2_taint advances its mark, so later groups reuse the first group's (summed) word
         for gi, group in enumerate(self.param_groups):
             live = [p for p in group["params"] if p.grad is not None]      # torch SGD skips grad=None
             if not live:
@@ -107,8 +116,15 @@ class FusedSGD(torch.optim.Optimizer):
                     p.data.data_ptr() >= fl["p"].data_ptr() + fl["p"].numel() * 4 for p in live):
                 self._build(gi, live)
                 fl = self._flat[gi]
-            ops.h2_taint(fl["g_all"][:1])          # clamps of this step's split-fp16 launches -> the word in front of the gradients
+            if taint is None:
+                ops.h2_taint(fl["g_all"][:1])      # clamps of this step's split-fp16 launches -> the word in front of the gradients
+            else:
+                fl["g_all"][:1].zero_()
             self._reduce(live, fl["g"], world, fl["g_all"])
+            if taint is None:
+                taint = fl["g_all"][:1]
+            else:
+                fl["g_all"][:1].copy_(taint)       # (already summed over the ranks)
             # buf starts at zero, so mu*buf + g reproduces torch's first-step "buf = g" exactly; a tainted step is skipped
             ops.sgd_momentum(fl["p"], fl["g"], fl["buf"], float(group["lr"]), float(group["momentum"]), 1.0 / world,
                              False, skip=fl["g_all"][:1])

@@ -243,16 +243,18 @@ class Solver:
             st = self._graph_stepper = GraphedTrainStep(self.model, self.cfg, optimizer=optim)
         return st
 
-    @staticmethod
-    def _check_h2_range(phase, optim):
+    def _check_h2_range(self, phase, optim):
         """The split-fp16 convs count a launch whose operand is out of fp16's range even after the in-launch range rescue: non-finite
         data (finite operands beyond ops.H2_HEADROOM x of growth are redone with their own scale inside the launch), or any
         clamp of the opt-in producer / consumer kernel form (fp16 ends at 65504; the reference's fp32 nn.Conv1d,
         model_nefnet.py:18-21, has no such limit).  A train step that contained such a launch was SKIPPED on the device when the
         optimiser is FusedSGD (ops.h2_taint): that is reported; counts nothing protected against -- a test-phase forward,
         another optimiser -- mean wrong results were used: raise, unless NEF_H2_ALLOW_CLAMP=1 (then warn).  NEF_H2=0 runs the
-        fp32 kernels instead."""
-        clamped, skipped = ops.h2_clamped(), ops.h2_skipped()
+        fp32 kernels instead.  Data parallel: the counters are per rank, so they are SUMMED over the process group before anything
+        is decided -- every rank raises (or warns) together; a rank that alone saw the bad operand must not leave the others
+        blocking in their next collective."""
+        clamped, skipped = parallel.sum_counts([ops.h2_clamped(), ops.h2_skipped()], self.device)
+        ops.h2_rebase(self.device)       # clamps of this (test / val) phase are not charged to the next train step's taint word
         if not clamped and not skipped:
             return
         msg = ('{} waves of split-fp16 conv launches met an operand outside fp16\'s range in this {} phase (non-finite data; finite '

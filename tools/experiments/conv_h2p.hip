@@ -46,19 +46,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-// process-wide kernel-form options (nef_set_option); under NEF_DIAG=1 the environment gives the initial values: NEF_H2P, NEF_H2P_WGS
-int g_opt[4] = {0, -1, -1, 0};
-void opt_init() {
-    if (__atomic_load_n(&g_opt[0], __ATOMIC_ACQUIRE)) return;
-    const char* e1 = nef_diag_env("NEF_H2P");
-    const char* e2 = nef_diag_env("NEF_H2P_WGS");
-    int v1 = e1 ? atoi(e1) : 0, v2 = e2 ? atoi(e2) : 1;
-    int neg = -1;
-    __atomic_compare_exchange_n(&g_opt[NEF_OPT_H2_FORM], &neg, v1, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
-    neg = -1;
-    __atomic_compare_exchange_n(&g_opt[NEF_OPT_H2P_WGS], &neg, v2, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
-    __atomic_store_n(&g_opt[0], 1, __ATOMIC_RELEASE);
-}
+// process-wide kernel-form options live in conv_h2.hip (nef_set_option / nef_get_option); this file only reads them
+}  // namespace
+__attribute__((visibility("hidden"))) int nef_opt_get(int key);
+namespace {
 
 constexpr int KC = 16;                 // input channels per stage
 constexpr int NTO = 256;               // outputs per tile
@@ -865,8 +856,7 @@ int launch_h2p(const nef_conv_args& a, hipStream_t st) {
     if (total <= 0 || total > 0x3fffffff) return NEF_E_SHAPE;
     // one resident workgroup of twelve waves per CU (a 6-wave workgroup does not share a CU with a second one at 168 registers: the
     // dispatcher wants 2 + 2 + 1 + 1 wave slots on the four SIMDs twice); a multiple of 8, so that a stream keeps its id mod 8
-    opt_init();
-    const int per_cu = __atomic_load_n(&g_opt[NEF_OPT_H2P_WGS], __ATOMIC_RELAXED);
+    const int per_cu = nef_opt_get(NEF_OPT_H2P_WGS);
     int64_t grid = (int64_t)(per_cu > 0 ? per_cu : 1) * nef_cu_count();
     grid -= grid % 8;
     if (grid < 8) grid = 8;
@@ -878,17 +868,7 @@ int launch_h2p(const nef_conv_args& a, hipStream_t st) {
 
 }  // namespace
 
-__attribute__((visibility("hidden"))) int nef_opt_h2_form() {
-    opt_init();
-    return __atomic_load_n(&g_opt[NEF_OPT_H2_FORM], __ATOMIC_RELAXED);
-}
-
 extern "C" {
-int nef_set_option(int key, int value) {
-    if (key != NEF_OPT_H2_FORM && key != NEF_OPT_H2P_WGS) return NEF_E_SHAPE;
-    opt_init();
-    return __atomic_exchange_n(&g_opt[key], value, __ATOMIC_RELAXED);
-}
 // diagnostics (not in the header): resident workgroups per CU the runtime reports for conv_h2p_kernel<3, 0>
 int nef_debug_h2p_occupancy(void) {
     int n = -1;
@@ -897,11 +877,6 @@ int nef_debug_h2p_occupancy(void) {
     nef_ensure_dyn_lds(reinterpret_cast<const void*>(&conv_h2p_kernel<3, 0>), lds, &lds_set);
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&conv_h2p_kernel<3, 0>), NTHREADS, lds);
     return e == hipSuccess ? n : -(int)e;
-}
-int nef_get_option(int key) {
-    if (key != NEF_OPT_H2_FORM && key != NEF_OPT_H2P_WGS) return NEF_E_SHAPE;
-    opt_init();
-    return __atomic_load_n(&g_opt[key], __ATOMIC_RELAXED);
 }
 }
 
