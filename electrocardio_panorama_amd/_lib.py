@@ -43,7 +43,7 @@ class ConvArgs(C.Structure):
 class PackDesc(C.Structure):
     """Mirror of `nef_pack_desc` (include/nefnet_hip.h)."""
     _fields_ = [("w", p), ("wp", p), ("G", i32), ("Cog", i32), ("Cig", i32), ("K", i32), ("transpose_flip", i32),
-                ("wino", i32)]
+                ("wino", i32), ("src_mode", i32), ("src_Cr", i32)]
 
 
 # name -> (restype, argtypes); every symbol include/nefnet_hip.h declares
@@ -103,15 +103,15 @@ SIGNATURES = {
     "nef_pass_combine_fwd": (i32, [p, p, p, i32, i32, i32, p]),
     "nef_pass_combine_bwd": (i32, [p, p, i32, i32, i32, p]),
     "nef_pass_combine_stats_ws_bytes": (sz, [i32, i32]),
-    "nef_pass_combine_fwd_stats": (i32, [p, p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, f32, f32, p]),
+    "nef_pass_combine_fwd_stats": (i32, [p, p, p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, f32, f32, p, p]),
     "nef_mix_bwd_up": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, p, i32, p]),
     "nef_upsample2_fwd": (i32, [p, p, i64, i32, p]),
     "nef_upsample2_bwd": (i32, [p, p, i64, i32, p]),
     "nef_upsample2_aff_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, p]),
     "nef_bn_ws_bytes": (sz, [i32, i32]),
-    "nef_bn_train_stats": (i32, [p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, f32, f32, p]),
+    "nef_bn_train_stats": (i32, [p, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, f32, f32, p, p]),
     "nef_conv_stats_slots": (i32, [i32, i32]),
-    "nef_bn_stats_from_slots": (i32, [p, i32, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, f32, f32, p]),
+    "nef_bn_stats_from_slots": (i32, [p, i32, p, p, p, p, p, p, p, p, p, sz, i32, i32, i32, i32, f32, f32, p, p]),
     "nef_bn_eval_affine": (i32, [p, p, p, p, p, p, i32, f32, p]),
     "nef_fold_bn": (i32, [p, p, p, p, p, p, i32, i32, p]),
     "nef_affine_relu_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, p]),
@@ -134,6 +134,9 @@ SIGNATURES = {
     "nef_loss_bwd": (i32, [p, p, p, p, p, p, p, p, i64, f32, f32, f32, i32, i32, p]),
     "nef_sgd_momentum": (i32, [p, p, p, i64, f32, f32, f32, i32, p, p, p, p]),
     "nef_h2_taint": (i32, [p, p, p, p]),
+    "nef_amax_roll": (i32, [p, p, i32, f32, f32, i32, p]),
+    "nef_flatten": (i32, [C.POINTER(p), C.POINTER(i64), i32, p, p]),
+    "nef_regroup_halves": (i32, [p, p, i32, i32, i32, i32, p]),
     "nef_slots_to_rows": (i32, [p, i32, p, i32, i32, p]),
     "nef_poly_weights": (i32, [p, p, i32, i32, i32, p]),
     "nef_poly_fwd_edge": (i32, [p, p, p, i32, i32, i32, i32, i32, p, p, i32, p, i32, p, p]),

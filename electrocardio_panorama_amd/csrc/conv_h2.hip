@@ -110,8 +110,34 @@ __device__ __forceinline__ void split2s(float x0, float x1, float s, float lim, 
 struct H2PackDesc {
     const float* w;
     _Float16* wp;
-    int G, Cog, Cig, K, flip;      // Cog / Cig: dimensions of w itself ([G*Cog][Cig][K])
+    int G, Cog, Cig, K, flip;      // Cog / Cig: dimensions of the LOGICAL weight tensor [G*Cog][Cig][K] that is packed
+    int src_mode, src_Cr;          // nef_pack_desc.src_mode / src_Cr: how the logical tensor is read out of `w`
 };
+
+// Element (row, ci, kk) of the logical weight tensor [G*Cog][Cig][K].  src_mode 0: w itself.  src_mode 1 (round 6): the PHASE weights
+// of conv1d(upsample2(x), w) formed on the fly from w [G*Cog/2][Cig][3] -- exactly poly_weights_kernel's expressions
+// and row orders (src_Cr = 0: row 2 r + p; src_Cr > 0: the tile order of the polyphase forward launch), so the packed operand is
+// bit-identical to packing nef_poly_weights' output and the fp32 phase tensor is never written.
+__device__ __forceinline__ float h2_pack_src(const H2PackDesc& d, int64_t row, int ci, int kk) {
+    if (d.src_mode == 0) return d.w[(row * d.Cig + ci) * d.K + kk];
+    int64_t r;
+    int p;
+    if (d.src_Cr > 0) {
+        const int Cr = d.src_Cr;
+        const int64_t g = row / (2 * Cr);
+        const int x = (int)(row - g * 2 * Cr);
+        const int y = x & 127;
+        p = (y >> 5) & 1;
+        r = g * Cr + (x >> 7) * 64 + (y >> 6) * 32 + (y & 31);
+    } else {
+        r = row >> 1;
+        p = (int)(row & 1);
+    }
+    const float* const wr = d.w + (r * d.Cig + ci) * 3;
+    const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
+    if (p == 0) return kk == 0 ? fmaf(0.75f, w0, 0.25f * w1) : (kk == 1 ? fmaf(0.25f, w0, 0.75f * (w1 + w2)) : 0.25f * w2);
+    return kk == 0 ? 0.25f * w0 : (kk == 1 ? fmaf(0.25f, w2, 0.75f * (w0 + w1)) : fmaf(0.75f, w2, 0.25f * w1));
+}
 constexpr int H2_PACK_MAX = 48;
 struct H2PackTable { H2PackDesc d[H2_PACK_MAX]; };
 
@@ -129,8 +155,7 @@ __global__ __launch_bounds__(256) void pack_h2_kernel(H2PackTable tab) {
         float m = 0.f;
         for (int i = lane; i < ci_n * K; i += 64) {
             const int ci = i / K, kk = i % K;
-            const float v = d.flip ? d.w[(((int64_t)g * d.Cog + ci) * d.Cig + co) * K + (K - 1 - kk)]
-                                   : d.w[(((int64_t)g * d.Cog + co) * d.Cig + ci) * K + kk];
+            const float v = d.flip ? h2_pack_src(d, (int64_t)g * d.Cog + ci, co, K - 1 - kk) : h2_pack_src(d, (int64_t)g * d.Cog + co, ci, kk);
             m = fmaxf(m, fabsf(v));
         }
 #pragma unroll
@@ -146,8 +171,7 @@ __global__ __launch_bounds__(256) void pack_h2_kernel(H2PackTable tab) {
         if (lane == 0) dsc[row] = ldexpf(1.f, -e);
         for (int i = lane; i < ci_n * K; i += 64) {
             const int ci = i / K, kk = i % K;
-            const float v = sc * (d.flip ? d.w[(((int64_t)g * d.Cog + ci) * d.Cig + co) * K + (K - 1 - kk)]
-                                         : d.w[(((int64_t)g * d.Cog + co) * d.Cig + ci) * K + kk]);
+            const float v = sc * (d.flip ? h2_pack_src(d, (int64_t)g * d.Cog + ci, co, K - 1 - kk) : h2_pack_src(d, (int64_t)g * d.Cog + co, ci, kk));
             const _Float16 h = (_Float16)v;
             const _Float16 l = (_Float16)(v - (float)h);
             const int64_t frag = ((((int64_t)g * nc16 + ci / 16) * K + kk) * ncot + co / 32) * 2;
@@ -1058,7 +1082,9 @@ __attribute__((visibility("hidden"))) int nef_h2_pack(const nef_pack_desc* descs
             if (!d.w || !d.wp) return NEF_E_NULL;
             const int co_n = d.transpose_flip ? d.Cig : d.Cog, ci_n = d.transpose_flip ? d.Cog : d.Cig;
             if (d.G <= 0 || co_n % 32 != 0 || ci_n % 16 != 0 || (d.K != 1 && d.K != 3 && d.K != 7)) return NEF_E_SHAPE;
-            tab.d[i] = H2PackDesc{d.w, reinterpret_cast<_Float16*>(d.wp), d.G, d.Cog, d.Cig, d.K, d.transpose_flip};
+            if (d.src_mode != 0 && !(d.src_mode == 1 && d.K == 3 && d.Cog % 2 == 0 && d.src_Cr >= 0 &&
+                                     (d.src_Cr == 0 || (d.src_Cr % 64 == 0 && d.Cog == 2 * d.src_Cr)))) return NEF_E_SHAPE;
+            tab.d[i] = H2PackDesc{d.w, reinterpret_cast<_Float16*>(d.wp), d.G, d.Cog, d.Cig, d.K, d.transpose_flip, d.src_mode, d.src_Cr};
             if (d.G * co_n > rows_max) rows_max = d.G * co_n;
         }
         hipLaunchKernelGGL(pack_h2_kernel, dim3((unsigned)((rows_max + 3) / 4), (unsigned)m), dim3(256), 0, st, tab);

@@ -2325,7 +2325,7 @@ __attribute__((visibility("hidden"))) int nef_h2_pack(const nef_pack_desc* descs
 
 extern "C" {
 
-int nef_abi_version(void) { return 17; }
+int nef_abi_version(void) { return 18; }
 
 int nef_pack_weight(const float* w, float* wp, int G, int Cog, int Cig, int K, int transpose_flip,
                     nef_stream_t stream) {
@@ -2366,6 +2366,7 @@ int nef_pack_weight_h2(const float* w, void* wp, int G, int Cog, int Cig, int K,
     d.w = w;
     d.wp = (float*)wp;
     d.G = G, d.Cog = Cog, d.Cig = Cig, d.K = K, d.transpose_flip = transpose_flip, d.wino = 3;
+    d.src_mode = 0, d.src_Cr = 0;
     return nef_h2_pack(&d, 1, (hipStream_t)stream);
 }
 
@@ -2385,6 +2386,7 @@ int nef_pack_weights(const nef_pack_desc* descs, int n, nef_stream_t stream) {
         NEF_REQUIRE(d.w && d.wp, NEF_E_NULL);
         NEF_REQUIRE(d.G > 0 && d.Cog > 0 && d.Cig > 0 && d.K > 0 && d.wino >= 0 && d.wino <= 3 &&
                         (!d.wino || d.K == 3 || d.K == 7 || (d.wino == 3 && d.K == 1)), NEF_E_SHAPE);
+        NEF_REQUIRE(d.src_mode == 0 || d.wino == 3, NEF_E_UNSUPPORTED);      // synthesized sources: split-fp16 operands only
         if (d.wino == 3) {
             if (n_h2 == PACK_MULTI_MAX) {
                 if (int e = nef_h2_pack(h2, n_h2, (hipStream_t)stream)) return e;

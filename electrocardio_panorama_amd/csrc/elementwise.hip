@@ -525,9 +525,10 @@ __global__ void bn_stats_final(const double* __restrict__ part, const float* __r
                                const float* __restrict__ beta, float* __restrict__ running_mean,
                                float* __restrict__ running_var, float* __restrict__ mean, float* __restrict__ invstd,
                                float* __restrict__ a, float* __restrict__ b, int P, int Bp, int C, int L, float eps,
-                               float momentum, int nsplit) {
+                               float momentum, int nsplit, int64_t* __restrict__ nbt) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (nbt && c == 0) nbt[0] += P;      // BatchNorm1d.num_batches_tracked: one per pass (torch/nn/modules/batchnorm.py)
     const double n = (double)Bp * (double)L;
     float rm = running_mean ? running_mean[c] : 0.f;
     float rv = running_var ? running_var[c] : 1.f;
@@ -1193,6 +1194,57 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 6: the last torch elementwise kernels of the train step, as one launch each.
+// amax_roll: ops.amax_roll's follow-up rule on the split-fp16 site table (was ~10 ATen launches: compares, ors, where, fill).
+__global__ __launch_bounds__(256) void amax_roll_kernel(float* __restrict__ cur, float* __restrict__ nxt, int n, float up, float down,
+                                                        int follow) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float c = cur[i], x = nxt[i];
+    const bool upd = x > 0.f && (follow || c <= 0.f || x > up * c || x * down < c);
+    if (upd) cur[i] = x;
+    nxt[i] = 0.f;
+}
+
+// flatten: out[off_k .. off_k + n_k) = src_k for up to FLAT_MAX tensors per launch (the flat gradient buffer; was torch.cat)
+constexpr int FLAT_MAX = 64;
+struct FlatDesc { const float* src; int64_t n, off; };
+struct FlatTable { FlatDesc d[FLAT_MAX]; };
+__global__ __launch_bounds__(256) void flatten_kernel(FlatTable t, float* __restrict__ out) {
+    const FlatDesc& d = t.d[blockIdx.y];
+    const float* __restrict__ src = d.src;
+    float* __restrict__ dst = out + d.off;
+    const int64_t n = d.n;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    // 16-byte body when both sides are 16-byte aligned (every weight gradient of the step is), scalar otherwise
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+            reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    }
+}
+
+// regroup_halves: w [Co][2 Cih][K] <-> grouped [2 Co][Cih][K] (group = input-channel half; engine._regroup_halves / _ungroup_halves)
+__global__ __launch_bounds__(256) void regroup_halves_kernel(const float* __restrict__ src, float* __restrict__ dst, int Co, int Cih,
+                                                            int K, int inverse) {
+    const int64_t n = (int64_t)2 * Co * Cih * K;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        // i indexes the GROUPED tensor [h][co][ci][k]
+        const int k = (int)(i % K);
+        const int64_t q = i / K;
+        const int ci = (int)(q % Cih);
+        const int64_t q2 = q / Cih;
+        const int co = (int)(q2 % Co), h = (int)(q2 / Co);
+        const int64_t j = (((int64_t)co * 2 + h) * Cih + ci) * K + k;      // the same element in [co][h][ci][k]
+        if (inverse) dst[j] = src[i];
+        else dst[i] = src[j];
+    }
+}
+
 // Diagnostics (bench.py --dry-collective): occupy `wgs` workgroups for `ticks` of the constant-rate wall clock -- a stand-in for a
 // collective of modelled duration on the communication stream of a ONE-GPU run (the all-reduce it replaces would hold a few CUs
 // of channel kernels for that long).  Bounded: the host side caps the duration at 50 ms.
@@ -1740,21 +1792,21 @@ size_t nef_bn_ws_bytes(int P, int C) {
 
 int nef_bn_train_stats(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                        float* mean, float* invstd, float* a, float* b, void* ws, size_t ws_bytes, int P, int Bp, int C,
-                       int L, float eps, float momentum, nef_stream_t stream) {
+                       int L, float eps, float momentum, int64_t* num_batches_tracked, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(x && gamma && beta && mean && invstd && a && b && ws, NEF_E_NULL);
     NEF_REQUIRE(P > 0 && Bp > 0 && C > 0 && L > 0 && (int64_t)Bp * L > 1, NEF_E_SHAPE);
     NEF_REQUIRE(ws_bytes >= nef_bn_ws_bytes(P, C), NEF_E_WORKSPACE);
     hipLaunchKernelGGL(bn_stats_partial, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, x, (double*)ws, P, Bp, C, L);
     hipLaunchKernelGGL(bn_stats_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)ws, gamma, beta,
-                       running_mean, running_var, mean, invstd, a, b, P, Bp, C, L, eps, momentum, BN_SPLIT);
+                       running_mean, running_var, mean, invstd, a, b, P, Bp, C, L, eps, momentum, BN_SPLIT, num_batches_tracked);
     return nef_launch_status();
 }
 
 int nef_bn_stats_from_slots(const float* slots, int nslot, const float* gamma, const float* beta, float* running_mean,
                             float* running_var, float* mean, float* invstd, float* a, float* b, void* ws,
                             size_t ws_bytes, int P, int Bp, int C, int L, float eps, float momentum,
-                            nef_stream_t stream) {
+                            int64_t* num_batches_tracked, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(slots && gamma && beta && mean && invstd && a && b && ws, NEF_E_NULL);
     NEF_REQUIRE(P > 0 && Bp > 0 && C > 0 && L > 0 && nslot > 0 && (int64_t)Bp * L > 1 &&
@@ -1763,7 +1815,7 @@ int nef_bn_stats_from_slots(const float* slots, int nslot, const float* gamma, c
     hipLaunchKernelGGL(bn_slots_reduce, dim3((unsigned)(P * C)), dim3(256), 0, NEF_ST, slots, (double*)ws, P, C,
                        Bp * nslot);
     hipLaunchKernelGGL(bn_stats_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)ws, gamma, beta,
-                       running_mean, running_var, mean, invstd, a, b, P, Bp, C, L, eps, momentum, 1);
+                       running_mean, running_var, mean, invstd, a, b, P, Bp, C, L, eps, momentum, 1, num_batches_tracked);
     return nef_launch_status();
 }
 
@@ -1772,7 +1824,7 @@ size_t nef_pass_combine_stats_ws_bytes(int B, int C) { return (size_t)3 * C * (B
 int nef_pass_combine_fwd_stats(const float* P2, const float* bias, float* c1, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float* mean, float* invstd, float* a, float* b,
                                void* ws, size_t ws_bytes, int B, int C, int L, float eps, float momentum,
-                               nef_stream_t stream) {
+                               int64_t* num_batches_tracked, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(P2 && bias && c1 && gamma && beta && mean && invstd && a && b && ws, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && C > 0 && L > 0 && (int64_t)B * C <= 0x7FFFFFFF && (int64_t)B * L > 1, NEF_E_SHAPE);
@@ -1783,7 +1835,7 @@ int nef_pass_combine_fwd_stats(const float* P2, const float* bias, float* c1, co
                        C, L);
     hipLaunchKernelGGL(bn_rows_reduce, dim3((unsigned)(3 * C)), dim3(256), 0, NEF_ST, (const double*)rows, tot, B);
     hipLaunchKernelGGL(bn_stats_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)tot, gamma, beta,
-                       running_mean, running_var, mean, invstd, a, b, 3, B, C, L, eps, momentum, 1);
+                       running_mean, running_var, mean, invstd, a, b, 3, B, C, L, eps, momentum, 1, num_batches_tracked);
     return nef_launch_status();
 }
 
@@ -2133,6 +2185,48 @@ int nef_poly_bwd_edge(const float* gy, const float* w, float* gx, int B, int G, 
     NEF_REQUIRE(!bnb_slots || (bnb_x && bnb_mean && bnb_invstd && bnb_a && bnb_b && bnb_Bp > 0 && nslot > 0), NEF_E_NULL);
     hipLaunchKernelGGL(poly_bwd_edge_kernel, dim3((unsigned)(B * G)), dim3(256), (size_t)4 * Cog * sizeof(float), NEF_ST, gy, w, gx, B, G,
                        Cog, Cig, T, bnb_x, bnb_mean, bnb_invstd, bnb_a, bnb_b, bnb_Bp, bnb_slots, nslot, gy_phase_major);
+    return nef_launch_status();
+}
+
+int nef_amax_roll(float* cur, float* nxt, int n, float follow_up, float follow_down, int follow_always, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(cur && nxt, NEF_E_NULL);
+    NEF_REQUIRE(n >= 0 && follow_up >= 1.f && follow_down >= 1.f, NEF_E_SHAPE);
+    if (n == 0) return NEF_OK;
+    hipLaunchKernelGGL(amax_roll_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, NEF_ST, cur, nxt, n, follow_up, follow_down,
+                       follow_always);
+    return nef_launch_status();
+}
+
+int nef_flatten(const float* const* srcs, const int64_t* sizes, int n, float* out, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE((srcs && sizes && out) || n == 0, NEF_E_NULL);
+    NEF_REQUIRE(n >= 0, NEF_E_SHAPE);
+    int64_t off = 0;
+    for (int i0 = 0; i0 < n; i0 += FLAT_MAX) {
+        FlatTable t;
+        const int m = n - i0 < FLAT_MAX ? n - i0 : FLAT_MAX;
+        int64_t biggest = 1;
+        for (int i = 0; i < m; ++i) {
+            NEF_REQUIRE(srcs[i0 + i] && sizes[i0 + i] >= 0, NEF_E_NULL);
+            t.d[i] = FlatDesc{srcs[i0 + i], sizes[i0 + i], off};
+            off += sizes[i0 + i];
+            if (sizes[i0 + i] > biggest) biggest = sizes[i0 + i];
+        }
+        int gx = (int)nef_cdiv(biggest, 256 * 4 * 4);      // ~4 16-byte transfers per thread on the largest tensor
+        if (gx > 128) gx = 128;
+        if (gx < 1) gx = 1;
+        hipLaunchKernelGGL(flatten_kernel, dim3((unsigned)gx, (unsigned)m), dim3(256), 0, NEF_ST, t, out);
+    }
+    return nef_launch_status();
+}
+
+int nef_regroup_halves(const float* src, float* dst, int Co, int Cih, int K, int inverse, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(src && dst, NEF_E_NULL);
+    NEF_REQUIRE(Co > 0 && Cih > 0 && K > 0, NEF_E_SHAPE);
+    const int64_t n = (int64_t)2 * Co * Cih * K;
+    hipLaunchKernelGGL(regroup_halves_kernel, dim3((unsigned)nef_stream_grid(n, 256)), dim3(256), 0, NEF_ST, src, dst, Co, Cih, K, inverse);
     return nef_launch_status();
 }
 

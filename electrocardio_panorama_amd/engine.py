@@ -135,6 +135,35 @@ def _decoder_pack_requests(P, T_lat, flip):
             ([] if poly else [(w3, 1, flip, 4 * T_lat, True)]) + [(P["decoder.3.double_conv.3.weight"], 1, flip, 4 * T_lat, True)])
 
 
+def _step_pack_requests(P, V, T):
+    """Every conv operand of a whole TRAIN step -- forward and backward-data, the polyphase ones included -- for ONE ops.pack_many
+    launch at the top of engine.forward(save=True) (round 5: 8 pack launches + 4 poly_weights launches per step).  The pass-level
+    pack_many calls further down find their requests in the table and do nothing; anything this list misses packs on demand."""
+    r0 = (T - 1) // 2
+    win = (r0 - 2, 6) if (T % 2 == 0 and r0 - 2 >= 0 and r0 + 4 <= T) else None
+    reqs = _latent_pack_requests(P, V, T, win, False) + _latent_pack_requests(P, V, T, win, True)
+    if 2 * T < 128:            # (_fusable: shorter sequences take the unfused decoder, which packs on demand)
+        return reqs
+    reqs += _decoder_pack_requests(P, T, False) + _decoder_pack_requests(P, T, True)
+    w0, w3 = P["decoder.1.double_conv.0.weight"], P["decoder.3.double_conv.0.weight"]
+    wg, site0 = _regroup_halves(w0, P), w0.data_ptr()
+    co0, co3 = w0.shape[0], w3.shape[0]
+    # first decoder conv (shared halves: 2 groups) and the conv behind the second upsampling: polyphase operands where the shape allows
+    if ops.poly_fwd_ok(2, co0, w0.shape[1] // 2, 2 * T):
+        reqs.append((wg, 2, False, T, False, ("poly", co0), False, site0))
+    else:
+        reqs.append((wg, 2, False, 2 * T, True, None, True, site0))
+    if ops.poly_bwd_ok(2, co0, w0.shape[1] // 2, 2 * T):
+        reqs.append((wg, 2, True, T, False, ("poly", 0), True, site0))
+    else:
+        reqs.append((wg, 2, True, 2 * T, True, None, True, site0))
+    if ops.poly_fwd_ok(1, co3, w3.shape[1], 4 * T):
+        reqs.append((w3, 1, False, 2 * T, False, ("poly", co3), False, None))
+    if ops.poly_bwd_ok(1, co3, w3.shape[1], 4 * T):
+        reqs.append((w3, 1, True, 2 * T, False, ("poly", 0), True, None))
+    return reqs
+
+
 # Below this many latent elements per step (B * 128V * T) the step is bound by the host issuing launches, and the second
 # stream's events and waits cost more than the overlap returns (batch 32 / L=512: 4.30 ms with it, 3.45 without)
 _SIDE_MIN_WORK = 1 << 24
@@ -196,15 +225,25 @@ _DEC = (("decoder.1", "0", "1", 128), ("decoder.1", "3", "4", 128), ("decoder.3"
         ("decoder.3", "3", "4", 64))
 
 
-def _regroup_halves(w):
-    """decoder.1.double_conv.0.weight [128, 256, 3] -> grouped-conv weight [2*128, 128, 3] (group = input-channel half)."""
-    co, ci, k = w.shape
-    return w.view(co, 2, ci // 2, k).permute(1, 0, 2, 3).contiguous().view(2 * co, ci // 2, k)
+_HALVES = "decoder.1.double_conv.0.weight#halves"      # key of the regrouped first decoder weight inside a pass's parameter dict
+
+
+def _regroup_halves(w, P=None):
+    """decoder.1.double_conv.0.weight [128, 256, 3] -> grouped-conv weight [2*128, 128, 3] (group = input-channel half).  With the
+    pass's parameter dict `P` the regrouped tensor is made once per step (forward) and found again by the backward pass -- the same
+    OBJECT, which is also what lets the step-level ops.pack_many hand its packed operands to both."""
+    if P is not None:
+        hit = P.get(_HALVES)
+        if hit is not None and hit[1] is w and hit[2] == w._version:
+            return hit[0]
+    wg = ops.regroup_halves(w)
+    if P is not None:
+        P[_HALVES] = (wg, w, w._version)
+    return wg
 
 
 def _ungroup_halves(w2):
-    co2, cih, k = w2.shape
-    return w2.view(2, co2 // 2, cih, k).permute(1, 0, 2, 3).contiguous().view(co2 // 2, 2 * cih, k)
+    return ops.regroup_halves(w2, inverse=True)
 
 
 def _fusable(D, passes):
@@ -223,8 +262,7 @@ def _decoder_fwd_unfused(D, P, Bf, passes, training, save):
         c = ops.conv(GV.dense(x, 1), ops.pack_weight(P[wname], 1, T=x.shape[2], f4=True), cout, 3, bias=P[bname])
         if training:
             mean, invstd, a, b = ops.bn_train_stats(c, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
-                                                    Bf[pre + ".running_var"], passes, BN_EPS, BN_MOM)
-            Bf[pre + ".num_batches_tracked"] += passes
+                                                    Bf[pre + ".running_var"], passes, BN_EPS, BN_MOM, nbt=Bf[pre + ".num_batches_tracked"])
             np_ = passes
         else:
             a, b = ops.bn_eval_affine(P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
@@ -272,13 +310,14 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
                                                      x_in.shape[1] // (2 if (li == 0 and shared_B is not None) else 1), T_out)
         if li == 0 and shared_B is not None:
             if poly:
-                p2 = ops.conv_poly_fwd(GV.dense(x_in, 2), _regroup_halves(P[wname]), cout, pro=pro, site=P[wname].data_ptr(), save_edge=save)
+                p2 = ops.conv_poly_fwd(GV.dense(x_in, 2), _regroup_halves(P[wname], P), cout, pro=pro, site=P[wname].data_ptr(), save_edge=save)
                 xedge = p2.nef_xedge
             else:
-                p2 = ops.conv(GV.dense(x_in, 2), ops.pack_weight(_regroup_halves(P[wname]), 2, T=T_out, f4=True, site=P[wname].data_ptr()), cout, 3, pro=pro)
+                p2 = ops.conv(GV.dense(x_in, 2), ops.pack_weight(_regroup_halves(P[wname], P), 2, T=T_out, f4=True, site=P[wname].data_ptr()), cout, 3, pro=pro)
             if training and passes == 3:      # the BatchNorm statistics of c1 come out of the same pass
                 c, *stats = ops.pass_combine_fwd_stats(p2, P[bname], shared_B, P[pre + ".weight"], P[pre + ".bias"],
-                                                       Bf[pre + ".running_mean"], Bf[pre + ".running_var"], BN_EPS, BN_MOM)
+                                                       Bf[pre + ".running_mean"], Bf[pre + ".running_var"], BN_EPS, BN_MOM,
+                                                       nbt=Bf[pre + ".num_batches_tracked"])
             else:
                 c = ops.pass_combine_fwd(p2, P[bname], shared_B)
         elif poly:
@@ -290,7 +329,8 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
             xedge = c.nef_xedge
             if slots is not None:
                 stats = ops.bn_stats_from_slots(slots, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
-                                                Bf[pre + ".running_var"], passes, N, T_out, BN_EPS, BN_MOM)
+                                                Bf[pre + ".running_var"], passes, N, T_out, BN_EPS, BN_MOM,
+                                                nbt=Bf[pre + ".num_batches_tracked"])
         else:
             wp = ops.pack_weight(P[wname], 1, T=T_out, f4=True)
             # train mode: the F(4,3) epilogue leaves the BatchNorm slot sums of c -- no statistics pass over c
@@ -298,15 +338,14 @@ def decoder_fwd(D, P, Bf, passes, training, save, shared_B=None):
             c = ops.conv(GV.dense(x_in, 1), wp, cout, 3, bias=P[bname], pro=pro, stats=slots)
             if slots is not None:
                 stats = ops.bn_stats_from_slots(slots, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
-                                                Bf[pre + ".running_var"], passes, N, T_out, BN_EPS, BN_MOM)
-        if stats is not None:
+                                                Bf[pre + ".running_var"], passes, N, T_out, BN_EPS, BN_MOM,
+                                                nbt=Bf[pre + ".num_batches_tracked"])
+        if stats is not None:      # (num_batches_tracked += passes: by the launch that updated the running statistics)
             mean, invstd, a, b = stats
-            Bf[pre + ".num_batches_tracked"] += passes
             Bp = N // passes
         elif training:
             mean, invstd, a, b = ops.bn_train_stats(c, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
-                                                    Bf[pre + ".running_var"], passes, BN_EPS, BN_MOM)
-            Bf[pre + ".num_batches_tracked"] += passes
+                                                    Bf[pre + ".running_var"], passes, BN_EPS, BN_MOM, nbt=Bf[pre + ".num_batches_tracked"])
             Bp = N // passes
         else:
             a, b = ops.bn_eval_affine(P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"],
@@ -369,10 +408,10 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
             else:
                 grads[wname] = side.run(lambda: _ungroup_halves(ops.conv_bwd_weight(xv, gpv, 3, pro=pro, site=P[wname].data_ptr())), x, gp2)
             if poly_b:      # straight to the gradient wrt the half-resolution D (polyphase pass): nothing left for the consumer to fold
-                g = ops.conv_bwd_data_poly(gpv, _regroup_halves(P[wname]), x.shape[1] // 2, site=P[wname].data_ptr(), phase_major=pm)
+                g = ops.conv_bwd_data_poly(gpv, _regroup_halves(P[wname], P), x.shape[1] // 2, site=P[wname].data_ptr(), phase_major=pm)
                 poly_first = True
             else:
-                g = ops.conv(gpv, ops.pack_weight(_regroup_halves(P[wname]), 2, flip=True, T=gp2.shape[2], f4=True, site=P[wname].data_ptr()), x.shape[1] // 2, 3,
+                g = ops.conv(gpv, ops.pack_weight(_regroup_halves(P[wname], P), 2, flip=True, T=gp2.shape[2], f4=True, site=P[wname].data_ptr()), x.shape[1] // 2, 3,
                              role="conv_bwd_data")
         else:
             gcv, xv = GV.dense(gc, 1), GV.dense(x, 1)
@@ -494,6 +533,8 @@ def forward(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", t
     T = L // 4
     ops.BATCH_HINT = B     # small batches stay on the fp32 kernels (ops._h2_fills)
     ops.amax_roll()        # split-fp16 convs: last pass's operand magnitudes become this pass's input scales
+    if save and phase == "train":
+        ops.pack_many(_step_pack_requests(P, V, T))
     z1, z2b, sv = _latents(P, x, in_theta, rois, drop, save)
     if phase == "gen":
         return (z1, z2b), None
@@ -657,8 +698,10 @@ def _head_bwd(P, sv, g_outs, grads, side, relu_z1=False):
     """Back through decoder passes, Standin mixes and mlp2: returns the gradients wrt the lead-blocked z1 and z2r."""
     B, V = sv["hB"], sv["hV"]
     like = sv["dec"][2]        # stacked decoder output [3B, 1, L]
-    parts = [g if g is not None else torch.zeros_like(like[0:B]) for g in g_outs]
-    g_out = torch.cat([p_.contiguous() for p_ in parts], dim=0)
+    g_out = ops.stacked3(g_outs) if all(g is not None for g in g_outs) else None      # ops.loss_bwd's three views of one buffer: no copy
+    if g_out is None:
+        parts = [g if g is not None else torch.zeros_like(like[0:B]) for g in g_outs]
+        g_out = torch.cat([p_.contiguous() for p_ in parts], dim=0)
     gD, up, shared = decoder_bwd(sv["dec"], g_out, P, grads, side)
     # relu_z1: z1 is the ReLU output of z1_conv's block, whose backward would start by masking gz1 -- done here
     if shared:

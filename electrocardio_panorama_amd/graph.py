@@ -118,7 +118,7 @@ class GraphedTrainStep:
                                       phase="train", training=True, drop=drop, lead_choice=self.choice_dev, save=True,
                                       status=self.status)
             o, p_, l_ = (t.contiguous() for t in outs)
-            self.losses.copy_(ops.loss_fwd(o, p_, l_, self.target, self.factors, self.reg_l2, self.use_mask))
+            ops.loss_fwd(o, p_, l_, self.target, self.factors, self.reg_l2, self.use_mask, out=self.losses)
             g3 = ops.loss_bwd(o, p_, l_, self.target, None, self.factors, self.reg_l2, self.use_mask)
             return engine.backward(P, sv, g3)
 
@@ -130,7 +130,7 @@ class GraphedTrainStep:
 
     def _body(self):
         grads = self._fwd_bwd()
-        torch.cat([grads[k].reshape(-1) for k in self.live], out=self.flat_g)
+        ops.flatten_into([grads[k] for k in self.live], self.flat_g)
         ops.h2_taint(self.flat_g_all[:1])      # this step's clamped split-fp16 launches: the update is skipped (on every rank)
         if not self.dp:
             self._sgd()
@@ -153,7 +153,7 @@ class GraphedTrainStep:
                 raise RuntimeError("early gradient bucket is not a suffix of the live parameters")
             named = dict(self.model.named_parameters())
             info["k0"], info["split"] = k0, sum(named[k].numel() for k in self.live[:k0])
-            torch.cat([grads[k].reshape(-1) for k in early], out=self.flat_g[info["split"]:])
+            ops.flatten_into([grads[k] for k in early], self.flat_g[info["split"]:])
             gA.capture_end()
             gB.capture_begin(pool=gA.pool())
 
@@ -172,7 +172,7 @@ class GraphedTrainStep:
             if "split" not in info:
                 raise RuntimeError("engine.backward never reached its early-bucket point")
             if info["k0"]:
-                torch.cat([grads[k].reshape(-1) for k in self.live[:info["k0"]]], out=self.flat_g[:info["split"]])
+                ops.flatten_into([grads[k] for k in self.live[:info["k0"]]], self.flat_g[:info["split"]])
             ops.h2_taint(self.flat_g_all[:1])
             gB.capture_end()
         torch.cuda.current_stream().wait_stream(cap)

@@ -381,12 +381,10 @@ def amax_roll():
     for st in _AMAX.values():
         st["occ"].clear()
         if st["used"]:
-            cur, nxt = st["cur"], st["nxt"]
-            upd = (nxt > 0) & ((cur <= 0) | (nxt > H2_FOLLOW_UP * cur) | (nxt * H2_FOLLOW_DOWN < cur))
-            if _H2_AMAX == "follow":
-                upd = nxt > 0
-            torch.where(upd, nxt, cur, out=cur)
-            nxt.zero_()
+            # one launch over the slots handed out so far (rounds 4-5: ~10 torch elementwise launches per pass)
+            with torch.cuda.device(st["cur"].device):
+                _lib.check(_lib.load().nef_amax_roll(_p(st["cur"]), _p(st["nxt"]), int(st["n"]), H2_FOLLOW_UP, H2_FOLLOW_DOWN,
+                                                     int(_H2_AMAX == "follow"), _stream()), "nef_amax_roll")
             st["used"] = False
 
 
@@ -415,13 +413,23 @@ def wino_ok(K, Cin_g, Cout_g, T_out, pro=0):
             ((Cout_g % 128 == 0 and T_out >= 128) or (Cout_g % 128 != 0 and Cout_g % 64 == 0 and T_out >= 256)))
 
 
-_PREPACKED = {}     # (weight data_ptr, G, flip, wino) -> operand packed by pack_many(), consumed by the next pack_weight()
+_PREPACKED = {}     # (weight data_ptr, G, flip, wino, src) -> operand packed by pack_many(), consumed by the next pack_weight()
 
 
-def _pack_shape(w, G, flip, T, f4=False, plain=True):
+def _logical_shape(w, src):
+    """Shape of the weight tensor that is packed: w's own, or -- src = ("poly", Cr) -- the PHASE weights of conv1d(upsample2(x), w)
+    (twice the rows, formed inside the pack kernel: nef_pack_desc.src_mode 1)."""
+    if src is None:
+        return tuple(w.shape)
+    assert src[0] == "poly" and w.shape[2] == 3, src
+    return (2 * w.shape[0], w.shape[1], 3)
+
+
+def _pack_shape(w, G, flip, T, f4=False, plain=True, src=None):
     """`plain`: the launch has no prologue, channel scale, statistics or BatchNorm-backward sums -- the only launches the packed
     short-row form of the split-fp16 kernel (8 <= T <= 64) takes; pass False for the others so that they fall back to the fp32 kernels."""
-    Cog, Cig, K = w.shape[0] // G, w.shape[1], w.shape[2]
+    shp = _logical_shape(w, src)
+    Cog, Cig, K = shp[0] // G, shp[1], shp[2]
     cin_g, cout_g = (Cog, Cig) if flip else (Cig, Cog)          # roles in the launch that consumes the operand
     wino = (WINO_FWD if f4 else 1) if (T is not None and wino_ok(K, cin_g, cout_g, T)) else 0
     if (T is not None and (T >= 128 or plain) and h2_ok(K, cin_g, cout_g, T) and _H2_DIR[bool(flip)] and str(K) in _H2_K and
@@ -430,58 +438,83 @@ def _pack_shape(w, G, flip, T, f4=False, plain=True):
     return Cog, Cig, K, wino
 
 
+def _req(r):
+    """(w, G, flip, T[, f4[, src[, plain[, site]]]]) -> the full tuple."""
+    w, G, flip, T, *rest = r
+    rest = list(rest) + [False, None, True, None][len(rest):]
+    return (w, G, bool(flip), T, bool(rest[0]), rest[1], bool(rest[2]), rest[3])
+
+
 def pack_many(requests):
-    """All operands of a pass in ONE launch.  `requests`: iterable of (w, G, flip, T[, f4]) exactly as the later
-    pack_weight(w, G, flip=flip, T=T, f4=f4) calls will ask for them; those calls then return the pre-packed operand instead of
-    launching.  Anything not pre-packed still packs on demand, so a missing or surplus request costs time, never
-    correctness; the table is reset at every call."""
+    """All operands of a pass -- or, from engine.forward(save=True), of a whole train step: forward AND backward-data operands,
+    the polyphase ones included -- in ONE launch.  `requests`: iterable of (w, G, flip, T[, f4[, src[, plain[, site]]]]) exactly as
+    the later pack_weight(w, G, flip=flip, T=T, f4=f4, src=src, plain=plain, site=site) calls will ask for them; those calls then
+    return the pre-packed operand instead of launching.  Anything not pre-packed still packs on demand, so a missing or surplus
+    request costs time, never correctness.  A call whose requests are ALL still waiting in the table (a pass-level call inside a
+    step whose step-level call has already packed everything) does nothing; any other call resets the table first."""
     L = _lib.load()
-    _PREPACKED.clear()
-    reqs = []
-    for w, G, flip, T, *rest in requests:
+    reqs, keys = [], []
+    for r in requests:
+        w, G, flip, T, f4, src, plain, site = _req(r)
         _chk(w)
-        Cog, Cig, K, wino = _pack_shape(w, G, flip, T, bool(rest and rest[0]))
-        key = (w.data_ptr(), G, bool(flip), wino)
-        if key not in _PREPACKED:
-            _PREPACKED[key] = None
-            reqs.append((key, w, G, Cog, Cig, K, bool(flip), wino))
+        Cog, Cig, K, wino = _pack_shape(w, G, flip, T, f4, plain, src)
+        key = (w.data_ptr(), G, flip, wino, src)
+        if key not in keys:
+            keys.append(key)
+            reqs.append((key, w, G, Cog, Cig, K, flip, wino, src, site))
+    if keys and all(_PREPACKED.get(k) is not None and _PREPACKED[k][1] is r_[1] and _PREPACKED[k][2] == r_[1]._version
+                    for k, r_ in zip(keys, reqs)):
+        return
+    _PREPACKED.clear()
     if not reqs:
         return
-    sizes = [(_packed_floats(wino, K, G, Cog, Cig, flip) + 3) // 4 * 4 for _, _, G, Cog, Cig, K, flip, wino in reqs]      # 16-byte aligned operands
+    sizes = [(_packed_floats(wino, K, G, Cog, Cig, flip) + 3) // 4 * 4 for _, _, G, Cog, Cig, K, flip, wino, _, _ in reqs]      # 16-byte aligned operands
     arena = torch.empty(sum(sizes), device=reqs[0][1].device, dtype=torch.float32)
     descs = (_lib.PackDesc * len(reqs))()
     off = 0
-    for d, n, (key, w, G, Cog, Cig, K, flip, wino) in zip(descs, sizes, reqs):
+    for d, n, (key, w, G, Cog, Cig, K, flip, wino, src, site) in zip(descs, sizes, reqs):
+        if src is not None and wino != 3:
+            raise _lib.NefLibraryError("pack_many: a synthesized (polyphase) operand outside the split-fp16 kernel")
         wp = arena[off:off + n]
         off += n
         if wino:
             wp.nef_wino = wino
-            wp.nef_site = (w.data_ptr(), flip)
+            wp.nef_site = (w.data_ptr() if site is None else site, flip)
         d.w, d.wp, d.G, d.Cog, d.Cig, d.K, d.transpose_flip, d.wino = w.data_ptr(), wp.data_ptr(), G, Cog, Cig, K, int(flip), int(wino)
-        _PREPACKED[key] = (wp, w)          # keep the source alive while its pointer is the key
+        d.src_mode, d.src_Cr = (1, int(src[1])) if src is not None else (0, 0)
+        _PREPACKED[key] = (wp, w, w._version)          # keep the source alive while its pointer is the key
     _lib.check(L.nef_pack_weights(descs, len(reqs), _stream()), "nef_pack_weights")
 
 
-def pack_weight(w, G, flip=False, T=None, f4=False, site=None, shared=False, plain=True):
+def pack_weight(w, G, flip=False, T=None, f4=False, site=None, shared=False, plain=True, src=None):
     """w [G*Cog, Cig, K] -> packed operand (forward: [G][K][Cig][Cog]; flip: [G][K][Cog][Cig], taps reversed).
     `T`: output length of the conv launch this operand is for; when the Winograd F(2,3) path applies to that launch
-    the operand is packed for it (marked with `.nef_wino`) and `conv()` takes that path; `f4` allows the F(4,3) form."""
+    the operand is packed for it (marked with `.nef_wino`) and `conv()` takes that path; `f4` allows the F(4,3) form.
+    `src` = ("poly", Cr): pack the phase weights of conv1d(upsample2(x), w) instead of w itself (split-fp16 operands only)."""
     L = _lib.load()
     _chk(w)
-    Cog, Cig, K, wino = _pack_shape(w, G, flip, T, f4, plain)
-    hit = _PREPACKED.pop((w.data_ptr(), G, bool(flip), wino), None)
-    if hit is not None and hit[1] is w:
+    Cog, Cig, K, wino = _pack_shape(w, G, flip, T, f4, plain, src)
+    hit = _PREPACKED.pop((w.data_ptr(), G, bool(flip), wino, src), None)
+    if hit is not None and hit[1] is w and hit[2] == w._version:
         return hit[0]
     # `site`: identity of the call site for the split-fp16 input-magnitude slots when `w` is a temporary (default: w's address)
     if wino == 3:
         wp = torch.empty(_packed_floats(3, K, G, Cog, Cig, flip), device=w.device, dtype=torch.float32)
-        _lib.check(L.nef_pack_weight_h2(_p(w), _p(wp), G, Cog, Cig, K, int(flip), _stream()), "nef_pack_weight_h2")
+        if src is None:
+            _lib.check(L.nef_pack_weight_h2(_p(w), _p(wp), G, Cog, Cig, K, int(flip), _stream()), "nef_pack_weight_h2")
+        else:
+            d = (_lib.PackDesc * 1)()
+            d[0].w, d[0].wp, d[0].G, d[0].Cog, d[0].Cig, d[0].K, d[0].transpose_flip, d[0].wino = w.data_ptr(), wp.data_ptr(), G, Cog, Cig, K, int(flip), 3
+            d[0].src_mode, d[0].src_Cr = 1, int(src[1])
+            _lib.check(L.nef_pack_weights(d, 1, _stream()), "nef_pack_weights")
         wp.nef_wino = 3
         wp.nef_site = (w.data_ptr() if site is None else site, bool(flip))
         # shared: every launch of a pass through this operand is ONE call site (a loop over chunks of one tensor family, e.g.
         # the panorama sweep's angle chunks) instead of one site per occurrence
         wp.nef_shared = bool(shared)
         return wp
+    if src is not None:
+        raise _lib.NefLibraryError("pack_weight: a synthesized (polyphase) operand outside the split-fp16 kernel")
     if wino:
         wp = torch.empty(G * _WINO_PLANES[(wino, K)] * Cog * Cig, device=w.device, dtype=torch.float32)
         fn = L.nef_pack_weight_wino if wino == 1 else L.nef_pack_weight_wino4
@@ -506,8 +539,9 @@ def conv_stats_buffer(wp, B, G, Cog, T_out, device):
     return torch.empty(G * Cog, B * nslot, 2, device=device, dtype=torch.float32), nslot
 
 
-def bn_stats_from_slots(stats, gamma, beta, running_mean, running_var, P, N, Ln, eps=1e-5, momentum=0.1):
-    """bn_train_stats from the slot sums a conv epilogue left (x [N, C, Ln] itself is not read)."""
+def bn_stats_from_slots(stats, gamma, beta, running_mean, running_var, P, N, Ln, eps=1e-5, momentum=0.1, nbt=None):
+    """bn_train_stats from the slot sums a conv epilogue left (x [N, C, Ln] itself is not read).  `nbt`: the BatchNorm's
+    num_batches_tracked (int64[]), incremented by P in the same launch."""
     L = _lib.load()
     slots, nslot = stats
     Ct = slots.shape[0]
@@ -515,7 +549,7 @@ def bn_stats_from_slots(stats, gamma, beta, running_mean, running_var, P, N, Ln,
     n = L.nef_bn_ws_bytes(P, Ct)
     ws = workspace(n, slots.device)
     _lib.check(L.nef_bn_stats_from_slots(_p(slots), nslot, _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(mean),
-                                         _p(invstd), _p(a), _p(b), _p(ws), n, P, N // P, Ct, Ln, eps, momentum, _stream()),
+                                         _p(invstd), _p(a), _p(b), _p(ws), n, P, N // P, Ct, Ln, eps, momentum, _p(nbt), _stream()),
                "nef_bn_stats_from_slots")
     return mean, invstd, a, b
 
@@ -642,8 +676,8 @@ def conv_poly_fwd(xv, w, Cog, bias=None, pro=None, stats=False, site=None, save_
     G, Cig, Th = xv.G, xv.Cg, xv.T
     assert w.shape == (G * Cog, Cig, 3) and xv.bs == G * Cig * Th and xv.gs == Cig * Th, "conv_poly_fwd: dense input rows"
     aff = pro is not None and bool(pro[0] & 1)
-    ws = poly_weights(w, Cog)
-    wp = pack_weight(ws, G, T=Th, site=w.data_ptr() if site is None else site, plain=False)
+    # the phase weights are formed inside the pack (nef_pack_desc.src_mode 1): no poly_weights launch, no fp32 phase tensor
+    wp = pack_weight(w, G, T=Th, site=w.data_ptr() if site is None else site, plain=False, src=("poly", Cog))
     if int(getattr(wp, "nef_wino", 0)) != 3:
         raise _lib.NefLibraryError("conv_poly_fwd: shape outside the split-fp16 kernel (ask poly_fwd_ok first)")
     y = torch.empty(xv.B, G * Cog, 2 * Th, device=xv.t.device, dtype=torch.float32)
@@ -681,8 +715,7 @@ def conv_bwd_data_poly(gyv, w, Cig, bnb=None, site=None, phase_major=False):
         G, Cog, T = gyv.G, gyv.Cg, gyv.T
     Th = T // 2
     assert w.shape == (G * Cog, Cig, 3) and gyv.gs == Cog * T, "conv_bwd_data_poly: dense gradient rows"
-    ws = poly_weights(w)
-    wp = pack_weight(ws, G, flip=True, T=Th, site=w.data_ptr() if site is None else site)
+    wp = pack_weight(w, G, flip=True, T=Th, site=w.data_ptr() if site is None else site, src=("poly", 0))
     if int(getattr(wp, "nef_wino", 0)) != 3:
         raise _lib.NefLibraryError("conv_bwd_data_poly: shape outside the split-fp16 kernel (ask poly_bwd_ok first)")
     xv = GV(gyv.t, gyv.B, G, 2 * Cog, Th, gyv.bs, gyv.gs, gyv.off)
@@ -1164,7 +1197,7 @@ def pass_combine_fwd(P2, bias, B):
     return c1
 
 
-def pass_combine_fwd_stats(P2, bias, B, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
+def pass_combine_fwd_stats(P2, bias, B, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, nbt=None):
     """pass_combine_fwd + the train-mode BatchNorm statistics of its output: returns (c1, mean, invstd, a, b)."""
     L = _lib.load()
     _chk(P2), _chk(bias)
@@ -1177,7 +1210,7 @@ def pass_combine_fwd_stats(P2, bias, B, gamma, beta, running_mean, running_var, 
     ev = _hbm("pass_combine_fwd", P2, c1)
     _lib.check(L.nef_pass_combine_fwd_stats(_p(P2), _p(bias), _p(c1), _p(gamma), _p(beta), _p(running_mean),
                                             _p(running_var), _p(mean), _p(invstd), _p(a), _p(b), _p(ws), n, B, Ct, Ln, eps,
-                                            momentum, _stream()), "nef_pass_combine_fwd_stats")
+                                            momentum, _p(nbt), _stream()), "nef_pass_combine_fwd_stats")
     _done(ev)
     return c1, mean, invstd, a, b
 
@@ -1239,7 +1272,7 @@ def upsample2_bwd(gy):
     return gx
 
 
-def bn_train_stats(x, gamma, beta, running_mean, running_var, P, eps=1e-5, momentum=0.1):
+def bn_train_stats(x, gamma, beta, running_mean, running_var, P, eps=1e-5, momentum=0.1, nbt=None):
     """Returns (mean, invstd, a, b), each [P, C]; updates the running statistics in place, pass by pass."""
     L = _lib.load()
     _chk(x)
@@ -1250,7 +1283,7 @@ def bn_train_stats(x, gamma, beta, running_mean, running_var, P, eps=1e-5, momen
     ws = workspace(n, x.device)
     ev = _hbm("bn_train_stats", x)
     _lib.check(L.nef_bn_train_stats(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(mean), _p(invstd),
-                                    _p(a), _p(b), _p(ws), n, P, Bp, Ct, Ln, eps, momentum, _stream()), "nef_bn_train_stats")
+                                    _p(a), _p(b), _p(ws), n, P, Bp, Ct, Ln, eps, momentum, _p(nbt), _stream()), "nef_bn_train_stats")
     _done(ev)
     return mean, invstd, a, b
 
@@ -1411,11 +1444,11 @@ def outconv_bwd_weight(gout, out, x, pro=None):
 
 
 # ------------------------------------------------------------------ loss / optimiser
-def loss_fwd(pred, pred_p, pred_l, target, factors, reg_l2, use_mask):
+def loss_fwd(pred, pred_p, pred_l, target, factors, reg_l2, use_mask, out=None):
     L = _lib.load()
     for t in (pred, pred_p, pred_l, target):
         _chk(t)
-    losses = torch.empty(4, device=pred.device, dtype=torch.float32)
+    losses = torch.empty(4, device=pred.device, dtype=torch.float32) if out is None else out
     n = L.nef_loss_ws_bytes()
     ws = workspace(n, pred.device)
     _lib.check(L.nef_loss_fwd(_p(pred), _p(pred_p), _p(pred_l), _p(target), _p(losses), _p(ws), n, pred.numel(),
@@ -1425,11 +1458,58 @@ def loss_fwd(pred, pred_p, pred_l, target, factors, reg_l2, use_mask):
 
 def loss_bwd(pred, pred_p, pred_l, target, gscale, factors, reg_l2, use_mask):
     L = _lib.load()
-    g_pred, g_p, g_l = torch.empty_like(pred), torch.empty_like(pred_p), torch.empty_like(pred_l)
+    # the three gradients as ONE [3B, 1, L] buffer (views): engine._head_bwd takes it as the stacked decoder-output gradient as is
+    g3 = torch.empty((3 * pred.shape[0],) + tuple(pred.shape[1:]), device=pred.device, dtype=torch.float32)
+    g_pred, g_p, g_l = g3[0:pred.shape[0]], g3[pred.shape[0]:2 * pred.shape[0]], g3[2 * pred.shape[0]:]
     _lib.check(L.nef_loss_bwd(_p(pred), _p(pred_p), _p(pred_l), _p(target), _p(gscale), _p(g_pred), _p(g_p), _p(g_l),
                               pred.numel(), factors[0], factors[1], factors[2], int(reg_l2), use_mask, _stream()),
                "nef_loss_bwd")
     return g_pred, g_p, g_l
+
+
+def flatten_into(tensors, out):
+    """out[:] = concatenation of `tensors` (contiguous fp32, flattened), ONE launch per 64 tensors (nef_flatten; was torch.cat)."""
+    n = len(tensors)
+    if n == 0:
+        return out
+    tensors = [t.detach() if t.is_contiguous() else t.detach().contiguous() for t in tensors]
+    if not out.is_cuda or any((not t.is_cuda) or t.dtype != torch.float32 for t in tensors) or out.dtype != torch.float32:
+        return torch.cat([t.reshape(-1) for t in tensors], out=out)          # (CPU plumbing tests; never on the device path)
+    assert out.is_contiguous() and out.numel() == sum(t.numel() for t in tensors), (out.numel(), sum(t.numel() for t in tensors))
+    srcs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    sizes = (C.c_int64 * n)(*[t.numel() for t in tensors])
+    _lib.check(_lib.load().nef_flatten(srcs, sizes, n, _p(out), _stream()), "nef_flatten")
+    return out
+
+
+def stacked3(parts):
+    """The three [B, 1, L] tensors as one [3B, 1, L] tensor WITHOUT a copy when they are consecutive views of one buffer (what
+    loss_bwd returns), else None."""
+    a, b, c = parts
+    if any(t is None or not t.is_contiguous() for t in parts) or not (a.shape == b.shape == c.shape):
+        return None
+    n = a.numel() * 4
+    if b.data_ptr() != a.data_ptr() + n or c.data_ptr() != b.data_ptr() + n or a._base is None or a._base is not b._base or a._base is not c._base:
+        return None
+    base = a._base
+    if base.is_contiguous() and base.data_ptr() == a.data_ptr() and base.numel() == 3 * a.numel():
+        return base.view((3 * a.shape[0],) + tuple(a.shape[1:]))
+    return None
+
+
+def regroup_halves(w, inverse=False):
+    """w [Co, 2 Cih, K] -> grouped [2 Co, Cih, K] (group = input-channel half); inverse: the other way.  One launch (nef_regroup_halves)."""
+    _chk(w)
+    if inverse:
+        co2, cih, k = w.shape
+        out = torch.empty(co2 // 2, 2 * cih, k, device=w.device, dtype=torch.float32)
+        co = co2 // 2
+    else:
+        co, ci, k = w.shape
+        cih = ci // 2
+        out = torch.empty(2 * co, cih, k, device=w.device, dtype=torch.float32)
+    _lib.check(_lib.load().nef_regroup_halves(_p(w), _p(out), co, cih, k, int(bool(inverse)), _stream()), "nef_regroup_halves")
+    return out
 
 
 def view_metrics(pred, gt, rois=None):

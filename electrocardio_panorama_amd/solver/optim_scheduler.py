@@ -78,7 +78,7 @@ class FusedSGD(torch.optim.Optimizer):
             if parallel.TIMING is not None and world > 1:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            torch.cat([p.grad.reshape(-1) for p in live], out=flat)
+            ops.flatten_into([p.grad for p in live], flat)
             if world > 1:
                 dist.all_reduce(flat if flat_all is None else flat_all)      # one RCCL sum all-reduce over xGMI (+ the taint word)
             if ev is not None:
@@ -87,7 +87,7 @@ class FusedSGD(torch.optim.Optimizer):
             return
         k = len(names) - len(early["names"])
         if k:
-            torch.cat([p.grad.reshape(-1) for p in live[:k]], out=flat[:split])
+            ops.flatten_into([p.grad for p in live[:k]], flat[:split])
         ev = None
         if parallel.TIMING is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

@@ -34,7 +34,7 @@ extern "C" {
 typedef void* nef_stream_t;
 
 /* ABI version of this header; bumped on any signature change. */
-int nef_abi_version(void);   /* 17 (round 5: + pro_mode 4 / 8 / 9, nef_poly_weights, nef_poly_fwd_edge, nef_poly_bwd_edge, nef_mix_bwd_shared: polyphase forward / backward-data through the x2 upsampling); 16 (round 5: + nef_set_option / nef_get_option); 15 (round 4: + x_clamped / clamped counters); 14 (round 4: + nef_conv_bwd_weight_h2); 13 (round 4: + nef_pack_weight_h2 / conv args wino = 3 and x_scale: direct convolutions on exact fp16 splits of the fp32 operands); 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
+int nef_abi_version(void);   /* 18 (round 6: nef_pack_desc + src_mode / src_Cr (polyphase weights synthesized inside the pack), + nef_amax_roll, nef_flatten, nef_regroup_halves, + num_batches_tracked in the three BatchNorm statistics entry points); 17 (round 5: + pro_mode 4 / 8 / 9, nef_poly_weights, nef_poly_fwd_edge, nef_poly_bwd_edge, nef_mix_bwd_shared: polyphase forward / backward-data through the x2 upsampling); 16 (round 5: + nef_set_option / nef_get_option); 15 (round 4: + x_clamped / clamped counters); 14 (round 4: + nef_conv_bwd_weight_h2); 13 (round 4: + nef_pack_weight_h2 / conv args wino = 3 and x_scale: direct convolutions on exact fp16 splits of the fp32 operands); 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
 
 /* Kernel-form options of the process (tuning / A-B hooks; every value computes the same results).  Not part of any reference
  * interface: the reference's nn.Conv1d has one form (codes/network/model_nefnet.py:18-21).  Returns the previous value, or
@@ -102,6 +102,11 @@ typedef struct nef_pack_desc {
     const float* w;
     float* wp;
     int32_t G, Cog, Cig, K, transpose_flip, wino;
+    /* round 6, wino = 3 only: how the packed tensor [G*Cog][Cig][K] is read out of `w`.  0: `w` is that tensor.  1: `w` is
+     * [G*Cog/2][Cig][3] and the packed tensor holds the two PHASE weights of each row (conv1d(upsample2(x), w) as two K = 3 convs on the
+     * half-resolution x, codes/network/model_nefnet.py:102-105 -- what nef_poly_weights would write, formed inside the pack so the
+     * phase tensor is never materialised); src_Cr = 0: row 2 r + p, src_Cr = Cog/2 > 0: the tile order of the polyphase forward launch. */
+    int32_t src_mode, src_Cr;
 } nef_pack_desc;
 int nef_pack_weights(const nef_pack_desc* descs, int n, nef_stream_t stream);
 
@@ -368,7 +373,7 @@ size_t nef_pass_combine_stats_ws_bytes(int B, int C);
 int nef_pass_combine_fwd_stats(const float* P2, const float* bias, float* c1, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float* mean, float* invstd, float* a, float* b,
                                void* ws, size_t ws_bytes, int B, int C, int L, float eps, float momentum,
-                               nef_stream_t stream);
+                               int64_t* num_batches_tracked, nef_stream_t stream);
 int nef_pass_combine_bwd(const float* gc1, float* gP2, int B, int C, int L, nef_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -397,10 +402,14 @@ int nef_conv_stats_slots(int T, int Cout_g);
 int nef_bn_stats_from_slots(const float* slots, int nslot, const float* gamma, const float* beta, float* running_mean,
                             float* running_var, float* mean, float* invstd, float* a, float* b, void* ws,
                             size_t ws_bytes, int P, int Bp, int C, int L, float eps, float momentum,
-                            nef_stream_t stream);
+                            int64_t* num_batches_tracked, nef_stream_t stream);
 int nef_bn_train_stats(const float* x, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, float* mean, float* invstd, float* a, float* b, void* ws, size_t ws_bytes,
-                       int P, int Bp, int C, int L, float eps, float momentum, nef_stream_t stream);
+                       int P, int Bp, int C, int L, float eps, float momentum, int64_t* num_batches_tracked,
+                       nef_stream_t stream);
+/* (round 6) num_batches_tracked: NULL, or the BatchNorm's int64 counter, incremented by the number of passes P by the same launch
+ * that updates the running statistics (nn.BatchNorm1d in train mode, codes/network/model_nefnet.py:19,22) -- in all three entry
+ * points above (nef_pass_combine_fwd_stats: P = 3). */
 int nef_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float* a, float* b, int C, float eps, nef_stream_t stream);
 /* Eval-mode BN folded into the preceding conv (inference sweep): w_out[co][:] = a[co]*w[co][:], bias_out = a*bias + b;
@@ -480,6 +489,17 @@ int nef_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, 
  * and makes nef_sgd_momentum skip the update.  No counterpart in the reference (its fp32 nn.Conv1d cannot overflow at 65504,
  * codes/network/model_nefnet.py:18-21); capturable, nothing is read by the host. */
 int nef_h2_taint(const int32_t* clamped_total, int32_t* mark, float* out, nef_stream_t stream);
+/* Once per forward pass over the table of split-fp16 call-site magnitudes (ops.amax_roll; no counterpart in the reference, whose
+ * fp32 convs need no operand scale): cur[i] = nxt[i] where nxt[i] > 0 and (cur[i] <= 0, or nxt[i] > follow_up * cur[i], or
+ * nxt[i] * follow_down < cur[i], or follow_always); then nxt[i] = 0.  One launch. */
+int nef_amax_roll(float* cur, float* nxt, int n, float follow_up, float follow_down, int follow_always, nef_stream_t stream);
+/* out = concatenation of the n device tensors srcs[k] (sizes[k] floats each), one launch per 64 tensors.  `srcs` / `sizes` are HOST
+ * arrays.  Builds the flat gradient buffer FusedSGD / the data-parallel all-reduce work on (replaces the torch.cat of
+ * codes/solver's per-parameter .grad tensors; optim_scheduler.py:10 steps them one by one). */
+int nef_flatten(const float* const* srcs, const int64_t* sizes, int n, float* out, nef_stream_t stream);
+/* w [Co][2 Cih][K] -> grouped [2 Co][Cih][K] (group = input-channel half: the first decoder conv runs once per distinct half,
+ * DESIGN.md section 2; weight of codes/network/model_nefnet.py:18), inverse != 0: the other way (its gradient). */
+int nef_regroup_halves(const float* src, float* dst, int Co, int Cih, int K, int inverse, nef_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Polyphase form of a K = 3 conv behind the x2 linear upsampling (codes/network/model_nefnet.py:101-105, nn.Upsample + DoubleConv's

@@ -23,7 +23,7 @@ def test_header_symbols_exported():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().nef_abi_version() == 17
+    assert _lib.load().nef_abi_version() == 18
     assert ctypes.sizeof(_lib.ConvArgs) == 384 == _lib.load().nef_conv_args_bytes()
 
 
