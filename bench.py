@@ -131,7 +131,7 @@ def secondary(dev, headline=None):
     out = {}
     if headline is not None:
         try:
-            out["strict_fp32"] = strict_fp32(dev, *headline)
+            out["strict_fp32"] = strict_fp32(dev, headline[0], headline[1], headline[2], dropout=headline[3])
         except Exception as exc:
             out["strict_fp32"] = {"error": f"{type(exc).__name__}: {exc}"}
     out["reference-native 32x3x512"] = native_shape(dev)
@@ -659,6 +659,9 @@ def main():
             # is skipped on the device (ops.h2_taint -> sgd_momentum) and counted in h2_skipped_steps; Solver checks both per epoch
             "h2_clamped_waves": int(ops.h2_clamped(reset=False)) if ops.H2 else None,
             "h2_skipped_steps": int(ops.h2_skipped(reset=False)) if ops.H2 else None,
+            # call sites whose operand was heavy-tailed when the site measured it (amax > ops.H2_TAIL_RATIO x rms: the bulk of such a
+            # tensor sits below the format's full-precision window) -- 0 for this model; a model that counts here wants NEF_H2=0
+            "h2_tail_sites": int(ops.h2_tail_sites(reset=False)) if ops.H2 else None,
             "h2_headroom": f"{ops.H2_HEADROOM}x growth of an operand between two consecutive steps",
             # N > 1: time the launching stream spends waiting for gradient collectives per step (the encoder bucket's
             # all-reduce + whatever is left of the early bucket's, which runs under the encoder's backward pass)

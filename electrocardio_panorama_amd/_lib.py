@@ -135,6 +135,7 @@ SIGNATURES = {
     "nef_sgd_momentum": (i32, [p, p, p, i64, f32, f32, f32, i32, p, p, p, p]),
     "nef_h2_taint": (i32, [p, p, p, p]),
     "nef_amax_roll": (i32, [p, p, i32, f32, f32, i32, p]),
+    "nef_step_words": (i32, [p, p, i32, i32, i64, p]),
     "nef_flatten": (i32, [C.POINTER(p), C.POINTER(i64), i32, p, p]),
     "nef_regroup_halves": (i32, [p, p, i32, i32, i32, i32, p]),
     "nef_slots_to_rows": (i32, [p, i32, p, i32, i32, p]),

@@ -6,6 +6,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+# conv_mfma.hip is compiled as four objects (-DNEF_MFMA_PART=1..4: see the top of that file), in parallel with the other sources
+MFMA_PARTS = 4
 SOURCES = ["conv_mfma.hip", "conv_h2.hip", "conv_h2w.hip", "conv_bww_glds.hip", "stem.hip", "elementwise.hip", "roi.hip", "convt_theta.hip", "pano_h.hip", "metrics.hip"]
 LIB = os.path.join(HERE, "libnefnet_hip.so")
 # per-source extra flags.  Every source that issues matrix instructions is built WITHOUT SLP vectorisation: the packed-fp32
@@ -22,7 +24,7 @@ _NO_SLP = ["-fno-slp-vectorize"]
 EXPERIMENTS = ["conv_h2p.hip"]
 EXP_DIR = os.path.join(ROOT, "tools", "experiments")
 EXTRA_FLAGS = {s: _NO_SLP for s in SOURCES + EXPERIMENTS}
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable",
          "-I", os.path.join(ROOT, "include"), "-I", HERE]
 
 
@@ -36,6 +38,17 @@ def _with_experiments(flag=None):
 
 def _src(s):
     return os.path.join(EXP_DIR if s in EXPERIMENTS else HERE, s)
+
+
+def _units(sources):
+    """(source, extra -D flags, object path) for every object of the library."""
+    out = []
+    for s in sources:
+        if s == "conv_mfma.hip":
+            out += [(s, [f"-DNEF_MFMA_PART={i}"], os.path.join(HERE, f"conv_mfma_p{i}.o")) for i in range(1, MFMA_PARTS + 1)]
+        else:
+            out.append((s, [], os.path.join(HERE, s.replace(".hip", ".o"))))
+    return out
 
 
 def _stamp():
@@ -62,12 +75,14 @@ def build_variant(name, defines, sources=("conv_mfma.hip",)):
     os.makedirs(vdir, exist_ok=True)
     objs = []
     srcs = SOURCES + (EXPERIMENTS if (os.path.exists(_stamp()) or any(s in EXPERIMENTS for s in sources)) else [])
-    for s in srcs:
-        o = os.path.join(HERE, s.replace(".hip", ".o"))
+    procs = []
+    for s, dflags, o in _units(srcs):
         if s in sources or (s in EXPERIMENTS and not os.path.exists(o)):
-            o = os.path.join(vdir, f"{name}_{s.replace('.hip', '.o')}")
-            subprocess.check_call([hipcc()] + FLAGS + ["-w"] + EXTRA_FLAGS.get(s, []) + [f"-D{d}" for d in defines] + ["-c", _src(s), "-o", o])
+            o = os.path.join(vdir, f"{name}_{os.path.basename(o)}")
+            procs.append(subprocess.Popen([hipcc()] + FLAGS + ["-w"] + EXTRA_FLAGS.get(s, []) + dflags + [f"-D{d}" for d in defines] + ["-c", _src(s), "-o", o]))
         objs.append(o)
+    if any(p_.wait() != 0 for p_ in procs):
+        raise RuntimeError("hipcc failed")
     lib = os.path.join(vdir, f"lib{name}.so")
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     return lib
@@ -79,10 +94,9 @@ def build(force=False, verbose=True, experiments=None):
         return LIB
     objs = []
     procs = []
-    for s in SOURCES + (EXPERIMENTS if exp else []):
-        o = os.path.join(HERE, s.replace(".hip", ".o"))
-        cmd = [hipcc()] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", _src(s), "-o", o]
-        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, dflags, o in _units(SOURCES + (EXPERIMENTS if exp else [])):
+        cmd = [hipcc()] + FLAGS + EXTRA_FLAGS.get(s, []) + dflags + ["-c", _src(s), "-o", o]
+        procs.append((s + " " + " ".join(dflags), subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(o)
     failed = False
     for s, p in procs:

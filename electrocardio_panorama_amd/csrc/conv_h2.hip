@@ -400,6 +400,7 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
         }
     }
     const float xlim_ = 65000.f / xs_;
+    (void)xlim_;
     float amax_ = 0.f;
     float over_ret = -1.f;
     (void)over_ret;

@@ -16,6 +16,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Build-time split (round 6): this file is compiled FOUR times, -DNEF_MFMA_PART=1..4, into four objects that build in parallel
+// (one translation unit took 52 s -- the long pole of the library build).  Every part sees all templates; a part only INSTANTIATES
+// what its own dispatch code names: 1 = the C entry points + the direct kernels (forward, weight gradient), packs, channel sums;
+// 2 = the F(4,.) forward / backward-data kernels; 3 = the F(2,.) ones; 4 = the transposed-Winograd weight gradients.  Parts 2..4
+// are reached from part 1 through the hidden nef_mfma_* functions below.  NEF_MFMA_PART undefined / 0: everything in one object.
+#ifndef NEF_MFMA_PART
+#define NEF_MFMA_PART 0
+#endif
+#define NEF_PART(n) (NEF_MFMA_PART == 0 || NEF_MFMA_PART == (n))
+
 namespace {
 
 // NEF_ABL: timing-only ablation builds (tools/ablate_k7.py; results are WRONG by construction, never shipped): bit0 = no
@@ -2323,6 +2333,14 @@ __attribute__((visibility("hidden"))) bool nef_h2_ok(const nef_conv_args* a);
 __attribute__((visibility("hidden"))) int nef_h2_launch(const nef_conv_args* a, hipStream_t st);
 __attribute__((visibility("hidden"))) int nef_h2_pack(const nef_pack_desc* descs, int n, hipStream_t st);
 
+__attribute__((visibility("hidden"))) int nef_mfma_wino4_fwd(const nef_conv_args* a, hipStream_t st);
+__attribute__((visibility("hidden"))) int nef_mfma_wino_fwd(const nef_conv_args* a, hipStream_t st);
+__attribute__((visibility("hidden"))) int nef_mfma_bww_wino4(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
+                              int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
+                              const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B,
+                              int T, int G, int Cin_g, int Cout_g, int K, nef_stream_t stream);
+
+#if NEF_PART(1)
 extern "C" {
 
 int nef_abi_version(void) { return 18; }
@@ -2457,36 +2475,8 @@ int nef_conv_fwd(const nef_conv_args* a, nef_stream_t stream) {
     const int KC = K == 1 ? FwdStage<1, 1>::KC : (big ? FwdStage<3, 2>::KC : FwdStage<3, 1>::KC);
     static_assert(FwdStage<7, 2>::KC == FwdStage<3, 2>::KC && FwdStage<7, 1>::KC == FwdStage<3, 1>::KC, "stage sizes");
     NEF_REQUIRE(a->Cin_g % KC == 0, NEF_E_SHAPE);
-    if (a->wino == 2) {  // weights packed for F(4,3) (nef_pack_weight_wino with variant 4)
-        NEF_REQUIRE((K == 3 || K == 7) && a->T % 2 == 0 && a->Cin_g % WKC == 0, NEF_E_SHAPE);
-        NEF_REQUIRE(a->pro_mode >= 0 && a->pro_mode <= 3 && !(a->pro_mode && a->in_scale), NEF_E_UNSUPPORTED);
-        NEF_REQUIRE(K == 3 || a->pro_mode == 0, NEF_E_UNSUPPORTED);
-        NEF_REQUIRE(!(a->pro_mode & 1) || (a->pro_a && a->pro_b && a->pro_Bp > 0), NEF_E_NULL);
-        const bool wide = (a->Cout_g % 128 == 0);
-        NEF_REQUIRE(a->T >= (wide ? 128 : 256), NEF_E_SHAPE);
-        if (K == 7) return wide ? launch_conv_wino4<7, 4, 0>(*a, st) : launch_conv_wino4<7, 2, 0>(*a, st);
-        switch (a->pro_mode) {
-            case 0: return wide ? launch_conv_wino4<3, 4, 0>(*a, st) : launch_conv_wino4<3, 2, 0>(*a, st);
-            case 1: return wide ? launch_conv_wino4<3, 4, 1>(*a, st) : launch_conv_wino4<3, 2, 1>(*a, st);
-            case 2: return wide ? launch_conv_wino4<3, 4, 2>(*a, st) : launch_conv_wino4<3, 2, 2>(*a, st);
-            default: return wide ? launch_conv_wino4<3, 4, 3>(*a, st) : launch_conv_wino4<3, 2, 3>(*a, st);
-        }
-    }
-    if (a->wino) {       // weights packed by nef_pack_weight_wino: Winograd F(2,3) path, whole tiles of one sample only
-        NEF_REQUIRE((K == 3 || K == 7) && a->T % 2 == 0 && a->Cin_g % WKC == 0, NEF_E_SHAPE);
-        NEF_REQUIRE(a->pro_mode >= 0 && a->pro_mode <= 3 && !(a->pro_mode && a->in_scale), NEF_E_UNSUPPORTED);
-        NEF_REQUIRE(K == 3 || a->pro_mode == 0, NEF_E_UNSUPPORTED);
-        NEF_REQUIRE(!(a->pro_mode & 1) || (a->pro_a && a->pro_b && a->pro_Bp > 0), NEF_E_NULL);
-        const bool wide = (a->Cout_g % 128 == 0);
-        NEF_REQUIRE(a->T >= (wide ? 128 : 256), NEF_E_SHAPE);
-        if (K == 7) return wide ? launch_conv_wino<7, 2, 0>(*a, st) : launch_conv_wino<7, 1, 0>(*a, st);
-        switch (a->pro_mode) {
-            case 0: return wide ? launch_conv_wino<3, 2, 0>(*a, st) : launch_conv_wino<3, 1, 0>(*a, st);
-            case 1: return wide ? launch_conv_wino<3, 2, 1>(*a, st) : launch_conv_wino<3, 1, 1>(*a, st);
-            case 2: return wide ? launch_conv_wino<3, 2, 2>(*a, st) : launch_conv_wino<3, 1, 2>(*a, st);
-            default: return wide ? launch_conv_wino<3, 2, 3>(*a, st) : launch_conv_wino<3, 1, 3>(*a, st);
-        }
-    }
+    if (a->wino == 2) return nef_mfma_wino4_fwd(a, st);      // weights packed for F(4,3): part 2 of this file
+    if (a->wino) return nef_mfma_wino_fwd(a, st);            // weights packed for F(2,3): part 3 of this file
     if (a->pro_mode != 0) {
         NEF_REQUIRE(K == 3 && a->pro_mode >= 1 && a->pro_mode <= 3 && !a->in_scale, NEF_E_UNSUPPORTED);
         NEF_REQUIRE(!(a->pro_mode & 1) || (a->pro_a && a->pro_b && a->pro_Bp > 0), NEF_E_NULL);
@@ -2638,13 +2628,78 @@ int nef_conv_bwd_weight_h2(const float* x, int64_t x_bs, int64_t x_gs, const flo
     return nef_launch_status();
 }
 
+int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
+                              int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
+                              const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B,
+                              int T, int G, int Cin_g, int Cout_g, int K, nef_stream_t stream) {
+    return nef_mfma_bww_wino4(x, x_bs, x_gs, in_scale, sc_bs, sc_gs, pro_a, pro_b, pro_mode, pro_Bp, gy, gy_bs, gy_gs, gw, ws, ws_bytes, B, T, G, Cin_g, Cout_g, K, stream);
+}
+
+size_t nef_chan_sum_ws_bytes(int C) { return (size_t)CHAN_SUM_SPLIT * C * sizeof(double); }
+
+int nef_chan_sum(const float* x, float* out, void* ws, size_t ws_bytes, int B, int C, int T, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && out && ws, NEF_E_NULL);
+    NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(ws_bytes >= nef_chan_sum_ws_bytes(C), NEF_E_WORKSPACE);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(chan_sum_partial, dim3(C * CHAN_SUM_SPLIT), dim3(256), 0, st, x, (double*)ws, B, C, T,
+                       CHAN_SUM_SPLIT);
+    hipLaunchKernelGGL(chan_sum_final, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, out, C,
+                       CHAN_SUM_SPLIT);
+    return nef_launch_status();
+}
+
+}  // extern "C"
+#endif  // part 1
+
+#if NEF_PART(2)
+__attribute__((visibility("hidden"))) int nef_mfma_wino4_fwd(const nef_conv_args* a, hipStream_t st) {
+    const int K = a->K;
+        NEF_REQUIRE((K == 3 || K == 7) && a->T % 2 == 0 && a->Cin_g % WKC == 0, NEF_E_SHAPE);
+        NEF_REQUIRE(a->pro_mode >= 0 && a->pro_mode <= 3 && !(a->pro_mode && a->in_scale), NEF_E_UNSUPPORTED);
+        NEF_REQUIRE(K == 3 || a->pro_mode == 0, NEF_E_UNSUPPORTED);
+        NEF_REQUIRE(!(a->pro_mode & 1) || (a->pro_a && a->pro_b && a->pro_Bp > 0), NEF_E_NULL);
+        const bool wide = (a->Cout_g % 128 == 0);
+        NEF_REQUIRE(a->T >= (wide ? 128 : 256), NEF_E_SHAPE);
+        if (K == 7) return wide ? launch_conv_wino4<7, 4, 0>(*a, st) : launch_conv_wino4<7, 2, 0>(*a, st);
+        switch (a->pro_mode) {
+            case 0: return wide ? launch_conv_wino4<3, 4, 0>(*a, st) : launch_conv_wino4<3, 2, 0>(*a, st);
+            case 1: return wide ? launch_conv_wino4<3, 4, 1>(*a, st) : launch_conv_wino4<3, 2, 1>(*a, st);
+            case 2: return wide ? launch_conv_wino4<3, 4, 2>(*a, st) : launch_conv_wino4<3, 2, 2>(*a, st);
+            default: return wide ? launch_conv_wino4<3, 4, 3>(*a, st) : launch_conv_wino4<3, 2, 3>(*a, st);
+        }
+}
+#endif
+
+#if NEF_PART(3)
+__attribute__((visibility("hidden"))) int nef_mfma_wino_fwd(const nef_conv_args* a, hipStream_t st) {
+    const int K = a->K;
+        NEF_REQUIRE((K == 3 || K == 7) && a->T % 2 == 0 && a->Cin_g % WKC == 0, NEF_E_SHAPE);
+        NEF_REQUIRE(a->pro_mode >= 0 && a->pro_mode <= 3 && !(a->pro_mode && a->in_scale), NEF_E_UNSUPPORTED);
+        NEF_REQUIRE(K == 3 || a->pro_mode == 0, NEF_E_UNSUPPORTED);
+        NEF_REQUIRE(!(a->pro_mode & 1) || (a->pro_a && a->pro_b && a->pro_Bp > 0), NEF_E_NULL);
+        const bool wide = (a->Cout_g % 128 == 0);
+        NEF_REQUIRE(a->T >= (wide ? 128 : 256), NEF_E_SHAPE);
+        if (K == 7) return wide ? launch_conv_wino<7, 2, 0>(*a, st) : launch_conv_wino<7, 1, 0>(*a, st);
+        switch (a->pro_mode) {
+            case 0: return wide ? launch_conv_wino<3, 2, 0>(*a, st) : launch_conv_wino<3, 1, 0>(*a, st);
+            case 1: return wide ? launch_conv_wino<3, 2, 1>(*a, st) : launch_conv_wino<3, 1, 1>(*a, st);
+            case 2: return wide ? launch_conv_wino<3, 2, 2>(*a, st) : launch_conv_wino<3, 1, 2>(*a, st);
+            default: return wide ? launch_conv_wino<3, 2, 3>(*a, st) : launch_conv_wino<3, 1, 3>(*a, st);
+        }
+}
+#endif
+
+#if NEF_PART(4)
+extern "C" {
 // conv_bww_glds.hip: the same forms with the tiles streamed by LDS-DMA through a ring of LDS buffers
 __attribute__((visibility("hidden"))) bool nef_bww_glds_ok(int B, int T, int Cig, int Cog, int K, int pro_mode, int pro_Bp, bool in_scale);
 __attribute__((visibility("hidden"))) int nef_bww_glds_launch(const float* x, int64_t x_bs, int64_t x_gs, const float* gy, int64_t gy_bs, int64_t gy_gs, float* ws,
                         int B, int T, int G, int Cig, int Cog, int K, int half, const float* pro_a, const float* pro_b,
                         int pro_mode, int pro_Bp, int S_max, int fixed_S, int* S_used, hipStream_t st);
-
-int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
+}
+__attribute__((visibility("hidden"))) int nef_mfma_bww_wino4(const float* x, int64_t x_bs, int64_t x_gs, const float* in_scale, int64_t sc_bs,
                               int64_t sc_gs, const float* pro_a, const float* pro_b, int pro_mode, int pro_Bp,
                               const float* gy, int64_t gy_bs, int64_t gy_gs, float* gw, void* ws, size_t ws_bytes, int B,
                               int T, int G, int Cin_g, int Cout_g, int K, nef_stream_t stream) {
@@ -2707,20 +2762,4 @@ int nef_conv_bwd_weight_wino4(const float* x, int64_t x_bs, int64_t x_gs, const 
                        Cin_g, K, p.S);
     return nef_launch_status();
 }
-
-size_t nef_chan_sum_ws_bytes(int C) { return (size_t)CHAN_SUM_SPLIT * C * sizeof(double); }
-
-int nef_chan_sum(const float* x, float* out, void* ws, size_t ws_bytes, int B, int C, int T, nef_stream_t stream) {
-    NEF_ENTER();
-    NEF_REQUIRE(x && out && ws, NEF_E_NULL);
-    NEF_REQUIRE(B > 0 && C > 0 && T > 0, NEF_E_SHAPE);
-    NEF_REQUIRE(ws_bytes >= nef_chan_sum_ws_bytes(C), NEF_E_WORKSPACE);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(chan_sum_partial, dim3(C * CHAN_SUM_SPLIT), dim3(256), 0, st, x, (double*)ws, B, C, T,
-                       CHAN_SUM_SPLIT);
-    hipLaunchKernelGGL(chan_sum_final, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, out, C,
-                       CHAN_SUM_SPLIT);
-    return nef_launch_status();
-}
-
-}  // extern "C"
+#endif

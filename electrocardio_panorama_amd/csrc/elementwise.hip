@@ -1245,6 +1245,17 @@ __global__ __launch_bounds__(256) void regroup_halves_kernel(const float* __rest
     }
 }
 
+// step_words: the per-step host decisions of a replayed train step (the two Standin lead choices, the dropout seed) written into
+// their device words by a launch that carries them as kernel ARGUMENTS -- stream-ordered and asynchronous, where the blocking
+// host-to-device copies of rounds 1-5 made the host wait for the previous step before it could stage the next.
+__global__ void step_words_kernel(int32_t* __restrict__ choice, int64_t* __restrict__ seed, int c1, int c2, int64_t sd) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        choice[0] = c1;
+        choice[1] = c2;
+        seed[0] = sd;
+    }
+}
+
 // Diagnostics (bench.py --dry-collective): occupy `wgs` workgroups for `ticks` of the constant-rate wall clock -- a stand-in for a
 // collective of modelled duration on the communication stream of a ONE-GPU run (the all-reduce it replaces would hold a few CUs
 // of channel kernels for that long).  Bounded: the host side caps the duration at 50 ms.
@@ -1587,6 +1598,83 @@ __global__ __launch_bounds__(256) void bn_slots_reduce(const float* __restrict__
     }
 }
 
+// Round 6: bn_slots_reduce + bn_stats_final (forward) / + bn_bwd_final (backward) as ONE launch -- one workgroup per CHANNEL walks
+// its P passes: each pass's slot sums are block-reduced exactly as bn_slots_reduce does (same stride, same tree: bit-identical
+// totals) and thread 0 then does that pass's share of the final (running statistics pass by pass, in order).  Two launches fewer
+// per BatchNorm and direction; 4 x fewer workgroups, each with 3 x the work -- the 15 MB of slots still stream in ~10 us.
+__device__ __forceinline__ void bn_slot_totals(const float* __restrict__ slots, int c, int p, int P, int per_pass, double* sm,
+                                               double& s1, double& s2) {
+    const float2* src = (const float2*)slots + ((int64_t)c * P + p) * per_pass;
+    s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < per_pass; i += 256) {
+        const float2 v = src[i];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+    }
+    s1 = nef_block_sum_d(s1, sm);
+    s2 = nef_block_sum_d(s2, sm);
+}
+
+__global__ __launch_bounds__(256) void bn_slots_stats_fused(const float* __restrict__ slots, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var, float* __restrict__ mean,
+                                                            float* __restrict__ invstd, float* __restrict__ a, float* __restrict__ b, int P,
+                                                            int Bp, int C, int L, float eps, float momentum, int per_pass,
+                                                            int64_t* __restrict__ nbt) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x;
+    const double n = (double)Bp * (double)L;
+    float rm = running_mean ? running_mean[c] : 0.f;
+    float rv = running_var ? running_var[c] : 1.f;
+    for (int p = 0; p < P; ++p) {
+        double s1, s2;
+        bn_slot_totals(slots, c, p, P, per_pass, sm, s1, s2);
+        if (threadIdx.x == 0) {      // (bn_stats_final's arithmetic)
+            const double m = s1 / n;
+            double var = s2 / n - m * m;
+            if (var < 0.0) var = 0.0;
+            const float mf = (float)m;
+            const float is = (float)(1.0 / sqrt(var + (double)eps));
+            mean[p * C + c] = mf;
+            invstd[p * C + c] = is;
+            const float af = gamma[c] * is;
+            a[p * C + c] = af;
+            b[p * C + c] = beta[c] - mf * af;
+            const float unbiased = (float)(var * (n / (n - 1.0)));
+            rm = (1.f - momentum) * rm + momentum * mf;
+            rv = (1.f - momentum) * rv + momentum * unbiased;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (running_mean) running_mean[c] = rm;
+        if (running_var) running_var[c] = rv;
+        if (nbt && c == 0) nbt[0] += P;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_slots_bwd_fused(const float* __restrict__ slots, float* __restrict__ coef,
+                                                          float* __restrict__ ggamma, float* __restrict__ gbeta, int P, int Bp, int C,
+                                                          int L, int per_pass) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x;
+    const double n = (double)Bp * (double)L;
+    double g1 = 0.0, g2 = 0.0;
+    for (int p = 0; p < P; ++p) {
+        double s1, s2;
+        bn_slot_totals(slots, c, p, P, per_pass, sm, s1, s2);
+        if (threadIdx.x == 0) {      // (bn_bwd_final's arithmetic)
+            coef[(p * C + c) * 2] = (float)(s1 / n);
+            coef[(p * C + c) * 2 + 1] = (float)(s2 / n);
+            g1 += s1;
+            g2 += s2;
+        }
+    }
+    if (threadIdx.x == 0) {
+        gbeta[c] = (float)g1;
+        ggamma[c] = (float)g2;
+    }
+}
+
 // adjoint: gP2 A-half[mean] = g0 + g2, A-half[pick] = g1, B-half[mean] = g0 + g1, B-half[pick] = g2
 __global__ __launch_bounds__(256) void pass_combine_bwd_kernel(const float* __restrict__ gc1, float* __restrict__ gP2,
                                                                int B, int C, int L) {
@@ -1812,10 +1900,8 @@ int nef_bn_stats_from_slots(const float* slots, int nslot, const float* gamma, c
     NEF_REQUIRE(P > 0 && Bp > 0 && C > 0 && L > 0 && nslot > 0 && (int64_t)Bp * L > 1 &&
                     (int64_t)Bp * nslot <= 0x7FFFFFFF && (int64_t)P * C <= 0x7FFFFFFF, NEF_E_SHAPE);
     NEF_REQUIRE(ws_bytes >= nef_bn_ws_bytes(P, C), NEF_E_WORKSPACE);
-    hipLaunchKernelGGL(bn_slots_reduce, dim3((unsigned)(P * C)), dim3(256), 0, NEF_ST, slots, (double*)ws, P, C,
-                       Bp * nslot);
-    hipLaunchKernelGGL(bn_stats_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)ws, gamma, beta,
-                       running_mean, running_var, mean, invstd, a, b, P, Bp, C, L, eps, momentum, 1, num_batches_tracked);
+    hipLaunchKernelGGL(bn_slots_stats_fused, dim3((unsigned)C), dim3(256), 0, NEF_ST, slots, gamma, beta, running_mean, running_var, mean,
+                       invstd, a, b, P, Bp, C, L, eps, momentum, Bp * nslot, num_batches_tracked);
     return nef_launch_status();
 }
 
@@ -1886,9 +1972,7 @@ static int bn_relu_bwd_impl(const float* gy, const float* x, const float* gamma,
     float* coef = (float*)((char*)ws + (size_t)P * C * BN_SPLIT * 2 * sizeof(double));
     double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(P, C)) : nullptr;
     if (slots) {        // the producing conv left the sums per slot: add them up in fp64, fixed order
-        hipLaunchKernelGGL(bn_slots_reduce, dim3((unsigned)(P * C)), dim3(256), 0, NEF_ST, slots, part, P, C, Bp * nslot);
-        hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma,
-                           gbeta, P, Bp, C, L, 1);
+        hipLaunchKernelGGL(bn_slots_bwd_fused, dim3((unsigned)C), dim3(256), 0, NEF_ST, slots, coef, ggamma, gbeta, P, Bp, C, L, Bp * nslot);
     } else {
         hipLaunchKernelGGL(bn_bwd_partial<0>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part,
                            P, Bp, C, L, (const float*)nullptr);
@@ -1937,9 +2021,7 @@ int nef_bn_relu_bwd_up(const float* gu, const float* x, const float* mean, const
     float* coef = (float*)((char*)ws + (size_t)P * C * BN_SPLIT * 2 * sizeof(double));
     double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(P, C)) : nullptr;
     if (slots) {
-        hipLaunchKernelGGL(bn_slots_reduce, dim3((unsigned)(P * C)), dim3(256), 0, NEF_ST, slots, part, P, C, Bp * nslot);
-        hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma,
-                           gbeta, P, Bp, C, L, 1);
+        hipLaunchKernelGGL(bn_slots_bwd_fused, dim3((unsigned)C), dim3(256), 0, NEF_ST, slots, coef, ggamma, gbeta, P, Bp, C, L, Bp * nslot);
     } else {
         hipLaunchKernelGGL(bn_bwd_partial<2>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gu, x, mean, invstd, a, b, part,
                            P, Bp, C, L, (const float*)nullptr);
@@ -1968,9 +2050,7 @@ static int bn_relu_bwd_combine3_impl(const float* gy, const float* x, const floa
     float* coef = (float*)((char*)ws + (size_t)3 * C * BN_SPLIT * 2 * sizeof(double));
     double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(3, C)) : nullptr;
     if (slots) {
-        hipLaunchKernelGGL(bn_slots_reduce, dim3((unsigned)(3 * C)), dim3(256), 0, NEF_ST, slots, part, 3, C, Bp * nslot);
-        hipLaunchKernelGGL(bn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, NEF_ST, (const double*)part, coef, ggamma,
-                           gbeta, 3, Bp, C, L, 1);
+        hipLaunchKernelGGL(bn_slots_bwd_fused, dim3((unsigned)C), dim3(256), 0, NEF_ST, slots, coef, ggamma, gbeta, 3, Bp, C, L, Bp * nslot);
     } else {
         hipLaunchKernelGGL(bn_bwd_partial<0>, dim3(3 * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part,
                            3, Bp, C, L, (const float*)nullptr);
@@ -2185,6 +2265,13 @@ int nef_poly_bwd_edge(const float* gy, const float* w, float* gx, int B, int G, 
     NEF_REQUIRE(!bnb_slots || (bnb_x && bnb_mean && bnb_invstd && bnb_a && bnb_b && bnb_Bp > 0 && nslot > 0), NEF_E_NULL);
     hipLaunchKernelGGL(poly_bwd_edge_kernel, dim3((unsigned)(B * G)), dim3(256), (size_t)4 * Cog * sizeof(float), NEF_ST, gy, w, gx, B, G,
                        Cog, Cig, T, bnb_x, bnb_mean, bnb_invstd, bnb_a, bnb_b, bnb_Bp, bnb_slots, nslot, gy_phase_major);
+    return nef_launch_status();
+}
+
+int nef_step_words(int32_t* choice, int64_t* seed, int c1, int c2, int64_t seed_value, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(choice && seed, NEF_E_NULL);
+    hipLaunchKernelGGL(step_words_kernel, dim3(1), dim3(64), 0, NEF_ST, choice, seed, c1, c2, seed_value);
     return nef_launch_status();
 }
 

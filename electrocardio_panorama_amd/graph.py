@@ -198,7 +198,6 @@ class GraphedTrainStep:
             self.status = torch.zeros(1, device=dev, dtype=torch.int32)
             self.losses = torch.zeros(4, device=dev, dtype=torch.float32)
             self.lr_dev = torch.full((1,), self.lr, device=dev, dtype=torch.float32)
-            self._host = torch.zeros(4, dtype=torch.int64).pin_memory()
         # the probe runs THIS step's inputs, Standin choices and dropout seed (drawn by __call__ before it builds): the split-fp16
         # convs measure their operands in it, and what they measure must be what the eager path measures on the same step
         self._stage(data, in_theta, q_theta, rois, target, draw=False)
@@ -253,11 +252,14 @@ class GraphedTrainStep:
         rank = dist.get_rank() if self.world > 1 else 0
         # same ingredients as the eager path (model_nefnet.py: initial seed + call counter + epoch + rank): a resumed run
         # (Solver sets model.dropout_epoch; `calls` travels in state_dict) does not replay the masks of step 1
-        self._host[2] = (torch.initial_seed() + self.calls + int(getattr(self.model, "dropout_epoch", 0)) * 0x1000003
-                         + rank * 0x9E3779B1) & 0x7FFFFFFFFFFF
-        self._host[0], self._host[1] = getattr(self, "_draws", (0, 0))
-        self.choice_dev.copy_(self._host[:2].to(torch.int32), non_blocking=False)
-        self.seed_dev.copy_(self._host[2:3], non_blocking=False)
+        seed = (torch.initial_seed() + self.calls + int(getattr(self.model, "dropout_epoch", 0)) * 0x1000003
+                + rank * 0x9E3779B1) & 0x7FFFFFFFFFFF
+        c1, c2 = getattr(self, "_draws", (0, 0))
+        # one asynchronous launch carrying the three values as kernel arguments (rounds 1-5: two BLOCKING host-to-device copies,
+        # which made the host wait for the previous step's replay before it could stage this one)
+        from . import _lib
+        _lib.check(_lib.load().nef_step_words(self.choice_dev.data_ptr(), self.seed_dev.data_ptr(), int(c1), int(c2), int(seed),
+                                              torch.cuda.current_stream().cuda_stream), "nef_step_words")
 
     # -------------------------------------------------------------------------------------------------
     def set_lr(self, lr):

@@ -280,6 +280,12 @@ def h2_ok(K, Cin_g, Cout_g, T_out, pro=0):
 H2_FOLLOW_UP = 2.0
 H2_FOLLOW_DOWN = 64.0
 H2_HEADROOM = 64
+# Heavy-tail guard (round 6): the format keeps 22-23 bits of an element only down to 2^-11 of its tensor's largest (one power-of-two
+# scale per tensor); a tensor whose largest element is more than H2_TAIL_RATIO x its rms has its BULK below that line, and the
+# products of two such operands (a weight gradient) lose per-element precision (test_conv_h2_operand_distributions[lognormal];
+# profiles/r06_h2_scale_granularity.md).  Every call site checks its operand ONCE, where it measures it (its first launch; never
+# inside a captured step), and counts itself in `tail`; bench.py and Solver report the count (h2_tail_sites) -- such a model wants NEF_H2=0.
+H2_TAIL_RATIO = 2048.0
 AMAX_SITES = 16384
 _AMAX = {}
 # A call site = (scope, weight address, direction, role, batch, length).  The scope is the owning model's token
@@ -311,7 +317,8 @@ def _amax_state(dev):
                                clamped=torch.zeros(1, device=dev, dtype=torch.int32),       # waves that clamped (device total, never reset)
                                mark=torch.zeros(1, device=dev, dtype=torch.int32),          # ... at the last step boundary (h2_taint)
                                skipped=torch.zeros(1, device=dev, dtype=torch.int32),       # train steps skipped because of a clamp
-                               seen=0, seen_skipped=0)                                       # ... as of the host's last h2_clamped() / h2_skipped()
+                               tail=torch.zeros(1, device=dev, dtype=torch.int32),          # call sites whose operand is heavy-tailed (H2_TAIL_RATIO)
+                               seen=0, seen_skipped=0, seen_tail=0)                                       # ... as of the host's last h2_clamped() / h2_skipped()
     return st
 
 
@@ -339,6 +346,28 @@ def h2_skipped(reset=True):
         if reset:
             st["seen_skipped"] = tot
     return n
+
+
+def h2_tail_sites(reset=True):
+    """Split-fp16 call sites whose operand, when the site measured it, had amax > H2_TAIL_RATIO x rms (since the last call).
+    Synchronises like h2_clamped()."""
+    n = 0
+    for st in _AMAX.values():
+        tot = int(st["tail"].item())
+        n += tot - st["seen_tail"]
+        if reset:
+            st["seen_tail"] = tot
+    return n
+
+
+def _note_tail(st, i, n, *tensors):
+    """At a site's measuring launch (eager, once per site): slots i .. i + n - 1 of `nxt` hold the operands' amax; count the site if
+    any operand's amax exceeds H2_TAIL_RATIO x its rms.  A handful of torch reductions per SITE LIFETIME, nothing per step."""
+    for k, t in enumerate(tensors[:n]):
+        if t is None or t.numel() == 0:
+            continue
+        rms = t.detach().float().pow(2).mean().sqrt()
+        st["tail"] += (st["nxt"][i + k] > H2_TAIL_RATIO * rms).to(torch.int32)
 
 
 def h2_taint(out):
@@ -622,6 +651,8 @@ def conv(xv, wp, Cog, K, out=None, bias=None, in_scale=None, res=None, gate=None
             st["nxt"][i] = 0.0
             _lib.check(L.nef_conv_fwd(C.byref(a), _stream()), "nef_conv_fwd")
             st["cur"][i] = st["nxt"][i]
+            if site is not None:
+                _note_tail(st, i, 1, xv.t)
             st["ready"].add(i)
         a.x_amax = st["cur"].data_ptr() + 4 * i
         a.x_clamped = st["clamped"].data_ptr()
@@ -813,6 +844,8 @@ def conv_bwd_weight(xv, gyv, K, in_scale=None, pro=None, wino=None, site=None, h
                 st["nxt"][i:i + 2] = 0.0
                 launch(None, nxt)
                 st["cur"][i:i + 2] = st["nxt"][i:i + 2]
+                if key is not None:
+                    _note_tail(st, i, 2, xv.t, gyv.t)
                 st["ready"].add(i)
             st["used"] = True
             launch(st["cur"].data_ptr() + 4 * i, nxt, st["clamped"].data_ptr())

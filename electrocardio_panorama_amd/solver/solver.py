@@ -255,6 +255,10 @@ class Solver:
         blocking in their next collective."""
         clamped, skipped = parallel.sum_counts([ops.h2_clamped(), ops.h2_skipped()], self.device)
         ops.h2_rebase(self.device)       # clamps of this (test / val) phase are not charged to the next train step's taint word
+        tails = ops.h2_tail_sites()
+        if tails:      # (per rank: a warning only)
+            print('WARNING: {} split-fp16 call site(s) measured an operand whose largest element exceeds {:g} x its rms: the bulk of such a '
+                  'tensor is below the format\'s full-precision window (DESIGN.md 3.0); NEF_H2=0 runs the fp32 kernels'.format(tails, ops.H2_TAIL_RATIO))
         if not clamped and not skipped:
             return
         msg = ('{} waves of split-fp16 conv launches met an operand outside fp16\'s range in this {} phase (non-finite data; finite '

@@ -489,6 +489,10 @@ int nef_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, 
  * and makes nef_sgd_momentum skip the update.  No counterpart in the reference (its fp32 nn.Conv1d cannot overflow at 65504,
  * codes/network/model_nefnet.py:18-21); capturable, nothing is read by the host. */
 int nef_h2_taint(const int32_t* clamped_total, int32_t* mark, float* out, nef_stream_t stream);
+/* choice[0..1] = (c1, c2), seed[0] = seed_value, by a launch that carries the values as kernel arguments: the per-step host
+ * decisions of a replayed (hipGraph) train step -- the two Standin lead draws of codes/network/model_nefnet.py:154,156 and the
+ * dropout seed -- reach the device words the captured kernels read without a blocking host-to-device copy. */
+int nef_step_words(int32_t* choice, int64_t* seed, int c1, int c2, int64_t seed_value, nef_stream_t stream);
 /* Once per forward pass over the table of split-fp16 call-site magnitudes (ops.amax_roll; no counterpart in the reference, whose
  * fp32 convs need no operand scale): cur[i] = nxt[i] where nxt[i] > 0 and (cur[i] <= 0, or nxt[i] > follow_up * cur[i], or
  * nxt[i] * follow_down < cur[i], or follow_always); then nxt[i] = 0.  One launch. */

@@ -50,8 +50,10 @@ class Recorder(orc.Decisions):
         return torch.nn.functional.l1_loss(a, b)
 
 
-def run(V, B, L, seed, reg, masked, dt, model2=False):
-    batch = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.make_batch(B, V, L, seed=seed).items()}
+def run(V, B, L, seed, reg, masked, dt, model2=False, Q=0):
+    """`Q`: rest views of the synthetic batch (the nefnet2 fixtures carry Q = 3; synth.make_batch's noise draws and normalisation
+    depend on it, so the search must see the batch the fixture will hold)."""
+    batch = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.make_batch(B, V, L, seed=seed, Q=Q).items()}
     masks = hw.hashed_masks(V, B, L // 4) if masked else None
     src = hw.hashed_params2() if model2 else hw.hashed_params(V)
     P = {k: v.to(dt) for k, v in src.items()}
@@ -72,8 +74,8 @@ def main():
     torch.set_num_threads(int(sys.argv[9]) if len(sys.argv) > 9 else 4)
     rows = []
     for seed in range(s0, s0 + n):
-        r64 = run(V, B, L, seed, reg, masked, torch.float64, model2)
-        r32 = run(V, B, L, seed, reg, masked, torch.float32, model2)
+        r64 = run(V, B, L, seed, reg, masked, torch.float64, model2, 3 if model2 else 0)
+        r32 = run(V, B, L, seed, reg, masked, torch.float32, model2, 3 if model2 else 0)
         same = all(torch.equal(r64.own[k], r32.own[k]) for k in r64.own)
         margin = {}
         for k, p64 in r64.pre.items():

@@ -46,6 +46,21 @@ def slack_caps(dec):
     return SLACK_CAPS
 
 
+TIE_FREE_FACTS = []      # (fixture, HIP-to-fixture rel-L2 on the flat statistic) of every tie-free fixture compared so far
+
+
+def _report_tie_free():
+    """One line in the run's `---- parity facts ----` tail (latest state: the line is replaced, not repeated)."""
+    import conftest
+    if not TIE_FREE_FACTS:
+        return
+    names = sorted({n for n, _ in TIE_FREE_FACTS})
+    worst = max(TIE_FREE_FACTS, key=lambda t: t[1])
+    conftest.REPORT[:] = [l for l in conftest.REPORT if not l.startswith("tie-free fixtures:")]
+    conftest.report(f"tie-free fixtures: {len(names)} (HIP vs the reference's own gradients at the plain bars, zero allowance, no replayed "
+                    f"decision, both conv paths), worst flat {worst[1]:.2e} <= {FLAT_TOL:g} ({worst[0]})")
+
+
 class Cfg(dict):
     __getattr__ = dict.__getitem__
 
@@ -205,27 +220,34 @@ def test_train_golden(golden_dir):
         # the decision-replaying fp64 oracle.  The second term is measured, not assumed: it holds the fixture's own
         # distance from exact arithmetic (up to 2e-4 on this statistic) and, in a step with a ReLU / L1 tie, the effect
         # of the decisions the reference took differently -- so no fixture is skipped.
+        # TIE-FREE fixtures (round 6; `tie_free` = 1: seeds on which the reference's fp32 run, its fp64 restatement and -- screened on
+        # the GPU, tests/screen_tie_free.py -- the HIP path take identical decisions): the reference's own gradients at the PLAIN
+        # bars, zero allowance, and the replaying oracle must have had nothing to replay
+        tie_free = "tie_free" in z.files and bool(int(z["tie_free"]))
+        nsub = int(z["nsub"]) if "nsub" in z.files else 256
+        if tie_free:
+            assert dec.total_flips() == 0, (name, "a tie-free fixture saw replayed decisions", dec.total_flips())
         if True:
             n_fixture_grad += 1
             sq, sq64, got_all, ref_all, x64_all = 0.0, 0.0, [], [], []
-            SLACK_CAP_FLAT, SLACK_CAP_TENSOR = slack_caps(dec)
+            SLACK_CAP_FLAT, SLACK_CAP_TENSOR = (0.0, 0.0) if tie_free else slack_caps(dec)
             for k, p in m.named_parameters():
                 if k in orc.DEAD_PARAMS:
                     assert p.grad is None, k
                     continue
                 ref_sub = z["gsub:" + k]
                 if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
-                    assert maxabs(sub(p.grad, 256), ref_sub) < 1e-6, (name, k)      # analytically zero
+                    assert maxabs(sub(p.grad, nsub), ref_sub) < 1e-6, (name, k)      # analytically zero
                     continue
-                x64 = sub(dec.oracle_params[k].grad, 256)
+                x64 = sub(dec.oracle_params[k].grad, nsub)
                 # bar = the fixed tolerance + the MEASURED distance between the decision-replaying fp64 oracle and the fixture,
                 # capped: a GPU-side decision bug must not be able to widen its own bar (the replaying oracle follows the
                 # GPU's decisions); the uncapped, fixed-bar check against that oracle is oracle_replaying() above
                 slack = min(rel(x64, ref_sub), SLACK_CAP_TENSOR)
-                assert rel(sub(p.grad, 256), ref_sub) < TENSOR_TOL + slack, (
-                    name, k, rel(sub(p.grad, 256), ref_sub), f"bar {TENSOR_TOL} + measured oracle-to-fixture distance {slack:.2e}")
+                assert rel(sub(p.grad, nsub), ref_sub) < TENSOR_TOL + slack, (
+                    name, k, rel(sub(p.grad, nsub), ref_sub), f"bar {TENSOR_TOL} + measured oracle-to-fixture distance {slack:.2e}")
                 w_k = (p.grad.numel() / len(ref_sub)) ** 0.5        # the fixture holds <= 256 entries per tensor:
-                got_all.append(w_k * sub(p.grad, 256))               # weight them back to the tensor's size, so the
+                got_all.append(w_k * sub(p.grad, nsub))               # weight them back to the tensor's size, so the
                 ref_all.append(w_k * ref_sub)                        # statistic estimates the FLAT gradient's rel-L2
                 x64_all.append(w_k * x64)
                 sq += float((p.grad.double() ** 2).sum())
@@ -238,6 +260,8 @@ def test_train_golden(golden_dir):
             fslack = min(rel(np.concatenate(x64_all), ref_cat), SLACK_CAP_FLAT)
             assert rel(np.concatenate(got_all), ref_cat) < FLAT_TOL + fslack, (
                 name, f"bar {FLAT_TOL} + measured oracle-to-fixture distance {fslack:.2e} (capped at {SLACK_CAP_FLAT})")
+            if tie_free:
+                TIE_FREE_FACTS.append((name, rel(np.concatenate(got_all), ref_cat)))
             if dec.total_flips() > 0 or fslack > 3e-4:
                 import conftest
                 conftest.report(f"{name}: {dec.total_flips()} replayed tie(s); replaying fp64 oracle to fixture {fslack:.2e}, "
@@ -249,6 +273,7 @@ def test_train_golden(golden_dir):
             if k.endswith("num_batches_tracked"):
                 assert int(sd[k]) == 3, k
     assert n_fixture_grad == len(golden(golden_dir, "train_*.npz")) >= 1
+    _report_tie_free()
 
 
 def test_train_vs_oracle_live():
@@ -936,24 +961,28 @@ def test_nefnet2_golden(golden_dir):
         assert maxabs(torch.stack([l_.detach() for l_ in losses]), z["losses"]) < 1e-6, name
         bc = {k: v.cpu() for k, v in b.items()}
         _, _, dec, _ = oracle_replaying(m, touts, bc, V, seed, reg=str(z["reg"]), model2=True, fold=(B, V), dt=torch.float64)
+        tie_free = "tie_free" in z.files and bool(int(z["tie_free"]))      # see test_train_golden
+        nsub = int(z["nsub"]) if "nsub" in z.files else 256
+        if tie_free:
+            assert dec.total_flips() == 0, (name, "a tie-free fixture saw replayed decisions", dec.total_flips())
         if True:      # the reference's own gradients for every fixture (bars + the measured distance replaying-fp64-oracle <-> fixture)
             n_fixture_grad += 1
             sq, sq64, got_all, ref_all, x64_all = 0.0, 0.0, [], [], []
-            SLACK_CAP_FLAT, SLACK_CAP_TENSOR = slack_caps(dec)
+            SLACK_CAP_FLAT, SLACK_CAP_TENSOR = (0.0, 0.0) if tie_free else slack_caps(dec)
             for k, p in m.named_parameters():
                 if k in orc.DEAD_PARAMS:
                     assert p.grad is None, k
                     continue
                 ref_sub = z["gsub:" + k]
                 if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
-                    assert maxabs(sub(p.grad, 256), ref_sub) < 1e-6, (name, k)
+                    assert maxabs(sub(p.grad, nsub), ref_sub) < 1e-6, (name, k)
                     continue
-                x64 = sub(dec.oracle_params[k].grad, 256)
+                x64 = sub(dec.oracle_params[k].grad, nsub)
                 slack = min(rel(x64, ref_sub), SLACK_CAP_TENSOR)      # capped measured allowance, see test_train_golden
-                assert rel(sub(p.grad, 256), ref_sub) < TENSOR_TOL + slack, (
-                    name, k, rel(sub(p.grad, 256), ref_sub), f"bar {TENSOR_TOL} + measured oracle-to-fixture distance {slack:.2e}")
+                assert rel(sub(p.grad, nsub), ref_sub) < TENSOR_TOL + slack, (
+                    name, k, rel(sub(p.grad, nsub), ref_sub), f"bar {TENSOR_TOL} + measured oracle-to-fixture distance {slack:.2e}")
                 w_k = (p.grad.numel() / len(ref_sub)) ** 0.5        # the fixture holds <= 256 entries per tensor:
-                got_all.append(w_k * sub(p.grad, 256))               # weight them back to the tensor's size, so the
+                got_all.append(w_k * sub(p.grad, nsub))               # weight them back to the tensor's size, so the
                 ref_all.append(w_k * ref_sub)                        # statistic estimates the FLAT gradient's rel-L2
                 x64_all.append(w_k * x64)
                 sq += float((p.grad.double() ** 2).sum())
@@ -966,6 +995,8 @@ def test_nefnet2_golden(golden_dir):
             fslack = min(rel(np.concatenate(x64_all), ref_cat), SLACK_CAP_FLAT)
             assert rel(np.concatenate(got_all), ref_cat) < FLAT_TOL + fslack, (
                 name, f"bar {FLAT_TOL} + measured oracle-to-fixture distance {fslack:.2e} (capped at {SLACK_CAP_FLAT})")
+            if tie_free:
+                TIE_FREE_FACTS.append((name, rel(np.concatenate(got_all), ref_cat)))
             if dec.total_flips() > 0 or fslack > 3e-4:
                 import conftest
                 conftest.report(f"{name}: {dec.total_flips()} replayed tie(s); replaying fp64 oracle to fixture {fslack:.2e}, "
@@ -975,6 +1006,7 @@ def test_nefnet2_golden(golden_dir):
             if "running" in k:
                 assert rel(sd[k], z["buf:" + k]) < 1e-5, (name, k)
     assert n_fixture_grad == len(golden(golden_dir, "nefnet2_*.npz")) >= 1
+    _report_tie_free()
 
 
 def test_nefnet2_sgd_step_runs_through_solver_api():

@@ -73,6 +73,37 @@ def test_train_fixture_small(golden_dir):
     assert int(Bf["decoder.1.double_conv.1.num_batches_tracked"]) == 3
 
 
+def test_tie_free_fixture_pins_oracle(golden_dir):
+    """Round 6: the tie-free train fixtures (seeds on which the reference's fp32 run, its fp64 restatement and the HIP path take
+    identical ReLU / L1 decisions: oracle/tie_search.py, tests/screen_tie_free.py) -- the oracle restates the reference's run on one of
+    them to fp32 round-off, gradients included, and the fp64 run of the oracle takes the SAME decisions (what makes the fixture's
+    gradients a valid target at the plain bars)."""
+    from oracle import hashweights as hw
+    from oracle import nefnet_oracle as orc
+    from oracle import tie_search as ts
+    files = sorted(glob.glob(os.path.join(golden_dir, "train_*_tf*.npz")))
+    assert len(files) >= 3 and glob.glob(os.path.join(golden_dir, "nefnet2_*_tf*.npz"))
+    z = np.load([f for f in files if "V3_L512" in f][0])
+    assert int(z["tie_free"]) == 1
+    B, V, L, seed = (int(z[k]) for k in ("B", "V", "L", "seed"))
+    b = _batch(B, V, L, seed)
+    P, Bf = orc.require_grad(hw.hashed_params(V)), hw.hashed_buffers()
+    random.seed(seed)
+    outs = orc.forward(P, Bf, b["data"], b["input_theta"], b["target_theta"], b["rois"], phase="train", training=True,
+                       masks=hw.hashed_masks(V, B, L // 4))
+    losses = orc.loss_v1(outs[0], outs[1], outs[2], b["target_view"].unsqueeze(1), reg_loss=str(z["reg"]))
+    losses[0].backward()
+    assert rel(outs[0], z["out"]) < 1e-6 and maxabs(torch.stack([l_.detach() for l_ in losses]), z["losses"]) < 1e-6
+    nsub = int(z["nsub"])
+    for k, p in P.items():
+        if k not in orc.DEAD_PARAMS and not (k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias")):
+            assert rel(sub(p.grad, nsub), z["gsub:" + k]) < 1e-4, k
+    r64 = ts.run(V, B, L, seed, str(z["reg"]), True, torch.float64)
+    r32 = ts.run(V, B, L, seed, str(z["reg"]), True, torch.float32)
+    assert all(torch.equal(r64.own[k], r32.own[k]) for k in r64.own)
+    assert sum(v.numel() for v in r64.own.values()) == int(z["decisions"])
+
+
 def test_fixture_inventory(golden_dir):
     names = {os.path.basename(f) for f in glob.glob(os.path.join(golden_dir, "*.npz"))}
     assert {"theta_table.npz", "roi_cases.npz", "sgd_B4_V3_L512.npz"} <= names
