@@ -459,8 +459,10 @@ def decoder_bwd(dsaved, g_out, P, grads, side=None):
 # ----------------------------------------------------------------------------------------------
 # Model_nefnet.forward / backward
 # ----------------------------------------------------------------------------------------------
-def _latents(P, x, in_theta, rois, drop, save):
-    """model_nefnet.py:117-138: everything up to (z1, z2 segments)."""
+def _latents(P, x, in_theta, rois, drop, save, pack_side=None):
+    """model_nefnet.py:117-138: everything up to (z1, z2 segments).  `pack_side`: the side stream the step-level weight pack was
+    issued on (engine.forward): it runs under the stem -- which reads the raw stem weight, not a packed operand -- and is joined
+    in front of the first conv that needs one."""
     B, V, L = x.shape
     T = L // 4
     sv = {}
@@ -468,6 +470,8 @@ def _latents(P, x, in_theta, rois, drop, save):
     win = (r0 - 2, 6) if (T % 2 == 0 and r0 - 2 >= 0 and r0 + 4 <= T) else None
     ops.pack_many(_latent_pack_requests(P, V, T, win, False))       # every conv operand of this function in one launch
     a = ops.stem_fwd(x, P["W_encoder.conv1.weight"])
+    if pack_side is not None:
+        pack_side.join()
     sv["blk_enc"] = []
     for i in range(3):
         a, s = block_fwd(GV.dense(a, V), P, f"W_encoder.layer1.{i}", 7, 128, drop)
@@ -533,9 +537,13 @@ def forward(P, Bf, x, in_theta, q_theta, rois, rest_theta=None, phase="train", t
     T = L // 4
     ops.BATCH_HINT = B     # small batches stay on the fp32 kernels (ops._h2_fills)
     ops.amax_roll()        # split-fp16 convs: last pass's operand magnitudes become this pass's input scales
+    pack_side = None
     if save and phase == "train":
-        ops.pack_many(_step_pack_requests(P, V, T))
-    z1, z2b, sv = _latents(P, x, in_theta, rois, drop, save)
+        # ONE pack launch for the whole step (~80 us at configs[1]), on the side stream: it overlaps the stem (round 6)
+        reqs = _step_pack_requests(P, V, T)
+        pack_side = _side(x.device, B * 128 * V * T)
+        pack_side.run(lambda: ops.pack_many(reqs))
+    z1, z2b, sv = _latents(P, x, in_theta, rois, drop, save, pack_side)
     if phase == "gen":
         return (z1, z2b), None
     z2r = ops.roi_unpool_fwd(z2b, rois, T, status)
