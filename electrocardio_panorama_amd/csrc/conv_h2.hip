@@ -221,6 +221,9 @@ __global__ __launch_bounds__(256) void pack_h2_kernel(H2PackTable tab) {
 #ifndef NEF_H2_T
 #define NEF_H2_T 0      // timing-only builds: 1 = no activation loads in the loop, 2 = no matrix instructions, 4 = no epilogue
 #endif
+#ifndef NEF_H2_XORDER
+#define NEF_H2_XORDER 1     // 1 (round 6): tap 1's A fragments are issued in front of the next stage's activation rows (see the stage loop)
+#endif
 #ifndef NEF_H2_UP_OCC3
 #define NEF_H2_UP_OCC3 0      // 1: the x2-upsampling forms of the 64-channel tile at three workgroups per CU too
 #endif
@@ -562,7 +565,12 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
         const unsigned char* const xb = Xl + (st & 1) * (2 * PLANE) + fb_lane;
         const bool more = st + 1 < nst;
         const __amdgpu_buffer_rsrc_t xrs_n = nef_rsrc_n(xbase, more ? 0x7FFFFFFCu : 0u);      // branch-free: see conv_wino4_kernel
-#if !(NEF_H2_T & 1)
+        // Issue order of the stage's vector-memory loads (round 6, NEF_H2_XORDER 1).  Loads return IN ORDER, so the wait for an A
+        // fragment also waits for every load issued before it.  Rounds 4-5 issued the next stage's activation rows first and tap 1's A
+        // fragments behind them: the wait in front of tap 1 then covered the activation rows -- they had ONE tap (768 cycles at K = 3,
+        // 128-row tile) to arrive from HBM, whatever the length of the stage.  Now tap 1's A fragments go out first: the first wait that
+        // covers the activation rows is the one in front of tap 2, two taps after their issue.
+#if !(NEF_H2_T & 1) && !NEF_H2_XORDER
         NEF_H2X_ISSUE((st + 1) * KC, xrs_n)
 #endif
         h16x8 fb[5][2];              // ring over s: [slot][plane]
@@ -581,6 +589,12 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
             // next tap's A fragments (the next stage's first tap behind the last one; past the end: a repeat, harmless)
             if (kk + 1 < K) NEF_H2A_ISSUE(st, kk + 1, (kk + 1) & 1)
             else NEF_H2A_ISSUE(more ? st + 1 : st, 0, (kk + 1) & 1)
+#if !(NEF_H2_T & 1) && NEF_H2_XORDER
+            if (kk == 0) {
+                __builtin_amdgcn_sched_barrier(0);      // keep the A issue in front of the activation rows
+                NEF_H2X_ISSUE((st + 1) * KC, xrs_n)
+            }
+#endif
             if (kk + 4 < NSF) NEF_H2B_LOAD(kk + 4)
             __builtin_amdgcn_s_setprio(1);      // scheduling fence (see conv_wino_kernel)
             // product-major order: the three MFMAs that accumulate into one tile are 4 TM instructions apart (never back to
