@@ -625,6 +625,8 @@ __global__ __launch_bounds__(256, (TM == 1 && ((PRO & 2) == 0 || NEF_H2_UP_OCC3)
 #pragma unroll
             for (int q = 0; q < 2 * TM; ++q) fa[0][q] = fa[1][q];
         }
+        // (round 6, measured and not kept: the split + LDS stores in front of the LAST tap's matrix instructions instead of behind them --
+        // the compiler keeps the two groups apart, and the launches read +-1 %: profiles/r06_xorder_ab.md)
         if (more) NEF_H2X_STORE((st + 1) * KC, Xl + ((st + 1) & 1) * (2 * PLANE))
         else {      // every element of the tile has been staged: publish this wave's magnitude with the loop's last barrier
 #pragma unroll
