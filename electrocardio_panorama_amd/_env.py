@@ -25,7 +25,7 @@ PRODUCT = {
     "NEF_TEST_HOOKS": "1: honour the test hooks (NEF_SHARE_GPU, NEF_DIST_BACKEND, NEF_DIST_FORCE)",
 }
 DIAGNOSTICS = {
-    "NEF_FUSE_L2", "NEF_FUSE_STATS", "NEF_BNB_UP", "NEF_POLY", "NEF_POLY_FWD", "NEF_POLY_W", "NEF_PANO_L4_WIDE", "NEF_FOLD_CHSCALE", "NEF_FOLD_CHSCALE_BWD", "NEF_BWD_F4", "NEF_GRAPH_SIDE", "NEF_PANO_FUSE_PAIR", "NEF_BW_WINO4", "NEF_BW7_F42",
+    "NEF_FUSE_L2", "NEF_FUSE_STATS", "NEF_BNB_UP", "NEF_POLY", "NEF_POLY_FWD", "NEF_POLY_W", "NEF_PANO_L4_WIDE", "NEF_FOLD_CHSCALE", "NEF_FOLD_CHSCALE_BWD", "NEF_BWD_F4", "NEF_GRAPH_SIDE", "NEF_PANO_FUSE_PAIR", "NEF_PANO_FUSE_TAIL", "NEF_BW_WINO4", "NEF_BW7_F42",
     "NEF_H2_FWD", "NEF_H2_BWD", "NEF_H2_K", "NEF_H2_64", "NEF_H2_MIN_T", "NEF_H2_W", "NEF_H2_WK", "NEF_H2_AMAX", "NEF_H2_PACK",
     "NEF_H2_MIN_WGS",
     # read by the C side (nef_diag_env): listed for the README

@@ -150,6 +150,7 @@ SIGNATURES = {
     "nef_pano_h_conv": (i32, [p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i64, i64, p]),
     "nef_pano_h_conv_pair": (i32, [p, p, p, p, p, p, p, i32, i32, i32, i32, i64, i64, p]),
     "nef_pano_h_conv_outconv": (i32, [p, p, p, p, p, p, i32, i32, i32, i64, i64, p]),
+    "nef_pano_h_conv_tail": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, i64, i64, p]),
     "nef_pano_h_outconv": (i32, [p, p, p, p, i32, i32, i32, i64, i64, p]),
 }
 

@@ -820,6 +820,204 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// hconv_tail_kernel (round 6): layers 3 and 4, the last conv and sigmoid(x/3) in ONE pass for sequences of one tile
+// (T <= 512 output rows, i.e. L <= 512 -- BASELINE config 4):
+//   c3 = ReLU(conv(128 -> 64)(up2(c2)) + b3)  and  c4 = ReLU(conv(64 -> 64)(c3) + b4)  never leave the chip; the 64 -> 1 conv is
+//   evaluated on the staged c4 rows and the finished fp32 view is the only thing written.  Per (sample, angle) pair the two-launch
+//   sequence wrote and read 64 KB of c3 and took two more small launches (edge zeroing, sigmoid); this reads c2 once (64 KB) and
+//   writes 2 KB.
+//   block   = 512 threads = 8 waves along time (64 co x 64 t each: 2 x 2 accumulator tiles), one pair at a time, persistent,
+//             1 block per CU.  LDS = two row buffers of 514 rows x 144 B (64 channels + pad): buffer A holds layer 3's first input
+//             chunk, buffer B its second chunk, THEN c3 (written by layer 3's epilogue over the consumed chunk), THEN c4.
+//   layer 3 = hconv_pair_kernel's scheme with 8-row staging groups (hconv_wide_kernel's x2 blend: 6 source rows -> 8 rows): chunk 1
+//             is fetched and staged during chunk 0's 12 k-steps
+//   layer 4 = 12 k-steps straight from the c3 rows, no staging and no barrier inside; the NEXT pair's first chunk is fetched and
+//             staged into buffer A meanwhile
+//   last conv = one thread per output row on the staged c4 tile (d0, d1, d2 as in hconv_kernel's OUT = 1), neighbours through LDS;
+//             the whole sequence sits in the block, so there are no tile edges, no atomics and no separate sigmoid pass
+// Same k order per output and the same fp16 roundings of c3 / c4 as the launches it replaces (tests/test_pano_gpu.py compares).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __restrict__ x, const nef_h8* __restrict__ wp3,
+                                                         const float* __restrict__ bias3, const nef_h8* __restrict__ wp4,
+                                                         const float* __restrict__ bias4, const float* __restrict__ wout,
+                                                         const float* __restrict__ bout, float* __restrict__ out, int T, int N,
+                                                         int nq, long out_bs, long out_is) {
+    constexpr int CIN = 128, NT = 512, NI = 2;
+    constexpr int XROWS = NT + 2;
+    constexpr int XBYTES = XROWS * PH_XRS;
+    constexpr int AD = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const XA = smem;
+    char* const XB = smem + XBYTES;           // layer 3's second chunk, then c3, then c4: row r = time r - 1
+    float* const Of = (float*)(smem + 2 * XBYTES);      // wout[192], d0[NT], d2[NT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int seg = tid & 7, rg = tid >> 3;  // staging: 8-channel segment, group of 8 output rows (0..63)
+    const int Tin = T / 2;
+    if (tid < 192) Of[tid] = wout[tid];
+
+    nef_f16acc acc[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    nef_h8 hzero;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hzero[e] = (_Float16)0.f;
+    // rows 0 and NT + 1 of both buffers are the convs' zero padding for the whole kernel
+    if (tid < 32) {
+        const int bsel = tid >> 4, r = ((tid >> 3) & 1) ? XROWS - 1 : 0;
+        *(nef_h8*)(smem + bsel * XBYTES + r * PH_XRS + seg * 16) = hzero;
+    }
+
+    nef_h8 xr[6];
+    // source rows 4 rg - 1 .. 4 rg + 4 (clamped: the align_corners=False edge rule) of the 64-channel chunk cc_ of pair n_
+#define PHT_FETCH(n_, cc_)                                                                                    \
+    {                                                                                                         \
+        const __amdgpu_buffer_rsrc_t xd_ = __builtin_amdgcn_make_buffer_rsrc(                                 \
+            const_cast<_Float16*>(x + (size_t)(n_) * Tin * CIN), 0, Tin * CIN * 2, 0x00020000);               \
+        _Pragma("unroll") for (int k = 0; k < 6; ++k) {                                                       \
+            int r_ = 4 * rg - 1 + k;                                                                          \
+            r_ = r_ < 0 ? 0 : (r_ > Tin - 1 ? Tin - 1 : r_);                                                  \
+            xr[k] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(                         \
+                xd_, r_ * (CIN * 2) + seg * 16, (cc_) * 128, 0));                                             \
+        }                                                                                                     \
+    }
+    // blended rows j (of this thread's 8: t = 8 rg + j) -> row buffer; hconv_wide_kernel's arithmetic (0.25 b exact, one fma rounding)
+#define PHT_STAGE(Xn_, J0_, J1_)                                                                              \
+    {                                                                                                         \
+        nef_h8 c75;                                                                                           \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) c75[e] = (_Float16)0.75f;                               \
+        _Pragma("unroll") for (int j = (J0_); j < (J1_); ++j) {                                               \
+            const nef_h8 a_ = xr[(j >> 1) + 1], b_ = (j & 1) ? xr[(j >> 1) + 2] : xr[j >> 1];                 \
+            nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);                             \
+            if (8 * rg + j >= T) v_ = hzero;                                                                  \
+            *(nef_h8*)((Xn_) + (8 * rg + 1 + j) * PH_XRS + seg * 16) = v_;                                    \
+        }                                                                                                     \
+    }
+    const __amdgpu_buffer_rsrc_t wd3 = nef_rsrc(wp3), wd4 = nef_rsrc(wp4);
+    const int avoff = lane * 16;
+    nef_h8 a[AD][2];
+    // A fragments of k-step `stage_` (two 1 KB fragments per k-step: 64 output channels)
+#define PHT_A(wd_, slot_, stage_)                                                                             \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                          \
+        a[slot_][mi] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(                      \
+            wd_, avoff, (stage_) * 2048 + mi * 1024, 0));
+    // 12 k-steps (3 taps x 4 x 16 channels) of one 64-channel chunk, B fragments at Bp_ + (ni * 32 + tap) * PH_XRS + kq * 32;
+    // A of k-step s + AD - 1 from (WDC_, SC_ + .) or, past the chunk, from (WDN_, SN_ + .); FE_: fetch (pair FN_, chunk FC_) at
+    // k-step 1; ST_: stage the fetched rows into XN_, one row per k-step, during k-steps 4 .. 11
+#define PHT_STEPS(Bp_, WDC_, SC_, WDN_, SN_, FE_, FN_, FC_, ST_, XN_)                                         \
+    {                                                                                                         \
+        nef_h8 b[NI];                                                                                         \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) b[ni] = *(const nef_h8*)((Bp_) + ni * 32 * PH_XRS); \
+        _Pragma("unroll") for (int s = 0; s < 12; ++s) {                                                      \
+            if (s + AD - 1 < 12) {                                                                            \
+                PHT_A(WDC_, (s + AD - 1) % AD, (SC_) + s + AD - 1)                                            \
+            } else {                                                                                          \
+                PHT_A(WDN_, (s + AD - 1) % AD, (SN_) + s + AD - 1 - 12)                                       \
+            }                                                                                                 \
+            if ((FE_) && s == 1) PHT_FETCH(FN_, FC_)                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            if ((ST_) && s >= 4) PHT_STAGE(XN_, s - 4, s - 3)                                                 \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
+                _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                              \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % AD][mi], b[ni], acc[mi][ni], 0, 0, 0); \
+                if (s + 1 < 12)                                                                               \
+                    b[ni] = *(const nef_h8*)((Bp_) + (ni * 32 + (s + 1) / 4) * PH_XRS + ((s + 1) % 4) * 32);  \
+            }                                                                                                 \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                            \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
+                __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                                           \
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                            \
+            }                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+        }                                                                                                     \
+    }
+    // accumulators -> bias + ReLU -> fp16 rows of buffer B (row 1 + t); ZERO_: rows t >= T are the next conv's padding
+#define PHT_TO_LDS(bias_, ZERO_)                                                                              \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                          \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                       \
+            const int co = mi * 32 + 8 * g + 4 * hi;                                                          \
+            const nef_f32x4 bv = *(const nef_f32x4*)((bias_) + co);                                           \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
+                const int t = wn * 64 + ni * 32 + lo;                                                         \
+                nef_h4 o;                                                                                     \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
+                    o[e] = ((ZERO_) && t >= T) ? (_Float16)0.f : (_Float16)fmaxf(acc[mi][ni][g * 4 + e] + bv[e], 0.f); \
+                    acc[mi][ni][g * 4 + e] = 0.f;                                                             \
+                }                                                                                             \
+                *(nef_h4*)(XB + (1 + t) * PH_XRS + co * 2) = o;                                               \
+            }                                                                                                 \
+        }
+
+    int n = blockIdx.x;
+    PHT_A(wd3, 0, 0)
+    PHT_A(wd3, 1, 1)
+    PHT_A(wd3, 2, 2)
+    if (n < N) {
+        PHT_FETCH(n, 0)
+        PHT_STAGE(XA, 0, 8)
+    }
+    __syncthreads();
+    const float b0 = bout[0];
+
+#pragma unroll 1
+    for (; n < N; n += gridDim.x) {
+        const int n_next = n + (int)gridDim.x < N ? n + (int)gridDim.x : n;   // last pair: re-stage itself (unread)
+        const char* const BA = XA + (wn * 64 + lo) * PH_XRS + 16 * hi;
+        const char* const BB = XB + (wn * 64 + lo) * PH_XRS + 16 * hi;
+        // ---- layer 3: chunk 0 from buffer A while chunk 1 is fetched and staged into buffer B, then chunk 1
+        PHT_STEPS(BA, wd3, 0, wd3, 12, true, n, 1, true, XB)
+        __syncthreads();
+        PHT_STEPS(BB, wd3, 12, wd4, 0, false, n, 0, false, XB)
+        __syncthreads();                     // every wave is done reading buffer B as an input chunk
+        PHT_TO_LDS(bias3, true)
+        __syncthreads();                     // c3 complete
+        // ---- layer 4: straight from the c3 rows; the next pair's first chunk rides along into buffer A
+        PHT_STEPS(BB, wd4, 0, wd3, 0, true, n_next, 0, true, XA)
+        __syncthreads();                     // every wave is done reading c3; buffer A holds the next pair's chunk 0
+        PHT_TO_LDS(bias4, false)
+        __syncthreads();                     // c4 staged
+        // ---- last conv on the staged rows: row r = this thread; d_k = sum_c wout[c][k] * c4[r][c]
+        {
+            const int r = tid;
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+            if (r < T) {
+#pragma unroll
+                for (int sg = 0; sg < 8; ++sg) {
+                    const nef_h8 v = *(const nef_h8*)(XB + (1 + r) * PH_XRS + sg * 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = (float)v[e];
+                        const float* wc = Of + (sg * 8 + e) * 3;
+                        d0 = fmaf(wc[0], f, d0);
+                        d1 = fmaf(wc[1], f, d1);
+                        d2 = fmaf(wc[2], f, d2);
+                    }
+                }
+            }
+            Of[192 + r] = d0;          // tap 0 weights this row into column t + 1
+            Of[192 + NT + r] = d2;     // tap 2 into column t - 1
+            __syncthreads();           // (also: every thread is done reading c4 -- buffer B is free for the next pair's chunk 1)
+            if (r < T) {
+                const float s_ = d1 + (r > 0 ? Of[192 + r - 1] : 0.f) + (r < NT - 1 ? Of[192 + NT + r + 1] : 0.f);
+                out[(size_t)(n / nq) * out_bs + (size_t)(n % nq) * out_is + r] = 1.0f / (1.0f + expf(-(s_ + b0) / 3.0f));
+            }
+            // the d arrays are rewritten five barriers from here
+        }
+    }
+#undef PHT_FETCH
+#undef PHT_STAGE
+#undef PHT_A
+#undef PHT_STEPS
+#undef PHT_TO_LDS
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Last conv 64 -> 1 (k3, bias) + sigmoid(x/3) (model_nefnet.py:106,:168/:186): HBM-bound.  8 lanes share one time
 // step (8 channels x 3 taps each), a block covers 256 consecutive time steps of one pair.
 // ------------------------------------------------------------------------------------------------------------
@@ -972,6 +1170,24 @@ static int launch_hconv_pair(const void* x, const void* wp1, const float* b1, co
     return nef_launch_status();
 }
 
+static int launch_hconv_tail(const void* x, const void* wp3, const float* b3, const void* wp4, const float* b4, const float* wout,
+                             const float* bout, float* out, int N, int T, int nq, long out_bs, long out_is, hipStream_t st) {
+    constexpr int LDS = 2 * 514 * PH_XRS + (192 + 2 * 512) * 4;
+    static int cus_dev[64] = {0};            // per device, idempotent -> thread-safe without a lock
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int cus = __atomic_load_n(&cus_dev[dev & 63], __ATOMIC_ACQUIRE);
+    if (cus == 0) {
+        hipError_t e = hipFuncSetAttribute((const void*)hconv_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
+        __atomic_store_n(&cus_dev[dev & 63], cus, __ATOMIC_RELEASE);
+    }
+    hipLaunchKernelGGL(hconv_tail_kernel, dim3(N < cus ? N : cus), dim3(512), LDS, st, (const _Float16*)x, (const nef_h8*)wp3, b3,
+                       (const nef_h8*)wp4, b4, wout, bout, out, T, N, nq, out_bs, out_is);
+    return nef_launch_status();
+}
+
 static bool ph_l4_old() {
     // the 64 -> 64 layer (+ fused last conv) on hconv_wide_kernel<64, 64, 0, OUT> measured SLOWER than the round-1 kernel (sweep 52.1 vs
     // 50.7 ms, gen_ecg share 9.98 vs 9.68: one 64-channel chunk per tile leaves the double buffer nothing to hide): opt-in, A/B only
@@ -1034,6 +1250,14 @@ int nef_pano_h_conv_pair(const void* x, const void* wp1, const float* bias1, con
     NEF_REQUIRE(N > 0 && T > 0 && T <= 256 && T % 2 == 0 && x_div > 0 && nq > 0, NEF_E_SHAPE);
     return launch_hconv_pair(x, wp1, bias1, scale, wp2, bias2, y, N, T, x_div, nq, (long)sc_bs, (long)sc_is,
                              (hipStream_t)stream);
+}
+
+int nef_pano_h_conv_tail(const void* x, const void* wp3, const float* bias3, const void* wp4, const float* bias4, const float* wout,
+                         const float* bout, float* out, int N, int T, int nq, int64_t out_bs, int64_t out_is, nef_stream_t stream) {
+    NEF_ENTER();
+    NEF_REQUIRE(x && wp3 && bias3 && wp4 && bias4 && wout && bout && out, NEF_E_NULL);
+    NEF_REQUIRE(N > 0 && T > 0 && T <= 512 && T % 2 == 0 && nq > 0, NEF_E_SHAPE);
+    return launch_hconv_tail(x, wp3, bias3, wp4, bias4, wout, bout, out, N, T, nq, (long)out_bs, (long)out_is, (hipStream_t)stream);
 }
 
 int nef_pano_h_conv_outconv(const void* x, const void* wp, const float* bias, const float* wout, const float* bout,

@@ -1642,6 +1642,24 @@ def pano_h_conv_pair(x, wp1, bias1, scale, wp2, bias2, N, x_div, nq, out=None):
     return y
 
 
+PANO_TAIL_MAX_T = 512     # nef_pano_h_conv_tail: one 512-row tile per (sample, angle)
+
+
+def pano_h_conv_tail(x, wp3, bias3, wp4, bias4, wout, bout, out, nq, out_bs, out_is):
+    """Layers 3 + 4 + last conv + sigmoid(x/3) in one pass (c3, c4 stay on chip): x fp16 [N, Tin, 128] (layer 2's output) -> the fp32
+    views at `out` (view base, addressed as in pano_h_conv_outconv); 2 * Tin <= 512."""
+    L = _lib.load()
+    _chk(x, torch.float16), _chk(bias3), _chk(bias4), _chk(wout)
+    N, Tin, Ci = x.shape
+    assert Ci == 128 and 2 * Tin <= PANO_TAIL_MAX_T
+    e = _timed(("pano_h_conv_tail", N, 2 * Tin))
+    _lib.check(L.nef_pano_h_conv_tail(_p(x), _p(wp3), _p(bias3), _p(wp4), _p(bias4), _p(wout), _p(bout), _p(out), N, 2 * Tin, nq,
+                                      out_bs, out_is, _stream()), "nef_pano_h_conv_tail")
+    if e is not None:
+        e.record()
+    return out
+
+
 def pano_h_outconv(x, w, bias, out, nq, out_bs, out_is):
     """out[(n/nq)*out_bs + (n%nq)*out_is + t] = sigmoid((conv_k3(x[n]) + bias)/3); x fp16 [N,T,64], out fp32 view base."""
     L = _lib.load()

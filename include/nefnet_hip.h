@@ -581,6 +581,14 @@ int nef_pano_h_conv(const void* x, const void* wp, const float* bias, const floa
  *   y[n] = ReLU(conv_k3(ReLU(conv_k3(scale[n] * up2(x[n / x_div])) + bias1)) + bias2),  x fp16 [.][T/2][256],
  * y fp16 [N][T][128]; the 128-channel intermediate stays on chip and is rounded to fp16 exactly as the two-call
  * sequence nef_pano_h_conv(pro_mode 3) + nef_pano_h_conv(pro_mode 0) rounds it (bit-identical results). */
+/* nef_pano_h_conv_tail (round 6): layers 3 and 4, the last conv and sigmoid(x/3) of the decoder (model_nefnet.py:104-106, :186) in
+ * one pass for sequences of one tile (T <= 512 output rows, T even; L <= 512):
+ *   out[(n/nq)*out_bs + (n%nq)*out_is + t] = sigmoid((conv_k3(ReLU(conv_k3(ReLU(conv_k3(up2(x[n])) + bias3)) + bias4); wout) + bout) / 3),
+ * x fp16 [N][T/2][128] (layer 2's output), wp3 / wp4 = nef_pano_h_pack_weight of the folded 128->64 / 64->64 weights, wout fp32
+ * [1][64][3].  The two 64-channel intermediates stay on chip, rounded to fp16 exactly as nef_pano_h_conv(pro_mode 2) +
+ * nef_pano_h_conv_outconv round them. */
+int nef_pano_h_conv_tail(const void* x, const void* wp3, const float* bias3, const void* wp4, const float* bias4, const float* wout,
+                         const float* bout, float* out, int N, int T, int nq, int64_t out_bs, int64_t out_is, nef_stream_t stream);
 int nef_pano_h_conv_pair(const void* x, const void* wp1, const float* bias1, const float* scale, const void* wp2,
                          const float* bias2, void* y, int N, int T, int x_div, int nq, int64_t sc_bs, int64_t sc_is,
                          nef_stream_t stream);

@@ -61,6 +61,34 @@ def test_fused_layer_pair_is_bit_identical_to_two_launches(T, NB, nq):
     assert torch.equal(y, ref), float((y.float() - ref.float()).abs().max())
 
 
+@pytest.mark.parametrize("T,NB,nq", [(512, 3, 4), (80, 2, 3), (508, 70, 5), (256, 2, 2)])
+def test_fused_tail_matches_two_launches(T, NB, nq):
+    """nef_pano_h_conv_tail (layers 3 + 4 + last conv + sigmoid, c3 / c4 on chip; round 6) against nef_pano_h_conv(upsample) +
+    nef_pano_h_conv_outconv: same k order per output and the same fp16 roundings of c3 and c4, so every view agrees to fp32 round-off
+    of the last conv's three-term sum (the two-launch form adds the tile-edge columns of its 256-row tiles through atomics, i.e. in
+    another order; everywhere else the bytes match) -- whole tile, short and ragged sequences, more pairs than CUs (a block walks
+    several pairs and re-uses both row buffers)."""
+    o = ops()
+    N, Tin = NB * nq, T // 2
+    c2 = F.relu(rnd(N, Tin, 128, seed=21)).to(torch.float16).to(DEV)
+    w3 = (rnd(64, 128, 3, seed=22) * (2.0 / (3 * 128)) ** 0.5).to(DEV)
+    w4 = (rnd(64, 64, 3, seed=23) * (2.0 / (3 * 64)) ** 0.5).to(DEV)
+    b3, b4 = rnd(64, seed=24, scale=0.1).to(DEV), rnd(64, seed=25, scale=0.1).to(DEV)
+    wout, bout = (rnd(1, 64, 3, seed=26) * 0.2).to(DEV), rnd(1, seed=27, scale=0.1).to(DEV)
+    wp3, wp4 = o.pano_h_pack_weight(w3), o.pano_h_pack_weight(w4)
+    ref = torch.full((NB, nq + 1, T), -7.0, device=DEV)
+    got = torch.full((NB, nq + 1, T), -7.0, device=DEV)
+    c3 = o.pano_h_conv(c2, wp3, b3, 64, upsample=True)
+    o.pano_h_conv_outconv(c3, wp4, b4, wout, bout, ref[:, 1:], nq, (nq + 1) * T, T)
+    o.pano_h_conv_tail(c2, wp3, b3, wp4, b4, wout, bout, got[:, 1:], nq, (nq + 1) * T, T)
+    assert torch.equal(got[:, 0], ref[:, 0])                          # the view in front of the addressed ones is untouched
+    assert float((got - ref).abs().max()) < 2e-7, float((got - ref).abs().max())
+    interior = torch.ones(T, dtype=torch.bool, device=DEV)
+    interior[[t for t in (255, 256) if t < T]] = False                # tile-edge columns of the two-launch form
+    assert torch.equal(got[:, 1:][:, :, interior], ref[:, 1:][:, :, interior])
+    assert float(got[:, 1:].min()) > 0.0 and float(got[:, 1:].max()) < 1.0
+
+
 @pytest.mark.parametrize("Cin,Cout,T,N,upsample,scaled", [
     (128, 128, 256, 2, False, False),      # whole tiles
     (128, 128, 300, 3, False, False),      # ragged last tile
