@@ -833,9 +833,11 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
 //             is fetched and staged during chunk 0's 12 k-steps
 //   layer 4 = 12 k-steps straight from the c3 rows, no staging and no barrier inside; the NEXT pair's first chunk is fetched and
 //             staged into buffer A meanwhile
-//   last conv = one thread per output row on the staged c4 tile (d0, d1, d2 as in hconv_kernel's OUT = 1), neighbours through LDS;
-//             the whole sequence sits in the block, so there are no tile edges, no atomics and no separate sigmoid pass
-// Same k order per output and the same fp16 roundings of c3 / c4 as the launches it replaces (tests/test_pano_gpu.py compares).
+//   last conv = on the matrix cores too (a 3-row A tile of the fp32 weights as two fp16 terms against the staged c4 rows), the three
+//             taps' partial sums meet through LDS; the whole sequence sits in the block, so there are no tile edges, no atomics and
+//             no separate sigmoid pass
+// Same k order per output and the same fp16 roundings of c3 / c4 as the launches it replaces; the last conv's 64-term sums run in the
+// matrix cores' order instead of one fused-multiply-add chain (views agree to fp32 round-off: tests/test_pano_gpu.py).
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __restrict__ x, const nef_h8* __restrict__ wp3,
                                                          const float* __restrict__ bias3, const nef_h8* __restrict__ wp4,
@@ -849,13 +851,33 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const XA = smem;
     char* const XB = smem + XBYTES;           // layer 3's second chunk, then c3, then c4: row r = time r - 1
-    float* const Of = (float*)(smem + 2 * XBYTES);      // wout[192], d0[NT], d2[NT]
+    float* const Of = (float*)(smem + 2 * XBYTES);      // d0[NT], d2[NT]
+    nef_h8* const Af = (nef_h8*)(smem + 2 * XBYTES + 2 * NT * 4);      // the last conv as matrix A fragments: [kq 0..3][hi | lo plane][lane]
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int lo = lane & 31, hi = lane >> 5;
     const int seg = tid & 7, rg = tid >> 3;  // staging: 8-channel segment, group of 8 output rows (0..63)
     const int Tin = T / 2;
-    if (tid < 192) Of[tid] = wout[tid];
+    // The 64 -> 1 conv on the matrix cores: d_k[t] = sum_c wout[c][k] c4[t][c] is a [3 x 64] x [64 x 512] product -- rows 0..2 of a 32-row
+    // A tile (the rest zero), the c4 rows as B exactly as layer 4 reads c3.  wout stays fp32-exact: it enters as two fp16 terms
+    // (hi + lo = 22 bits), two matrix instructions per 16 channels.  16 matrix instructions per wave replace ~400 vector
+    // instructions per thread (one thread per row, 192 fused multiply-adds) during which the matrix pipes of this one-block-per-CU
+    // kernel stood still.
+    if (tid < 64) {
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            nef_h8 fh, fl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = kq * 16 + 8 * hi + e;
+                const float w_ = lo < 3 ? wout[c * 3 + lo] : 0.f;
+                fh[e] = (_Float16)w_;
+                fl[e] = (_Float16)(w_ - (float)fh[e]);
+            }
+            Af[(kq * 2 + 0) * 64 + lane] = fh;
+            Af[(kq * 2 + 1) * 64 + lane] = fl;
+        }
+    }
 
     nef_f16acc acc[2][NI];
 #pragma unroll
@@ -980,32 +1002,42 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
         // ---- layer 4: straight from the c3 rows; the next pair's first chunk rides along into buffer A
         PHT_STEPS(BB, wd4, 0, wd3, 0, true, n_next, 0, true, XA)
         __syncthreads();                     // every wave is done reading c3; buffer A holds the next pair's chunk 0
-        PHT_TO_LDS(bias4, false)
+        PHT_TO_LDS(bias4, true)              // (rows t >= T zero: their share of the last conv is zero)
         __syncthreads();                     // c4 staged
-        // ---- last conv on the staged rows: row r = this thread; d_k = sum_c wout[c][k] * c4[r][c]
+        // ---- last conv on the matrix cores: rows 0..2 of the product are d0, d1, d2 of column t = wn 64 + ni 32 + lo (lanes hi = 0)
         {
-            const int r = tid;
-            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-            if (r < T) {
 #pragma unroll
-                for (int sg = 0; sg < 8; ++sg) {
-                    const nef_h8 v = *(const nef_h8*)(XB + (1 + r) * PH_XRS + sg * 16);
+            for (int kq = 0; kq < 4; ++kq) {
+                const nef_h8 ah = Af[(kq * 2 + 0) * 64 + lane], al = Af[(kq * 2 + 1) * 64 + lane];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float f = (float)v[e];
-                        const float* wc = Of + (sg * 8 + e) * 3;
-                        d0 = fmaf(wc[0], f, d0);
-                        d1 = fmaf(wc[1], f, d1);
-                        d2 = fmaf(wc[2], f, d2);
-                    }
+                for (int ni = 0; ni < NI; ++ni) {
+                    const nef_h8 bq = *(const nef_h8*)(XB + (1 + wn * 64 + ni * 32 + lo) * PH_XRS + kq * 32 + 16 * hi);
+                    acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq, acc[0][ni], 0, 0, 0);
+                    acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq, acc[0][ni], 0, 0, 0);
                 }
             }
-            Of[192 + r] = d0;          // tap 0 weights this row into column t + 1
-            Of[192 + NT + r] = d2;     // tap 2 into column t - 1
-            __syncthreads();           // (also: every thread is done reading c4 -- buffer B is free for the next pair's chunk 1)
-            if (r < T) {
-                const float s_ = d1 + (r > 0 ? Of[192 + r - 1] : 0.f) + (r < NT - 1 ? Of[192 + NT + r + 1] : 0.f);
-                out[(size_t)(n / nq) * out_bs + (size_t)(n % nq) * out_is + r] = 1.0f / (1.0f + expf(-(s_ + b0) / 3.0f));
+            float d1[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int t = wn * 64 + ni * 32 + lo;
+                d1[ni] = acc[0][ni][1];
+                if (hi == 0) {
+                    Of[t] = acc[0][ni][0];          // tap 0 weights this row into column t + 1
+                    Of[NT + t] = acc[0][ni][2];     // tap 2 into column t - 1
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][ni][r] = 0.f;
+            }
+            __syncthreads();           // (also: every wave is done reading c4 -- buffer B is free for the next pair's chunk 1)
+            if (hi == 0) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int t = wn * 64 + ni * 32 + lo;
+                    if (t < T) {
+                        const float s_ = d1[ni] + (t > 0 ? Of[t - 1] : 0.f) + (t < NT - 1 ? Of[NT + t + 1] : 0.f);
+                        out[(size_t)(n / nq) * out_bs + (size_t)(n % nq) * out_is + t] = 1.0f / (1.0f + expf(-(s_ + b0) / 3.0f));
+                    }
+                }
             }
             // the d arrays are rewritten five barriers from here
         }
@@ -1172,7 +1204,7 @@ static int launch_hconv_pair(const void* x, const void* wp1, const float* b1, co
 
 static int launch_hconv_tail(const void* x, const void* wp3, const float* b3, const void* wp4, const float* b4, const float* wout,
                              const float* bout, float* out, int N, int T, int nq, long out_bs, long out_is, hipStream_t st) {
-    constexpr int LDS = 2 * 514 * PH_XRS + (192 + 2 * 512) * 4;
+    constexpr int LDS = 2 * 514 * PH_XRS + 2 * 512 * 4 + 8 * 64 * 16;      // two row buffers, d0 / d2, the last conv's A fragments
     static int cus_dev[64] = {0};            // per device, idempotent -> thread-safe without a lock
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;

@@ -64,10 +64,10 @@ def test_fused_layer_pair_is_bit_identical_to_two_launches(T, NB, nq):
 @pytest.mark.parametrize("T,NB,nq", [(512, 3, 4), (80, 2, 3), (508, 70, 5), (256, 2, 2)])
 def test_fused_tail_matches_two_launches(T, NB, nq):
     """nef_pano_h_conv_tail (layers 3 + 4 + last conv + sigmoid, c3 / c4 on chip; round 6) against nef_pano_h_conv(upsample) +
-    nef_pano_h_conv_outconv: same k order per output and the same fp16 roundings of c3 and c4, so every view agrees to fp32 round-off
-    of the last conv's three-term sum (the two-launch form adds the tile-edge columns of its 256-row tiles through atomics, i.e. in
-    another order; everywhere else the bytes match) -- whole tile, short and ragged sequences, more pairs than CUs (a block walks
-    several pairs and re-uses both row buffers)."""
+    nef_pano_h_conv_outconv: same k order per output and the same fp16 roundings of c3 and c4; the last conv runs on the matrix cores
+    here (fp32 weights as two fp16 terms) and as a fused-multiply-add chain there, so the views agree to fp32 round-off of a 192-term
+    sum, not bit for bit -- whole tile, short and ragged sequences, more pairs than CUs (a block walks several pairs and re-uses
+    both row buffers)."""
     o = ops()
     N, Tin = NB * nq, T // 2
     c2 = F.relu(rnd(N, Tin, 128, seed=21)).to(torch.float16).to(DEV)
@@ -82,10 +82,7 @@ def test_fused_tail_matches_two_launches(T, NB, nq):
     o.pano_h_conv_outconv(c3, wp4, b4, wout, bout, ref[:, 1:], nq, (nq + 1) * T, T)
     o.pano_h_conv_tail(c2, wp3, b3, wp4, b4, wout, bout, got[:, 1:], nq, (nq + 1) * T, T)
     assert torch.equal(got[:, 0], ref[:, 0])                          # the view in front of the addressed ones is untouched
-    assert float((got - ref).abs().max()) < 2e-7, float((got - ref).abs().max())
-    interior = torch.ones(T, dtype=torch.bool, device=DEV)
-    interior[[t for t in (255, 256) if t < T]] = False                # tile-edge columns of the two-launch form
-    assert torch.equal(got[:, 1:][:, :, interior], ref[:, 1:][:, :, interior])
+    assert float((got - ref).abs().max()) < 5e-7, float((got - ref).abs().max())
     assert float(got[:, 1:].min()) > 0.0 and float(got[:, 1:].max()) < 1.0
 
 
