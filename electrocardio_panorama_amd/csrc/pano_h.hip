@@ -847,7 +847,11 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
     constexpr int CIN = 128, NT = 512, NI = 2;
     constexpr int XROWS = NT + 2;
     constexpr int XBYTES = XROWS * PH_XRS;
-    constexpr int AD = 4;
+#ifndef NEF_PHT_AD
+#define NEF_PHT_AD 4
+#endif
+    constexpr int AD = NEF_PHT_AD;          // A ring: fragments of AD - 1 k-steps in flight (a divisor of 12; 6 measured slower: 24 B of scratch, 44.5 vs 44.1 ms per sweep)
+    static_assert(12 % AD == 0, "the ring position of a k-step must not depend on the chunk");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const XA = smem;
     char* const XB = smem + XBYTES;           // layer 3's second chunk, then c3, then c4: row r = time r - 1
@@ -977,9 +981,8 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
         }
 
     int n = blockIdx.x;
-    PHT_A(wd3, 0, 0)
-    PHT_A(wd3, 1, 1)
-    PHT_A(wd3, 2, 2)
+#pragma unroll
+    for (int j = 0; j < AD - 1; ++j) PHT_A(wd3, j, j)
     if (n < N) {
         PHT_FETCH(n, 0)
         PHT_STAGE(XA, 0, 8)
