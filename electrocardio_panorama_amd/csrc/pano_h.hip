@@ -839,11 +839,17 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
 // Same k order per output and the same fp16 roundings of c3 / c4 as the launches it replaces; the last conv's 64-term sums run in the
 // matrix cores' order instead of one fused-multiply-add chain (views agree to fp32 round-off: tests/test_pano_gpu.py).
 // ------------------------------------------------------------------------------------------------------------
+template <bool TILED>
 __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __restrict__ x, const nef_h8* __restrict__ wp3,
                                                          const float* __restrict__ bias3, const nef_h8* __restrict__ wp4,
                                                          const float* __restrict__ bias4, const float* __restrict__ wout,
                                                          const float* __restrict__ bout, float* __restrict__ out, int T, int N,
-                                                         int nq, long out_bs, long out_is) {
+                                                         int nq, long out_bs, long out_is, int tiles_per_n) {
+    // TILED (sequences longer than one tile -- configs[4]'s 5000 rows): a work item is (pair, tile); tile k produces the NOUT = 508
+    // output rows o = 508 k .. 508 k + 507 from 512-slot tiles of c3 and c4 whose slot j is time base + j, base = o - 2: two fused
+    // K = 3 layers + the last conv eat three rows of context per side, of which the row buffers' rows 0 / 513 supply one -- as real
+    // halo rows of the upsampled input here, as the convs' zero padding in the one-tile form (base = 0, slot = time).
+    constexpr int NOUT = 508;
     constexpr int CIN = 128, NT = 512, NI = 2;
     constexpr int XROWS = NT + 2;
     constexpr int XBYTES = XROWS * PH_XRS;
@@ -900,28 +906,40 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
     }
 
     nef_h8 xr[6];
-    // source rows 4 rg - 1 .. 4 rg + 4 (clamped: the align_corners=False edge rule) of the 64-channel chunk cc_ of pair n_
-#define PHT_FETCH(n_, cc_)                                                                                    \
+    int fbase = 0;                            // `base` of the tile held in xr
+    // source rows base / 2 + 4 rg - 1 .. + 4 (clamped: the align_corners=False edge rule) of the 64-channel chunk cc_ of work item w_
+#define PHT_FETCH(w_, cc_)                                                                                    \
     {                                                                                                         \
+        const int n_ = TILED ? (w_) / tiles_per_n : (w_);                                                     \
+        fbase = TILED ? ((w_) % tiles_per_n) * NOUT - 2 : 0;                                                  \
         const __amdgpu_buffer_rsrc_t xd_ = __builtin_amdgcn_make_buffer_rsrc(                                 \
             const_cast<_Float16*>(x + (size_t)(n_) * Tin * CIN), 0, Tin * CIN * 2, 0x00020000);               \
         _Pragma("unroll") for (int k = 0; k < 6; ++k) {                                                       \
-            int r_ = 4 * rg - 1 + k;                                                                          \
+            int r_ = fbase / 2 + 4 * rg - 1 + k;                                                              \
             r_ = r_ < 0 ? 0 : (r_ > Tin - 1 ? Tin - 1 : r_);                                                  \
             xr[k] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(                         \
                 xd_, r_ * (CIN * 2) + seg * 16, (cc_) * 128, 0));                                             \
         }                                                                                                     \
     }
-    // blended rows j (of this thread's 8: t = 8 rg + j) -> row buffer; hconv_wide_kernel's arithmetic (0.25 b exact, one fma rounding)
+    // blended rows j (of this thread's 8: time fbase + 8 rg + j) -> row buffer; hconv_wide_kernel's arithmetic (0.25 b exact, one fma
+    // rounding).  TILED, j = 8 (J1_ = 9): the two halo rows 0 / 513 (times fbase - 1, fbase + 512) by the first / last row group
 #define PHT_STAGE(Xn_, J0_, J1_)                                                                              \
     {                                                                                                         \
         nef_h8 c75;                                                                                           \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) c75[e] = (_Float16)0.75f;                               \
-        _Pragma("unroll") for (int j = (J0_); j < (J1_); ++j) {                                               \
+        _Pragma("unroll") for (int j = (J0_); j < (J1_) && j < 8; ++j) {                                      \
             const nef_h8 a_ = xr[(j >> 1) + 1], b_ = (j & 1) ? xr[(j >> 1) + 2] : xr[j >> 1];                 \
             nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);                             \
-            if (8 * rg + j >= T) v_ = hzero;                                                                  \
+            const int tau_ = fbase + 8 * rg + j;                                                              \
+            if (tau_ >= T || (TILED && tau_ < 0)) v_ = hzero;                                                 \
             *(nef_h8*)((Xn_) + (8 * rg + 1 + j) * PH_XRS + seg * 16) = v_;                                    \
+        }                                                                                                     \
+        if (TILED && (J1_) > 8 && (rg == 0 || rg == 63)) {                                                    \
+            const nef_h8 a_ = rg == 0 ? xr[0] : xr[5], b_ = rg == 0 ? xr[1] : xr[4];                          \
+            nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);                             \
+            const int tau_ = rg == 0 ? fbase - 1 : fbase + NT;                                                \
+            if (tau_ >= T || tau_ < 0) v_ = hzero;                                                            \
+            *(nef_h8*)((Xn_) + (rg == 0 ? 0 : XROWS - 1) * PH_XRS + seg * 16) = v_;                           \
         }                                                                                                     \
     }
     const __amdgpu_buffer_rsrc_t wd3 = nef_rsrc(wp3), wd4 = nef_rsrc(wp4);
@@ -948,6 +966,7 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
             if ((FE_) && s == 1) PHT_FETCH(FN_, FC_)                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                                \
             if ((ST_) && s >= 4) PHT_STAGE(XN_, s - 4, s - 3)                                                 \
+            if ((ST_) && TILED && s == 11) PHT_STAGE(XN_, 8, 9)                                               \
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
                 _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                              \
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % AD][mi], b[ni], acc[mi][ni], 0, 0, 0); \
@@ -963,7 +982,7 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
             __builtin_amdgcn_sched_barrier(0);                                                                \
         }                                                                                                     \
     }
-    // accumulators -> bias + ReLU -> fp16 rows of buffer B (row 1 + t); ZERO_: rows t >= T are the next conv's padding
+    // accumulators -> bias + ReLU -> fp16 rows of buffer B (row 1 + slot); ZERO_: slots outside the sequence are the next conv's padding
 #define PHT_TO_LDS(bias_, ZERO_)                                                                              \
     _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                          \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                       \
@@ -973,32 +992,36 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
                 const int t = wn * 64 + ni * 32 + lo;                                                         \
                 nef_h4 o;                                                                                     \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-                    o[e] = ((ZERO_) && t >= T) ? (_Float16)0.f : (_Float16)fmaxf(acc[mi][ni][g * 4 + e] + bv[e], 0.f); \
+                    o[e] = ((ZERO_) && (base + t >= T || (TILED && base + t < 0))) ? (_Float16)0.f                    \
+                                                                                   : (_Float16)fmaxf(acc[mi][ni][g * 4 + e] + bv[e], 0.f); \
                     acc[mi][ni][g * 4 + e] = 0.f;                                                             \
                 }                                                                                             \
                 *(nef_h4*)(XB + (1 + t) * PH_XRS + co * 2) = o;                                               \
             }                                                                                                 \
         }
 
-    int n = blockIdx.x;
+    const int total = TILED ? N * tiles_per_n : N;      // work items: (pair, tile)
+    int w = blockIdx.x;
 #pragma unroll
     for (int j = 0; j < AD - 1; ++j) PHT_A(wd3, j, j)
-    if (n < N) {
-        PHT_FETCH(n, 0)
-        PHT_STAGE(XA, 0, 8)
+    if (w < total) {
+        PHT_FETCH(w, 0)
+        PHT_STAGE(XA, 0, 9)
     }
     __syncthreads();
     const float b0 = bout[0];
 
 #pragma unroll 1
-    for (; n < N; n += gridDim.x) {
-        const int n_next = n + (int)gridDim.x < N ? n + (int)gridDim.x : n;   // last pair: re-stage itself (unread)
+    for (; w < total; w += gridDim.x) {
+        const int n = TILED ? w / tiles_per_n : w;
+        const int base = TILED ? (w % tiles_per_n) * NOUT - 2 : 0;      // time of slot 0
+        const int n_next = w + (int)gridDim.x < total ? w + (int)gridDim.x : w;   // last item: re-stage itself (unread)
         const char* const BA = XA + (wn * 64 + lo) * PH_XRS + 16 * hi;
         const char* const BB = XB + (wn * 64 + lo) * PH_XRS + 16 * hi;
         // ---- layer 3: chunk 0 from buffer A while chunk 1 is fetched and staged into buffer B, then chunk 1
-        PHT_STEPS(BA, wd3, 0, wd3, 12, true, n, 1, true, XB)
+        PHT_STEPS(BA, wd3, 0, wd3, 12, true, w, 1, true, XB)
         __syncthreads();
-        PHT_STEPS(BB, wd3, 12, wd4, 0, false, n, 0, false, XB)
+        PHT_STEPS(BB, wd3, 12, wd4, 0, false, w, 0, false, XB)
         __syncthreads();                     // every wave is done reading buffer B as an input chunk
         PHT_TO_LDS(bias3, true)
         __syncthreads();                     // c3 complete
@@ -1036,9 +1059,10 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int t = wn * 64 + ni * 32 + lo;
-                    if (t < T) {
+                    // slot t is time base + t; a tile of the TILED form owns slots 2 .. 509 (the others lack context)
+                    if (base + t < T && (!TILED || (t >= 2 && t < 2 + NOUT))) {
                         const float s_ = d1[ni] + (t > 0 ? Of[t - 1] : 0.f) + (t < NT - 1 ? Of[NT + t + 1] : 0.f);
-                        out[(size_t)(n / nq) * out_bs + (size_t)(n % nq) * out_is + t] = 1.0f / (1.0f + expf(-(s_ + b0) / 3.0f));
+                        out[(size_t)(n / nq) * out_bs + (size_t)(n % nq) * out_is + base + t] = 1.0f / (1.0f + expf(-(s_ + b0) / 3.0f));
                     }
                 }
             }
@@ -1213,13 +1237,22 @@ static int launch_hconv_tail(const void* x, const void* wp3, const float* b3, co
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     int cus = __atomic_load_n(&cus_dev[dev & 63], __ATOMIC_ACQUIRE);
     if (cus == 0) {
-        hipError_t e = hipFuncSetAttribute((const void*)hconv_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)hconv_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
+        if ((e = hipFuncSetAttribute((const void*)hconv_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)) != hipSuccess) return (int)e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
         __atomic_store_n(&cus_dev[dev & 63], cus, __ATOMIC_RELEASE);
     }
-    hipLaunchKernelGGL(hconv_tail_kernel, dim3(N < cus ? N : cus), dim3(512), LDS, st, (const _Float16*)x, (const nef_h8*)wp3, b3,
-                       (const nef_h8*)wp4, b4, wout, bout, out, T, N, nq, out_bs, out_is);
+    if (T <= 512) {      // one tile per pair
+        hipLaunchKernelGGL(hconv_tail_kernel<false>, dim3(N < cus ? N : cus), dim3(512), LDS, st, (const _Float16*)x, (const nef_h8*)wp3, b3,
+                           (const nef_h8*)wp4, b4, wout, bout, out, T, N, nq, out_bs, out_is, 1);
+    } else {             // 508 output rows per tile
+        const int tiles = (T + 507) / 508;
+        const int64_t total = (int64_t)N * tiles;
+        if (total > 0x7FFFFFFF) return NEF_E_SHAPE;
+        hipLaunchKernelGGL(hconv_tail_kernel<true>, dim3((unsigned)(total < cus ? total : cus)), dim3(512), LDS, st, (const _Float16*)x,
+                           (const nef_h8*)wp3, b3, (const nef_h8*)wp4, b4, wout, bout, out, T, N, nq, out_bs, out_is, tiles);
+    }
     return nef_launch_status();
 }
 
@@ -1291,7 +1324,7 @@ int nef_pano_h_conv_tail(const void* x, const void* wp3, const float* bias3, con
                          const float* bout, float* out, int N, int T, int nq, int64_t out_bs, int64_t out_is, nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(x && wp3 && bias3 && wp4 && bias4 && wout && bout && out, NEF_E_NULL);
-    NEF_REQUIRE(N > 0 && T > 0 && T <= 512 && T % 2 == 0 && nq > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(N > 0 && T > 0 && T % 2 == 0 && nq > 0, NEF_E_SHAPE);
     return launch_hconv_tail(x, wp3, bias3, wp4, bias4, wout, bout, out, N, T, nq, (long)out_bs, (long)out_is, (hipStream_t)stream);
 }
 

@@ -685,7 +685,7 @@ def sweep_eval_h(P, Bf, latent, query_thetas, pair_budget=16384):
             c1 = ops.pano_h_conv(lat_h, wp[0], bias[0], 128, N=N, upsample=True, scale=(rq[:, q0:], Q * 256, 256),
                                  x_div=n, nq=n, out=bufs[0])
             c2 = ops.pano_h_conv(c1, wp[1], bias[1], 128, out=bufs[1])
-        if 4 * T <= ops.PANO_TAIL_MAX_T and PANO_FUSE_TAIL:     # one tile per pair: layers 3 + 4 + last conv in one pass
+        if PANO_FUSE_TAIL:      # layers 3 + 4 + last conv + sigmoid in one pass (one tile per pair up to 512 rows, tiles of 508 beyond)
             ops.pano_h_conv_tail(c2, wp[2], bias[2], wp[3], bias[3], P["decoder.4.weight"], P["decoder.4.bias"], rest[:, q0:], n,
                                  Q * 4 * T, 4 * T)
             continue

@@ -281,14 +281,18 @@ H2_FOLLOW_UP = 2.0
 H2_FOLLOW_DOWN = 64.0
 H2_HEADROOM = 64
 # Heavy-tail guard (round 6): the format keeps 22-23 bits of an element only down to H2_TAIL_WINDOW = 2^-11 of its tensor's largest
-# (one power-of-two scale per tensor).  A tensor with more than H2_TAIL_FRAC of its NONZERO elements below that line has its bulk
-# outside the full-precision window, and the products of two such operands (a weight gradient) lose per-element precision
-# (test_conv_h2_operand_distributions[lognormal]: exp(4 N(0,1)) has 80 % there; profiles/r06_h2_scale_granularity.md).  Every call
-# site checks its operand ONCE, where it measures it (its first launch; never inside a captured step), and counts itself in `tail`;
-# bench.py and Solver report the count (h2_tail_sites) -- such a model wants NEF_H2=0.  (An amax / rms ratio does not work as the
-# criterion: the rms of a heavy-tailed sample is itself dominated by its largest elements.)
+# (one power-of-two scale per tensor).  A call site counts itself in `tail` when its operand has BOTH more than H2_TAIL_FRAC of its
+# nonzero elements below that line AND more than H2_TAIL_ENERGY of its energy (sum of squares) there: the bulk of such a tensor sits
+# outside the full-precision window and carries weight, and the products of two such operands (a weight gradient) lose per-element
+# precision (test_conv_h2_operand_distributions[lognormal]: exp(4 N(0,1)) has 99 % of its elements and ~1e-3 of its energy there;
+# profiles/r06_h2_scale_granularity.md).  The count condition alone also fires on this model's own tensors -- the fringe of a beat's
+# all-zero tail, where the encoder activations decay geometrically to 1e-9 of the tensor's rms: most NONZERO elements of a half-empty
+# tensor, none of its energy (1e-18) -- and an amax / rms ratio fires on neither (the rms of a heavy-tailed sample is dominated by its
+# largest elements).  Checked ONCE per site, where it measures its operand (its first launch; never inside a captured step);
+# bench.py and Solver report the count (h2_tail_sites) -- such a model wants NEF_H2=0.
 H2_TAIL_WINDOW = 2.0 ** -11
 H2_TAIL_FRAC = 0.5
+H2_TAIL_ENERGY = 1e-6
 AMAX_SITES = 16384
 _AMAX = {}
 # A call site = (scope, weight address, direction, role, batch, length).  The scope is the owning model's token
@@ -320,7 +324,8 @@ def _amax_state(dev):
                                clamped=torch.zeros(1, device=dev, dtype=torch.int32),       # waves that clamped (device total, never reset)
                                mark=torch.zeros(1, device=dev, dtype=torch.int32),          # ... at the last step boundary (h2_taint)
                                skipped=torch.zeros(1, device=dev, dtype=torch.int32),       # train steps skipped because of a clamp
-                               tail=torch.zeros(1, device=dev, dtype=torch.int32),          # call sites whose operand is heavy-tailed (H2_TAIL_RATIO)
+                               tail=torch.zeros(1, device=dev, dtype=torch.int32),          # call sites whose operand is heavy-tailed (H2_TAIL_*)
+                               tail_stat=torch.zeros(2, device=dev, dtype=torch.float32),   # diagnostics: largest (count, energy) fraction below the window seen at a site
                                seen=0, seen_skipped=0, seen_tail=0)                                       # ... as of the host's last h2_clamped() / h2_skipped()
     return st
 
@@ -352,8 +357,8 @@ def h2_skipped(reset=True):
 
 
 def h2_tail_sites(reset=True):
-    """Split-fp16 call sites whose operand, when the site measured it, had more than H2_TAIL_FRAC of its nonzero elements below
-    H2_TAIL_WINDOW x its largest (since the last call).  Synchronises like h2_clamped()."""
+    """Split-fp16 call sites whose operand, when the site measured it, had more than H2_TAIL_FRAC of its nonzero elements AND more than
+    H2_TAIL_ENERGY of its energy below H2_TAIL_WINDOW x its largest (since the last call).  Synchronises like h2_clamped()."""
     n = 0
     for st in _AMAX.values():
         tot = int(st["tail"].item())
@@ -365,19 +370,33 @@ def h2_tail_sites(reset=True):
 
 def _note_tail(st, i, n, *tensors):
     """At a site's measuring launch (eager, once per site): slots i .. i + n - 1 of `nxt` hold the operands' amax; count the site if
-    more than H2_TAIL_FRAC of any operand's nonzero elements lie below H2_TAIL_WINDOW x that amax.  A handful of torch passes per
-    SITE LIFETIME (the tensor as stored: prologues and channel scales are not applied), nothing per step, nothing read by the host."""
+    an operand has more than H2_TAIL_FRAC of its nonzero elements and more than H2_TAIL_ENERGY of its energy below H2_TAIL_WINDOW x that
+    amax.  A handful of torch passes per SITE LIFETIME (the tensor as stored: prologues and channel scales are not applied), nothing per
+    step, nothing read by the host."""
     hit = None
     for k, t in enumerate(tensors[:n]):
         if t is None or t.numel() == 0:
             continue
         a = t.detach().abs()
-        nz = (a > 0).sum()
-        below = ((a > 0) & (a < st["nxt"][i + k] * H2_TAIL_WINDOW)).sum()
-        h = below.to(torch.float32) > H2_TAIL_FRAC * nz.to(torch.float32)
+        small = (a > 0) & (a < st["nxt"][i + k] * H2_TAIL_WINDOW)
+        cf = small.sum().to(torch.float32) / (a > 0).sum().clamp_min(1).to(torch.float32)
+        a2 = a.double() * a.double()
+        ef = ((a2 * small).sum() / a2.sum().clamp_min(1e-300)).to(torch.float32)
+        h = (cf > H2_TAIL_FRAC) & (ef > H2_TAIL_ENERGY)
         hit = h if hit is None else (hit | h)
+        st["tail_stat"][0] = torch.maximum(st["tail_stat"][0], cf)
+        st["tail_stat"][1] = torch.maximum(st["tail_stat"][1], ef)
     if hit is not None:
         st["tail"] += hit.to(torch.int32)
+
+
+def h2_tail_stats():
+    """Diagnostics: the largest (count fraction, energy fraction) below the window any site's operand had when it was measured."""
+    out = [0.0, 0.0]
+    for st in _AMAX.values():
+        v = st["tail_stat"].tolist()
+        out = [max(out[0], v[0]), max(out[1], v[1])]
+    return out
 
 
 def h2_taint(out):
@@ -1642,16 +1661,17 @@ def pano_h_conv_pair(x, wp1, bias1, scale, wp2, bias2, N, x_div, nq, out=None):
     return y
 
 
-PANO_TAIL_MAX_T = 512     # nef_pano_h_conv_tail: one 512-row tile per (sample, angle)
+PANO_TAIL_MAX_T = 512     # nef_pano_h_conv_tail: up to here one tile per (sample, angle); longer sequences in tiles of 508 output rows
 
 
 def pano_h_conv_tail(x, wp3, bias3, wp4, bias4, wout, bout, out, nq, out_bs, out_is):
     """Layers 3 + 4 + last conv + sigmoid(x/3) in one pass (c3, c4 stay on chip): x fp16 [N, Tin, 128] (layer 2's output) -> the fp32
-    views at `out` (view base, addressed as in pano_h_conv_outconv); 2 * Tin <= 512."""
+    views at `out` (view base, addressed as in pano_h_conv_outconv).  Sequences of up to 512 rows are one tile per pair; longer ones run
+    in tiles of 508 output rows with three recomputed halo rows per side."""
     L = _lib.load()
     _chk(x, torch.float16), _chk(bias3), _chk(bias4), _chk(wout)
     N, Tin, Ci = x.shape
-    assert Ci == 128 and 2 * Tin <= PANO_TAIL_MAX_T
+    assert Ci == 128
     e = _timed(("pano_h_conv_tail", N, 2 * Tin))
     _lib.check(L.nef_pano_h_conv_tail(_p(x), _p(wp3), _p(bias3), _p(wp4), _p(bias4), _p(wout), _p(bout), _p(out), N, 2 * Tin, nq,
                                       out_bs, out_is, _stream()), "nef_pano_h_conv_tail")

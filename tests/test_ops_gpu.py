@@ -1334,8 +1334,10 @@ def test_conv_h2_operand_distributions(conv_algo, kind, K):
 
 def test_conv_h2_heavy_tail_sites_are_counted(conv_algo):
     """The runtime guard behind the format's per-region limit (round 6): a call site whose operand, when the site measures it, has
-    more than ops.H2_TAIL_FRAC of its nonzero elements below 2^-11 of its largest counts itself in ops.h2_tail_sites() -- log-normal
-    operands do (forward site and both operands' weight-gradient site), uniform ones and ReLU outputs (half zeros) do not.  (The model's own tensors: 0, asserted in test_model_gpu / reported by bench.py.)"""
+    more than ops.H2_TAIL_FRAC of its nonzero elements AND more than ops.H2_TAIL_ENERGY of its energy below 2^-11 of its largest counts
+    itself in ops.h2_tail_sites() -- log-normal operands do (forward site and both operands' weight-gradient site); uniform ones, ReLU
+    outputs (half zeros) and a tensor with a geometrically decaying fringe (most nonzero elements tiny, none of the energy: what the
+    edge of a beat's zero tail looks like in this model) do not.  (The model's own tensors: 0, asserted in test_model_gpu / reported by bench.py.)"""
     if conv_algo != "h2":
         pytest.skip("split-fp16 path")
     o = ops()
@@ -1343,9 +1345,14 @@ def test_conv_h2_heavy_tail_sites_are_counted(conv_algo):
     B, G, C, T, K = 4, 1, 128, 512, 3
     w = g(rnd(G * C, C, K, seed=771, scale=0.05))
     o.h2_tail_sites()
-    for kind, want in (("uniform", 0), ("relu", 0), ("lognormal", 2)):
-        x = g(F.relu(rnd(B, G * C, T, seed=774)) if kind == "relu" else _dist_operand(kind, (B, G * C, T), 772))
-        gy = g(_dist_operand("uniform" if kind == "relu" else kind, (B, G * C, T), 773))
+    for kind, want in (("uniform", 0), ("relu", 0), ("fringe", 0), ("lognormal", 2)):
+        if kind == "fringe":      # 1/4 of the row carries the signal, the rest decays by 2^-1 per position down to 1e-30
+            xf = rnd(B, G * C, T, seed=775)
+            xf[:, :, T // 4:] *= torch.pow(0.5, torch.arange(T - T // 4, dtype=torch.float32)).clamp_min(1e-30)
+            x = g(xf)
+        else:
+            x = g(F.relu(rnd(B, G * C, T, seed=774)) if kind == "relu" else _dist_operand(kind, (B, G * C, T), 772))
+        gy = g(_dist_operand("uniform" if kind in ("relu", "fringe") else kind, (B, G * C, T), 773))
         with o.amax_scope((o.new_amax_scope(), True)):
             o.conv(GV.dense(x, G), o.pack_weight(w, G, T=T), C, K)
             o.conv_bwd_weight(GV.dense(x, G), GV.dense(gy, G), K, site=w.data_ptr())

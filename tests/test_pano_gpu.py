@@ -61,13 +61,15 @@ def test_fused_layer_pair_is_bit_identical_to_two_launches(T, NB, nq):
     assert torch.equal(y, ref), float((y.float() - ref.float()).abs().max())
 
 
-@pytest.mark.parametrize("T,NB,nq", [(512, 3, 4), (80, 2, 3), (508, 70, 5), (256, 2, 2)])
+@pytest.mark.parametrize("T,NB,nq", [(512, 3, 4), (80, 2, 3), (508, 70, 5), (256, 2, 2),
+                                     (514, 2, 2), (1016, 2, 3), (1100, 3, 2), (5000, 2, 3), (2500, 40, 7)])
 def test_fused_tail_matches_two_launches(T, NB, nq):
     """nef_pano_h_conv_tail (layers 3 + 4 + last conv + sigmoid, c3 / c4 on chip; round 6) against nef_pano_h_conv(upsample) +
     nef_pano_h_conv_outconv: same k order per output and the same fp16 roundings of c3 and c4; the last conv runs on the matrix cores
     here (fp32 weights as two fp16 terms) and as a fused-multiply-add chain there, so the views agree to fp32 round-off of a 192-term
     sum, not bit for bit -- whole tile, short and ragged sequences, more pairs than CUs (a block walks several pairs and re-uses
-    both row buffers)."""
+    both row buffers).  Sequences longer than 512 rows (configs[4]: 5000) run in tiles of 508 output rows with recomputed halo rows: tile
+    starts, exact multiples, ragged ends, more (pair, tile) items than CUs."""
     o = ops()
     N, Tin = NB * nq, T // 2
     c2 = F.relu(rnd(N, Tin, 128, seed=21)).to(torch.float16).to(DEV)
