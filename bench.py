@@ -659,9 +659,8 @@ def main():
             # is skipped on the device (ops.h2_taint -> sgd_momentum) and counted in h2_skipped_steps; Solver checks both per epoch
             "h2_clamped_waves": int(ops.h2_clamped(reset=False)) if ops.H2 else None,
             "h2_skipped_steps": int(ops.h2_skipped(reset=False)) if ops.H2 else None,
-            # call sites whose operand was heavy-tailed when the site measured it (more than ops.H2_TAIL_FRAC of its nonzero elements and
-            # more than ops.H2_TAIL_ENERGY of its energy below 2^-11 of its largest: outside the format's full-precision window) -- a
-            # model that counts here wants NEF_H2=0
+            # call sites whose operand was heavy-tailed when the site measured it (more than ops.H2_TAIL_FRAC = 90 % of its nonzero
+            # elements below 2^-11 of its largest: outside the format's full-precision window) -- a model that counts here wants NEF_H2=0
             "h2_tail_sites": int(ops.h2_tail_sites(reset=False)) if ops.H2 else None,
             "h2_tail_worst": ([round(v, 12) for v in ops.h2_tail_stats()] if ops.H2 else None),      # largest (count, energy) fraction below the window at any site
             "h2_headroom": f"{ops.H2_HEADROOM}x growth of an operand between two consecutive steps",

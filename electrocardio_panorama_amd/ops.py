@@ -281,18 +281,18 @@ H2_FOLLOW_UP = 2.0
 H2_FOLLOW_DOWN = 64.0
 H2_HEADROOM = 64
 # Heavy-tail guard (round 6): the format keeps 22-23 bits of an element only down to H2_TAIL_WINDOW = 2^-11 of its tensor's largest
-# (one power-of-two scale per tensor).  A call site counts itself in `tail` when its operand has BOTH more than H2_TAIL_FRAC of its
-# nonzero elements below that line AND more than H2_TAIL_ENERGY of its energy (sum of squares) there: the bulk of such a tensor sits
-# outside the full-precision window and carries weight, and the products of two such operands (a weight gradient) lose per-element
-# precision (test_conv_h2_operand_distributions[lognormal]: exp(4 N(0,1)) has 99 % of its elements and ~1e-3 of its energy there;
-# profiles/r06_h2_scale_granularity.md).  The count condition alone also fires on this model's own tensors -- the fringe of a beat's
-# all-zero tail, where the encoder activations decay geometrically to 1e-9 of the tensor's rms: most NONZERO elements of a half-empty
-# tensor, none of its energy (1e-18) -- and an amax / rms ratio fires on neither (the rms of a heavy-tailed sample is dominated by its
-# largest elements).  Checked ONCE per site, where it measures its operand (its first launch; never inside a captured step);
-# bench.py and Solver report the count (h2_tail_sites) -- such a model wants NEF_H2=0.
+# (one power-of-two scale per tensor).  A call site counts itself in `tail` when more than H2_TAIL_FRAC = 90 % of its operand's
+# nonzero elements lie below that line: practically the whole tensor sits outside the full-precision window, and the products of two
+# such operands (a weight gradient) lose per-element precision (test_conv_h2_operand_distributions[lognormal]: exp(4 N(0,1)) has
+# 99.4 % there; profiles/r06_h2_scale_granularity.md).  There is no sharp line -- the format is fp32-class on the NORM whatever the
+# distribution -- and this model's own tensors are not far from it: the worst site of configs[1] (a gradient: a few large entries, a
+# long tail) has 74 % of its nonzero elements below the window, carrying 0.26 % of its energy (`h2_tail_worst` in the bench line;
+# full-size gradient parity 3.3e-5 on the flat norm, every tensor <= 1e-3).  An amax / rms ratio (the review's suggestion) fires on
+# neither: the rms of a heavy-tailed sample is dominated by its largest elements (log-normal: 100-500, not > 2048).  Checked ONCE per
+# site, where it measures its operand (its first launch; never inside a captured step); bench.py and Solver report the count
+# (h2_tail_sites) -- a model that counts here wants NEF_H2=0.
 H2_TAIL_WINDOW = 2.0 ** -11
-H2_TAIL_FRAC = 0.5
-H2_TAIL_ENERGY = 1e-6
+H2_TAIL_FRAC = 0.9
 AMAX_SITES = 16384
 _AMAX = {}
 # A call site = (scope, weight address, direction, role, batch, length).  The scope is the owning model's token
@@ -357,8 +357,8 @@ def h2_skipped(reset=True):
 
 
 def h2_tail_sites(reset=True):
-    """Split-fp16 call sites whose operand, when the site measured it, had more than H2_TAIL_FRAC of its nonzero elements AND more than
-    H2_TAIL_ENERGY of its energy below H2_TAIL_WINDOW x its largest (since the last call).  Synchronises like h2_clamped()."""
+    """Split-fp16 call sites whose operand, when the site measured it, had more than H2_TAIL_FRAC of its nonzero elements below
+    H2_TAIL_WINDOW x its largest (since the last call).  Synchronises like h2_clamped()."""
     n = 0
     for st in _AMAX.values():
         tot = int(st["tail"].item())
@@ -370,8 +370,8 @@ def h2_tail_sites(reset=True):
 
 def _note_tail(st, i, n, *tensors):
     """At a site's measuring launch (eager, once per site): slots i .. i + n - 1 of `nxt` hold the operands' amax; count the site if
-    an operand has more than H2_TAIL_FRAC of its nonzero elements and more than H2_TAIL_ENERGY of its energy below H2_TAIL_WINDOW x that
-    amax.  A handful of torch passes per SITE LIFETIME (the tensor as stored: prologues and channel scales are not applied), nothing per
+    an operand has more than H2_TAIL_FRAC of its nonzero elements below H2_TAIL_WINDOW x that amax (the energy fraction there is kept
+    for the diagnostics, h2_tail_stats).  A handful of torch passes per SITE LIFETIME (the tensor as stored: prologues and channel scales are not applied), nothing per
     step, nothing read by the host."""
     hit = None
     for k, t in enumerate(tensors[:n]):
@@ -382,7 +382,7 @@ def _note_tail(st, i, n, *tensors):
         cf = small.sum().to(torch.float32) / (a > 0).sum().clamp_min(1).to(torch.float32)
         a2 = a.double() * a.double()
         ef = ((a2 * small).sum() / a2.sum().clamp_min(1e-300)).to(torch.float32)
-        h = (cf > H2_TAIL_FRAC) & (ef > H2_TAIL_ENERGY)
+        h = cf > H2_TAIL_FRAC
         hit = h if hit is None else (hit | h)
         st["tail_stat"][0] = torch.maximum(st["tail_stat"][0], cf)
         st["tail_stat"][1] = torch.maximum(st["tail_stat"][1], ef)

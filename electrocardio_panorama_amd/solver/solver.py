@@ -257,9 +257,9 @@ class Solver:
         ops.h2_rebase(self.device)       # clamps of this (test / val) phase are not charged to the next train step's taint word
         tails = ops.h2_tail_sites()
         if tails:      # (per rank: a warning only)
-            print('WARNING: {} split-fp16 call site(s) measured an operand with more than {:.0%} of its nonzero elements and more than {:g} of '
-                  'its energy below 2^-11 of its largest: the bulk of such a tensor is outside the format\'s full-precision window '
-                  '(DESIGN.md 3.0); NEF_H2=0 runs the fp32 kernels'.format(tails, ops.H2_TAIL_FRAC, ops.H2_TAIL_ENERGY))
+            print('WARNING: {} split-fp16 call site(s) measured an operand with more than {:.0%} of its nonzero elements below 2^-11 of its '
+                  'largest: practically the whole tensor is outside the format\'s full-precision window (DESIGN.md 3.0); NEF_H2=0 runs the '
+                  'fp32 kernels'.format(tails, ops.H2_TAIL_FRAC))
         if not clamped and not skipped:
             return
         msg = ('{} waves of split-fp16 conv launches met an operand outside fp16\'s range in this {} phase (non-finite data; finite '
