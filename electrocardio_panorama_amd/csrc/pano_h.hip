@@ -899,8 +899,9 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
     nef_h8 hzero;
 #pragma unroll
     for (int e = 0; e < 8; ++e) hzero[e] = (_Float16)0.f;
-    // rows 0 and NT + 1 of both buffers are the convs' zero padding for the whole kernel
-    if (tid < 32) {
+    // one-tile form: rows 0 and NT + 1 of both buffers are the convs' zero padding for the whole kernel (TILED: they are halo rows,
+    // staged with every chunk -- by OTHER threads than these, so zeroing them here would race with the first item's staging)
+    if (!TILED && tid < 32) {
         const int bsel = tid >> 4, r = ((tid >> 3) & 1) ? XROWS - 1 : 0;
         *(nef_h8*)(smem + bsel * XBYTES + r * PH_XRS + seg * 16) = hzero;
     }
