@@ -30,5 +30,7 @@ flat = torch.empty(sum(p.numel() for p in local))
 parallel.reduce_flat_grads([p.grad for p in local], flat)                   # sum over ranks
 flat *= 1.0 / world
 expect = torch.cat([p.grad.reshape(-1) for p in grads_for(full)])
-np.savez(f"{out}/rank{rank}.npz", flat=flat.numpy(), expect=expect.numpy(), idx=np.asarray(idx))
+# the collective range check of Solver._check_h2_range: per-rank counters (rank 1 alone saw a clamp) become the same totals everywhere
+counts = parallel.sum_counts([3 if rank == 1 else 0, rank], torch.device("cpu"))
+np.savez(f"{out}/rank{rank}.npz", flat=flat.numpy(), expect=expect.numpy(), idx=np.asarray(idx), counts=np.asarray(counts))
 dist.destroy_process_group()

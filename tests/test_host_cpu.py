@@ -107,6 +107,18 @@ def test_data_parallel_plumbing_gloo_world2(tmp_path):
     assert np.array_equal(a["flat"], b["flat"])
     assert np.allclose(a["flat"], a["expect"], rtol=1e-6, atol=1e-7)
     assert sorted(np.concatenate([a["idx"], b["idx"]]).tolist()) == list(range(8))
+    # parallel.sum_counts (round 6): a counter only rank 1 incremented is seen by BOTH ranks, so both take the same decision
+    assert a["counts"].tolist() == b["counts"].tolist() == [3, 1]
+
+
+def test_dry_collective_model_and_single_rank_counts():
+    """The modelled all-reduce duration of bench.py --dry-collective (ring over xGMI, per-link bound: 2 (N-1)/N S / 153 GB/s + 20 us,
+    SURVEY section 5) and parallel.sum_counts without a process group."""
+    from electrocardio_panorama_amd import parallel
+    d = parallel.DryCollective(8)
+    assert abs(d.ms(75.3e6) - (2 * 7 / 8 * 75.3e6 / 153e9 * 1e3 + 0.02)) < 1e-9 and 0.85 < d.ms(75.3e6) < 0.9
+    assert abs(parallel.DryCollective(2).ms(153e6) - (1.0 + 0.02)) < 1e-9
+    assert parallel.sum_counts([2, 0], "cpu") == [2, 0]
 
 
 def test_metrics_psnr_ssim():

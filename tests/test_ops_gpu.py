@@ -1332,6 +1332,53 @@ def test_conv_h2_operand_distributions(conv_algo, kind, K):
     assert e[1] < small[0] and ed[1] < small[1] and ew[1] < small[2], (kind, e, ed, ew)
 
 
+def test_round6_library_ops_match_the_torch_ops_they_replace(conv_algo):
+    """The launches that took the last torch kernels out of the replayed train step (round 6): nef_flatten against torch.cat (odd
+    sizes, a 4-byte-aligned destination, more than 64 tensors), nef_regroup_halves against the view / permute it replaces (+ inverse),
+    nef_amax_roll against the follow-up rule it implements (ops.H2_FOLLOW_UP / _DOWN, `follow` mode), and a pack whose polyphase
+    weights are formed INSIDE the pack kernel (nef_pack_desc.src_mode 1) against packing nef_poly_weights' output: same bytes."""
+    if conv_algo != "h2":
+        pytest.skip("library-level: once")
+    o = ops()
+    from electrocardio_panorama_amd import _lib
+    L = _lib.load()
+    # flatten
+    ts = [g(rnd(*shp, seed=800 + i)) for i, shp in enumerate([(5, 3), (7,), (2, 2, 2), (1,), (384, 128, 7), (13,)] + [(3,)] * 70)]
+    buf = torch.zeros(sum(t.numel() for t in ts) + 5, device=DEV)
+    for off in (4, 1):      # 16-byte aligned and 4-byte aligned destinations
+        out = buf[off:off + sum(t.numel() for t in ts)]
+        out.zero_()
+        o.flatten_into(ts, out)
+        assert torch.equal(out, torch.cat([t.reshape(-1) for t in ts]))
+    # regroup halves
+    w = g(rnd(128, 256, 3, seed=801))
+    wg = o.regroup_halves(w)
+    assert torch.equal(wg, w.view(128, 2, 128, 3).permute(1, 0, 2, 3).contiguous().view(256, 128, 3))
+    assert torch.equal(o.regroup_halves(wg, inverse=True), w)
+    # amax roll
+    gen = torch.Generator().manual_seed(5)
+    cur0 = torch.exp(3 * torch.randn(1000, generator=gen)) * (torch.rand(1000, generator=gen) > 0.2)
+    nxt0 = torch.exp(3 * torch.randn(1000, generator=gen)) * (torch.rand(1000, generator=gen) > 0.3)
+    for follow in (0, 1):
+        cur, nxt = g(cur0.clone()), g(nxt0.clone())
+        _lib.check(L.nef_amax_roll(cur.data_ptr(), nxt.data_ptr(), 900, o.H2_FOLLOW_UP, o.H2_FOLLOW_DOWN, follow, torch.cuda.current_stream().cuda_stream))
+        upd = (nxt0 > 0) & ((nxt0 > 0) if follow else ((cur0 <= 0) | (nxt0 > o.H2_FOLLOW_UP * cur0) | (nxt0 * o.H2_FOLLOW_DOWN < cur0)))
+        want = torch.where(upd, nxt0, cur0)
+        want[900:] = cur0[900:]
+        assert torch.equal(cur.cpu(), want)
+        assert float(nxt[:900].abs().max()) == 0.0 and torch.equal(nxt[900:].cpu(), nxt0[900:])
+    # polyphase weights formed inside the pack
+    for G, Cog, Cig, T in ((1, 64, 128, 2500), (2, 128, 128, 1250)):
+        wc = g(rnd(G * Cog, Cig, 3, seed=802, scale=0.05))
+        for flip, Cr in ((False, Cog), (True, 0)):
+            ref = o.pack_weight(o.poly_weights(wc, Cr), G, flip=flip, T=T, plain=flip)
+            got = o.pack_weight(wc, G, flip=flip, T=T, plain=flip, src=("poly", Cr))
+            assert ref.nef_wino == got.nef_wino == 3 and torch.equal(ref, got), (G, Cog, flip)
+            # ... and through the step-level multi-descriptor launch
+            o.pack_many([(wc, G, flip, T, False, ("poly", Cr), flip, None)])
+            assert torch.equal(o.pack_weight(wc, G, flip=flip, T=T, plain=flip, src=("poly", Cr)), ref)
+
+
 def test_conv_h2_heavy_tail_sites_are_counted(conv_algo):
     """The runtime guard behind the format's per-region limit (round 6): a call site whose operand, when the site measures it, has
     more than ops.H2_TAIL_FRAC = 90 % of its nonzero elements below 2^-11 of its largest counts itself in ops.h2_tail_sites() --
