@@ -1606,10 +1606,20 @@ __device__ __forceinline__ void bn_slot_totals(const float* __restrict__ slots, 
                                                double& s1, double& s2) {
     const float2* src = (const float2*)slots + ((int64_t)c * P + p) * per_pass;
     s1 = 0.0, s2 = 0.0;
-    for (int i = threadIdx.x; i < per_pass; i += 256) {
-        const float2 v = src[i];
-        s1 += (double)v.x;
-        s2 += (double)v.y;
+    // eight loads in flight per thread, added in index order (the same sums as a plain loop: one workgroup per channel has only four
+    // waves on its CU to hide the loads' latency behind -- a load per trip made this pass 37 us for 15 MB)
+    for (int i0 = threadIdx.x; i0 < per_pass; i0 += 8 * 256) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            v[u] = i < per_pass ? src[i] : float2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s1 += (double)v[u].x;
+            s2 += (double)v[u].y;
+        }
     }
     s1 = nef_block_sum_d(s1, sm);
     s2 = nef_block_sum_d(s2, sm);

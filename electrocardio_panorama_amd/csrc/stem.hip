@@ -324,8 +324,15 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_reduce(const float* __res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     float s = 0.f;
-    if (i < n)
-        for (int sp = wave; sp < nsplit; sp += 4) s += part[(int64_t)sp * n + i];
+    if (i < n) {      // eight loads in flight, added in slot order
+        for (int sp0 = wave; sp0 < nsplit; sp0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = sp0 + 4 * u < nsplit ? part[(int64_t)(sp0 + 4 * u) * n + i] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+    }
     sm[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && i < n) gw[i] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
