@@ -1599,20 +1599,20 @@ __global__ __launch_bounds__(256) void bn_slots_reduce(const float* __restrict__
 }
 
 // Round 6: bn_slots_reduce + bn_stats_final (forward) / + bn_bwd_final (backward) as ONE launch -- one workgroup per CHANNEL walks
-// its P passes: each pass's slot sums are block-reduced exactly as bn_slots_reduce does (same stride, same tree: bit-identical
-// totals) and thread 0 then does that pass's share of the final (running statistics pass by pass, in order).  Two launches fewer
-// per BatchNorm and direction; 4 x fewer workgroups, each with 3 x the work -- the 15 MB of slots still stream in ~10 us.
+// its P passes: each pass's slot sums are block-reduced in fp64 in a fixed order (1024 threads, eight loads in flight each) and thread 0
+// then does that pass's share of the final (running statistics pass by pass, in order).  Two launches fewer per BatchNorm and direction.
+constexpr int BNF_THREADS = 1024;      // sixteen waves per channel: the slots of a pass are two round trips of eight loads per thread
 __device__ __forceinline__ void bn_slot_totals(const float* __restrict__ slots, int c, int p, int P, int per_pass, double* sm,
                                                double& s1, double& s2) {
     const float2* src = (const float2*)slots + ((int64_t)c * P + p) * per_pass;
     s1 = 0.0, s2 = 0.0;
-    // eight loads in flight per thread, added in index order (the same sums as a plain loop: one workgroup per channel has only four
-    // waves on its CU to hide the loads' latency behind -- a load per trip made this pass 37 us for 15 MB)
-    for (int i0 = threadIdx.x; i0 < per_pass; i0 += 8 * 256) {
+    // eight loads in flight per thread, added in index order.  One workgroup per channel is all the parallelism this pass has
+    // (64-128 workgroups): with 256 threads and a load per trip it took 37 us for 15 MB -- ~2 us of latency per dependent trip
+    for (int i0 = threadIdx.x; i0 < per_pass; i0 += 8 * BNF_THREADS) {
         float2 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 256;
+            const int i = i0 + u * BNF_THREADS;
             v[u] = i < per_pass ? src[i] : float2{0.f, 0.f};
         }
 #pragma unroll
@@ -1621,17 +1621,25 @@ __device__ __forceinline__ void bn_slot_totals(const float* __restrict__ slots, 
             s2 += (double)v[u].y;
         }
     }
-    s1 = nef_block_sum_d(s1, sm);
-    s2 = nef_block_sum_d(s2, sm);
+    // block sum over sixteen waves, fixed order (deterministic): wave sums, then wave 0's order 0..15
+    s1 = nef_wave_sum_d(s1);
+    s2 = nef_wave_sum_d(s2);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[2 * w] = s1, sm[2 * w + 1] = s2;
+    __syncthreads();
+    s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < BNF_THREADS / 64; ++k) s1 += sm[2 * k], s2 += sm[2 * k + 1];
 }
 
-__global__ __launch_bounds__(256) void bn_slots_stats_fused(const float* __restrict__ slots, const float* __restrict__ gamma,
+__global__ __launch_bounds__(BNF_THREADS) void bn_slots_stats_fused(const float* __restrict__ slots, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ running_mean,
                                                             float* __restrict__ running_var, float* __restrict__ mean,
                                                             float* __restrict__ invstd, float* __restrict__ a, float* __restrict__ b, int P,
                                                             int Bp, int C, int L, float eps, float momentum, int per_pass,
                                                             int64_t* __restrict__ nbt) {
-    __shared__ double sm[4];
+    __shared__ double sm[2 * BNF_THREADS / 64];
     const int c = blockIdx.x;
     const double n = (double)Bp * (double)L;
     float rm = running_mean ? running_mean[c] : 0.f;
@@ -1662,10 +1670,10 @@ __global__ __launch_bounds__(256) void bn_slots_stats_fused(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void bn_slots_bwd_fused(const float* __restrict__ slots, float* __restrict__ coef,
+__global__ __launch_bounds__(BNF_THREADS) void bn_slots_bwd_fused(const float* __restrict__ slots, float* __restrict__ coef,
                                                           float* __restrict__ ggamma, float* __restrict__ gbeta, int P, int Bp, int C,
                                                           int L, int per_pass) {
-    __shared__ double sm[4];
+    __shared__ double sm[2 * BNF_THREADS / 64];
     const int c = blockIdx.x;
     const double n = (double)Bp * (double)L;
     double g1 = 0.0, g2 = 0.0;
@@ -1910,7 +1918,7 @@ int nef_bn_stats_from_slots(const float* slots, int nslot, const float* gamma, c
     NEF_REQUIRE(P > 0 && Bp > 0 && C > 0 && L > 0 && nslot > 0 && (int64_t)Bp * L > 1 &&
                     (int64_t)Bp * nslot <= 0x7FFFFFFF && (int64_t)P * C <= 0x7FFFFFFF, NEF_E_SHAPE);
     NEF_REQUIRE(ws_bytes >= nef_bn_ws_bytes(P, C), NEF_E_WORKSPACE);
-    hipLaunchKernelGGL(bn_slots_stats_fused, dim3((unsigned)C), dim3(256), 0, NEF_ST, slots, gamma, beta, running_mean, running_var, mean,
+    hipLaunchKernelGGL(bn_slots_stats_fused, dim3((unsigned)C), dim3(BNF_THREADS), 0, NEF_ST, slots, gamma, beta, running_mean, running_var, mean,
                        invstd, a, b, P, Bp, C, L, eps, momentum, Bp * nslot, num_batches_tracked);
     return nef_launch_status();
 }
@@ -1982,7 +1990,7 @@ static int bn_relu_bwd_impl(const float* gy, const float* x, const float* gamma,
     float* coef = (float*)((char*)ws + (size_t)P * C * BN_SPLIT * 2 * sizeof(double));
     double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(P, C)) : nullptr;
     if (slots) {        // the producing conv left the sums per slot: add them up in fp64, fixed order
-        hipLaunchKernelGGL(bn_slots_bwd_fused, dim3((unsigned)C), dim3(256), 0, NEF_ST, slots, coef, ggamma, gbeta, P, Bp, C, L, Bp * nslot);
+        hipLaunchKernelGGL(bn_slots_bwd_fused, dim3((unsigned)C), dim3(BNF_THREADS), 0, NEF_ST, slots, coef, ggamma, gbeta, P, Bp, C, L, Bp * nslot);
     } else {
         hipLaunchKernelGGL(bn_bwd_partial<0>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part,
                            P, Bp, C, L, (const float*)nullptr);
@@ -2031,7 +2039,7 @@ int nef_bn_relu_bwd_up(const float* gu, const float* x, const float* mean, const
     float* coef = (float*)((char*)ws + (size_t)P * C * BN_SPLIT * 2 * sizeof(double));
     double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(P, C)) : nullptr;
     if (slots) {
-        hipLaunchKernelGGL(bn_slots_bwd_fused, dim3((unsigned)C), dim3(256), 0, NEF_ST, slots, coef, ggamma, gbeta, P, Bp, C, L, Bp * nslot);
+        hipLaunchKernelGGL(bn_slots_bwd_fused, dim3((unsigned)C), dim3(BNF_THREADS), 0, NEF_ST, slots, coef, ggamma, gbeta, P, Bp, C, L, Bp * nslot);
     } else {
         hipLaunchKernelGGL(bn_bwd_partial<2>, dim3(P * C * BN_SPLIT), dim3(256), 0, NEF_ST, gu, x, mean, invstd, a, b, part,
                            P, Bp, C, L, (const float*)nullptr);
@@ -2060,7 +2068,7 @@ static int bn_relu_bwd_combine3_impl(const float* gy, const float* x, const floa
     float* coef = (float*)((char*)ws + (size_t)3 * C * BN_SPLIT * 2 * sizeof(double));
     double* rowsum = gx_chan_sum ? (double*)((char*)ws + nef_bn_ws_bytes(3, C)) : nullptr;
     if (slots) {
-        hipLaunchKernelGGL(bn_slots_bwd_fused, dim3((unsigned)C), dim3(256), 0, NEF_ST, slots, coef, ggamma, gbeta, 3, Bp, C, L, Bp * nslot);
+        hipLaunchKernelGGL(bn_slots_bwd_fused, dim3((unsigned)C), dim3(BNF_THREADS), 0, NEF_ST, slots, coef, ggamma, gbeta, 3, Bp, C, L, Bp * nslot);
     } else {
         hipLaunchKernelGGL(bn_bwd_partial<0>, dim3(3 * C * BN_SPLIT), dim3(256), 0, NEF_ST, gy, x, mean, invstd, a, b, part,
                            3, Bp, C, L, (const float*)nullptr);
