@@ -643,11 +643,17 @@ __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __re
 // ------------------------------------------------------------------------------------------------------------
 #define PHP_CRS 272   // bytes per c1 / y row in LDS: 128 halfs + 16 B pad (conflict-free ds_read_b128 across 16 rows)
 
+template <bool TILED>
 __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __restrict__ x, const nef_h8* __restrict__ wp1,
                                                          const float* __restrict__ bias1, const float* __restrict__ scale,
                                                          const nef_h8* __restrict__ wp2, const float* __restrict__ bias2,
                                                          _Float16* __restrict__ y, int T, int N, int x_div, int nq,
-                                                         long sc_bs, long sc_is) {
+                                                         long sc_bs, long sc_is, int tiles_per_n) {
+    // TILED (round 6; sequences longer than one tile -- configs[4]'s 2500 rows): a work item is (pair, tile); tile k produces the
+    // NOUT = 252 output rows o = 252 k .. 252 k + 251 from 256-slot tiles of c1 and c2 whose slot j is time base + j, base = o - 2
+    // (even: the x2 blend's row parity is that of the one-tile form); rows 0 / 257 of the X buffers hold real halo rows of the scaled,
+    // upsampled input there and the conv's zero padding in the one-tile form (base = 0, slot = time).
+    constexpr int NOUT = 252;
     constexpr int CIN = 256, COUT = 128, NT = 256, NI = 2;
     constexpr int XROWS = NT + 2;
     constexpr int XBYTES = XROWS * PH_XRS;
@@ -672,8 +678,9 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
 #pragma unroll
     for (int e = 0; e < 8; ++e) hzero[e] = (_Float16)0.f;
 
-    // the padding rows of both X buffers and of the c1 tile are zero for the whole kernel (one tile per pair)
-    if (tid < 32) {
+    // the padding rows of both X buffers and of the c1 tile are zero for the whole kernel (one tile per pair; TILED: the X buffers'
+    // rows 0 / 257 are halo rows staged with every chunk -- by other threads than these, so zeroing them here would race)
+    if (!TILED && tid < 32) {
         const int bsel = tid >> 4, r = ((tid >> 3) & 1) ? XROWS - 1 : 0;
         *(nef_h8*)(smem + bsel * XBYTES + r * PH_XRS + seg * 16) = hzero;
     }
@@ -684,13 +691,16 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
 
     nef_h8 xr[4];
     float qr[8];
-    // source rows 2 rg - 1 .. 2 rg + 2 (clamped to the sequence: the align_corners=False edge rule) of chunk cc_ of pair n_
-#define PHP_FETCH(n_, cc_)                                                                                    \
+    int fbase = 0;                            // `base` of the tile held in xr
+    // source rows base / 2 + 2 rg - 1 .. + 2 (clamped to the sequence: the align_corners=False edge rule) of chunk cc_ of work item w_
+#define PHP_FETCH(w_, cc_)                                                                                    \
     {                                                                                                         \
+        const int n_ = TILED ? (w_) / tiles_per_n : (w_);                                                     \
+        fbase = TILED ? ((w_) % tiles_per_n) * NOUT - 2 : 0;                                                  \
         const __amdgpu_buffer_rsrc_t xd_ = __builtin_amdgcn_make_buffer_rsrc(                                 \
             const_cast<_Float16*>(x + (size_t)((n_) / x_div) * Tin * CIN), 0, Tin * CIN * 2, 0x00020000);     \
         _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                       \
-            int r_ = 2 * rg - 1 + k;                                                                          \
+            int r_ = fbase / 2 + 2 * rg - 1 + k;                                                              \
             r_ = r_ < 0 ? 0 : (r_ > Tin - 1 ? Tin - 1 : r_);                                                  \
             xr[k] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(                         \
                 xd_, r_ * (CIN * 2) + seg * 16, (cc_) * 128, 0));                                             \
@@ -700,17 +710,27 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
         const nef_f32x4 q0_ = nef_buf_f32x4(sd_, seg * 32, 0), q1_ = nef_buf_f32x4(sd_, seg * 32 + 16, 0);    \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) { qr[e] = q0_[e]; qr[4 + e] = q1_[e]; }                 \
     }
-    // blended rows j (of this thread's 4: t = 4 rg + j) -> X buffer; same arithmetic as hconv_wide_kernel
+    // blended rows j (of this thread's 4: time fbase + 4 rg + j) -> X buffer; same arithmetic as hconv_wide_kernel.  TILED, j = 4
+    // (J1_ = 5): the two halo rows 0 / 257 (times fbase - 1, fbase + 256) by the first / last row group
 #define PHP_STAGE(Xn_, J0_, J1_)                                                                              \
     {                                                                                                         \
         nef_h8 qh, c75;                                                                                       \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) { c75[e] = (_Float16)0.75f; qh[e] = (_Float16)qr[e]; }  \
-        _Pragma("unroll") for (int j = (J0_); j < (J1_); ++j) {                                               \
+        _Pragma("unroll") for (int j = (J0_); j < (J1_) && j < 4; ++j) {                                      \
             const nef_h8 a_ = xr[(j >> 1) + 1], b_ = (j & 1) ? xr[(j >> 1) + 2] : xr[j >> 1];                 \
             nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);                             \
             v_ = v_ * qh;                                                                                     \
-            if (4 * rg + j >= T) v_ = hzero;                                                                  \
+            const int tau_ = fbase + 4 * rg + j;                                                              \
+            if (tau_ >= T || (TILED && tau_ < 0)) v_ = hzero;                                                 \
             *(nef_h8*)((Xn_) + (4 * rg + 1 + j) * PH_XRS + seg * 16) = v_;                                    \
+        }                                                                                                     \
+        if (TILED && (J1_) > 4 && (rg == 0 || rg == 63)) {                                                    \
+            const nef_h8 a_ = rg == 0 ? xr[0] : xr[3], b_ = rg == 0 ? xr[1] : xr[2];                          \
+            nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);                            \
+            v_ = v_ * qh;                                                                                     \
+            const int tau_ = rg == 0 ? fbase - 1 : fbase + NT;                                                \
+            if (tau_ >= T || tau_ < 0) v_ = hzero;                                                            \
+            *(nef_h8*)((Xn_) + (rg == 0 ? 0 : XROWS - 1) * PH_XRS + seg * 16) = v_;                           \
         }                                                                                                     \
     }
     const __amdgpu_buffer_rsrc_t wd1 = nef_rsrc(wp1), wd2 = nef_rsrc(wp2);
@@ -736,6 +756,7 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
             if ((FE_) && s == 1) PHP_FETCH(FN_, FC_)                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                                \
             if ((ST_) && s >= 6 && s <= 9) PHP_STAGE(XN_, s - 6, s - 5)                                       \
+            if ((ST_) && TILED && s == 10) PHP_STAGE(XN_, 4, 5)                                               \
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
                 _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                              \
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % AD][mi], b[ni], acc[mi][ni], 0, 0, 0); \
@@ -761,35 +782,39 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
                 const int t = wn * 64 + ni * 32 + lo;                                                         \
                 nef_h4 o;                                                                                     \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-                    o[e] = ((ZERO_) && t >= T) ? (_Float16)0.f : (_Float16)fmaxf(acc[mi][ni][g * 4 + e] + bv[e], 0.f); \
+                    o[e] = ((ZERO_) && (base + t >= T || (TILED && base + t < 0))) ? (_Float16)0.f                    \
+                                                                                   : (_Float16)fmaxf(acc[mi][ni][g * 4 + e] + bv[e], 0.f); \
                     acc[mi][ni][g * 4 + e] = 0.f;                                                             \
                 }                                                                                             \
                 *(nef_h4*)(C1 + (1 + t) * PHP_CRS + co * 2) = o;                                              \
             }                                                                                                 \
         }
 
-    int n = blockIdx.x;
+    const int total = TILED ? N * tiles_per_n : N;      // work items: (pair, tile)
+    int w = blockIdx.x;
     PHP_A(wd1, 0, 0)
     PHP_A(wd1, 1, 1)
     PHP_A(wd1, 2, 2)
-    if (n < N) {
-        PHP_FETCH(n, 0)
-        PHP_STAGE(smem, 0, 4)
+    if (w < total) {
+        PHP_FETCH(w, 0)
+        PHP_STAGE(smem, 0, 5)
     }
     __syncthreads();
 
 #pragma unroll 1
-    for (; n < N; n += gridDim.x) {
-        const int n_next = n + (int)gridDim.x < N ? n + (int)gridDim.x : n;   // last pair: re-stage itself (unread)
+    for (; w < total; w += gridDim.x) {
+        const int n = TILED ? w / tiles_per_n : w;
+        const int base = TILED ? (w % tiles_per_n) * NOUT - 2 : 0;      // time of slot 0
+        const int n_next = w + (int)gridDim.x < total ? w + (int)gridDim.x : w;   // last item: re-stage itself (unread)
         // ---- layer 1: four 64-channel chunks, buffers 0 1 0 1; chunk cc + 1 staged during chunk cc
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
             const char* Bp = smem + (cc & 1) * XBYTES + (wn * 64 + lo) * PH_XRS + 16 * hi;
             char* Xn = smem + ((cc + 1) & 1) * XBYTES;
             if (cc < 3) {
-                PHP_STEPS(Bp, PH_XRS, wd1, cc * 12, wd1, (cc + 1) * 12, true, n, cc + 1, true, Xn)
+                PHP_STEPS(Bp, PH_XRS, wd1, cc * 12, wd1, (cc + 1) * 12, true, w, cc + 1, true, Xn)
             } else {
-                PHP_STEPS(Bp, PH_XRS, wd1, cc * 12, wd2, 0, false, n, 0, false, Xn)
+                PHP_STEPS(Bp, PH_XRS, wd1, cc * 12, wd2, 0, false, w, 0, false, Xn)
             }
             __syncthreads();
         }
@@ -798,7 +823,7 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
         // ---- layer 2: two 64-channel chunks straight from the c1 rows; the next pair's first X chunk rides along
         {
             const char* Bp = C1 + (wn * 64 + lo) * PHP_CRS + 16 * hi;
-            PHP_STEPS(Bp, PHP_CRS, wd2, 0, wd2, 12, false, n, 0, false, smem)
+            PHP_STEPS(Bp, PHP_CRS, wd2, 0, wd2, 12, false, w, 0, false, smem)
             PHP_STEPS(Bp + 128, PHP_CRS, wd2, 12, wd1, 0, true, n_next, 0, true, smem)
         }
         __syncthreads();                     // every wave is done reading c1; X chunk 0 of the next pair is staged
@@ -808,7 +833,9 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int idx = tid + k * 512, r = idx >> 4, v = idx & 15;
-            if (r < T) *(nef_h8*)(yb + (size_t)r * COUT + v * 8) = *(const nef_h8*)(C1 + (1 + r) * PHP_CRS + v * 16);
+            // slot r is time base + r; a tile of the TILED form owns slots 2 .. 253 (the others lack context)
+            if (base + r < T && (!TILED || (r >= 2 && r < 2 + NOUT)))
+                *(nef_h8*)(yb + (size_t)(base + r) * COUT + v * 8) = *(const nef_h8*)(C1 + (1 + r) * PHP_CRS + v * 16);
         }
         // no barrier: the c1 rows are next written four chunk barriers from here
     }
@@ -1220,13 +1247,22 @@ static int launch_hconv_pair(const void* x, const void* wp1, const float* b1, co
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     int cus = __atomic_load_n(&cus_dev[dev & 63], __ATOMIC_ACQUIRE);
     if (cus == 0) {
-        hipError_t e = hipFuncSetAttribute((const void*)hconv_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)hconv_pair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
+        if ((e = hipFuncSetAttribute((const void*)hconv_pair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)) != hipSuccess) return (int)e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
         __atomic_store_n(&cus_dev[dev & 63], cus, __ATOMIC_RELEASE);
     }
-    hipLaunchKernelGGL(hconv_pair_kernel, dim3(N < cus ? N : cus), dim3(512), LDS, st, (const _Float16*)x,
-                       (const nef_h8*)wp1, b1, scale, (const nef_h8*)wp2, b2, (_Float16*)y, T, N, x_div, nq, sc_bs, sc_is);
+    if (T <= 256) {      // one tile per pair
+        hipLaunchKernelGGL(hconv_pair_kernel<false>, dim3(N < cus ? N : cus), dim3(512), LDS, st, (const _Float16*)x,
+                           (const nef_h8*)wp1, b1, scale, (const nef_h8*)wp2, b2, (_Float16*)y, T, N, x_div, nq, sc_bs, sc_is, 1);
+    } else {             // 252 output rows per tile
+        const int tiles = (T + 251) / 252;
+        const int64_t total = (int64_t)N * tiles;
+        if (total > 0x7FFFFFFF) return NEF_E_SHAPE;
+        hipLaunchKernelGGL(hconv_pair_kernel<true>, dim3((unsigned)(total < cus ? total : cus)), dim3(512), LDS, st, (const _Float16*)x,
+                           (const nef_h8*)wp1, b1, scale, (const nef_h8*)wp2, b2, (_Float16*)y, T, N, x_div, nq, sc_bs, sc_is, tiles);
+    }
     return nef_launch_status();
 }
 
@@ -1316,7 +1352,7 @@ int nef_pano_h_conv_pair(const void* x, const void* wp1, const float* bias1, con
                          nef_stream_t stream) {
     NEF_ENTER();
     NEF_REQUIRE(x && wp1 && bias1 && scale && wp2 && bias2 && y, NEF_E_NULL);
-    NEF_REQUIRE(N > 0 && T > 0 && T <= 256 && T % 2 == 0 && x_div > 0 && nq > 0, NEF_E_SHAPE);
+    NEF_REQUIRE(N > 0 && T > 0 && T % 2 == 0 && x_div > 0 && nq > 0, NEF_E_SHAPE);
     return launch_hconv_pair(x, wp1, bias1, scale, wp2, bias2, y, N, T, x_div, nq, (long)sc_bs, (long)sc_is,
                              (hipStream_t)stream);
 }

@@ -678,7 +678,7 @@ def sweep_eval_h(P, Bf, latent, query_thetas, pair_budget=16384):
             bufs = (torch.empty(N, 2 * T, 128, device=dev, dtype=torch.float16),
                     torch.empty(N, 2 * T, 128, device=dev, dtype=torch.float16),
                     torch.empty(N, 4 * T, 64, device=dev, dtype=torch.float16))
-        if 2 * T <= ops.PANO_PAIR_MAX_T and PANO_FUSE_PAIR:     # one tile per pair: layers 1 + 2 in one pass
+        if PANO_FUSE_PAIR:      # layers 1 + 2 in one pass (one tile per pair up to 256 rows, tiles of 252 rows beyond)
             c2 = ops.pano_h_conv_pair(lat_h, wp[0], bias[0], (rq[:, q0:], Q * 256, 256), wp[1], bias[1], N, n, n,
                                       out=bufs[1])
         else:

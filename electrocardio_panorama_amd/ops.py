@@ -1640,17 +1640,18 @@ def pano_h_conv(x, wp, bias, Cout, N=None, upsample=False, scale=None, x_div=1, 
     return y
 
 
-PANO_PAIR_MAX_T = 256     # nef_pano_h_conv_pair: one 256-column tile per (sample, angle)
+PANO_PAIR_MAX_T = 256     # nef_pano_h_conv_pair: up to here one 256-row tile per (sample, angle); longer sequences in tiles of 252 output rows
 
 
 def pano_h_conv_pair(x, wp1, bias1, scale, wp2, bias2, N, x_div, nq, out=None):
-    """Decoder layers 1 + 2 in one pass (c1 stays on chip): x fp16 [.,Tin,256] -> fp16 [N,2*Tin,128]; 2*Tin <= 256.
+    """Decoder layers 1 + 2 in one pass (c1 stays on chip): x fp16 [.,Tin,256] -> fp16 [N,2*Tin,128].  Up to 256 output rows one tile per
+    pair; longer sequences (round 6) in tiles of 252 output rows with two recomputed slots + one halo row per side.
     `scale` = (tensor, sc_bs, sc_is) as in pano_h_conv."""
     L = _lib.load()
     _chk(x, torch.float16), _chk(bias1), _chk(bias2)
     Tin, Ci = x.shape[1], x.shape[2]
     T = 2 * Tin
-    assert Ci == 256 and T <= PANO_PAIR_MAX_T
+    assert Ci == 256
     y = torch.empty(N, T, 128, device=x.device, dtype=torch.float16) if out is None else out
     sc, sc_bs, sc_is = scale
     e = _timed(("pano_h_conv_pair", N, T))

@@ -40,11 +40,12 @@ def test_from_f32_is_a_rounding_transpose():
     assert torch.equal(y.cpu(), x.transpose(1, 2).to(torch.float16))
 
 
-@pytest.mark.parametrize("T,NB,nq", [(256, 3, 4), (40, 2, 3), (254, 70, 5)])
+@pytest.mark.parametrize("T,NB,nq", [(256, 3, 4), (40, 2, 3), (254, 70, 5), (258, 2, 2), (504, 2, 3), (1000, 3, 2), (2500, 2, 3), (1250, 40, 7)])
 def test_fused_layer_pair_is_bit_identical_to_two_launches(T, NB, nq):
     """nef_pano_h_conv_pair (layers 1 + 2 with c1 on chip) against nef_pano_h_conv twice: same k order per output and
-    the same fp16 rounding of the intermediate, so the bytes must match; more pairs than CUs in the last case, so a
-    block walks several pairs and re-uses its c1 rows."""
+    the same fp16 rounding of the intermediate, so the bytes must match; more pairs than CUs in the third case, so a
+    block walks several pairs and re-uses its c1 rows.  Sequences longer than 256 rows (round 6: configs[4]'s 2500) run in tiles of
+    252 output rows with recomputed halo slots: tile starts, exact multiples, ragged ends, more (pair, tile) items than CUs."""
     o = ops()
     N, Tin = NB * nq, T // 2
     xh = rnd(NB, Tin, 256, seed=11).to(torch.float16).to(DEV)
