@@ -34,14 +34,15 @@ extern "C" {
 typedef void* nef_stream_t;
 
 /* ABI version of this header; bumped on any signature change. */
-int nef_abi_version(void);   /* 18 (round 6: nef_pack_desc + src_mode / src_Cr (polyphase weights synthesized inside the pack), + nef_amax_roll, nef_flatten, nef_regroup_halves, + num_batches_tracked in the three BatchNorm statistics entry points); 17 (round 5: + pro_mode 4 / 8 / 9, nef_poly_weights, nef_poly_fwd_edge, nef_poly_bwd_edge, nef_mix_bwd_shared: polyphase forward / backward-data through the x2 upsampling); 16 (round 5: + nef_set_option / nef_get_option); 15 (round 4: + x_clamped / clamped counters); 14 (round 4: + nef_conv_bwd_weight_h2); 13 (round 4: + nef_pack_weight_h2 / conv args wino = 3 and x_scale: direct convolutions on exact fp16 splits of the fp32 operands); 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
+int nef_abi_version(void);   /* 18 (round 6: nef_pack_desc + src_mode / src_Cr (polyphase weights synthesized inside the pack), + nef_amax_roll, nef_flatten, nef_regroup_halves, nef_step_words, nef_pano_h_conv_tail, + num_batches_tracked in the three BatchNorm statistics entry points, nef_pano_h_conv_pair for any length); 17 (round 5: + pro_mode 4 / 8 / 9, nef_poly_weights, nef_poly_fwd_edge, nef_poly_bwd_edge, nef_mix_bwd_shared: polyphase forward / backward-data through the x2 upsampling); 16 (round 5: + nef_set_option / nef_get_option); 15 (round 4: + x_clamped / clamped counters); 14 (round 4: + nef_conv_bwd_weight_h2); 13 (round 4: + nef_pack_weight_h2 / conv args wino = 3 and x_scale: direct convolutions on exact fp16 splits of the fp32 operands); 12 (round 4: nef_conv_bwd_weight_wino -- the transposed F(3,2) weight gradient -- is gone, nef_conv_bwd_weight_wino4 covers every shape it took; 11, round 3: the K = 7 F(4,.) operand has 13 planes, Winograd operands are laid out as 16-byte vectors; 10: + nef_pano_h_conv_pair) */
 
 /* Kernel-form options of the process (tuning / A-B hooks; every value computes the same results).  Not part of any reference
  * interface: the reference's nn.Conv1d has one form (codes/network/model_nefnet.py:18-21).  Returns the previous value, or
  * NEF_E_SHAPE for an unknown key.  Read by the launches that follow; not meant to be flipped while a hipGraph capture is open. */
 #define NEF_OPT_H2_FORM 1       /* split-fp16 forward / backward-data convolutions (conv args wino = 3): 0 (default) = every wave
                                    stages, multiplies and stores in turn (csrc/conv_h2.hip); 1 = producer and consumer waves in a
-                                   persistent twelve-wave workgroup (csrc/conv_h2p.hip) wherever its shape rules hold -- bit-identical
+                                   persistent twelve-wave workgroup (tools/experiments/conv_h2p.hip; only in libraries built with
+                                   `csrc/build.py --with-experiments`, ignored otherwise) wherever its shape rules hold -- bit-identical
                                    results, measured slower in round 5, kept as the A/B reference */
 #define NEF_OPT_H2P_WGS 2       /* persistent workgroups per CU of that form (default 1: twelve waves fill a CU at 168 registers) */
 int nef_set_option(int key, int value);
@@ -577,12 +578,13 @@ int nef_pano_h_pack_weight(const float* w, void* wp, int Cout, int Cin, nef_stre
 int nef_pano_h_conv(const void* x, const void* wp, const float* bias, const float* scale, void* y, int N, int T, int Cin,
                     int Cout, int pro_mode, int x_div, int nq, int64_t sc_bs, int64_t sc_is, nef_stream_t stream);
  /* nef_pano_h_conv_pair: layers 1 and 2 of the decoder (model_nefnet.py:102-103: Upsample, DoubleConv(256,128)) in one
- * pass for sequences of one tile (T <= 256, T even; L <= 512):
+ * pass (T even; up to 256 output rows one tile per pair, longer sequences -- round 6 -- in tiles of 252 output rows with recomputed
+ * halo slots):
  *   y[n] = ReLU(conv_k3(ReLU(conv_k3(scale[n] * up2(x[n / x_div])) + bias1)) + bias2),  x fp16 [.][T/2][256],
  * y fp16 [N][T][128]; the 128-channel intermediate stays on chip and is rounded to fp16 exactly as the two-call
  * sequence nef_pano_h_conv(pro_mode 3) + nef_pano_h_conv(pro_mode 0) rounds it (bit-identical results). */
 /* nef_pano_h_conv_tail (round 6): layers 3 and 4, the last conv and sigmoid(x/3) of the decoder (model_nefnet.py:104-106, :186) in
- * one pass for sequences of one tile (T <= 512 output rows, T even; L <= 512):
+ * one pass (T even; up to 512 output rows one tile per pair, longer sequences in tiles of 508 output rows with recomputed halo slots):
  *   out[(n/nq)*out_bs + (n%nq)*out_is + t] = sigmoid((conv_k3(ReLU(conv_k3(ReLU(conv_k3(up2(x[n])) + bias3)) + bias4); wout) + bout) / 3),
  * x fp16 [N][T/2][128] (layer 2's output), wp3 / wp4 = nef_pano_h_pack_weight of the folded 128->64 / 64->64 weights, wout fp32
  * [1][64][3].  The two 64-channel intermediates stay on chip, rounded to fp16 exactly as nef_pano_h_conv(pro_mode 2) +
