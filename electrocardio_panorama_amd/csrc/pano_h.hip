@@ -877,11 +877,17 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
     // K = 3 layers + the last conv eat three rows of context per side, of which the row buffers' rows 0 / 513 supply one -- as real
     // halo rows of the upsampled input here, as the convs' zero padding in the one-tile form (base = 0, slot = time).
     constexpr int NOUT = 508;
-    constexpr int CIN = 128, NT = 512, NI = 2;
+#ifndef NEF_PHT_T
+#define NEF_PHT_T 0      // timing-only builds (results wrong): 1 = no matrix instructions in layers 3 / 4, 2 = no epilogues, 4 = no last conv / output, 8 = no fetch + staging, 16 = weight fragments loaded once, 32 = one activation fragment per chunk
+#endif
+    constexpr int CIN = 128, NT = 512, NI = 4;
     constexpr int XROWS = NT + 2;
     constexpr int XBYTES = XROWS * PH_XRS;
 #ifndef NEF_PHT_AD
 #define NEF_PHT_AD 4
+#endif
+#ifndef NEF_PHT_EARLY
+#define NEF_PHT_EARLY 1  // the input rows of a staging pass are fetched one phase ahead, just before the preceding epilogue (see the main loop)
 #endif
     constexpr int AD = NEF_PHT_AD;          // A ring: fragments of AD - 1 k-steps in flight (a divisor of 12; 6 measured slower: 24 B of scratch, 44.5 vs 44.1 ms per sweep)
     static_assert(12 % AD == 0, "the ring position of a k-step must not depend on the chunk");
@@ -891,7 +897,8 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
     float* const Of = (float*)(smem + 2 * XBYTES);      // d0[NT], d2[NT]
     nef_h8* const Af = (nef_h8*)(smem + 2 * XBYTES + 2 * NT * 4);      // the last conv as matrix A fragments: [kq 0..3][hi | lo plane][lane]
 
-    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;  // wave = 32 co x 128 t: 8 waves = 2 (co) x 4 (t)
     const int lo = lane & 31, hi = lane >> 5;
     const int seg = tid & 7, rg = tid >> 3;  // staging: 8-channel segment, group of 8 output rows (0..63)
     const int Tin = T / 2;
@@ -916,13 +923,11 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
         }
     }
 
-    nef_f16acc acc[2][NI];
+    nef_f16acc acc[NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
     nef_h8 hzero;
 #pragma unroll
     for (int e = 0; e < 8; ++e) hzero[e] = (_Float16)0.f;
@@ -935,6 +940,18 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
 
     nef_h8 xr[6];
     int fbase = 0;                            // `base` of the tile held in xr
+    char* const stA = XA + (8 * rg + 1) * PH_XRS + seg * 16;      // this thread's first staged row
+    char* const stB = stA + XBYTES;
+    // rows of the staged tile (base fb_) that hold times -1 and T: the convs' zero padding.  Block-uniform and rare (ragged or first
+    // tiles), so the extra barrier -- the stores above come from other threads -- is free in the common case.
+#define PHT_PAD_ROWS(Xn_, fb_)                                                                                \
+    if ((fb_) + NT > T || (TILED && (fb_) < 0)) {                                                            \
+        __syncthreads();                                                                                      \
+        if (tid < 16) {                                                                                       \
+            const int r_ = (tid >> 3) ? T - (fb_) + 1 : -(fb_);      /* row r holds time fb_ + r - 1 */       \
+            if (r_ >= (TILED ? 0 : 1) && r_ <= NT + 1) *(nef_h8*)((Xn_) + r_ * PH_XRS + seg * 16) = hzero;    \
+        }                                                                                                     \
+    }
     // source rows base / 2 + 4 rg - 1 .. + 4 (clamped: the align_corners=False edge rule) of the 64-channel chunk cc_ of work item w_
 #define PHT_FETCH(w_, cc_)                                                                                    \
     {                                                                                                         \
@@ -950,17 +967,17 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
         }                                                                                                     \
     }
     // blended rows j (of this thread's 8: time fbase + 8 rg + j) -> row buffer; hconv_wide_kernel's arithmetic (0.25 b exact, one fma
-    // rounding).  TILED, j = 8 (J1_ = 9): the two halo rows 0 / 513 (times fbase - 1, fbase + 512) by the first / last row group
+    // rounding).  Rows outside the sequence are NOT masked here (four selects per row on every row of every pair, for rows that exist
+    // only in a ragged last tile): PHT_PAD_ROWS zeroes the two rows that matter -- times -1 and T, the conv's padding -- afterwards.
+    // TILED, j = 8 (J1_ = 9): the two halo rows 0 / 513 (times fbase - 1, fbase + 512) by the first / last row group
 #define PHT_STAGE(Xn_, J0_, J1_)                                                                              \
     {                                                                                                         \
         nef_h8 c75;                                                                                           \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) c75[e] = (_Float16)0.75f;                               \
         _Pragma("unroll") for (int j = (J0_); j < (J1_) && j < 8; ++j) {                                      \
             const nef_h8 a_ = xr[(j >> 1) + 1], b_ = (j & 1) ? xr[(j >> 1) + 2] : xr[j >> 1];                 \
-            nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);                             \
-            const int tau_ = fbase + 8 * rg + j;                                                              \
-            if (tau_ >= T || (TILED && tau_ < 0)) v_ = hzero;                                                 \
-            *(nef_h8*)((Xn_) + (8 * rg + 1 + j) * PH_XRS + seg * 16) = v_;                                    \
+            const nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);                       \
+            *(nef_h8*)(((Xn_) == XA ? stA : stB) + j * PH_XRS) = v_;                                          \
         }                                                                                                     \
         if (TILED && (J1_) > 8 && (rg == 0 || rg == 63)) {                                                    \
             const nef_h8 a_ = rg == 0 ? xr[0] : xr[5], b_ = rg == 0 ? xr[1] : xr[4];                          \
@@ -970,64 +987,86 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
             *(nef_h8*)((Xn_) + (rg == 0 ? 0 : XROWS - 1) * PH_XRS + seg * 16) = v_;                           \
         }                                                                                                     \
     }
+#ifdef NEF_PHT_WREP
+    const int wcopy_ = (blockIdx.x >> 3) % NEF_PHT_WREP;
+    const __amdgpu_buffer_rsrc_t wd3 = nef_rsrc((const char*)wp3 + (size_t)wcopy_ * 69632), wd4 = nef_rsrc((const char*)wp4 + (size_t)wcopy_ * 36864);
+#else
     const __amdgpu_buffer_rsrc_t wd3 = nef_rsrc(wp3), wd4 = nef_rsrc(wp4);
-    const int avoff = lane * 16;
-    nef_h8 a[AD][2];
-    // A fragments of k-step `stage_` (two 1 KB fragments per k-step: 64 output channels)
+#endif
+    const int avoff = lane * 16 + wm * 1024;
+    nef_h8 a[AD];
+    // A fragment of k-step `stage_` (two 1 KB fragments per k-step = 64 output channels; this wave's 32 are fragment wm)
 #define PHT_A(wd_, slot_, stage_)                                                                             \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                          \
-        a[slot_][mi] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(                      \
-            wd_, avoff, (stage_) * 2048 + mi * 1024, 0));
+    if (!(NEF_PHT_T & 16) || (stage_) < 3) a[slot_] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128( \
+        wd_, avoff, (stage_) * 2048, 0));
     // 12 k-steps (3 taps x 4 x 16 channels) of one 64-channel chunk, B fragments at Bp_ + (ni * 32 + tap) * PH_XRS + kq * 32;
     // A of k-step s + AD - 1 from (WDC_, SC_ + .) or, past the chunk, from (WDN_, SN_ + .); FE_: fetch (pair FN_, chunk FC_) at
     // k-step 1; ST_: stage the fetched rows into XN_, one row per k-step, during k-steps 4 .. 11
 #define PHT_STEPS(Bp_, WDC_, SC_, WDN_, SN_, FE_, FN_, FC_, ST_, XN_)                                         \
     {                                                                                                         \
-        nef_h8 b[NI];                                                                                         \
-        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) b[ni] = *(const nef_h8*)((Bp_) + ni * 32 * PH_XRS); \
+        nef_h8 b[2][NI];                                                                                      \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) b[0][ni] = *(const nef_h8*)((Bp_) + ni * 32 * PH_XRS); \
         _Pragma("unroll") for (int s = 0; s < 12; ++s) {                                                      \
             if (s + AD - 1 < 12) {                                                                            \
                 PHT_A(WDC_, (s + AD - 1) % AD, (SC_) + s + AD - 1)                                            \
             } else {                                                                                          \
                 PHT_A(WDN_, (s + AD - 1) % AD, (SN_) + s + AD - 1 - 12)                                       \
             }                                                                                                 \
-            if ((FE_) && s == 1) PHT_FETCH(FN_, FC_)                                                          \
+            /* the B fragments of k-step s + 1 go out a whole k-step ahead (behind the staging store they were read one matrix */ \
+            /* instruction ahead and every k-step opened on a full LDS round trip) */                        \
+            if (s + 1 < 12 && !(NEF_PHT_T & 32))                                                              \
+                _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                             \
+                    b[(s + 1) & 1][ni] = *(const nef_h8*)((Bp_) + (ni * 32 + (s + 1) / 4) * PH_XRS + ((s + 1) % 4) * 32); \
+            if ((FE_) && !NEF_PHT_EARLY && s == 1 && !(NEF_PHT_T & 8)) PHT_FETCH(FN_, FC_)                   \
             __builtin_amdgcn_sched_barrier(0);                                                                \
-            if ((ST_) && s >= 4) PHT_STAGE(XN_, s - 4, s - 3)                                                 \
-            if ((ST_) && TILED && s == 11) PHT_STAGE(XN_, 8, 9)                                               \
+            if ((ST_) && s >= 4 && !(NEF_PHT_T & 8)) PHT_STAGE(XN_, s - 4, s - 3)                             \
+            if ((ST_) && TILED && s == 11 && !(NEF_PHT_T & 8)) PHT_STAGE(XN_, 8, 9)                           \
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
-                _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                              \
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % AD][mi], b[ni], acc[mi][ni], 0, 0, 0); \
-                if (s + 1 < 12)                                                                               \
-                    b[ni] = *(const nef_h8*)((Bp_) + (ni * 32 + (s + 1) / 4) * PH_XRS + ((s + 1) % 4) * 32);  \
+                if (!(NEF_PHT_T & 1)) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % AD], b[s & 1][ni], acc[ni], 0, 0, 0); \
+                else acc[ni][0] += (float)a[s % AD][0] * (float)b[s & 1][ni][0];                              \
             }                                                                                                 \
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                            \
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
-                __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                                           \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                            \
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                            \
             }                                                                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                                \
         }                                                                                                     \
     }
-    // accumulators -> bias + ReLU -> fp16 rows of buffer B (row 1 + slot); ZERO_: slots outside the sequence are the next conv's padding
-#define PHT_TO_LDS(bias_, ZERO_)                                                                              \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                          \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                       \
-            const int co = mi * 32 + 8 * g + 4 * hi;                                                          \
-            const nef_f32x4 bv = *(const nef_f32x4*)((bias_) + co);                                           \
-            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
-                const int t = wn * 64 + ni * 32 + lo;                                                         \
-                nef_h4 o;                                                                                     \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-                    o[e] = ((ZERO_) && (base + t >= T || (TILED && base + t < 0))) ? (_Float16)0.f                    \
-                                                                                   : (_Float16)fmaxf(acc[mi][ni][g * 4 + e] + bv[e], 0.f); \
-                    acc[mi][ni][g * 4 + e] = 0.f;                                                             \
-                }                                                                                             \
-                *(nef_h4*)(XB + (1 + t) * PH_XRS + co * 2) = o;                                               \
+    // accumulators -> bias + ReLU -> fp16 rows of buffer B (row 1 + slot): two packed adds, two packed converts (round to nearest even,
+    // as v_cvt_f16_f32) and two packed max per four values -- round 6 first half: 19 vector instructions per four (per-value add, max,
+    // convert, select, pack).  Slots outside the sequence (the next conv's zero padding, zero weight in the last conv) are zeroed
+    // afterwards by PHT_ZERO_SLOTS instead of selected per value.
+#define PHT_TO_LDS(bv_)                                                                                       \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                           \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                   \
+            nef_f32x4 v_;                                                                                     \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
+                v_[e] = acc[ni][g * 4 + e];                                                                   \
+                acc[ni][g * 4 + e] = 0.f;                                                                     \
             }                                                                                                 \
-        }
+            const nef_h4 z_ = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};                   \
+            const nef_h4 o = __builtin_elementwise_max(__builtin_convertvector(v_ + (bv_)[g], nef_h4), z_);   \
+            if (!(NEF_PHT_T & 2) || o[0] == (_Float16)12345.f) *(nef_h4*)(eb + ni * 32 * PH_XRS + g * 16) = o; \
+        }                                                                                                     \
+    }
+    // slots t of buffer B with base + t outside [0, T): rows 1 + t -> 0 (block-uniform, ragged / first tiles only)
+#define PHT_ZERO_SLOTS()                                                                                      \
+    if (base + NT > T || (TILED && base < 0)) {                                                               \
+        __syncthreads();                                                                                      \
+        _Pragma("unroll 1") for (int r_ = rg; r_ < NT; r_ += 64)                                              \
+            if (base + r_ >= T || base + r_ < 0) *(nef_h8*)(XB + (1 + r_) * PH_XRS + seg * 16) = hzero;       \
+    }
 
+    // the biases of this wave's 32 output channels, once (a load inside the epilogue would also wait -- memory returns in order -- for
+    // the input rows fetched just ahead of it)
+    nef_f32x4 bv3[4], bv4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bv3[g] = *(const nef_f32x4*)(bias3 + wm * 32 + 8 * g + 4 * hi);
+        bv4[g] = *(const nef_f32x4*)(bias4 + wm * 32 + 8 * g + 4 * hi);
+    }
+    char* const eb = XB + (1 + wn * 128 + lo) * PH_XRS + (wm * 32 + 4 * hi) * 2;      // epilogue rows: + ni 32 rows + g 16 bytes
     const int total = TILED ? N * tiles_per_n : N;      // work items: (pair, tile)
     int w = blockIdx.x;
 #pragma unroll
@@ -1035,6 +1074,8 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
     if (w < total) {
         PHT_FETCH(w, 0)
         PHT_STAGE(XA, 0, 9)
+        PHT_PAD_ROWS(XA, fbase)
+        if (NEF_PHT_EARLY) PHT_FETCH(w, 1)
     }
     __syncthreads();
     const float b0 = bout[0];
@@ -1044,49 +1085,59 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
         const int n = TILED ? w / tiles_per_n : w;
         const int base = TILED ? (w % tiles_per_n) * NOUT - 2 : 0;      // time of slot 0
         const int n_next = w + (int)gridDim.x < total ? w + (int)gridDim.x : w;   // last item: re-stage itself (unread)
-        const char* const BA = XA + (wn * 64 + lo) * PH_XRS + 16 * hi;
-        const char* const BB = XB + (wn * 64 + lo) * PH_XRS + 16 * hi;
+        const char* const BA = XA + (wn * 128 + lo) * PH_XRS + 16 * hi;
+        const char* const BB = XB + (wn * 128 + lo) * PH_XRS + 16 * hi;
         // ---- layer 3: chunk 0 from buffer A while chunk 1 is fetched and staged into buffer B, then chunk 1
         PHT_STEPS(BA, wd3, 0, wd3, 12, true, w, 1, true, XB)
+        PHT_PAD_ROWS(XB, base)
         __syncthreads();
         PHT_STEPS(BB, wd3, 12, wd4, 0, false, w, 0, false, XB)
+        // Memory returns in issue order: a weight fragment issued behind these rows cannot be consumed before they have arrived.  Issued
+        // here the rows have the epilogue and AD - 1 k-steps to come from HBM; issued at k-step 1 of the staging phase (rounds 2-5)
+        // they had AD k-steps, and the matrix pipes waited for them.
+        if (NEF_PHT_EARLY && !(NEF_PHT_T & 8)) PHT_FETCH(n_next, 0)
         __syncthreads();                     // every wave is done reading buffer B as an input chunk
-        PHT_TO_LDS(bias3, true)
+        PHT_TO_LDS(bv3)
+        PHT_ZERO_SLOTS()
         __syncthreads();                     // c3 complete
         // ---- layer 4: straight from the c3 rows; the next pair's first chunk rides along into buffer A
         PHT_STEPS(BB, wd4, 0, wd3, 0, true, n_next, 0, true, XA)
+        PHT_PAD_ROWS(XA, fbase)              // (fbase: the next item's tile)
+        if (NEF_PHT_EARLY && !(NEF_PHT_T & 8)) PHT_FETCH(n_next, 1)      // for the next item's first phase
         __syncthreads();                     // every wave is done reading c3; buffer A holds the next pair's chunk 0
-        PHT_TO_LDS(bias4, true)              // (rows t >= T zero: their share of the last conv is zero)
+        PHT_TO_LDS(bv4)
+        PHT_ZERO_SLOTS()                     // (rows outside the sequence zero: their share of the last conv is zero)
         __syncthreads();                     // c4 staged
-        // ---- last conv on the matrix cores: rows 0..2 of the product are d0, d1, d2 of column t = wn 64 + ni 32 + lo (lanes hi = 0)
-        {
+        // ---- last conv on the matrix cores: rows 0..2 of the product are d0, d1, d2 of column t (lanes hi = 0); the two waves of
+        // a 128-column stripe take 64 columns each: t = wn 128 + wm 64 + ni 32 + lo
+        if (!(NEF_PHT_T & 4)) {
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
                 const nef_h8 ah = Af[(kq * 2 + 0) * 64 + lane], al = Af[(kq * 2 + 1) * 64 + lane];
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const nef_h8 bq = *(const nef_h8*)(XB + (1 + wn * 64 + ni * 32 + lo) * PH_XRS + kq * 32 + 16 * hi);
-                    acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq, acc[0][ni], 0, 0, 0);
-                    acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq, acc[0][ni], 0, 0, 0);
+                for (int ni = 0; ni < 2; ++ni) {
+                    const nef_h8 bq = *(const nef_h8*)(XB + (1 + wn * 128 + wm * 64 + ni * 32 + lo) * PH_XRS + kq * 32 + 16 * hi);
+                    acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq, acc[ni], 0, 0, 0);
+                    acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq, acc[ni], 0, 0, 0);
                 }
             }
-            float d1[NI];
+            float d1[2];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int t = wn * 64 + ni * 32 + lo;
-                d1[ni] = acc[0][ni][1];
+            for (int ni = 0; ni < 2; ++ni) {
+                const int t = wn * 128 + wm * 64 + ni * 32 + lo;
+                d1[ni] = acc[ni][1];
                 if (hi == 0) {
-                    Of[t] = acc[0][ni][0];          // tap 0 weights this row into column t + 1
-                    Of[NT + t] = acc[0][ni][2];     // tap 2 into column t - 1
+                    Of[t] = acc[ni][0];          // tap 0 weights this row into column t + 1
+                    Of[NT + t] = acc[ni][2];     // tap 2 into column t - 1
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[0][ni][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
             }
             __syncthreads();           // (also: every wave is done reading c4 -- buffer B is free for the next pair's chunk 1)
             if (hi == 0) {
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int t = wn * 64 + ni * 32 + lo;
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int t = wn * 128 + wm * 64 + ni * 32 + lo;
                     // slot t is time base + t; a tile of the TILED form owns slots 2 .. 509 (the others lack context)
                     if (base + t < T && (!TILED || (t >= 2 && t < 2 + NOUT))) {
                         const float s_ = d1[ni] + (t > 0 ? Of[t - 1] : 0.f) + (t < NT - 1 ? Of[NT + t + 1] : 0.f);
@@ -1102,6 +1153,8 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
 #undef PHT_A
 #undef PHT_STEPS
 #undef PHT_TO_LDS
+#undef PHT_ZERO_SLOTS
+#undef PHT_PAD_ROWS
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1280,6 +1333,17 @@ static int launch_hconv_tail(const void* x, const void* wp3, const float* b3, co
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
         __atomic_store_n(&cus_dev[dev & 63], cus, __ATOMIC_RELEASE);
     }
+#ifdef NEF_PHT_WREP
+    {   // experiment: NEF_PHT_WREP copies of the weights, each one L2 channel (4 KB) further on
+        static char* rep_ = nullptr;
+        if (!rep_ && hipMalloc((void**)&rep_, 16 * (69632 + 36864)) != hipSuccess) return NEF_E_SHAPE;
+        for (int c = 0; c < NEF_PHT_WREP; ++c) {
+            hipMemcpyAsync(rep_ + (size_t)c * 69632, wp3, 49152, hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(rep_ + 16 * 69632 + (size_t)c * 36864, wp4, 24576, hipMemcpyDeviceToDevice, st);
+        }
+        wp3 = rep_; wp4 = rep_ + 16 * 69632;
+    }
+#endif
     if (T <= 512) {      // one tile per pair
         hipLaunchKernelGGL(hconv_tail_kernel<false>, dim3(N < cus ? N : cus), dim3(512), LDS, st, (const _Float16*)x, (const nef_h8*)wp3, b3,
                            (const nef_h8*)wp4, b4, wout, bout, out, T, N, nq, out_bs, out_is, 1);
