@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void hconv_wide_kernel(const _Float16* __re
 //   written to nor read from memory (2 x 64 KB per pair), layer 2 needs no staging and no barrier inside its 24 k-steps.
 //   block   = 512 threads = 8 waves (2 per SIMD), one pair at a time, persistent, 1 block per CU:
 //             LDS = two X buffers (74 KB) + the c1 tile (70 KB)
-//   wave    = 64 co x 64 t (2 x 2 accumulator tiles) in both layers; 8 waves = 2 (co) x 4 (t)
+//   wave    = 32 co x 128 t (four accumulator tiles) in both layers; 8 waves = 4 (co) x 2 (t)
 //   A       = weight fragments from L2 in a ring of AD k-steps that runs on across chunks, layers and pairs
 //   layer 1 = hconv_wide_kernel's scheme (double-buffered 64-channel chunks, staging pieces among the MFMAs); the
 //             next pair's first chunk is fetched and staged during layer 2
@@ -654,26 +654,28 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
     // (even: the x2 blend's row parity is that of the one-tile form); rows 0 / 257 of the X buffers hold real halo rows of the scaled,
     // upsampled input there and the conv's zero padding in the one-tile form (base = 0, slot = time).
     constexpr int NOUT = 252;
-    constexpr int CIN = 256, COUT = 128, NT = 256, NI = 2;
+    constexpr int CIN = 256, COUT = 128, NT = 256, NI = 4;
     constexpr int XROWS = NT + 2;
     constexpr int XBYTES = XROWS * PH_XRS;
-    constexpr int AD = 4;
+#ifndef NEF_PHP_AD
+#define NEF_PHP_AD 6
+#endif
+    constexpr int AD = NEF_PHP_AD;           // A ring: fragments of AD - 1 k-steps in flight (a divisor of 12)
+    static_assert(12 % AD == 0, "the ring position of a k-step must not depend on the chunk");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const C1 = smem + 2 * XBYTES;      // [258][PHP_CRS]: row r = time r - 1
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave & 3, wn = wave >> 2;  // wave = 32 co x 128 t (four accumulator tiles) in both layers: 8 waves = 4 (co) x 2 (t)
     const int lo = lane & 31, hi = lane >> 5;
     const int seg = tid & 7, rg = tid >> 3;  // staging: 8-channel segment, group of 4 output rows (0..63)
     const int Tin = T / 2;
 
-    nef_f16acc acc[2][NI];
+    nef_f16acc acc[NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
     nef_h8 hzero;
 #pragma unroll
     for (int e = 0; e < 8; ++e) hzero[e] = (_Float16)0.f;
@@ -689,9 +691,9 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
         *(nef_h8*)(C1 + r * PHP_CRS + (tid & 15) * 16) = hzero;
     }
 
-    nef_h8 xr[4];
-    float qr[8];
+    nef_h8 xr[4], qh;
     int fbase = 0;                            // `base` of the tile held in xr
+    char* const st0 = smem + (4 * rg + 1) * PH_XRS + seg * 16;      // this thread's first staged row, buffer 0
     // source rows base / 2 + 2 rg - 1 .. + 2 (clamped to the sequence: the align_corners=False edge rule) of chunk cc_ of work item w_
 #define PHP_FETCH(w_, cc_)                                                                                    \
     {                                                                                                         \
@@ -708,96 +710,108 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
         const float* sc_ = scale + (size_t)((n_) / nq) * sc_bs + (size_t)((n_) % nq) * sc_is + (cc_) * 64;    \
         const __amdgpu_buffer_rsrc_t sd_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sc_), 0, 256, 0x00020000); \
         const nef_f32x4 q0_ = nef_buf_f32x4(sd_, seg * 32, 0), q1_ = nef_buf_f32x4(sd_, seg * 32 + 16, 0);    \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) { qr[e] = q0_[e]; qr[4 + e] = q1_[e]; }                 \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) { qh[e] = (_Float16)q0_[e]; qh[4 + e] = (_Float16)q1_[e]; } \
     }
-    // blended rows j (of this thread's 4: time fbase + 4 rg + j) -> X buffer; same arithmetic as hconv_wide_kernel.  TILED, j = 4
+    // blended, scaled rows j (of this thread's 4: time fbase + 4 rg + j) -> X buffer BUF_; same arithmetic as hconv_wide_kernel.  Rows
+    // outside the sequence are not masked here (four selects per row, on every row of every pair, for rows that only a ragged last
+    // tile has): PHP_PAD_ROWS zeroes the two that matter -- times -1 and T, the conv's padding -- afterwards.  TILED, j = 4
     // (J1_ = 5): the two halo rows 0 / 257 (times fbase - 1, fbase + 256) by the first / last row group
-#define PHP_STAGE(Xn_, J0_, J1_)                                                                              \
+#define PHP_STAGE(BUF_, J0_, J1_)                                                                             \
     {                                                                                                         \
-        nef_h8 qh, c75;                                                                                       \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) { c75[e] = (_Float16)0.75f; qh[e] = (_Float16)qr[e]; }  \
+        nef_h8 c75;                                                                                           \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) c75[e] = (_Float16)0.75f;                               \
         _Pragma("unroll") for (int j = (J0_); j < (J1_) && j < 4; ++j) {                                      \
             const nef_h8 a_ = xr[(j >> 1) + 1], b_ = (j & 1) ? xr[(j >> 1) + 2] : xr[j >> 1];                 \
-            nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);                             \
-            v_ = v_ * qh;                                                                                     \
-            const int tau_ = fbase + 4 * rg + j;                                                              \
-            if (tau_ >= T || (TILED && tau_ < 0)) v_ = hzero;                                                 \
-            *(nef_h8*)((Xn_) + (4 * rg + 1 + j) * PH_XRS + seg * 16) = v_;                                    \
+            const nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f) * qh;                  \
+            *(nef_h8*)(st0 + (BUF_) * XBYTES + j * PH_XRS) = v_;                                              \
         }                                                                                                     \
         if (TILED && (J1_) > 4 && (rg == 0 || rg == 63)) {                                                    \
             const nef_h8 a_ = rg == 0 ? xr[0] : xr[3], b_ = rg == 0 ? xr[1] : xr[2];                          \
-            nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f);                            \
-            v_ = v_ * qh;                                                                                     \
+            nef_h8 v_ = __builtin_elementwise_fma(a_, c75, b_ * (_Float16)0.25f) * qh;                        \
             const int tau_ = rg == 0 ? fbase - 1 : fbase + NT;                                                \
             if (tau_ >= T || tau_ < 0) v_ = hzero;                                                            \
-            *(nef_h8*)((Xn_) + (rg == 0 ? 0 : XROWS - 1) * PH_XRS + seg * 16) = v_;                           \
+            *(nef_h8*)(smem + (BUF_) * XBYTES + (rg == 0 ? 0 : XROWS - 1) * PH_XRS + seg * 16) = v_;          \
+        }                                                                                                     \
+    }
+    // rows of the staged tile (base fb_) that hold times -1 and T.  Block-uniform and rare (ragged or first tiles), so the extra
+    // barrier -- the rows were stored by other threads -- costs nothing in the common case.
+#define PHP_PAD_ROWS(BUF_, fb_)                                                                               \
+    if ((fb_) + NT > T || (TILED && (fb_) < 0)) {                                                             \
+        __syncthreads();                                                                                      \
+        if (tid < 16) {                                                                                       \
+            const int r_ = (tid >> 3) ? T - (fb_) + 1 : -(fb_);      /* row r holds time fb_ + r - 1 */       \
+            if (r_ >= (TILED ? 0 : 1) && r_ <= NT + 1) *(nef_h8*)(smem + (BUF_) * XBYTES + r_ * PH_XRS + seg * 16) = hzero; \
         }                                                                                                     \
     }
     const __amdgpu_buffer_rsrc_t wd1 = nef_rsrc(wp1), wd2 = nef_rsrc(wp2);
-    const int avoff = lane * 16 + wm * 2048;
-    nef_h8 a[AD][2];
+    const int avoff = lane * 16 + wm * 1024;
+    nef_h8 a[AD];
+    // A fragment of k-step `stage_` (four 1 KB fragments per k-step = 128 output channels; this wave's 32 are fragment wm)
 #define PHP_A(wd_, slot_, stage_)                                                                             \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                          \
-        a[slot_][mi] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(                      \
-            wd_, avoff, (stage_) * 4096 + mi * 1024, 0));
-    // 12 k-steps (3 taps x 4 x 16 channels) of one 64-channel chunk: B fragments at Bp_ + (ni*32 + tap) * PITCH_ + kq*32;
-    // A of k-step s + AD - 1 comes from (WDC_, stage SC_ + .) or, past the chunk, from (WDN_, stage SN_ + .);
-    // FE_: fetch (pair, chunk) for the staging at k-step 1; ST_: stage into XN_ during k-steps 6..9
-#define PHP_STEPS(Bp_, PITCH_, WDC_, SC_, WDN_, SN_, FE_, FN_, FC_, ST_, XN_)                                 \
+    a[slot_] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(wd_, avoff, (stage_) * 4096, 0));
+    // 12 k-steps (3 taps x 4 x 16 channels) of one 64-channel chunk: B fragments at Bp_ + (ni*32 + tap) * PITCH_ + kq*32, read a whole
+    // k-step ahead; A of k-step s + AD - 1 comes from (WDC_, stage SC_ + .) or, past the chunk, from (WDN_, stage SN_ + .);
+    // FE_: fetch (pair, chunk) for the staging at k-step 1; ST_: stage into buffer BUF_ during k-steps 6..9
+#define PHP_STEPS(Bp_, PITCH_, WDC_, SC_, WDN_, SN_, FE_, FN_, FC_, ST_, BUF_)                                \
     {                                                                                                         \
-        nef_h8 b[NI];                                                                                         \
-        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) b[ni] = *(const nef_h8*)((Bp_) + ni * 32 * (PITCH_)); \
+        nef_h8 b[2][NI];                                                                                      \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) b[0][ni] = *(const nef_h8*)((Bp_) + ni * 32 * (PITCH_)); \
         _Pragma("unroll") for (int s = 0; s < 12; ++s) {                                                      \
             if (s + AD - 1 < 12) {                                                                            \
                 PHP_A(WDC_, (s + AD - 1) % AD, (SC_) + s + AD - 1)                                            \
             } else {                                                                                          \
                 PHP_A(WDN_, (s + AD - 1) % AD, (SN_) + s + AD - 1 - 12)                                       \
             }                                                                                                 \
+            if (s + 1 < 12)                                                                                   \
+                _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                             \
+                    b[(s + 1) & 1][ni] = *(const nef_h8*)((Bp_) + (ni * 32 + (s + 1) / 4) * (PITCH_) + ((s + 1) % 4) * 32); \
             if ((FE_) && s == 1) PHP_FETCH(FN_, FC_)                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                                \
-            if ((ST_) && s >= 6 && s <= 9) PHP_STAGE(XN_, s - 6, s - 5)                                       \
-            if ((ST_) && TILED && s == 10) PHP_STAGE(XN_, 4, 5)                                               \
+            if ((ST_) && s >= 6 && s <= 9) PHP_STAGE(BUF_, s - 6, s - 5)                                      \
+            if ((ST_) && TILED && s == 10) PHP_STAGE(BUF_, 4, 5)                                              \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                 \
+                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % AD], b[s & 1][ni], acc[ni], 0, 0, 0);  \
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
-                _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                              \
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % AD][mi], b[ni], acc[mi][ni], 0, 0, 0); \
-                if (s + 1 < 12)                                                                               \
-                    b[ni] = *(const nef_h8*)((Bp_) + (ni * 32 + (s + 1) / 4) * (PITCH_) + ((s + 1) % 4) * 32); \
-            }                                                                                                 \
-            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                            \
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
-                __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                                           \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                            \
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                            \
             }                                                                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                                \
         }                                                                                                     \
     }
-    // accumulators -> bias + ReLU -> fp16 rows of the c1 region (row 1 + t); ZERO_: rows t >= T are the next conv's padding
-#define PHP_TO_LDS(bias_, ZERO_)                                                                              \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                          \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                       \
-            const int co = wm * 64 + mi * 32 + 8 * g + 4 * hi;                                                \
-            const nef_f32x4 bv = *(const nef_f32x4*)((bias_) + co);                                           \
-            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
-                const int t = wn * 64 + ni * 32 + lo;                                                         \
-                nef_h4 o;                                                                                     \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-                    o[e] = ((ZERO_) && (base + t >= T || (TILED && base + t < 0))) ? (_Float16)0.f                    \
-                                                                                   : (_Float16)fmaxf(acc[mi][ni][g * 4 + e] + bv[e], 0.f); \
-                    acc[mi][ni][g * 4 + e] = 0.f;                                                             \
-                }                                                                                             \
-                *(nef_h4*)(C1 + (1 + t) * PHP_CRS + co * 2) = o;                                              \
+    // accumulators -> bias + ReLU -> fp16 rows of the c1 region (row 1 + slot): two packed adds, two packed converts (round to nearest
+    // even, as v_cvt_f16_f32) and two packed max per four values (rounds 2-5: 19 vector instructions per four)
+#define PHP_TO_LDS(bv_)                                                                                       \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                           \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                   \
+            nef_f32x4 v_;                                                                                     \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
+                v_[e] = acc[ni][g * 4 + e];                                                                   \
+                acc[ni][g * 4 + e] = 0.f;                                                                     \
             }                                                                                                 \
-        }
+            const nef_h4 z_ = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};                   \
+            *(nef_h4*)(eb + ni * 32 * PHP_CRS + g * 16) =                                                     \
+                __builtin_elementwise_max(__builtin_convertvector(v_ + (bv_)[g], nef_h4), z_);                \
+        }                                                                                                     \
+    }
 
+    // the biases of this wave's 32 output channels, once (a load inside the epilogue would also wait -- memory returns in order -- for
+    // whatever was issued ahead of it)
+    nef_f32x4 bv1[4], bv2[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bv1[g] = *(const nef_f32x4*)(bias1 + wm * 32 + 8 * g + 4 * hi);
+        bv2[g] = *(const nef_f32x4*)(bias2 + wm * 32 + 8 * g + 4 * hi);
+    }
+    char* const eb = C1 + (1 + wn * 128 + lo) * PHP_CRS + (wm * 32 + 4 * hi) * 2;      // epilogue rows: + ni 32 rows + g 16 bytes
     const int total = TILED ? N * tiles_per_n : N;      // work items: (pair, tile)
     int w = blockIdx.x;
-    PHP_A(wd1, 0, 0)
-    PHP_A(wd1, 1, 1)
-    PHP_A(wd1, 2, 2)
+#pragma unroll
+    for (int j = 0; j < AD - 1; ++j) PHP_A(wd1, j, j)
     if (w < total) {
         PHP_FETCH(w, 0)
-        PHP_STAGE(smem, 0, 5)
+        PHP_STAGE(0, 0, 5)
+        PHP_PAD_ROWS(0, fbase)
     }
     __syncthreads();
 
@@ -809,25 +823,33 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
         // ---- layer 1: four 64-channel chunks, buffers 0 1 0 1; chunk cc + 1 staged during chunk cc
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-            const char* Bp = smem + (cc & 1) * XBYTES + (wn * 64 + lo) * PH_XRS + 16 * hi;
-            char* Xn = smem + ((cc + 1) & 1) * XBYTES;
+            const char* Bp = smem + (cc & 1) * XBYTES + (wn * 128 + lo) * PH_XRS + 16 * hi;
             if (cc < 3) {
-                PHP_STEPS(Bp, PH_XRS, wd1, cc * 12, wd1, (cc + 1) * 12, true, w, cc + 1, true, Xn)
+                PHP_STEPS(Bp, PH_XRS, wd1, cc * 12, wd1, (cc + 1) * 12, true, w, cc + 1, true, (cc + 1) & 1)
+                PHP_PAD_ROWS((cc + 1) & 1, base)
             } else {
-                PHP_STEPS(Bp, PH_XRS, wd1, cc * 12, wd2, 0, false, w, 0, false, Xn)
+                PHP_STEPS(Bp, PH_XRS, wd1, cc * 12, wd2, 0, false, w, 0, false, 0)
             }
             __syncthreads();
         }
-        PHP_TO_LDS(bias1, true)
+        PHP_TO_LDS(bv1)
+        // slots of c1 outside the sequence are the next conv's zero padding (block-uniform: ragged / first tiles only)
+        if (base + NT > T || (TILED && base < 0)) {
+            __syncthreads();
+#pragma unroll 1
+            for (int r_ = tid >> 4; r_ < NT; r_ += 32)
+                if (base + r_ >= T || base + r_ < 0) *(nef_h8*)(C1 + (1 + r_) * PHP_CRS + (tid & 15) * 16) = hzero;
+        }
         __syncthreads();                     // c1 complete
         // ---- layer 2: two 64-channel chunks straight from the c1 rows; the next pair's first X chunk rides along
         {
-            const char* Bp = C1 + (wn * 64 + lo) * PHP_CRS + 16 * hi;
-            PHP_STEPS(Bp, PHP_CRS, wd2, 0, wd2, 12, false, w, 0, false, smem)
-            PHP_STEPS(Bp + 128, PHP_CRS, wd2, 12, wd1, 0, true, n_next, 0, true, smem)
+            const char* Bp = C1 + (wn * 128 + lo) * PHP_CRS + 16 * hi;
+            PHP_STEPS(Bp, PHP_CRS, wd2, 0, wd2, 12, false, w, 0, false, 0)
+            PHP_STEPS(Bp + 128, PHP_CRS, wd2, 12, wd1, 0, true, n_next, 0, true, 0)
+            PHP_PAD_ROWS(0, fbase)           // (fbase: the next item's tile)
         }
         __syncthreads();                     // every wave is done reading c1; X chunk 0 of the next pair is staged
-        PHP_TO_LDS(bias2, false)
+        PHP_TO_LDS(bv2)
         __syncthreads();
         _Float16* yb = y + (size_t)n * T * COUT;
 #pragma unroll
@@ -841,6 +863,7 @@ __global__ __launch_bounds__(512, 1) void hconv_pair_kernel(const _Float16* __re
     }
 #undef PHP_FETCH
 #undef PHP_STAGE
+#undef PHP_PAD_ROWS
 #undef PHP_A
 #undef PHP_STEPS
 #undef PHP_TO_LDS
@@ -884,12 +907,12 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
     constexpr int XROWS = NT + 2;
     constexpr int XBYTES = XROWS * PH_XRS;
 #ifndef NEF_PHT_AD
-#define NEF_PHT_AD 4
+#define NEF_PHT_AD 6
 #endif
 #ifndef NEF_PHT_EARLY
 #define NEF_PHT_EARLY 1  // the input rows of a staging pass are fetched one phase ahead, just before the preceding epilogue (see the main loop)
 #endif
-    constexpr int AD = NEF_PHT_AD;          // A ring: fragments of AD - 1 k-steps in flight (a divisor of 12; 6 measured slower: 24 B of scratch, 44.5 vs 44.1 ms per sweep)
+    constexpr int AD = NEF_PHT_AD;          // A ring: fragments of AD - 1 k-steps in flight (a divisor of 12; one 1 KB fragment per k-step and wave: 6 = 24 registers)
     static_assert(12 % AD == 0, "the ring position of a k-step must not depend on the chunk");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const XA = smem;
