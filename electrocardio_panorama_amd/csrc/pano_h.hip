@@ -900,9 +900,6 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
     // K = 3 layers + the last conv eat three rows of context per side, of which the row buffers' rows 0 / 513 supply one -- as real
     // halo rows of the upsampled input here, as the convs' zero padding in the one-tile form (base = 0, slot = time).
     constexpr int NOUT = 508;
-#ifndef NEF_PHT_T
-#define NEF_PHT_T 0      // timing-only builds (results wrong): 1 = no matrix instructions in layers 3 / 4, 2 = no epilogues, 4 = no last conv / output, 8 = no fetch + staging, 16 = weight fragments loaded once, 32 = one activation fragment per chunk
-#endif
     constexpr int CIN = 128, NT = 512, NI = 4;
     constexpr int XROWS = NT + 2;
     constexpr int XBYTES = XROWS * PH_XRS;
@@ -917,8 +914,8 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const XA = smem;
     char* const XB = smem + XBYTES;           // layer 3's second chunk, then c3, then c4: row r = time r - 1
-    float* const Of = (float*)(smem + 2 * XBYTES);      // d0[NT], d2[NT]
-    nef_h8* const Af = (nef_h8*)(smem + 2 * XBYTES + 2 * NT * 4);      // the last conv as matrix A fragments: [kq 0..3][hi | lo plane][lane]
+    float* const Of = (float*)(smem + 2 * XBYTES);      // d0[NT], d2[NT], d1[NT]
+    nef_h8* const Af = (nef_h8*)(smem + 2 * XBYTES + 3 * NT * 4);      // the last conv as matrix A fragments: [kq 0..3][hi | lo plane][lane]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;  // wave = 32 co x 128 t: 8 waves = 2 (co) x 4 (t)
@@ -1010,18 +1007,12 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
             *(nef_h8*)((Xn_) + (rg == 0 ? 0 : XROWS - 1) * PH_XRS + seg * 16) = v_;                           \
         }                                                                                                     \
     }
-#ifdef NEF_PHT_WREP
-    const int wcopy_ = (blockIdx.x >> 3) % NEF_PHT_WREP;
-    const __amdgpu_buffer_rsrc_t wd3 = nef_rsrc((const char*)wp3 + (size_t)wcopy_ * 69632), wd4 = nef_rsrc((const char*)wp4 + (size_t)wcopy_ * 36864);
-#else
     const __amdgpu_buffer_rsrc_t wd3 = nef_rsrc(wp3), wd4 = nef_rsrc(wp4);
-#endif
     const int avoff = lane * 16 + wm * 1024;
     nef_h8 a[AD];
     // A fragment of k-step `stage_` (two 1 KB fragments per k-step = 64 output channels; this wave's 32 are fragment wm)
 #define PHT_A(wd_, slot_, stage_)                                                                             \
-    if (!(NEF_PHT_T & 16) || (stage_) < 3) a[slot_] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128( \
-        wd_, avoff, (stage_) * 2048, 0));
+    a[slot_] = __builtin_bit_cast(nef_h8, __builtin_amdgcn_raw_buffer_load_b128(wd_, avoff, (stage_) * 2048, 0));
     // 12 k-steps (3 taps x 4 x 16 channels) of one 64-channel chunk, B fragments at Bp_ + (ni * 32 + tap) * PH_XRS + kq * 32;
     // A of k-step s + AD - 1 from (WDC_, SC_ + .) or, past the chunk, from (WDN_, SN_ + .); FE_: fetch (pair FN_, chunk FC_) at
     // k-step 1; ST_: stage the fetched rows into XN_, one row per k-step, during k-steps 4 .. 11
@@ -1037,16 +1028,15 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
             }                                                                                                 \
             /* the B fragments of k-step s + 1 go out a whole k-step ahead (behind the staging store they were read one matrix */ \
             /* instruction ahead and every k-step opened on a full LDS round trip) */                        \
-            if (s + 1 < 12 && !(NEF_PHT_T & 32))                                                              \
+            if (s + 1 < 12)                                                                                   \
                 _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                             \
                     b[(s + 1) & 1][ni] = *(const nef_h8*)((Bp_) + (ni * 32 + (s + 1) / 4) * PH_XRS + ((s + 1) % 4) * 32); \
-            if ((FE_) && !NEF_PHT_EARLY && s == 1 && !(NEF_PHT_T & 8)) PHT_FETCH(FN_, FC_)                   \
+            if ((FE_) && !NEF_PHT_EARLY && s == 1) PHT_FETCH(FN_, FC_)                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                \
-            if ((ST_) && s >= 4 && !(NEF_PHT_T & 8)) PHT_STAGE(XN_, s - 4, s - 3)                             \
-            if ((ST_) && TILED && s == 11 && !(NEF_PHT_T & 8)) PHT_STAGE(XN_, 8, 9)                           \
+            if ((ST_) && s >= 4) PHT_STAGE(XN_, s - 4, s - 3)                                                 \
+            if ((ST_) && TILED && s == 11) PHT_STAGE(XN_, 8, 9)                                               \
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
-                if (!(NEF_PHT_T & 1)) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % AD], b[s & 1][ni], acc[ni], 0, 0, 0); \
-                else acc[ni][0] += (float)a[s % AD][0] * (float)b[s & 1][ni][0];                              \
+                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % AD], b[s & 1][ni], acc[ni], 0, 0, 0);  \
             }                                                                                                 \
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                               \
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
@@ -1069,8 +1059,8 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
                 acc[ni][g * 4 + e] = 0.f;                                                                     \
             }                                                                                                 \
             const nef_h4 z_ = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};                   \
-            const nef_h4 o = __builtin_elementwise_max(__builtin_convertvector(v_ + (bv_)[g], nef_h4), z_);   \
-            if (!(NEF_PHT_T & 2) || o[0] == (_Float16)12345.f) *(nef_h4*)(eb + ni * 32 * PH_XRS + g * 16) = o; \
+            *(nef_h4*)(eb + ni * 32 * PH_XRS + g * 16) =                                                      \
+                __builtin_elementwise_max(__builtin_convertvector(v_ + (bv_)[g], nef_h4), z_);                \
         }                                                                                                     \
     }
     // slots t of buffer B with base + t outside [0, T): rows 1 + t -> 0 (block-uniform, ragged / first tiles only)
@@ -1118,7 +1108,7 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
         // Memory returns in issue order: a weight fragment issued behind these rows cannot be consumed before they have arrived.  Issued
         // here the rows have the epilogue and AD - 1 k-steps to come from HBM; issued at k-step 1 of the staging phase (rounds 2-5)
         // they had AD k-steps, and the matrix pipes waited for them.
-        if (NEF_PHT_EARLY && !(NEF_PHT_T & 8)) PHT_FETCH(n_next, 0)
+        if (NEF_PHT_EARLY) PHT_FETCH(n_next, 0)
         __syncthreads();                     // every wave is done reading buffer B as an input chunk
         PHT_TO_LDS(bv3)
         PHT_ZERO_SLOTS()
@@ -1126,14 +1116,15 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
         // ---- layer 4: straight from the c3 rows; the next pair's first chunk rides along into buffer A
         PHT_STEPS(BB, wd4, 0, wd3, 0, true, n_next, 0, true, XA)
         PHT_PAD_ROWS(XA, fbase)              // (fbase: the next item's tile)
-        if (NEF_PHT_EARLY && !(NEF_PHT_T & 8)) PHT_FETCH(n_next, 1)      // for the next item's first phase
+        if (NEF_PHT_EARLY) PHT_FETCH(n_next, 1)      // for the next item's first phase
         __syncthreads();                     // every wave is done reading c3; buffer A holds the next pair's chunk 0
         PHT_TO_LDS(bv4)
         PHT_ZERO_SLOTS()                     // (rows outside the sequence zero: their share of the last conv is zero)
         __syncthreads();                     // c4 staged
         // ---- last conv on the matrix cores: rows 0..2 of the product are d0, d1, d2 of column t (lanes hi = 0); the two waves of
-        // a 128-column stripe take 64 columns each: t = wn 128 + wm 64 + ni 32 + lo
-        if (!(NEF_PHT_T & 4)) {
+        // a 128-column stripe take 64 columns each: t = wn 128 + wm 64 + ni 32 + lo.  The hi and lo weight terms go to separate
+        // accumulators (no matrix instruction waits for the one before it) and meet in the d arrays.
+        {
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
                 const nef_h8 ah = Af[(kq * 2 + 0) * 64 + lane], al = Af[(kq * 2 + 1) * 64 + lane];
@@ -1141,31 +1132,27 @@ __global__ __launch_bounds__(512, 1) void hconv_tail_kernel(const _Float16* __re
                 for (int ni = 0; ni < 2; ++ni) {
                     const nef_h8 bq = *(const nef_h8*)(XB + (1 + wn * 128 + wm * 64 + ni * 32 + lo) * PH_XRS + kq * 32 + 16 * hi);
                     acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq, acc[ni], 0, 0, 0);
-                    acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq, acc[ni], 0, 0, 0);
+                    acc[2 + ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq, acc[2 + ni], 0, 0, 0);
                 }
             }
-            float d1[2];
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const int t = wn * 128 + wm * 64 + ni * 32 + lo;
-                d1[ni] = acc[ni][1];
                 if (hi == 0) {
-                    Of[t] = acc[ni][0];          // tap 0 weights this row into column t + 1
-                    Of[NT + t] = acc[ni][2];     // tap 2 into column t - 1
+                    Of[t] = acc[ni][0] + acc[2 + ni][0];                  // tap 0 weights this row into column t + 1
+                    Of[NT + t] = acc[ni][2] + acc[2 + ni][2];             // tap 2 into column t - 1
+                    Of[2 * NT + t] = acc[ni][1] + acc[2 + ni][1];
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[ni][r] = acc[2 + ni][r] = 0.f;
             }
             __syncthreads();           // (also: every wave is done reading c4 -- buffer B is free for the next pair's chunk 1)
-            if (hi == 0) {
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int t = wn * 128 + wm * 64 + ni * 32 + lo;
-                    // slot t is time base + t; a tile of the TILED form owns slots 2 .. 509 (the others lack context)
-                    if (base + t < T && (!TILED || (t >= 2 && t < 2 + NOUT))) {
-                        const float s_ = d1[ni] + (t > 0 ? Of[t - 1] : 0.f) + (t < NT - 1 ? Of[NT + t + 1] : 0.f);
-                        out[(size_t)(n / nq) * out_bs + (size_t)(n % nq) * out_is + base + t] = 1.0f / (1.0f + expf(-(s_ + b0) / 3.0f));
-                    }
+            {
+                const int t = wn * 128 + wm * 64 + lane;      // one column per lane, whole 256-byte rows out
+                // slot t is time base + t; a tile of the TILED form owns slots 2 .. 509 (the others lack context)
+                if (base + t < T && (!TILED || (t >= 2 && t < 2 + NOUT))) {
+                    const float s_ = Of[2 * NT + t] + (t > 0 ? Of[t - 1] : 0.f) + (t < NT - 1 ? Of[NT + t + 1] : 0.f);
+                    out[(size_t)(n / nq) * out_bs + (size_t)(n % nq) * out_is + base + t] = 1.0f / (1.0f + expf(-(s_ + b0) / 3.0f));
                 }
             }
             // the d arrays are rewritten five barriers from here
@@ -1344,7 +1331,7 @@ static int launch_hconv_pair(const void* x, const void* wp1, const float* b1, co
 
 static int launch_hconv_tail(const void* x, const void* wp3, const float* b3, const void* wp4, const float* b4, const float* wout,
                              const float* bout, float* out, int N, int T, int nq, long out_bs, long out_is, hipStream_t st) {
-    constexpr int LDS = 2 * 514 * PH_XRS + 2 * 512 * 4 + 8 * 64 * 16;      // two row buffers, d0 / d2, the last conv's A fragments
+    constexpr int LDS = 2 * 514 * PH_XRS + 3 * 512 * 4 + 8 * 64 * 16;      // two row buffers, d0 / d2 / d1, the last conv's A fragments
     static int cus_dev[64] = {0};            // per device, idempotent -> thread-safe without a lock
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -1356,17 +1343,6 @@ static int launch_hconv_tail(const void* x, const void* wp3, const float* b3, co
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
         __atomic_store_n(&cus_dev[dev & 63], cus, __ATOMIC_RELEASE);
     }
-#ifdef NEF_PHT_WREP
-    {   // experiment: NEF_PHT_WREP copies of the weights, each one L2 channel (4 KB) further on
-        static char* rep_ = nullptr;
-        if (!rep_ && hipMalloc((void**)&rep_, 16 * (69632 + 36864)) != hipSuccess) return NEF_E_SHAPE;
-        for (int c = 0; c < NEF_PHT_WREP; ++c) {
-            hipMemcpyAsync(rep_ + (size_t)c * 69632, wp3, 49152, hipMemcpyDeviceToDevice, st);
-            hipMemcpyAsync(rep_ + 16 * 69632 + (size_t)c * 36864, wp4, 24576, hipMemcpyDeviceToDevice, st);
-        }
-        wp3 = rep_; wp4 = rep_ + 16 * 69632;
-    }
-#endif
     if (T <= 512) {      // one tile per pair
         hipLaunchKernelGGL(hconv_tail_kernel<false>, dim3(N < cus ? N : cus), dim3(512), LDS, st, (const _Float16*)x, (const nef_h8*)wp3, b3,
                            (const nef_h8*)wp4, b4, wout, bout, out, T, N, nq, out_bs, out_is, 1);
