@@ -213,6 +213,68 @@ __global__ __launch_bounds__(256) void lead_mean_mix_shared_kernel(const float* 
     }
 }
 
+// The same pass for T % 4 == 2 (configs[1]: T = 1250) on 16-byte accesses: a row is 5000 bytes, so every second row starts 8 bytes off a
+// 16-byte boundary and the kernel above is held to 8-byte accesses (0.54-0.70 of the 16-byte rate).  Two consecutive channel rows
+// (c even, c + 1) are one aligned span of T / 2 four-float vectors in every tensor involved; a wave takes such a PAIR, and the one
+// vector that straddles the two rows carries both rows' scale.  Same expressions per element: bit-identical outputs.
+__global__ __launch_bounds__(256) void lead_mean_mix_shared_pair_kernel(const float* __restrict__ z1, const float* __restrict__ z2r,
+                                                                        const float* __restrict__ q, float* __restrict__ latent,
+                                                                        float* __restrict__ D2, int B, int V, int T, int c1, int c2,
+                                                                        const int32_t* __restrict__ choice_dev) {
+    typedef float vec __attribute__((ext_vector_type(4)));
+    if (choice_dev) { c1 = choice_dev[0]; c2 = choice_dev[1]; }
+    const int64_t pairs = (int64_t)B * 128;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float fv = (float)V;
+    const int TW = T / 2;                     // vectors per row pair
+    const int mid = T / 4;                    // the vector with two elements of either row
+    const int64_t pass = pairs * TW;
+    const int64_t lead = (int64_t)128 * T / 4;
+    for (int64_t pr = (int64_t)blockIdx.x * 4 + wave; pr < pairs; pr += (int64_t)gridDim.x * 4) {
+        const int64_t row = 2 * pr;
+        const int b = (int)(row >> 8), c = (int)(row & 255);
+        const vec* src = (const vec*)((c < 128 ? z1 : z2r) + ((int64_t)b * V * 128 + (c & 127)) * T);
+        const int cp = c < 128 ? c1 : c2;
+        const float f0 = q[row], f1 = q[row + 1];
+        vec* lat = (vec*)latent + pr * TW;
+        vec* d0 = (vec*)D2 + pr * TW;
+        int t = lane;
+        for (; t + 64 < TW; t += 128) {
+            vec s0 = src[t], s1 = src[t + 64];
+            vec p0 = s0, p1 = s1;
+            for (int v = 1; v < V; ++v) {
+                const vec x0 = src[(int64_t)v * lead + t], x1 = src[(int64_t)v * lead + t + 64];
+                s0 += x0;
+                s1 += x1;
+                if (v == cp) { p0 = x0; p1 = x1; }
+            }
+            const vec m0 = s0 / fv, m1 = s1 / fv;
+            const vec g0 = t < mid ? vec{f0, f0, f0, f0} : (t > mid ? vec{f1, f1, f1, f1} : vec{f0, f0, f1, f1});
+            const vec g1 = t + 64 < mid ? vec{f0, f0, f0, f0} : (t + 64 > mid ? vec{f1, f1, f1, f1} : vec{f0, f0, f1, f1});
+            lat[t] = m0;
+            lat[t + 64] = m1;
+            d0[t] = g0 * m0;
+            d0[t + 64] = g1 * m1;
+            d0[pass + t] = g0 * p0;
+            d0[pass + t + 64] = g1 * p1;
+        }
+        for (; t < TW; t += 64) {
+            vec sm = src[t];
+            vec pk = sm;
+            for (int v = 1; v < V; ++v) {
+                const vec x = src[(int64_t)v * lead + t];
+                sm += x;
+                if (v == cp) pk = x;
+            }
+            const vec m = sm / fv;
+            const vec g0 = t < mid ? vec{f0, f0, f0, f0} : (t > mid ? vec{f1, f1, f1, f1} : vec{f0, f0, f1, f1});
+            lat[t] = m;
+            d0[t] = g0 * m;
+            d0[pass + t] = g0 * pk;
+        }
+    }
+}
+
 __device__ __forceinline__ float up2_bwd_edge(const float* __restrict__ gr, int Tin, int m) {
     const int To = 2 * Tin;
     float s = 0.f;
@@ -337,6 +399,63 @@ __global__ void mix_bwd_kernel(const float* __restrict__ gD, const float* __rest
         }
         acc = nef_wave_sum(acc);
         if (lane == 0) gq[row] = acc;
+    }
+}
+
+// mix_bwd_kernel<false, true> for T % 4 == 2 (configs[1]: T = 1250) on 16-byte accesses: a wave takes two consecutive channel rows
+// (c even, c + 1), one aligned span of T / 2 four-float vectors in every tensor involved (see lead_mean_mix_shared_pair_kernel); the
+// vector that straddles the rows carries both rows' scale and feeds both rows' gq sum.  gz1 / gz2r: the same expressions per element
+// (bit-identical); gq: the same terms in another lane order, as between the two paths of mix_bwd_kernel.
+__global__ __launch_bounds__(256) void mix_bwd_shared_pair_kernel(const float* __restrict__ gD, const float* __restrict__ latent,
+                                                                  const float* __restrict__ z1, const float* __restrict__ z2r,
+                                                                  const float* __restrict__ q, float* __restrict__ gz1,
+                                                                  float* __restrict__ gz2r, float* __restrict__ gq, int B, int V, int T,
+                                                                  int c1, int c2, const int32_t* __restrict__ choice_dev, int relu_z1) {
+    typedef float vec __attribute__((ext_vector_type(4)));
+    if (choice_dev) { c1 = choice_dev[0]; c2 = choice_dev[1]; }
+    const int64_t pairs = (int64_t)B * 128;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float fv = (float)V;
+    const int TW = T / 2, mid = T / 4;
+    const int64_t gpass = pairs * TW;
+    const int64_t lead = (int64_t)128 * T / 4;
+    for (int64_t pr = (int64_t)blockIdx.x * 4 + wave; pr < pairs; pr += (int64_t)gridDim.x * 4) {
+        const int64_t row = 2 * pr;
+        const int b = (int)(row >> 8), c = (int)(row & 255);
+        const bool first = c < 128;
+        const int pick_v = first ? c1 : c2;
+        const float f0 = q[row], f1 = q[row + 1];
+        const vec* lat = (const vec*)latent + pr * TW;
+        const vec* zsrc = (const vec*)((first ? z1 : z2r) + ((int64_t)b * V * 128 + (c & 127)) * T);
+        vec* gdst = (vec*)((first ? gz1 : gz2r) + ((int64_t)b * V * 128 + (c & 127)) * T);
+        const vec* g0 = (const vec*)gD + pr * TW;
+        const vec* g1r = g0 + gpass;
+        const bool mask = relu_z1 && first;
+        float acc0 = 0.f, acc1 = 0.f;
+        for (int t = lane; t < TW; t += 64) {
+            const vec ga = g0[t], gb = g1r[t], l4 = lat[t], pk = zsrc[(int64_t)pick_v * lead + t];
+            const vec fq = t < mid ? vec{f0, f0, f0, f0} : (t > mid ? vec{f1, f1, f1, f1} : vec{f0, f0, f1, f1});
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float term = ga[e] * l4[e] + gb[e] * pk[e];
+                if (t < mid || (t == mid && e < 2)) acc0 += term; else acc1 += term;
+            }
+            for (int v = 0; v < V; ++v) {
+                vec o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fq[e] * ga[e] / fv + (v == pick_v ? fq[e] * gb[e] : 0.f);
+                if (mask) {
+                    const vec z = zsrc[(int64_t)v * lead + t];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (!(z[e] > 0.f)) o[e] = 0.f;
+                }
+                gdst[(int64_t)v * lead + t] = o;
+            }
+        }
+        acc0 = nef_wave_sum(acc0);
+        acc1 = nef_wave_sum(acc1);
+        if (lane == 0) { gq[row] = acc0; gq[row + 1] = acc1; }
     }
 }
 
@@ -1480,8 +1599,13 @@ int nef_mix_bwd_shared(const float* gD2, const float* latent, const float* z1, c
     NEF_ENTER();
     NEF_REQUIRE(gD2 && latent && z1 && z2r && q && gz1 && gz2r && gq, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && V > 0 && T > 1 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
-    hipLaunchKernelGGL((mix_bwd_kernel<false, true>), dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gD2,
-                       latent, z1, z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev, relu_z1);
+    const bool al16 = (((uintptr_t)gD2 | (uintptr_t)latent | (uintptr_t)z1 | (uintptr_t)z2r | (uintptr_t)gz1 | (uintptr_t)gz2r) & 15) == 0;
+    if (T % 4 == 2 && T >= 8 && al16)
+        hipLaunchKernelGGL(mix_bwd_shared_pair_kernel, dim3(nef_stream_grid((int64_t)B * 128, 4)), dim3(256), 0, NEF_ST, gD2, latent, z1,
+                           z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev, relu_z1);
+    else
+        hipLaunchKernelGGL((mix_bwd_kernel<false, true>), dim3(nef_stream_grid((int64_t)B * 256, 4)), dim3(256), 0, NEF_ST, gD2,
+                           latent, z1, z2r, q, gz1, gz2r, gq, B, V, T, c1, c2, choice_dev, relu_z1);
     return nef_launch_status();
 }
 
@@ -1826,7 +1950,11 @@ int nef_lead_mean_mix_shared(const float* z1, const float* z2r, const float* q, 
     NEF_REQUIRE(z1 && z2r && q && latent && D2, NEF_E_NULL);
     NEF_REQUIRE(B > 0 && V > 0 && T > 0 && c1 >= 0 && c1 < V && c2 >= 0 && c2 < V, NEF_E_SHAPE);
     const dim3 grid(nef_stream_grid((int64_t)B * 256, 4));
-    if (T % 2 == 0)
+    const bool al16 = (((uintptr_t)z1 | (uintptr_t)z2r | (uintptr_t)latent | (uintptr_t)D2) & 15) == 0;
+    if (T % 4 == 2 && al16)
+        hipLaunchKernelGGL(lead_mean_mix_shared_pair_kernel, dim3(nef_stream_grid((int64_t)B * 128, 4)), dim3(256), 0, NEF_ST, z1, z2r, q,
+                           latent, D2, B, V, T, c1, c2, choice_dev);
+    else if (T % 2 == 0)
         hipLaunchKernelGGL(lead_mean_mix_shared_kernel<2>, grid, dim3(256), 0, NEF_ST, z1, z2r, q, latent, D2, B, V, T, c1,
                            c2, choice_dev);
     else

@@ -503,7 +503,7 @@ def test_shared_first_conv_pieces():
     D2 = o.mix_fwd_shared(g(lat), g(z1), g(z2r), g(q), V, (c1, c2))
     assert D2.shape == (2 * B, 256, T) and rel(D2, D2ref) < 1e-6
     # the one-pass form of lead_mean + mix_fwd_shared: bit-identical, even and odd T, device-side lead choice
-    for Tq in (T, 67):
+    for Tq in (T, 67, 68, 1250):      # (66 and 1250: T % 4 == 2, the row-pair form on 16-byte accesses)
         z1q, z2q = g(rnd(B, 128 * V, Tq, seed=175)), g(rnd(B, 128 * V, Tq, seed=176))
         lat_ref = o.lead_mean(z1q, z2q, V)
         D2_ref = o.mix_fwd_shared(lat_ref, z1q, z2q, g(q), V, (c1, c2))
@@ -521,6 +521,20 @@ def test_shared_first_conv_pieces():
     exp_z1 = z1r.grad + glat[:, :128].repeat(1, V, 1) / V
     exp_z2 = z2rr.grad + glat[:, 128:].repeat(1, V, 1) / V
     assert rel(gz1, exp_z1) < 1e-5 and rel(gz2r, exp_z2) < 1e-5 and rel(gq, qr.grad) < 1e-5
+    # the same backward at the latent's own resolution (what the polyphase backward-data pass leaves): T % 4 == 2 runs on row PAIRS
+    # with 16-byte accesses when every tensor is 16-byte aligned -- against the 8-byte form (the same operands, 8 bytes off)
+    def off8(t):
+        buf = torch.empty(t.numel() + 2, device=DEV)
+        v = buf[2:].view(t.shape)
+        v.copy_(t)
+        return v
+    for Tq in (66, 1250):
+        latq, z1q, z2q = g(rnd(B, 256, Tq, seed=180)), g(rnd(B, 128 * V, Tq, seed=181)), g(rnd(B, 128 * V, Tq, seed=182))
+        gD2 = g(rnd(2 * B, 256, Tq, seed=183))
+        for relu in (False, True):
+            a = o.mix_bwd_shared_up(gD2, latq, z1q, z2q, g(q), V, (c1, c2), relu_z1=relu)
+            b = o.mix_bwd_shared_up(off8(gD2), off8(latq), off8(z1q), off8(z2q), g(q), V, (c1, c2), relu_z1=relu)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and rel(a[2], b[2]) < 1e-6
     # combine: c1[p] = A[ia] + B[ib] + bias and its adjoint
     C, L = 8, 37
     P2, bias, gc1 = rnd(2 * B, 2 * C, L, seed=165), rnd(C, seed=166), rnd(3 * B, C, L, seed=167)
