@@ -204,7 +204,13 @@ class GraphedTrainStep:
         self.model.train()
         # eager probe (no update): which parameters are live, and every kernel variant gets its one-time setup
         saved = {k: v.clone() for k, v in self.model.named_buffers()}
+        # ... and no history either: the probe rolls and re-measures the operand magnitudes of the split-fp16 call sites; the sites
+        # that existed before it get back what they held, so the step that follows rolls them exactly once -- as the eager path and
+        # an already captured shape do.  (Without this a stepper restored from a checkpoint rolled twice on its first step and was
+        # not bit-identical to the uninterrupted run; a fresh run is unaffected: rolling the same pair twice is rolling it once.)
+        amax0 = ops.amax_snapshot(dev)
         grads = self._fwd_bwd()
+        ops.amax_restore(dev, amax0)
         if self.dp:                          # the eager probe may have started an early gradient bucket: retire it
             from . import parallel
             pend = parallel.take_early()

@@ -85,8 +85,21 @@ class Model_nefnet(nn.Module):
             return self._ENGINE[1](*args, **kw)
 
     def load_state_dict(self, *args, **kw):
-        self._nef_scope = ops.new_amax_scope()      # other weights, other magnitudes: measure again
+        self._nef_scope = ops.new_amax_scope()      # other weights, other magnitudes: measure again (or load_h2_state)
         return super().load_state_dict(*args, **kw)
+
+    def h2_state(self):
+        """The operand magnitudes of this model's split-fp16 call sites (ops.h2_export) -- not part of the reference's state_dict
+        (codes/utils/checkpointer.py:24-36 saves model / optimizer / scheduler); CheckPointer stores it next to them so that a
+        resumed run continues bit for bit."""
+        return ops.h2_export(self._nef_scope, {p.data_ptr(): n for n, p in self.named_parameters()})
+
+    def load_h2_state(self, blob):
+        """After load_state_dict: the call sites take up the magnitudes the checkpointed run had reached."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            return 0
+        return ops.h2_import(self._nef_scope, {n: p.data_ptr() for n, p in self.named_parameters()}, blob, dev)
 
     def __init__(self, theta_encoder_len=1, lead_num=1):
         super().__init__()

@@ -429,6 +429,51 @@ def _amax_index(st, site, n):
     return i
 
 
+def h2_export(scope_id, ptr_names):
+    """The operand-magnitude slots of a model's call sites as a checkpointable blob (CPU tensors and plain tuples): the keys of
+    _amax_index with the owning model's scope token dropped and the weight ADDRESSES replaced by parameter names (`ptr_names`:
+    {data_ptr: name}).  With it a restored run splits its operands with the scales the uninterrupted run would have used, i.e.
+    continues bit for bit (h2_import); without it a restored model measures again (equal arithmetic, a different power-of-two operand
+    scale wherever a magnitude sits near a binade edge).  Sites through tensors that are not parameters (BatchNorm-folded
+    panorama weights) are left out: they measure again.  Reads the device (synchronises)."""
+    keys, cur, nxt = [], [], []
+    for st in _AMAX.values():
+        c_, n_ = st["cur"].cpu(), st["nxt"].cpu()
+        for key, i in st["index"].items():
+            if i not in st["ready"] or len(key) != 6 or not isinstance(key[0], tuple) or key[0][0] != scope_id:
+                continue
+            name = ptr_names.get(key[1][0])
+            if name is None:
+                continue
+            n = 2 if key[2] == "conv_bwd_weight" else 1
+            keys.append((bool(key[0][1]), (name, key[1][1]), key[2], int(key[3]), int(key[4]), int(key[5])))
+            cur.append([float(c_[i + j]) for j in range(n)])
+            nxt.append([float(n_[i + j]) for j in range(n)])
+    return {"version": 1, "keys": keys, "cur": cur, "nxt": nxt}
+
+
+def h2_import(scope_id, name_ptrs, blob, device):
+    """Hands the slots of h2_export back to the call sites of the model that now owns `scope_id` (`name_ptrs`: {name: data_ptr});
+    entries whose parameter is gone are skipped (they measure)."""
+    if not blob or blob.get("version") != 1:
+        return 0
+    st = _amax_state(torch.device(device))
+    done = 0
+    for key, c_, n_ in zip(blob["keys"], blob["cur"], blob["nxt"]):
+        ptr = name_ptrs.get(key[1][0])
+        if ptr is None:
+            continue
+        full = ((scope_id, bool(key[0])), (ptr, key[1][1])) + tuple(key[2:])
+        i = _amax_index(st, full, len(c_))
+        st["cur"][i:i + len(c_)] = torch.tensor(c_, dtype=torch.float32)
+        st["nxt"][i:i + len(n_)] = torch.tensor(n_, dtype=torch.float32)
+        st["ready"].add(i)
+        done += 1
+    if done:
+        st["used"] = True
+    return done
+
+
 def amax_roll():
     """Once per pass (stream-ordered, a handful of tiny launches): a site's reference magnitude `cur` follows what its last launch
     measured (`nxt`) UP as soon as that exceeds H2_FOLLOW_UP x cur and DOWN once it fell below cur / H2_FOLLOW_DOWN -- the scale is
@@ -444,6 +489,24 @@ def amax_roll():
                 _lib.check(_lib.load().nef_amax_roll(_p(st["cur"]), _p(st["nxt"]), int(st["n"]), H2_FOLLOW_UP, H2_FOLLOW_DOWN,
                                                      int(_H2_AMAX == "follow"), _stream()), "nef_amax_roll")
             st["used"] = False
+
+
+def amax_snapshot(dev):
+    """The magnitudes of the call sites handed out so far (GraphedTrainStep: around its eager probe)."""
+    st = _amax_state(torch.device(dev))
+    n = int(st["n"])
+    return n, st["cur"][:n].clone(), st["nxt"][:n].clone(), st.get("gen", 0)
+
+
+def amax_restore(dev, snap):
+    """Puts the sites that existed at amax_snapshot() back to what they held then (sites created since keep what they measured)."""
+    n, cur, nxt, gen = snap
+    st = _amax_state(torch.device(dev))
+    if n == 0 or st.get("gen", 0) != gen:
+        return
+    st["cur"][:n].copy_(cur)
+    st["nxt"][:n].copy_(nxt)
+    st["used"] = True
 
 
 def amax_generation(dev):

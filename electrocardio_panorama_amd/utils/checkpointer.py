@@ -22,6 +22,11 @@ class CheckPointer:
             data['optimizer'] = self.optimizer.state_dict()
         if self.scheduler is not None:
             data['scheduler'] = self.scheduler.state_dict()
+        core = getattr(self.model, 'module', self.model)
+        if hasattr(core, 'h2_state'):
+            # beyond the reference's file (checkpointer.py:24-36): the operand magnitudes of the split-fp16 call sites, so that a resumed
+            # run is bit-identical to the uninterrupted one (a reference-side loader ignores the extra key)
+            data['h2_state'] = core.h2_state()
         data.update(kwargs)
         save_file = os.path.join(self.save_dir, '{}.pkl'.format(name))
         torch.save(data, save_file)
@@ -45,6 +50,10 @@ class CheckPointer:
         checkpoint = torch.load(f, map_location='cpu')
         model_sd = {(k[7:] if k.startswith('module.') else k): v for k, v in checkpoint.pop('model').items()}
         self.model.load_state_dict(model_sd)
+        h2 = checkpoint.pop('h2_state', None)
+        core = getattr(self.model, 'module', self.model)
+        if h2 is not None and hasattr(core, 'load_h2_state'):
+            core.load_h2_state(h2)
         if 'optimizer' in checkpoint and self.optimizer:
             self.optimizer.load_state_dict(checkpoint.pop('optimizer'))
         if 'scheduler' in checkpoint and self.scheduler:
