@@ -40,7 +40,8 @@ def test_from_f32_is_a_rounding_transpose():
     assert torch.equal(y.cpu(), x.transpose(1, 2).to(torch.float16))
 
 
-@pytest.mark.parametrize("T,NB,nq", [(256, 3, 4), (40, 2, 3), (254, 70, 5), (258, 2, 2), (504, 2, 3), (1000, 3, 2), (2500, 2, 3), (1250, 40, 7)])
+@pytest.mark.parametrize("T,NB,nq", [(256, 3, 4), (40, 2, 3), (254, 70, 5), (258, 2, 2), (504, 2, 3), (1000, 3, 2), (2500, 2, 3), (1250, 40, 7),
+                                     (2, 1, 1), (6, 2, 3), (252, 3, 2), (506, 2, 2), (758, 1, 3)])      # (padding rows / out-of-sequence slots of ragged tiles)
 def test_fused_layer_pair_is_bit_identical_to_two_launches(T, NB, nq):
     """nef_pano_h_conv_pair (layers 1 + 2 with c1 on chip) against nef_pano_h_conv twice: same k order per output and
     the same fp16 rounding of the intermediate, so the bytes must match; more pairs than CUs in the third case, so a
@@ -63,7 +64,8 @@ def test_fused_layer_pair_is_bit_identical_to_two_launches(T, NB, nq):
 
 
 @pytest.mark.parametrize("T,NB,nq", [(512, 3, 4), (80, 2, 3), (508, 70, 5), (256, 2, 2),
-                                     (514, 2, 2), (1016, 2, 3), (1100, 3, 2), (5000, 2, 3), (2500, 40, 7)])
+                                     (514, 2, 2), (1016, 2, 3), (1100, 3, 2), (5000, 2, 3), (2500, 40, 7),
+                                     (2, 1, 1), (6, 2, 3), (510, 3, 2), (1018, 2, 2), (1526, 1, 3)])      # (padding rows / out-of-sequence slots of ragged tiles)
 def test_fused_tail_matches_two_launches(T, NB, nq):
     """nef_pano_h_conv_tail (layers 3 + 4 + last conv + sigmoid, c3 / c4 on chip; round 6) against nef_pano_h_conv(upsample) +
     nef_pano_h_conv_outconv: same k order per output and the same fp16 roundings of c3 and c4; the last conv runs on the matrix cores
